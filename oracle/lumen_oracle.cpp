@@ -1,0 +1,1316 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see lumen_oracle.h for the parity status).
+//
+// CPU restatement of WaveFrontRenderer::TraceFrame and every kernel it launches.  Each function cites the
+// reference file:line it follows (paths relative to /root/reference/Lumen_Engine/LumenPT/src unless noted).
+// Deliberate, documented deviations (DESIGN.md "Decisions"):
+//   D1 radiance is accumulated in fp32, one add per pixel per wave in wave order (reference: racy fp16 RMW);
+//   D2 ReSTIR light-bag choice = f(16x16 pixel tile) instead of the hardware SM id (ReSTIRKernels.cu:433);
+//   D3 light sort is stable on (mean radiance, build order); the CDF prefix sum is accumulated in double and
+//      rounded to float per entry (thrust order is unspecified);
+//   D4 closest hit = minimum t, ties broken by lower global triangle index; hit interval is tmin < t < tmax;
+//      ray/triangle test is the Woop unit-triangle form on world-space triangles (OptiX is closed source);
+//   D5 uninitialised reads in the reference are defined as zero; camera "previous matrix" of the first frame
+//      equals the current one;
+//   D6 texture filtering is exact fp32 bilinear (CUDA uses 8-bit fixed-point weights), sRGB decode per texel.
+#include "lumen_oracle.h"
+#include "orc_bsdf.h"
+
+#include <algorithm>
+#include <atomic>
+#include <functional>
+#include <thread>
+#include <vector>
+#include <cstdio>
+#include <cstdlib>
+
+using namespace orc;
+
+namespace {
+
+// ----------------------------------------------------------------------------------------------------------
+// wire structs
+// ----------------------------------------------------------------------------------------------------------
+struct Vertex { f3 pos; f2 uv; f3 normal; f4 tangent; };                 // Shaders/CppCommon/ModelStructs.h:21-28
+static_assert(sizeof(Vertex) == 48, "Vertex is 48 bytes");
+
+enum SurfaceFlag : uint8_t { SF_NONE = 0, SF_EMISSIVE = 1, SF_ALPHA = 2, SF_NON_INTERSECT = 4 };   // SurfaceData.h:18-24
+
+struct Surface {                                                          // SurfaceData.h:49-104
+    uint16_t px, py;
+    f3 position, normal, geomNormal, tangent;
+    float t;
+    f3 incoming;
+    Material mat;
+    uint8_t flags;
+    f3 transport;
+};
+struct Ray { uint16_t px, py; f3 origin, dir, contribution; };            // IntersectionRayData.h:21-80
+struct Hit { uint32_t instance, prim; uint16_t bu, bv; float t; };        // IntersectionData.h:26-108 (half2 barycentrics)
+struct ShadowRay { uint16_t px, py; f3 origin, dir; float maxDist; f3 radiance; uint32_t channel; };   // ShadowRayData.h:13-62
+struct TriLight { f3 p0, p1, p2, normal, radiance; float area; };         // LightData.h:21-27
+struct LightSample { f3 radiance, normal, position; float area; f3 contribution; float solidAnglePdf; };   // ReSTIRData.h:98-109
+struct Reservoir { float weightSum; long long sampleCount; float weight; LightSample sample; };            // ReSTIRData.h:115-178
+struct LightBagEntry { TriLight light; float pdf; };                      // ReSTIRData.h:309-313
+struct RestirShadowRay { f3 origin, dir; float distance; uint32_t index; };   // ReSTIRData.h:71-77
+
+struct Texture { uint32_t w = 0, h = 0; bool srgb = false; std::vector<uint8_t> px; };
+struct DeviceMaterial {                                                   // ModelStructs.h:33-63
+    Material data;
+    int texClearCoat, texClearCoatRough, texTransmission, texDiffuse, texEmissive, texMetalRough, texNormal, texTint;
+    f3 emissiveColor;
+};
+struct Primitive {
+    std::vector<Vertex> verts;
+    std::vector<uint32_t> idx;
+    int material = -1;
+    std::vector<uint8_t> emissive;      // per triangle (FindEmissives)
+    uint32_t numLights = 0;
+    bool containEmissive = false;
+};
+struct Mesh { std::vector<int> prims; };
+struct TableEntry {                                                       // DevicePrimitiveInstance, ModelStructs.h:73-80
+    int prim; int material; float M[16]; int mode; f4 emissiveColorAndScale; int instance;
+};
+struct MeshInstance { int mesh; float M[16]; int mode; f3 overrideRadiance; float scale; int overrideMaterial; std::vector<int> entries; };
+
+struct Woop { float r0[4], r1[4], r2[4]; };
+struct BvhNode { float lo[3], hi[3]; int left, right; uint32_t first, count; };
+
+// ----------------------------------------------------------------------------------------------------------
+static float g_srgb_lut[256];
+static void init_srgb_lut()
+{
+    static bool done = false;
+    if (done) return;
+    for (int i = 0; i < 256; i++) {
+        const double c = i / 255.0;
+        g_srgb_lut[i] = (float)(c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4));
+    }
+    done = true;
+}
+
+static inline f4 mat4_mul(const float* m, const f4& v)                    // sutil/Matrix.h:474-494 operation order
+{
+    f4 r;
+    r.x = m[0] * v.x + m[1] * v.y + m[2] * v.z + m[3] * v.w;
+    r.y = m[4] * v.x + m[5] * v.y + m[6] * v.z + m[7] * v.w;
+    r.z = m[8] * v.x + m[9] * v.y + m[10] * v.z + m[11] * v.w;
+    r.w = m[12] * v.x + m[13] * v.y + m[14] * v.z + m[15] * v.w;
+    return r;
+}
+
+}  // namespace
+
+// ----------------------------------------------------------------------------------------------------------
+struct orc_ctx {
+    int threads = 1;
+    std::vector<Texture> textures;
+    std::vector<DeviceMaterial> materials;
+    std::vector<Primitive> prims;
+    std::vector<Mesh> meshes;
+    std::vector<MeshInstance> instances;
+    std::vector<TableEntry> table;
+
+    // camera (Lumen/src/Lumen/Renderer/Camera.cpp:79-140)
+    f3 camPos{0, 0, 0}, camRight{-1, 0, 0}, camUp{0, 1, 0}, camForward{0, 0, 1};
+    float fovY = 90.f;
+    float prevCamWorld[16]; bool havePrev = false;
+
+    uint32_t W = 0, H = 0, depth = 5;
+    bool blend = false;
+    uint32_t wx0 = 0, wy0 = 0, wx1 = 0, wy1 = 0; bool windowSet = false;
+
+    // persistent renderer state
+    uint32_t frameCount = 0;       // the function-static of WaveFrontRenderer.cpp:592
+    uint32_t blendCounter = 0;
+    int frameIndex = 0;            // m_FrameIndex
+    int swapChainIndex = 0;        // ReSTIR::m_SwapChainIndex
+    bool sceneDirty = true;
+
+    // geometry the tracer sees
+    std::vector<f3> worldTris;                 // 3 per triangle
+    std::vector<uint32_t> triEntry, triPrim;   // global triangle -> (table entry, primitive-local index)
+    std::vector<Woop> woop;
+    std::vector<BvhNode> bvh; std::vector<uint32_t> bvhTris;
+    float bvhPad = 0.f;
+
+    // frame buffers
+    std::vector<Surface> surface[3];
+    std::vector<Reservoir> reservoirs[4];
+    std::vector<f2> motion;                    // half2 values, stored dequantised
+    std::vector<f4> channel[4];
+    std::vector<f4> combined;
+    std::vector<uint8_t> output;
+    std::vector<TriLight> lights; std::vector<float> cdf; float cdfSum = 0;
+    std::vector<LightBagEntry> bags;
+    uint64_t stats[4 + 64] = {0};
+
+    void resize();
+    void flatten();
+    template <class F> void pfor(uint32_t n, F f) const;
+};
+
+template <class F> void orc_ctx::pfor(uint32_t n, F f) const
+{
+    const int nt = std::max(1, std::min<int>(threads, (int)((n + 255) / 256)));
+    if (nt == 1) { f(0u, n, 0); return; }
+    std::vector<std::thread> th;
+    const uint32_t chunk = (n + nt - 1) / nt;
+    for (int t = 0; t < nt; t++) {
+        const uint32_t b = std::min(n, t * chunk), e = std::min(n, b + chunk);
+        th.emplace_back([=, &f] { f(b, e, t); });
+    }
+    for (auto& t : th) t.join();
+}
+
+void orc_ctx::resize()
+{
+    const size_t n = (size_t)W * H;
+    if (surface[0].size() == n) return;
+    Surface zs; memset(&zs, 0, sizeof zs);
+    Reservoir zr; memset(&zr, 0, sizeof zr);
+    for (auto& s : surface) s.assign(n, zs);
+    for (auto& r : reservoirs) r.assign(n, zr);      // ResetReservoirs, ReSTIRKernels.cu:36-47
+    motion.assign(n, f2{0, 0});
+    for (auto& c : channel) c.assign(n, f4{0, 0, 0, 0});
+    combined.assign(n, f4{0, 0, 0, 0});
+    output.assign(n * 4, 0);
+    blendCounter = 0; frameIndex = 0; swapChainIndex = 0;
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// Textures — PTTexture.cpp:35-74: RGBA8, bilinear, wrap, normalised coords, optional sRGB decode  (D6)
+// ----------------------------------------------------------------------------------------------------------
+static f4 texel(const Texture& t, int x, int y)
+{
+    const uint8_t* p = &t.px[((size_t)y * t.w + x) * 4];
+    if (t.srgb) return f4{g_srgb_lut[p[0]], g_srgb_lut[p[1]], g_srgb_lut[p[2]], (float)p[3] / 255.0f};
+    return f4{(float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f, (float)p[3] / 255.0f};
+}
+static inline int wrapi(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
+static f4 tex2D(const orc_ctx* c, int id, float u, float v)
+{
+    if (id < 0) return f4{0, 0, 0, 0};                     // null texture object (quirk 12): defined as 0
+    const Texture& t = c->textures[id];
+    const float x = u * (float)t.w - 0.5f, y = v * (float)t.h - 0.5f;
+    const float fx0 = floorf(x), fy0 = floorf(y);
+    const float ax = x - fx0, ay = y - fy0;
+    const int x0 = wrapi((int)fx0, (int)t.w), y0 = wrapi((int)fy0, (int)t.h);
+    const int x1 = wrapi(x0 + 1, (int)t.w), y1 = wrapi(y0 + 1, (int)t.h);
+    const f4 t00 = texel(t, x0, y0), t10 = texel(t, x1, y0), t01 = texel(t, x0, y1), t11 = texel(t, x1, y1);
+    auto l = [](float a, float b, float w) { return a + w * (b - a); };
+    f4 r;
+    r.x = l(l(t00.x, t10.x, ax), l(t01.x, t11.x, ax), ay);
+    r.y = l(l(t00.y, t10.y, ax), l(t01.y, t11.y, ax), ay);
+    r.z = l(l(t00.z, t10.z, ax), l(t01.z, t11.z, ax), ay);
+    r.w = l(l(t00.w, t10.w, ax), l(t01.w, t11.w, ax), ay);
+    return r;
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// Scene flattening: world-space triangle soup + Woop packets + a simple median-split BVH  (D4)
+// ----------------------------------------------------------------------------------------------------------
+static Woop make_woop(const f3& a, const f3& b, const f3& c)
+{
+    const double v0[3] = {a.x, a.y, a.z};
+    const double e1[3] = {(double)b.x - a.x, (double)b.y - a.y, (double)b.z - a.z};
+    const double e2[3] = {(double)c.x - a.x, (double)c.y - a.y, (double)c.z - a.z};
+    const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    const double det = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+    Woop w; memset(&w, 0, sizeof w);
+    if (!(det > 0.0) || !std::isfinite(det)) return w;     // degenerate: all-zero packet never hits
+    const double ru[3] = {e2[1] * n[2] - e2[2] * n[1], e2[2] * n[0] - e2[0] * n[2], e2[0] * n[1] - e2[1] * n[0]};
+    const double rv[3] = {n[1] * e1[2] - n[2] * e1[1], n[2] * e1[0] - n[0] * e1[2], n[0] * e1[1] - n[1] * e1[0]};
+    double du = 0, dv = 0, dw = 0;
+    for (int i = 0; i < 3; i++) {
+        w.r0[i] = (float)(ru[i] / det); w.r1[i] = (float)(rv[i] / det); w.r2[i] = (float)(n[i] / det);
+        du -= ru[i] / det * v0[i]; dv -= rv[i] / det * v0[i]; dw -= n[i] / det * v0[i];
+    }
+    w.r0[3] = (float)du; w.r1[3] = (float)dv; w.r2[3] = (float)dw;
+    return w;
+}
+
+// ray/triangle test on a Woop packet; returns true and (t,u,v) for tmin < t < tmax
+static inline bool woop_hit(const Woop& w, const f3& o, const f3& d, float tmin, float tmax, float& t, float& u, float& v)
+{
+    const float Oz = fmaf(w.r2[0], o.x, fmaf(w.r2[1], o.y, fmaf(w.r2[2], o.z, w.r2[3])));
+    const float Dz = fmaf(w.r2[0], d.x, fmaf(w.r2[1], d.y, w.r2[2] * d.z));
+    t = -Oz / Dz;
+    if (!(t > tmin && t < tmax)) return false;
+    const float Ox = fmaf(w.r0[0], o.x, fmaf(w.r0[1], o.y, fmaf(w.r0[2], o.z, w.r0[3])));
+    const float Dx = fmaf(w.r0[0], d.x, fmaf(w.r0[1], d.y, w.r0[2] * d.z));
+    u = fmaf(t, Dx, Ox);
+    if (!(u >= 0.0f)) return false;
+    const float Oy = fmaf(w.r1[0], o.x, fmaf(w.r1[1], o.y, fmaf(w.r1[2], o.z, w.r1[3])));
+    const float Dy = fmaf(w.r1[0], d.x, fmaf(w.r1[1], d.y, w.r1[2] * d.z));
+    v = fmaf(t, Dy, Oy);
+    if (!(v >= 0.0f)) return false;
+    return u + v <= 1.0f;
+}
+
+static int build_bvh(orc_ctx* c, std::vector<uint32_t>& ids, uint32_t first, uint32_t count, const std::vector<f3>& cen)
+{
+    BvhNode node; node.left = node.right = -1; node.first = first; node.count = count;
+    for (int k = 0; k < 3; k++) { node.lo[k] = INFINITY; node.hi[k] = -INFINITY; }
+    float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = first; i < first + count; i++) {
+        const uint32_t t = ids[i];
+        for (int vtx = 0; vtx < 3; vtx++) {
+            const f3& p = c->worldTris[t * 3 + vtx];
+            const float pv[3] = {p.x, p.y, p.z};
+            for (int k = 0; k < 3; k++) { node.lo[k] = fminf(node.lo[k], pv[k]); node.hi[k] = fmaxf(node.hi[k], pv[k]); }
+        }
+        const float cv[3] = {cen[t].x, cen[t].y, cen[t].z};
+        for (int k = 0; k < 3; k++) { clo[k] = fminf(clo[k], cv[k]); chi[k] = fmaxf(chi[k], cv[k]); }
+    }
+    for (int k = 0; k < 3; k++) { node.lo[k] -= c->bvhPad; node.hi[k] += c->bvhPad; }
+    const int self = (int)c->bvh.size();
+    c->bvh.push_back(node);
+    if (count <= 4) return self;
+    int axis = 0;
+    if (chi[1] - clo[1] > chi[axis] - clo[axis]) axis = 1;
+    if (chi[2] - clo[2] > chi[axis] - clo[axis]) axis = 2;
+    const uint32_t mid = first + count / 2;
+    auto key = [&](uint32_t t) { return axis == 0 ? cen[t].x : axis == 1 ? cen[t].y : cen[t].z; };
+    std::nth_element(ids.begin() + first, ids.begin() + mid, ids.begin() + first + count,
+                     [&](uint32_t a, uint32_t b) { const float ka = key(a), kb = key(b); return ka < kb || (ka == kb && a < b); });
+    const int l = build_bvh(c, ids, first, mid - first, cen);
+    const int r = build_bvh(c, ids, mid, first + count - mid, cen);
+    c->bvh[self].left = l; c->bvh[self].right = r; c->bvh[self].count = 0;
+    return self;
+}
+
+void orc_ctx::flatten()
+{
+    if (!sceneDirty) return;
+    sceneDirty = false;
+    // scene data table: one entry per (mesh instance, primitive) in creation order — PTMeshInstance.cpp:123-178
+    table.clear();
+    for (size_t ii = 0; ii < instances.size(); ii++) {
+        MeshInstance& mi = instances[ii];
+        mi.entries.clear();
+        for (int p : meshes[mi.mesh].prims) {
+            TableEntry e;
+            e.prim = p; e.instance = (int)ii;
+            e.material = mi.overrideMaterial >= 0 ? mi.overrideMaterial : prims[p].material;
+            memcpy(e.M, mi.M, sizeof e.M);
+            e.mode = mi.mode;
+            e.emissiveColorAndScale = f4{mi.overrideRadiance.x, mi.overrideRadiance.y, mi.overrideRadiance.z, mi.scale};
+            mi.entries.push_back((int)table.size());
+            table.push_back(e);
+        }
+    }
+    worldTris.clear(); triEntry.clear(); triPrim.clear(); woop.clear();
+    float maxAbs = 0.f;
+    for (size_t e = 0; e < table.size(); e++) {
+        const Primitive& pr = prims[table[e].prim];
+        for (size_t t = 0; t + 2 < pr.idx.size(); t += 3) {
+            f3 wp[3];
+            for (int k = 0; k < 3; k++) {
+                const f3& p = pr.verts[pr.idx[t + k]].pos;
+                wp[k] = mk3(mat4_mul(table[e].M, mk4(p, 1.f)));
+                maxAbs = fmaxf(maxAbs, fmaxf(fabsf(wp[k].x), fmaxf(fabsf(wp[k].y), fabsf(wp[k].z))));
+                worldTris.push_back(wp[k]);
+            }
+            triEntry.push_back((uint32_t)e); triPrim.push_back((uint32_t)(t / 3));
+            woop.push_back(make_woop(wp[0], wp[1], wp[2]));
+        }
+    }
+    const uint32_t nt = (uint32_t)triEntry.size();
+    bvhPad = maxAbs * (1.0f / 32768.0f);
+    std::vector<f3> cen(nt);
+    for (uint32_t t = 0; t < nt; t++) cen[t] = (worldTris[t * 3] + worldTris[t * 3 + 1] + worldTris[t * 3 + 2]) * (1.0f / 3.0f);
+    bvh.clear(); bvhTris.resize(nt);
+    for (uint32_t t = 0; t < nt; t++) bvhTris[t] = t;
+    if (nt) build_bvh(this, bvhTris, 0, nt, cen);
+}
+
+static inline bool slab(const BvhNode& n, const f3& o, const f3& inv, float tmin, float tmax)
+{
+    // conservative (double) slab test; the node boxes are already padded
+    double t0 = tmin, t1 = tmax;
+    const double ov[3] = {o.x, o.y, o.z}, iv[3] = {inv.x, inv.y, inv.z};
+    for (int k = 0; k < 3; k++) {
+        double a = (n.lo[k] - ov[k]) * iv[k], b = (n.hi[k] - ov[k]) * iv[k];
+        if (a > b) std::swap(a, b);
+        if (a != a || b != b) continue;                    // 0 * inf: ray lies in the slab plane, axis gives no bound
+        t0 = std::max(t0, a); t1 = std::min(t1, b);
+    }
+    return t0 <= t1 * 1.0000001 + 1e-30;
+}
+
+struct HitRec { float t, u, v; uint32_t tri; bool hit; };
+
+static HitRec closest_hit(const orc_ctx* c, const f3& o, const f3& d, float tmin, float tmax, bool useBvh)
+{
+    HitRec best{tmax, 0, 0, 0xffffffffu, false};
+    auto test = [&](uint32_t tri) {
+        float t, u, v;
+        if (woop_hit(c->woop[tri], o, d, tmin, tmax, t, u, v)) {
+            if (t < best.t || (t == best.t && best.hit && tri < best.tri)) { best = HitRec{t, u, v, tri, true}; }
+        }
+    };
+    if (!useBvh || c->bvh.empty()) {
+        for (uint32_t tri = 0; tri < c->woop.size(); tri++) test(tri);
+        return best;
+    }
+    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    int stack[128]; int sp = 0; stack[sp++] = 0;
+    while (sp) {
+        const BvhNode& n = c->bvh[stack[--sp]];
+        if (!slab(n, o, inv, tmin, best.t)) continue;
+        if (n.left < 0) { for (uint32_t i = 0; i < n.count; i++) test(c->bvhTris[n.first + i]); }
+        else { stack[sp++] = n.left; stack[sp++] = n.right; }
+    }
+    return best;
+}
+static bool any_hit(const orc_ctx* c, const f3& o, const f3& d, float tmin, float tmax, bool useBvh)
+{
+    float t, u, v;
+    if (!useBvh || c->bvh.empty()) {
+        for (uint32_t tri = 0; tri < c->woop.size(); tri++) if (woop_hit(c->woop[tri], o, d, tmin, tmax, t, u, v)) return true;
+        return false;
+    }
+    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    int stack[128]; int sp = 0; stack[sp++] = 0;
+    while (sp) {
+        const BvhNode& n = c->bvh[stack[--sp]];
+        if (!slab(n, o, inv, tmin, tmax)) continue;
+        if (n.left < 0) { for (uint32_t i = 0; i < n.count; i++) if (woop_hit(c->woop[c->bvhTris[n.first + i]], o, d, tmin, tmax, t, u, v)) return true; }
+        else { stack[sp++] = n.left; stack[sp++] = n.right; }
+    }
+    return false;
+}
+
+// closest-hit query of one ray — Shaders/WaveFrontShaders.cu:42-76 + 301-340 (hit record packing)
+static Hit trace_ray(const orc_ctx* c, const f3& o, const f3& d, float tmin, float tmax)
+{
+    Hit h; h.instance = 0; h.prim = 0; h.bu = 0; h.bv = 0; h.t = -1.f;     // IntersectionData.h:29-35, :100-104
+    const HitRec r = closest_hit(c, o, d, tmin, tmax, true);
+    if (r.hit) {
+        h.instance = c->triEntry[r.tri]; h.prim = c->triPrim[r.tri];
+        h.bu = f32_to_f16(r.u); h.bv = f32_to_f16(r.v); h.t = r.t;
+    }
+    return h;
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// FindEmissives — CUDAKernels/WaveFrontKernels/GPUEmissiveLookup.cu:13-109 (called from WaveFrontRenderer.cpp:1192-1210)
+// ----------------------------------------------------------------------------------------------------------
+static void find_emissives(orc_ctx* c, Primitive& p)
+{
+    const DeviceMaterial& m = c->materials[p.material];
+    p.emissive.assign(p.idx.size() / 3, 0);
+    p.numLights = 0;
+    if (m.emissiveColor.x == 0.f && m.emissiveColor.y == 0.f && m.emissiveColor.z == 0.f) { p.containEmissive = false; return; }
+    for (size_t b = 0; b + 2 < p.idx.size(); b += 3) {
+        const Vertex &v0 = p.verts[p.idx[b]], &v1 = p.verts[p.idx[b + 1]], &v2 = p.verts[p.idx[b + 2]];
+        constexpr float oneThird = 1.f / 3.f;
+        const f2 uvc = (v0.uv + v1.uv + v2.uv) * oneThird;
+        f4 e = m.data.emissive;
+        if (m.texEmissive >= 0) e = e * tex2D(c, m.texEmissive, uvc.x, uvc.y);
+        if (e.x > 0.0f || e.y > 0.0f || e.z > 0.0f) { p.emissive[b / 3] = 1; p.numLights++; }
+    }
+    p.containEmissive = p.numLights > 0;
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// Light list — Framework/LightDataBuffer.cpp:37-125 + GPUDataBufferKernels.cu:9-186 + CPUDataBufferKernels.cu:35-56
+// Returns totalNumEmissive (the value TraceFrame tests against 0, WaveFrontRenderer.cpp:456-464).
+// ----------------------------------------------------------------------------------------------------------
+static uint32_t build_lights(orc_ctx* c)
+{
+    struct LID { uint32_t tableIndex, numTriangles, numEmissives; };
+    std::vector<LID> lid;
+    uint32_t numEmissivePrims = 0, total = 0;
+    float avg = 0;
+    for (const MeshInstance& mi : c->instances) {
+        bool meshEmissive = false;
+        for (int p : c->meshes[mi.mesh].prims) meshEmissive |= c->prims[p].containEmissive;     // PTMesh emissiveness
+        if (mi.mode != 1 && ((mi.mode == 0 && meshEmissive) || mi.mode == 2)) {
+            for (size_t k = 0; k < c->meshes[mi.mesh].prims.size(); k++) {
+                const Primitive& pr = c->prims[c->meshes[mi.mesh].prims[k]];
+                if (pr.containEmissive || mi.mode == 2) {
+                    const uint32_t numTriangles = (uint32_t)(pr.idx.size() / 3);
+                    avg = ((avg * (float)numEmissivePrims) + (float)numTriangles) / (float)(numEmissivePrims + 1);
+                    numEmissivePrims++;
+                    total += pr.numLights;
+                    lid.push_back(LID{(uint32_t)mi.entries[k], numTriangles, pr.numLights});
+                }
+            }
+        }
+    }
+    const uint32_t bufferSize = 1000000u;                                  // WaveFrontRenderer.cpp:295
+    if (total > bufferSize) {                                              // LightDataBuffer.cpp:94-111
+        size_t keep = lid.size();
+        while (keep > 0) { total -= lid[keep - 1].numEmissives; keep--; if (total < bufferSize) break; }
+        lid.resize(keep);
+    }
+    // launch shape: block (8,64), grid (ceil(inst/8), ceil(round(avg)/64)) => threads along y per instance
+    const uint32_t avgTri = (uint32_t)roundf(avg);
+    const uint32_t gridH = (uint32_t)ceilf((float)avgTri / 64.f);
+    const uint32_t threadsY = gridH * 64u;
+    c->lights.clear();
+    for (const LID& d : lid) {
+        if (threadsY == 0) break;
+        const uint32_t perThread = (uint32_t)ceilf((float)d.numTriangles / (float)threadsY);
+        const TableEntry& e = c->table[d.tableIndex];
+        const Primitive& pr = c->prims[e.prim];
+        const DeviceMaterial& mat = c->materials[e.material];
+        for (uint32_t ty = 0; ty < threadsY; ty++) {
+            const uint32_t start = ty * perThread;
+            if (!(start < d.numTriangles - 1u)) continue;                  // sic: GPUDataBufferKernels.cu:37 drops a slice starting at the last triangle
+            const uint32_t num = (start + perThread) < d.numTriangles ? perThread : d.numTriangles - start;
+            for (uint32_t k = 0; k < num; k++) {
+                const uint32_t tri = start + k;
+                TriLight L; memset(&L, 0, sizeof L);                       // reserved-but-unset slots: defined as zero (D5)
+                if ((e.mode == 0 && pr.emissive[tri]) || e.mode == 2) {
+                    const Vertex &v0 = pr.verts[pr.idx[tri * 3]], &v1 = pr.verts[pr.idx[tri * 3 + 1]], &v2 = pr.verts[pr.idx[tri * 3 + 2]];
+                    const f3 p0 = mk3(mat4_mul(e.M, mk4(v0.pos, 1.f)));
+                    const f3 p1 = mk3(mat4_mul(e.M, mk4(v1.pos, 1.f)));
+                    const f3 p2 = mk3(mat4_mul(e.M, mk4(v2.pos, 1.f)));
+                    constexpr float oneThird = 1.f / 3.f;
+                    const f2 uvc = (v0.uv + v1.uv + v2.uv) * oneThird;
+                    f4 em{0, 0, 0, 0};
+                    if (e.mode == 0) { em = tex2D(c, mat.texEmissive, uvc.x, uvc.y); em = em * (mat.data.emissive * e.emissiveColorAndScale.w); }
+                    else em = e.emissiveColorAndScale * e.emissiveColorAndScale.w;
+                    if (em.x > 0.f || em.y > 0.f || em.z > 0.f) {
+                        L.p0 = p0; L.p1 = p1; L.p2 = p2;
+                        L.radiance = mk3(em);
+                        const f3 nrm = (v0.normal + v1.normal + v2.normal) * oneThird;
+                        L.normal = normalize(mk3(mat4_mul(e.M, mk4(nrm, 0.f))));
+                        const f3 a = p0 - p1, b = p0 - p2;
+                        const float cx = (a.y * b.z - b.y * a.z), cy = (a.x * b.z - b.x * a.z), cz = (a.x * b.y - b.x * a.y);
+                        L.area = sqrtf(cx * cx + cy * cy + cz * cz) / 2.0f;
+                    }
+                }
+                c->lights.push_back(L);
+            }
+        }
+    }
+    return total;
+}
+
+// CDF — ReSTIRKernels.cu:49-130,165-190 (sort by mean radiance, weights, inclusive scan)  (D3)
+static void build_cdf(orc_ctx* c)
+{
+    auto key = [](const TriLight& l) { return (l.radiance.x + l.radiance.y + l.radiance.z) / 3.f; };
+    std::stable_sort(c->lights.begin(), c->lights.end(), [&](const TriLight& a, const TriLight& b) { return key(a) < key(b); });
+    c->cdf.resize(c->lights.size());
+    double acc = 0;
+    for (size_t i = 0; i < c->lights.size(); i++) { acc += (double)key(c->lights[i]); c->cdf[i] = (float)acc; }
+    c->cdfSum = c->cdf.empty() ? 0.f : c->cdf.back();
+}
+// CDF::Get / BinarySearch — Shaders/CppCommon/ReSTIRData.h:230-306
+static void cdf_get(const orc_ctx* c, float value, uint32_t& index, float& pdf)
+{
+    const float required = c->cdfSum * value;
+    int first = 0, last = (int)c->cdf.size() - 1, center = 0;
+    for (;;) {
+        center = (last + first) / 2;
+        const float higher = c->cdf[center];
+        const float lower = center != 0 ? c->cdf[center - 1] : 0.f;
+        if (required < lower && center - 1 >= first) { last = center - 1; continue; }
+        if (required > higher && center + 1 <= last) { first = center + 1; continue; }
+        break;
+    }
+    const float higher = c->cdf[center];
+    const float lower = center != 0 ? c->cdf[center - 1] : 0.f;
+    index = (uint32_t)center;
+    pdf = (higher - lower) / c->cdfSum;
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// GeneratePrimaryRay — GPUGeneratePrimRay.cu:28-82; camera basis Camera.cpp:79-93
+// ----------------------------------------------------------------------------------------------------------
+static Ray primary_ray(const orc_ctx* c, uint32_t i, const f3& U, const f3& V, const f3& Wv, const f3& eye, uint32_t frameCount)
+{
+    const int sy = (int)(i / c->W), sx = (int)(i - (uint32_t)sy * c->W);
+    const float jx = halton(frameCount + i, 2), jy = halton(frameCount + i, 3);
+    f3 dir = mk3(((float)sx + jx) / (float)c->W, ((float)sy + jy) / (float)c->H, 0.f);
+    dir.x = -(dir.x * 2.0f - 1.0f);
+    dir.y = -(dir.y * 2.0f - 1.0f);
+    dir = normalize(dir.x * U + dir.y * V + Wv);
+    return Ray{(uint16_t)sx, (uint16_t)sy, eye, dir, mk3(1.f, 1.f, 1.f)};
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// ExtractSurfaceDataGpu — GPUExtractSurfaceData.cu:8-228
+// ----------------------------------------------------------------------------------------------------------
+static void extract_surface(const orc_ctx* c, const Hit& h, const Ray& ray, Surface& dst)
+{
+    if (!(h.t > 0.f)) { dst.flags = SF_NON_INTERSECT; return; }          // :222-226 (only the flag is written)
+    const TableEntry& e = c->table[h.instance];
+    const Primitive& pr = c->prims[e.prim];
+    const DeviceMaterial& mat = c->materials[e.material];
+    const Vertex &A = pr.verts[pr.idx[3 * h.prim]], &B = pr.verts[pr.idx[3 * h.prim + 1]], &C = pr.verts[pr.idx[3 * h.prim + 2]];
+    const float U = f16_to_f32(h.bu), V = f16_to_f32(h.bv), Wt = 1.f - (U + V);
+    const f2 uv = A.uv * Wt + B.uv * U + C.uv * V;
+    const float flip = A.tangent.w;
+    const f4 normalMap = tex2D(c, mat.texNormal, uv.x, uv.y);
+    const f4 texColor = tex2D(c, mat.texDiffuse, uv.x, uv.y);
+    f4 emissive{0, 0, 0, 0};
+    if (e.mode == 0) { emissive = mat.data.emissive * e.emissiveColorAndScale.w; emissive = emissive * tex2D(c, mat.texEmissive, uv.x, uv.y); }
+    else if (e.mode == 2) emissive = e.emissiveColorAndScale * e.emissiveColorAndScale.w;
+
+    Surface out; memset(&out, 0, sizeof out);                             // D5
+    out.flags = SF_NONE;
+    const f4 localNormal = mk4(normalize(A.normal * Wt + B.normal * U + C.normal * V), 0.f);
+    const f3 lt = mk3(A.tangent) * Wt + mk3(B.tangent) * U + mk3(C.tangent) * V;
+    const f4 localTangent = mk4(normalize(lt), 0.f);
+    const f3 normalWorld = normalize(mk3(mat4_mul(e.M, localNormal)));
+    const f3 tangentWorld = normalize(mk3(mat4_mul(e.M, localTangent)));
+    const f3 bitangentWorld = cross(normalWorld, tangentWorld) * flip;
+    f3 nm = mk3(normalMap.x, normalMap.y, normalMap.z);
+    nm = nm * 2.f + (-1.f);
+    nm = normalize(nm);
+    nm = normalize(mk3(nm.x * tangentWorld.x + nm.y * bitangentWorld.x + nm.z * normalWorld.x,
+                       nm.x * tangentWorld.y + nm.y * bitangentWorld.y + nm.z * normalWorld.y,
+                       nm.x * tangentWorld.z + nm.y * bitangentWorld.z + nm.z * normalWorld.z));
+    out.px = ray.px; out.py = ray.py;
+    out.t = h.t;
+    out.normal = nm;
+    if (emissive.x > 0.f || emissive.y > 0.f || emissive.z > 0.f) {       // :120-136
+        const float maximum = fmaxf(emissive.x, fmaxf(emissive.y, emissive.z));
+        const float inv = 1.0f / maximum;
+        out.mat.color = emissive * inv;
+        out.flags |= SF_EMISSIVE;
+        dst = out;
+        return;
+    }
+    if (texColor.w < 0.51f) {                                             // :139-151
+        out.flags |= SF_ALPHA;
+        out.position = ray.origin + ray.dir * h.t;
+        out.incoming = ray.dir;
+        out.transport = ray.contribution;
+        dst = out;
+        return;
+    }
+    const float eta = 1.f / mat.data.transmittance.w;
+    out.geomNormal = normalWorld;
+    out.position = ray.origin + ray.dir * h.t;
+    out.incoming = ray.dir;
+    out.transport = ray.contribution;
+    out.tangent = tangentWorld;
+    out.mat = mat.data;
+    const f4 mr = tex2D(c, mat.texMetalRough, uv.x, uv.y);
+    mat_set(out.mat, P_METALLIC, mr.z * mat_get(mat.data, P_METALLIC));
+    mat_set(out.mat, P_ROUGHNESS, mr.y * mat_get(mat.data, P_ROUGHNESS));
+    out.mat.color = texColor * mat.data.color;
+    const f4 cc = tex2D(c, mat.texClearCoat, uv.x, uv.y);
+    const f4 ccr = tex2D(c, mat.texClearCoatRough, uv.x, uv.y);
+    const f4 tr = tex2D(c, mat.texTransmission, uv.x, uv.y);
+    const f4 tint = tex2D(c, mat.texTint, uv.x, uv.y);
+    const f3 finalTint = mk3(tint.x, tint.y, tint.z) * mk3(mat.data.tint);
+    const float finalClearCoat = mat_get(mat.data, P_CLEARCOAT) * cc.x;
+    const float gloss = mat_get(mat.data, P_CLEARCOATGLOSS) * (1.f - ccr.x);
+    const float finalTransmission = mat_get(mat.data, P_TRANSMISSION) * tr.x;
+    mat_set(out.mat, P_CLEARCOAT, finalClearCoat);
+    mat_set(out.mat, P_CLEARCOATGLOSS, gloss);
+    out.mat.tint = mk4(finalTint, out.mat.tint.w);
+    mat_set(out.mat, P_TRANSMISSION, finalTransmission);
+    out.mat.transmittance.w = eta;
+    dst = out;
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// ShadeDirect — GPUShadeDirect.cu:42-153
+// ----------------------------------------------------------------------------------------------------------
+static bool shade_direct(const orc_ctx* c, const Surface& s, uint32_t pixelIndex, uint32_t px, uint32_t py, uint32_t a_Seed, ShadowRay& out)
+{
+    uint32_t seed = wang_hash(a_Seed + pixelIndex);
+    if (s.flags) return false;
+    uint32_t index; float pdf;
+    cdf_get(c, random_float(seed), index, pdf);
+    const TriLight& light = c->lights[index];
+    const float u = random_float(seed);
+    const float v = random_float(seed) * (1.f - u);
+    const f3 arm1 = light.p1 - light.p0, arm2 = light.p2 - light.p0;
+    const f3 lightCenter = light.p0 + (arm1 * u) + (arm2 * v);
+    f3 toLight = lightCenter - s.position;
+    const float lDistance = length(toLight);
+    toLight /= lDistance;
+    const float cosIn = fmaxf(dot(toLight, s.normal), 0.f);
+    const float cosOut = fmaxf(0.f, dot(light.normal, -toLight));
+    if (cosIn <= 0.f || lDistance <= 0.01f) return false;
+    const float solidAngle = (cosOut * light.area) / (lDistance * lDistance);
+    float bsdfPdf = 0.f;
+    const f3 bsdf = evaluate_bsdf(s.mat, s.normal, s.tangent, -s.incoming, toLight, bsdfPdf);
+    if (bsdfPdf <= kBsdfEpsilon) return false;
+    f3 contribution = (bsdf / bsdfPdf) * solidAngle * cosIn * light.radiance;
+    contribution *= ((1.f / pdf) * s.transport);
+    out = ShadowRay{(uint16_t)px, (uint16_t)py, s.position, toLight, lDistance - 0.2f, contribution, 1u /* INDIRECT */};
+    return true;
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// ShadeIndirect — GPUShadeIndirect.cu:7-146
+// ----------------------------------------------------------------------------------------------------------
+static bool shade_indirect(const Surface& s, uint32_t pixelIndex, uint32_t px, uint32_t py, uint32_t a_Seed, Ray& out)
+{
+    uint32_t seed = wang_hash(a_Seed + wang_hash(pixelIndex));
+    if (s.flags & SF_ALPHA) { out = Ray{(uint16_t)px, (uint16_t)py, s.position, s.incoming, s.transport}; return true; }
+    if (s.flags) return false;
+    if (fabsf(dot(s.normal, s.incoming)) < 3.f * kBsdfEpsilon) return false;
+    f3 bounce = mk3(0);
+    float pdf = 0.f;
+    bool specular = false;
+    const float r0 = random_float(seed), r1 = random_float(seed), r2 = random_float(seed);     // argument order = draw order
+    const f3 bsdf = sample_bsdf(s.mat, s.normal, s.normal, s.tangent, -s.incoming, 1.f, r0, r1, r2, bounce, pdf, specular);
+    const float chk = pdf + bsdf.x + bsdf.y + bsdf.z;
+    if (pdf <= kBsdfEpsilon || chk != chk) return false;
+    const float rrWeight = specular ? 1.f : fminf(fmaxf(bsdf.x, fmaxf(bsdf.y, bsdf.z)), 1.f);
+    const float rnd = random_float(seed);
+    if (rrWeight < rnd) return false;
+    const float rrPdf = 1.f / rrWeight;
+    f3 contribution = s.transport * rrPdf;
+    contribution *= bsdf * fabsf(dot(s.normal, bounce)) * (1.f / pdf);
+    out = Ray{(uint16_t)px, (uint16_t)py, s.position, bounce, contribution};
+    return true;
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// ReSTIR — Shaders/CppCommon/ReSTIRData.h:115-178, CUDAKernels/ReSTIRKernels.cu
+// ----------------------------------------------------------------------------------------------------------
+static inline void res_reset(Reservoir& r) { r.weightSum = 0.f; r.sampleCount = 0; r.weight = 0.f; }     // ReSTIRData.h:165-170
+static inline Reservoir res_fresh() { Reservoir r; memset(&r, 0, sizeof r); return r; }                  // ctor :117-120 + LightSample ctor (D5)
+static inline bool res_update(Reservoir& r, const LightSample& s, float w, uint32_t seed /* by value: quirk 6 */)
+{
+    r.weightSum += w;
+    ++r.sampleCount;
+    const float rnd = random_float(seed);
+    if (rnd <= (w / r.weightSum)) { r.sample = s; return true; }
+    return false;
+}
+static inline void res_update_weight(Reservoir& r)
+{
+    if (r.sampleCount == 0 || r.weightSum <= 0.f) { r.weight = 0; return; }
+    r.weight = (1.f / fmaxf(r.sample.solidAnglePdf, 1.1920928955078125e-7f)) * ((1.f / (float)r.sampleCount) * r.weightSum);
+}
+// Resample — ReSTIRKernels.cu:1259-1325
+static void resample(const LightSample& in, const Surface& px, LightSample& out)
+{
+    out = in;
+    f3 toLight = in.position - px.position;
+    const float lDistance = length(toLight);
+    toLight /= lDistance;
+    const float cosIn = fmaxf(dot(toLight, px.normal), 0.f);
+    const float cosOut = fmaxf(dot(in.normal, -toLight), 0.f);
+    if (cosIn <= 0 || cosOut <= 0 || lDistance <= 0.01f) { out.solidAnglePdf = 0; return; }
+    const float solidAngle = (cosOut * in.area) / (lDistance * lDistance);
+    float pdf = 0.f;
+    const f3 bsdf = evaluate_bsdf(px.mat, px.normal, px.tangent, -px.incoming, toLight, pdf);
+    const float added = pdf + bsdf.x + bsdf.y + bsdf.z;
+    if (pdf <= kBsdfEpsilon || added != added || std::isinf(added)) { out.contribution = mk3(0.f); out.solidAnglePdf = 0; return; }
+    const f3 contribution = (bsdf / pdf) * solidAngle * cosIn * out.radiance;
+    out.contribution = contribution;
+    out.solidAnglePdf = (contribution.x + contribution.y + contribution.z) / 3.f;
+}
+// CombineBiased — ReSTIRKernels.cu:1200-1257
+static void combine_biased(Reservoir& dst, int count, const Reservoir* rs, const Surface& px, uint32_t seed)
+{
+    Reservoir out = res_fresh();
+    long long sum = 0;
+    for (int i = 0; i < count; i++) {
+        LightSample rsd;
+        resample(rs[i].sample, px, rsd);
+        const float w = (float)rs[i].sampleCount * rs[i].weight * rsd.solidAnglePdf;
+        res_update(out, rsd, w, seed);
+        sum += rs[i].sampleCount;
+    }
+    out.sampleCount = sum;
+    res_update_weight(out);
+    dst = out;
+}
+// ShadeReservoirs — ReSTIRKernels.cu:618-665 (fp32 accumulate, D1)
+static inline void shade_reservoir(orc_ctx* c, const Reservoir& r, uint32_t outIdx)
+{
+    if (r.weight > 0.f) {
+        const f3 add = r.sample.contribution * (r.weight / 3.f);          // numShadedSamples = 1*(1+1+1)
+        f4& px = c->channel[0][outIdx];
+        px.x += add.x; px.y += add.y; px.z += add.z; px.w += 0.f;
+    }
+}
+
+static inline bool in_window(const orc_ctx* c, int x, int y) { return x >= (int)c->wx0 && x < (int)c->wx1 && y >= (int)c->wy0 && y < (int)c->wy1; }
+
+// visibility pass: GenerateShadowRay (ReSTIRKernels.cu:546-582) + ReSTIRRayGen (WaveFrontShaders.cu:181-216), tmin 0.1 (ReSTIR.cpp:310)
+static uint64_t visibility_check(orc_ctx* c, std::vector<Reservoir>& res, const std::vector<Surface>& surf, const std::vector<uint32_t>& pixels)
+{
+    std::atomic<uint64_t> count{0};
+    c->pfor((uint32_t)pixels.size(), [&](uint32_t b, uint32_t e, int) {
+        uint64_t local = 0;
+        for (uint32_t k = b; k < e; k++) {
+            const uint32_t i = pixels[k];
+            const Surface& s = surf[i];
+            if (s.flags) continue;
+            Reservoir& r = res[i];
+            if (!(r.weight > 0.f)) continue;
+            f3 toLight = r.sample.position - s.position;
+            const float l = length(toLight);
+            toLight /= l;
+            local++;
+            if (any_hit(c, s.position, toLight, 0.1f, l - 0.05f, true)) r.weight = 0.f;
+        }
+        count += local;
+    });
+    return count;
+}
+
+static void restir_run(orc_ctx* c, int cur, int prev, uint32_t a_Seed, const std::vector<uint32_t>& pixels)      // Framework/ReSTIR.cpp:65-233
+{
+    const uint32_t W = c->W;
+    const std::vector<Surface>& curS = c->surface[cur];
+    const std::vector<Surface>& prevS = c->surface[prev];
+    const int currentIndex = c->swapChainIndex, temporalIndex = currentIndex == 1 ? 0 : 1;
+    std::vector<Reservoir>& RC = c->reservoirs[currentIndex];
+    std::vector<Reservoir>& RT = c->reservoirs[temporalIndex];
+    uint32_t seed = wang_hash(a_Seed);
+
+    build_cdf(c);                                                           // ReSTIR.cpp:125
+    // FillLightBags — ReSTIRKernels.cu:343-370 (seed = a_Seed, ReSTIR.cpp:135-141)
+    const uint32_t nBags = 50, perBag = 1000;
+    c->bags.resize(nBags * perBag);
+    c->pfor(nBags * perBag, [&](uint32_t b, uint32_t e, int) {
+        for (uint32_t i = b; i < e; i++) {
+            uint32_t s = wang_hash(a_Seed + wang_hash(i));
+            const float rnd = random_float(s);
+            uint32_t li; float pdf;
+            cdf_get(c, rnd, li, pdf);
+            c->bags[i] = LightBagEntry{c->lights[li], pdf};
+        }
+    });
+    // PickPrimarySamples — ReSTIRKernels.cu:402-522
+    seed = wang_hash(seed);
+    {
+        const uint32_t s0 = seed;
+        const uint32_t tilesX = (W + 15u) / 16u;
+        c->pfor((uint32_t)pixels.size(), [&](uint32_t b, uint32_t e, int) {
+            for (uint32_t k = b; k < e; k++) {
+                const uint32_t index = pixels[k];
+                const uint32_t py = index / W, px = index - py * W;
+                uint32_t bagSeed = wang_hash(s0 + ((py / 16u) * tilesX + (px / 16u)));      // D2 (reference: seed + %smid)
+                const float rb = random_float(bagSeed);
+                const int bagIndex = (int)roundf((float)(nBags - 1) * rb);
+                const LightBagEntry* bag = &c->bags[(size_t)bagIndex * perBag];
+                const Surface& pixel = curS[index];
+                if (pixel.flags) { RC[index].weight = 0.f; continue; }
+                uint32_t s = wang_hash(s0 + wang_hash(index));
+                Reservoir fresh = res_fresh();
+                for (int smp = 0; smp < 32; smp++) {
+                    const float r = random_float(s);
+                    const int li = (int)roundf((float)(perBag - 1) * r);
+                    const TriLight& light = bag[li].light;
+                    const float initialPdf = bag[li].pdf;
+                    const float u = random_float(s);
+                    const float v = random_float(s) * (1.f - u);
+                    LightSample ls; memset(&ls, 0, sizeof ls);
+                    ls.radiance = light.radiance; ls.normal = light.normal; ls.area = light.area;
+                    const f3 arm1 = light.p1 - light.p0, arm2 = light.p2 - light.p0;
+                    ls.position = light.p0 + (arm1 * u) + (arm2 * v);
+                    LightSample rs; resample(ls, pixel, rs);
+                    const float pdf = rs.solidAnglePdf / initialPdf;
+                    res_update(fresh, rs, pdf, s);
+                }
+                res_update_weight(fresh);
+                RC[index] = fresh;
+            }
+        });
+    }
+    c->stats[2] += visibility_check(c, RC, curS, pixels);                   // ReSTIR.cpp:161
+    for (uint32_t i : pixels) shade_reservoir(c, RC[i], i);                 // ReSTIR.cpp:162 (ShadeInternal :600-616)
+
+    // Temporal — ReSTIRKernels.cu:1015-1121
+    seed = wang_hash(seed);
+    {
+        const uint32_t s0 = seed;
+        c->pfor((uint32_t)pixels.size(), [&](uint32_t b, uint32_t e, int) {
+            for (uint32_t k = b; k < e; k++) {
+                const uint32_t index = pixels[k];
+                const int cy = (int)(index / W), cx = (int)(index - (uint32_t)cy * W);
+                const f2 vel = c->motion[index];
+                const int movedX = (int)roundf((float)c->W * vel.x), movedY = (int)roundf((float)c->H * vel.y);
+                int ty = cy + movedY, tx = cx + movedX;
+                uint32_t tIndex = index;
+                if (in_window(c, tx, ty)) tIndex = (uint32_t)ty * W + (uint32_t)tx; else { tx = cx; ty = cy; }
+                const Surface& p0 = prevS[tIndex];
+                const Surface& p1 = curS[index];
+                if (!p0.flags && !p1.flags) {
+                    Reservoir toCombine[2] = {RT[tIndex], RC[index]};
+                    const float d1 = p0.t, d2 = p1.t;
+                    const float depthDif = fabsf(d1 - d2) / ((d1 + d2) / 2.f);
+                    const float angle = dot(p0.normal, p1.normal);
+                    if (depthDif < 0.10f && angle > 0.72222222223f) {
+                        shade_reservoir(c, RT[tIndex], index);              // shades the *previous* reservoir into this pixel
+                        toCombine[0].sampleCount = std::min(toCombine[0].sampleCount, toCombine[1].sampleCount * 20);
+                        combine_biased(RC[index], 2, toCombine, p1, wang_hash(s0 + index));
+                    }
+                }
+            }
+        });
+    }
+    // Spatial — ReSTIRKernels.cu:745-980 (two ping-pong iterations; returns buffers[3])
+    seed = wang_hash(seed);
+    {
+        const uint32_t s0 = seed;
+        std::vector<Reservoir>* from = &RC; std::vector<Reservoir>* to = &c->reservoirs[2];
+        for (int it = 0; it < 2; it++) {
+            std::vector<Reservoir>& In = *from; std::vector<Reservoir>& Out = *to;
+            c->pfor((uint32_t)pixels.size(), [&](uint32_t b, uint32_t e, int) {
+                for (uint32_t k = b; k < e; k++) {
+                    const uint32_t index = pixels[k];
+                    const Surface& cs = curS[index];
+                    if (cs.flags) continue;
+                    uint32_t s = wang_hash(s0 + index);
+                    const int y = (int)(index / W), x = (int)(index - (uint32_t)y * W);
+                    const Surface* nbS[5]; const Reservoir* nbR[5];
+                    int count = 0;
+                    for (int nb = 0; nb < 5; nb++) {
+                        const int ny = (int)roundf((random_float(s) * 2.f - 1.f) * 30.f) + y;
+                        const int nx = (int)roundf((random_float(s) * 2.f - 1.f) * 30.f) + x;
+                        if (!in_window(c, nx, ny)) continue;
+                        const uint32_t ni = (uint32_t)ny * W + (uint32_t)nx;
+                        nbS[count] = &curS[ni];
+                        if (nbS[count]->flags) continue;
+                        nbR[count] = &In[ni];
+                        const float d1 = nbS[count]->t, d2 = cs.t;
+                        const float depthDif = fabsf(d1 - d2) / ((d1 + d2) / 2.f);
+                        const float angle = dot(nbS[count]->normal, cs.normal);
+                        if (depthDif < 0.10f && angle > 0.72222222223f) ++count;
+                    }
+                    if (count > 1) {
+                        long long sum = 0;
+                        Reservoir out = res_fresh();
+                        for (int i = 0; i < count; i++) {
+                            LightSample rs;
+                            resample(nbR[i]->sample, *nbS[0], rs);          // sic: resampled at the FIRST neighbour's surface (:883)
+                            const float w = (float)nbR[i]->sampleCount * nbR[i]->weight * rs.solidAnglePdf;
+                            res_update(out, rs, w, s0);                     // sic: the global seed, same r for every pixel (quirk 6)
+                            sum += nbR[i]->sampleCount;
+                        }
+                        out.sampleCount = sum;
+                        res_update_weight(out);
+                        Out[index] = out;
+                    } else res_reset(Out[index]);
+                }
+            });
+            if (it == 0) { from = &c->reservoirs[2]; to = &c->reservoirs[3]; } else std::swap(from, to);
+        }
+        std::vector<Reservoir>& neighbour = *from;                           // == reservoirs[3]
+        c->stats[2] += visibility_check(c, RC, curS, pixels);               // ReSTIR.cpp:211 (on the CURRENT buffer, quirk 7)
+        for (uint32_t i : pixels) shade_reservoir(c, RC[i], i);             // ReSTIR.cpp:212
+        // CombineReservoirBuffers — ReSTIRKernels.cu:1407-1436, seed WangHash(seed) (ReSTIR.cpp:220)
+        const uint32_t s1 = wang_hash(seed);
+        c->pfor((uint32_t)pixels.size(), [&](uint32_t b, uint32_t e, int) {
+            for (uint32_t k = b; k < e; k++) {
+                const uint32_t i = pixels[k];
+                const Surface& sf = curS[i];
+                if (sf.flags) continue;
+                Reservoir two[2] = {RC[i], neighbour[i]};
+                combine_biased(RC[i], 2, two, sf, wang_hash(s1 + i));
+            }
+        });
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// motion vectors — CUDAKernels/MotionVectors.cu:8-55; matrices WaveFrontRenderer.cpp:760-781, Camera.cpp:106-109
+// ----------------------------------------------------------------------------------------------------------
+static void mat4_mul44(const float* a, const float* b, float* out)        // row-major a*b, sutil Matrix operator* order
+{
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) {
+        float s = 0.f;
+        for (int k = 0; k < 4; k++) s += a[i * 4 + k] * b[k * 4 + j];
+        out[i * 4 + j] = s;
+    }
+}
+static void rigid_inverse(const float* m, float* out)
+{
+    // general 4x4 inverse by cofactors in double (sutil::Matrix4x4::inverse is a float Gauss-Jordan; the result
+    // is rounded to float once here — unpinned at the ulp level, D5)
+    double a[16], inv[16];
+    for (int i = 0; i < 16; i++) a[i] = m[i];
+    inv[0] = a[5]*a[10]*a[15] - a[5]*a[11]*a[14] - a[9]*a[6]*a[15] + a[9]*a[7]*a[14] + a[13]*a[6]*a[11] - a[13]*a[7]*a[10];
+    inv[4] = -a[4]*a[10]*a[15] + a[4]*a[11]*a[14] + a[8]*a[6]*a[15] - a[8]*a[7]*a[14] - a[12]*a[6]*a[11] + a[12]*a[7]*a[10];
+    inv[8] = a[4]*a[9]*a[15] - a[4]*a[11]*a[13] - a[8]*a[5]*a[15] + a[8]*a[7]*a[13] + a[12]*a[5]*a[11] - a[12]*a[7]*a[9];
+    inv[12] = -a[4]*a[9]*a[14] + a[4]*a[10]*a[13] + a[8]*a[5]*a[14] - a[8]*a[6]*a[13] - a[12]*a[5]*a[10] + a[12]*a[6]*a[9];
+    inv[1] = -a[1]*a[10]*a[15] + a[1]*a[11]*a[14] + a[9]*a[2]*a[15] - a[9]*a[3]*a[14] - a[13]*a[2]*a[11] + a[13]*a[3]*a[10];
+    inv[5] = a[0]*a[10]*a[15] - a[0]*a[11]*a[14] - a[8]*a[2]*a[15] + a[8]*a[3]*a[14] + a[12]*a[2]*a[11] - a[12]*a[3]*a[10];
+    inv[9] = -a[0]*a[9]*a[15] + a[0]*a[11]*a[13] + a[8]*a[1]*a[15] - a[8]*a[3]*a[13] - a[12]*a[1]*a[11] + a[12]*a[3]*a[9];
+    inv[13] = a[0]*a[9]*a[14] - a[0]*a[10]*a[13] - a[8]*a[1]*a[14] + a[8]*a[2]*a[13] + a[12]*a[1]*a[10] - a[12]*a[2]*a[9];
+    inv[2] = a[1]*a[6]*a[15] - a[1]*a[7]*a[14] - a[5]*a[2]*a[15] + a[5]*a[3]*a[14] + a[13]*a[2]*a[7] - a[13]*a[3]*a[6];
+    inv[6] = -a[0]*a[6]*a[15] + a[0]*a[7]*a[14] + a[4]*a[2]*a[15] - a[4]*a[3]*a[14] - a[12]*a[2]*a[7] + a[12]*a[3]*a[6];
+    inv[10] = a[0]*a[5]*a[15] - a[0]*a[7]*a[13] - a[4]*a[1]*a[15] + a[4]*a[3]*a[13] + a[12]*a[1]*a[7] - a[12]*a[3]*a[5];
+    inv[14] = -a[0]*a[5]*a[14] + a[0]*a[6]*a[13] + a[4]*a[1]*a[14] - a[4]*a[2]*a[13] - a[12]*a[1]*a[6] + a[12]*a[2]*a[5];
+    inv[3] = -a[1]*a[6]*a[11] + a[1]*a[7]*a[10] + a[5]*a[2]*a[11] - a[5]*a[3]*a[10] - a[9]*a[2]*a[7] + a[9]*a[3]*a[6];
+    inv[7] = a[0]*a[6]*a[11] - a[0]*a[7]*a[10] - a[4]*a[2]*a[11] + a[4]*a[3]*a[10] + a[8]*a[2]*a[7] - a[8]*a[3]*a[6];
+    inv[11] = -a[0]*a[5]*a[11] + a[0]*a[7]*a[9] + a[4]*a[1]*a[11] - a[4]*a[3]*a[9] - a[8]*a[1]*a[7] + a[8]*a[3]*a[5];
+    inv[15] = a[0]*a[5]*a[10] - a[0]*a[6]*a[9] - a[4]*a[1]*a[10] + a[4]*a[2]*a[9] + a[8]*a[1]*a[6] - a[8]*a[2]*a[5];
+    const double det = a[0]*inv[0] + a[1]*inv[4] + a[2]*inv[8] + a[3]*inv[12];
+    for (int i = 0; i < 16; i++) out[i] = (float)(inv[i] / det);
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// TraceFrame — Framework/WaveFrontRenderer.cpp:435-1089 (loop order + seed evolution), Shade: CPUShadingKernels.cu:89-193
+// ----------------------------------------------------------------------------------------------------------
+static int trace_frame(orc_ctx* c)
+{
+    c->resize();
+    c->flatten();
+    if (!c->windowSet) { c->wx0 = 0; c->wy0 = 0; c->wx1 = c->W; c->wy1 = c->H; }
+    const uint32_t W = c->W, H = c->H;
+    memset(c->stats, 0, sizeof c->stats);
+
+    const uint32_t totalEmissive = build_lights(c);                        // :456
+    c->stats[3] = c->lights.size();
+    if (totalEmissive == 0 || c->lights.empty()) return 1;                 // :459-464 (an empty list would make ReSTIR read garbage: also skipped)
+
+    const int currentIndex = c->frameIndex, temporalIndex = c->frameIndex == 1 ? 0 : 1;
+    std::vector<uint32_t> pixels;
+    for (uint32_t y = c->wy0; y < c->wy1; y++) for (uint32_t x = c->wx0; x < c->wx1; x++) pixels.push_back(y * W + x);
+
+    for (auto& ch : c->channel) for (uint32_t i : pixels) ch[i] = f4{0, 0, 0, 0};       // :556
+    if (!c->blend) for (uint32_t i : pixels) c->combined[i] = f4{0, 0, 0, 0};           // :559
+
+    // camera — Camera.cpp:79-93,122-128 (aspect = render W/H, WaveFrontRenderer.cpp:577)
+    const float aspect = (float)W / (float)H;
+    const float halfY = 1.0f * (float)tan((double)(c->fovY * 0.01745329251994329576923690768489f) * 0.5);
+    const float halfX = halfY * aspect;
+    const f3 U = c->camRight * halfX, V = c->camUp * halfY, Wv = c->camForward * 1.0f, eye = c->camPos;
+    float camWorld[16] = {c->camRight.x, c->camUp.x, c->camForward.x, c->camPos.x,
+                          c->camRight.y, c->camUp.y, c->camForward.y, c->camPos.y,
+                          c->camRight.z, c->camUp.z, c->camForward.z, c->camPos.z, 0, 0, 0, 1};
+    if (!c->havePrev) { memcpy(c->prevCamWorld, camWorld, sizeof camWorld); c->havePrev = true; }
+
+    ++c->frameCount;                                                        // :593
+    std::vector<Ray> rays(pixels.size());
+    c->pfor((uint32_t)pixels.size(), [&](uint32_t b, uint32_t e, int) {
+        for (uint32_t k = b; k < e; k++) rays[k] = primary_ray(c, pixels[k], U, V, Wv, eye, c->frameCount);
+    });
+    { Surface zs; memset(&zs, 0, sizeof zs); for (uint32_t i : pixels) c->surface[currentIndex][i] = zs; }   // :652
+    std::vector<ShadowRay> shadowRays;
+    uint32_t seed = wang_hash(c->frameCount);                               // :685
+
+    std::vector<uint32_t> active = pixels;     // pixels that own a live ray in this wave (quirk 16: the reference launches over all N)
+    for (uint32_t depth = 0; depth < c->depth && !rays.empty(); ++depth) {
+        const uint32_t nRays = (uint32_t)rays.size();
+        c->stats[0] += nRays; if (depth < 60) c->stats[4 + depth] = nRays;
+        std::vector<Hit> hits(nRays);
+        c->pfor(nRays, [&](uint32_t b, uint32_t e, int) {
+            for (uint32_t k = b; k < e; k++) hits[k] = trace_ray(c, rays[k].origin, rays[k].dir, 0.01f, 5000.f);   // :678,:703
+        });
+        const int sIdx = depth == 0 ? currentIndex : 2;
+        std::vector<Surface>& S = c->surface[sIdx];
+        c->pfor(nRays, [&](uint32_t b, uint32_t e, int) {
+            for (uint32_t k = b; k < e; k++) extract_surface(c, hits[k], rays[k], S[(uint32_t)rays[k].py * W + rays[k].px]);
+        });
+        if (depth == 0) {
+            // GenerateMotionVectors: M = projection * inverse(previous camera world matrix)
+            float proj[16] = {0}, invPrev[16], M[16];
+            const float tanHalf = (float)tan((double)(c->fovY * 0.01745329251994329576923690768489f) / 2.0);
+            const float zn = 0.5f, zf = 10000.f;                           // glm::perspective RH, -1..1 depth (Camera.cpp:106-109)
+            proj[0] = 1.0f / (aspect * tanHalf); proj[5] = 1.0f / tanHalf;
+            proj[10] = -(zf + zn) / (zf - zn); proj[11] = -(2.0f * zf * zn) / (zf - zn); proj[14] = -1.0f;
+            rigid_inverse(c->prevCamWorld, invPrev);
+            mat4_mul44(proj, invPrev, M);
+            c->pfor((uint32_t)pixels.size(), [&](uint32_t b, uint32_t e, int) {
+                for (uint32_t k = b; k < e; k++) {
+                    const uint32_t i = pixels[k];
+                    const uint32_t py = i / W, px = i - py * W;
+                    f2 mv{0.f, 0.f};
+                    const Surface& s = c->surface[currentIndex][i];
+                    if (s.t > 0.f) {
+                        f2 cur{(float)px, (float)py};
+                        cur.x += 0.5f; cur.y += 0.5f;
+                        cur.x /= (float)W; cur.y /= (float)H;
+                        const f4 clip = mat4_mul(M, mk4(s.position, 1.0f));
+                        const f3 ndc = mk3(clip.x, clip.y, clip.z) / clip.w;
+                        const f2 prevScreen{ndc.x * 0.5f + 0.5f, ndc.y * 0.5f + 0.5f};
+                        mv = f2{quantize_f16(prevScreen.x - cur.x), quantize_f16(prevScreen.y - cur.y)};
+                    }
+                    c->motion[i] = mv;
+                }
+            });
+        }
+        // Shade()
+        std::vector<Ray> next;
+        if (depth == 0) {
+            for (uint32_t i : pixels) {                                    // ResolveDirectLightHits, GPUShadeDirect.cu:11-40
+                const Surface& s = S[i];
+                if (s.flags & SF_EMISSIVE) c->channel[0][i] = s.mat.color;
+            }
+            restir_run(c, currentIndex, temporalIndex, seed, pixels);
+        } else {
+            std::vector<std::vector<ShadowRay>> parts(c->threads + 1);
+            c->pfor((uint32_t)active.size(), [&](uint32_t b, uint32_t e, int t) {
+                for (uint32_t k = b; k < e; k++) {
+                    const uint32_t i = active[k];
+                    ShadowRay sr;
+                    if (shade_direct(c, S[i], i, i % W, i / W, seed, sr)) parts[t].push_back(sr);
+                }
+            });
+            for (auto& p : parts) shadowRays.insert(shadowRays.end(), p.begin(), p.end());
+        }
+        const uint32_t seed2 = wang_hash(seed);                             // CPUShadingKernels.cu:178
+        if (depth < c->depth - 1) {
+            std::vector<std::vector<Ray>> parts(c->threads + 1);
+            c->pfor((uint32_t)active.size(), [&](uint32_t b, uint32_t e, int t) {
+                for (uint32_t k = b; k < e; k++) {
+                    const uint32_t i = active[k];
+                    Ray r;
+                    if (shade_indirect(S[i], i, i % W, i / W, seed2, r)) parts[t].push_back(r);
+                }
+            });
+            for (auto& p : parts) next.insert(next.end(), p.begin(), p.end());
+        }
+        rays.swap(next);
+        if (sIdx == 2) { Surface zs; memset(&zs, 0, sizeof zs); for (uint32_t i : active) c->surface[2][i] = zs; }   // :818 (only touched slots can be non-zero)
+        active.resize(rays.size());
+        for (size_t k = 0; k < rays.size(); k++) active[k] = (uint32_t)rays[k].py * W + rays[k].px;
+        c->swapChainIndex = (c->swapChainIndex + 1) >= 2 ? 0 : c->swapChainIndex + 1;                            // ReSTIR::SwapBuffers
+        seed = wang_hash(seed);                                             // :830
+    }
+    // shadow rays — ShadowRaysRayGen, WaveFrontShaders.cu:114-179 (tmin 0.01, fp32 accumulate in append order, D1)
+    c->stats[1] = shadowRays.size();
+    {
+        std::vector<uint8_t> occ(shadowRays.size());
+        c->pfor((uint32_t)shadowRays.size(), [&](uint32_t b, uint32_t e, int) {
+            for (uint32_t k = b; k < e; k++) occ[k] = any_hit(c, shadowRays[k].origin, shadowRays[k].dir, 0.01f, shadowRays[k].maxDist, true);
+        });
+        for (size_t k = 0; k < shadowRays.size(); k++) if (!occ[k]) {
+            f4& px = c->channel[shadowRays[k].channel][(uint32_t)shadowRays[k].py * W + shadowRays[k].px];
+            px.x += shadowRays[k].radiance.x; px.y += shadowRays[k].radiance.y; px.z += shadowRays[k].radiance.z; px.w += 0.f;
+        }
+    }
+    // MergeOutputChannels — GPUMergeOutputChannels.cu:5-88 (fp32, D1)
+    for (uint32_t i : pixels) {
+        f4 m{0, 0, 0, 0};
+        for (int ch = 0; ch < 3; ch++) m = m + c->channel[ch][i];
+        const f4 vol = c->channel[3][i];
+        const float alpha = vol.w;
+        m = m * (1.0f - alpha) + vol * alpha;
+        if (c->blend) {
+            const f4 old = c->combined[i];
+            const float k = (float)c->blendCounter, k1 = (float)(c->blendCounter + 1);
+            const f4 s = old * k + m;
+            c->combined[i] = f4{s.x / k1, s.y / k1, s.z / k1, s.w / k1};
+        } else c->combined[i] = m;
+    }
+    // WriteToOutput — GPUShadingKernels.cu:28-56 + vendor/Include/Cuda/cuda/helpers.h:35-66
+    for (uint32_t i : pixels) {
+        const f4 cc = c->combined[i];
+        const float in[3] = {clampf(cc.x, 0.f, 1.f), clampf(cc.y, 0.f, 1.f), clampf(cc.z, 0.f, 1.f)};
+        for (int k = 0; k < 3; k++) {
+            const float powed = det_powf(in[k], 1.0f / 2.4f);
+            float s = in[k] < 0.0031308f ? 12.92f * in[k] : 1.055f * powed - 0.055f;
+            s = clampf(s, 0.f, 1.f);
+            const unsigned q = std::min((unsigned)(s * 256.f), 255u);
+            c->output[(size_t)i * 4 + k] = (uint8_t)q;
+        }
+        c->output[(size_t)i * 4 + 3] = 255;
+    }
+    if (c->blend) ++c->blendCounter;                                        // :1039-1042
+    c->frameIndex = c->frameIndex + 1 == 2 ? 0 : c->frameIndex + 1;         // :1045-1049
+    memcpy(c->prevCamWorld, camWorld, sizeof camWorld);                     // :1051
+    ++c->frameCount;                                                        // :1052
+    return 0;
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// C API
+// ----------------------------------------------------------------------------------------------------------
+static Material material_from23(const float* m)
+{
+    Material sd = mat_zero();
+    sd.color = f4{m[0], m[1], m[2], m[3]};
+    sd.tint = f4{m[4], m[5], m[6], m[7]};
+    sd.transmittance = f4{m[8], m[9], m[10], m[11]};
+    static const ParamSlot order[11] = {P_METALLIC, P_SUBSURFACE, P_SPECULAR, P_ROUGHNESS, P_SPECTINT, P_ANISOTROPIC, P_SHEEN, P_SHEENTINT, P_CLEARCOAT, P_CLEARCOATGLOSS, P_TRANSMISSION};
+    for (int i = 0; i < 11; i++) mat_set(sd, order[i], m[12 + i]);
+    return sd;
+}
+
+extern "C" {
+
+orc_ctx* orc_create(void) { init_srgb_lut(); return new orc_ctx(); }
+void orc_destroy(orc_ctx* c) { delete c; }
+void orc_set_threads(orc_ctx* c, int n) { c->threads = std::max(1, n); }
+
+int orc_add_texture(orc_ctx* c, const uint8_t* rgba8, uint32_t w, uint32_t h, int srgb)
+{
+    Texture t; t.w = w; t.h = h; t.srgb = srgb != 0; t.px.assign(rgba8, rgba8 + (size_t)w * h * 4);
+    c->textures.push_back(std::move(t));
+    return (int)c->textures.size() - 1;
+}
+int orc_add_material(orc_ctx* c, const orc_material_desc* d)
+{
+    // WaveFrontRenderer::CreateMaterial (WaveFrontRenderer.cpp:1269-1318) on a PTMaterial (PTMaterial.cpp:10-19: MaterialData(0), roughness 1)
+    DeviceMaterial m;
+    m.data = mat_zero();
+    mat_set(m.data, P_ROUGHNESS, 1.f);
+    m.data.color = f4{d->diffuse_color[0], d->diffuse_color[1], d->diffuse_color[2], d->diffuse_color[3]};
+    m.data.emissive = f4{d->emission[0], d->emission[1], d->emission[2], 0.f};          // make_float4(float3) -> w = 0
+    m.emissiveColor = f3{d->emission[0], d->emission[1], d->emission[2]};
+    mat_set(m.data, P_TRANSMISSION, d->transmission);
+    mat_set(m.data, P_CLEARCOAT, d->clearcoat);
+    mat_set(m.data, P_CLEARCOATGLOSS, 1.f - d->clearcoat_roughness);                    // PTMaterial.cpp:176-181
+    m.data.transmittance.w = d->ior;
+    mat_set(m.data, P_SPECULAR, d->specular);
+    mat_set(m.data, P_SPECTINT, d->specular_tint);
+    mat_set(m.data, P_SUBSURFACE, d->subsurface);
+    m.data.tint.w = d->luminance;
+    mat_set(m.data, P_ANISOTROPIC, d->anisotropic);
+    mat_set(m.data, P_SHEEN, d->sheen);
+    mat_set(m.data, P_SHEENTINT, d->sheen_tint);
+    m.data.tint = f4{d->tint[0], d->tint[1], d->tint[2], m.data.tint.w};
+    m.data.transmittance = f4{d->transmittance[0], d->transmittance[1], d->transmittance[2], m.data.transmittance.w};
+    mat_set(m.data, P_ROUGHNESS, d->roughness);
+    mat_set(m.data, P_METALLIC, d->metallic);
+    m.texDiffuse = d->tex_diffuse; m.texNormal = d->tex_normal; m.texMetalRough = d->tex_metal_rough; m.texEmissive = d->tex_emissive;
+    m.texTransmission = d->tex_transmission; m.texTint = d->tex_tint;
+    // PTMaterial::CreateDeviceMaterial (PTMaterial.cpp:97-148): the clear-coat-roughness texture lands in the
+    // clear-coat slot and the roughness slot stays a null handle (quirk 12)
+    m.texClearCoat = d->tex_clearcoat;
+    if (d->tex_clearcoat_rough >= 0) m.texClearCoat = d->tex_clearcoat_rough;
+    m.texClearCoatRough = -1;
+    c->materials.push_back(m);
+    return (int)c->materials.size() - 1;
+}
+int orc_add_primitive(orc_ctx* c, const float* vertices, uint32_t nv, const uint32_t* indices, uint32_t ni, int material)
+{
+    Primitive p;
+    p.verts.resize(nv);
+    memcpy(p.verts.data(), vertices, (size_t)nv * sizeof(Vertex));
+    p.idx.assign(indices, indices + ni);
+    p.material = material;
+    find_emissives(c, p);
+    c->prims.push_back(std::move(p));
+    c->sceneDirty = true;
+    return (int)c->prims.size() - 1;
+}
+int orc_add_mesh(orc_ctx* c, const int* primitives, uint32_t n)
+{
+    Mesh m; m.prims.assign(primitives, primitives + n);
+    c->meshes.push_back(m);
+    return (int)c->meshes.size() - 1;
+}
+int orc_add_instance(orc_ctx* c, int mesh, const float transform[16], int mode, const float rad[3], float scale, int overrideMaterial)
+{
+    MeshInstance mi;
+    mi.mesh = mesh; memcpy(mi.M, transform, sizeof mi.M); mi.mode = mode;
+    mi.overrideRadiance = f3{rad[0], rad[1], rad[2]}; mi.scale = scale; mi.overrideMaterial = overrideMaterial;
+    c->instances.push_back(mi);
+    c->sceneDirty = true;
+    return (int)c->instances.size() - 1;
+}
+void orc_set_instance_transform(orc_ctx* c, int inst, const float transform[16]) { memcpy(c->instances[inst].M, transform, 64); c->sceneDirty = true; }
+void orc_set_camera(orc_ctx* c, const float pos[3], const float right[3], const float up[3], const float fwd[3], float fov)
+{
+    c->camPos = f3{pos[0], pos[1], pos[2]}; c->camRight = f3{right[0], right[1], right[2]};
+    c->camUp = f3{up[0], up[1], up[2]}; c->camForward = f3{fwd[0], fwd[1], fwd[2]}; c->fovY = fov;
+}
+void orc_set_resolution(orc_ctx* c, uint32_t w, uint32_t h) { c->W = w; c->H = h; }
+void orc_set_depth(orc_ctx* c, uint32_t d) { c->depth = d; }
+void orc_set_blend(orc_ctx* c, int b) { c->blend = b != 0; if (b) c->blendCounter = 0; }      // WaveFrontRenderer.cpp:377-381
+void orc_set_window(orc_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) { c->wx0 = x0; c->wy0 = y0; c->wx1 = x1; c->wy1 = y1; c->windowSet = true; }
+int  orc_trace_frame(orc_ctx* c) { return trace_frame(c); }
+void orc_get_radiance(orc_ctx* c, float* out) { memcpy(out, c->combined.data(), c->combined.size() * sizeof(f4)); }
+void orc_get_channel(orc_ctx* c, int ch, float* out) { memcpy(out, c->channel[ch].data(), c->channel[ch].size() * sizeof(f4)); }
+void orc_get_output_pixels(orc_ctx* c, uint8_t* out) { memcpy(out, c->output.data(), c->output.size()); }
+void orc_get_stats(orc_ctx* c, uint64_t* out, uint32_t n) { for (uint32_t i = 0; i < n && i < 68; i++) out[i] = c->stats[i]; }
+
+uint32_t orc_wang_hash(uint32_t s) { return wang_hash(s); }
+void orc_random_floats(uint32_t seed, uint32_t n, float* out, uint32_t* states) { uint32_t s = seed; for (uint32_t i = 0; i < n; i++) { out[i] = random_float(s); if (states) states[i] = s; } }
+float orc_halton(uint32_t index, uint32_t base) { return halton(index, base); }
+void orc_pack_material(const float mat[23], uint32_t params_out[3], float g[11])
+{
+    const Material sd = material_from23(mat);
+    params_out[0] = sd.params[0]; params_out[1] = sd.params[1]; params_out[2] = sd.params[2];
+    static const ParamSlot order[11] = {P_METALLIC, P_SUBSURFACE, P_SPECULAR, P_ROUGHNESS, P_SPECTINT, P_ANISOTROPIC, P_SHEEN, P_SHEENTINT, P_CLEARCOAT, P_CLEARCOATGLOSS, P_TRANSMISSION};
+    for (int i = 0; i < 11; i++) g[i] = mat_get(sd, order[i]);
+}
+void orc_eval_bsdf(uint32_t n, const float* mat23, const float* N, const float* T, const float* wo, const float* wi, float* out)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        const Material sd = material_from23(mat23 + 23 * i);
+        float pdf = 0.f;
+        const f3 b = evaluate_bsdf(sd, f3{N[3*i], N[3*i+1], N[3*i+2]}, f3{T[3*i], T[3*i+1], T[3*i+2]}, f3{wo[3*i], wo[3*i+1], wo[3*i+2]}, f3{wi[3*i], wi[3*i+1], wi[3*i+2]}, pdf);
+        out[4*i] = b.x; out[4*i+1] = b.y; out[4*i+2] = b.z; out[4*i+3] = pdf;
+    }
+}
+void orc_sample_bsdf(uint32_t n, const float* mat23, const float* N, const float* T, const float* wo, const float* r, float* out)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        const Material sd = material_from23(mat23 + 23 * i);
+        float pdf = 0.f; bool spec = false; f3 wi = mk3(0);
+        const f3 n3{N[3*i], N[3*i+1], N[3*i+2]};
+        const f3 b = sample_bsdf(sd, n3, n3, f3{T[3*i], T[3*i+1], T[3*i+2]}, f3{wo[3*i], wo[3*i+1], wo[3*i+2]}, 1.f, r[3*i], r[3*i+1], r[3*i+2], wi, pdf, spec);
+        out[8*i] = b.x; out[8*i+1] = b.y; out[8*i+2] = b.z; out[8*i+3] = wi.x; out[8*i+4] = wi.y; out[8*i+5] = wi.z; out[8*i+6] = pdf; out[8*i+7] = spec ? 1.f : 0.f;
+    }
+}
+void orc_det_math(uint32_t n, int fn, const float* x, const float* y, float* out)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        float s, c;
+        switch (fn) {
+        case 0: det_sincosf(x[i], &s, &c); out[i] = s; break;
+        case 1: det_sincosf(x[i], &s, &c); out[i] = c; break;
+        case 2: out[i] = det_logf(x[i]); break;
+        case 3: out[i] = det_expf(x[i]); break;
+        default: out[i] = det_powf(x[i], y[i]); break;
+        }
+    }
+}
+uint16_t orc_f32_to_f16(float f) { return f32_to_f16(f); }
+float orc_f16_to_f32(uint16_t h) { return f16_to_f32(h); }
+
+void orc_trace_closest(orc_ctx* c, uint32_t n, const float* o, const float* d, float tmin, float tmax, uint32_t* ip, float* uvt, int useBvh)
+{
+    c->flatten();
+    c->pfor(n, [&](uint32_t b, uint32_t e, int) {
+        for (uint32_t i = b; i < e; i++) {
+            const HitRec r = closest_hit(c, f3{o[3*i], o[3*i+1], o[3*i+2]}, f3{d[3*i], d[3*i+1], d[3*i+2]}, tmin, tmax, useBvh != 0);
+            if (r.hit) { ip[2*i] = c->triEntry[r.tri]; ip[2*i+1] = c->triPrim[r.tri]; uvt[3*i] = r.u; uvt[3*i+1] = r.v; uvt[3*i+2] = r.t; }
+            else { ip[2*i] = 0; ip[2*i+1] = 0; uvt[3*i] = 0; uvt[3*i+1] = 0; uvt[3*i+2] = -1.f; }
+        }
+    });
+}
+void orc_trace_any(orc_ctx* c, uint32_t n, const float* o, const float* d, float tmin, const float* tmax, uint8_t* occ, int useBvh)
+{
+    c->flatten();
+    c->pfor(n, [&](uint32_t b, uint32_t e, int) {
+        for (uint32_t i = b; i < e; i++) occ[i] = any_hit(c, f3{o[3*i], o[3*i+1], o[3*i+2]}, f3{d[3*i], d[3*i+1], d[3*i+2]}, tmin, tmax[i], useBvh != 0) ? 1 : 0;
+    });
+}
+uint32_t orc_world_triangles(orc_ctx* c, float* out)
+{
+    c->flatten();
+    if (out) memcpy(out, c->worldTris.data(), c->worldTris.size() * sizeof(f3));
+    return (uint32_t)(c->worldTris.size() / 3);
+}
+uint32_t orc_lights(orc_ctx* c, float* out, float* cdf)
+{
+    c->flatten();
+    build_lights(c); build_cdf(c);
+    if (out) memcpy(out, c->lights.data(), c->lights.size() * sizeof(TriLight));
+    if (cdf) memcpy(cdf, c->cdf.data(), c->cdf.size() * sizeof(float));
+    return (uint32_t)c->lights.size();
+}
+void orc_get_gbuffer(orc_ctx* c, float* out)
+{
+    // planes: 0 (pos, t) 1 (normal, flags) 2 (tangent, 0) 3 (incoming, 0) 4 color 5 (tint, lum) 6 (transmittance, eta) 7 (params.xyz as bits, 0)
+    const int last = c->frameIndex == 0 ? 1 : 0;     // frame index was flipped at the end of trace_frame
+    const std::vector<Surface>& S = c->surface[last];
+    for (size_t i = 0; i < S.size(); i++) {
+        const Surface& s = S[i];
+        float* o = out + i * 32;
+        o[0] = s.position.x; o[1] = s.position.y; o[2] = s.position.z; o[3] = s.t;
+        o[4] = s.normal.x; o[5] = s.normal.y; o[6] = s.normal.z; o[7] = (float)s.flags;
+        o[8] = s.tangent.x; o[9] = s.tangent.y; o[10] = s.tangent.z; o[11] = 0;
+        o[12] = s.incoming.x; o[13] = s.incoming.y; o[14] = s.incoming.z; o[15] = 0;
+        memcpy(o + 16, &s.mat.color, 16); memcpy(o + 20, &s.mat.tint, 16); memcpy(o + 24, &s.mat.transmittance, 16);
+        memcpy(o + 28, s.mat.params, 12); o[31] = 0;
+    }
+}
+
+}  // extern "C"

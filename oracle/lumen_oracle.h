@@ -1,0 +1,91 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY.
+ *
+ * C API of the CPU restatement of the LumenPT wavefront path.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the product
+ * (lumenrenderer_amd/, include/) never links, imports or executes anything under oracle/.
+ *
+ * Parity status: the reference as a whole cannot be built or run here (CUDA 10 + OptiX 7.1 + D3D11,
+ * SURVEY.md §0 F10).  The header-only parts (RNG, material packing, Disney BSDF) ARE pinned against the
+ * reference's own headers through tests/golden/ref_kat.npz (generator: oracle/ref_kat/).  Everything that
+ * lives in __global__ kernels, OptiX programs or closed libraries (traversal, texture filtering, thrust
+ * sort/scan order, %smid bag choice, racy fp16 accumulation) has no reference-side vectors:
+ * for those stages this oracle is "parity unpinned" and is the definition the HIP path is held to.
+ */
+#ifndef LUMEN_ORACLE_H
+#define LUMEN_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_ctx orc_ctx;
+
+/* 25 floats in, see LumenRenderer.h:64-112 (MaterialData) for the meaning of each factor */
+typedef struct orc_material_desc {
+    float diffuse_color[4];
+    float emission[3];
+    int32_t tex_diffuse, tex_normal, tex_metal_rough, tex_emissive;      /* texture ids (>=0) */
+    int32_t tex_transmission, tex_clearcoat, tex_clearcoat_rough, tex_tint;
+    float transmission, clearcoat, clearcoat_roughness, ior, specular, specular_tint, subsurface,
+          luminance, anisotropic, sheen, sheen_tint, metallic, roughness;
+    float tint[3];
+    float transmittance[3];
+} orc_material_desc;
+
+orc_ctx* orc_create(void);
+void     orc_destroy(orc_ctx*);
+void     orc_set_threads(orc_ctx*, int n);
+
+int  orc_add_texture(orc_ctx*, const uint8_t* rgba8, uint32_t w, uint32_t h, int srgb);
+int  orc_add_material(orc_ctx*, const orc_material_desc*);
+/* vertices: n * 12 floats (pos3 uv2 normal3 tangent4 = the 48-byte Vertex of ModelStructs.h:21-28) */
+int  orc_add_primitive(orc_ctx*, const float* vertices, uint32_t n_vertices, const uint32_t* indices, uint32_t n_indices, int material);
+int  orc_add_mesh(orc_ctx*, const int* primitives, uint32_t n);
+/* transform: row-major 4x4 world matrix. emission_mode: 0 ENABLED, 1 DISABLED, 2 OVERRIDE (MeshInstance.h:14-19) */
+int  orc_add_instance(orc_ctx*, int mesh, const float transform[16], int emission_mode, const float override_radiance[3], float scale, int override_material);
+void orc_set_instance_transform(orc_ctx*, int instance, const float transform[16]);
+
+/* camera: position + rotation matrix columns right/up/forward (Camera.cpp:122-140), vertical fov in degrees */
+void orc_set_camera(orc_ctx*, const float pos[3], const float right[3], const float up[3], const float forward[3], float fov_y_deg);
+void orc_set_resolution(orc_ctx*, uint32_t w, uint32_t h);
+void orc_set_depth(orc_ctx*, uint32_t depth);
+void orc_set_blend(orc_ctx*, int blend);
+/* render window [x0,x1) x [y0,y1) of the full image (tile sharding); default = whole image */
+void orc_set_window(orc_ctx*, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1);
+
+/* one TraceFrame(); returns 0, or 1 when the frame was skipped because the scene holds no lights */
+int  orc_trace_frame(orc_ctx*);
+void orc_get_radiance(orc_ctx*, float* rgba32f);            /* merged (blended) radiance, w*h*4 */
+void orc_get_channel(orc_ctx*, int channel, float* rgba32f);/* 0 DIRECT 1 INDIRECT 2 SPECULAR 3 VOLUMETRIC */
+void orc_get_output_pixels(orc_ctx*, uint8_t* rgba8);       /* sRGB RGBA8 as WriteToOutput produces */
+/* per-frame counters: [0]=closest-hit rays, [1]=NEE shadow rays, [2]=ReSTIR shadow rays, [3]=lights,
+ * [4..4+depth) = rays per wave */
+void orc_get_stats(orc_ctx*, uint64_t* out, uint32_t n);
+
+/* ---- unit-level entry points (known-answer tests) ---- */
+uint32_t orc_wang_hash(uint32_t);
+void  orc_random_floats(uint32_t seed, uint32_t n, float* out, uint32_t* states);
+float orc_halton(uint32_t index, uint32_t base);
+/* material "mat": 12 floats (color4 tint3 lum transmittance3 ior) + 11 parameter floats fed through the 8-bit setters */
+void  orc_pack_material(const float mat[23], uint32_t params_out[3], float getters_out[11]);
+void  orc_eval_bsdf(uint32_t n, const float* mat23, const float* N, const float* T, const float* wo, const float* wi, float* bsdf_pdf4);
+void  orc_sample_bsdf(uint32_t n, const float* mat23, const float* N, const float* T, const float* wo, const float* r3, float* out8);
+void  orc_det_math(uint32_t n, int fn, const float* x, const float* y, float* out);  /* fn: 0 sin 1 cos 2 log 3 exp 4 pow */
+uint16_t orc_f32_to_f16(float);
+float orc_f16_to_f32(uint16_t);
+
+/* ray-query seam (OptixWrapper::TraceRays): n rays (origin3, dir3) -> hits (instance, prim, u, v, t) */
+void  orc_trace_closest(orc_ctx*, uint32_t n, const float* origins, const float* dirs, float tmin, float tmax,
+                        uint32_t* inst_prim, float* uvt, int use_bvh);
+void  orc_trace_any(orc_ctx*, uint32_t n, const float* origins, const float* dirs, float tmin, const float* tmax, uint8_t* occluded, int use_bvh);
+/* world-space triangle soup the tracer sees: returns count; fills 9 floats per triangle when out != NULL */
+uint32_t orc_world_triangles(orc_ctx*, float* out);
+/* sorted light list as ReSTIR sees it: 16 floats per light (p0 p1 p2 normal radiance area); returns count */
+uint32_t orc_lights(orc_ctx*, float* out, float* cdf);
+/* depth-0 surface data of the last frame: 8 float4 planes per pixel in the order documented in DESIGN.md */
+void  orc_get_gbuffer(orc_ctx*, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
