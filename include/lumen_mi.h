@@ -1,0 +1,156 @@
+/* lumen_mi.h — C ABI of the MI355X-native wavefront path tracer ("liblumen_mi.so").
+ *
+ * The reference has no C ABI: its renderer is the C++ abstract class LumenRenderer, statically linked and chosen at
+ * compile time (Lumen/src/Lumen/Renderer/LumenRenderer.h:37-219, LumenPT/src/LumenPT.h:8-20,
+ * Sandbox/src/Application.cpp:81-99).  Each entry point below replaces one member of that class (or of the
+ * objects it hands out) and cites it; include/lumen_mi_renderer.hpp is the header-only C++ adapter that gives
+ * the reference's own class shape back on top of these calls.
+ *
+ * Conventions: plain pointers and sizes only; handles are opaque 64-bit integers; every call returns an int
+ * status (0 = LUMEN_MI_OK) and lumen_mi_last_error() describes the last failure of the calling thread.  Pixel,
+ * vertex and index memory is borrowed for the duration of the call only (as in the reference,
+ * SceneManager.cpp:737-743).  Matrices are row-major float[16].  Nothing here includes HIP headers.
+ */
+#ifndef LUMEN_MI_H
+#define LUMEN_MI_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lumen_mi_renderer lumen_mi_renderer;
+typedef uint64_t lumen_mi_handle;
+
+enum {
+    LUMEN_MI_OK = 0,
+    LUMEN_MI_ERR_INVALID = 1,       /* bad argument / handle */
+    LUMEN_MI_ERR_DEVICE = 2,        /* HIP error (no GPU, out of memory, launch failure) */
+    LUMEN_MI_ERR_STATE = 3,         /* call order (e.g. trace before init / without a scene) */
+    LUMEN_MI_NO_LIGHTS = 4          /* frame skipped: the scene holds no emissive triangle (WaveFrontRenderer.cpp:456-464) */
+};
+
+/* WaveFrontSettings (LumenPT/src/Framework/WaveFrontRenderer.h:31-48); shader paths have no meaning here */
+typedef struct lumen_mi_settings {
+    uint32_t depth;                 /* maximum path depth (Sandbox: 5) */
+    uint32_t render_width, render_height;
+    uint32_t output_width, output_height;
+    int32_t  blend_output;
+    int32_t  device;                /* HIP device ordinal of this process */
+} lumen_mi_settings;
+
+/* LumenRenderer::MaterialData (LumenRenderer.h:64-112); textures are handles from lumen_mi_create_texture (0 = none) */
+typedef struct lumen_mi_material_data {
+    float diffuse_color[4];
+    float emission[3];
+    lumen_mi_handle diffuse_texture, normal_map, metallic_roughness_texture, emissive_texture;
+    lumen_mi_handle transmission_texture, clearcoat_texture, clearcoat_roughness_texture, tint_texture;
+    float transmission_factor, clearcoat_factor, clearcoat_roughness_factor, index_of_refraction;
+    float specular_factor, specular_tint_factor, subsurface_factor, luminance, anisotropic;
+    float sheen_factor, sheen_tint_factor, metallic_factor, roughness_factor;
+    float tint_factor[3];
+    float transmittance[3];
+} lumen_mi_material_data;
+
+/* LumenRenderer::PrimitiveData (LumenRenderer.h:44-61).  Either interleaved 48-byte vertices
+ * (pos3 uv2 normal3 tangent4, ModelStructs.h:21-28) or separate attribute arrays (any of uv/normal/tangent may be NULL). */
+typedef struct lumen_mi_primitive_data {
+    int32_t interleaved;
+    const void* vertex_binary;      /* interleaved: n_vertices * 48 bytes */
+    const float* positions;         /* 3 floats per vertex */
+    const float* tex_coords;        /* 2 */
+    const float* normals;           /* 3 */
+    const float* tangents;          /* 4 */
+    uint32_t n_vertices;
+    const void* index_binary;
+    uint32_t n_indices;
+    uint32_t index_size;            /* 2 or 4 bytes */
+    lumen_mi_handle material;
+} lumen_mi_primitive_data;
+
+/* Lumen::EmissionMode (MeshInstance.h:14-19) */
+enum { LUMEN_MI_EMISSION_ENABLED = 0, LUMEN_MI_EMISSION_DISABLED = 1, LUMEN_MI_EMISSION_OVERRIDE = 2 };
+
+/* ---- lifetime: `new WaveFrontRenderer` + WaveFrontRenderer::Init (WaveFrontRenderer.h:86, .cpp:70-322), dtor (.cpp:1360-1371) */
+int lumen_mi_create(lumen_mi_renderer** out);
+int lumen_mi_init(lumen_mi_renderer*, const lumen_mi_settings*);
+int lumen_mi_destroy(lumen_mi_renderer*);
+const char* lumen_mi_last_error(void);
+/* stream every kernel of this renderer is enqueued on (hipStream_t passed as void*; NULL = default stream) */
+int lumen_mi_set_stream(lumen_mi_renderer*, void* hip_stream);
+
+/* ---- resource factories */
+int lumen_mi_create_texture(lumen_mi_renderer*, const void* rgba8, uint32_t width, uint32_t height, int normalize, lumen_mi_handle* out);      /* CreateTexture  LumenRenderer.h:161 */
+int lumen_mi_create_material(lumen_mi_renderer*, const lumen_mi_material_data*, lumen_mi_handle* out);                                     /* CreateMaterial LumenRenderer.h:164 */
+int lumen_mi_create_default_resources(lumen_mi_renderer*, lumen_mi_handle* white, lumen_mi_handle* normal, lumen_mi_handle* diffuse);      /* CreateDefaultResources LumenRenderer.cpp:50-58 */
+int lumen_mi_create_primitive(lumen_mi_renderer*, const lumen_mi_primitive_data*, lumen_mi_handle* out, uint32_t* num_lights);               /* CreatePrimitive LumenRenderer.h:157; ILumenPrimitive::m_NumLights */
+int lumen_mi_create_mesh(lumen_mi_renderer*, const lumen_mi_handle* primitives, uint32_t n, lumen_mi_handle* out);                          /* CreateMesh     LumenRenderer.h:159 */
+int lumen_mi_create_scene(lumen_mi_renderer*, lumen_mi_handle* out);                                                                       /* CreateScene    LumenRenderer.h:166 */
+int lumen_mi_set_scene(lumen_mi_renderer*, lumen_mi_handle scene);                                                                         /* m_Scene        LumenRenderer.h:201 */
+
+/* ---- ILumenScene / MeshInstance (ILumenScene.h:48-67, MeshInstance.h:22-112) */
+int lumen_mi_scene_add_mesh(lumen_mi_renderer*, lumen_mi_handle scene, lumen_mi_handle mesh, lumen_mi_handle* instance_out);               /* AddMesh()->SetMesh() */
+int lumen_mi_scene_clear(lumen_mi_renderer*, lumen_mi_handle scene);                                                                       /* Clear() */
+int lumen_mi_instance_set_transform(lumen_mi_renderer*, lumen_mi_handle instance, const float world_matrix[16]);                           /* m_Transform */
+int lumen_mi_instance_set_emissiveness(lumen_mi_renderer*, lumen_mi_handle instance, int mode, const float override_radiance[3], float scale); /* SetEmissiveness */
+int lumen_mi_instance_set_override_material(lumen_mi_renderer*, lumen_mi_handle instance, lumen_mi_handle material);                       /* SetOverrideMaterial */
+
+/* ---- camera (Lumen/src/Lumen/Renderer/Camera.h:14-64): position + rotation matrix columns right/up/forward + vertical FOV */
+int lumen_mi_camera_set(lumen_mi_renderer*, const float position[3], const float right[3], const float up[3], const float forward[3], float fov_y_degrees);
+
+/* ---- settings (LumenRenderer.h:178-196) */
+int lumen_mi_set_render_resolution(lumen_mi_renderer*, uint32_t w, uint32_t h);     /* also forces the output resolution (WaveFrontRenderer.cpp:352) */
+int lumen_mi_set_output_resolution(lumen_mi_renderer*, uint32_t w, uint32_t h);
+int lumen_mi_get_render_resolution(lumen_mi_renderer*, uint32_t* w, uint32_t* h);
+int lumen_mi_get_output_resolution(lumen_mi_renderer*, uint32_t* w, uint32_t* h);
+int lumen_mi_set_blend_mode(lumen_mi_renderer*, int blend);                          /* resets the blend counter when enabling (WaveFrontRenderer.cpp:377-381) */
+int lumen_mi_get_blend_mode(lumen_mi_renderer*, int* blend);
+int lumen_mi_set_depth(lumen_mi_renderer*, uint32_t depth);                          /* WaveFrontSettings::depth */
+
+/* ---- rendering */
+int lumen_mi_trace_frame(lumen_mi_renderer*);           /* body of WaveFrontRenderer::TraceFrame (.cpp:435-1089); blocking */
+int lumen_mi_trace_frame_async(lumen_mi_renderer*);     /* enqueue only; lumen_mi_synchronize() or any readback completes it */
+int lumen_mi_synchronize(lumen_mi_renderer*);
+int lumen_mi_start_rendering(lumen_mi_renderer*);       /* StartRendering LumenRenderer.h:151: render thread looping TraceFrame (.cpp:1109-1117) */
+int lumen_mi_stop_rendering(lumen_mi_renderer*);
+int lumen_mi_perform_deferred_operations(lumen_mi_renderer*);   /* PerformDeferredOperations LumenRenderer.h:152 (nothing is deferred here) */
+
+/* ---- readback */
+int lumen_mi_get_output_pixels(lumen_mi_renderer*, uint8_t* rgba8, size_t capacity_bytes, uint32_t* w, uint32_t* h);   /* GetOutputTexturePixels LumenRenderer.h:176 */
+int lumen_mi_get_radiance(lumen_mi_renderer*, float* rgba32f, size_t capacity_bytes);     /* merged fp32 radiance of the render window (no reference equivalent; parity checks) */
+int lumen_mi_copy_radiance_device(lumen_mi_renderer*, void* device_rgba32f);              /* same, device-to-device on the renderer's stream (RCCL gather source) */
+int lumen_mi_get_channel(lumen_mi_renderer*, int channel, float* rgba32f, size_t capacity_bytes);   /* 0 DIRECT, 1 INDIRECT */
+int lumen_mi_get_gbuffer(lumen_mi_renderer*, float* planes8x4, size_t capacity_bytes);   /* depth-0 surface data of the last frame, pixel-major [n][8][4] */
+
+/* FrameStats (LumenRenderer.h:29-34, GetLastFrameStats :203): key/value pairs in microseconds under the reference's key names */
+int lumen_mi_get_frame_stat(lumen_mi_renderer*, const char* key, uint64_t* microseconds);
+/* counters of the last completed frame: [0] closest-hit rays, [1] NEE shadow rays, [2] ReSTIR shadow rays, [3] lights,
+ * [4..4+depth) rays per wave, [20] BVH nodes visited, [21] triangles tested (both only in the instrumented build) */
+int lumen_mi_get_counters(lumen_mi_renderer*, uint64_t* out, uint32_t n);
+/* device time of one kernel class over the last frame, measured with HIP events on the renderer's stream.
+ * which: 0 closest-hit traversal, 1 shadow traversal, 2 shade, 3 ReSTIR, 4 everything */
+int lumen_mi_get_kernel_time(lumen_mi_renderer*, int which, float* milliseconds, uint32_t* launches);
+int lumen_mi_enable_kernel_timing(lumen_mi_renderer*, int enable);
+int lumen_mi_set_instrumented(lumen_mi_renderer*, int enable);   /* use the node/triangle counting traversal kernels */
+
+/* ---- tile sharding (new functionality: the reference is single-GPU) */
+/* render only [x0,x1) x [y0,y1) of the image; RNG streams stay those of the full image */
+int lumen_mi_set_window(lumen_mi_renderer*, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1);
+
+/* ---- ray-query seam (OptixWrapper::TraceRays, LumenPT/src/Framework/OptixWrapper.h:58-81): host arrays in, host arrays out */
+int lumen_mi_query_closest(lumen_mi_renderer*, uint32_t n, const float* origins3, const float* directions3, float tmin, float tmax,
+                           uint32_t* instance_prim2, float* uvt3);
+int lumen_mi_query_any(lumen_mi_renderer*, uint32_t n, const float* origins3, const float* directions3, float tmin, const float* tmax, uint8_t* occluded);
+
+/* ---- known-answer hooks: run the device BSDF / math on host arrays */
+int lumen_mi_test_bsdf(lumen_mi_renderer*, uint32_t n, int mode, const float* mat23, const float* N, const float* T, const float* wo, const float* aux3, float* out8);
+int lumen_mi_test_math(lumen_mi_renderer*, uint32_t n, int fn, const float* x, const float* y, float* out);
+/* host-side scene products, for tests: world-space triangles (9 floats each) and the sorted light list (16 floats each) + CDF */
+int lumen_mi_get_world_triangles(lumen_mi_renderer*, float* out, uint32_t capacity_triangles, uint32_t* count);
+int lumen_mi_get_lights(lumen_mi_renderer*, float* lights16, float* cdf, uint32_t capacity, uint32_t* count);
+int lumen_mi_get_bvh_info(lumen_mi_renderer*, uint32_t* nodes, uint32_t* triangles, uint32_t* max_depth);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,99 @@
+"""ctypes binding of include/lumen_mi.h (the drop-in C ABI).  No torch types cross this boundary."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+OK, ERR_INVALID, ERR_DEVICE, ERR_STATE, NO_LIGHTS = 0, 1, 2, 3, 4
+
+
+class LumenMIError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"lumen_mi error {code}: {msg}")
+        self.code = code
+
+
+class Settings(C.Structure):
+    _fields_ = [("depth", C.c_uint32), ("render_width", C.c_uint32), ("render_height", C.c_uint32),
+                ("output_width", C.c_uint32), ("output_height", C.c_uint32), ("blend_output", C.c_int32), ("device", C.c_int32)]
+
+
+class MaterialData(C.Structure):
+    _fields_ = [("diffuse_color", C.c_float * 4), ("emission", C.c_float * 3),
+                ("diffuse_texture", C.c_uint64), ("normal_map", C.c_uint64), ("metallic_roughness_texture", C.c_uint64), ("emissive_texture", C.c_uint64),
+                ("transmission_texture", C.c_uint64), ("clearcoat_texture", C.c_uint64), ("clearcoat_roughness_texture", C.c_uint64), ("tint_texture", C.c_uint64),
+                ("transmission_factor", C.c_float), ("clearcoat_factor", C.c_float), ("clearcoat_roughness_factor", C.c_float), ("index_of_refraction", C.c_float),
+                ("specular_factor", C.c_float), ("specular_tint_factor", C.c_float), ("subsurface_factor", C.c_float), ("luminance", C.c_float), ("anisotropic", C.c_float),
+                ("sheen_factor", C.c_float), ("sheen_tint_factor", C.c_float), ("metallic_factor", C.c_float), ("roughness_factor", C.c_float),
+                ("tint_factor", C.c_float * 3), ("transmittance", C.c_float * 3)]
+
+
+class PrimitiveData(C.Structure):
+    _fields_ = [("interleaved", C.c_int32), ("vertex_binary", C.c_void_p), ("positions", C.POINTER(C.c_float)), ("tex_coords", C.POINTER(C.c_float)),
+                ("normals", C.POINTER(C.c_float)), ("tangents", C.POINTER(C.c_float)), ("n_vertices", C.c_uint32), ("index_binary", C.c_void_p),
+                ("n_indices", C.c_uint32), ("index_size", C.c_uint32), ("material", C.c_uint64)]
+
+
+def library_path():
+    return os.path.join(_HERE, "liblumen_mi.so")
+
+
+# every symbol include/lumen_mi.h declares: (name, argtypes); all return int except last_error
+_FP, _U8P, _U32P, _U64P = C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+_R, _H = C.c_void_p, C.c_uint64
+SYMBOLS = {
+    "lumen_mi_create": [C.POINTER(C.c_void_p)], "lumen_mi_init": [_R, C.POINTER(Settings)], "lumen_mi_destroy": [_R],
+    "lumen_mi_set_stream": [_R, C.c_void_p],
+    "lumen_mi_create_texture": [_R, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, _U64P],
+    "lumen_mi_create_material": [_R, C.POINTER(MaterialData), _U64P],
+    "lumen_mi_create_default_resources": [_R, _U64P, _U64P, _U64P],
+    "lumen_mi_create_primitive": [_R, C.POINTER(PrimitiveData), _U64P, _U32P],
+    "lumen_mi_create_mesh": [_R, _U64P, C.c_uint32, _U64P], "lumen_mi_create_scene": [_R, _U64P], "lumen_mi_set_scene": [_R, _H],
+    "lumen_mi_scene_add_mesh": [_R, _H, _H, _U64P], "lumen_mi_scene_clear": [_R, _H],
+    "lumen_mi_instance_set_transform": [_R, _H, _FP], "lumen_mi_instance_set_emissiveness": [_R, _H, C.c_int, _FP, C.c_float],
+    "lumen_mi_instance_set_override_material": [_R, _H, _H],
+    "lumen_mi_camera_set": [_R, _FP, _FP, _FP, _FP, C.c_float],
+    "lumen_mi_set_render_resolution": [_R, C.c_uint32, C.c_uint32], "lumen_mi_set_output_resolution": [_R, C.c_uint32, C.c_uint32],
+    "lumen_mi_get_render_resolution": [_R, _U32P, _U32P], "lumen_mi_get_output_resolution": [_R, _U32P, _U32P],
+    "lumen_mi_set_blend_mode": [_R, C.c_int], "lumen_mi_get_blend_mode": [_R, C.POINTER(C.c_int)], "lumen_mi_set_depth": [_R, C.c_uint32],
+    "lumen_mi_trace_frame": [_R], "lumen_mi_trace_frame_async": [_R], "lumen_mi_synchronize": [_R],
+    "lumen_mi_start_rendering": [_R], "lumen_mi_stop_rendering": [_R], "lumen_mi_perform_deferred_operations": [_R],
+    "lumen_mi_get_output_pixels": [_R, _U8P, C.c_size_t, _U32P, _U32P], "lumen_mi_get_radiance": [_R, _FP, C.c_size_t],
+    "lumen_mi_copy_radiance_device": [_R, C.c_void_p], "lumen_mi_get_channel": [_R, C.c_int, _FP, C.c_size_t],
+    "lumen_mi_get_gbuffer": [_R, _FP, C.c_size_t],
+    "lumen_mi_get_frame_stat": [_R, C.c_char_p, _U64P], "lumen_mi_get_counters": [_R, _U64P, C.c_uint32],
+    "lumen_mi_get_kernel_time": [_R, C.c_int, _FP, _U32P], "lumen_mi_enable_kernel_timing": [_R, C.c_int], "lumen_mi_set_instrumented": [_R, C.c_int],
+    "lumen_mi_set_window": [_R, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32],
+    "lumen_mi_query_closest": [_R, C.c_uint32, _FP, _FP, C.c_float, C.c_float, _U32P, _FP],
+    "lumen_mi_query_any": [_R, C.c_uint32, _FP, _FP, C.c_float, _FP, _U8P],
+    "lumen_mi_test_bsdf": [_R, C.c_uint32, C.c_int, _FP, _FP, _FP, _FP, _FP, _FP], "lumen_mi_test_math": [_R, C.c_uint32, C.c_int, _FP, _FP, _FP],
+    "lumen_mi_get_world_triangles": [_R, _FP, C.c_uint32, _U32P], "lumen_mi_get_lights": [_R, _FP, _FP, C.c_uint32, _U32P],
+    "lumen_mi_get_bvh_info": [_R, _U32P, _U32P, _U32P],
+}
+
+
+def load_library():
+    """Load liblumen_mi.so.  Fails loudly when it has not been built: there is no fallback path."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise LumenMIError(ERR_STATE, f"{path} is missing - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                                      "(make -C lumenrenderer_amd/csrc); the HIP library is the only implementation")
+    lib = C.CDLL(path)
+    for name, args in SYMBOLS.items():
+        f = getattr(lib, name)
+        f.argtypes = args
+        f.restype = C.c_int
+    lib.lumen_mi_last_error.argtypes = []
+    lib.lumen_mi_last_error.restype = C.c_char_p
+    _LIB = lib
+    return lib
+
+
+def check(lib, rc, allow=()):
+    if rc != OK and rc not in allow:
+        raise LumenMIError(rc, (lib.lumen_mi_last_error() or b"").decode("utf-8", "replace"))
+    return rc

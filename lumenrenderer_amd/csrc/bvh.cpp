@@ -1,0 +1,191 @@
+// bvh.cpp — host-side BVH2 builder (binned SAH) and Woop triangle packets.
+//
+// Replaces the reference's two opaque calls OptixWrapper::BuildGeometryAccelerationStructure /
+// BuildInstanceAccelerationStructure (LumenPT/src/Framework/OptixWrapper.cpp:46-131): instance transforms are
+// baked, the whole scene becomes ONE BVH2 over world-space triangles (the reference rebuilds its instance AS on
+// every transform change anyway, PTScene.cpp:145-153).  Node boxes are padded by 2^-15 * (largest |coordinate|)
+// so that box tests are conservative with respect to the fp32 Woop triangle test (DESIGN.md "Traversal").
+#include "bvh.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() { for (int k = 0; k < 3; k++) { lo[k] = INFINITY; hi[k] = -INFINITY; } }
+    void grow(const float* p) { for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); } }
+    void grow(const Box& b) { for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], b.lo[k]); hi[k] = std::max(hi[k], b.hi[k]); } }
+    float area() const { const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2]; return (dx < 0 || dy < 0 || dz < 0) ? 0.f : 2.f * (dx * dy + dy * dz + dz * dx); }
+};
+
+struct Builder {
+    const float* tris;                 // 9 floats per triangle
+    std::vector<Box> tbox;
+    std::vector<float> cen;            // 3 per triangle
+    std::vector<uint32_t> ids;
+    LmBvh* out;
+    float pad;
+    uint32_t maxDepth = 0;
+
+    struct Ref { int ref; Box box; };
+
+    static int ilog2ceil(uint32_t v) { int r = 0; while ((1u << r) < v) r++; return r; }
+
+    Ref makeLeaf(uint32_t first, uint32_t count, const Box& box)
+    {
+        const uint32_t start = (uint32_t)out->order.size();
+        for (uint32_t i = 0; i < count; i++) out->order.push_back(ids[first + i]);
+        Ref r; r.ref = ~(int)((start << 3) | (count - 1u)); r.box = box;
+        return r;
+    }
+
+    Ref build(uint32_t first, uint32_t count, uint32_t depth)
+    {
+        maxDepth = std::max(maxDepth, depth);
+        Box box; box.reset();
+        Box cbox; cbox.reset();
+        for (uint32_t i = first; i < first + count; i++) { box.grow(tbox[ids[i]]); cbox.grow(&cen[3 * ids[i]]); }
+        if (count <= 2) return makeLeaf(first, count, box);
+        // depth guard: from here a median split is guaranteed to finish within the traversal stack
+        const bool forceMedian = (int)depth + ilog2ceil(count) + 2 >= LM_STACK_DEPTH - 2;
+        uint32_t mid = 0;
+        bool split = false;
+        if (!forceMedian) {
+            const int NB = 16;
+            float bestCost = INFINITY; int bestAxis = -1, bestBin = -1;
+            for (int axis = 0; axis < 3; axis++) {
+                const float lo = cbox.lo[axis], ext = cbox.hi[axis] - lo;
+                if (!(ext > 0.f)) continue;
+                Box bb[NB]; uint32_t bc[NB];
+                for (int b = 0; b < NB; b++) { bb[b].reset(); bc[b] = 0; }
+                const float scale = (float)NB / ext;
+                for (uint32_t i = first; i < first + count; i++) {
+                    int b = (int)((cen[3 * ids[i] + axis] - lo) * scale);
+                    b = std::min(NB - 1, std::max(0, b));
+                    bb[b].grow(tbox[ids[i]]); bc[b]++;
+                }
+                float rightArea[NB]; uint32_t rightCount[NB];
+                Box acc; acc.reset(); uint32_t cnt = 0;
+                for (int b = NB - 1; b > 0; b--) { acc.grow(bb[b]); cnt += bc[b]; rightArea[b] = acc.area(); rightCount[b] = cnt; }
+                acc.reset(); cnt = 0;
+                for (int b = 0; b < NB - 1; b++) {
+                    acc.grow(bb[b]); cnt += bc[b];
+                    if (cnt == 0 || rightCount[b + 1] == 0) continue;
+                    const float cost = acc.area() * (float)cnt + rightArea[b + 1] * (float)rightCount[b + 1];
+                    if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestBin = b; }
+                }
+            }
+            const float leafCost = box.area() * (float)count;
+            if (bestAxis >= 0 && (count > 4 || bestCost + box.area() * 1.0f < leafCost)) {
+                const float lo = cbox.lo[bestAxis], ext = cbox.hi[bestAxis] - lo;
+                const float scale = 16.f / ext;
+                auto it = std::partition(ids.begin() + first, ids.begin() + first + count, [&](uint32_t t) {
+                    int b = (int)((cen[3 * t + bestAxis] - lo) * scale);
+                    b = std::min(15, std::max(0, b));
+                    return b <= bestBin;
+                });
+                mid = (uint32_t)(it - ids.begin());
+                split = mid > first && mid < first + count;
+            } else if (count <= 4) {
+                return makeLeaf(first, count, box);
+            }
+        }
+        if (!split) {
+            if (count <= LM_MAX_LEAF && !forceMedian) return makeLeaf(first, count, box);
+            if (count <= 4) return makeLeaf(first, count, box);
+            int axis = 0;
+            for (int k = 1; k < 3; k++) if (cbox.hi[k] - cbox.lo[k] > cbox.hi[axis] - cbox.lo[axis]) axis = k;
+            mid = first + count / 2;
+            std::nth_element(ids.begin() + first, ids.begin() + mid, ids.begin() + first + count, [&](uint32_t a, uint32_t b) {
+                const float ka = cen[3 * a + axis], kb = cen[3 * b + axis];
+                return ka < kb || (ka == kb && a < b);
+            });
+        }
+        const int self = (int)out->nodes.size();
+        out->nodes.emplace_back();
+        const Ref l = build(first, mid - first, depth + 1);
+        const Ref r = build(mid, first + count - mid, depth + 1);
+        setNode(self, l, r);
+        Ref me; me.ref = self; me.box = box;
+        return me;
+    }
+
+    void setNode(int idx, const Ref& l, const Ref& r)
+    {
+        LmNode& n = out->nodes[idx];
+        auto P = [&](float v, float s) { return v + s * pad; };
+        n.n0 = make_float4(P(l.box.lo[0], -1), P(l.box.hi[0], 1), P(l.box.lo[1], -1), P(l.box.hi[1], 1));
+        n.n1 = make_float4(P(r.box.lo[0], -1), P(r.box.hi[0], 1), P(r.box.lo[1], -1), P(r.box.hi[1], 1));
+        n.n2 = make_float4(P(l.box.lo[2], -1), P(l.box.hi[2], 1), P(r.box.lo[2], -1), P(r.box.hi[2], 1));
+        n.ref = make_int4(l.ref, r.ref, 0, 0);
+    }
+};
+
+}  // namespace
+
+LmWoop lm_make_woop(const float* t)
+{
+    const double v0[3] = {t[0], t[1], t[2]};
+    const double e1[3] = {(double)t[3] - t[0], (double)t[4] - t[1], (double)t[5] - t[2]};
+    const double e2[3] = {(double)t[6] - t[0], (double)t[7] - t[1], (double)t[8] - t[2]};
+    const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    const double det = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+    LmWoop w;
+    memset(&w, 0, sizeof w);
+    if (!(det > 0.0) || !std::isfinite(det)) return w;         // degenerate triangle: the zero packet never reports a hit
+    const double ru[3] = {e2[1] * n[2] - e2[2] * n[1], e2[2] * n[0] - e2[0] * n[2], e2[0] * n[1] - e2[1] * n[0]};
+    const double rv[3] = {n[1] * e1[2] - n[2] * e1[1], n[2] * e1[0] - n[0] * e1[2], n[0] * e1[1] - n[1] * e1[0]};
+    float r0[4], r1[4], r2[4];
+    double du = 0, dv = 0, dw = 0;
+    for (int i = 0; i < 3; i++) {
+        r0[i] = (float)(ru[i] / det); r1[i] = (float)(rv[i] / det); r2[i] = (float)(n[i] / det);
+        du -= ru[i] / det * v0[i]; dv -= rv[i] / det * v0[i]; dw -= n[i] / det * v0[i];
+    }
+    r0[3] = (float)du; r1[3] = (float)dv; r2[3] = (float)dw;
+    w.r0 = make_float4(r0[0], r0[1], r0[2], r0[3]);
+    w.r1 = make_float4(r1[0], r1[1], r1[2], r1[3]);
+    w.r2 = make_float4(r2[0], r2[1], r2[2], r2[3]);
+    return w;
+}
+
+void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out)
+{
+    out->nodes.clear(); out->order.clear(); out->woop.clear();
+    Builder b;
+    b.tris = tris; b.out = out;
+    b.tbox.resize(nTris); b.cen.resize(3 * (size_t)nTris); b.ids.resize(nTris);
+    float maxAbs = 0.f;
+    for (uint32_t t = 0; t < nTris; t++) {
+        b.tbox[t].reset();
+        for (int v = 0; v < 3; v++) {
+            const float* p = tris + 9 * (size_t)t + 3 * v;
+            b.tbox[t].grow(p);
+            for (int k = 0; k < 3; k++) maxAbs = std::max(maxAbs, std::fabs(p[k]));
+        }
+        for (int k = 0; k < 3; k++) b.cen[3 * (size_t)t + k] = 0.5f * (b.tbox[t].lo[k] + b.tbox[t].hi[k]);
+        b.ids[t] = t;
+    }
+    b.pad = maxAbs * (1.0f / 32768.0f);
+    out->pad = b.pad;
+    // absent child: a point box far outside any ray interval (min/max slab tests would enter an inverted box)
+    Builder::Ref empty; empty.ref = ~0;
+    for (int k = 0; k < 3; k++) { empty.box.lo[k] = 3.0e38f; empty.box.hi[k] = 3.0e38f; }
+    if (nTris == 0) {
+        out->nodes.emplace_back();
+        b.setNode(0, empty, empty);
+    } else {
+        out->nodes.reserve(nTris);
+        out->order.reserve(nTris);
+        Builder::Ref root = b.build(0, nTris, 0);
+        if (root.ref < 0) {                                    // whole scene fits one leaf: node 0 must still be an inner node
+            out->nodes.emplace_back();
+            b.setNode(0, root, empty);
+        }
+    }
+    out->maxDepth = b.maxDepth + 1;
+    out->woop.resize(out->order.size());
+    for (size_t s = 0; s < out->order.size(); s++) out->woop[s] = lm_make_woop(tris + 9 * (size_t)out->order[s]);
+}

@@ -1,0 +1,1007 @@
+// kernels.hip — hand-written HIP kernels (gfx950) of the wavefront path tracer.
+//
+// One frame = primary-ray generation, then per wave: closest-hit BVH2 traversal, surface extraction + shading
+// (ReSTIR DI at depth 0, CDF next-event estimation afterwards), Russian-roulette continuation with wavefront
+// ballot/prefix-sum compaction, any-hit shadow rays, and finally channel merge + output.  Behaviour follows the
+// reference kernels cited at each function (paths relative to /root/reference/Lumen_Engine/LumenPT/src);
+// structure does not: queues are SoA float4 streams, depth>=1 extraction+NEE+continuation are one fused
+// kernel, shadow rays are resolved per wave (one fp32 add per pixel per wave), launches are fixed-size
+// grid-stride over device-side counters so a frame needs no host round trip.
+#include "lm_layout.h"
+#include "lm_bsdf.h"
+
+#define LM_BLOCK 256
+#ifndef LM_INSTRUMENT
+#define LM_INSTRUMENT 0
+#endif
+// the file is compiled twice into one library: kernel symbols of the counting build get a suffix
+#if LM_INSTRUMENT
+#define KN(x) x##_inst
+#else
+#define KN(x) x
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lm_lane() { return __lane_id(); }
+
+// wavefront-aggregated append: one atomic per 64-lane wave (ballot + prefix popcount)
+__device__ __forceinline__ uint32_t lm_append_slot(uint32_t* counter, bool pred)
+{
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return 0u;
+    const uint32_t lane = lm_lane();
+    const uint32_t prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    return base + prefix;
+}
+__device__ __forceinline__ void lm_count(uint32_t* counter, bool pred)
+{
+    const unsigned long long mask = __ballot(pred);
+    if (mask != 0ull && (int)lm_lane() == __ffsll((long long)mask) - 1) atomicAdd(counter, (uint32_t)__popcll(mask));
+}
+
+__device__ __forceinline__ float4 lm_mul_m34(const float* m, const lf3& v, float w)   // rows 0..2 of sutil Matrix4x4 * float4
+{
+    float4 r;
+    r.x = m[0] * v.x + m[1] * v.y + m[2] * v.z + m[3] * w;
+    r.y = m[4] * v.x + m[5] * v.y + m[6] * v.z + m[7] * w;
+    r.z = m[8] * v.x + m[9] * v.y + m[10] * v.z + m[11] * w;
+    r.w = 0.f;
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// BVH2 traversal with Woop unit-triangle test.  Per-lane stack lives in LDS, interleaved by lane (bank-conflict free).
+// Closest hit: minimum t in (tmin, tmax); equal t -> lower global triangle index (order independent).
+// ---------------------------------------------------------------------------------------------------------------------
+struct LmHit { float t, u, v; uint32_t slot; };
+
+__device__ __forceinline__ bool lm_woop(const LmWoop* __restrict__ woop, uint32_t slot, const lf3& o, const lf3& d,
+                                        float tmin, float tmax, float& t, float& u, float& v)
+{
+    const float4 r2 = woop[slot].r2;
+    const float Oz = fmaf(r2.x, o.x, fmaf(r2.y, o.y, fmaf(r2.z, o.z, r2.w)));
+    const float Dz = fmaf(r2.x, d.x, fmaf(r2.y, d.y, r2.z * d.z));
+    t = -Oz / Dz;
+    if (!(t > tmin && t < tmax)) return false;
+    const float4 r0 = woop[slot].r0;
+    const float Ox = fmaf(r0.x, o.x, fmaf(r0.y, o.y, fmaf(r0.z, o.z, r0.w)));
+    const float Dx = fmaf(r0.x, d.x, fmaf(r0.y, d.y, r0.z * d.z));
+    u = fmaf(t, Dx, Ox);
+    if (!(u >= 0.0f)) return false;
+    const float4 r1 = woop[slot].r1;
+    const float Oy = fmaf(r1.x, o.x, fmaf(r1.y, o.y, fmaf(r1.z, o.z, r1.w)));
+    const float Dy = fmaf(r1.x, d.x, fmaf(r1.y, d.y, r1.z * d.z));
+    v = fmaf(t, Dy, Oy);
+    if (!(v >= 0.0f)) return false;
+    return u + v <= 1.0f;
+}
+
+__device__ __forceinline__ float lm_safe_rcp(float d)
+{
+    const float ooeps = 1e-20f;
+    return 1.0f / (fabsf(d) > ooeps ? d : copysignf(ooeps, d));
+}
+
+template <bool ANY>
+__device__ __forceinline__ bool lm_traverse(const LmScene& sc, const lf3& o, const lf3& d, float tmin, float tmax,
+                                            int* __restrict__ stack /* LDS, stride LM_BLOCK */, LmHit& hit, uint32_t* cnt)
+{
+    const float idx = lm_safe_rcp(d.x), idy = lm_safe_rcp(d.y), idz = lm_safe_rcp(d.z);
+    const float oox = o.x * idx, ooy = o.y * idy, ooz = o.z * idz;
+    float hitT = tmax;
+    uint32_t hitOrder = 0xffffffffu;
+    bool found = false;
+    int sp = 0;
+    int cur = 0;
+#if LM_INSTRUMENT
+    uint32_t nNodes = 0, nTris = 0;
+#endif
+    for (;;) {
+        while (cur >= 0) {
+            const LmNode* nd = sc.nodes + cur;
+            const float4 n0 = nd->n0, n1 = nd->n1, n2 = nd->n2;
+            const int4 ref = nd->ref;
+#if LM_INSTRUMENT
+            nNodes++;
+#endif
+            const float c0lox = fmaf(n0.x, idx, -oox), c0hix = fmaf(n0.y, idx, -oox);
+            const float c0loy = fmaf(n0.z, idy, -ooy), c0hiy = fmaf(n0.w, idy, -ooy);
+            const float c0loz = fmaf(n2.x, idz, -ooz), c0hiz = fmaf(n2.y, idz, -ooz);
+            const float c1lox = fmaf(n1.x, idx, -oox), c1hix = fmaf(n1.y, idx, -oox);
+            const float c1loy = fmaf(n1.z, idy, -ooy), c1hiy = fmaf(n1.w, idy, -ooy);
+            const float c1loz = fmaf(n2.z, idz, -ooz), c1hiz = fmaf(n2.w, idz, -ooz);
+            const float tn0 = fmaxf(fmaxf(fminf(c0lox, c0hix), fminf(c0loy, c0hiy)), fmaxf(fminf(c0loz, c0hiz), tmin));
+            const float tf0 = fminf(fminf(fmaxf(c0lox, c0hix), fmaxf(c0loy, c0hiy)), fminf(fmaxf(c0loz, c0hiz), hitT));
+            const float tn1 = fmaxf(fmaxf(fminf(c1lox, c1hix), fminf(c1loy, c1hiy)), fmaxf(fminf(c1loz, c1hiz), tmin));
+            const float tf1 = fminf(fminf(fmaxf(c1lox, c1hix), fmaxf(c1loy, c1hiy)), fminf(fmaxf(c1loz, c1hiz), hitT));
+            const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+            if (!h0 && !h1) {
+                if (sp == 0) { cur = 0x7fffffff; break; }
+                cur = stack[(--sp) * LM_BLOCK];
+            } else {
+                int first = h0 ? ref.x : ref.y;
+                if (h0 && h1) {
+                    int second = ref.y;
+                    if (tn1 < tn0) { second = first; first = ref.y; }
+                    stack[(sp++) * LM_BLOCK] = second;
+                }
+                cur = first;
+            }
+        }
+        if (cur == 0x7fffffff) break;
+        // leaf
+        const uint32_t leaf = (uint32_t)(~cur);
+        const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
+        for (uint32_t k = 0; k < count; k++) {
+            float t, u, v;
+#if LM_INSTRUMENT
+            nTris++;
+#endif
+            if (lm_woop(sc.woop, first + k, o, d, tmin, tmax, t, u, v)) {
+                if (ANY) { found = true; break; }
+                const uint32_t order = sc.triOrder[first + k];
+                if (t < hitT || (t == hitT && found && order < hitOrder)) {
+                    hitT = t; hitOrder = order; found = true;
+                    hit.t = t; hit.u = u; hit.v = v; hit.slot = first + k;
+                }
+            }
+        }
+        if (ANY && found) break;
+        if (sp == 0) break;
+        cur = stack[(--sp) * LM_BLOCK];
+    }
+#if LM_INSTRUMENT
+    atomicAdd((unsigned long long*)(cnt + LM_CNT_NODES), (unsigned long long)nNodes);
+    atomicAdd((unsigned long long*)(cnt + LM_CNT_TRIS), (unsigned long long)nTris);
+#endif
+    return found;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K1: primary rays — reference GPUGeneratePrimRay.cu:28-82 (Halton(2,3) jitter indexed by frameCount + pixel index)
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_primary)(LmFrame fr, LmCamera cam, uint32_t frameCount)
+{
+    const uint32_t stride = gridDim.x * LM_BLOCK;
+    for (uint32_t li = blockIdx.x * LM_BLOCK + threadIdx.x; li < fr.n; li += stride) {
+        const uint32_t ly = li / fr.ww, lx = li - ly * fr.ww;
+        const uint32_t sx = fr.x0 + lx, sy = fr.y0 + ly;
+        const uint32_t gi = sy * fr.W + sx;
+        const float jx = lm_halton(frameCount + gi, 2u), jy = lm_halton(frameCount + gi, 3u);
+        float dx = ((float)(int)sx + jx) / (float)fr.W;
+        float dy = ((float)(int)sy + jy) / (float)fr.H;
+        dx = -(dx * 2.0f - 1.0f);
+        dy = -(dy * 2.0f - 1.0f);
+        const lf3 U = v3(cam.U[0], cam.U[1], cam.U[2]), V = v3(cam.V[0], cam.V[1], cam.V[2]), Wv = v3(cam.Wv[0], cam.Wv[1], cam.Wv[2]);
+        const lf3 dir = normalize3(dx * U + dy * V + Wv);
+        fr.rayO[0][li] = make_float4(cam.eye[0], cam.eye[1], cam.eye[2], 0.f);
+        fr.rayD[0][li] = make_float4(dir.x, dir.y, dir.z, u2f(li));
+        fr.rayC[0][li] = make_float4(1.f, 1.f, 1.f, 0.f);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) fr.counters[LM_CNT_RAYS(0)] = fr.n;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K2-K4: closest-hit query — reference WaveFrontShaders.cu:42-76,301-340 (tmin 0.01, tmax 5000, miss => t = -1)
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_trace_closest)(LmScene sc, const float4* __restrict__ rayO, const float4* __restrict__ rayD, const uint32_t* __restrict__ countPtr,
+                   uint4* __restrict__ hits, float tmin, float tmax, uint32_t* counters)
+{
+    __shared__ int s_stack[LM_STACK_DEPTH * LM_BLOCK];
+    int* stack = s_stack + threadIdx.x;
+    const uint32_t n = *countPtr;
+    const uint32_t stride = gridDim.x * LM_BLOCK;
+    for (uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x; i < n; i += stride) {
+        const float4 o4 = rayO[i], d4 = rayD[i];
+        LmHit h; h.t = -1.f; h.u = 0.f; h.v = 0.f; h.slot = 0;
+        const bool found = lm_traverse<false>(sc, v3(o4), v3(d4), tmin, tmax, stack, h, counters);
+        uint4 out = make_uint4(0u, 0u, 0u, f2u(-1.f));
+        if (found) {
+            const uint2 id = sc.triId[h.slot];
+            out.x = id.x; out.y = id.y;
+            out.z = lm_f32_to_f16(h.u) | (lm_f32_to_f16(h.v) << 16);      // half2 barycentrics (IntersectionData.h:90)
+            out.w = f2u(h.t);
+        }
+        hits[i] = out;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// texture fetch: RGBA8, bilinear, wrap, normalised coordinates, optional sRGB decode (reference PTTexture.cpp:35-74)
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 lm_texel(const LmScene& sc, const LmTexDesc& t, int x, int y)
+{
+    const uint32_t p = sc.texels[t.offset + (uint32_t)y * t.w + (uint32_t)x];
+    const uint32_t r = p & 255u, g = (p >> 8) & 255u, b = (p >> 16) & 255u, a = p >> 24;
+    if (t.srgb) return make_float4(sc.srgbLut[r], sc.srgbLut[g], sc.srgbLut[b], (float)a / 255.0f);
+    return make_float4((float)r / 255.0f, (float)g / 255.0f, (float)b / 255.0f, (float)a / 255.0f);
+}
+__device__ __forceinline__ int lm_wrapi(int i, int n) { const int m = i % n; return m < 0 ? m + n : m; }
+__device__ float4 lm_tex2D(const LmScene& sc, int id, float u, float v)
+{
+    if (id < 0) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const LmTexDesc t = sc.texDesc[id];
+    if (t.w == 1u && t.h == 1u) return lm_texel(sc, t, 0, 0);           // lerp(a, a, w) == a exactly
+    const float x = u * (float)t.w - 0.5f, y = v * (float)t.h - 0.5f;
+    const float fx0 = floorf(x), fy0 = floorf(y);
+    const float ax = x - fx0, ay = y - fy0;
+    const int x0 = lm_wrapi((int)fx0, (int)t.w), y0 = lm_wrapi((int)fy0, (int)t.h);
+    const int x1 = lm_wrapi(x0 + 1, (int)t.w), y1 = lm_wrapi(y0 + 1, (int)t.h);
+    const float4 t00 = lm_texel(sc, t, x0, y0), t10 = lm_texel(sc, t, x1, y0), t01 = lm_texel(sc, t, x0, y1), t11 = lm_texel(sc, t, x1, y1);
+    float4 r;
+    r.x = lerpf(lerpf(t00.x, t10.x, ax), lerpf(t01.x, t11.x, ax), ay);
+    r.y = lerpf(lerpf(t00.y, t10.y, ax), lerpf(t01.y, t11.y, ax), ay);
+    r.z = lerpf(lerpf(t00.z, t10.z, ax), lerpf(t01.z, t11.z, ax), ay);
+    r.w = lerpf(lerpf(t00.w, t10.w, ax), lerpf(t01.w, t11.w, ax), ay);
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// surface extraction — reference GPUExtractSurfaceData.cu:8-228
+// ---------------------------------------------------------------------------------------------------------------------
+struct LmSurface {
+    lf3 position, normal, tangent, incoming, transport;
+    float t;
+    uint32_t flags;
+    LmMaterial mat;
+};
+struct LmVertex { lf3 pos; lf2 uv; lf3 normal; float4 tangent; };
+__device__ __forceinline__ LmVertex lm_load_vertex(const float4* __restrict__ verts, uint32_t v)
+{
+    const float4 a = verts[3u * v], b = verts[3u * v + 1u], c = verts[3u * v + 2u];
+    LmVertex r;
+    r.pos = v3(a.x, a.y, a.z); r.uv.x = a.w; r.uv.y = b.x; r.normal = v3(b.y, b.z, b.w); r.tangent = c;
+    return r;
+}
+
+__device__ void lm_extract(const LmScene& sc, const uint4 hit, const lf3& ro, const lf3& rd, const lf3& rc, LmSurface& s)
+{
+    s.position = v3(0.f); s.normal = v3(0.f); s.tangent = v3(0.f); s.incoming = v3(0.f); s.transport = v3(0.f);
+    s.t = 0.f; s.flags = 0u;
+    s.mat.color = make_float4(0.f, 0.f, 0.f, 0.f); s.mat.transmittance = s.mat.color; s.mat.tint = s.mat.color;
+    s.mat.p0 = s.mat.p1 = s.mat.p2 = 0u;
+    const float t = u2f(hit.w);
+    if (!(t > 0.f)) { s.flags = LM_SF_NON_INTERSECT; return; }
+    const LmEntry e = sc.entries[hit.x];
+    const LmDevMaterial* mat = sc.materials + e.material;
+    const uint32_t i0 = sc.indices[e.idxBase + 3u * hit.y], i1 = sc.indices[e.idxBase + 3u * hit.y + 1u], i2 = sc.indices[e.idxBase + 3u * hit.y + 2u];
+    const LmVertex A = lm_load_vertex(sc.verts, e.vertBase + i0), B = lm_load_vertex(sc.verts, e.vertBase + i1), C = lm_load_vertex(sc.verts, e.vertBase + i2);
+    const float U = lm_f16_to_f32(hit.z & 0xffffu), V = lm_f16_to_f32(hit.z >> 16), Wt = 1.f - (U + V);
+    const float uvx = A.uv.x * Wt + B.uv.x * U + C.uv.x * V;
+    const float uvy = A.uv.y * Wt + B.uv.y * U + C.uv.y * V;
+    const float flip = A.tangent.w;
+    const float4 normalMap = lm_tex2D(sc, mat->tex[6], uvx, uvy);
+    const float4 texColor = lm_tex2D(sc, mat->tex[3], uvx, uvy);
+    float4 emissive = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e.mode == 0u) { emissive = mat->emissive * e.emissive.w; emissive = emissive * lm_tex2D(sc, mat->tex[4], uvx, uvy); }
+    else if (e.mode == 2u) emissive = e.emissive * e.emissive.w;
+
+    const lf3 localNormal = normalize3(A.normal * Wt + B.normal * U + C.normal * V);
+    const lf3 localTangent = normalize3(v3(A.tangent) * Wt + v3(B.tangent) * U + v3(C.tangent) * V);
+    const lf3 normalWorld = normalize3(v3(lm_mul_m34(e.m, localNormal, 0.f)));
+    const lf3 tangentWorld = normalize3(v3(lm_mul_m34(e.m, localTangent, 0.f)));
+    const lf3 bitangentWorld = cross3(normalWorld, tangentWorld) * flip;
+    lf3 nm = v3(normalMap.x, normalMap.y, normalMap.z);
+    nm = nm * 2.f - 1.f;
+    nm = normalize3(nm);
+    nm = normalize3(v3(nm.x * tangentWorld.x + nm.y * bitangentWorld.x + nm.z * normalWorld.x,
+                       nm.x * tangentWorld.y + nm.y * bitangentWorld.y + nm.z * normalWorld.y,
+                       nm.x * tangentWorld.z + nm.y * bitangentWorld.z + nm.z * normalWorld.z));
+    s.t = t;
+    s.normal = nm;
+    if (emissive.x > 0.f || emissive.y > 0.f || emissive.z > 0.f) {
+        const float maximum = fmaxf(emissive.x, fmaxf(emissive.y, emissive.z));
+        const float inv = 1.0f / maximum;
+        s.mat.color = emissive * inv;
+        s.flags = LM_SF_EMISSIVE;
+        return;
+    }
+    if (texColor.w < 0.51f) {
+        s.flags = LM_SF_ALPHA;
+        s.position = ro + rd * t;
+        s.incoming = rd;
+        s.transport = rc;
+        return;
+    }
+    const float eta = 1.f / mat->transmittance.w;
+    s.position = ro + rd * t;
+    s.incoming = rd;
+    s.transport = rc;
+    s.tangent = tangentWorld;
+    s.mat.color = mat->color; s.mat.transmittance = mat->transmittance; s.mat.tint = mat->tint;
+    s.mat.p0 = mat->p[0]; s.mat.p1 = mat->p[1]; s.mat.p2 = mat->p[2];
+    const float4 mr = lm_tex2D(sc, mat->tex[5], uvx, uvy);
+    const float baseMetal = lm_unpack8(mat->p[0], 0), baseRough = lm_unpack8(mat->p[0], 24);
+    lm_pack8(s.mat.p0, 0, mr.z * baseMetal);
+    lm_pack8(s.mat.p0, 24, mr.y * baseRough);
+    s.mat.color = texColor * mat->color;
+    const float4 cc = lm_tex2D(sc, mat->tex[0], uvx, uvy);
+    const float4 ccr = lm_tex2D(sc, mat->tex[1], uvx, uvy);
+    const float4 tr = lm_tex2D(sc, mat->tex[2], uvx, uvy);
+    const float4 tint = lm_tex2D(sc, mat->tex[7], uvx, uvy);
+    const lf3 finalTint = v3(tint.x, tint.y, tint.z) * v3(mat->tint);
+    const float finalClearCoat = lm_unpack8(mat->p[2], 0) * cc.x;
+    const float gloss = lm_unpack8(mat->p[2], 8) * (1.f - ccr.x);
+    const float finalTransmission = lm_unpack8(mat->p[2], 16) * tr.x;
+    lm_pack8(s.mat.p2, 0, finalClearCoat);
+    lm_pack8(s.mat.p2, 8, gloss);
+    s.mat.tint = make_float4(finalTint.x, finalTint.y, finalTint.z, s.mat.tint.w);
+    lm_pack8(s.mat.p2, 16, finalTransmission);
+    s.mat.transmittance.w = eta;
+}
+
+// G-buffer planes (depth-0 SurfaceData in SoA form), plane p of pixel li at gbuf[p * n + li]:
+//   0 (position, t)   1 (normal, flags bits)   2 (tangent, 0)   3 (incoming, 0)
+//   4 color           5 (tint, luminance)      6 (transmittance, eta)   7 (p0, p1, p2 bits, 0)
+__device__ __forceinline__ void lm_gbuf_store(float4* __restrict__ g, uint32_t n, uint32_t li, const LmSurface& s)
+{
+    g[li] = v4(s.position, s.t);
+    g[n + li] = v4(s.normal, u2f(s.flags));
+    g[2u * n + li] = v4(s.tangent, 0.f);
+    g[3u * n + li] = v4(s.incoming, 0.f);
+    g[4u * n + li] = s.mat.color;
+    g[5u * n + li] = s.mat.tint;
+    g[6u * n + li] = s.mat.transmittance;
+    g[7u * n + li] = make_float4(u2f(s.mat.p0), u2f(s.mat.p1), u2f(s.mat.p2), 0.f);
+}
+__device__ __forceinline__ void lm_gbuf_load(const float4* __restrict__ g, uint32_t n, uint32_t li, LmSurface& s)
+{
+    const float4 a = g[li], b = g[n + li], c = g[2u * n + li], d = g[3u * n + li];
+    s.position = v3(a); s.t = a.w; s.normal = v3(b); s.flags = f2u(b.w); s.tangent = v3(c); s.incoming = v3(d);
+    s.mat.color = g[4u * n + li]; s.mat.tint = g[5u * n + li]; s.mat.transmittance = g[6u * n + li];
+    const float4 p = g[7u * n + li];
+    s.mat.p0 = f2u(p.x); s.mat.p1 = f2u(p.y); s.mat.p2 = f2u(p.z);
+    s.transport = v3(1.f, 1.f, 1.f);
+}
+
+// K7 (depth 0) + K9 motion vectors (MotionVectors.cu:8-55) + K10 ResolveDirectLightHits (GPUShadeDirect.cu:11-40) + channel clear
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_extract0)(LmScene sc, LmFrame fr, LmCamera cam, int cur)
+{
+    const uint32_t stride = gridDim.x * LM_BLOCK;
+    float4* g = fr.gbuf[cur];
+    for (uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x; i < fr.n; i += stride) {
+        const float4 o4 = fr.rayO[0][i], d4 = fr.rayD[0][i], c4 = fr.rayC[0][i];
+        const uint32_t li = f2u(d4.w);
+        LmSurface s;
+        lm_extract(sc, fr.hits[i], v3(o4), v3(d4), v3(c4), s);
+        lm_gbuf_store(g, fr.n, li, s);
+        // motion vector
+        const uint32_t ly = li / fr.ww, lx = li - ly * fr.ww;
+        const uint32_t px = fr.x0 + lx, py = fr.y0 + ly;
+        uint32_t mv = 0u;
+        if (s.t > 0.f) {
+            float csx = (float)(int)px, csy = (float)(int)py;
+            csx += 0.5f; csy += 0.5f;
+            csx /= (float)fr.W; csy /= (float)fr.H;
+            const float* M = cam.prevViewProj;
+            const float cx = M[0] * s.position.x + M[1] * s.position.y + M[2] * s.position.z + M[3] * 1.0f;
+            const float cy = M[4] * s.position.x + M[5] * s.position.y + M[6] * s.position.z + M[7] * 1.0f;
+            const float cz = M[8] * s.position.x + M[9] * s.position.y + M[10] * s.position.z + M[11] * 1.0f;
+            const float cw = M[12] * s.position.x + M[13] * s.position.y + M[14] * s.position.z + M[15] * 1.0f;
+            const lf3 ndc = v3(cx, cy, cz) / cw;
+            const float psx = ndc.x * 0.5f + 0.5f, psy = ndc.y * 0.5f + 0.5f;
+            mv = lm_f32_to_f16(psx - csx) | (lm_f32_to_f16(psy - csy) << 16);
+        }
+        fr.motion[li] = mv;
+        fr.direct[li] = (s.flags & LM_SF_EMISSIVE) ? s.mat.color : make_float4(0.f, 0.f, 0.f, 0.f);
+        fr.indirect[li] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// lights / CDF — reference ReSTIRData.h:230-306 (CDF::Get, BinarySearch)
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lm_cdf_get(const LmScene& sc, float value, uint32_t& index, float& pdf)
+{
+    const float required = sc.cdfSum * value;
+    int first = 0, last = (int)sc.numLights - 1, center = 0;
+    for (;;) {
+        center = (last + first) / 2;
+        const float higher = sc.cdf[center];
+        const float lower = center != 0 ? sc.cdf[center - 1] : 0.f;
+        if (required < lower && center - 1 >= first) { last = center - 1; continue; }
+        if (required > higher && center + 1 <= last) { first = center + 1; continue; }
+        index = (uint32_t)center;
+        pdf = (higher - lower) / sc.cdfSum;
+        return;
+    }
+}
+struct LmTriLight { lf3 p0, p1, p2, normal, radiance; float area; };
+__device__ __forceinline__ LmTriLight lm_load_light(const LmLight* __restrict__ lights, uint32_t i)
+{
+    const float4 a = lights[i].a, b = lights[i].b, c = lights[i].c, d = lights[i].d;
+    LmTriLight l;
+    l.p0 = v3(a.x, a.y, a.z); l.p1 = v3(a.w, b.x, b.y); l.p2 = v3(b.z, b.w, c.x);
+    l.normal = v3(c.y, c.z, c.w); l.radiance = v3(d.x, d.y, d.z); l.area = d.w;
+    return l;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// NEE (reference GPUShadeDirect.cu:42-153) and continuation (GPUShadeIndirect.cu:7-146) on one surface
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ bool lm_shade_direct(const LmScene& sc, const LmSurface& s, uint32_t gi, uint32_t seedIn, lf3& dir, float& tmaxOut, lf3& radiance)
+{
+    uint32_t seed = lm_wang_hash(seedIn + gi);
+    if (s.flags) return false;
+    uint32_t index; float pdf;
+    lm_cdf_get(sc, lm_random_float(seed), index, pdf);
+    const LmTriLight light = lm_load_light(sc.lights, index);
+    const float u = lm_random_float(seed);
+    const float v = lm_random_float(seed) * (1.f - u);
+    const lf3 arm1 = light.p1 - light.p0, arm2 = light.p2 - light.p0;
+    const lf3 lightCenter = light.p0 + (arm1 * u) + (arm2 * v);
+    lf3 toLight = lightCenter - s.position;
+    const float lDistance = length3(toLight);
+    toLight = toLight / lDistance;
+    const float cosIn = fmaxf(dot3(toLight, s.normal), 0.f);
+    const float cosOut = fmaxf(0.f, dot3(light.normal, -toLight));
+    if (cosIn <= 0.f || lDistance <= 0.01f) return false;
+    const float solidAngle = (cosOut * light.area) / (lDistance * lDistance);
+    float bsdfPdf = 0.f;
+    const lf3 bsdf = lm_evaluate_bsdf(s.mat, s.normal, s.tangent, -s.incoming, toLight, bsdfPdf);
+    if (bsdfPdf <= LM_EPSILON) return false;
+    lf3 contribution = (bsdf / bsdfPdf) * solidAngle * cosIn * light.radiance;
+    contribution = contribution * ((1.f / pdf) * s.transport);
+    dir = toLight; tmaxOut = lDistance - 0.2f; radiance = contribution;
+    return true;
+}
+__device__ bool lm_shade_indirect(const LmSurface& s, uint32_t gi, uint32_t seedIn, lf3& origin, lf3& dir, lf3& contributionOut)
+{
+    uint32_t seed = lm_wang_hash(seedIn + lm_wang_hash(gi));
+    if (s.flags & LM_SF_ALPHA) { origin = s.position; dir = s.incoming; contributionOut = s.transport; return true; }
+    if (s.flags) return false;
+    if (fabsf(dot3(s.normal, s.incoming)) < 3.f * LM_EPSILON) return false;
+    lf3 bounce = v3(0.f);
+    float pdf = 0.f;
+    bool specular = false;
+    const float r0 = lm_random_float(seed), r1 = lm_random_float(seed), r2 = lm_random_float(seed);
+    const lf3 bsdf = lm_sample_bsdf(s.mat, s.normal, s.normal, s.tangent, -s.incoming, 1.f, r0, r1, r2, bounce, pdf, specular);
+    const float chk = pdf + bsdf.x + bsdf.y + bsdf.z;
+    if (pdf <= LM_EPSILON || chk != chk) return false;
+    const float rrWeight = specular ? 1.f : fminf(fmaxf(bsdf.x, fmaxf(bsdf.y, bsdf.z)), 1.f);
+    const float rnd = lm_random_float(seed);
+    if (rrWeight < rnd) return false;
+    const float rrPdf = 1.f / rrWeight;
+    lf3 contribution = s.transport * rrPdf;
+    contribution = contribution * (bsdf * fabsf(dot3(s.normal, bounce)) * (1.f / pdf));
+    origin = s.position; dir = bounce; contributionOut = contribution;
+    return true;
+}
+
+// depth 0 continuation: reads the G-buffer written by KN(lm_k_extract0)
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_shade_indirect0)(LmFrame fr, int cur, uint32_t seed2, int outQ, uint32_t* outCount)
+{
+    const uint32_t stride = gridDim.x * LM_BLOCK;
+    const uint32_t nIter = (fr.n + stride - 1u) / stride;
+    for (uint32_t it = 0; it < nIter; it++) {
+        const uint32_t li = it * stride + blockIdx.x * LM_BLOCK + threadIdx.x;
+        bool emit = false;
+        lf3 o = v3(0.f), d = v3(0.f), c = v3(0.f);
+        if (li < fr.n) {
+            LmSurface s;
+            lm_gbuf_load(fr.gbuf[cur], fr.n, li, s);
+            const uint32_t ly = li / fr.ww, lx = li - ly * fr.ww;
+            const uint32_t gi = (fr.y0 + ly) * fr.W + (fr.x0 + lx);
+            emit = lm_shade_indirect(s, gi, seed2, o, d, c);
+        }
+        const uint32_t slot = lm_append_slot(outCount, emit);
+        if (emit) {
+            fr.rayO[outQ][slot] = v4(o, 0.f);
+            fr.rayD[outQ][slot] = v4(d, u2f(li));
+            fr.rayC[outQ][slot] = v4(c, 0.f);
+        }
+    }
+}
+
+// depth >= 1: extraction + NEE + continuation fused (no SurfaceData round trip through HBM)
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_shade_wave)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict__ inCount, uint32_t seed, uint32_t seed2, int doIndirect,
+                uint32_t* outCount, uint32_t* shadowCount)
+{
+    const uint32_t n = *inCount;
+    const uint32_t stride = gridDim.x * LM_BLOCK;
+    const uint32_t nIter = (n + stride - 1u) / stride;
+    const int outQ = inQ ^ 1;
+    for (uint32_t it = 0; it < nIter; it++) {
+        const uint32_t i = it * stride + blockIdx.x * LM_BLOCK + threadIdx.x;
+        bool emitShadow = false, emitRay = false;
+        lf3 sdir = v3(0.f), srad = v3(0.f), o = v3(0.f), d = v3(0.f), c = v3(0.f), spos = v3(0.f);
+        float stmax = 0.f;
+        uint32_t li = 0;
+        if (i < n) {
+            const float4 o4 = fr.rayO[inQ][i], d4 = fr.rayD[inQ][i], c4 = fr.rayC[inQ][i];
+            li = f2u(d4.w);
+            LmSurface s;
+            lm_extract(sc, fr.hits[i], v3(o4), v3(d4), v3(c4), s);
+            const uint32_t ly = li / fr.ww, lx = li - ly * fr.ww;
+            const uint32_t gi = (fr.y0 + ly) * fr.W + (fr.x0 + lx);
+            emitShadow = lm_shade_direct(sc, s, gi, seed, sdir, stmax, srad);
+            spos = s.position;
+            if (doIndirect) emitRay = lm_shade_indirect(s, gi, seed2, o, d, c);
+        }
+        const uint32_t ss = lm_append_slot(shadowCount, emitShadow);
+        if (emitShadow) {
+            fr.shO[ss] = v4(spos, stmax);
+            fr.shD[ss] = v4(sdir, u2f(li));
+            fr.shR[ss] = v4(srad, 0.f);
+        }
+        const uint32_t rs = lm_append_slot(outCount, emitRay);
+        if (emitRay) {
+            fr.rayO[outQ][rs] = v4(o, 0.f);
+            fr.rayD[outQ][rs] = v4(d, u2f(li));
+            fr.rayC[outQ][rs] = v4(c, 0.f);
+        }
+    }
+}
+
+// K5: NEE shadow rays — reference WaveFrontShaders.cu:114-179 (tmin 0.01; unoccluded => channel += radiance).
+// At most one shadow ray per pixel per wave, so the add is a plain fp32 read-modify-write.
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_trace_shadow)(LmScene sc, LmFrame fr, const uint32_t* __restrict__ countPtr, float tmin)
+{
+    __shared__ int s_stack[LM_STACK_DEPTH * LM_BLOCK];
+    int* stack = s_stack + threadIdx.x;
+    const uint32_t n = *countPtr;
+    const uint32_t stride = gridDim.x * LM_BLOCK;
+    for (uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x; i < n; i += stride) {
+        const float4 o4 = fr.shO[i], d4 = fr.shD[i];
+        LmHit h;
+        const bool occluded = lm_traverse<true>(sc, v3(o4), v3(d4), tmin, o4.w, stack, h, fr.counters);
+        if (!occluded) {
+            const uint32_t li = f2u(d4.w);
+            const float4 r = fr.shR[i];
+            float4 px = fr.indirect[li];
+            px.x += r.x; px.y += r.y; px.z += r.z;
+            fr.indirect[li] = px;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ReSTIR DI — reference ReSTIRData.h:115-178, ReSTIRKernels.cu, Framework/ReSTIR.cpp:65-233
+// reservoir planes (5 float4 per pixel): 0 (weightSum, weight, sampleCount bits, solidAnglePdf)
+//   1 (radiance, area)  2 (normal, 0)  3 (position, 0)  4 (unshadowed contribution, 0)
+// ---------------------------------------------------------------------------------------------------------------------
+struct LmSample { lf3 radiance, normal, position, contribution; float area, pdf; };
+struct LmReservoir { float weightSum, weight; long long count; LmSample s; };
+
+__device__ __forceinline__ void lm_sample_zero(LmSample& s) { s.radiance = v3(0.f); s.normal = v3(0.f); s.position = v3(0.f); s.contribution = v3(0.f); s.area = 0.f; s.pdf = 0.f; }
+__device__ __forceinline__ void lm_res_fresh(LmReservoir& r) { r.weightSum = 0.f; r.weight = 0.f; r.count = 0; lm_sample_zero(r.s); }
+__device__ __forceinline__ void lm_res_load(const float4* __restrict__ b, uint32_t n, uint32_t li, LmReservoir& r)
+{
+    const float4 a = b[li], p1 = b[n + li], p2 = b[2u * n + li], p3 = b[3u * n + li], p4 = b[4u * n + li];
+    r.weightSum = a.x; r.weight = a.y; r.count = (long long)f2u(a.z); r.s.pdf = a.w;
+    r.s.radiance = v3(p1); r.s.area = p1.w; r.s.normal = v3(p2); r.s.position = v3(p3); r.s.contribution = v3(p4);
+}
+__device__ __forceinline__ void lm_res_store(float4* __restrict__ b, uint32_t n, uint32_t li, const LmReservoir& r)
+{
+    b[li] = make_float4(r.weightSum, r.weight, u2f((uint32_t)r.count), r.s.pdf);
+    b[n + li] = v4(r.s.radiance, r.s.area);
+    b[2u * n + li] = v4(r.s.normal, 0.f);
+    b[3u * n + li] = v4(r.s.position, 0.f);
+    b[4u * n + li] = v4(r.s.contribution, 0.f);
+}
+__device__ __forceinline__ void lm_res_update(LmReservoir& r, const LmSample& s, float w, uint32_t seed /* by value: reference quirk */)
+{
+    r.weightSum += w;
+    ++r.count;
+    const float rnd = lm_random_float(seed);
+    if (rnd <= (w / r.weightSum)) r.s = s;
+}
+__device__ __forceinline__ void lm_res_update_weight(LmReservoir& r)
+{
+    if (r.count == 0 || r.weightSum <= 0.f) { r.weight = 0; return; }
+    r.weight = (1.f / fmaxf(r.s.pdf, 1.1920928955078125e-7f)) * ((1.f / (float)r.count) * r.weightSum);
+}
+// Resample — ReSTIRKernels.cu:1259-1325
+__device__ void lm_resample(const LmSample& in, const LmSurface& px, LmSample& out)
+{
+    out = in;
+    lf3 toLight = in.position - px.position;
+    const float lDistance = length3(toLight);
+    toLight = toLight / lDistance;
+    const float cosIn = fmaxf(dot3(toLight, px.normal), 0.f);
+    const float cosOut = fmaxf(dot3(in.normal, -toLight), 0.f);
+    if (cosIn <= 0 || cosOut <= 0 || lDistance <= 0.01f) { out.pdf = 0; return; }
+    const float solidAngle = (cosOut * in.area) / (lDistance * lDistance);
+    float pdf = 0.f;
+    const lf3 bsdf = lm_evaluate_bsdf(px.mat, px.normal, px.tangent, -px.incoming, toLight, pdf);
+    const float added = pdf + bsdf.x + bsdf.y + bsdf.z;
+    if (pdf <= LM_EPSILON || added != added || fabsf(added) == u2f(0x7f800000u)) { out.contribution = v3(0.f); out.pdf = 0; return; }
+    const lf3 contribution = (bsdf / pdf) * solidAngle * cosIn * out.radiance;
+    out.contribution = contribution;
+    out.pdf = (contribution.x + contribution.y + contribution.z) / 3.f;
+}
+// CombineBiased for two reservoirs — ReSTIRKernels.cu:1200-1257
+__device__ void lm_combine2(LmReservoir& dst, const LmReservoir& a, const LmReservoir& b, const LmSurface& px, uint32_t seed)
+{
+    LmReservoir out; lm_res_fresh(out);
+    LmSample rs;
+    lm_resample(a.s, px, rs);
+    lm_res_update(out, rs, (float)a.count * a.weight * rs.pdf, seed);
+    lm_resample(b.s, px, rs);
+    lm_res_update(out, rs, (float)b.count * b.weight * rs.pdf, seed);
+    out.count = a.count + b.count;
+    lm_res_update_weight(out);
+    dst = out;
+}
+
+// K20 FillLightBags — ReSTIRKernels.cu:343-370
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_fill_bags)(LmScene sc, LmFrame fr, uint32_t seed, uint32_t total)
+{
+    const uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x;
+    if (i >= total) return;
+    uint32_t s = lm_wang_hash(seed + lm_wang_hash(i));
+    const float rnd = lm_random_float(s);
+    uint32_t li; float pdf;
+    lm_cdf_get(sc, rnd, li, pdf);
+    fr.bags[i] = make_uint2(li, f2u(pdf));
+}
+
+// K21 PickPrimarySamples — ReSTIRKernels.cu:402-522.  One 16x16 pixel tile shares a light bag (the reference keys
+// the bag on the hardware SM id, which is not reproducible: DESIGN.md decision D2); the bag's 1000 (index, pdf)
+// pairs are staged in LDS once per tile.
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_pick_primary)(LmScene sc, LmFrame fr, int cur, float4* __restrict__ resCur, uint32_t seed)
+{
+    __shared__ uint2 s_bag[1000];
+    const uint32_t tilesX = (fr.W + 15u) / 16u;
+    // block -> tile of the window (tiles aligned to the global 16x16 grid)
+    const uint32_t tx0 = fr.x0 / 16u, ty0 = fr.y0 / 16u;
+    const uint32_t wtx = (fr.x0 + fr.ww + 15u) / 16u - tx0;
+    const uint32_t tileX = tx0 + blockIdx.x % wtx, tileY = ty0 + blockIdx.x / wtx;
+    uint32_t bagSeed = lm_wang_hash(seed + (tileY * tilesX + tileX));
+    const float rb = lm_random_float(bagSeed);
+    const int bagIndex = (int)roundf((float)(50 - 1) * rb);
+    for (uint32_t k = threadIdx.x; k < 1000u; k += LM_BLOCK) s_bag[k] = fr.bags[(uint32_t)bagIndex * 1000u + k];
+    __syncthreads();
+    const uint32_t px = tileX * 16u + (threadIdx.x & 15u), py = tileY * 16u + (threadIdx.x >> 4);
+    if (px < fr.x0 || py < fr.y0 || px >= fr.x0 + fr.ww || py >= fr.y0 + fr.wh) return;
+    const uint32_t li = (py - fr.y0) * fr.ww + (px - fr.x0);
+    const uint32_t gi = py * fr.W + px;
+    LmSurface pixel;
+    lm_gbuf_load(fr.gbuf[cur], fr.n, li, pixel);
+    if (pixel.flags) { float4 a = resCur[li]; a.y = 0.f; resCur[li] = a; return; }
+    uint32_t s = lm_wang_hash(seed + lm_wang_hash(gi));
+    LmReservoir fresh; lm_res_fresh(fresh);
+    for (int smp = 0; smp < 32; smp++) {
+        const float r = lm_random_float(s);
+        const int pick = (int)roundf((float)(1000 - 1) * r);
+        const uint2 entry = s_bag[pick];
+        const LmTriLight light = lm_load_light(sc.lights, entry.x);
+        const float initialPdf = u2f(entry.y);
+        const float u = lm_random_float(s);
+        const float v = lm_random_float(s) * (1.f - u);
+        LmSample ls; lm_sample_zero(ls);
+        ls.radiance = light.radiance; ls.normal = light.normal; ls.area = light.area;
+        const lf3 arm1 = light.p1 - light.p0, arm2 = light.p2 - light.p0;
+        ls.position = light.p0 + (arm1 * u) + (arm2 * v);
+        LmSample rs;
+        lm_resample(ls, pixel, rs);
+        const float pdf = rs.pdf / initialPdf;
+        lm_res_update(fresh, rs, pdf, s);
+    }
+    lm_res_update_weight(fresh);
+    lm_res_store(resCur, fr.n, li, fresh);
+}
+
+// K22 + K6 + K23: visibility ray of the pixel's reservoir (tmin 0.1, tmax d - 0.05; ReSTIRKernels.cu:546-582,
+// WaveFrontShaders.cu:181-216), then shade it into DIRECT with weight/3 (ReSTIRKernels.cu:600-665)
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_restir_visibility_shade)(LmScene sc, LmFrame fr, int cur, float4* __restrict__ res)
+{
+    __shared__ int s_stack[LM_STACK_DEPTH * LM_BLOCK];
+    int* stack = s_stack + threadIdx.x;
+    const uint32_t stride = gridDim.x * LM_BLOCK;
+    const uint32_t nIter = (fr.n + stride - 1u) / stride;
+    const float4* g = fr.gbuf[cur];
+    for (uint32_t it = 0; it < nIter; it++) {
+        const uint32_t li = it * stride + blockIdx.x * LM_BLOCK + threadIdx.x;
+        bool shoot = false;
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        lf3 pos = v3(0.f), toLight = v3(0.f);
+        float l = 0.f;
+        if (li < fr.n && f2u(g[fr.n + li].w) == 0u) {
+            r0 = res[li];
+            if (r0.y > 0.f) {
+                pos = v3(g[li]);
+                toLight = v3(res[3u * fr.n + li]) - pos;
+                l = length3(toLight);
+                toLight = toLight / l;
+                shoot = true;
+            }
+        }
+        lm_count(fr.counters + LM_CNT_RESTIR, shoot);
+        if (shoot) {
+            LmHit h;
+            if (lm_traverse<true>(sc, pos, toLight, 0.1f, l - 0.05f, stack, h, fr.counters)) { r0.y = 0.f; res[li] = r0; }
+            if (r0.y > 0.f) {
+                const lf3 add = v3(res[4u * fr.n + li]) * (r0.y / 3.f);
+                float4 px = fr.direct[li];
+                px.x += add.x; px.y += add.y; px.z += add.z;
+                fr.direct[li] = px;
+            }
+        }
+    }
+}
+
+// K24 temporal reuse — ReSTIRKernels.cu:1015-1121
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_restir_temporal)(LmFrame fr, int cur, int prev, float4* __restrict__ resCur, const float4* __restrict__ resPrev, uint32_t seed)
+{
+    const uint32_t stride = gridDim.x * LM_BLOCK;
+    for (uint32_t li = blockIdx.x * LM_BLOCK + threadIdx.x; li < fr.n; li += stride) {
+        const int ly = (int)(li / fr.ww), lx = (int)(li - (uint32_t)ly * fr.ww);
+        const uint32_t gi = (fr.y0 + (uint32_t)ly) * fr.W + (fr.x0 + (uint32_t)lx);
+        const uint32_t mv = fr.motion[li];
+        const float vx = lm_f16_to_f32(mv & 0xffffu), vy = lm_f16_to_f32(mv >> 16);
+        const int movedX = (int)roundf((float)fr.W * vx), movedY = (int)roundf((float)fr.H * vy);
+        int ty = ly + movedY, tx = lx + movedX;
+        uint32_t tli = li;
+        if (ty >= 0 && ty < (int)fr.wh && tx >= 0 && tx < (int)fr.ww) tli = (uint32_t)ty * fr.ww + (uint32_t)tx;
+        const float4* gp = fr.gbuf[prev];
+        const float4* gc = fr.gbuf[cur];
+        const float4 pn = gp[fr.n + tli], cn = gc[fr.n + li];
+        if (f2u(pn.w) != 0u || f2u(cn.w) != 0u) continue;
+        const float d1 = gp[tli].w, d2 = gc[li].w;
+        const float depthDif = fabsf(d1 - d2) / ((d1 + d2) / 2.f);
+        const float angle = dot3(v3(pn), v3(cn));
+        if (!(depthDif < 0.10f && angle > 0.72222222223f)) continue;
+        LmReservoir rp, rc;
+        lm_res_load(resPrev, fr.n, tli, rp);
+        lm_res_load(resCur, fr.n, li, rc);
+        if (rp.weight > 0.f) {                                   // ShadeReservoirs on the PREVIOUS reservoir
+            const lf3 add = rp.s.contribution * (rp.weight / 3.f);
+            float4 px = fr.direct[li];
+            px.x += add.x; px.y += add.y; px.z += add.z;
+            fr.direct[li] = px;
+        }
+        const long long cap = rc.count * 20;
+        if (cap < rp.count) rp.count = cap;
+        LmSurface s;
+        lm_gbuf_load(gc, fr.n, li, s);
+        LmReservoir out;
+        lm_combine2(out, rp, rc, s, lm_wang_hash(seed + gi));
+        lm_res_store(resCur, fr.n, li, out);
+    }
+}
+
+// K25 spatial reuse — ReSTIRKernels.cu:787-980 (biased branch)
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_restir_spatial)(LmFrame fr, int cur, const float4* __restrict__ resIn, float4* __restrict__ resOut, uint32_t seed)
+{
+    const uint32_t stride = gridDim.x * LM_BLOCK;
+    const float4* g = fr.gbuf[cur];
+    for (uint32_t li = blockIdx.x * LM_BLOCK + threadIdx.x; li < fr.n; li += stride) {
+        const float4 cn = g[fr.n + li];
+        if (f2u(cn.w) != 0u) continue;
+        const int y = (int)(li / fr.ww), x = (int)(li - (uint32_t)y * fr.ww);
+        const uint32_t gi = (fr.y0 + (uint32_t)y) * fr.W + (fr.x0 + (uint32_t)x);
+        uint32_t s = lm_wang_hash(seed + gi);
+        const float ct = g[li].w;
+        uint32_t nb[5];
+        int count = 0;
+        for (int k = 0; k < 5; k++) {
+            const int ny = (int)roundf((lm_random_float(s) * 2.f - 1.f) * 30.f) + y;
+            const int nx = (int)roundf((lm_random_float(s) * 2.f - 1.f) * 30.f) + x;
+            if (nx < 0 || nx >= (int)fr.ww || ny < 0 || ny >= (int)fr.wh) continue;
+            const uint32_t ni = (uint32_t)ny * fr.ww + (uint32_t)nx;
+            const float4 nn = g[fr.n + ni];
+            if (f2u(nn.w) != 0u) continue;
+            const float d1 = g[ni].w;
+            const float depthDif = fabsf(d1 - ct) / ((d1 + ct) / 2.f);
+            const float angle = dot3(v3(nn), v3(cn));
+            if (depthDif < 0.10f && angle > 0.72222222223f) nb[count++] = ni;
+        }
+        if (count > 1) {
+            LmSurface s0;
+            lm_gbuf_load(g, fr.n, nb[0], s0);                    // every candidate is re-evaluated at the FIRST neighbour's surface (reference :883)
+            LmReservoir out; lm_res_fresh(out);
+            long long sum = 0;
+            for (int k = 0; k < count; k++) {
+                LmReservoir r;
+                lm_res_load(resIn, fr.n, nb[k], r);
+                LmSample rs;
+                lm_resample(r.s, s0, rs);
+                lm_res_update(out, rs, (float)r.count * r.weight * rs.pdf, seed);   // global seed: same draw for all pixels (reference quirk)
+                sum += r.count;
+            }
+            out.count = sum;
+            lm_res_update_weight(out);
+            lm_res_store(resOut, fr.n, li, out);
+        } else {
+            resOut[li] = make_float4(0.f, 0.f, u2f(0u), resOut[li].w);   // Reset(): weightSum, sampleCount, weight
+        }
+    }
+}
+
+// K26 CombineReservoirBuffers — ReSTIRKernels.cu:1407-1436
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_restir_combine)(LmFrame fr, int cur, float4* __restrict__ resCur, const float4* __restrict__ resSpatial, uint32_t seed)
+{
+    const uint32_t stride = gridDim.x * LM_BLOCK;
+    const float4* g = fr.gbuf[cur];
+    for (uint32_t li = blockIdx.x * LM_BLOCK + threadIdx.x; li < fr.n; li += stride) {
+        if (f2u(g[fr.n + li].w) != 0u) continue;
+        const uint32_t ly = li / fr.ww, lx = li - ly * fr.ww;
+        const uint32_t gi = (fr.y0 + ly) * fr.W + (fr.x0 + lx);
+        LmSurface s;
+        lm_gbuf_load(g, fr.n, li, s);
+        LmReservoir a, b, out;
+        lm_res_load(resCur, fr.n, li, a);
+        lm_res_load(resSpatial, fr.n, li, b);
+        lm_combine2(out, a, b, s, lm_wang_hash(seed + gi));
+        lm_res_store(resCur, fr.n, li, out);
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_clear_f4)(float4* __restrict__ p, uint32_t n)
+{
+    const uint32_t stride = gridDim.x * LM_BLOCK;
+    for (uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x; i < n; i += stride) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// K13 + K14: channel merge with optional running-mean blend (GPUMergeOutputChannels.cu:5-88, fp32) and sRGB8 output
+// (GPUShadingKernels.cu:28-56, vendor/Include/Cuda/cuda/helpers.h:35-66)
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_merge_output)(LmFrame fr, int blend, uint32_t blendCount)
+{
+    const uint32_t stride = gridDim.x * LM_BLOCK;
+    for (uint32_t li = blockIdx.x * LM_BLOCK + threadIdx.x; li < fr.n; li += stride) {
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+        m = m + fr.direct[li];
+        m = m + fr.indirect[li];
+        float4 c;
+        if (blend) {
+            const float4 old = fr.combined[li];
+            const float k = (float)blendCount, k1 = (float)(blendCount + 1u);
+            const float4 s = old * k + m;
+            c = make_float4(s.x / k1, s.y / k1, s.z / k1, s.w / k1);
+        } else c = m;
+        fr.combined[li] = c;
+        const float in[3] = {clampf(c.x, 0.f, 1.f), clampf(c.y, 0.f, 1.f), clampf(c.z, 0.f, 1.f)};
+        uint32_t q[3];
+        for (int k = 0; k < 3; k++) {
+            const float powed = lm_powf(in[k], 1.0f / 2.4f);
+            float sv = in[k] < 0.0031308f ? 12.92f * in[k] : 1.055f * powed - 0.055f;
+            sv = clampf(sv, 0.f, 1.f);
+            const uint32_t v = (uint32_t)(sv * 256.f);
+            q[k] = v < 255u ? v : 255u;
+        }
+        fr.output[li] = make_uchar4((unsigned char)q[0], (unsigned char)q[1], (unsigned char)q[2], 255);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// test / seam kernels (the ray-query seam of OptixWrapper::TraceRays and batch BSDF evaluation for known-answer tests)
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_query_any)(LmScene sc, const float4* __restrict__ rayO /* w = tmax */, const float4* __restrict__ rayD, uint32_t n, float tmin,
+               uint32_t* __restrict__ occluded, uint32_t* counters)
+{
+    __shared__ int s_stack[LM_STACK_DEPTH * LM_BLOCK];
+    int* stack = s_stack + threadIdx.x;
+    const uint32_t stride = gridDim.x * LM_BLOCK;
+    for (uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x; i < n; i += stride) {
+        const float4 o4 = rayO[i], d4 = rayD[i];
+        LmHit h;
+        occluded[i] = lm_traverse<true>(sc, v3(o4), v3(d4), tmin, o4.w, stack, h, counters) ? 1u : 0u;
+    }
+}
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_query_closest_raw)(LmScene sc, const float4* __restrict__ rayO, const float4* __restrict__ rayD, uint32_t n, float tmin, float tmax,
+                       uint4* __restrict__ idOut, float4* __restrict__ uvtOut, uint32_t* counters)
+{
+    __shared__ int s_stack[LM_STACK_DEPTH * LM_BLOCK];
+    int* stack = s_stack + threadIdx.x;
+    const uint32_t stride = gridDim.x * LM_BLOCK;
+    for (uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x; i < n; i += stride) {
+        LmHit h; h.t = -1.f; h.u = 0.f; h.v = 0.f; h.slot = 0;
+        const bool found = lm_traverse<false>(sc, v3(rayO[i]), v3(rayD[i]), tmin, tmax, stack, h, counters);
+        uint2 id = make_uint2(0u, 0u);
+        if (found) id = sc.triId[h.slot];
+        idOut[i] = make_uint4(id.x, id.y, found ? 1u : 0u, 0u);
+        uvtOut[i] = found ? make_float4(h.u, h.v, h.t, 0.f) : make_float4(0.f, 0.f, -1.f, 0.f);
+    }
+}
+// mat: 23 floats per item (color4 tint3 lum transmittance3 ior + 11 parameters through the 8-bit setters)
+__device__ __forceinline__ LmMaterial lm_material_from23(const float* m)
+{
+    LmMaterial sd;
+    sd.color = make_float4(m[0], m[1], m[2], m[3]);
+    sd.tint = make_float4(m[4], m[5], m[6], m[7]);
+    sd.transmittance = make_float4(m[8], m[9], m[10], m[11]);
+    sd.p0 = sd.p1 = sd.p2 = 0u;
+    lm_pack8(sd.p0, 0, m[12]); lm_pack8(sd.p0, 8, m[13]); lm_pack8(sd.p0, 16, m[14]); lm_pack8(sd.p0, 24, m[15]);
+    lm_pack8(sd.p1, 0, m[16]); lm_pack8(sd.p1, 8, m[17]); lm_pack8(sd.p1, 16, m[18]); lm_pack8(sd.p1, 24, m[19]);
+    lm_pack8(sd.p2, 0, m[20]); lm_pack8(sd.p2, 8, m[21]); lm_pack8(sd.p2, 16, m[22]);
+    return sd;
+}
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_test_bsdf)(uint32_t n, int mode, const float* __restrict__ mat, const float* __restrict__ N, const float* __restrict__ T,
+               const float* __restrict__ wo, const float* __restrict__ aux, float* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const LmMaterial sd = lm_material_from23(mat + 23u * i);
+    const lf3 n3 = v3(N[3*i], N[3*i+1], N[3*i+2]), t3 = v3(T[3*i], T[3*i+1], T[3*i+2]), wo3 = v3(wo[3*i], wo[3*i+1], wo[3*i+2]);
+    if (mode == 0) {
+        float pdf = 0.f;
+        const lf3 b = lm_evaluate_bsdf(sd, n3, t3, wo3, v3(aux[3*i], aux[3*i+1], aux[3*i+2]), pdf);
+        out[8*i] = b.x; out[8*i+1] = b.y; out[8*i+2] = b.z; out[8*i+3] = pdf; out[8*i+4] = 0; out[8*i+5] = 0; out[8*i+6] = 0; out[8*i+7] = 0;
+    } else {
+        float pdf = 0.f; bool spec = false; lf3 wi = v3(0.f);
+        const lf3 b = lm_sample_bsdf(sd, n3, n3, t3, wo3, 1.f, aux[3*i], aux[3*i+1], aux[3*i+2], wi, pdf, spec);
+        out[8*i] = b.x; out[8*i+1] = b.y; out[8*i+2] = b.z; out[8*i+3] = wi.x; out[8*i+4] = wi.y; out[8*i+5] = wi.z; out[8*i+6] = pdf; out[8*i+7] = spec ? 1.f : 0.f;
+    }
+}
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_test_math)(uint32_t n, int fn, const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float s, c;
+    switch (fn) {
+    case 0: lm_sincosf(x[i], &s, &c); out[i] = s; break;
+    case 1: lm_sincosf(x[i], &s, &c); out[i] = c; break;
+    case 2: out[i] = lm_logf(x[i]); break;
+    case 3: out[i] = lm_expf(x[i]); break;
+    case 4: out[i] = lm_powf(x[i], y[i]); break;
+    case 5: out[i] = lm_halton(f2u(x[i]), f2u(y[i])); break;
+    case 6: out[i] = u2f(lm_wang_hash(f2u(x[i]))); break;
+    case 7: out[i] = u2f(lm_f32_to_f16(x[i])); break;
+    default: out[i] = lm_f16_to_f32(f2u(x[i])); break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// launch table: this file is compiled twice (LM_INSTRUMENT = 0 / 1); the renderer picks a table at run time
+// ---------------------------------------------------------------------------------------------------------------------
+#include "lm_launch.h"
+#define LM_GRID(g) dim3((unsigned)(g)), dim3(LM_BLOCK), 0, s
+
+static void l_primary(hipStream_t s, int g, LmFrame fr, LmCamera cam, uint32_t frameCount) { hipLaunchKernelGGL(KN(lm_k_primary), LM_GRID(g), fr, cam, frameCount); }
+static void l_trace_closest(hipStream_t s, int g, LmScene sc, const float4* o, const float4* d, const uint32_t* cnt, uint4* hits, float tmin, float tmax, uint32_t* counters)
+{ hipLaunchKernelGGL(KN(lm_k_trace_closest), LM_GRID(g), sc, o, d, cnt, hits, tmin, tmax, counters); }
+static void l_extract0(hipStream_t s, int g, LmScene sc, LmFrame fr, LmCamera cam, int cur) { hipLaunchKernelGGL(KN(lm_k_extract0), LM_GRID(g), sc, fr, cam, cur); }
+static void l_shade_indirect0(hipStream_t s, int g, LmFrame fr, int cur, uint32_t seed2, int outQ, uint32_t* outCount) { hipLaunchKernelGGL(KN(lm_k_shade_indirect0), LM_GRID(g), fr, cur, seed2, outQ, outCount); }
+static void l_shade_wave(hipStream_t s, int g, LmScene sc, LmFrame fr, int inQ, const uint32_t* inCount, uint32_t seed, uint32_t seed2, int doIndirect, uint32_t* outCount, uint32_t* shadowCount)
+{ hipLaunchKernelGGL(KN(lm_k_shade_wave), LM_GRID(g), sc, fr, inQ, inCount, seed, seed2, doIndirect, outCount, shadowCount); }
+static void l_trace_shadow(hipStream_t s, int g, LmScene sc, LmFrame fr, const uint32_t* cnt, float tmin) { hipLaunchKernelGGL(KN(lm_k_trace_shadow), LM_GRID(g), sc, fr, cnt, tmin); }
+static void l_fill_bags(hipStream_t s, LmScene sc, LmFrame fr, uint32_t seed, uint32_t total) { hipLaunchKernelGGL(KN(lm_k_fill_bags), LM_GRID((total + LM_BLOCK - 1) / LM_BLOCK), sc, fr, seed, total); }
+static void l_pick_primary(hipStream_t s, int tiles, LmScene sc, LmFrame fr, int cur, float4* res, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_pick_primary), LM_GRID(tiles), sc, fr, cur, res, seed); }
+static void l_visibility_shade(hipStream_t s, int g, LmScene sc, LmFrame fr, int cur, float4* res) { hipLaunchKernelGGL(KN(lm_k_restir_visibility_shade), LM_GRID(g), sc, fr, cur, res); }
+static void l_temporal(hipStream_t s, int g, LmFrame fr, int cur, int prev, float4* rc, const float4* rp, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_restir_temporal), LM_GRID(g), fr, cur, prev, rc, rp, seed); }
+static void l_spatial(hipStream_t s, int g, LmFrame fr, int cur, const float4* in, float4* out, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_restir_spatial), LM_GRID(g), fr, cur, in, out, seed); }
+static void l_combine(hipStream_t s, int g, LmFrame fr, int cur, float4* rc, const float4* rs, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_restir_combine), LM_GRID(g), fr, cur, rc, rs, seed); }
+static void l_clear(hipStream_t s, int g, float4* p, uint32_t n) { hipLaunchKernelGGL(KN(lm_k_clear_f4), LM_GRID(g), p, n); }
+static void l_merge(hipStream_t s, int g, LmFrame fr, int blend, uint32_t blendCount) { hipLaunchKernelGGL(KN(lm_k_merge_output), LM_GRID(g), fr, blend, blendCount); }
+static void l_query_any(hipStream_t s, int g, LmScene sc, const float4* o, const float4* d, uint32_t n, float tmin, uint32_t* occ, uint32_t* counters) { hipLaunchKernelGGL(KN(lm_k_query_any), LM_GRID(g), sc, o, d, n, tmin, occ, counters); }
+static void l_query_closest(hipStream_t s, int g, LmScene sc, const float4* o, const float4* d, uint32_t n, float tmin, float tmax, uint4* id, float4* uvt, uint32_t* counters)
+{ hipLaunchKernelGGL(KN(lm_k_query_closest_raw), LM_GRID(g), sc, o, d, n, tmin, tmax, id, uvt, counters); }
+static void l_test_bsdf(hipStream_t s, uint32_t n, int mode, const float* mat, const float* N, const float* T, const float* wo, const float* aux, float* out)
+{ hipLaunchKernelGGL(KN(lm_k_test_bsdf), LM_GRID((n + LM_BLOCK - 1) / LM_BLOCK), n, mode, mat, N, T, wo, aux, out); }
+static void l_test_math(hipStream_t s, uint32_t n, int fn, const float* x, const float* y, float* out) { hipLaunchKernelGGL(KN(lm_k_test_math), LM_GRID((n + LM_BLOCK - 1) / LM_BLOCK), n, fn, x, y, out); }
+
+#if LM_INSTRUMENT
+extern "C" const LmKernelTable* lm_kernel_table_instrumented()
+#else
+extern "C" const LmKernelTable* lm_kernel_table()
+#endif
+{
+    static const LmKernelTable t = {l_primary, l_trace_closest, l_extract0, l_shade_indirect0, l_shade_wave, l_trace_shadow, l_fill_bags, l_pick_primary,
+                                    l_visibility_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_test_bsdf, l_test_math};
+    return &t;
+}

@@ -1,0 +1,97 @@
+// lm_layout.h — HBM data layout of the MI355X wavefront path tracer (shared by host C++ and HIP kernels).
+//
+// Everything the kernels stream is struct-of-arrays of 16-byte elements, so that a wavefront's 64 lanes read
+// or write 1 KiB per instruction (DESIGN.md "Data layout").  The reference's AoS wire formats
+// (IntersectionRayData 40 B, IntersectionData 16 B, SurfaceData 176 B, Reservoir 80 B, ShadowRayData 48 B —
+// LumenPT/src/Shaders/CppCommon/WaveFrontDataStructs/*.h, ReSTIRData.h) carry the same fields.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define LM_STACK_DEPTH 48        // traversal stack entries per lane; the BVH builder bounds the tree depth to this
+#define LM_MAX_LEAF 8            // triangles per leaf representable in a leaf reference
+#define LM_MAX_DEPTH 16          // path depth the counter block is sized for
+
+// surface flags (reference: SurfaceData.h:18-24)
+#define LM_SF_EMISSIVE 1u
+#define LM_SF_ALPHA 2u
+#define LM_SF_NON_INTERSECT 4u
+
+// BVH2 node, 64 bytes: the two children's boxes + references.  ref >= 0: inner node index; ref < 0: leaf,
+// ~ref = (first_triangle << 3) | (count - 1).  An absent child has an inverted (never hit) box.
+struct LmNode {
+    float4 n0;      // c0.lo.x c0.hi.x c0.lo.y c0.hi.y
+    float4 n1;      // c1.lo.x c1.hi.x c1.lo.y c1.hi.y
+    float4 n2;      // c0.lo.z c0.hi.z c1.lo.z c1.hi.z
+    int4 ref;       // c0, c1, unused, unused
+};
+// Woop unit-triangle packet, 48 bytes: rows of the affine map world -> (u, v, w)
+struct LmWoop { float4 r0, r1, r2; };
+
+// scene data table entry (reference: DevicePrimitiveInstance, ModelStructs.h:73-80)
+struct LmEntry {
+    float m[12];            // rows 0..2 of the row-major world matrix
+    uint32_t vertBase;      // first vertex (in 48-byte vertices)
+    uint32_t idxBase;       // first index
+    uint32_t material;
+    uint32_t mode;          // 0 ENABLED 1 DISABLED 2 OVERRIDE
+    float4 emissive;        // override radiance rgb, w = scale
+};
+// device material (reference: DeviceMaterial, ModelStructs.h:33-63)
+struct LmDevMaterial {
+    float4 color, emissive, transmittance, tint;
+    uint32_t p[4];
+    int32_t tex[8];         // 0 clearcoat 1 clearcoatRoughness 2 transmission 3 diffuse 4 emissive 5 metalRoughness 6 normal 7 tint; -1 = null
+};
+struct LmTexDesc { uint32_t offset, w, h, srgb; };
+// emissive triangle, 64 bytes, memory order of TriangleLight (LightData.h:21-27)
+struct LmLight { float4 a, b, c, d; };   // a = p0.xyz p1.x | b = p1.yz p2.xy | c = p2.z n.xyz | d = radiance.xyz area
+
+struct LmScene {
+    const LmNode* nodes;
+    const LmWoop* woop;
+    const uint2* triId;         // per BVH triangle slot: (table entry, primitive-local triangle), .x|0x80000000 never used
+    const uint32_t* triOrder;   // per BVH triangle slot: global triangle index (tie-break key)
+    const float4* verts;        // 3 float4 per vertex: (pos.xyz, uv.x) (uv.y, n.xyz) (tangent.xyzw)
+    const uint32_t* indices;
+    const LmEntry* entries;
+    const LmDevMaterial* materials;
+    const LmTexDesc* texDesc;
+    const uint32_t* texels;     // RGBA8 pool
+    const float* srgbLut;       // 256 entries
+    const LmLight* lights;      // sorted by mean radiance
+    const float* cdf;
+    uint32_t numLights;
+    float cdfSum;
+};
+
+// per-frame working set; all per-pixel arrays are indexed by the window-local pixel index
+struct LmFrame {
+    uint32_t W, H;              // full image
+    uint32_t x0, y0, ww, wh;    // render window (tile + halo) inside the image
+    uint32_t n;                 // ww * wh
+    // ray queues (ping-pong): origin.xyz | dir.xyz + local pixel index | contribution.xyz
+    float4 *rayO[2], *rayD[2], *rayC[2];
+    uint4* hits;                // entry, prim, half2 barycentrics, t bits
+    // shadow-ray queue of the current wave: origin.xyz + tmax | dir.xyz + pixel | radiance.xyz
+    float4 *shO, *shD, *shR;
+    // depth-0 surface data, two frames: 8 planes of n float4 each (see kernels.hip "G-buffer planes")
+    float4* gbuf[2];
+    // reservoirs: 4 buffers x 5 planes of n float4
+    float4* res[4];
+    uint32_t* motion;           // half2 motion vector per pixel
+    float4 *direct, *indirect;  // fp32 light channels
+    float4* combined;           // merged / blended radiance
+    uchar4* output;             // sRGB8
+    uint32_t* counters;         // see LM_CNT_*
+    uint2* bags;                // 50 x 1000 light-bag entries: (light index, pdf bits)
+};
+// counter block layout (uint32 each)
+#define LM_CNT_RAYS(d) (d)                       // rays entering wave d            [0, LM_MAX_DEPTH]
+#define LM_CNT_SHADOW(d) (32 + (d))              // NEE shadow rays emitted by wave d
+#define LM_CNT_RESTIR 64                         // ReSTIR visibility rays (both passes)
+#define LM_CNT_NODES 66                          // instrumented build only: BVH nodes visited (u64 as 2 words)
+#define LM_CNT_TRIS 68                           // instrumented build only: triangles tested (u64 as 2 words)
+#define LM_CNT_WORDS 80
+
+struct LmCamera { float eye[3], U[3], V[3], Wv[3]; float prevViewProj[16]; };

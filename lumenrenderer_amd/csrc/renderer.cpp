@@ -1,0 +1,1066 @@
+// renderer.cpp — host side of liblumen_mi.so: resource tables, scene flattening, light list, frame loop, C ABI.
+//
+// Mirrors the call surface of the reference's WaveFront::WaveFrontRenderer : LumenRenderer
+// (LumenPT/src/Framework/WaveFrontRenderer.{h,cpp}); every extern "C" entry point is declared and cited in
+// include/lumen_mi.h.  The frame loop follows WaveFrontRenderer::TraceFrame (.cpp:435-1089) for order of
+// operations, seed evolution and counters, but enqueues the whole frame on one HIP stream without host round
+// trips (the reference synchronises ~40 times per frame).
+#include "../../include/lumen_mi.h"
+#include "bvh.h"
+#include "lm_launch.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_lastError;
+int fail(int code, const std::string& msg) { g_lastError = msg; return code; }
+
+#define LM_HIP(expr)                                                                                              \
+    do {                                                                                                          \
+        hipError_t e_ = (expr);                                                                                   \
+        if (e_ != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// ---- handles: type tag in the top byte ---------------------------------------------------------------------
+enum HType : uint64_t { H_TEXTURE = 1, H_MATERIAL = 2, H_PRIMITIVE = 3, H_MESH = 4, H_SCENE = 5, H_INSTANCE = 6 };
+inline lumen_mi_handle mkh(HType t, size_t idx) { return ((uint64_t)t << 56) | (uint64_t)(idx + 1); }
+inline bool unh(lumen_mi_handle h, HType t, size_t n, size_t& idx) { if ((h >> 56) != (uint64_t)t) return false; idx = (size_t)(h & 0x00ffffffffffffffull); if (idx == 0 || idx > n) return false; idx--; return true; }
+
+struct Vertex48 { float pos[3]; float uv[2]; float normal[3]; float tangent[4]; };
+static_assert(sizeof(Vertex48) == 48, "Vertex layout (ModelStructs.h:21-28)");
+
+struct Texture { uint32_t w, h; bool srgb; std::vector<uint32_t> px; };
+struct Material { LmDevMaterial dev; float emissiveColor[3]; };
+struct Primitive { std::vector<Vertex48> verts; std::vector<uint32_t> idx; size_t material; std::vector<uint8_t> emissive; uint32_t numLights = 0; bool containEmissive = false; };
+struct Mesh { std::vector<size_t> prims; };
+struct Instance { size_t scene; size_t mesh; float M[16]; int mode; float radiance[3]; float scale; long overrideMaterial; std::vector<uint32_t> entries; };
+struct Scene { std::vector<size_t> instances; };
+
+template <class T> struct DevBuf {
+    T* p = nullptr; size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        if (hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return 1;
+        cap = n; return 0;
+    }
+    int upload(const std::vector<T>& v, hipStream_t s) {
+        if (ensure(v.size())) return 1;
+        if (!v.empty() && hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s) != hipSuccess) return 1;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+float g_srgbLut[256];
+void initLut() { static bool d = false; if (d) return; for (int i = 0; i < 256; i++) { const double c = i / 255.0; g_srgbLut[i] = (float)(c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4)); } d = true; }
+
+inline uint32_t wangHash(uint32_t s) { s = (s ^ 61u) ^ (s >> 16); s *= 9u; s = s ^ (s >> 4); s *= 0x27d4eb2du; s = s ^ (s >> 15); return s; }
+inline void pack8(uint32_t& w, uint32_t shift, float v) { const uint32_t q = (uint32_t)(v * 255.f); w &= ~(255u << shift); w |= q << shift; }
+
+inline void mulPoint(const float* m, const float* v, float w, float* out)     // rows 0..2, operation order of sutil Matrix4x4 * float4
+{
+    out[0] = m[0] * v[0] + m[1] * v[1] + m[2] * v[2] + m[3] * w;
+    out[1] = m[4] * v[0] + m[5] * v[1] + m[6] * v[2] + m[7] * w;
+    out[2] = m[8] * v[0] + m[9] * v[1] + m[10] * v[2] + m[11] * w;
+}
+
+}  // namespace
+
+struct lumen_mi_renderer {
+    bool initialised = false;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int numCU = 256;
+    const LmKernelTable* K = nullptr;
+    bool instrumented = false;
+
+    lumen_mi_settings settings{};
+    lumen_mi_settings pending{};
+    std::mutex settingsMutex, frameMutex;
+
+    std::vector<Texture> textures;
+    std::vector<Material> materials;
+    std::vector<Primitive> prims;
+    std::vector<Mesh> meshes;
+    std::vector<Scene> scenes;
+    std::vector<Instance> instances;
+    long activeScene = -1;
+    bool sceneDirty = true, texturesDirty = true, materialsDirty = true;
+
+    // camera
+    float camPos[3] = {0, 0, 0}, camRight[3] = {-1, 0, 0}, camUp[3] = {0, 1, 0}, camFwd[3] = {0, 0, 1};
+    float fovY = 90.f;
+    float prevCamWorld[16]; bool havePrev = false;
+
+    // window
+    uint32_t wx0 = 0, wy0 = 0, wx1 = 0, wy1 = 0; bool windowSet = false;
+
+    // persistent state (WaveFrontRenderer members)
+    uint32_t frameCount = 0, blendCounter = 0;
+    int frameIndex = 0, swapChainIndex = 0;
+
+    // flattened scene (host)
+    std::vector<LmEntry> entries;
+    std::vector<size_t> entryPrim;          // table entry -> primitive
+    std::vector<float> worldTris;
+    std::vector<uint32_t> triEntry, triPrim;
+    LmBvh bvh;
+    std::vector<LmLight> lights; std::vector<float> cdf;
+    uint32_t totalEmissive = 0;
+    bool lightsDirty = true;
+
+    // device scene
+    DevBuf<LmNode> dNodes; DevBuf<LmWoop> dWoop; DevBuf<uint2> dTriId; DevBuf<uint32_t> dTriOrder;
+    DevBuf<float4> dVerts; DevBuf<uint32_t> dIndices; DevBuf<LmEntry> dEntries; DevBuf<LmDevMaterial> dMaterials;
+    DevBuf<LmTexDesc> dTexDesc; DevBuf<uint32_t> dTexels; DevBuf<float> dLut; DevBuf<LmLight> dLights; DevBuf<float> dCdf;
+    LmScene dscene{};
+
+    // device frame
+    LmFrame fr{};
+    uint32_t allocN = 0, allocDepth = 0;
+    DevBuf<float4> dRay[6], dSh[3], dGbuf[2], dRes[4], dDirect, dIndirect, dCombined;
+    DevBuf<uint4> dHits; DevBuf<uint32_t> dMotion, dCounters; DevBuf<uchar4> dOutput; DevBuf<uint2> dBags;
+    uint32_t hostCounters[LM_CNT_WORDS] = {0};
+    bool countersValid = false;
+    uint32_t lastDepth = 0;
+    size_t lastLightCount = 0;
+
+    // timing
+    bool timing = false;
+    struct EvPair { hipEvent_t a, b; int cls; };
+    std::vector<EvPair> evPool; size_t evUsed = 0;
+    float classMs[5] = {0}; uint32_t classLaunches[5] = {0};
+    std::map<std::string, uint64_t> frameStats;
+
+    // render thread
+    std::thread renderThread; std::atomic<bool> stopFlag{false};
+
+    int gridFor(uint32_t n, int perCU) const { const int full = (int)((n + 255u) / 256u); return std::max(1, std::min(full, numCU * perCU)); }
+};
+
+namespace {
+
+using R = lumen_mi_renderer;
+
+// ---- host texture fetch (light-list build only; same definition as the device fetch) -------------------------
+void texel(const Texture& t, int x, int y, float out[4])
+{
+    const uint32_t p = t.px[(size_t)y * t.w + x];
+    const uint32_t r = p & 255u, g = (p >> 8) & 255u, b = (p >> 16) & 255u, a = p >> 24;
+    if (t.srgb) { out[0] = g_srgbLut[r]; out[1] = g_srgbLut[g]; out[2] = g_srgbLut[b]; } else { out[0] = (float)r / 255.0f; out[1] = (float)g / 255.0f; out[2] = (float)b / 255.0f; }
+    out[3] = (float)a / 255.0f;
+}
+int wrapi(int i, int n) { const int m = i % n; return m < 0 ? m + n : m; }
+void tex2D(const R* r, int id, float u, float v, float out[4])
+{
+    if (id < 0) { out[0] = out[1] = out[2] = out[3] = 0.f; return; }
+    const Texture& t = r->textures[id];
+    if (t.w == 1 && t.h == 1) { texel(t, 0, 0, out); return; }
+    const float x = u * (float)t.w - 0.5f, y = v * (float)t.h - 0.5f;
+    const float fx0 = floorf(x), fy0 = floorf(y);
+    const float ax = x - fx0, ay = y - fy0;
+    const int x0 = wrapi((int)fx0, (int)t.w), y0 = wrapi((int)fy0, (int)t.h);
+    const int x1 = wrapi(x0 + 1, (int)t.w), y1 = wrapi(y0 + 1, (int)t.h);
+    float t00[4], t10[4], t01[4], t11[4];
+    texel(t, x0, y0, t00); texel(t, x1, y0, t10); texel(t, x0, y1, t01); texel(t, x1, y1, t11);
+    for (int k = 0; k < 4; k++) {
+        const float a = t00[k] + ax * (t10[k] - t00[k]);
+        const float b = t01[k] + ax * (t11[k] - t01[k]);
+        out[k] = a + ay * (b - a);
+    }
+}
+
+// FindEmissives — reference GPUEmissiveLookup.cu:13-109, gate WaveFrontRenderer.cpp:1192-1210
+void findEmissives(const R* r, Primitive& p)
+{
+    const Material& m = r->materials[p.material];
+    p.emissive.assign(p.idx.size() / 3, 0);
+    p.numLights = 0;
+    if (m.emissiveColor[0] == 0.f && m.emissiveColor[1] == 0.f && m.emissiveColor[2] == 0.f) { p.containEmissive = false; return; }
+    for (size_t b = 0; b + 2 < p.idx.size(); b += 3) {
+        const Vertex48 &v0 = p.verts[p.idx[b]], &v1 = p.verts[p.idx[b + 1]], &v2 = p.verts[p.idx[b + 2]];
+        constexpr float oneThird = 1.f / 3.f;
+        const float uvx = (v0.uv[0] + v1.uv[0] + v2.uv[0]) * oneThird, uvy = (v0.uv[1] + v1.uv[1] + v2.uv[1]) * oneThird;
+        float e[4] = {m.dev.emissive.x, m.dev.emissive.y, m.dev.emissive.z, m.dev.emissive.w};
+        if (m.dev.tex[4] >= 0) { float t[4]; tex2D(r, m.dev.tex[4], uvx, uvy, t); for (int k = 0; k < 4; k++) e[k] = e[k] * t[k]; }
+        if (e[0] > 0.0f || e[1] > 0.0f || e[2] > 0.0f) { p.emissive[b / 3] = 1; p.numLights++; }
+    }
+    p.containEmissive = p.numLights > 0;
+}
+
+// scene data table + world-space triangle soup + BVH — replaces PTScene/PTMeshInstance/OptixWrapper AS builds
+int flatten(R* r)
+{
+    if (!r->sceneDirty) return 0;
+    if (r->activeScene < 0) return fail(LUMEN_MI_ERR_STATE, "no scene set (lumen_mi_set_scene)");
+    Scene& sc = r->scenes[r->activeScene];
+    r->entries.clear(); r->entryPrim.clear(); r->worldTris.clear(); r->triEntry.clear(); r->triPrim.clear();
+    // vertex / index pools: one slot range per primitive
+    std::vector<uint32_t> vertBase(r->prims.size()), idxBase(r->prims.size());
+    std::vector<float4> verts; std::vector<uint32_t> indices;
+    for (size_t p = 0; p < r->prims.size(); p++) {
+        vertBase[p] = (uint32_t)(verts.size() / 3); idxBase[p] = (uint32_t)indices.size();
+        for (const Vertex48& v : r->prims[p].verts) {
+            verts.push_back(make_float4(v.pos[0], v.pos[1], v.pos[2], v.uv[0]));
+            verts.push_back(make_float4(v.uv[1], v.normal[0], v.normal[1], v.normal[2]));
+            verts.push_back(make_float4(v.tangent[0], v.tangent[1], v.tangent[2], v.tangent[3]));
+        }
+        indices.insert(indices.end(), r->prims[p].idx.begin(), r->prims[p].idx.end());
+    }
+    for (size_t ii : sc.instances) {
+        Instance& mi = r->instances[ii];
+        mi.entries.clear();
+        for (size_t p : r->meshes[mi.mesh].prims) {
+            LmEntry e;
+            memcpy(e.m, mi.M, sizeof e.m);
+            e.vertBase = vertBase[p]; e.idxBase = idxBase[p];
+            e.material = (uint32_t)(mi.overrideMaterial >= 0 ? (size_t)mi.overrideMaterial : r->prims[p].material);
+            e.mode = (uint32_t)mi.mode;
+            e.emissive = make_float4(mi.radiance[0], mi.radiance[1], mi.radiance[2], mi.scale);
+            const uint32_t entryIdx = (uint32_t)r->entries.size();
+            mi.entries.push_back(entryIdx);
+            r->entries.push_back(e);
+            r->entryPrim.push_back(p);
+            const Primitive& pr = r->prims[p];
+            for (size_t t = 0; t + 2 < pr.idx.size(); t += 3) {
+                for (int k = 0; k < 3; k++) {
+                    float w[3];
+                    mulPoint(e.m, pr.verts[pr.idx[t + k]].pos, 1.f, w);
+                    r->worldTris.push_back(w[0]); r->worldTris.push_back(w[1]); r->worldTris.push_back(w[2]);
+                }
+                r->triEntry.push_back(entryIdx); r->triPrim.push_back((uint32_t)(t / 3));
+            }
+        }
+    }
+    const uint32_t nt = (uint32_t)r->triEntry.size();
+    lm_build_bvh(r->worldTris.data(), nt, &r->bvh);
+    std::vector<uint2> triId(nt);
+    for (uint32_t s = 0; s < nt; s++) triId[s] = make_uint2(r->triEntry[r->bvh.order[s]], r->triPrim[r->bvh.order[s]]);
+    hipStream_t st = r->stream;
+    if (r->dNodes.upload(r->bvh.nodes, st) || r->dWoop.upload(r->bvh.woop, st) || r->dTriId.upload(triId, st) || r->dTriOrder.upload(r->bvh.order, st) ||
+        r->dVerts.upload(verts, st) || r->dIndices.upload(indices, st) || r->dEntries.upload(r->entries, st))
+        return fail(LUMEN_MI_ERR_DEVICE, "scene upload failed (hipMalloc/hipMemcpy)");
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "scene upload sync failed");
+    r->dscene.nodes = r->dNodes.p; r->dscene.woop = r->dWoop.p; r->dscene.triId = r->dTriId.p; r->dscene.triOrder = r->dTriOrder.p;
+    r->dscene.verts = r->dVerts.p; r->dscene.indices = r->dIndices.p; r->dscene.entries = r->dEntries.p;
+    r->sceneDirty = false;
+    r->lightsDirty = true;
+    return 0;
+}
+
+int uploadResources(R* r)
+{
+    hipStream_t st = r->stream;
+    if (r->texturesDirty) {
+        std::vector<LmTexDesc> desc; std::vector<uint32_t> texels;
+        for (const Texture& t : r->textures) { desc.push_back(LmTexDesc{(uint32_t)texels.size(), t.w, t.h, t.srgb ? 1u : 0u}); texels.insert(texels.end(), t.px.begin(), t.px.end()); }
+        std::vector<float> lut(g_srgbLut, g_srgbLut + 256);
+        if (r->dTexDesc.upload(desc, st) || r->dTexels.upload(texels, st) || r->dLut.upload(lut, st)) return fail(LUMEN_MI_ERR_DEVICE, "texture upload failed");
+        if (hipStreamSynchronize(st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "texture upload sync failed");
+        r->dscene.texDesc = r->dTexDesc.p; r->dscene.texels = r->dTexels.p; r->dscene.srgbLut = r->dLut.p;
+        r->texturesDirty = false;
+    }
+    if (r->materialsDirty) {
+        std::vector<LmDevMaterial> m;
+        for (const Material& x : r->materials) m.push_back(x.dev);
+        if (r->dMaterials.upload(m, st)) return fail(LUMEN_MI_ERR_DEVICE, "material upload failed");
+        if (hipStreamSynchronize(st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "material upload sync failed");
+        r->dscene.materials = r->dMaterials.p;
+        r->materialsDirty = false;
+    }
+    return 0;
+}
+
+// light list + CDF — reference LightDataBuffer.cpp:37-125, GPUDataBufferKernels.cu:9-186 (launch shape
+// CPUDataBufferKernels.cu:35-56), ReSTIRKernels.cu:49-130 (sort by mean radiance, weights, inclusive scan).
+// Built on the host and cached while the scene is unchanged (the reference rebuilds both every frame).
+int buildLights(R* r)
+{
+    if (!r->lightsDirty) return 0;
+    struct LID { uint32_t tableIndex, numTriangles, numEmissives; };
+    std::vector<LID> lid;
+    uint32_t numEmissivePrims = 0, total = 0;
+    float avg = 0;
+    const Scene& sc = r->scenes[r->activeScene];
+    for (size_t ii : sc.instances) {
+        const Instance& mi = r->instances[ii];
+        bool meshEmissive = false;
+        for (size_t p : r->meshes[mi.mesh].prims) meshEmissive |= r->prims[p].containEmissive;
+        if (mi.mode != 1 && ((mi.mode == 0 && meshEmissive) || mi.mode == 2)) {
+            for (size_t k = 0; k < r->meshes[mi.mesh].prims.size(); k++) {
+                const Primitive& pr = r->prims[r->meshes[mi.mesh].prims[k]];
+                if (pr.containEmissive || mi.mode == 2) {
+                    const uint32_t numTriangles = (uint32_t)(pr.idx.size() / 3);
+                    avg = ((avg * (float)numEmissivePrims) + (float)numTriangles) / (float)(numEmissivePrims + 1);
+                    numEmissivePrims++;
+                    total += pr.numLights;
+                    lid.push_back(LID{mi.entries[k], numTriangles, pr.numLights});
+                }
+            }
+        }
+    }
+    const uint32_t bufferSize = 1000000u;                       // LightDataBuffer(1'000'000), WaveFrontRenderer.cpp:295
+    if (total > bufferSize) {
+        size_t keep = lid.size();
+        while (keep > 0) { total -= lid[keep - 1].numEmissives; keep--; if (total < bufferSize) break; }
+        lid.resize(keep);
+    }
+    const uint32_t avgTri = (uint32_t)roundf(avg);
+    const uint32_t gridH = (uint32_t)ceilf((float)avgTri / 64.f);
+    const uint32_t threadsY = gridH * 64u;
+    std::vector<LmLight> L;
+    for (const LID& d : lid) {
+        if (threadsY == 0) break;
+        const uint32_t perThread = (uint32_t)ceilf((float)d.numTriangles / (float)threadsY);
+        const LmEntry& e = r->entries[d.tableIndex];
+        const Primitive& pr = r->prims[r->entryPrim[d.tableIndex]];
+        const Material& mat = r->materials[e.material];
+        for (uint32_t ty = 0; ty < threadsY; ty++) {
+            const uint32_t start = ty * perThread;
+            if (!(start < d.numTriangles - 1u)) continue;      // reference behaviour: a slice that starts at the last triangle is dropped (GPUDataBufferKernels.cu:37)
+            const uint32_t num = (start + perThread) < d.numTriangles ? perThread : d.numTriangles - start;
+            for (uint32_t k = 0; k < num; k++) {
+                const uint32_t tri = start + k;
+                LmLight out; memset(&out, 0, sizeof out);       // reserved slot that is never set: zero light
+                if ((e.mode == 0u && pr.emissive[tri]) || e.mode == 2u) {
+                    const Vertex48 &v0 = pr.verts[pr.idx[tri * 3]], &v1 = pr.verts[pr.idx[tri * 3 + 1]], &v2 = pr.verts[pr.idx[tri * 3 + 2]];
+                    float p0[3], p1[3], p2[3];
+                    mulPoint(e.m, v0.pos, 1.f, p0); mulPoint(e.m, v1.pos, 1.f, p1); mulPoint(e.m, v2.pos, 1.f, p2);
+                    constexpr float oneThird = 1.f / 3.f;
+                    const float uvx = (v0.uv[0] + v1.uv[0] + v2.uv[0]) * oneThird, uvy = (v0.uv[1] + v1.uv[1] + v2.uv[1]) * oneThird;
+                    float em[4] = {0, 0, 0, 0};
+                    if (e.mode == 0u) {
+                        float t[4]; tex2D(r, mat.dev.tex[4], uvx, uvy, t);
+                        const float me[4] = {mat.dev.emissive.x * e.emissive.w, mat.dev.emissive.y * e.emissive.w, mat.dev.emissive.z * e.emissive.w, mat.dev.emissive.w * e.emissive.w};
+                        for (int q = 0; q < 4; q++) em[q] = t[q] * me[q];
+                    } else {
+                        em[0] = e.emissive.x * e.emissive.w; em[1] = e.emissive.y * e.emissive.w; em[2] = e.emissive.z * e.emissive.w; em[3] = e.emissive.w * e.emissive.w;
+                    }
+                    if (em[0] > 0.f || em[1] > 0.f || em[2] > 0.f) {
+                        const float nl[3] = {(v0.normal[0] + v1.normal[0] + v2.normal[0]) * oneThird, (v0.normal[1] + v1.normal[1] + v2.normal[1]) * oneThird,
+                                             (v0.normal[2] + v1.normal[2] + v2.normal[2]) * oneThird};
+                        float nw[3];
+                        mulPoint(e.m, nl, 0.f, nw);
+                        const float inv = 1.0f / sqrtf(nw[0] * nw[0] + nw[1] * nw[1] + nw[2] * nw[2]);
+                        nw[0] *= inv; nw[1] *= inv; nw[2] *= inv;
+                        const float a[3] = {p0[0] - p1[0], p0[1] - p1[1], p0[2] - p1[2]}, b[3] = {p0[0] - p2[0], p0[1] - p2[1], p0[2] - p2[2]};
+                        const float cx = (a[1] * b[2] - b[1] * a[2]), cy = (a[0] * b[2] - b[0] * a[2]), cz = (a[0] * b[1] - b[0] * a[1]);
+                        const float area = sqrtf(cx * cx + cy * cy + cz * cz) / 2.0f;
+                        out.a = make_float4(p0[0], p0[1], p0[2], p1[0]);
+                        out.b = make_float4(p1[1], p1[2], p2[0], p2[1]);
+                        out.c = make_float4(p2[2], nw[0], nw[1], nw[2]);
+                        out.d = make_float4(em[0], em[1], em[2], area);
+                    }
+                }
+                L.push_back(out);
+            }
+        }
+    }
+    auto key = [](const LmLight& l) { return (l.d.x + l.d.y + l.d.z) / 3.f; };
+    std::stable_sort(L.begin(), L.end(), [&](const LmLight& a, const LmLight& b) { return key(a) < key(b); });
+    r->cdf.resize(L.size());
+    double acc = 0;
+    for (size_t i = 0; i < L.size(); i++) { acc += (double)key(L[i]); r->cdf[i] = (float)acc; }
+    r->lights.swap(L);
+    r->totalEmissive = total;
+    if (r->dLights.upload(r->lights, r->stream) || r->dCdf.upload(r->cdf, r->stream)) return fail(LUMEN_MI_ERR_DEVICE, "light upload failed");
+    if (hipStreamSynchronize(r->stream) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "light upload sync failed");
+    r->dscene.lights = r->dLights.p; r->dscene.cdf = r->dCdf.p;
+    r->dscene.numLights = (uint32_t)r->lights.size();
+    r->dscene.cdfSum = r->cdf.empty() ? 0.f : r->cdf.back();
+    r->lightsDirty = false;
+    return 0;
+}
+
+int ensureFrameBuffers(R* r)
+{
+    const uint32_t W = r->settings.render_width, H = r->settings.render_height;
+    if (!r->windowSet) { r->wx0 = 0; r->wy0 = 0; r->wx1 = W; r->wy1 = H; }
+    if (r->wx1 > W || r->wy1 > H || r->wx0 >= r->wx1 || r->wy0 >= r->wy1) return fail(LUMEN_MI_ERR_INVALID, "render window outside the image");
+    const uint32_t ww = r->wx1 - r->wx0, wh = r->wy1 - r->wy0, n = ww * wh;
+    LmFrame& f = r->fr;
+    const bool realloc = n != r->allocN || f.W != W || f.H != H || f.x0 != r->wx0 || f.y0 != r->wy0 || f.ww != ww;
+    f.W = W; f.H = H; f.x0 = r->wx0; f.y0 = r->wy0; f.ww = ww; f.wh = wh; f.n = n;
+    if (!realloc) return 0;
+    int bad = 0;
+    for (int i = 0; i < 6; i++) bad |= r->dRay[i].ensure(n);
+    for (int i = 0; i < 3; i++) bad |= r->dSh[i].ensure(n);
+    for (int i = 0; i < 2; i++) bad |= r->dGbuf[i].ensure((size_t)8 * n);
+    for (int i = 0; i < 4; i++) bad |= r->dRes[i].ensure((size_t)5 * n);
+    bad |= r->dDirect.ensure(n) | r->dIndirect.ensure(n) | r->dCombined.ensure(n) | r->dHits.ensure(n) | r->dMotion.ensure(n) | r->dOutput.ensure(n);
+    bad |= r->dCounters.ensure(LM_CNT_WORDS) | r->dBags.ensure(50 * 1000);
+    if (bad) return fail(LUMEN_MI_ERR_DEVICE, "frame buffer allocation failed");
+    for (int q = 0; q < 2; q++) { f.rayO[q] = r->dRay[3 * q].p; f.rayD[q] = r->dRay[3 * q + 1].p; f.rayC[q] = r->dRay[3 * q + 2].p; }
+    f.shO = r->dSh[0].p; f.shD = r->dSh[1].p; f.shR = r->dSh[2].p;
+    f.hits = r->dHits.p;
+    for (int i = 0; i < 2; i++) f.gbuf[i] = r->dGbuf[i].p;
+    for (int i = 0; i < 4; i++) f.res[i] = r->dRes[i].p;
+    f.motion = r->dMotion.p; f.direct = r->dDirect.p; f.indirect = r->dIndirect.p; f.combined = r->dCombined.p; f.output = r->dOutput.p;
+    f.counters = r->dCounters.p; f.bags = r->dBags.p;
+    // ResizeBuffers (WaveFrontRenderer.cpp:1424-1540): history is dropped; reservoirs reset (ReSTIRKernels.cu:36-47)
+    hipStream_t st = r->stream;
+    for (int i = 0; i < 2; i++) if (hipMemsetAsync(f.gbuf[i], 0, (size_t)8 * n * sizeof(float4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
+    for (int i = 0; i < 4; i++) if (hipMemsetAsync(f.res[i], 0, (size_t)5 * n * sizeof(float4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
+    if (hipMemsetAsync(f.combined, 0, (size_t)n * sizeof(float4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
+    if (hipMemsetAsync(f.output, 0, (size_t)n * sizeof(uchar4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
+    r->allocN = n;
+    r->blendCounter = 0; r->frameIndex = 0; r->swapChainIndex = 0;
+    return 0;
+}
+
+void invert4(const float* m, float* out)
+{
+    double a[16], inv[16];
+    for (int i = 0; i < 16; i++) a[i] = m[i];
+    inv[0] = a[5]*a[10]*a[15] - a[5]*a[11]*a[14] - a[9]*a[6]*a[15] + a[9]*a[7]*a[14] + a[13]*a[6]*a[11] - a[13]*a[7]*a[10];
+    inv[4] = -a[4]*a[10]*a[15] + a[4]*a[11]*a[14] + a[8]*a[6]*a[15] - a[8]*a[7]*a[14] - a[12]*a[6]*a[11] + a[12]*a[7]*a[10];
+    inv[8] = a[4]*a[9]*a[15] - a[4]*a[11]*a[13] - a[8]*a[5]*a[15] + a[8]*a[7]*a[13] + a[12]*a[5]*a[11] - a[12]*a[7]*a[9];
+    inv[12] = -a[4]*a[9]*a[14] + a[4]*a[10]*a[13] + a[8]*a[5]*a[14] - a[8]*a[6]*a[13] - a[12]*a[5]*a[10] + a[12]*a[6]*a[9];
+    inv[1] = -a[1]*a[10]*a[15] + a[1]*a[11]*a[14] + a[9]*a[2]*a[15] - a[9]*a[3]*a[14] - a[13]*a[2]*a[11] + a[13]*a[3]*a[10];
+    inv[5] = a[0]*a[10]*a[15] - a[0]*a[11]*a[14] - a[8]*a[2]*a[15] + a[8]*a[3]*a[14] + a[12]*a[2]*a[11] - a[12]*a[3]*a[10];
+    inv[9] = -a[0]*a[9]*a[15] + a[0]*a[11]*a[13] + a[8]*a[1]*a[15] - a[8]*a[3]*a[13] - a[12]*a[1]*a[11] + a[12]*a[3]*a[9];
+    inv[13] = a[0]*a[9]*a[14] - a[0]*a[10]*a[13] - a[8]*a[1]*a[14] + a[8]*a[2]*a[13] + a[12]*a[1]*a[10] - a[12]*a[2]*a[9];
+    inv[2] = a[1]*a[6]*a[15] - a[1]*a[7]*a[14] - a[5]*a[2]*a[15] + a[5]*a[3]*a[14] + a[13]*a[2]*a[7] - a[13]*a[3]*a[6];
+    inv[6] = -a[0]*a[6]*a[15] + a[0]*a[7]*a[14] + a[4]*a[2]*a[15] - a[4]*a[3]*a[14] - a[12]*a[2]*a[7] + a[12]*a[3]*a[6];
+    inv[10] = a[0]*a[5]*a[15] - a[0]*a[7]*a[13] - a[4]*a[1]*a[15] + a[4]*a[3]*a[13] + a[12]*a[1]*a[7] - a[12]*a[3]*a[5];
+    inv[14] = -a[0]*a[5]*a[14] + a[0]*a[6]*a[13] + a[4]*a[1]*a[14] - a[4]*a[2]*a[13] - a[12]*a[1]*a[6] + a[12]*a[2]*a[5];
+    inv[3] = -a[1]*a[6]*a[11] + a[1]*a[7]*a[10] + a[5]*a[2]*a[11] - a[5]*a[3]*a[10] - a[9]*a[2]*a[7] + a[9]*a[3]*a[6];
+    inv[7] = a[0]*a[6]*a[11] - a[0]*a[7]*a[10] - a[4]*a[2]*a[11] + a[4]*a[3]*a[10] + a[8]*a[2]*a[7] - a[8]*a[3]*a[6];
+    inv[11] = -a[0]*a[5]*a[11] + a[0]*a[7]*a[9] + a[4]*a[1]*a[11] - a[4]*a[3]*a[9] - a[8]*a[1]*a[7] + a[8]*a[3]*a[5];
+    inv[15] = a[0]*a[5]*a[10] - a[0]*a[6]*a[9] - a[4]*a[1]*a[10] + a[4]*a[2]*a[9] + a[8]*a[1]*a[6] - a[8]*a[2]*a[5];
+    const double det = a[0]*inv[0] + a[1]*inv[4] + a[2]*inv[8] + a[3]*inv[12];
+    for (int i = 0; i < 16; i++) out[i] = (float)(inv[i] / det);
+}
+
+// timing helpers: HIP events on the renderer's own stream
+void evBegin(R* r, int cls, size_t& slot)
+{
+    slot = (size_t)-1;
+    if (!r->timing) return;
+    if (r->evUsed == r->evPool.size()) { R::EvPair p; if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return; p.cls = 0; r->evPool.push_back(p); }
+    slot = r->evUsed++;
+    r->evPool[slot].cls = cls;
+    (void)hipEventRecord(r->evPool[slot].a, r->stream);
+}
+void evEnd(R* r, size_t slot) { if (slot != (size_t)-1) (void)hipEventRecord(r->evPool[slot].b, r->stream); }
+
+int traceFrameAsync(R* r)
+{
+    if (!r->initialised) return fail(LUMEN_MI_ERR_STATE, "lumen_mi_init has not been called");
+    { std::lock_guard<std::mutex> lk(r->settingsMutex); r->settings = r->pending; }          // WaveFrontRenderer.cpp:480-505
+    if (hipSetDevice(r->device) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "hipSetDevice failed");
+    int rc;
+    if ((rc = uploadResources(r))) return rc;
+    if ((rc = flatten(r))) return rc;
+    if ((rc = buildLights(r))) return rc;                                                     // :456
+    r->countersValid = false;
+    if (r->totalEmissive == 0 || r->lights.empty()) return LUMEN_MI_NO_LIGHTS;                // :459-464
+    if ((rc = ensureFrameBuffers(r))) return rc;
+    const LmKernelTable* K = r->K;
+    hipStream_t st = r->stream;
+    LmFrame& fr = r->fr;
+    const uint32_t depthMax = std::min<uint32_t>(r->settings.depth, LM_MAX_DEPTH);
+    const int currentIndex = r->frameIndex, temporalIndex = r->frameIndex == 1 ? 0 : 1;
+    const bool blend = r->settings.blend_output != 0;
+
+    // camera (Camera.cpp:79-93,122-140; aspect = render W/H, WaveFrontRenderer.cpp:577)
+    LmCamera cam;
+    const float aspect = (float)fr.W / (float)fr.H;
+    const float halfY = 1.0f * (float)tan((double)(r->fovY * 0.01745329251994329576923690768489f) * 0.5);
+    const float halfX = halfY * aspect;
+    for (int k = 0; k < 3; k++) { cam.eye[k] = r->camPos[k]; cam.U[k] = r->camRight[k] * halfX; cam.V[k] = r->camUp[k] * halfY; cam.Wv[k] = r->camFwd[k] * 1.0f; }
+    float camWorld[16] = {r->camRight[0], r->camUp[0], r->camFwd[0], r->camPos[0], r->camRight[1], r->camUp[1], r->camFwd[1], r->camPos[1],
+                          r->camRight[2], r->camUp[2], r->camFwd[2], r->camPos[2], 0, 0, 0, 1};
+    if (!r->havePrev) { memcpy(r->prevCamWorld, camWorld, sizeof camWorld); r->havePrev = true; }
+    {   // M = projection(fovY, aspect, 0.5, 10000) * inverse(previous camera world matrix)   (WaveFrontRenderer.cpp:763-776)
+        float proj[16] = {0}, invPrev[16];
+        const float tanHalf = (float)tan((double)(r->fovY * 0.01745329251994329576923690768489f) / 2.0);
+        const float zn = 0.5f, zf = 10000.f;
+        proj[0] = 1.0f / (aspect * tanHalf); proj[5] = 1.0f / tanHalf;
+        proj[10] = -(zf + zn) / (zf - zn); proj[11] = -(2.0f * zf * zn) / (zf - zn); proj[14] = -1.0f;
+        invert4(r->prevCamWorld, invPrev);
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { float s = 0.f; for (int k = 0; k < 4; k++) s += proj[i * 4 + k] * invPrev[k * 4 + j]; cam.prevViewProj[i * 4 + j] = s; }
+    }
+
+    size_t evAll; evBegin(r, 4, evAll);
+    LM_HIP(hipMemsetAsync(fr.counters, 0, LM_CNT_WORDS * sizeof(uint32_t), st));
+    if (!blend) K->clear(st, r->gridFor(fr.n, 8), fr.combined, fr.n);                        // :559
+    ++r->frameCount;                                                                          // :593
+    K->primary(st, r->gridFor(fr.n, 8), fr, cam, r->frameCount);
+    uint32_t seed = wangHash(r->frameCount);                                                  // :685
+    int q = 0;
+    const int traceGrid = r->numCU * 12;
+    size_t ev;
+    for (uint32_t depth = 0; depth < depthMax; ++depth) {
+        uint32_t* inCount = fr.counters + LM_CNT_RAYS(depth);
+        uint32_t* outCount = fr.counters + LM_CNT_RAYS(depth + 1);
+        evBegin(r, 0, ev);
+        K->trace_closest(st, traceGrid, r->dscene, fr.rayO[q], fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters);   // :678,:703
+        evEnd(r, ev);
+        const uint32_t seed2 = wangHash(seed);                                                // CPUShadingKernels.cu:178
+        const int doIndirect = depth < depthMax - 1 ? 1 : 0;
+        if (depth == 0) {
+            evBegin(r, 2, ev);
+            K->extract0(st, r->gridFor(fr.n, 8), r->dscene, fr, cam, currentIndex);
+            evEnd(r, ev);
+            // ReSTIR::Run (Framework/ReSTIR.cpp:65-233)
+            evBegin(r, 3, ev);
+            const int cur = r->swapChainIndex, tmp = cur == 1 ? 0 : 1;
+            uint32_t rs = wangHash(seed);
+            K->fill_bags(st, r->dscene, fr, seed, 50u * 1000u);
+            rs = wangHash(rs);
+            const uint32_t tx0 = fr.x0 / 16u, ty0 = fr.y0 / 16u;
+            const uint32_t wtx = (fr.x0 + fr.ww + 15u) / 16u - tx0, wty = (fr.y0 + fr.wh + 15u) / 16u - ty0;
+            K->pick_primary(st, (int)(wtx * wty), r->dscene, fr, currentIndex, fr.res[cur], rs);
+            const int g8 = r->gridFor(fr.n, 8);
+            K->visibility_shade(st, traceGrid, r->dscene, fr, currentIndex, fr.res[cur]);
+            rs = wangHash(rs);
+            K->temporal(st, g8, fr, currentIndex, temporalIndex, fr.res[cur], fr.res[tmp], rs);
+            rs = wangHash(rs);
+            K->spatial(st, g8, fr, currentIndex, fr.res[cur], fr.res[2], rs);
+            K->spatial(st, g8, fr, currentIndex, fr.res[2], fr.res[3], rs);
+            K->visibility_shade(st, traceGrid, r->dscene, fr, currentIndex, fr.res[cur]);
+            K->combine(st, g8, fr, currentIndex, fr.res[cur], fr.res[3], wangHash(rs));
+            evEnd(r, ev);
+            if (doIndirect) { evBegin(r, 2, ev); K->shade_indirect0(st, g8, fr, currentIndex, seed2, q ^ 1, outCount); evEnd(r, ev); }
+        } else {
+            uint32_t* shCount = fr.counters + LM_CNT_SHADOW(depth);
+            evBegin(r, 2, ev);
+            K->shade_wave(st, r->numCU * 8, r->dscene, fr, q, inCount, seed, seed2, doIndirect, outCount, shCount);
+            evEnd(r, ev);
+            evBegin(r, 1, ev);
+            K->trace_shadow(st, traceGrid, r->dscene, fr, shCount, 0.01f);                   // tmin of the intersection launch (:843)
+            evEnd(r, ev);
+        }
+        q ^= 1;
+        r->swapChainIndex = r->swapChainIndex + 1 >= 2 ? 0 : r->swapChainIndex + 1;         // ReSTIR::SwapBuffers once per wave (:827)
+        seed = wangHash(seed);                                                               // :830
+    }
+    K->merge(st, r->gridFor(fr.n, 8), fr, blend ? 1 : 0, r->blendCounter);
+    evEnd(r, evAll);
+    LM_HIP(hipGetLastError());
+    r->lastDepth = depthMax;
+    r->lastLightCount = r->lights.size();
+    if (blend) ++r->blendCounter;                                                            // :1039-1042
+    r->frameIndex = r->frameIndex + 1 == 2 ? 0 : r->frameIndex + 1;                          // :1045-1049
+    memcpy(r->prevCamWorld, camWorld, sizeof camWorld);                                      // :1051
+    ++r->frameCount;                                                                         // :1052
+    return 0;
+}
+
+int syncAndCollect(R* r)
+{
+    if (!r->initialised) return fail(LUMEN_MI_ERR_STATE, "not initialised");
+    LM_HIP(hipStreamSynchronize(r->stream));
+    if (!r->countersValid && r->fr.counters) {
+        LM_HIP(hipMemcpy(r->hostCounters, r->fr.counters, sizeof r->hostCounters, hipMemcpyDeviceToHost));
+        r->countersValid = true;
+    }
+    if (r->timing && r->evUsed) {
+        for (int c = 0; c < 5; c++) { r->classMs[c] = 0.f; r->classLaunches[c] = 0; }
+        for (size_t i = 0; i < r->evUsed; i++) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, r->evPool[i].a, r->evPool[i].b) == hipSuccess) { r->classMs[r->evPool[i].cls] += ms; r->classLaunches[r->evPool[i].cls]++; }
+        }
+        r->evUsed = 0;
+        r->frameStats["Wavefront Iteration"] = (uint64_t)((r->classMs[0] + r->classMs[2] + r->classMs[3]) * 1000.f);
+        r->frameStats["Shadow Rays"] = (uint64_t)(r->classMs[1] * 1000.f);
+        r->frameStats["ReSTIR"] = (uint64_t)(r->classMs[3] * 1000.f);
+        r->frameStats["Total Frame Time"] = (uint64_t)(r->classMs[4] * 1000.f);
+    }
+    return 0;
+}
+
+}  // namespace
+
+// ==============================================================================================================
+// C ABI
+// ==============================================================================================================
+extern "C" {
+
+const char* lumen_mi_last_error(void) { return g_lastError.c_str(); }
+
+int lumen_mi_create(lumen_mi_renderer** out)
+{
+    if (!out) return fail(LUMEN_MI_ERR_INVALID, "out is NULL");
+    initLut();
+    *out = new lumen_mi_renderer();
+    (*out)->K = lm_kernel_table();
+    return 0;
+}
+
+int lumen_mi_init(lumen_mi_renderer* r, const lumen_mi_settings* s)
+{
+    if (!r || !s) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    if (s->render_width == 0 || s->render_height == 0 || s->render_width > 65535 || s->render_height > 65535) return fail(LUMEN_MI_ERR_INVALID, "render resolution must be in [1, 65535]");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(LUMEN_MI_ERR_DEVICE, "no HIP device: the MI355X path needs a GPU (there is no CPU fallback)");
+    if (s->device < 0 || s->device >= count) return fail(LUMEN_MI_ERR_INVALID, "device ordinal out of range");
+    LM_HIP(hipSetDevice(s->device));
+    hipDeviceProp_t prop;
+    LM_HIP(hipGetDeviceProperties(&prop, s->device));
+    r->numCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    r->device = s->device;
+    r->settings = *s; r->pending = *s;
+    if (r->settings.depth == 0) { r->settings.depth = 5; r->pending.depth = 5; }
+    r->pending.output_width = r->settings.output_width = s->output_width ? s->output_width : s->render_width;
+    r->pending.output_height = r->settings.output_height = s->output_height ? s->output_height : s->render_height;
+    r->initialised = true;
+    return 0;
+}
+
+int lumen_mi_destroy(lumen_mi_renderer* r)
+{
+    if (!r) return 0;
+    lumen_mi_stop_rendering(r);
+    if (r->initialised) {
+        (void)hipSetDevice(r->device);
+        (void)hipStreamSynchronize(r->stream);
+        r->dNodes.release(); r->dWoop.release(); r->dTriId.release(); r->dTriOrder.release(); r->dVerts.release(); r->dIndices.release();
+        r->dEntries.release(); r->dMaterials.release(); r->dTexDesc.release(); r->dTexels.release(); r->dLut.release(); r->dLights.release(); r->dCdf.release();
+        for (auto& b : r->dRay) b.release(); for (auto& b : r->dSh) b.release(); for (auto& b : r->dGbuf) b.release(); for (auto& b : r->dRes) b.release();
+        r->dDirect.release(); r->dIndirect.release(); r->dCombined.release(); r->dHits.release(); r->dMotion.release(); r->dCounters.release(); r->dOutput.release(); r->dBags.release();
+        for (auto& e : r->evPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    }
+    delete r;
+    return 0;
+}
+
+int lumen_mi_set_stream(lumen_mi_renderer* r, void* s) { if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer"); r->stream = (hipStream_t)s; return 0; }
+
+int lumen_mi_create_texture(lumen_mi_renderer* r, const void* rgba8, uint32_t w, uint32_t h, int normalize, lumen_mi_handle* out)
+{
+    if (!r || !rgba8 || !out || w == 0 || h == 0) return fail(LUMEN_MI_ERR_INVALID, "bad texture arguments");
+    Texture t; t.w = w; t.h = h; t.srgb = normalize != 0;          // a_Normalize selects sRGB decode (PTTexture.cpp:57-73)
+    t.px.resize((size_t)w * h);
+    memcpy(t.px.data(), rgba8, (size_t)w * h * 4);
+    r->textures.push_back(std::move(t));
+    r->texturesDirty = true;
+    *out = mkh(H_TEXTURE, r->textures.size() - 1);
+    return 0;
+}
+
+int lumen_mi_create_default_resources(lumen_mi_renderer* r, lumen_mi_handle* white, lumen_mi_handle* normal, lumen_mi_handle* diffuse)
+{
+    // LumenRenderer::CreateDefaultResources (Lumen/src/Lumen/Renderer/LumenRenderer.cpp:50-58): three 1x1 textures, normalize = false
+    const uint8_t w[4] = {255, 255, 255, 255}, n[4] = {128, 128, 255, 0}, d[4] = {255, 255, 255, 255};
+    lumen_mi_handle hw, hn, hd; int rc;
+    if ((rc = lumen_mi_create_texture(r, w, 1, 1, 0, &hw)) || (rc = lumen_mi_create_texture(r, n, 1, 1, 0, &hn)) || (rc = lumen_mi_create_texture(r, d, 1, 1, 0, &hd))) return rc;
+    if (white) *white = hw; if (normal) *normal = hn; if (diffuse) *diffuse = hd;
+    return 0;
+}
+
+int lumen_mi_create_material(lumen_mi_renderer* r, const lumen_mi_material_data* d, lumen_mi_handle* out)
+{
+    if (!r || !d || !out) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    if (!(d->roughness_factor > 0.f)) return fail(LUMEN_MI_ERR_INVALID, "roughness factor must be > 0 (WaveFrontRenderer.cpp:1283)");
+    auto tex = [&](lumen_mi_handle h, int& id) -> bool { if (h == 0) { id = -1; return true; } size_t i; if (!unh(h, H_TEXTURE, r->textures.size(), i)) return false; id = (int)i; return true; };
+    int tDiff, tNorm, tMR, tEm, tTr, tCC, tCCR, tTint;
+    if (!tex(d->diffuse_texture, tDiff) || !tex(d->normal_map, tNorm) || !tex(d->metallic_roughness_texture, tMR) || !tex(d->emissive_texture, tEm) ||
+        !tex(d->transmission_texture, tTr) || !tex(d->clearcoat_texture, tCC) || !tex(d->clearcoat_roughness_texture, tCCR) || !tex(d->tint_texture, tTint))
+        return fail(LUMEN_MI_ERR_INVALID, "bad texture handle in material");
+    // the reference asserts that all eight textures are present (WaveFrontRenderer.cpp:1273-1280)
+    if (tDiff < 0 || tNorm < 0 || tMR < 0 || tEm < 0 || tTr < 0 || tCC < 0 || tCCR < 0 || tTint < 0) return fail(LUMEN_MI_ERR_INVALID, "all eight material textures are required (use the default textures)");
+    Material m; memset(&m, 0, sizeof m);
+    LmDevMaterial& v = m.dev;
+    // PTMaterial(): MaterialData(0), roughness 1 (PTMaterial.cpp:10-19), then the setters in the order of CreateMaterial
+    pack8(v.p[0], 24, 1.f);
+    v.color = make_float4(d->diffuse_color[0], d->diffuse_color[1], d->diffuse_color[2], d->diffuse_color[3]);
+    v.emissive = make_float4(d->emission[0], d->emission[1], d->emission[2], 0.f);
+    for (int k = 0; k < 3; k++) m.emissiveColor[k] = d->emission[k];
+    pack8(v.p[2], 16, d->transmission_factor);
+    pack8(v.p[2], 0, d->clearcoat_factor);
+    pack8(v.p[2], 8, 1.f - d->clearcoat_roughness_factor);       // gloss = 1 - roughness (PTMaterial.cpp:176-181)
+    v.transmittance.w = d->index_of_refraction;
+    pack8(v.p[0], 16, d->specular_factor);
+    pack8(v.p[1], 0, d->specular_tint_factor);
+    pack8(v.p[0], 8, d->subsurface_factor);
+    v.tint.w = d->luminance;
+    pack8(v.p[1], 8, d->anisotropic);
+    pack8(v.p[1], 16, d->sheen_factor);
+    pack8(v.p[1], 24, d->sheen_tint_factor);
+    v.tint = make_float4(d->tint_factor[0], d->tint_factor[1], d->tint_factor[2], v.tint.w);
+    v.transmittance = make_float4(d->transmittance[0], d->transmittance[1], d->transmittance[2], v.transmittance.w);
+    pack8(v.p[0], 24, d->roughness_factor);
+    pack8(v.p[0], 0, d->metallic_factor);
+    // PTMaterial::CreateDeviceMaterial (PTMaterial.cpp:97-148): the clear-coat-roughness texture overwrites the clear-coat
+    // slot and the roughness slot stays a null handle; kept for parity
+    v.tex[0] = tCCR; v.tex[1] = -1; v.tex[2] = tTr; v.tex[3] = tDiff; v.tex[4] = tEm; v.tex[5] = tMR; v.tex[6] = tNorm; v.tex[7] = tTint;
+    r->materials.push_back(m);
+    r->materialsDirty = true;
+    *out = mkh(H_MATERIAL, r->materials.size() - 1);
+    return 0;
+}
+
+int lumen_mi_create_primitive(lumen_mi_renderer* r, const lumen_mi_primitive_data* d, lumen_mi_handle* out, uint32_t* numLights)
+{
+    if (!r || !d || !out) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    size_t mat;
+    if (!unh(d->material, H_MATERIAL, r->materials.size(), mat)) return fail(LUMEN_MI_ERR_INVALID, "bad material handle");
+    if (d->n_vertices == 0 || d->n_indices < 3 || !d->index_binary || (d->index_size != 2 && d->index_size != 4)) return fail(LUMEN_MI_ERR_INVALID, "bad primitive data");
+    Primitive p;
+    p.material = mat;
+    p.verts.resize(d->n_vertices);
+    if (d->interleaved) {
+        if (!d->vertex_binary) return fail(LUMEN_MI_ERR_INVALID, "interleaved primitive without vertex_binary");
+        memcpy(p.verts.data(), d->vertex_binary, (size_t)d->n_vertices * 48);
+    } else {
+        // InterleaveVertexData (WaveFrontRenderer.cpp:1091-1107): absent attributes stay zero
+        if (!d->positions) return fail(LUMEN_MI_ERR_INVALID, "primitive without positions");
+        memset(p.verts.data(), 0, (size_t)d->n_vertices * 48);
+        for (uint32_t i = 0; i < d->n_vertices; i++) {
+            memcpy(p.verts[i].pos, d->positions + 3 * i, 12);
+            if (d->tex_coords) memcpy(p.verts[i].uv, d->tex_coords + 2 * i, 8);
+            if (d->normals) memcpy(p.verts[i].normal, d->normals + 3 * i, 12);
+            if (d->tangents) memcpy(p.verts[i].tangent, d->tangents + 4 * i, 16);
+        }
+    }
+    p.idx.resize(d->n_indices);                                   // 16-bit indices are widened (WaveFrontRenderer.cpp:1161-1181)
+    if (d->index_size == 2) { const uint16_t* s = (const uint16_t*)d->index_binary; for (uint32_t i = 0; i < d->n_indices; i++) p.idx[i] = s[i]; }
+    else memcpy(p.idx.data(), d->index_binary, (size_t)d->n_indices * 4);
+    for (uint32_t i : p.idx) if (i >= d->n_vertices) return fail(LUMEN_MI_ERR_INVALID, "index out of range");
+    findEmissives(r, p);
+    if (numLights) *numLights = p.numLights;
+    r->prims.push_back(std::move(p));
+    r->sceneDirty = true;
+    *out = mkh(H_PRIMITIVE, r->prims.size() - 1);
+    return 0;
+}
+
+int lumen_mi_create_mesh(lumen_mi_renderer* r, const lumen_mi_handle* prims, uint32_t n, lumen_mi_handle* out)
+{
+    if (!r || !prims || !out || n == 0) return fail(LUMEN_MI_ERR_INVALID, "bad mesh arguments");
+    Mesh m;
+    for (uint32_t i = 0; i < n; i++) { size_t p; if (!unh(prims[i], H_PRIMITIVE, r->prims.size(), p)) return fail(LUMEN_MI_ERR_INVALID, "bad primitive handle"); m.prims.push_back(p); }
+    r->meshes.push_back(m);
+    *out = mkh(H_MESH, r->meshes.size() - 1);
+    return 0;
+}
+
+int lumen_mi_create_scene(lumen_mi_renderer* r, lumen_mi_handle* out)
+{
+    if (!r || !out) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    r->scenes.emplace_back();
+    *out = mkh(H_SCENE, r->scenes.size() - 1);
+    return 0;
+}
+
+int lumen_mi_set_scene(lumen_mi_renderer* r, lumen_mi_handle scene)
+{
+    size_t s;
+    if (!r || !unh(scene, H_SCENE, r->scenes.size(), s)) return fail(LUMEN_MI_ERR_INVALID, "bad scene handle");
+    r->activeScene = (long)s; r->sceneDirty = true;
+    return 0;
+}
+
+int lumen_mi_scene_add_mesh(lumen_mi_renderer* r, lumen_mi_handle scene, lumen_mi_handle mesh, lumen_mi_handle* inst)
+{
+    size_t s, m;
+    if (!r || !inst || !unh(scene, H_SCENE, r->scenes.size(), s) || !unh(mesh, H_MESH, r->meshes.size(), m)) return fail(LUMEN_MI_ERR_INVALID, "bad scene/mesh handle");
+    Instance i;
+    i.scene = s; i.mesh = m;
+    const float id[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    memcpy(i.M, id, sizeof id);
+    i.mode = LUMEN_MI_EMISSION_ENABLED; i.radiance[0] = i.radiance[1] = i.radiance[2] = 0.f; i.scale = 1.f; i.overrideMaterial = -1;   // MeshInstance.h:24-35
+    r->instances.push_back(i);
+    r->scenes[s].instances.push_back(r->instances.size() - 1);
+    r->sceneDirty = true;
+    *inst = mkh(H_INSTANCE, r->instances.size() - 1);
+    return 0;
+}
+
+int lumen_mi_scene_clear(lumen_mi_renderer* r, lumen_mi_handle scene)
+{
+    size_t s;
+    if (!r || !unh(scene, H_SCENE, r->scenes.size(), s)) return fail(LUMEN_MI_ERR_INVALID, "bad scene handle");
+    r->scenes[s].instances.clear(); r->sceneDirty = true;
+    return 0;
+}
+
+int lumen_mi_instance_set_transform(lumen_mi_renderer* r, lumen_mi_handle inst, const float m[16])
+{
+    size_t i;
+    if (!r || !m || !unh(inst, H_INSTANCE, r->instances.size(), i)) return fail(LUMEN_MI_ERR_INVALID, "bad instance handle");
+    memcpy(r->instances[i].M, m, 64); r->sceneDirty = true;
+    return 0;
+}
+
+int lumen_mi_instance_set_emissiveness(lumen_mi_renderer* r, lumen_mi_handle inst, int mode, const float rad[3], float scale)
+{
+    size_t i;
+    if (!r || !rad || mode < 0 || mode > 2 || !unh(inst, H_INSTANCE, r->instances.size(), i)) return fail(LUMEN_MI_ERR_INVALID, "bad emissiveness arguments");
+    Instance& x = r->instances[i];
+    x.mode = mode; x.radiance[0] = rad[0]; x.radiance[1] = rad[1]; x.radiance[2] = rad[2]; x.scale = scale;
+    r->sceneDirty = true;
+    return 0;
+}
+
+int lumen_mi_instance_set_override_material(lumen_mi_renderer* r, lumen_mi_handle inst, lumen_mi_handle mat)
+{
+    size_t i, m;
+    if (!r || !unh(inst, H_INSTANCE, r->instances.size(), i) || !unh(mat, H_MATERIAL, r->materials.size(), m)) return fail(LUMEN_MI_ERR_INVALID, "bad handle");
+    r->instances[i].overrideMaterial = (long)m; r->sceneDirty = true;
+    return 0;
+}
+
+int lumen_mi_camera_set(lumen_mi_renderer* r, const float p[3], const float right[3], const float up[3], const float fwd[3], float fov)
+{
+    if (!r || !p || !right || !up || !fwd) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    for (int k = 0; k < 3; k++) { r->camPos[k] = p[k]; r->camRight[k] = right[k]; r->camUp[k] = up[k]; r->camFwd[k] = fwd[k]; }
+    r->fovY = fov;
+    return 0;
+}
+
+int lumen_mi_set_render_resolution(lumen_mi_renderer* r, uint32_t w, uint32_t h)
+{
+    if (!r || w == 0 || h == 0 || w > 65535 || h > 65535) return fail(LUMEN_MI_ERR_INVALID, "bad resolution");
+    std::lock_guard<std::mutex> lk(r->settingsMutex);
+    r->pending.render_width = w; r->pending.render_height = h;
+    r->pending.output_width = w; r->pending.output_height = h;     // WaveFrontRenderer.cpp:352
+    return 0;
+}
+int lumen_mi_set_output_resolution(lumen_mi_renderer* r, uint32_t w, uint32_t h)
+{
+    if (!r || w == 0 || h == 0) return fail(LUMEN_MI_ERR_INVALID, "bad resolution");
+    std::lock_guard<std::mutex> lk(r->settingsMutex);
+    r->pending.output_width = w; r->pending.output_height = h;
+    return 0;
+}
+int lumen_mi_get_render_resolution(lumen_mi_renderer* r, uint32_t* w, uint32_t* h) { if (!r || !w || !h) return fail(LUMEN_MI_ERR_INVALID, "NULL argument"); *w = r->pending.render_width; *h = r->pending.render_height; return 0; }
+int lumen_mi_get_output_resolution(lumen_mi_renderer* r, uint32_t* w, uint32_t* h) { if (!r || !w || !h) return fail(LUMEN_MI_ERR_INVALID, "NULL argument"); *w = r->pending.output_width; *h = r->pending.output_height; return 0; }
+int lumen_mi_set_blend_mode(lumen_mi_renderer* r, int b) { if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer"); r->pending.blend_output = b ? 1 : 0; if (b) r->blendCounter = 0; return 0; }
+int lumen_mi_get_blend_mode(lumen_mi_renderer* r, int* b) { if (!r || !b) return fail(LUMEN_MI_ERR_INVALID, "NULL argument"); *b = r->pending.blend_output; return 0; }
+int lumen_mi_set_depth(lumen_mi_renderer* r, uint32_t d) { if (!r || d == 0 || d > LM_MAX_DEPTH) return fail(LUMEN_MI_ERR_INVALID, "depth must be in [1, 16]"); r->pending.depth = d; return 0; }
+
+int lumen_mi_trace_frame_async(lumen_mi_renderer* r) { if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer"); std::lock_guard<std::mutex> lk(r->frameMutex); return traceFrameAsync(r); }
+int lumen_mi_synchronize(lumen_mi_renderer* r) { if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer"); std::lock_guard<std::mutex> lk(r->frameMutex); return syncAndCollect(r); }
+int lumen_mi_trace_frame(lumen_mi_renderer* r)
+{
+    if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer");
+    std::lock_guard<std::mutex> lk(r->frameMutex);
+    const int rc = traceFrameAsync(r);
+    if (rc) return rc;
+    return syncAndCollect(r);
+}
+int lumen_mi_start_rendering(lumen_mi_renderer* r)
+{
+    if (!r || !r->initialised) return fail(LUMEN_MI_ERR_STATE, "not initialised");
+    if (r->renderThread.joinable()) return 0;
+    r->stopFlag = false;
+    r->renderThread = std::thread([r] { while (!r->stopFlag.load()) { if (lumen_mi_trace_frame(r) != 0) std::this_thread::sleep_for(std::chrono::milliseconds(5)); } });
+    return 0;
+}
+int lumen_mi_stop_rendering(lumen_mi_renderer* r)
+{
+    if (!r) return 0;
+    if (r->renderThread.joinable()) { r->stopFlag = true; r->renderThread.join(); }
+    return 0;
+}
+int lumen_mi_perform_deferred_operations(lumen_mi_renderer*) { return 0; }
+
+static int copyOut(lumen_mi_renderer* r, const void* dev, size_t bytes, void* host, size_t capacity)
+{
+    if (!r || !host) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    if (!dev) return fail(LUMEN_MI_ERR_STATE, "no frame has been traced yet");
+    if (capacity < bytes) return fail(LUMEN_MI_ERR_INVALID, "buffer too small");
+    std::lock_guard<std::mutex> lk(r->frameMutex);
+    int rc = syncAndCollect(r);
+    if (rc) return rc;
+    LM_HIP(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+int lumen_mi_get_output_pixels(lumen_mi_renderer* r, uint8_t* rgba8, size_t cap, uint32_t* w, uint32_t* h)
+{
+    if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer");
+    if (w) *w = r->fr.ww; if (h) *h = r->fr.wh;
+    return copyOut(r, r->fr.output, (size_t)r->fr.n * 4, rgba8, cap);
+}
+int lumen_mi_get_radiance(lumen_mi_renderer* r, float* out, size_t cap) { if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer"); return copyOut(r, r->fr.combined, (size_t)r->fr.n * 16, out, cap); }
+int lumen_mi_get_channel(lumen_mi_renderer* r, int ch, float* out, size_t cap)
+{
+    if (!r || ch < 0 || ch > 1) return fail(LUMEN_MI_ERR_INVALID, "channel must be 0 (DIRECT) or 1 (INDIRECT)");
+    return copyOut(r, ch == 0 ? r->fr.direct : r->fr.indirect, (size_t)r->fr.n * 16, out, cap);
+}
+int lumen_mi_copy_radiance_device(lumen_mi_renderer* r, void* dst)
+{
+    if (!r || !dst) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    if (!r->fr.combined) return fail(LUMEN_MI_ERR_STATE, "no frame has been traced yet");
+    LM_HIP(hipMemcpyAsync(dst, r->fr.combined, (size_t)r->fr.n * 16, hipMemcpyDeviceToDevice, r->stream));
+    return 0;
+}
+int lumen_mi_get_gbuffer(lumen_mi_renderer* r, float* out, size_t cap)
+{
+    if (!r || !out) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    const uint32_t n = r->fr.n;
+    if (cap < (size_t)n * 128) return fail(LUMEN_MI_ERR_INVALID, "buffer too small");
+    const int last = r->frameIndex == 0 ? 1 : 0;
+    std::vector<float> planes((size_t)n * 32);
+    int rc = copyOut(r, r->fr.gbuf[last], (size_t)n * 128, planes.data(), (size_t)n * 128);
+    if (rc) return rc;
+    for (uint32_t i = 0; i < n; i++) for (int p = 0; p < 8; p++) memcpy(out + ((size_t)i * 8 + p) * 4, planes.data() + ((size_t)p * n + i) * 4, 16);
+    return 0;
+}
+
+int lumen_mi_get_frame_stat(lumen_mi_renderer* r, const char* key, uint64_t* us)
+{
+    if (!r || !key || !us) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    auto it = r->frameStats.find(key);
+    if (it == r->frameStats.end()) return fail(LUMEN_MI_ERR_INVALID, std::string("no such frame-stat key: ") + key);
+    *us = it->second;
+    return 0;
+}
+int lumen_mi_get_counters(lumen_mi_renderer* r, uint64_t* out, uint32_t n)
+{
+    if (!r || !out) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    { std::lock_guard<std::mutex> lk(r->frameMutex); int rc = syncAndCollect(r); if (rc) return rc; }
+    uint64_t v[24] = {0};
+    const uint32_t* c = r->hostCounters;
+    for (uint32_t d = 0; d < r->lastDepth && d < 16; d++) { v[0] += c[LM_CNT_RAYS(d)]; v[4 + d] = c[LM_CNT_RAYS(d)]; v[1] += c[LM_CNT_SHADOW(d)]; }
+    v[2] = c[LM_CNT_RESTIR];
+    v[3] = r->lastLightCount;
+    v[20] = (uint64_t)c[LM_CNT_NODES] | ((uint64_t)c[LM_CNT_NODES + 1] << 32);
+    v[21] = (uint64_t)c[LM_CNT_TRIS] | ((uint64_t)c[LM_CNT_TRIS + 1] << 32);
+    for (uint32_t i = 0; i < n && i < 24; i++) out[i] = v[i];
+    return 0;
+}
+int lumen_mi_get_kernel_time(lumen_mi_renderer* r, int which, float* ms, uint32_t* launches)
+{
+    if (!r || which < 0 || which > 4) return fail(LUMEN_MI_ERR_INVALID, "bad kernel class");
+    if (ms) *ms = r->classMs[which]; if (launches) *launches = r->classLaunches[which];
+    return 0;
+}
+int lumen_mi_enable_kernel_timing(lumen_mi_renderer* r, int e) { if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer"); r->timing = e != 0; return 0; }
+int lumen_mi_set_instrumented(lumen_mi_renderer* r, int e) { if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer"); r->instrumented = e != 0; r->K = e ? lm_kernel_table_instrumented() : lm_kernel_table(); return 0; }
+
+int lumen_mi_set_window(lumen_mi_renderer* r, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1)
+{
+    if (!r || x0 >= x1 || y0 >= y1) return fail(LUMEN_MI_ERR_INVALID, "empty window");
+    r->wx0 = x0; r->wy0 = y0; r->wx1 = x1; r->wy1 = y1; r->windowSet = true;
+    return 0;
+}
+
+static int prepareScene(lumen_mi_renderer* r)
+{
+    if (!r || !r->initialised) return fail(LUMEN_MI_ERR_STATE, "not initialised");
+    if (hipSetDevice(r->device) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "hipSetDevice failed");
+    int rc;
+    if ((rc = uploadResources(r))) return rc;
+    if ((rc = flatten(r))) return rc;
+    if ((rc = r->dCounters.ensure(LM_CNT_WORDS))) return fail(LUMEN_MI_ERR_DEVICE, "counter allocation failed");
+    return 0;
+}
+
+int lumen_mi_query_closest(lumen_mi_renderer* r, uint32_t n, const float* o, const float* d, float tmin, float tmax, uint32_t* ip, float* uvt)
+{
+    if (!r || !o || !d || !ip || !uvt) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lk(r->frameMutex);
+    int rc = prepareScene(r); if (rc) return rc;
+    std::vector<float4> ho(n), hd(n);
+    for (uint32_t i = 0; i < n; i++) { ho[i] = make_float4(o[3*i], o[3*i+1], o[3*i+2], 0.f); hd[i] = make_float4(d[3*i], d[3*i+1], d[3*i+2], 0.f); }
+    DevBuf<float4> dO, dD, dU; DevBuf<uint4> dI;
+    if (dO.upload(ho, r->stream) || dD.upload(hd, r->stream) || dU.ensure(n) || dI.ensure(n)) return fail(LUMEN_MI_ERR_DEVICE, "query allocation failed");
+    r->K->query_closest(r->stream, r->numCU * 12, r->dscene, dO.p, dD.p, n, tmin, tmax, dI.p, dU.p, r->dCounters.p);
+    std::vector<uint4> hi(n); std::vector<float4> hu(n);
+    LM_HIP(hipStreamSynchronize(r->stream));
+    LM_HIP(hipMemcpy(hi.data(), dI.p, (size_t)n * 16, hipMemcpyDeviceToHost));
+    LM_HIP(hipMemcpy(hu.data(), dU.p, (size_t)n * 16, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; i++) { ip[2*i] = hi[i].x; ip[2*i+1] = hi[i].y; uvt[3*i] = hu[i].x; uvt[3*i+1] = hu[i].y; uvt[3*i+2] = hu[i].z; }
+    dO.release(); dD.release(); dU.release(); dI.release();
+    return 0;
+}
+int lumen_mi_query_any(lumen_mi_renderer* r, uint32_t n, const float* o, const float* d, float tmin, const float* tmax, uint8_t* occ)
+{
+    if (!r || !o || !d || !tmax || !occ) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lk(r->frameMutex);
+    int rc = prepareScene(r); if (rc) return rc;
+    std::vector<float4> ho(n), hd(n);
+    for (uint32_t i = 0; i < n; i++) { ho[i] = make_float4(o[3*i], o[3*i+1], o[3*i+2], tmax[i]); hd[i] = make_float4(d[3*i], d[3*i+1], d[3*i+2], 0.f); }
+    DevBuf<float4> dO, dD; DevBuf<uint32_t> dR;
+    if (dO.upload(ho, r->stream) || dD.upload(hd, r->stream) || dR.ensure(n)) return fail(LUMEN_MI_ERR_DEVICE, "query allocation failed");
+    r->K->query_any(r->stream, r->numCU * 12, r->dscene, dO.p, dD.p, n, tmin, dR.p, r->dCounters.p);
+    std::vector<uint32_t> hr(n);
+    LM_HIP(hipStreamSynchronize(r->stream));
+    LM_HIP(hipMemcpy(hr.data(), dR.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; i++) occ[i] = (uint8_t)hr[i];
+    dO.release(); dD.release(); dR.release();
+    return 0;
+}
+
+int lumen_mi_test_bsdf(lumen_mi_renderer* r, uint32_t n, int mode, const float* mat23, const float* N, const float* T, const float* wo, const float* aux, float* out8)
+{
+    if (!r || !r->initialised) return fail(LUMEN_MI_ERR_STATE, "not initialised");
+    if (!mat23 || !N || !T || !wo || !aux || !out8) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    LM_HIP(hipSetDevice(r->device));
+    DevBuf<float> dm, dn, dt, dw, da, dout;
+    std::vector<float> vm(mat23, mat23 + (size_t)23 * n), vn(N, N + (size_t)3 * n), vt(T, T + (size_t)3 * n), vw(wo, wo + (size_t)3 * n), va(aux, aux + (size_t)3 * n);
+    if (dm.upload(vm, r->stream) || dn.upload(vn, r->stream) || dt.upload(vt, r->stream) || dw.upload(vw, r->stream) || da.upload(va, r->stream) || dout.ensure((size_t)8 * n)) return fail(LUMEN_MI_ERR_DEVICE, "allocation failed");
+    r->K->test_bsdf(r->stream, n, mode, dm.p, dn.p, dt.p, dw.p, da.p, dout.p);
+    LM_HIP(hipStreamSynchronize(r->stream));
+    LM_HIP(hipMemcpy(out8, dout.p, (size_t)8 * n * 4, hipMemcpyDeviceToHost));
+    dm.release(); dn.release(); dt.release(); dw.release(); da.release(); dout.release();
+    return 0;
+}
+int lumen_mi_test_math(lumen_mi_renderer* r, uint32_t n, int fn, const float* x, const float* y, float* out)
+{
+    if (!r || !r->initialised) return fail(LUMEN_MI_ERR_STATE, "not initialised");
+    if (!x || !y || !out) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    LM_HIP(hipSetDevice(r->device));
+    DevBuf<float> dx, dy, dout;
+    std::vector<float> vx(x, x + n), vy(y, y + n);
+    if (dx.upload(vx, r->stream) || dy.upload(vy, r->stream) || dout.ensure(n)) return fail(LUMEN_MI_ERR_DEVICE, "allocation failed");
+    r->K->test_math(r->stream, n, fn, dx.p, dy.p, dout.p);
+    LM_HIP(hipStreamSynchronize(r->stream));
+    LM_HIP(hipMemcpy(out, dout.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    dx.release(); dy.release(); dout.release();
+    return 0;
+}
+
+// host-only scene products (no device needed beyond what flatten uploads)
+int lumen_mi_get_world_triangles(lumen_mi_renderer* r, float* out, uint32_t cap, uint32_t* count)
+{
+    if (!r || !count) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lk(r->frameMutex);
+    int rc = prepareScene(r); if (rc) return rc;
+    *count = (uint32_t)r->triEntry.size();
+    if (out) { if (cap < *count) return fail(LUMEN_MI_ERR_INVALID, "buffer too small"); memcpy(out, r->worldTris.data(), r->worldTris.size() * 4); }
+    return 0;
+}
+int lumen_mi_get_lights(lumen_mi_renderer* r, float* lights16, float* cdf, uint32_t cap, uint32_t* count)
+{
+    if (!r || !count) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lk(r->frameMutex);
+    int rc = prepareScene(r); if (rc) return rc;
+    if ((rc = buildLights(r))) return rc;
+    *count = (uint32_t)r->lights.size();
+    if (lights16 || cdf) {
+        if (cap < *count) return fail(LUMEN_MI_ERR_INVALID, "buffer too small");
+        if (lights16) memcpy(lights16, r->lights.data(), r->lights.size() * sizeof(LmLight));
+        if (cdf) memcpy(cdf, r->cdf.data(), r->cdf.size() * 4);
+    }
+    return 0;
+}
+int lumen_mi_get_bvh_info(lumen_mi_renderer* r, uint32_t* nodes, uint32_t* tris, uint32_t* maxDepth)
+{
+    if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer");
+    std::lock_guard<std::mutex> lk(r->frameMutex);
+    int rc = prepareScene(r); if (rc) return rc;
+    if (nodes) *nodes = (uint32_t)r->bvh.nodes.size(); if (tris) *tris = (uint32_t)r->bvh.order.size(); if (maxDepth) *maxDepth = r->bvh.maxDepth;
+    return 0;
+}
+
+}  // extern "C"

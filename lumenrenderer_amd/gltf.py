@@ -1,0 +1,138 @@
+"""Minimal glTF 2.0 reader that reproduces the reference's ingest rules (the path WaveFrontRenderer actually takes:
+glTF -> .ollad -> renderer factories; LumenPT/src/Tools/LumenPTModelConverter.cpp:336-560, 664-928, 72-273):
+
+  * attributes POSITION / NORMAL / TEXCOORD_0 / TANGENT; a missing TEXCOORD_0 leaves UV = (0,0) on every vertex
+    (zero-initialised interleave buffer, :909-919), missing tangents are generated from the UVs (:734-900);
+  * 16-bit indices stay 16-bit in the file and are widened by CreatePrimitive;
+  * materials: baseColor/emissive/metallic factors, roughness clamped to >= 0.01 (:399), Disney extras at their
+    .ollad defaults (luminance 1, transmittance 0, tint 0, ior 1, ...), KHR_materials_{transmission,sheen,ior,
+    clearcoat,specular} factors; textures (sRGB decode only for base colour and emissive, :130-133) are decoded by the
+    caller-supplied ``image_loader`` (PNG/JPEG decoding is outside this package; the Cornell box has no images);
+  * node hierarchy: local = T*R*S or the given matrix, world = parent*local (Transform.cpp:265-308); every node with
+    a mesh becomes one mesh instance with EmissionMode::ENABLED; the glTF camera is ignored (as in the reference).
+"""
+import base64
+import json
+import os
+
+import numpy as np
+
+from .scenes import SceneDescription, generate_tangents, interleave
+
+_COMP = {5120: np.int8, 5121: np.uint8, 5122: np.int16, 5123: np.uint16, 5125: np.uint32, 5126: np.float32}
+_NCOMP = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4, "MAT4": 16}
+
+
+def _accessor(doc, buffers, idx):
+    acc = doc["accessors"][idx]
+    bv = doc["bufferViews"][acc["bufferView"]]
+    dt, nc = np.dtype(_COMP[acc["componentType"]]), _NCOMP[acc["type"]]
+    off = bv.get("byteOffset", 0) + acc.get("byteOffset", 0)
+    stride = bv.get("byteStride", 0) or dt.itemsize * nc
+    raw = buffers[bv["buffer"]]
+    out = np.zeros((acc["count"], nc), dt)
+    for i in range(acc["count"]):
+        out[i] = np.frombuffer(raw, dt, nc, off + i * stride)
+    return out
+
+
+def _node_local(node):
+    if "matrix" in node:
+        return np.asarray(node["matrix"], np.float64).reshape(4, 4).T      # glTF matrices are column-major
+    T, R, S = np.eye(4), np.eye(4), np.eye(4)
+    if "translation" in node:
+        T[:3, 3] = node["translation"]
+    if "rotation" in node:
+        x, y, z, w = node["rotation"]
+        R[:3, :3] = [[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]]
+    if "scale" in node:
+        S[0, 0], S[1, 1], S[2, 2] = node["scale"]
+    return T @ R @ S
+
+
+def load_gltf(path, image_loader=None):
+    with open(path) as f:
+        doc = json.load(f)
+    base = os.path.dirname(path)
+    buffers = []
+    for b in doc.get("buffers", []):
+        uri = b["uri"]
+        if uri.startswith("data:"):
+            buffers.append(base64.b64decode(uri.split(",", 1)[1]))
+        else:
+            with open(os.path.join(base, uri), "rb") as fb:
+                buffers.append(fb.read())
+    d = SceneDescription()
+    tex_cache = {}
+
+    def texture(info, srgb, metal_rough=False):
+        if info is None or info.get("index", -1) < 0:
+            return None
+        src = doc["textures"][info["index"]]["source"]
+        key = (src, srgb)
+        if key not in tex_cache:
+            if image_loader is None:
+                raise ValueError("glTF image needs an image_loader(path_or_bytes) -> HxWx4 uint8")
+            img = doc["images"][src]
+            px = np.array(image_loader(os.path.join(base, img["uri"])), np.uint8)
+            if metal_rough:
+                px[..., 1] = np.maximum(px[..., 1], 1)                       # roughness >= 1/255 (LumenPTModelConverter.cpp:121-128)
+            tex_cache[key] = d.add_texture(px, srgb)
+        return tex_cache[key]
+
+    mats = []
+    for m in doc.get("materials", []):
+        pbr = m.get("pbrMetallicRoughness", {})
+        ext = m.get("extensions", {})
+        kw = dict(diffuse_color=tuple(pbr.get("baseColorFactor", (1, 1, 1, 1))), emission=tuple(m.get("emissiveFactor", (0, 0, 0))),
+                  metallic_factor=pbr.get("metallicFactor", 1.0), roughness_factor=max(0.01, pbr.get("roughnessFactor", 1.0)))
+        for field, info, srgb, mr in (("diffuse_texture", pbr.get("baseColorTexture"), True, False), ("normal_map", m.get("normalTexture"), False, False),
+                                      ("metallic_roughness_texture", pbr.get("metallicRoughnessTexture"), False, True),
+                                      ("emissive_texture", m.get("emissiveTexture"), True, False)):
+            t = texture(info, srgb, mr)
+            if t is not None:
+                kw[field] = t
+        if "KHR_materials_transmission" in ext:
+            kw["transmission_factor"] = ext["KHR_materials_transmission"].get("transmissionFactor", 0.0)
+        if "KHR_materials_sheen" in ext:
+            kw["sheen_factor"] = ext["KHR_materials_sheen"].get("sheenRoughnessFactor", 0.0); kw["sheen_tint_factor"] = 1.0
+        if "KHR_materials_ior" in ext:
+            kw["index_of_refraction"] = ext["KHR_materials_ior"].get("ior", 1.0)
+        if "KHR_materials_clearcoat" in ext:
+            kw["clearcoat_factor"] = ext["KHR_materials_clearcoat"].get("clearcoatFactor", 0.0)
+            kw["clearcoat_roughness_factor"] = ext["KHR_materials_clearcoat"].get("clearcoatRoughnessFactor", 0.0)
+        if "KHR_materials_specular" in ext:
+            kw["specular_factor"] = ext["KHR_materials_specular"].get("specularFactor", 0.0); kw["specular_tint_factor"] = 1.0
+        mats.append(d.add_material(**kw))
+    meshes = []
+    for mesh in doc.get("meshes", []):
+        prims = []
+        for p in mesh["primitives"]:
+            at = p["attributes"]
+            pos = _accessor(doc, buffers, at["POSITION"]).astype(np.float32)
+            nrm = _accessor(doc, buffers, at["NORMAL"]).astype(np.float32) if "NORMAL" in at else None
+            uv = _accessor(doc, buffers, at["TEXCOORD_0"]).astype(np.float32) if "TEXCOORD_0" in at else None
+            idx = _accessor(doc, buffers, p["indices"])
+            index_size = idx.dtype.itemsize if idx.dtype.itemsize in (2, 4) else 4
+            idx = idx.astype(np.uint32).ravel()
+            if "TANGENT" in at:
+                tang = _accessor(doc, buffers, at["TANGENT"]).astype(np.float32)
+            else:
+                tang = generate_tangents(pos, nrm if nrm is not None else np.tile(np.float32([0, 1, 0]), (len(pos), 1)), uv, idx)
+            prims.append(d.add_primitive(interleave(pos, uv, nrm, tang), idx, mats[p["material"]], index_size))
+        meshes.append(d.add_mesh(prims))
+
+    def walk(ni, parent):
+        node = doc["nodes"][ni]
+        world = parent @ _node_local(node)
+        if "mesh" in node:
+            d.add_instance(meshes[node["mesh"]], world.astype(np.float32))
+        for c in node.get("children", []):
+            walk(c, world)
+
+    scene = doc["scenes"][doc.get("scene", 0)]
+    for n in scene["nodes"]:
+        walk(n, np.eye(4))
+    return d

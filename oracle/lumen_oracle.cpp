@@ -1305,7 +1305,7 @@ void orc_get_gbuffer(orc_ctx* c, float* out)
         const Surface& s = S[i];
         float* o = out + i * 32;
         o[0] = s.position.x; o[1] = s.position.y; o[2] = s.position.z; o[3] = s.t;
-        o[4] = s.normal.x; o[5] = s.normal.y; o[6] = s.normal.z; o[7] = (float)s.flags;
+        o[4] = s.normal.x; o[5] = s.normal.y; o[6] = s.normal.z; { const uint32_t fl = s.flags; memcpy(&o[7], &fl, 4); }
         o[8] = s.tangent.x; o[9] = s.tangent.y; o[10] = s.tangent.z; o[11] = 0;
         o[12] = s.incoming.x; o[13] = s.incoming.y; o[14] = s.incoming.z; o[15] = 0;
         memcpy(o + 16, &s.mat.color, 16); memcpy(o + 20, &s.mat.tint, 16); memcpy(o + 24, &s.mat.transmittance, 16);
