@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on its config: Mrays/s and ms/frame at 1440p, 4 spp, depth 6, Sponza (stand-in).
+
+A "step" is one displayed frame = 4 blended TraceFrame() calls (the reference has no spp parameter: SURVEY.md F3) over
+synthetic geometry already resident in HBM.  N GPUs shard the frame by tile (lumenrenderer_amd/tiles.py) and gather the
+radiance on rank 0 with one RCCL collective; the total work is fixed, so scaling is "strong".
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+WORKLOADS = {
+    # name: (scene factory kwargs, width, height, depth, spp)
+    "c2": ("sponza", dict(), 2560, 1440, 6, 4),
+    "c3": ("sponza", dict(extra_lights=512), 2560, 1440, 6, 4),
+    "c4": ("sponza", dict(), 3840, 2160, 8, 8),
+    "c5": ("foliage", dict(), 1920, 1080, 6, 1),
+    "c1": ("cornell", dict(), 256, 256, 2, 1),
+}
+
+
+def make_scene(kind, kw):
+    from lumenrenderer_amd import scenes
+    if kind == "sponza":
+        return scenes.sponza_standin(**kw)
+    if kind == "foliage":
+        return scenes.foliage_stress(**kw)
+    return scenes.cornell_box(fixture=os.path.join(ROOT, "tests", "golden", "cornell_box.npz"))
+
+
+def algorithmic_bytes_closest(rays, nodes, tris):
+    """closest-hit launch = 56 B/ray (read 40 + write 16) + 64 B per BVH2 node visited + 48 B per Woop packet tested."""
+    return 56.0 * rays + 64.0 * nodes + 48.0 * tris
+
+
+def cpu_baseline(kind, kw, depth, spp):
+    """The CPU oracle ("port") timed on this box's host cores on a bounded sample of the same workload: the same scene at
+    480x270, `spp` blended frames.  Test infrastructure used as a reported baseline only — never as the measured path."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import oracle_from
+    cores = os.cpu_count() or 1
+    w, h = 480, 270
+    o = oracle_from(make_scene(kind, kw), w, h, depth, blend=True, threads=cores)
+    o.world_triangles()                                   # scene flattening + BVH build outside the timed region (as on the GPU)
+    t0 = time.perf_counter()
+    rays = 0
+    for _ in range(spp):
+        o.trace_frame()
+        s = o.stats(4)
+        rays += s[0] + s[1] + s[2]
+    dt = time.perf_counter() - t0
+    o.close()
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"{w}x{h} x {spp} blended frames, depth {depth}, same scene ({dt:.1f} s, {rays} rays); ms/frame {dt * 1e3:.0f}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from lumenrenderer_amd import LumenRendererMI, tiles
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    kind, kw, W, H, depth, spp = WORKLOADS[args.workload]
+    desc = make_scene(kind, kw)
+    r = LumenRendererMI()
+    r.Init(depth=depth, render_resolution=(W, H), blend_output=True, device=local_rank)
+    r.set_stream(torch.cuda.current_stream().cuda_stream)
+    r.LoadSceneDescription(desc)
+    tile = tiles.tile_rect(rank, world, W, H)
+    win = tiles.window_rect(tile, W, H) if world > 1 else (0, 0, W, H)
+    r.SetWindow(*win)
+    wh, ww = win[3] - win[1], win[2] - win[0]
+    window_buf = torch.empty((wh, ww, 4), dtype=torch.float32, device=dev)
+
+    def frame():
+        r.SetBlendMode(True)                              # a fresh 4-spp accumulation per displayed frame
+        for _ in range(spp):
+            r.TraceFrameAsync()
+        r.CopyRadianceToDevice(window_buf.data_ptr())
+        local = window_buf[tile[1] - win[1]: tile[3] - win[1], tile[0] - win[0]: tile[2] - win[0]]
+        return tiles.gather_tiles(local, rank, world, W, H, dist)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- instrumented pass (outside the timed region): BVH nodes / triangles per closest-hit ray for the roofline
+    r.SetInstrumented(True)
+    r.SetBlendMode(True)
+    r.TraceFrame()
+    ci = r.GetCounters()
+    nodes_per_ray = ci[20] / max(1, ci[0] + ci[1] + ci[2])
+    tris_per_ray = ci[21] / max(1, ci[0] + ci[1] + ci[2])
+    r.SetInstrumented(False)
+
+    for _ in range(args.warmup):
+        frame()
+    r.EnableKernelTiming(True)
+    barrier()
+    t0 = time.perf_counter()
+    rays_total = 0
+    closest_ms, closest_launches, closest_rays, shadow_ms, shade_ms, restir_ms = 0.0, 0, 0, 0.0, 0.0, 0.0
+    img = None
+    for _ in range(args.steps):
+        img = frame()
+    barrier()
+    dt = time.perf_counter() - t0
+    r.EnableKernelTiming(False)
+    # counters / kernel times of the LAST TraceFrame (every step repeats the same deterministic work pattern)
+    c = r.GetCounters()
+    rays_last = c[0] + c[1] + c[2]
+    closest_ms, closest_launches = r.GetKernelTime(0)
+    shadow_ms, _ = r.GetKernelTime(1)
+    shade_ms, _ = r.GetKernelTime(2)
+    restir_ms, _ = r.GetKernelTime(3)
+    total_ms, _ = r.GetKernelTime(4)
+
+    stats = torch.tensor([dt, float(rays_last)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = stats.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = stats.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt = float(tmax[0]); rays_last_all = float(tsum[1])
+    else:
+        rays_last_all = float(rays_last)
+    if rank == 0:
+        # rays/frame: the spp TraceFrame()s of one step trace (to within RNG noise) the same number of rays each
+        rays_per_frame = rays_last_all * spp
+        ms_per_step = dt * 1e3 / args.steps
+        value = rays_per_frame / (ms_per_step * 1e-3) / 1e6
+        # roofline of the dominant kernel (closest-hit BVH2 traversal) on rank 0: algorithmic bytes / measured device time
+        nodes_c = ci[20] * (c[0] / max(1, ci[0] + ci[1] + ci[2]))       # share of instrumented counts attributed to closest-hit rays
+        tris_c = ci[21] * (c[0] / max(1, ci[0] + ci[1] + ci[2]))
+        alg = algorithmic_bytes_closest(c[0], nodes_c, tris_c)
+        per_launch_ms = closest_ms / max(1, closest_launches)
+        achieved = (alg / max(1, closest_launches)) / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {kind} stand-in, {W}x{H}, {spp} spp (blended TraceFrames), depth {depth}, ReSTIR DI on",
+                       "triangles": desc.triangle_count(), "rays_per_frame": int(rays_per_frame), "ms_per_frame": round(ms_per_step, 4),
+                       "tiles": f"{tiles.grid_for(world, W, H)[0]}x{tiles.grid_for(world, W, H)[1]} + {tiles.HALO}px halo" if world > 1 else "1x1",
+                       "nodes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2)},
+            "roofline": {"bound": "hbm", "kernel": "lm_k_trace_closest", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "launch_ms": round(per_launch_ms, 4), "launches_per_traceframe": closest_launches,
+                         "algorithmic_bytes_per_launch": int(alg / max(1, closest_launches))},
+            "device_ms_per_traceframe": {"closest": round(closest_ms, 3), "shadow": round(shadow_ms, 3), "shade": round(shade_ms, 3),
+                                         "restir": round(restir_ms, 3), "total": round(total_ms, 3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(kind, kw, depth, spp)
+        print(json.dumps(out), flush=True)
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
