@@ -127,8 +127,9 @@ int lumen_mi_get_frame_stat(lumen_mi_renderer*, const char* key, uint64_t* micro
 /* counters of the last completed frame: [0] closest-hit rays, [1] NEE shadow rays, [2] ReSTIR shadow rays, [3] lights,
  * [4..4+depth) rays per wave, [20] BVH nodes visited, [21] triangles tested (both only in the instrumented build) */
 int lumen_mi_get_counters(lumen_mi_renderer*, uint64_t* out, uint32_t n);
-/* device time of one kernel class over the last frame, measured with HIP events on the renderer's stream.
- * which: 0 closest-hit traversal, 1 shadow traversal, 2 shade, 3 ReSTIR, 4 everything */
+/* device time of one kernel class, summed over every frame traced since timing was enabled, measured with HIP events
+ * on the renderer's stream; `launches` = number of timed launches (class 4: number of frames).
+ * which: 0 closest-hit traversal, 1 shadow traversal, 2 extract+shade, 3 ReSTIR (all passes), 4 whole frame */
 int lumen_mi_get_kernel_time(lumen_mi_renderer*, int which, float* milliseconds, uint32_t* launches);
 int lumen_mi_enable_kernel_timing(lumen_mi_renderer*, int enable);
 int lumen_mi_set_instrumented(lumen_mi_renderer*, int enable);   /* use the node/triangle counting traversal kernels */

@@ -571,17 +571,18 @@ int syncAndCollect(R* r)
         LM_HIP(hipMemcpy(r->hostCounters, r->fr.counters, sizeof r->hostCounters, hipMemcpyDeviceToHost));
         r->countersValid = true;
     }
-    if (r->timing && r->evUsed) {
-        for (int c = 0; c < 5; c++) { r->classMs[c] = 0.f; r->classLaunches[c] = 0; }
+    if (r->evUsed) {
+        // accumulate over every frame enqueued since the last lumen_mi_enable_kernel_timing(1)
         for (size_t i = 0; i < r->evUsed; i++) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, r->evPool[i].a, r->evPool[i].b) == hipSuccess) { r->classMs[r->evPool[i].cls] += ms; r->classLaunches[r->evPool[i].cls]++; }
         }
         r->evUsed = 0;
-        r->frameStats["Wavefront Iteration"] = (uint64_t)((r->classMs[0] + r->classMs[2] + r->classMs[3]) * 1000.f);
-        r->frameStats["Shadow Rays"] = (uint64_t)(r->classMs[1] * 1000.f);
-        r->frameStats["ReSTIR"] = (uint64_t)(r->classMs[3] * 1000.f);
-        r->frameStats["Total Frame Time"] = (uint64_t)(r->classMs[4] * 1000.f);
+        const float frames = (float)std::max<uint32_t>(1u, r->classLaunches[4]);
+        r->frameStats["Wavefront Iteration"] = (uint64_t)((r->classMs[0] + r->classMs[2] + r->classMs[3]) * 1000.f / frames);
+        r->frameStats["Shadow Rays"] = (uint64_t)(r->classMs[1] * 1000.f / frames);
+        r->frameStats["ReSTIR"] = (uint64_t)(r->classMs[3] * 1000.f / frames);
+        r->frameStats["Total Frame Time"] = (uint64_t)(r->classMs[4] * 1000.f / frames);
     }
     return 0;
 }
@@ -944,7 +945,13 @@ int lumen_mi_get_kernel_time(lumen_mi_renderer* r, int which, float* ms, uint32_
     if (ms) *ms = r->classMs[which]; if (launches) *launches = r->classLaunches[which];
     return 0;
 }
-int lumen_mi_enable_kernel_timing(lumen_mi_renderer* r, int e) { if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer"); r->timing = e != 0; return 0; }
+int lumen_mi_enable_kernel_timing(lumen_mi_renderer* r, int e)
+{
+    if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer");
+    if (e) { for (int c = 0; c < 5; c++) { r->classMs[c] = 0.f; r->classLaunches[c] = 0; } }      // enabling starts a new accumulation window
+    r->timing = e != 0;
+    return 0;
+}
 int lumen_mi_set_instrumented(lumen_mi_renderer* r, int e) { if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer"); r->instrumented = e != 0; r->K = e ? lm_kernel_table_instrumented() : lm_kernel_table(); return 0; }
 
 int lumen_mi_set_window(lumen_mi_renderer* r, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1)
