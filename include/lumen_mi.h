@@ -82,6 +82,7 @@ int lumen_mi_set_stream(lumen_mi_renderer*, void* hip_stream);
 /* ---- resource factories */
 int lumen_mi_create_texture(lumen_mi_renderer*, const void* rgba8, uint32_t width, uint32_t height, int normalize, lumen_mi_handle* out);      /* CreateTexture  LumenRenderer.h:161 */
 int lumen_mi_create_material(lumen_mi_renderer*, const lumen_mi_material_data*, lumen_mi_handle* out);                                     /* CreateMaterial LumenRenderer.h:164 */
+int lumen_mi_update_material(lumen_mi_renderer*, lumen_mi_handle material, const lumen_mi_material_data*);                                    /* ILumenMaterial setters, ILumenResources.h:23-55 */
 int lumen_mi_create_default_resources(lumen_mi_renderer*, lumen_mi_handle* white, lumen_mi_handle* normal, lumen_mi_handle* diffuse);      /* CreateDefaultResources LumenRenderer.cpp:50-58 */
 int lumen_mi_create_primitive(lumen_mi_renderer*, const lumen_mi_primitive_data*, lumen_mi_handle* out, uint32_t* num_lights);               /* CreatePrimitive LumenRenderer.h:157; ILumenPrimitive::m_NumLights */
 int lumen_mi_create_mesh(lumen_mi_renderer*, const lumen_mi_handle* primitives, uint32_t n, lumen_mi_handle* out);                          /* CreateMesh     LumenRenderer.h:159 */

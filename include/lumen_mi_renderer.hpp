@@ -1,0 +1,285 @@
+// lumen_mi_renderer.hpp — header-only C++ adapter: the reference's own class shape on top of the C ABI.
+//
+// Drop this file (and lumen_mi.h) into the reference tree, link liblumen_mi.so, and construct
+// `MI355X::Renderer` where Sandbox constructs `LumenPT` (LumenPT/src/LumenPT.h:12, Sandbox/src/Application.cpp:83):
+//
+//     auto renderer = std::make_shared<MI355X::Renderer>();
+//     MI355X::Renderer::Settings s; s.depth = 5; s.renderResolution = {1280, 720}; ...
+//     renderer->Init(s);                       // WaveFrontRenderer::Init(const WaveFrontSettings&)  (Application.cpp:84-95)
+//     renderer->CreateDefaultResources(); ...  // everything after this line is the unchanged Sandbox code
+//
+// It derives from the reference's LumenRenderer (Lumen/src/Lumen/Renderer/LumenRenderer.h:37-219) and returns
+// objects implementing ILumenTexture / ILumenMaterial / ILumenPrimitive / ILumenMesh / ILumenScene
+// (ILumenResources.h:12-127, ILumenScene.h:11-71), so SceneManager, OutputLayer and the tool UI keep working.
+// This header includes only reference headers and lumen_mi.h — no HIP.  It cannot be compiled outside the
+// reference tree (it needs Lumen's headers and glm); INTEGRATION.md describes the build hook.
+#pragma once
+#include "lumen_mi.h"
+
+#include "Lumen/Renderer/LumenRenderer.h"
+#include "Lumen/Renderer/ILumenResources.h"
+#include "Lumen/ModelLoading/ILumenScene.h"
+#include "Lumen/ModelLoading/MeshInstance.h"
+#include "Lumen/Renderer/Camera.h"
+
+#include <glm/glm.hpp>
+#include <glm/gtc/type_ptr.hpp>
+
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <vector>
+
+namespace MI355X
+{
+    inline void Check(int rc, const char* what)
+    {
+        // the reference has no error returns: it asserts / aborts (CudaUtilities.h:24-28); keep that contract at this level
+        if (rc != LUMEN_MI_OK && rc != LUMEN_MI_NO_LIGHTS) { std::fprintf(stderr, "[lumen_mi] %s failed (%d): %s\n", what, rc, lumen_mi_last_error()); std::abort(); }
+    }
+
+    class Texture : public Lumen::ILumenTexture
+    {
+    public:
+        explicit Texture(lumen_mi_handle h) : m_Handle(h) {}
+        lumen_mi_handle m_Handle;
+    };
+
+    // ILumenMaterial: 25 setters + 19 getters; every setter re-sends the whole MaterialData (lumen_mi_update_material)
+    class Material : public Lumen::ILumenMaterial
+    {
+    public:
+        Material(lumen_mi_renderer* r, const LumenRenderer::MaterialData& d) : m_R(r), m_Data(d) { auto c = ToC(); Check(lumen_mi_create_material(m_R, &c, &m_Handle), "create_material"); }
+
+        void SetDiffuseColor(const glm::vec4& v) override { m_Data.m_DiffuseColor = v; Push(); }
+        void SetDiffuseTexture(std::shared_ptr<Lumen::ILumenTexture> t) override { m_Data.m_DiffuseTexture = t; Push(); }
+        void SetEmission(const glm::vec3& v = glm::vec3(0.f)) override { m_Data.m_EmissionVal = v; Push(); }
+        void SetEmissiveTexture(std::shared_ptr<Lumen::ILumenTexture> t) override { m_Data.m_EmissiveTexture = t; Push(); }
+        void SetMetalRoughnessTexture(std::shared_ptr<Lumen::ILumenTexture> t) override { m_Data.m_MetallicRoughnessTexture = t; Push(); }
+        void SetNormalTexture(std::shared_ptr<Lumen::ILumenTexture> t) override { m_Data.m_NormalMap = t; Push(); }
+        void SetClearCoatTexture(std::shared_ptr<Lumen::ILumenTexture> t) override { m_Data.m_ClearCoatTexture = t; Push(); }
+        void SetClearCoatRoughnessTexture(std::shared_ptr<Lumen::ILumenTexture> t) override { m_Data.m_ClearCoatRoughnessTexture = t; Push(); }
+        void SetClearCoatFactor(float f) override { m_Data.m_ClearCoatFactor = f; Push(); }
+        void SetClearCoatRoughnessFactor(float f) override { m_Data.m_ClearCoatRoughnessFactor = f; Push(); }
+        void SetLuminance(float f) override { m_Data.m_Luminance = f; Push(); }
+        void SetSheenFactor(float f) override { m_Data.m_SheenFactor = f; Push(); }
+        void SetSheenTintFactor(float f) override { m_Data.m_SheenTintFactor = f; Push(); }
+        void SetAnisotropic(float f) override { m_Data.m_Anisotropic = f; Push(); }
+        void SetTintTexture(std::shared_ptr<Lumen::ILumenTexture> t) override { m_Data.m_TintTexture = t; Push(); }
+        void SetTintFactor(const glm::vec3& v) override { m_Data.m_TintFactor = v; Push(); }
+        void SetTransmissionTexture(std::shared_ptr<Lumen::ILumenTexture> t) override { m_Data.m_TransmissionTexture = t; Push(); }
+        void SetTransmissionFactor(float f) override { m_Data.m_TransmissionFactor = f; Push(); }
+        void SetTransmittanceFactor(const glm::vec3& v) override { m_Data.m_Transmittance = v; Push(); }
+        void SetIndexOfRefraction(float f) override { m_Data.m_IndexOfRefraction = f; Push(); }
+        void SetSpecularFactor(float f) override { m_Data.m_SpecularFactor = f; Push(); }
+        void SetSpecularTintFactor(float f) override { m_Data.m_SpecularTintFactor = f; Push(); }
+        void SetSubSurfaceFactor(float f) override { m_Data.m_SubSurfaceFactor = f; Push(); }
+        void SetMetallicFactor(float f) override { m_Data.m_MetallicFactor = f; Push(); }
+        void SetRoughnessFactor(float f) override { m_Data.m_RoughnessFactor = f; Push(); }
+
+        float GetClearCoatFactor() override { return m_Data.m_ClearCoatFactor; }
+        float GetClearCoatRoughnessFactor() override { return m_Data.m_ClearCoatRoughnessFactor; }
+        float GetLuminance() override { return m_Data.m_Luminance; }
+        float GetSheenFactor() override { return m_Data.m_SheenFactor; }
+        float GetSheenTintFactor() override { return m_Data.m_SheenTintFactor; }
+        float GetAnisotropic() override { return m_Data.m_Anisotropic; }
+        glm::vec3 GetTintFactor() override { return m_Data.m_TintFactor; }
+        float GetTransmissionFactor() override { return m_Data.m_TransmissionFactor; }
+        glm::vec3 GetTransmittanceFactor() override { return m_Data.m_Transmittance; }
+        float GetIndexOfRefraction() override { return m_Data.m_IndexOfRefraction; }
+        float GetSpecularFactor() override { return m_Data.m_SpecularFactor; }
+        float GetSpecularTintFactor() override { return m_Data.m_SpecularTintFactor; }
+        float GetSubSurfaceFactor() override { return m_Data.m_SubSurfaceFactor; }
+        float GetMetallicFactor() override { return m_Data.m_MetallicFactor; }
+        float GetRoughnessFactor() override { return m_Data.m_RoughnessFactor; }
+        glm::vec4 GetDiffuseColor() const override { return m_Data.m_DiffuseColor; }
+        glm::vec3 GetEmissiveColor() const override { return m_Data.m_EmissionVal; }
+        Lumen::ILumenTexture& GetDiffuseTexture() const override { return *m_Data.m_DiffuseTexture; }
+        Lumen::ILumenTexture& GetEmissiveTexture() const override { return *m_Data.m_EmissiveTexture; }
+
+        lumen_mi_handle m_Handle = 0;
+
+    private:
+        static lumen_mi_handle H(const std::shared_ptr<Lumen::ILumenTexture>& t) { return t ? static_cast<Texture*>(t.get())->m_Handle : 0; }
+        lumen_mi_material_data ToC() const
+        {
+            lumen_mi_material_data c{};
+            for (int i = 0; i < 4; i++) c.diffuse_color[i] = m_Data.m_DiffuseColor[i];
+            for (int i = 0; i < 3; i++) { c.emission[i] = m_Data.m_EmissionVal[i]; c.tint_factor[i] = m_Data.m_TintFactor[i]; c.transmittance[i] = m_Data.m_Transmittance[i]; }
+            c.diffuse_texture = H(m_Data.m_DiffuseTexture); c.normal_map = H(m_Data.m_NormalMap);
+            c.metallic_roughness_texture = H(m_Data.m_MetallicRoughnessTexture); c.emissive_texture = H(m_Data.m_EmissiveTexture);
+            c.transmission_texture = H(m_Data.m_TransmissionTexture); c.clearcoat_texture = H(m_Data.m_ClearCoatTexture);
+            c.clearcoat_roughness_texture = H(m_Data.m_ClearCoatRoughnessTexture); c.tint_texture = H(m_Data.m_TintTexture);
+            c.transmission_factor = m_Data.m_TransmissionFactor; c.clearcoat_factor = m_Data.m_ClearCoatFactor;
+            c.clearcoat_roughness_factor = m_Data.m_ClearCoatRoughnessFactor; c.index_of_refraction = m_Data.m_IndexOfRefraction;
+            c.specular_factor = m_Data.m_SpecularFactor; c.specular_tint_factor = m_Data.m_SpecularTintFactor; c.subsurface_factor = m_Data.m_SubSurfaceFactor;
+            c.luminance = m_Data.m_Luminance; c.anisotropic = m_Data.m_Anisotropic; c.sheen_factor = m_Data.m_SheenFactor; c.sheen_tint_factor = m_Data.m_SheenTintFactor;
+            c.metallic_factor = m_Data.m_MetallicFactor; c.roughness_factor = m_Data.m_RoughnessFactor;
+            return c;
+        }
+        void Push() { auto c = ToC(); Check(lumen_mi_update_material(m_R, m_Handle, &c), "update_material"); }
+        lumen_mi_renderer* m_R;
+        LumenRenderer::MaterialData m_Data;
+    };
+
+    class Primitive : public Lumen::ILumenPrimitive { public: lumen_mi_handle m_Handle = 0; };
+
+    class Mesh : public Lumen::ILumenMesh
+    {
+    public:
+        Mesh(std::vector<std::shared_ptr<Lumen::ILumenPrimitive>>& prims, lumen_mi_handle h) : ILumenMesh(prims), m_Handle(h) {}
+        lumen_mi_handle m_Handle;
+    };
+
+    class MeshInstance : public Lumen::MeshInstance
+    {
+    public:
+        MeshInstance(lumen_mi_renderer* r, lumen_mi_handle scene) : m_R(r), m_Scene(scene) {}
+        void SetMesh(std::shared_ptr<Lumen::ILumenMesh> mesh) override
+        {
+            Lumen::MeshInstance::SetMesh(mesh);
+            Check(lumen_mi_scene_add_mesh(m_R, m_Scene, static_cast<Mesh*>(mesh.get())->m_Handle, &m_Handle), "scene_add_mesh");
+        }
+        void SetEmissiveness(const Emissiveness& e) override { Lumen::MeshInstance::SetEmissiveness(e); PushEmissiveness(); }
+        void SetOverrideMaterial(std::shared_ptr<Lumen::ILumenMaterial> m) override
+        {
+            Lumen::MeshInstance::SetOverrideMaterial(m);
+            if (m_Handle) Check(lumen_mi_instance_set_override_material(m_R, m_Handle, static_cast<Material*>(m.get())->m_Handle), "set_override_material");
+        }
+        // called by Renderer before every frame: the app edits m_Transform directly (the reference polls dirty flags, PTMeshInstance.cpp:123-178)
+        void Sync()
+        {
+            if (!m_Handle) return;
+            const glm::mat4 rowMajor = glm::transpose(m_Transform.GetWorldTransformationMatrix());     // PTMeshInstance.cpp:147-151
+            Check(lumen_mi_instance_set_transform(m_R, m_Handle, glm::value_ptr(rowMajor)), "set_transform");
+            PushEmissiveness();
+        }
+        lumen_mi_handle m_Handle = 0;
+
+    private:
+        void PushEmissiveness()
+        {
+            if (!m_Handle) return;
+            const float rad[3] = {m_EmissiveProperties.m_OverrideRadiance.x, m_EmissiveProperties.m_OverrideRadiance.y, m_EmissiveProperties.m_OverrideRadiance.z};
+            Check(lumen_mi_instance_set_emissiveness(m_R, m_Handle, static_cast<int>(m_EmissiveProperties.m_EmissionMode), rad, m_EmissiveProperties.m_Scale), "set_emissiveness");
+        }
+        lumen_mi_renderer* m_R;
+        lumen_mi_handle m_Scene;
+    };
+
+    class Scene : public Lumen::ILumenScene
+    {
+    public:
+        Scene(lumen_mi_renderer* r, const LumenRenderer::SceneData& d) : ILumenScene(d.m_CameraPosition, d.m_CameraUp), m_R(r) { Check(lumen_mi_create_scene(m_R, &m_Handle), "create_scene"); }
+        Lumen::MeshInstance* AddMesh() override
+        {
+            m_MeshInstances.push_back(std::make_unique<MeshInstance>(m_R, m_Handle));
+            return m_MeshInstances.back().get();
+        }
+        void Clear() override { ILumenScene::Clear(); Check(lumen_mi_scene_clear(m_R, m_Handle), "scene_clear"); }
+        lumen_mi_handle m_Handle = 0;
+
+    private:
+        lumen_mi_renderer* m_R;
+    };
+
+    class Renderer : public LumenRenderer
+    {
+    public:
+        // WaveFrontSettings (LumenPT/src/Framework/WaveFrontRenderer.h:31-48) without the PTX paths
+        struct Settings { unsigned depth = 5; glm::uvec2 renderResolution{1280, 720}; glm::uvec2 outputResolution{1280, 720}; bool blendOutput = false; int device = 0; };
+
+        Renderer() { Check(lumen_mi_create(&m_R), "create"); }
+        ~Renderer() override { lumen_mi_destroy(m_R); }
+
+        void Init(const Settings& s)
+        {
+            lumen_mi_settings c{s.depth, s.renderResolution.x, s.renderResolution.y, s.outputResolution.x, s.outputResolution.y, s.blendOutput ? 1 : 0, s.device};
+            Check(lumen_mi_init(m_R, &c), "init");
+        }
+
+        void StartRendering() override { m_Threaded = true; /* frames are driven from PerformDeferredOperations so that scene edits are picked up */ }
+        void PerformDeferredOperations() override { if (m_Threaded) TraceFrame(); }
+
+        std::unique_ptr<Lumen::ILumenPrimitive> CreatePrimitive(PrimitiveData& d) override
+        {
+            lumen_mi_primitive_data c{};
+            c.interleaved = d.m_Interleaved ? 1 : 0;
+            c.vertex_binary = d.m_VertexBinary.data();
+            c.positions = reinterpret_cast<const float*>(&d.m_Positions[0]);
+            c.tex_coords = d.m_TexCoords.Empty() ? nullptr : reinterpret_cast<const float*>(&d.m_TexCoords[0]);
+            c.normals = d.m_Normals.Empty() ? nullptr : reinterpret_cast<const float*>(&d.m_Normals[0]);
+            c.tangents = d.m_Tangents.Empty() ? nullptr : reinterpret_cast<const float*>(&d.m_Tangents[0]);
+            c.n_vertices = static_cast<uint32_t>(d.m_Interleaved ? d.m_VertexBinary.size() / 48 : d.m_Positions.Size());
+            c.index_binary = d.m_IndexBinary.data();
+            c.index_size = static_cast<uint32_t>(d.m_IndexSize);
+            c.n_indices = static_cast<uint32_t>(d.m_IndexBinary.size() / d.m_IndexSize);
+            c.material = static_cast<Material*>(d.m_Material.get())->m_Handle;
+            auto p = std::make_unique<Primitive>();
+            uint32_t numLights = 0;
+            Check(lumen_mi_create_primitive(m_R, &c, &p->m_Handle, &numLights), "create_primitive");
+            p->m_Material = d.m_Material; p->m_NumLights = numLights; p->m_ContainEmissive = numLights > 0;
+            return p;
+        }
+        std::shared_ptr<Lumen::ILumenMesh> CreateMesh(std::vector<std::shared_ptr<Lumen::ILumenPrimitive>>& prims) override
+        {
+            std::vector<lumen_mi_handle> hs;
+            for (auto& p : prims) hs.push_back(static_cast<Primitive*>(p.get())->m_Handle);
+            lumen_mi_handle h = 0;
+            Check(lumen_mi_create_mesh(m_R, hs.data(), static_cast<uint32_t>(hs.size()), &h), "create_mesh");
+            return std::make_shared<Mesh>(prims, h);
+        }
+        std::shared_ptr<Lumen::ILumenTexture> CreateTexture(void* px, uint32_t w, uint32_t h, bool normalize) override
+        {
+            lumen_mi_handle t = 0;
+            Check(lumen_mi_create_texture(m_R, px, w, h, normalize ? 1 : 0, &t), "create_texture");
+            return std::make_shared<Texture>(t);
+        }
+        std::shared_ptr<Lumen::ILumenMaterial> CreateMaterial(const MaterialData& d) override { return std::make_shared<Material>(m_R, d); }
+        std::shared_ptr<Lumen::ILumenScene> CreateScene(SceneData d = {}) override { return std::make_shared<Scene>(m_R, d); }
+        std::shared_ptr<Lumen::ILumenVolume> CreateVolume(const std::string&) override { return nullptr; }   // volumes are out of scope
+        void InitNGX() override {}                                                                             // DLSS: out of scope
+
+        unsigned int GetOutputTexture() override { return 0; }   // no GL interop: OutputLayer uploads GetOutputTexturePixels() instead
+        std::vector<uint8_t> GetOutputTexturePixels(uint32_t& w, uint32_t& h) override
+        {
+            uint32_t rw = 0, rh = 0;
+            lumen_mi_get_render_resolution(m_R, &rw, &rh);
+            std::vector<uint8_t> px(static_cast<size_t>(rw) * rh * 4);
+            Check(lumen_mi_get_output_pixels(m_R, px.data(), px.size(), &w, &h), "get_output_pixels");
+            return px;
+        }
+        void SetRenderResolution(glm::uvec2 r) override { Check(lumen_mi_set_render_resolution(m_R, r.x, r.y), "set_render_resolution"); }
+        void SetOutputResolution(glm::uvec2 r) override { Check(lumen_mi_set_output_resolution(m_R, r.x, r.y), "set_output_resolution"); }
+        glm::uvec2 GetRenderResolution() override { uint32_t w, h; lumen_mi_get_render_resolution(m_R, &w, &h); return {w, h}; }
+        glm::uvec2 GetOutputResolution() override { uint32_t w, h; lumen_mi_get_output_resolution(m_R, &w, &h); return {w, h}; }
+        void SetBlendMode(bool b) override { Check(lumen_mi_set_blend_mode(m_R, b ? 1 : 0), "set_blend_mode"); }
+        bool GetBlendMode() const override { int b = 0; lumen_mi_get_blend_mode(m_R, &b); return b != 0; }
+        void BeginSnapshot() override {}
+        std::unique_ptr<FrameSnapshot> EndSnapshot() override { return nullptr; }
+
+        // body of WaveFrontRenderer::TraceFrame: push the app-side scene state, then render one frame
+        void TraceFrame()
+        {
+            if (!m_Scene) return;
+            auto* scene = static_cast<Scene*>(m_Scene.get());
+            Check(lumen_mi_set_scene(m_R, scene->m_Handle), "set_scene");
+            for (auto& mi : scene->m_MeshInstances) static_cast<MeshInstance*>(mi.get())->Sync();
+            glm::mat4 prev, cur;
+            scene->m_Camera->GetMatrixData(prev, cur);            // columns: right, up, forward, position (Camera.cpp:122-140)
+            const float pos[3] = {cur[3].x, cur[3].y, cur[3].z}, right[3] = {cur[0].x, cur[0].y, cur[0].z}, up[3] = {cur[1].x, cur[1].y, cur[1].z}, fwd[3] = {cur[2].x, cur[2].y, cur[2].z};
+            Check(lumen_mi_camera_set(m_R, pos, right, up, fwd, 90.0f), "camera_set");   // Camera::m_FovY is fixed at 90 (Camera.h:63)
+            Check(lumen_mi_trace_frame(m_R), "trace_frame");
+            std::lock_guard<std::mutex> lk(m_FrameStatsMutex);
+            static const char* keys[] = {"Wavefront Iteration", "Shadow Rays", "ReSTIR", "Total Frame Time"};
+            for (const char* k : keys) { uint64_t us = 0; if (lumen_mi_get_frame_stat(m_R, k, &us) == LUMEN_MI_OK) m_LastFrameStats.m_Times[k] = us; }
+            ++m_LastFrameStats.m_Id;
+        }
+
+        lumen_mi_renderer* Native() { return m_R; }
+
+    private:
+        lumen_mi_renderer* m_R = nullptr;
+        bool m_Threaded = false;
+    };
+}  // namespace MI355X

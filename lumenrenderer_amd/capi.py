@@ -47,6 +47,7 @@ SYMBOLS = {
     "lumen_mi_set_stream": [_R, C.c_void_p],
     "lumen_mi_create_texture": [_R, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, _U64P],
     "lumen_mi_create_material": [_R, C.POINTER(MaterialData), _U64P],
+    "lumen_mi_update_material": [_R, _H, C.POINTER(MaterialData)],
     "lumen_mi_create_default_resources": [_R, _U64P, _U64P, _U64P],
     "lumen_mi_create_primitive": [_R, C.POINTER(PrimitiveData), _U64P, _U32P],
     "lumen_mi_create_mesh": [_R, _U64P, C.c_uint32, _U64P], "lumen_mi_create_scene": [_R, _U64P], "lumen_mi_set_scene": [_R, _H],

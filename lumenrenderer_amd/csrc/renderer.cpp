@@ -666,9 +666,8 @@ int lumen_mi_create_default_resources(lumen_mi_renderer* r, lumen_mi_handle* whi
     return 0;
 }
 
-int lumen_mi_create_material(lumen_mi_renderer* r, const lumen_mi_material_data* d, lumen_mi_handle* out)
+static int fillMaterial(lumen_mi_renderer* r, const lumen_mi_material_data* d, Material& m)
 {
-    if (!r || !d || !out) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
     if (!(d->roughness_factor > 0.f)) return fail(LUMEN_MI_ERR_INVALID, "roughness factor must be > 0 (WaveFrontRenderer.cpp:1283)");
     auto tex = [&](lumen_mi_handle h, int& id) -> bool { if (h == 0) { id = -1; return true; } size_t i; if (!unh(h, H_TEXTURE, r->textures.size(), i)) return false; id = (int)i; return true; };
     int tDiff, tNorm, tMR, tEm, tTr, tCC, tCCR, tTint;
@@ -677,7 +676,7 @@ int lumen_mi_create_material(lumen_mi_renderer* r, const lumen_mi_material_data*
         return fail(LUMEN_MI_ERR_INVALID, "bad texture handle in material");
     // the reference asserts that all eight textures are present (WaveFrontRenderer.cpp:1273-1280)
     if (tDiff < 0 || tNorm < 0 || tMR < 0 || tEm < 0 || tTr < 0 || tCC < 0 || tCCR < 0 || tTint < 0) return fail(LUMEN_MI_ERR_INVALID, "all eight material textures are required (use the default textures)");
-    Material m; memset(&m, 0, sizeof m);
+    memset(&m, 0, sizeof m);
     LmDevMaterial& v = m.dev;
     // PTMaterial(): MaterialData(0), roughness 1 (PTMaterial.cpp:10-19), then the setters in the order of CreateMaterial
     pack8(v.p[0], 24, 1.f);
@@ -702,9 +701,35 @@ int lumen_mi_create_material(lumen_mi_renderer* r, const lumen_mi_material_data*
     // PTMaterial::CreateDeviceMaterial (PTMaterial.cpp:97-148): the clear-coat-roughness texture overwrites the clear-coat
     // slot and the roughness slot stays a null handle; kept for parity
     v.tex[0] = tCCR; v.tex[1] = -1; v.tex[2] = tTr; v.tex[3] = tDiff; v.tex[4] = tEm; v.tex[5] = tMR; v.tex[6] = tNorm; v.tex[7] = tTint;
+    return 0;
+}
+
+int lumen_mi_create_material(lumen_mi_renderer* r, const lumen_mi_material_data* d, lumen_mi_handle* out)
+{
+    if (!r || !d || !out) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    Material m;
+    const int rc = fillMaterial(r, d, m);
+    if (rc) return rc;
     r->materials.push_back(m);
     r->materialsDirty = true;
     *out = mkh(H_MATERIAL, r->materials.size() - 1);
+    return 0;
+}
+
+int lumen_mi_update_material(lumen_mi_renderer* r, lumen_mi_handle material, const lumen_mi_material_data* d)
+{
+    size_t idx;
+    if (!r || !d || !unh(material, H_MATERIAL, r->materials.size(), idx)) return fail(LUMEN_MI_ERR_INVALID, "bad material handle");
+    Material m;
+    const int rc = fillMaterial(r, d, m);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(r->frameMutex);
+    r->materials[idx] = m;
+    r->materialsDirty = true;
+    // the emissive classification of primitives is a function of their material (FindEmissives at CreatePrimitive time in the
+    // reference; re-evaluated here so that the light list follows the edit)
+    for (Primitive& p : r->prims) if (p.material == idx) findEmissives(r, p);
+    r->lightsDirty = true;
     return 0;
 }
 
@@ -797,7 +822,7 @@ int lumen_mi_instance_set_transform(lumen_mi_renderer* r, lumen_mi_handle inst, 
 {
     size_t i;
     if (!r || !m || !unh(inst, H_INSTANCE, r->instances.size(), i)) return fail(LUMEN_MI_ERR_INVALID, "bad instance handle");
-    memcpy(r->instances[i].M, m, 64); r->sceneDirty = true;
+    if (memcmp(r->instances[i].M, m, 64) != 0) { memcpy(r->instances[i].M, m, 64); r->sceneDirty = true; }   // polled every frame by the adapter
     return 0;
 }
 
@@ -806,8 +831,8 @@ int lumen_mi_instance_set_emissiveness(lumen_mi_renderer* r, lumen_mi_handle ins
     size_t i;
     if (!r || !rad || mode < 0 || mode > 2 || !unh(inst, H_INSTANCE, r->instances.size(), i)) return fail(LUMEN_MI_ERR_INVALID, "bad emissiveness arguments");
     Instance& x = r->instances[i];
+    if (x.mode != mode || x.radiance[0] != rad[0] || x.radiance[1] != rad[1] || x.radiance[2] != rad[2] || x.scale != scale) r->sceneDirty = true;
     x.mode = mode; x.radiance[0] = rad[0]; x.radiance[1] = rad[1]; x.radiance[2] = rad[2]; x.scale = scale;
-    r->sceneDirty = true;
     return 0;
 }
 
