@@ -341,6 +341,7 @@ __device__ void lm_extract(const LmScene& sc, const uint4 hit, const lf3& ro, co
 // G-buffer planes (depth-0 SurfaceData in SoA form), plane p of pixel li at gbuf[p * n + li]:
 //   0 (position, t)   1 (normal, flags bits)   2 (tangent, 0)   3 (incoming, 0)
 //   4 color           5 (tint, luminance)      6 (transmittance, eta)   7 (p0, p1, p2 bits, 0)
+//   8 reuse probe: (normal, flags ? -1 : t) — the only data ReSTIR's similarity tests need, one 16-byte gather per candidate
 __device__ __forceinline__ void lm_gbuf_store(float4* __restrict__ g, uint32_t n, uint32_t li, const LmSurface& s)
 {
     g[li] = v4(s.position, s.t);
@@ -351,6 +352,7 @@ __device__ __forceinline__ void lm_gbuf_store(float4* __restrict__ g, uint32_t n
     g[5u * n + li] = s.mat.tint;
     g[6u * n + li] = s.mat.transmittance;
     g[7u * n + li] = make_float4(u2f(s.mat.p0), u2f(s.mat.p1), u2f(s.mat.p2), 0.f);
+    g[8u * n + li] = v4(s.normal, s.flags ? -1.f : s.t);
 }
 __device__ __forceinline__ void lm_gbuf_load(const float4* __restrict__ g, uint32_t n, uint32_t li, LmSurface& s)
 {
@@ -752,9 +754,9 @@ KN(lm_k_restir_temporal)(LmFrame fr, int cur, int prev, float4* __restrict__ res
         if (ty >= 0 && ty < (int)fr.wh && tx >= 0 && tx < (int)fr.ww) tli = (uint32_t)ty * fr.ww + (uint32_t)tx;
         const float4* gp = fr.gbuf[prev];
         const float4* gc = fr.gbuf[cur];
-        const float4 pn = gp[fr.n + tli], cn = gc[fr.n + li];
-        if (f2u(pn.w) != 0u || f2u(cn.w) != 0u) continue;
-        const float d1 = gp[tli].w, d2 = gc[li].w;
+        const float4 pn = gp[8u * fr.n + tli], cn = gc[8u * fr.n + li];
+        if (pn.w < 0.f || cn.w < 0.f) continue;                 // flagged surface on either side
+        const float d1 = pn.w, d2 = cn.w;
         const float depthDif = fabsf(d1 - d2) / ((d1 + d2) / 2.f);
         const float angle = dot3(v3(pn), v3(cn));
         if (!(depthDif < 0.10f && angle > 0.72222222223f)) continue;
@@ -777,45 +779,65 @@ KN(lm_k_restir_temporal)(LmFrame fr, int cur, int prev, float4* __restrict__ res
     }
 }
 
-// K25 spatial reuse — ReSTIRKernels.cu:787-980 (biased branch)
+// K25 spatial reuse — ReSTIRKernels.cu:787-980 (biased branch).  The five candidate probes are issued together (one
+// 16-byte gather each from the probe plane) and the accepted candidates' reservoirs are fetched one iteration ahead of
+// their re-evaluation, so the kernel is not a chain of dependent L2 round trips.
+__device__ __forceinline__ void lm_res_load4(const float4* __restrict__ b, uint32_t n, uint32_t li, float4& a, float4& p1, float4& p2, float4& p3)
+{
+    a = b[li]; p1 = b[n + li]; p2 = b[2u * n + li]; p3 = b[3u * n + li];
+}
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
 KN(lm_k_restir_spatial)(LmFrame fr, int cur, const float4* __restrict__ resIn, float4* __restrict__ resOut, uint32_t seed)
 {
     const uint32_t stride = gridDim.x * LM_BLOCK;
     const float4* g = fr.gbuf[cur];
+    const float4* probe = g + 8u * fr.n;
     for (uint32_t li = blockIdx.x * LM_BLOCK + threadIdx.x; li < fr.n; li += stride) {
-        const float4 cn = g[fr.n + li];
-        if (f2u(cn.w) != 0u) continue;
+        const float4 cn = probe[li];
+        if (cn.w < 0.f) continue;
         const int y = (int)(li / fr.ww), x = (int)(li - (uint32_t)y * fr.ww);
         const uint32_t gi = (fr.y0 + (uint32_t)y) * fr.W + (fr.x0 + (uint32_t)x);
         uint32_t s = lm_wang_hash(seed + gi);
-        const float ct = g[li].w;
-        uint32_t nb[5];
-        int count = 0;
+        const float ct = cn.w;
+        uint32_t cand[5];
+        float4 pr[5];
+#pragma unroll
         for (int k = 0; k < 5; k++) {
             const int ny = (int)roundf((lm_random_float(s) * 2.f - 1.f) * 30.f) + y;
             const int nx = (int)roundf((lm_random_float(s) * 2.f - 1.f) * 30.f) + x;
-            if (nx < 0 || nx >= (int)fr.ww || ny < 0 || ny >= (int)fr.wh) continue;
-            const uint32_t ni = (uint32_t)ny * fr.ww + (uint32_t)nx;
-            const float4 nn = g[fr.n + ni];
-            if (f2u(nn.w) != 0u) continue;
-            const float d1 = g[ni].w;
+            const bool in = !(nx < 0 || nx >= (int)fr.ww || ny < 0 || ny >= (int)fr.wh);
+            cand[k] = in ? (uint32_t)ny * fr.ww + (uint32_t)nx : 0xffffffffu;
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) pr[k] = probe[cand[k] != 0xffffffffu ? cand[k] : li];
+        uint32_t nb[5];
+        int count = 0;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            if (cand[k] == 0xffffffffu || pr[k].w < 0.f) continue;
+            const float d1 = pr[k].w;
             const float depthDif = fabsf(d1 - ct) / ((d1 + ct) / 2.f);
-            const float angle = dot3(v3(nn), v3(cn));
-            if (depthDif < 0.10f && angle > 0.72222222223f) nb[count++] = ni;
+            const float angle = dot3(v3(pr[k]), v3(cn));
+            if (depthDif < 0.10f && angle > 0.72222222223f) nb[count++] = cand[k];
         }
         if (count > 1) {
+            float4 a, p1, p2, p3;
+            lm_res_load4(resIn, fr.n, nb[0], a, p1, p2, p3);
             LmSurface s0;
             lm_gbuf_load(g, fr.n, nb[0], s0);                    // every candidate is re-evaluated at the FIRST neighbour's surface (reference :883)
             LmReservoir out; lm_res_fresh(out);
             long long sum = 0;
             for (int k = 0; k < count; k++) {
-                LmReservoir r;
-                lm_res_load(resIn, fr.n, nb[k], r);
+                float4 na = a, np1 = p1, np2 = p2, np3 = p3;
+                if (k + 1 < count) lm_res_load4(resIn, fr.n, nb[k + 1], na, np1, np2, np3);     // prefetch the next candidate
+                LmSample in; lm_sample_zero(in);
+                in.radiance = v3(p1); in.area = p1.w; in.normal = v3(p2); in.position = v3(p3);
+                const long long cnt = (long long)f2u(a.z);
                 LmSample rs;
-                lm_resample(r.s, s0, rs);
-                lm_res_update(out, rs, (float)r.count * r.weight * rs.pdf, seed);   // global seed: same draw for all pixels (reference quirk)
-                sum += r.count;
+                lm_resample(in, s0, rs);
+                lm_res_update(out, rs, (float)cnt * a.y * rs.pdf, seed);   // global seed: same draw for all pixels (reference quirk)
+                sum += cnt;
+                a = na; p1 = np1; p2 = np2; p3 = np3;
             }
             out.count = sum;
             lm_res_update_weight(out);

@@ -8,8 +8,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define LM_STACK_DEPTH 48        // traversal stack entries per lane; the BVH builder bounds the tree depth to this
+#define LM_STACK_DEPTH 32        // traversal stack entries per lane; the BVH builder bounds the tree depth to this
 #define LM_MAX_LEAF 8            // triangles per leaf representable in a leaf reference
+#define LM_GBUF_PLANES 9
 #define LM_MAX_DEPTH 16          // path depth the counter block is sized for
 
 // surface flags (reference: SurfaceData.h:18-24)
@@ -75,7 +76,7 @@ struct LmFrame {
     uint4* hits;                // entry, prim, half2 barycentrics, t bits
     // shadow-ray queue of the current wave: origin.xyz + tmax | dir.xyz + pixel | radiance.xyz
     float4 *shO, *shD, *shR;
-    // depth-0 surface data, two frames: 8 planes of n float4 each (see kernels.hip "G-buffer planes")
+    // depth-0 surface data, two frames: LM_GBUF_PLANES planes of n float4 each (see kernels.hip "G-buffer planes")
     float4* gbuf[2];
     // reservoirs: 4 buffers x 5 planes of n float4
     float4* res[4];

@@ -400,7 +400,7 @@ int ensureFrameBuffers(R* r)
     int bad = 0;
     for (int i = 0; i < 6; i++) bad |= r->dRay[i].ensure(n);
     for (int i = 0; i < 3; i++) bad |= r->dSh[i].ensure(n);
-    for (int i = 0; i < 2; i++) bad |= r->dGbuf[i].ensure((size_t)8 * n);
+    for (int i = 0; i < 2; i++) bad |= r->dGbuf[i].ensure((size_t)LM_GBUF_PLANES * n);
     for (int i = 0; i < 4; i++) bad |= r->dRes[i].ensure((size_t)5 * n);
     bad |= r->dDirect.ensure(n) | r->dIndirect.ensure(n) | r->dCombined.ensure(n) | r->dHits.ensure(n) | r->dMotion.ensure(n) | r->dOutput.ensure(n);
     bad |= r->dCounters.ensure(LM_CNT_WORDS) | r->dBags.ensure(50 * 1000);
@@ -414,7 +414,7 @@ int ensureFrameBuffers(R* r)
     f.counters = r->dCounters.p; f.bags = r->dBags.p;
     // ResizeBuffers (WaveFrontRenderer.cpp:1424-1540): history is dropped; reservoirs reset (ReSTIRKernels.cu:36-47)
     hipStream_t st = r->stream;
-    for (int i = 0; i < 2; i++) if (hipMemsetAsync(f.gbuf[i], 0, (size_t)8 * n * sizeof(float4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
+    for (int i = 0; i < 2; i++) if (hipMemsetAsync(f.gbuf[i], 0, (size_t)LM_GBUF_PLANES * n * sizeof(float4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
     for (int i = 0; i < 4; i++) if (hipMemsetAsync(f.res[i], 0, (size_t)5 * n * sizeof(float4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
     if (hipMemsetAsync(f.combined, 0, (size_t)n * sizeof(float4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
     if (hipMemsetAsync(f.output, 0, (size_t)n * sizeof(uchar4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
