@@ -164,14 +164,32 @@ __device__ __forceinline__ bool lm_traverse(const LmScene& sc, const lf3& o, con
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// K1: primary rays — reference GPUGeneratePrimRay.cu:28-82 (Halton(2,3) jitter indexed by frameCount + pixel index)
+// K1: primary rays — reference GPUGeneratePrimRay.cu:28-82 (Halton(2,3) jitter indexed by frameCount + pixel index).
+// Ray slot i holds the pixel of an 8x8-tile enumeration of the window (every consumer finds the pixel in rayD.w), so one
+// wavefront traces an 8x8 pixel bundle instead of a 64x1 strip.
 // ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lm_slot_to_pixel(const LmFrame& fr, uint32_t i, uint32_t& lx, uint32_t& ly)
+{
+    const uint32_t w8 = fr.ww & ~7u, h8 = fr.wh & ~7u, nA = w8 * h8;
+    if (i < nA) {
+        const uint32_t t = i >> 6, l = i & 63u, tpr = w8 >> 3;
+        lx = (t % tpr) * 8u + (l & 7u); ly = (t / tpr) * 8u + (l >> 3);
+        return;
+    }
+    uint32_t j = i - nA;
+    const uint32_t rw = fr.ww - w8;
+    if (j < rw * h8) { ly = j / rw; lx = w8 + j % rw; return; }
+    j -= rw * h8;
+    ly = h8 + j / fr.ww; lx = j % fr.ww;
+}
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
 KN(lm_k_primary)(LmFrame fr, LmCamera cam, uint32_t frameCount)
 {
     const uint32_t stride = gridDim.x * LM_BLOCK;
-    for (uint32_t li = blockIdx.x * LM_BLOCK + threadIdx.x; li < fr.n; li += stride) {
-        const uint32_t ly = li / fr.ww, lx = li - ly * fr.ww;
+    for (uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x; i < fr.n; i += stride) {
+        uint32_t lx, ly;
+        lm_slot_to_pixel(fr, i, lx, ly);
+        const uint32_t li = ly * fr.ww + lx;
         const uint32_t sx = fr.x0 + lx, sy = fr.y0 + ly;
         const uint32_t gi = sy * fr.W + sx;
         const float jx = lm_halton(frameCount + gi, 2u), jy = lm_halton(frameCount + gi, 3u);
@@ -181,9 +199,9 @@ KN(lm_k_primary)(LmFrame fr, LmCamera cam, uint32_t frameCount)
         dy = -(dy * 2.0f - 1.0f);
         const lf3 U = v3(cam.U[0], cam.U[1], cam.U[2]), V = v3(cam.V[0], cam.V[1], cam.V[2]), Wv = v3(cam.Wv[0], cam.Wv[1], cam.Wv[2]);
         const lf3 dir = normalize3(dx * U + dy * V + Wv);
-        fr.rayO[0][li] = make_float4(cam.eye[0], cam.eye[1], cam.eye[2], 0.f);
-        fr.rayD[0][li] = make_float4(dir.x, dir.y, dir.z, u2f(li));
-        fr.rayC[0][li] = make_float4(1.f, 1.f, 1.f, 0.f);
+        fr.rayO[0][i] = make_float4(cam.eye[0], cam.eye[1], cam.eye[2], 0.f);
+        fr.rayD[0][i] = make_float4(dir.x, dir.y, dir.z, u2f(li));
+        fr.rayC[0][i] = make_float4(1.f, 1.f, 1.f, 0.f);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) fr.counters[LM_CNT_RAYS(0)] = fr.n;
 }
@@ -338,30 +356,51 @@ __device__ void lm_extract(const LmScene& sc, const uint4 hit, const lf3& ro, co
     s.mat.transmittance.w = eta;
 }
 
-// G-buffer planes (depth-0 SurfaceData in SoA form), plane p of pixel li at gbuf[p * n + li]:
+// Depth-0 surface data ("G-buffer"): one 128-byte record per pixel = exactly one cache line, because ReSTIR gathers whole
+// records of OTHER pixels (spatial / temporal reuse):  float4[8] =
 //   0 (position, t)   1 (normal, flags bits)   2 (tangent, 0)   3 (incoming, 0)
 //   4 color           5 (tint, luminance)      6 (transmittance, eta)   7 (p0, p1, p2 bits, 0)
-//   8 reuse probe: (normal, flags ? -1 : t) — the only data ReSTIR's similarity tests need, one 16-byte gather per candidate
-__device__ __forceinline__ void lm_gbuf_store(float4* __restrict__ g, uint32_t n, uint32_t li, const LmSurface& s)
+// plus a separate 16-byte "reuse probe" plane (normal, flags ? -1 : t): all that the similarity tests need.
+__device__ __forceinline__ void lm_gbuf_store(float4* __restrict__ g, float4* __restrict__ probe, uint32_t li, const LmSurface& s)
 {
-    g[li] = v4(s.position, s.t);
-    g[n + li] = v4(s.normal, u2f(s.flags));
-    g[2u * n + li] = v4(s.tangent, 0.f);
-    g[3u * n + li] = v4(s.incoming, 0.f);
-    g[4u * n + li] = s.mat.color;
-    g[5u * n + li] = s.mat.tint;
-    g[6u * n + li] = s.mat.transmittance;
-    g[7u * n + li] = make_float4(u2f(s.mat.p0), u2f(s.mat.p1), u2f(s.mat.p2), 0.f);
-    g[8u * n + li] = v4(s.normal, s.flags ? -1.f : s.t);
+    float4* r = g + 8u * li;
+    r[0] = v4(s.position, s.t);
+    r[1] = v4(s.normal, u2f(s.flags));
+    r[2] = v4(s.tangent, 0.f);
+    r[3] = v4(s.incoming, 0.f);
+    r[4] = s.mat.color;
+    r[5] = s.mat.tint;
+    r[6] = s.mat.transmittance;
+    r[7] = make_float4(u2f(s.mat.p0), u2f(s.mat.p1), u2f(s.mat.p2), 0.f);
+    probe[li] = v4(s.normal, s.flags ? -1.f : s.t);
 }
-__device__ __forceinline__ void lm_gbuf_load(const float4* __restrict__ g, uint32_t n, uint32_t li, LmSurface& s)
+__device__ __forceinline__ void lm_gbuf_load(const float4* __restrict__ g, uint32_t li, LmSurface& s)
 {
-    const float4 a = g[li], b = g[n + li], c = g[2u * n + li], d = g[3u * n + li];
+    const float4* r = g + 8u * li;
+    const float4 a = r[0], b = r[1], c = r[2], d = r[3];
     s.position = v3(a); s.t = a.w; s.normal = v3(b); s.flags = f2u(b.w); s.tangent = v3(c); s.incoming = v3(d);
-    s.mat.color = g[4u * n + li]; s.mat.tint = g[5u * n + li]; s.mat.transmittance = g[6u * n + li];
-    const float4 p = g[7u * n + li];
+    s.mat.color = r[4]; s.mat.tint = r[5]; s.mat.transmittance = r[6];
+    const float4 p = r[7];
     s.mat.p0 = f2u(p.x); s.mat.p1 = f2u(p.y); s.mat.p2 = f2u(p.z);
     s.transport = v3(1.f, 1.f, 1.f);
+}
+
+// per-pixel kernels: one 256-thread block = one 16x16 pixel tile of the window.  Tiles are enumerated in bands of 8 tile
+// rows, column-major inside a band, and each XCD (blocks b, b+8, ... share one) gets a contiguous run of that order, so the
+// tiles resident on one XCD form a compact patch and neighbour gathers (+-30 px) hit that XCD's L2.  Speed only.
+__device__ __forceinline__ bool lm_tile_pixel(const LmFrame& fr, uint32_t& li, uint32_t& gi)
+{
+    const uint32_t tilesX = (fr.ww + 15u) >> 4, tilesY = (fr.wh + 15u) >> 4, T = tilesX * tilesY;
+    const uint32_t b = blockIdx.x, q = T >> 3, r = T & 7u, xcd = b & 7u;
+    const uint32_t t = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (b >> 3);
+    const uint32_t band = t / (8u * tilesX), within = t - band * 8u * tilesX;
+    const uint32_t bh = min(8u, tilesY - band * 8u);
+    const uint32_t tx = within / bh, ty = band * 8u + within % bh;
+    const uint32_t lx = tx * 16u + (threadIdx.x & 15u), ly = ty * 16u + (threadIdx.x >> 4);
+    if (lx >= fr.ww || ly >= fr.wh) return false;
+    li = ly * fr.ww + lx;
+    gi = (fr.y0 + ly) * fr.W + (fr.x0 + lx);
+    return true;
 }
 
 // K7 (depth 0) + K9 motion vectors (MotionVectors.cu:8-55) + K10 ResolveDirectLightHits (GPUShadeDirect.cu:11-40) + channel clear
@@ -369,13 +408,12 @@ extern "C" __global__ void __launch_bounds__(LM_BLOCK)
 KN(lm_k_extract0)(LmScene sc, LmFrame fr, LmCamera cam, int cur)
 {
     const uint32_t stride = gridDim.x * LM_BLOCK;
-    float4* g = fr.gbuf[cur];
     for (uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x; i < fr.n; i += stride) {
         const float4 o4 = fr.rayO[0][i], d4 = fr.rayD[0][i], c4 = fr.rayC[0][i];
         const uint32_t li = f2u(d4.w);
         LmSurface s;
         lm_extract(sc, fr.hits[i], v3(o4), v3(d4), v3(c4), s);
-        lm_gbuf_store(g, fr.n, li, s);
+        lm_gbuf_store(fr.gbuf[cur], fr.probe[cur], li, s);
         // motion vector
         const uint32_t ly = li / fr.ww, lx = li - ly * fr.ww;
         const uint32_t px = fr.x0 + lx, py = fr.y0 + ly;
@@ -479,29 +517,24 @@ __device__ bool lm_shade_indirect(const LmSurface& s, uint32_t gi, uint32_t seed
     return true;
 }
 
-// depth 0 continuation: reads the G-buffer written by KN(lm_k_extract0)
+// depth 0 continuation: reads the G-buffer written by lm_k_extract0 (one block per 16x16 tile)
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
 KN(lm_k_shade_indirect0)(LmFrame fr, int cur, uint32_t seed2, int outQ, uint32_t* outCount)
 {
-    const uint32_t stride = gridDim.x * LM_BLOCK;
-    const uint32_t nIter = (fr.n + stride - 1u) / stride;
-    for (uint32_t it = 0; it < nIter; it++) {
-        const uint32_t li = it * stride + blockIdx.x * LM_BLOCK + threadIdx.x;
-        bool emit = false;
-        lf3 o = v3(0.f), d = v3(0.f), c = v3(0.f);
-        if (li < fr.n) {
-            LmSurface s;
-            lm_gbuf_load(fr.gbuf[cur], fr.n, li, s);
-            const uint32_t ly = li / fr.ww, lx = li - ly * fr.ww;
-            const uint32_t gi = (fr.y0 + ly) * fr.W + (fr.x0 + lx);
-            emit = lm_shade_indirect(s, gi, seed2, o, d, c);
-        }
-        const uint32_t slot = lm_append_slot(outCount, emit);
-        if (emit) {
-            fr.rayO[outQ][slot] = v4(o, 0.f);
-            fr.rayD[outQ][slot] = v4(d, u2f(li));
-            fr.rayC[outQ][slot] = v4(c, 0.f);
-        }
+    uint32_t li = 0, gi = 0;
+    const bool valid = lm_tile_pixel(fr, li, gi);
+    bool emit = false;
+    lf3 o = v3(0.f), d = v3(0.f), c = v3(0.f);
+    if (valid) {
+        LmSurface s;
+        lm_gbuf_load(fr.gbuf[cur], li, s);
+        emit = lm_shade_indirect(s, gi, seed2, o, d, c);
+    }
+    const uint32_t slot = lm_append_slot(outCount, emit);
+    if (emit) {
+        fr.rayO[outQ][slot] = v4(o, 0.f);
+        fr.rayD[outQ][slot] = v4(d, u2f(li));
+        fr.rayC[outQ][slot] = v4(c, 0.f);
     }
 }
 
@@ -571,27 +604,34 @@ KN(lm_k_trace_shadow)(LmScene sc, LmFrame fr, const uint32_t* __restrict__ count
 
 // ---------------------------------------------------------------------------------------------------------------------
 // ReSTIR DI — reference ReSTIRData.h:115-178, ReSTIRKernels.cu, Framework/ReSTIR.cpp:65-233
-// reservoir planes (5 float4 per pixel): 0 (weightSum, weight, sampleCount bits, solidAnglePdf)
-//   1 (radiance, area)  2 (normal, 0)  3 (position, 0)  4 (unshadowed contribution, 0)
+// reservoir storage: a 64-byte "hot" record per pixel (what reuse passes gather from other pixels):
+//   0 (weightSum, weight, sampleCount bits, solidAnglePdf)   1 (radiance, area)   2 (normal, 0)   3 (position, 0)
+// plus a separate plane with the unshadowed contribution (only ever read for the pixel being shaded).
 // ---------------------------------------------------------------------------------------------------------------------
 struct LmSample { lf3 radiance, normal, position, contribution; float area, pdf; };
 struct LmReservoir { float weightSum, weight; long long count; LmSample s; };
 
 __device__ __forceinline__ void lm_sample_zero(LmSample& s) { s.radiance = v3(0.f); s.normal = v3(0.f); s.position = v3(0.f); s.contribution = v3(0.f); s.area = 0.f; s.pdf = 0.f; }
 __device__ __forceinline__ void lm_res_fresh(LmReservoir& r) { r.weightSum = 0.f; r.weight = 0.f; r.count = 0; lm_sample_zero(r.s); }
-__device__ __forceinline__ void lm_res_load(const float4* __restrict__ b, uint32_t n, uint32_t li, LmReservoir& r)
+__device__ __forceinline__ void lm_res_unpack(const float4& a, const float4& p1, const float4& p2, const float4& p3, LmReservoir& r)
 {
-    const float4 a = b[li], p1 = b[n + li], p2 = b[2u * n + li], p3 = b[3u * n + li], p4 = b[4u * n + li];
     r.weightSum = a.x; r.weight = a.y; r.count = (long long)f2u(a.z); r.s.pdf = a.w;
-    r.s.radiance = v3(p1); r.s.area = p1.w; r.s.normal = v3(p2); r.s.position = v3(p3); r.s.contribution = v3(p4);
+    r.s.radiance = v3(p1); r.s.area = p1.w; r.s.normal = v3(p2); r.s.position = v3(p3);
 }
-__device__ __forceinline__ void lm_res_store(float4* __restrict__ b, uint32_t n, uint32_t li, const LmReservoir& r)
+__device__ __forceinline__ void lm_res_load(const float4* __restrict__ hot, const float4* __restrict__ contrib, uint32_t li, LmReservoir& r)
 {
-    b[li] = make_float4(r.weightSum, r.weight, u2f((uint32_t)r.count), r.s.pdf);
-    b[n + li] = v4(r.s.radiance, r.s.area);
-    b[2u * n + li] = v4(r.s.normal, 0.f);
-    b[3u * n + li] = v4(r.s.position, 0.f);
-    b[4u * n + li] = v4(r.s.contribution, 0.f);
+    const float4* h = hot + 4u * li;
+    lm_res_unpack(h[0], h[1], h[2], h[3], r);
+    r.s.contribution = v3(contrib[li]);
+}
+__device__ __forceinline__ void lm_res_store(float4* __restrict__ hot, float4* __restrict__ contrib, uint32_t li, const LmReservoir& r)
+{
+    float4* h = hot + 4u * li;
+    h[0] = make_float4(r.weightSum, r.weight, u2f((uint32_t)r.count), r.s.pdf);
+    h[1] = v4(r.s.radiance, r.s.area);
+    h[2] = v4(r.s.normal, 0.f);
+    h[3] = v4(r.s.position, 0.f);
+    contrib[li] = v4(r.s.contribution, 0.f);
 }
 __device__ __forceinline__ void lm_res_update(LmReservoir& r, const LmSample& s, float w, uint32_t seed /* by value: reference quirk */)
 {
@@ -651,15 +691,14 @@ KN(lm_k_fill_bags)(LmScene sc, LmFrame fr, uint32_t seed, uint32_t total)
     fr.bags[i] = make_uint2(li, f2u(pdf));
 }
 
-// K21 PickPrimarySamples — ReSTIRKernels.cu:402-522.  One 16x16 pixel tile shares a light bag (the reference keys
-// the bag on the hardware SM id, which is not reproducible: DESIGN.md decision D2); the bag's 1000 (index, pdf)
-// pairs are staged in LDS once per tile.
+// K21 PickPrimarySamples — ReSTIRKernels.cu:402-522.  One 16x16 pixel tile (aligned to the GLOBAL 16x16 grid) shares a light
+// bag (the reference keys the bag on the hardware SM id, which is not reproducible: DESIGN.md decision D2); the bag's 1000
+// (index, pdf) pairs are staged in LDS once per tile.
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
-KN(lm_k_pick_primary)(LmScene sc, LmFrame fr, int cur, float4* __restrict__ resCur, uint32_t seed)
+KN(lm_k_pick_primary)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed)
 {
     __shared__ uint2 s_bag[1000];
     const uint32_t tilesX = (fr.W + 15u) / 16u;
-    // block -> tile of the window (tiles aligned to the global 16x16 grid)
     const uint32_t tx0 = fr.x0 / 16u, ty0 = fr.y0 / 16u;
     const uint32_t wtx = (fr.x0 + fr.ww + 15u) / 16u - tx0;
     const uint32_t tileX = tx0 + blockIdx.x % wtx, tileY = ty0 + blockIdx.x / wtx;
@@ -672,9 +711,10 @@ KN(lm_k_pick_primary)(LmScene sc, LmFrame fr, int cur, float4* __restrict__ resC
     if (px < fr.x0 || py < fr.y0 || px >= fr.x0 + fr.ww || py >= fr.y0 + fr.wh) return;
     const uint32_t li = (py - fr.y0) * fr.ww + (px - fr.x0);
     const uint32_t gi = py * fr.W + px;
+    float4* hot = fr.res[rc];
     LmSurface pixel;
-    lm_gbuf_load(fr.gbuf[cur], fr.n, li, pixel);
-    if (pixel.flags) { float4 a = resCur[li]; a.y = 0.f; resCur[li] = a; return; }
+    lm_gbuf_load(fr.gbuf[cur], li, pixel);
+    if (pixel.flags) { float4 a = hot[4u * li]; a.y = 0.f; hot[4u * li] = a; return; }
     uint32_t s = lm_wang_hash(seed + lm_wang_hash(gi));
     LmReservoir fresh; lm_res_fresh(fresh);
     for (int smp = 0; smp < 32; smp++) {
@@ -695,177 +735,162 @@ KN(lm_k_pick_primary)(LmScene sc, LmFrame fr, int cur, float4* __restrict__ resC
         lm_res_update(fresh, rs, pdf, s);
     }
     lm_res_update_weight(fresh);
-    lm_res_store(resCur, fr.n, li, fresh);
+    lm_res_store(hot, fr.resC[rc], li, fresh);
 }
 
 // K22 + K6 + K23: visibility ray of the pixel's reservoir (tmin 0.1, tmax d - 0.05; ReSTIRKernels.cu:546-582,
-// WaveFrontShaders.cu:181-216), then shade it into DIRECT with weight/3 (ReSTIRKernels.cu:600-665)
+// WaveFrontShaders.cu:181-216), then shade it into DIRECT with weight/3 (ReSTIRKernels.cu:600-665).  One block per 16x16 tile.
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
-KN(lm_k_restir_visibility_shade)(LmScene sc, LmFrame fr, int cur, float4* __restrict__ res)
+KN(lm_k_restir_visibility_shade)(LmScene sc, LmFrame fr, int cur, int rc)
 {
     __shared__ int s_stack[LM_STACK_DEPTH * LM_BLOCK];
     int* stack = s_stack + threadIdx.x;
-    const uint32_t stride = gridDim.x * LM_BLOCK;
-    const uint32_t nIter = (fr.n + stride - 1u) / stride;
-    const float4* g = fr.gbuf[cur];
-    for (uint32_t it = 0; it < nIter; it++) {
-        const uint32_t li = it * stride + blockIdx.x * LM_BLOCK + threadIdx.x;
-        bool shoot = false;
-        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f);
-        lf3 pos = v3(0.f), toLight = v3(0.f);
-        float l = 0.f;
-        if (li < fr.n && f2u(g[fr.n + li].w) == 0u) {
-            r0 = res[li];
-            if (r0.y > 0.f) {
-                pos = v3(g[li]);
-                toLight = v3(res[3u * fr.n + li]) - pos;
-                l = length3(toLight);
-                toLight = toLight / l;
-                shoot = true;
-            }
+    uint32_t li = 0, gi = 0;
+    const bool valid = lm_tile_pixel(fr, li, gi);
+    float4* hot = fr.res[rc];
+    bool shoot = false;
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    lf3 pos = v3(0.f), toLight = v3(0.f);
+    float l = 0.f;
+    if (valid && fr.probe[cur][li].w >= 0.f) {
+        r0 = hot[4u * li];
+        if (r0.y > 0.f) {
+            pos = v3(fr.gbuf[cur][8u * li]);
+            toLight = v3(hot[4u * li + 3u]) - pos;
+            l = length3(toLight);
+            toLight = toLight / l;
+            shoot = true;
         }
-        lm_count(fr.counters + LM_CNT_RESTIR, shoot);
-        if (shoot) {
-            LmHit h;
-            if (lm_traverse<true>(sc, pos, toLight, 0.1f, l - 0.05f, stack, h, fr.counters)) { r0.y = 0.f; res[li] = r0; }
-            if (r0.y > 0.f) {
-                const lf3 add = v3(res[4u * fr.n + li]) * (r0.y / 3.f);
-                float4 px = fr.direct[li];
-                px.x += add.x; px.y += add.y; px.z += add.z;
-                fr.direct[li] = px;
-            }
+    }
+    lm_count(fr.counters + LM_CNT_RESTIR, shoot);
+    if (shoot) {
+        LmHit h;
+        if (lm_traverse<true>(sc, pos, toLight, 0.1f, l - 0.05f, stack, h, fr.counters)) { r0.y = 0.f; hot[4u * li] = r0; }
+        if (r0.y > 0.f) {
+            const lf3 add = v3(fr.resC[rc][li]) * (r0.y / 3.f);
+            float4 px = fr.direct[li];
+            px.x += add.x; px.y += add.y; px.z += add.z;
+            fr.direct[li] = px;
         }
     }
 }
 
 // K24 temporal reuse — ReSTIRKernels.cu:1015-1121
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
-KN(lm_k_restir_temporal)(LmFrame fr, int cur, int prev, float4* __restrict__ resCur, const float4* __restrict__ resPrev, uint32_t seed)
+KN(lm_k_restir_temporal)(LmFrame fr, int cur, int prev, int rc, int rp, uint32_t seed)
 {
-    const uint32_t stride = gridDim.x * LM_BLOCK;
-    for (uint32_t li = blockIdx.x * LM_BLOCK + threadIdx.x; li < fr.n; li += stride) {
-        const int ly = (int)(li / fr.ww), lx = (int)(li - (uint32_t)ly * fr.ww);
-        const uint32_t gi = (fr.y0 + (uint32_t)ly) * fr.W + (fr.x0 + (uint32_t)lx);
-        const uint32_t mv = fr.motion[li];
-        const float vx = lm_f16_to_f32(mv & 0xffffu), vy = lm_f16_to_f32(mv >> 16);
-        const int movedX = (int)roundf((float)fr.W * vx), movedY = (int)roundf((float)fr.H * vy);
-        int ty = ly + movedY, tx = lx + movedX;
-        uint32_t tli = li;
-        if (ty >= 0 && ty < (int)fr.wh && tx >= 0 && tx < (int)fr.ww) tli = (uint32_t)ty * fr.ww + (uint32_t)tx;
-        const float4* gp = fr.gbuf[prev];
-        const float4* gc = fr.gbuf[cur];
-        const float4 pn = gp[8u * fr.n + tli], cn = gc[8u * fr.n + li];
-        if (pn.w < 0.f || cn.w < 0.f) continue;                 // flagged surface on either side
-        const float d1 = pn.w, d2 = cn.w;
-        const float depthDif = fabsf(d1 - d2) / ((d1 + d2) / 2.f);
-        const float angle = dot3(v3(pn), v3(cn));
-        if (!(depthDif < 0.10f && angle > 0.72222222223f)) continue;
-        LmReservoir rp, rc;
-        lm_res_load(resPrev, fr.n, tli, rp);
-        lm_res_load(resCur, fr.n, li, rc);
-        if (rp.weight > 0.f) {                                   // ShadeReservoirs on the PREVIOUS reservoir
-            const lf3 add = rp.s.contribution * (rp.weight / 3.f);
-            float4 px = fr.direct[li];
-            px.x += add.x; px.y += add.y; px.z += add.z;
-            fr.direct[li] = px;
-        }
-        const long long cap = rc.count * 20;
-        if (cap < rp.count) rp.count = cap;
-        LmSurface s;
-        lm_gbuf_load(gc, fr.n, li, s);
-        LmReservoir out;
-        lm_combine2(out, rp, rc, s, lm_wang_hash(seed + gi));
-        lm_res_store(resCur, fr.n, li, out);
+    uint32_t li = 0, gi = 0;
+    if (!lm_tile_pixel(fr, li, gi)) return;
+    const int ly = (int)(li / fr.ww), lx = (int)(li - (uint32_t)ly * fr.ww);
+    const uint32_t mv = fr.motion[li];
+    const float vx = lm_f16_to_f32(mv & 0xffffu), vy = lm_f16_to_f32(mv >> 16);
+    const int movedX = (int)roundf((float)fr.W * vx), movedY = (int)roundf((float)fr.H * vy);
+    const int ty = ly + movedY, tx = lx + movedX;
+    uint32_t tli = li;
+    if (ty >= 0 && ty < (int)fr.wh && tx >= 0 && tx < (int)fr.ww) tli = (uint32_t)ty * fr.ww + (uint32_t)tx;
+    const float4 pn = fr.probe[prev][tli], cn = fr.probe[cur][li];
+    if (pn.w < 0.f || cn.w < 0.f) return;                      // flagged surface on either side
+    const float d1 = pn.w, d2 = cn.w;
+    const float depthDif = fabsf(d1 - d2) / ((d1 + d2) / 2.f);
+    const float angle = dot3(v3(pn), v3(cn));
+    if (!(depthDif < 0.10f && angle > 0.72222222223f)) return;
+    LmReservoir rpv, rcv;
+    lm_res_load(fr.res[rp], fr.resC[rp], tli, rpv);
+    lm_res_load(fr.res[rc], fr.resC[rc], li, rcv);
+    if (rpv.weight > 0.f) {                                     // ShadeReservoirs on the PREVIOUS reservoir
+        const lf3 add = rpv.s.contribution * (rpv.weight / 3.f);
+        float4 px = fr.direct[li];
+        px.x += add.x; px.y += add.y; px.z += add.z;
+        fr.direct[li] = px;
     }
+    const long long cap = rcv.count * 20;
+    if (cap < rpv.count) rpv.count = cap;
+    LmSurface s;
+    lm_gbuf_load(fr.gbuf[cur], li, s);
+    LmReservoir out;
+    lm_combine2(out, rpv, rcv, s, lm_wang_hash(seed + gi));
+    lm_res_store(fr.res[rc], fr.resC[rc], li, out);
 }
 
 // K25 spatial reuse — ReSTIRKernels.cu:787-980 (biased branch).  The five candidate probes are issued together (one
-// 16-byte gather each from the probe plane) and the accepted candidates' reservoirs are fetched one iteration ahead of
-// their re-evaluation, so the kernel is not a chain of dependent L2 round trips.
-__device__ __forceinline__ void lm_res_load4(const float4* __restrict__ b, uint32_t n, uint32_t li, float4& a, float4& p1, float4& p2, float4& p3)
-{
-    a = b[li]; p1 = b[n + li]; p2 = b[2u * n + li]; p3 = b[3u * n + li];
-}
+// 16-byte gather each from the probe plane) and the accepted candidates' 64-byte reservoir records are fetched one
+// iteration ahead of their re-evaluation, so the kernel is not a chain of dependent L2 round trips.
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
-KN(lm_k_restir_spatial)(LmFrame fr, int cur, const float4* __restrict__ resIn, float4* __restrict__ resOut, uint32_t seed)
+KN(lm_k_restir_spatial)(LmFrame fr, int cur, int rin, int rout, uint32_t seed)
 {
-    const uint32_t stride = gridDim.x * LM_BLOCK;
-    const float4* g = fr.gbuf[cur];
-    const float4* probe = g + 8u * fr.n;
-    for (uint32_t li = blockIdx.x * LM_BLOCK + threadIdx.x; li < fr.n; li += stride) {
-        const float4 cn = probe[li];
-        if (cn.w < 0.f) continue;
-        const int y = (int)(li / fr.ww), x = (int)(li - (uint32_t)y * fr.ww);
-        const uint32_t gi = (fr.y0 + (uint32_t)y) * fr.W + (fr.x0 + (uint32_t)x);
-        uint32_t s = lm_wang_hash(seed + gi);
-        const float ct = cn.w;
-        uint32_t cand[5];
-        float4 pr[5];
+    uint32_t li = 0, gi = 0;
+    if (!lm_tile_pixel(fr, li, gi)) return;
+    const float4* probe = fr.probe[cur];
+    const float4* hotIn = fr.res[rin];
+    const float4 cn = probe[li];
+    if (cn.w < 0.f) return;
+    const int y = (int)(li / fr.ww), x = (int)(li - (uint32_t)y * fr.ww);
+    uint32_t s = lm_wang_hash(seed + gi);
+    const float ct = cn.w;
+    uint32_t cand[5];
+    float4 pr[5];
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const int ny = (int)roundf((lm_random_float(s) * 2.f - 1.f) * 30.f) + y;
-            const int nx = (int)roundf((lm_random_float(s) * 2.f - 1.f) * 30.f) + x;
-            const bool in = !(nx < 0 || nx >= (int)fr.ww || ny < 0 || ny >= (int)fr.wh);
-            cand[k] = in ? (uint32_t)ny * fr.ww + (uint32_t)nx : 0xffffffffu;
-        }
+    for (int k = 0; k < 5; k++) {
+        const int ny = (int)roundf((lm_random_float(s) * 2.f - 1.f) * 30.f) + y;
+        const int nx = (int)roundf((lm_random_float(s) * 2.f - 1.f) * 30.f) + x;
+        const bool in = !(nx < 0 || nx >= (int)fr.ww || ny < 0 || ny >= (int)fr.wh);
+        cand[k] = in ? (uint32_t)ny * fr.ww + (uint32_t)nx : 0xffffffffu;
+    }
 #pragma unroll
-        for (int k = 0; k < 5; k++) pr[k] = probe[cand[k] != 0xffffffffu ? cand[k] : li];
-        uint32_t nb[5];
-        int count = 0;
+    for (int k = 0; k < 5; k++) pr[k] = probe[cand[k] != 0xffffffffu ? cand[k] : li];
+    uint32_t nb[5];
+    int count = 0;
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
-            if (cand[k] == 0xffffffffu || pr[k].w < 0.f) continue;
-            const float d1 = pr[k].w;
-            const float depthDif = fabsf(d1 - ct) / ((d1 + ct) / 2.f);
-            const float angle = dot3(v3(pr[k]), v3(cn));
-            if (depthDif < 0.10f && angle > 0.72222222223f) nb[count++] = cand[k];
+    for (int k = 0; k < 5; k++) {
+        if (cand[k] == 0xffffffffu || pr[k].w < 0.f) continue;
+        const float d1 = pr[k].w;
+        const float depthDif = fabsf(d1 - ct) / ((d1 + ct) / 2.f);
+        const float angle = dot3(v3(pr[k]), v3(cn));
+        if (depthDif < 0.10f && angle > 0.72222222223f) nb[count++] = cand[k];
+    }
+    float4* hotOut = fr.res[rout];
+    if (count > 1) {
+        const float4* h = hotIn + 4u * nb[0];
+        float4 a = h[0], p1 = h[1], p2 = h[2], p3 = h[3];
+        LmSurface s0;
+        lm_gbuf_load(fr.gbuf[cur], nb[0], s0);                  // every candidate is re-evaluated at the FIRST neighbour's surface (reference :883)
+        LmReservoir out; lm_res_fresh(out);
+        long long sum = 0;
+        for (int k = 0; k < count; k++) {
+            float4 na = a, np1 = p1, np2 = p2, np3 = p3;
+            if (k + 1 < count) { const float4* hn = hotIn + 4u * nb[k + 1]; na = hn[0]; np1 = hn[1]; np2 = hn[2]; np3 = hn[3]; }   // prefetch
+            LmSample in; lm_sample_zero(in);
+            in.radiance = v3(p1); in.area = p1.w; in.normal = v3(p2); in.position = v3(p3);
+            const long long cnt = (long long)f2u(a.z);
+            LmSample rs;
+            lm_resample(in, s0, rs);
+            lm_res_update(out, rs, (float)cnt * a.y * rs.pdf, seed);   // global seed: same draw for all pixels (reference quirk)
+            sum += cnt;
+            a = na; p1 = np1; p2 = np2; p3 = np3;
         }
-        if (count > 1) {
-            float4 a, p1, p2, p3;
-            lm_res_load4(resIn, fr.n, nb[0], a, p1, p2, p3);
-            LmSurface s0;
-            lm_gbuf_load(g, fr.n, nb[0], s0);                    // every candidate is re-evaluated at the FIRST neighbour's surface (reference :883)
-            LmReservoir out; lm_res_fresh(out);
-            long long sum = 0;
-            for (int k = 0; k < count; k++) {
-                float4 na = a, np1 = p1, np2 = p2, np3 = p3;
-                if (k + 1 < count) lm_res_load4(resIn, fr.n, nb[k + 1], na, np1, np2, np3);     // prefetch the next candidate
-                LmSample in; lm_sample_zero(in);
-                in.radiance = v3(p1); in.area = p1.w; in.normal = v3(p2); in.position = v3(p3);
-                const long long cnt = (long long)f2u(a.z);
-                LmSample rs;
-                lm_resample(in, s0, rs);
-                lm_res_update(out, rs, (float)cnt * a.y * rs.pdf, seed);   // global seed: same draw for all pixels (reference quirk)
-                sum += cnt;
-                a = na; p1 = np1; p2 = np2; p3 = np3;
-            }
-            out.count = sum;
-            lm_res_update_weight(out);
-            lm_res_store(resOut, fr.n, li, out);
-        } else {
-            resOut[li] = make_float4(0.f, 0.f, u2f(0u), resOut[li].w);   // Reset(): weightSum, sampleCount, weight
-        }
+        out.count = sum;
+        lm_res_update_weight(out);
+        lm_res_store(hotOut, fr.resC[rout], li, out);
+    } else {
+        const float4 old = hotOut[4u * li];
+        hotOut[4u * li] = make_float4(0.f, 0.f, u2f(0u), old.w);   // Reset(): weightSum, sampleCount, weight
     }
 }
 
 // K26 CombineReservoirBuffers — ReSTIRKernels.cu:1407-1436
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
-KN(lm_k_restir_combine)(LmFrame fr, int cur, float4* __restrict__ resCur, const float4* __restrict__ resSpatial, uint32_t seed)
+KN(lm_k_restir_combine)(LmFrame fr, int cur, int rc, int rs, uint32_t seed)
 {
-    const uint32_t stride = gridDim.x * LM_BLOCK;
-    const float4* g = fr.gbuf[cur];
-    for (uint32_t li = blockIdx.x * LM_BLOCK + threadIdx.x; li < fr.n; li += stride) {
-        if (f2u(g[fr.n + li].w) != 0u) continue;
-        const uint32_t ly = li / fr.ww, lx = li - ly * fr.ww;
-        const uint32_t gi = (fr.y0 + ly) * fr.W + (fr.x0 + lx);
-        LmSurface s;
-        lm_gbuf_load(g, fr.n, li, s);
-        LmReservoir a, b, out;
-        lm_res_load(resCur, fr.n, li, a);
-        lm_res_load(resSpatial, fr.n, li, b);
-        lm_combine2(out, a, b, s, lm_wang_hash(seed + gi));
-        lm_res_store(resCur, fr.n, li, out);
-    }
+    uint32_t li = 0, gi = 0;
+    if (!lm_tile_pixel(fr, li, gi)) return;
+    if (fr.probe[cur][li].w < 0.f) return;
+    LmSurface s;
+    lm_gbuf_load(fr.gbuf[cur], li, s);
+    LmReservoir a, b, out;
+    lm_res_load(fr.res[rc], fr.resC[rc], li, a);
+    lm_res_load(fr.res[rs], fr.resC[rs], li, b);
+    lm_combine2(out, a, b, s, lm_wang_hash(seed + gi));
+    lm_res_store(fr.res[rc], fr.resC[rc], li, out);
 }
 
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
@@ -1003,11 +1028,11 @@ static void l_shade_wave(hipStream_t s, int g, LmScene sc, LmFrame fr, int inQ, 
 { hipLaunchKernelGGL(KN(lm_k_shade_wave), LM_GRID(g), sc, fr, inQ, inCount, seed, seed2, doIndirect, outCount, shadowCount); }
 static void l_trace_shadow(hipStream_t s, int g, LmScene sc, LmFrame fr, const uint32_t* cnt, float tmin) { hipLaunchKernelGGL(KN(lm_k_trace_shadow), LM_GRID(g), sc, fr, cnt, tmin); }
 static void l_fill_bags(hipStream_t s, LmScene sc, LmFrame fr, uint32_t seed, uint32_t total) { hipLaunchKernelGGL(KN(lm_k_fill_bags), LM_GRID((total + LM_BLOCK - 1) / LM_BLOCK), sc, fr, seed, total); }
-static void l_pick_primary(hipStream_t s, int tiles, LmScene sc, LmFrame fr, int cur, float4* res, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_pick_primary), LM_GRID(tiles), sc, fr, cur, res, seed); }
-static void l_visibility_shade(hipStream_t s, int g, LmScene sc, LmFrame fr, int cur, float4* res) { hipLaunchKernelGGL(KN(lm_k_restir_visibility_shade), LM_GRID(g), sc, fr, cur, res); }
-static void l_temporal(hipStream_t s, int g, LmFrame fr, int cur, int prev, float4* rc, const float4* rp, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_restir_temporal), LM_GRID(g), fr, cur, prev, rc, rp, seed); }
-static void l_spatial(hipStream_t s, int g, LmFrame fr, int cur, const float4* in, float4* out, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_restir_spatial), LM_GRID(g), fr, cur, in, out, seed); }
-static void l_combine(hipStream_t s, int g, LmFrame fr, int cur, float4* rc, const float4* rs, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_restir_combine), LM_GRID(g), fr, cur, rc, rs, seed); }
+static void l_pick_primary(hipStream_t s, int tiles, LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_pick_primary), LM_GRID(tiles), sc, fr, cur, rc, seed); }
+static void l_visibility_shade(hipStream_t s, int g, LmScene sc, LmFrame fr, int cur, int rc) { hipLaunchKernelGGL(KN(lm_k_restir_visibility_shade), LM_GRID(g), sc, fr, cur, rc); }
+static void l_temporal(hipStream_t s, int g, LmFrame fr, int cur, int prev, int rc, int rp, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_restir_temporal), LM_GRID(g), fr, cur, prev, rc, rp, seed); }
+static void l_spatial(hipStream_t s, int g, LmFrame fr, int cur, int rin, int rout, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_restir_spatial), LM_GRID(g), fr, cur, rin, rout, seed); }
+static void l_combine(hipStream_t s, int g, LmFrame fr, int cur, int rc, int rs, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_restir_combine), LM_GRID(g), fr, cur, rc, rs, seed); }
 static void l_clear(hipStream_t s, int g, float4* p, uint32_t n) { hipLaunchKernelGGL(KN(lm_k_clear_f4), LM_GRID(g), p, n); }
 static void l_merge(hipStream_t s, int g, LmFrame fr, int blend, uint32_t blendCount) { hipLaunchKernelGGL(KN(lm_k_merge_output), LM_GRID(g), fr, blend, blendCount); }
 static void l_query_any(hipStream_t s, int g, LmScene sc, const float4* o, const float4* d, uint32_t n, float tmin, uint32_t* occ, uint32_t* counters) { hipLaunchKernelGGL(KN(lm_k_query_any), LM_GRID(g), sc, o, d, n, tmin, occ, counters); }

@@ -6,15 +6,15 @@ struct LmKernelTable {
     void (*primary)(hipStream_t, int grid, LmFrame, LmCamera, uint32_t frameCount);
     void (*trace_closest)(hipStream_t, int grid, LmScene, const float4* o, const float4* d, const uint32_t* count, uint4* hits, float tmin, float tmax, uint32_t* counters);
     void (*extract0)(hipStream_t, int grid, LmScene, LmFrame, LmCamera, int cur);
-    void (*shade_indirect0)(hipStream_t, int grid, LmFrame, int cur, uint32_t seed2, int outQ, uint32_t* outCount);
+    void (*shade_indirect0)(hipStream_t, int tiles, LmFrame, int cur, uint32_t seed2, int outQ, uint32_t* outCount);
     void (*shade_wave)(hipStream_t, int grid, LmScene, LmFrame, int inQ, const uint32_t* inCount, uint32_t seed, uint32_t seed2, int doIndirect, uint32_t* outCount, uint32_t* shadowCount);
     void (*trace_shadow)(hipStream_t, int grid, LmScene, LmFrame, const uint32_t* count, float tmin);
     void (*fill_bags)(hipStream_t, LmScene, LmFrame, uint32_t seed, uint32_t total);
-    void (*pick_primary)(hipStream_t, int tiles, LmScene, LmFrame, int cur, float4* res, uint32_t seed);
-    void (*visibility_shade)(hipStream_t, int grid, LmScene, LmFrame, int cur, float4* res);
-    void (*temporal)(hipStream_t, int grid, LmFrame, int cur, int prev, float4* resCur, const float4* resPrev, uint32_t seed);
-    void (*spatial)(hipStream_t, int grid, LmFrame, int cur, const float4* in, float4* out, uint32_t seed);
-    void (*combine)(hipStream_t, int grid, LmFrame, int cur, float4* resCur, const float4* resSpatial, uint32_t seed);
+    void (*pick_primary)(hipStream_t, int tiles, LmScene, LmFrame, int cur, int rc, uint32_t seed);
+    void (*visibility_shade)(hipStream_t, int tiles, LmScene, LmFrame, int cur, int rc);
+    void (*temporal)(hipStream_t, int tiles, LmFrame, int cur, int prev, int rc, int rp, uint32_t seed);
+    void (*spatial)(hipStream_t, int tiles, LmFrame, int cur, int rin, int rout, uint32_t seed);
+    void (*combine)(hipStream_t, int tiles, LmFrame, int cur, int rc, int rs, uint32_t seed);
     void (*clear)(hipStream_t, int grid, float4* p, uint32_t n);
     void (*merge)(hipStream_t, int grid, LmFrame, int blend, uint32_t blendCount);
     void (*query_any)(hipStream_t, int grid, LmScene, const float4* o, const float4* d, uint32_t n, float tmin, uint32_t* occluded, uint32_t* counters);

@@ -10,7 +10,6 @@
 
 #define LM_STACK_DEPTH 32        // traversal stack entries per lane; the BVH builder bounds the tree depth to this
 #define LM_MAX_LEAF 8            // triangles per leaf representable in a leaf reference
-#define LM_GBUF_PLANES 9
 #define LM_MAX_DEPTH 16          // path depth the counter block is sized for
 
 // surface flags (reference: SurfaceData.h:18-24)
@@ -76,10 +75,12 @@ struct LmFrame {
     uint4* hits;                // entry, prim, half2 barycentrics, t bits
     // shadow-ray queue of the current wave: origin.xyz + tmax | dir.xyz + pixel | radiance.xyz
     float4 *shO, *shD, *shR;
-    // depth-0 surface data, two frames: LM_GBUF_PLANES planes of n float4 each (see kernels.hip "G-buffer planes")
+    // depth-0 surface data, two frames: one 128-byte record (8 float4) per pixel + a 16-byte reuse-probe plane (kernels.hip)
     float4* gbuf[2];
-    // reservoirs: 4 buffers x 5 planes of n float4
+    float4* probe[2];
+    // reservoirs, 4 buffers: one 64-byte hot record (4 float4) per pixel + a contribution plane
     float4* res[4];
+    float4* resC[4];
     uint32_t* motion;           // half2 motion vector per pixel
     float4 *direct, *indirect;  // fp32 light channels
     float4* combined;           // merged / blended radiance

@@ -133,7 +133,7 @@ struct lumen_mi_renderer {
     // device frame
     LmFrame fr{};
     uint32_t allocN = 0, allocDepth = 0;
-    DevBuf<float4> dRay[6], dSh[3], dGbuf[2], dRes[4], dDirect, dIndirect, dCombined;
+    DevBuf<float4> dRay[6], dSh[3], dGbuf[2], dProbe[2], dRes[4], dResC[4], dDirect, dIndirect, dCombined;
     DevBuf<uint4> dHits; DevBuf<uint32_t> dMotion, dCounters; DevBuf<uchar4> dOutput; DevBuf<uint2> dBags;
     uint32_t hostCounters[LM_CNT_WORDS] = {0};
     bool countersValid = false;
@@ -400,22 +400,22 @@ int ensureFrameBuffers(R* r)
     int bad = 0;
     for (int i = 0; i < 6; i++) bad |= r->dRay[i].ensure(n);
     for (int i = 0; i < 3; i++) bad |= r->dSh[i].ensure(n);
-    for (int i = 0; i < 2; i++) bad |= r->dGbuf[i].ensure((size_t)LM_GBUF_PLANES * n);
-    for (int i = 0; i < 4; i++) bad |= r->dRes[i].ensure((size_t)5 * n);
+    for (int i = 0; i < 2; i++) bad |= r->dGbuf[i].ensure((size_t)8 * n) | r->dProbe[i].ensure(n);
+    for (int i = 0; i < 4; i++) bad |= r->dRes[i].ensure((size_t)4 * n) | r->dResC[i].ensure(n);
     bad |= r->dDirect.ensure(n) | r->dIndirect.ensure(n) | r->dCombined.ensure(n) | r->dHits.ensure(n) | r->dMotion.ensure(n) | r->dOutput.ensure(n);
     bad |= r->dCounters.ensure(LM_CNT_WORDS) | r->dBags.ensure(50 * 1000);
     if (bad) return fail(LUMEN_MI_ERR_DEVICE, "frame buffer allocation failed");
     for (int q = 0; q < 2; q++) { f.rayO[q] = r->dRay[3 * q].p; f.rayD[q] = r->dRay[3 * q + 1].p; f.rayC[q] = r->dRay[3 * q + 2].p; }
     f.shO = r->dSh[0].p; f.shD = r->dSh[1].p; f.shR = r->dSh[2].p;
     f.hits = r->dHits.p;
-    for (int i = 0; i < 2; i++) f.gbuf[i] = r->dGbuf[i].p;
-    for (int i = 0; i < 4; i++) f.res[i] = r->dRes[i].p;
+    for (int i = 0; i < 2; i++) { f.gbuf[i] = r->dGbuf[i].p; f.probe[i] = r->dProbe[i].p; }
+    for (int i = 0; i < 4; i++) { f.res[i] = r->dRes[i].p; f.resC[i] = r->dResC[i].p; }
     f.motion = r->dMotion.p; f.direct = r->dDirect.p; f.indirect = r->dIndirect.p; f.combined = r->dCombined.p; f.output = r->dOutput.p;
     f.counters = r->dCounters.p; f.bags = r->dBags.p;
     // ResizeBuffers (WaveFrontRenderer.cpp:1424-1540): history is dropped; reservoirs reset (ReSTIRKernels.cu:36-47)
     hipStream_t st = r->stream;
-    for (int i = 0; i < 2; i++) if (hipMemsetAsync(f.gbuf[i], 0, (size_t)LM_GBUF_PLANES * n * sizeof(float4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
-    for (int i = 0; i < 4; i++) if (hipMemsetAsync(f.res[i], 0, (size_t)5 * n * sizeof(float4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
+    for (int i = 0; i < 2; i++) if (hipMemsetAsync(f.gbuf[i], 0, (size_t)8 * n * sizeof(float4), st) != hipSuccess || hipMemsetAsync(f.probe[i], 0, (size_t)n * sizeof(float4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
+    for (int i = 0; i < 4; i++) if (hipMemsetAsync(f.res[i], 0, (size_t)4 * n * sizeof(float4), st) != hipSuccess || hipMemsetAsync(f.resC[i], 0, (size_t)n * sizeof(float4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
     if (hipMemsetAsync(f.combined, 0, (size_t)n * sizeof(float4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
     if (hipMemsetAsync(f.output, 0, (size_t)n * sizeof(uchar4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
     r->allocN = n;
@@ -526,18 +526,18 @@ int traceFrameAsync(R* r)
             rs = wangHash(rs);
             const uint32_t tx0 = fr.x0 / 16u, ty0 = fr.y0 / 16u;
             const uint32_t wtx = (fr.x0 + fr.ww + 15u) / 16u - tx0, wty = (fr.y0 + fr.wh + 15u) / 16u - ty0;
-            K->pick_primary(st, (int)(wtx * wty), r->dscene, fr, currentIndex, fr.res[cur], rs);
-            const int g8 = r->gridFor(fr.n, 8);
-            K->visibility_shade(st, traceGrid, r->dscene, fr, currentIndex, fr.res[cur]);
+            K->pick_primary(st, (int)(wtx * wty), r->dscene, fr, currentIndex, cur, rs);
+            const int tiles = (int)(((fr.ww + 15u) / 16u) * ((fr.wh + 15u) / 16u));
+            K->visibility_shade(st, tiles, r->dscene, fr, currentIndex, cur);
             rs = wangHash(rs);
-            K->temporal(st, g8, fr, currentIndex, temporalIndex, fr.res[cur], fr.res[tmp], rs);
+            K->temporal(st, tiles, fr, currentIndex, temporalIndex, cur, tmp, rs);
             rs = wangHash(rs);
-            K->spatial(st, g8, fr, currentIndex, fr.res[cur], fr.res[2], rs);
-            K->spatial(st, g8, fr, currentIndex, fr.res[2], fr.res[3], rs);
-            K->visibility_shade(st, traceGrid, r->dscene, fr, currentIndex, fr.res[cur]);
-            K->combine(st, g8, fr, currentIndex, fr.res[cur], fr.res[3], wangHash(rs));
+            K->spatial(st, tiles, fr, currentIndex, cur, 2, rs);
+            K->spatial(st, tiles, fr, currentIndex, 2, 3, rs);
+            K->visibility_shade(st, tiles, r->dscene, fr, currentIndex, cur);
+            K->combine(st, tiles, fr, currentIndex, cur, 3, wangHash(rs));
             evEnd(r, ev);
-            if (doIndirect) { evBegin(r, 2, ev); K->shade_indirect0(st, g8, fr, currentIndex, seed2, q ^ 1, outCount); evEnd(r, ev); }
+            if (doIndirect) { evBegin(r, 2, ev); K->shade_indirect0(st, (int)(((fr.ww + 15u) / 16u) * ((fr.wh + 15u) / 16u)), fr, currentIndex, seed2, q ^ 1, outCount); evEnd(r, ev); }
         } else {
             uint32_t* shCount = fr.counters + LM_CNT_SHADOW(depth);
             evBegin(r, 2, ev);
@@ -634,7 +634,7 @@ int lumen_mi_destroy(lumen_mi_renderer* r)
         (void)hipStreamSynchronize(r->stream);
         r->dNodes.release(); r->dWoop.release(); r->dTriId.release(); r->dTriOrder.release(); r->dVerts.release(); r->dIndices.release();
         r->dEntries.release(); r->dMaterials.release(); r->dTexDesc.release(); r->dTexels.release(); r->dLut.release(); r->dLights.release(); r->dCdf.release();
-        for (auto& b : r->dRay) b.release(); for (auto& b : r->dSh) b.release(); for (auto& b : r->dGbuf) b.release(); for (auto& b : r->dRes) b.release();
+        for (auto& b : r->dRay) b.release(); for (auto& b : r->dSh) b.release(); for (auto& b : r->dGbuf) b.release(); for (auto& b : r->dProbe) b.release(); for (auto& b : r->dRes) b.release(); for (auto& b : r->dResC) b.release();
         r->dDirect.release(); r->dIndirect.release(); r->dCombined.release(); r->dHits.release(); r->dMotion.release(); r->dCounters.release(); r->dOutput.release(); r->dBags.release();
         for (auto& e : r->evPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     }
@@ -935,11 +935,7 @@ int lumen_mi_get_gbuffer(lumen_mi_renderer* r, float* out, size_t cap)
     const uint32_t n = r->fr.n;
     if (cap < (size_t)n * 128) return fail(LUMEN_MI_ERR_INVALID, "buffer too small");
     const int last = r->frameIndex == 0 ? 1 : 0;
-    std::vector<float> planes((size_t)n * 32);
-    int rc = copyOut(r, r->fr.gbuf[last], (size_t)n * 128, planes.data(), (size_t)n * 128);
-    if (rc) return rc;
-    for (uint32_t i = 0; i < n; i++) for (int p = 0; p < 8; p++) memcpy(out + ((size_t)i * 8 + p) * 4, planes.data() + ((size_t)p * n + i) * 4, 16);
-    return 0;
+    return copyOut(r, r->fr.gbuf[last], (size_t)n * 128, out, cap);
 }
 
 int lumen_mi_get_frame_stat(lumen_mi_renderer* r, const char* key, uint64_t* us)
