@@ -170,9 +170,9 @@ void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out)
     }
     b.pad = maxAbs * (1.0f / 32768.0f);
     out->pad = b.pad;
-    // absent child: a point box far outside any ray interval (min/max slab tests would enter an inverted box)
+    // absent child: marked by NaN boxes here; the quantised tree points it at the sentinel (never hit) triangle packet
     Builder::Ref empty; empty.ref = ~0;
-    for (int k = 0; k < 3; k++) { empty.box.lo[k] = 3.0e38f; empty.box.hi[k] = 3.0e38f; }
+    for (int k = 0; k < 3; k++) { empty.box.lo[k] = NAN; empty.box.hi[k] = NAN; }
     if (nTris == 0) {
         out->nodes.emplace_back();
         b.setNode(0, empty, empty);
@@ -186,6 +186,42 @@ void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out)
         }
     }
     out->maxDepth = b.maxDepth + 1;
-    out->woop.resize(out->order.size());
-    for (size_t s = 0; s < out->order.size(); s++) out->woop[s] = lm_make_woop(tris + 9 * (size_t)out->order[s]);
+    const size_t nSlots = out->order.size();
+    out->woop.resize(nSlots + 1);
+    for (size_t s = 0; s < nSlots; s++) out->woop[s] = lm_make_woop(tris + 9 * (size_t)out->order[s]);
+    memset(&out->woop[nSlots], 0, sizeof(LmWoop));               // sentinel packet: t = -0/0 = NaN, never a hit
+
+    // ---- 16-bit quantisation relative to the (padded) scene box, rounded outward by one extra step
+    float smin[3] = {INFINITY, INFINITY, INFINITY}, smax[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t t = 0; t < nTris; t++) for (int k = 0; k < 3; k++) { smin[k] = std::min(smin[k], b.tbox[t].lo[k]); smax[k] = std::max(smax[k], b.tbox[t].hi[k]); }
+    for (int k = 0; k < 3; k++) {
+        if (!(smin[k] <= smax[k])) { smin[k] = 0.f; smax[k] = 1.f; }
+        const float m = 4.f * b.pad + 1e-6f * std::max(std::fabs(smin[k]), std::fabs(smax[k])) + 1e-30f;
+        smin[k] -= m; smax[k] += m;
+        out->qmin[k] = smin[k];
+        out->qstep[k] = (smax[k] - smin[k]) / 65535.0f;
+    }
+    const int sentinelLeaf = ~(int)(((uint32_t)nSlots << 3) | 0u);
+    auto quant = [&](float lo, float hi, int k, uint32_t& packed) {
+        const double inv = 1.0 / (double)out->qstep[k];
+        long long ql = (long long)std::floor(((double)lo - (double)out->qmin[k]) * inv) - 1;
+        long long qh = (long long)std::ceil(((double)hi - (double)out->qmin[k]) * inv) + 1;
+        ql = std::max(0LL, std::min(65535LL, ql)); qh = std::max(0LL, std::min(65535LL, qh));
+        packed = (uint32_t)ql | ((uint32_t)qh << 16);
+    };
+    out->qnodes.resize(out->nodes.size());
+    for (size_t i = 0; i < out->nodes.size(); i++) {
+        const LmNode& n = out->nodes[i];
+        LmNodeQ q;
+        const float c0[6] = {n.n0.x, n.n0.y, n.n0.z, n.n0.w, n.n2.x, n.n2.y}, c1[6] = {n.n1.x, n.n1.y, n.n1.z, n.n1.w, n.n2.z, n.n2.w};
+        uint32_t p0[3], p1[3];
+        const bool e0 = c0[0] != c0[0], e1 = c1[0] != c1[0];
+        for (int k = 0; k < 3; k++) {
+            if (e0) p0[k] = 0xffffffffu; else quant(c0[2 * k], c0[2 * k + 1], k, p0[k]);
+            if (e1) p1[k] = 0xffffffffu; else quant(c1[2 * k], c1[2 * k + 1], k, p1[k]);
+        }
+        q.c0 = make_uint4(p0[0], p0[1], p0[2], (uint32_t)(e0 ? sentinelLeaf : n.ref.x));
+        q.c1 = make_uint4(p1[0], p1[1], p1[2], (uint32_t)(e1 ? sentinelLeaf : n.ref.y));
+        out->qnodes[i] = q;
+    }
 }

@@ -93,7 +93,9 @@ __device__ __forceinline__ bool lm_traverse(const LmScene& sc, const lf3& o, con
                                             int* __restrict__ stack /* LDS, stride LM_BLOCK */, LmHit& hit, uint32_t* cnt)
 {
     const float idx = lm_safe_rcp(d.x), idy = lm_safe_rcp(d.y), idz = lm_safe_rcp(d.z);
-    const float oox = o.x * idx, ooy = o.y * idy, ooz = o.z * idz;
+    // node boxes are 16-bit fixed point: world = qmin + q * qstep, so t = q * (qstep * idir) + (qmin - o) * idir
+    const float ax = sc.qstep[0] * idx, ay = sc.qstep[1] * idy, az = sc.qstep[2] * idz;
+    const float bx = (sc.qmin[0] - o.x) * idx, by = (sc.qmin[1] - o.y) * idy, bz = (sc.qmin[2] - o.z) * idz;
     float hitT = tmax;
     uint32_t hitOrder = 0xffffffffu;
     bool found = false;
@@ -104,22 +106,22 @@ __device__ __forceinline__ bool lm_traverse(const LmScene& sc, const lf3& o, con
 #endif
     for (;;) {
         while (cur >= 0) {
-            const LmNode* nd = sc.nodes + cur;
-            const float4 n0 = nd->n0, n1 = nd->n1, n2 = nd->n2;
-            const int4 ref = nd->ref;
+            const LmNodeQ* nd = sc.nodes + cur;
+            const uint4 q0 = nd->c0, q1 = nd->c1;
 #if LM_INSTRUMENT
             nNodes++;
 #endif
-            const float c0lox = fmaf(n0.x, idx, -oox), c0hix = fmaf(n0.y, idx, -oox);
-            const float c0loy = fmaf(n0.z, idy, -ooy), c0hiy = fmaf(n0.w, idy, -ooy);
-            const float c0loz = fmaf(n2.x, idz, -ooz), c0hiz = fmaf(n2.y, idz, -ooz);
-            const float c1lox = fmaf(n1.x, idx, -oox), c1hix = fmaf(n1.y, idx, -oox);
-            const float c1loy = fmaf(n1.z, idy, -ooy), c1hiy = fmaf(n1.w, idy, -ooy);
-            const float c1loz = fmaf(n2.z, idz, -ooz), c1hiz = fmaf(n2.w, idz, -ooz);
+            const float c0lox = fmaf((float)(q0.x & 0xffffu), ax, bx), c0hix = fmaf((float)(q0.x >> 16), ax, bx);
+            const float c0loy = fmaf((float)(q0.y & 0xffffu), ay, by), c0hiy = fmaf((float)(q0.y >> 16), ay, by);
+            const float c0loz = fmaf((float)(q0.z & 0xffffu), az, bz), c0hiz = fmaf((float)(q0.z >> 16), az, bz);
+            const float c1lox = fmaf((float)(q1.x & 0xffffu), ax, bx), c1hix = fmaf((float)(q1.x >> 16), ax, bx);
+            const float c1loy = fmaf((float)(q1.y & 0xffffu), ay, by), c1hiy = fmaf((float)(q1.y >> 16), ay, by);
+            const float c1loz = fmaf((float)(q1.z & 0xffffu), az, bz), c1hiz = fmaf((float)(q1.z >> 16), az, bz);
             const float tn0 = fmaxf(fmaxf(fminf(c0lox, c0hix), fminf(c0loy, c0hiy)), fmaxf(fminf(c0loz, c0hiz), tmin));
             const float tf0 = fminf(fminf(fmaxf(c0lox, c0hix), fmaxf(c0loy, c0hiy)), fminf(fmaxf(c0loz, c0hiz), hitT));
             const float tn1 = fmaxf(fmaxf(fminf(c1lox, c1hix), fminf(c1loy, c1hiy)), fmaxf(fminf(c1loz, c1hiz), tmin));
             const float tf1 = fminf(fminf(fmaxf(c1lox, c1hix), fmaxf(c1loy, c1hiy)), fminf(fmaxf(c1loz, c1hiz), hitT));
+            const int2 ref = make_int2((int)q0.w, (int)q1.w);
             const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
             if (!h0 && !h1) {
                 if (sp == 0) { cur = 0x7fffffff; break; }

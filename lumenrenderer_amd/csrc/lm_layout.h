@@ -17,13 +17,20 @@
 #define LM_SF_ALPHA 2u
 #define LM_SF_NON_INTERSECT 4u
 
-// BVH2 node, 64 bytes: the two children's boxes + references.  ref >= 0: inner node index; ref < 0: leaf,
-// ~ref = (first_triangle << 3) | (count - 1).  An absent child has an inverted (never hit) box.
+// BVH2 node as the host builder produces it (64 bytes: the two children's fp32 boxes + references).  ref >= 0: inner node
+// index; ref < 0: leaf, ~ref = (first_triangle << 3) | (count - 1).
 struct LmNode {
     float4 n0;      // c0.lo.x c0.hi.x c0.lo.y c0.hi.y
     float4 n1;      // c1.lo.x c1.hi.x c1.lo.y c1.hi.y
     float4 n2;      // c0.lo.z c0.hi.z c1.lo.z c1.hi.z
     int4 ref;       // c0, c1, unused, unused
+};
+// BVH2 node as the GPU traverses it: 32 bytes.  Child boxes are 16-bit fixed point relative to the scene box, rounded
+// outward (lo | hi << 16 per axis), so a node step moves half the bytes of the fp32 node; boxes only cull, so the hit
+// record is unchanged.  An absent child references the sentinel (never hit) triangle packet.
+struct LmNodeQ {
+    uint4 c0;       // x: lo.x | hi.x << 16   y: lo.y | hi.y << 16   z: lo.z | hi.z << 16   w: reference
+    uint4 c1;
 };
 // Woop unit-triangle packet, 48 bytes: rows of the affine map world -> (u, v, w)
 struct LmWoop { float4 r0, r1, r2; };
@@ -48,7 +55,8 @@ struct LmTexDesc { uint32_t offset, w, h, srgb; };
 struct LmLight { float4 a, b, c, d; };   // a = p0.xyz p1.x | b = p1.yz p2.xy | c = p2.z n.xyz | d = radiance.xyz area
 
 struct LmScene {
-    const LmNode* nodes;
+    const LmNodeQ* nodes;
+    float qmin[3], qstep[3];    // dequantisation of node boxes: world = qmin + q * qstep
     const LmWoop* woop;
     const uint2* triId;         // per BVH triangle slot: (table entry, primitive-local triangle), .x|0x80000000 never used
     const uint32_t* triOrder;   // per BVH triangle slot: global triangle index (tie-break key)

@@ -125,7 +125,7 @@ struct lumen_mi_renderer {
     bool lightsDirty = true;
 
     // device scene
-    DevBuf<LmNode> dNodes; DevBuf<LmWoop> dWoop; DevBuf<uint2> dTriId; DevBuf<uint32_t> dTriOrder;
+    DevBuf<LmNodeQ> dNodes; DevBuf<LmWoop> dWoop; DevBuf<uint2> dTriId; DevBuf<uint32_t> dTriOrder;
     DevBuf<float4> dVerts; DevBuf<uint32_t> dIndices; DevBuf<LmEntry> dEntries; DevBuf<LmDevMaterial> dMaterials;
     DevBuf<LmTexDesc> dTexDesc; DevBuf<uint32_t> dTexels; DevBuf<float> dLut; DevBuf<LmLight> dLights; DevBuf<float> dCdf;
     LmScene dscene{};
@@ -252,10 +252,11 @@ int flatten(R* r)
     std::vector<uint2> triId(nt);
     for (uint32_t s = 0; s < nt; s++) triId[s] = make_uint2(r->triEntry[r->bvh.order[s]], r->triPrim[r->bvh.order[s]]);
     hipStream_t st = r->stream;
-    if (r->dNodes.upload(r->bvh.nodes, st) || r->dWoop.upload(r->bvh.woop, st) || r->dTriId.upload(triId, st) || r->dTriOrder.upload(r->bvh.order, st) ||
+    if (r->dNodes.upload(r->bvh.qnodes, st) || r->dWoop.upload(r->bvh.woop, st) || r->dTriId.upload(triId, st) || r->dTriOrder.upload(r->bvh.order, st) ||
         r->dVerts.upload(verts, st) || r->dIndices.upload(indices, st) || r->dEntries.upload(r->entries, st))
         return fail(LUMEN_MI_ERR_DEVICE, "scene upload failed (hipMalloc/hipMemcpy)");
     if (hipStreamSynchronize(st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "scene upload sync failed");
+    for (int k = 0; k < 3; k++) { r->dscene.qmin[k] = r->bvh.qmin[k]; r->dscene.qstep[k] = r->bvh.qstep[k]; }
     r->dscene.nodes = r->dNodes.p; r->dscene.woop = r->dWoop.p; r->dscene.triId = r->dTriId.p; r->dscene.triOrder = r->dTriOrder.p;
     r->dscene.verts = r->dVerts.p; r->dscene.indices = r->dIndices.p; r->dscene.entries = r->dEntries.p;
     r->sceneDirty = false;
