@@ -44,6 +44,40 @@ __device__ __forceinline__ void lm_count(uint32_t* counter, bool pred)
     const unsigned long long mask = __ballot(pred);
     if (mask != 0ull && (int)lm_lane() == __ffsll((long long)mask) - 1) atomicAdd(counter, (uint32_t)__popcll(mask));
 }
+// Block-aggregated forms.  One returning atomic on ONE address retires at only ~88 per microsecond on MI355X, so a launch
+// must not issue one atomic per wavefront on a shared counter (57 600 waves at 1440p = 0.65 ms of pure atomic time):
+// the waves of a block first combine through LDS and the block issues a single atomic.  Every thread of the block must call
+// these (they contain barriers).  `s_tmp` = LDS scratch of (waves per block + 1) words.
+__device__ __forceinline__ uint32_t lm_append_slot_block(uint32_t* counter, bool pred, uint32_t* s_tmp)
+{
+    const unsigned long long mask = __ballot(pred);
+    const uint32_t lane = lm_lane(), wave = threadIdx.x >> 6, nWaves = blockDim.x >> 6;
+    const uint32_t prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) s_tmp[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < nWaves; w++) { const uint32_t c = s_tmp[w]; s_tmp[w] = total; total += c; }
+        s_tmp[nWaves] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    const uint32_t slot = s_tmp[nWaves] + s_tmp[wave] + prefix;
+    __syncthreads();                      // s_tmp may be reused by the caller's next iteration
+    return slot;
+}
+__device__ __forceinline__ void lm_count_block(uint32_t* counter, bool pred, uint32_t* s_tmp)
+{
+    const unsigned long long mask = __ballot(pred);
+    const uint32_t lane = lm_lane(), wave = threadIdx.x >> 6, nWaves = blockDim.x >> 6;
+    if (lane == 0) s_tmp[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < nWaves; w++) total += s_tmp[w];
+        if (total) atomicAdd(counter, total);
+    }
+    __syncthreads();
+}
 
 __device__ __forceinline__ float4 lm_mul_m34(const float* m, const lf3& v, float w)   // rows 0..2 of sutil Matrix4x4 * float4
 {
@@ -390,15 +424,17 @@ __device__ __forceinline__ void lm_gbuf_load(const float4* __restrict__ g, uint3
 // per-pixel kernels: one 256-thread block = one 16x16 pixel tile of the window.  Tiles are enumerated in bands of 8 tile
 // rows, column-major inside a band, and each XCD (blocks b, b+8, ... share one) gets a contiguous run of that order, so the
 // tiles resident on one XCD form a compact patch and neighbour gathers (+-30 px) hit that XCD's L2.  Speed only.
+template <uint32_t LOG_TS = 4>   // tile edge = 1 << LOG_TS: 16 for 256-thread blocks, 32 for 1024-thread blocks
 __device__ __forceinline__ bool lm_tile_pixel(const LmFrame& fr, uint32_t& li, uint32_t& gi)
 {
-    const uint32_t tilesX = (fr.ww + 15u) >> 4, tilesY = (fr.wh + 15u) >> 4, T = tilesX * tilesY;
+    constexpr uint32_t TS = 1u << LOG_TS;
+    const uint32_t tilesX = (fr.ww + TS - 1u) >> LOG_TS, tilesY = (fr.wh + TS - 1u) >> LOG_TS, T = tilesX * tilesY;
     const uint32_t b = blockIdx.x, q = T >> 3, r = T & 7u, xcd = b & 7u;
     const uint32_t t = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (b >> 3);
     const uint32_t band = t / (8u * tilesX), within = t - band * 8u * tilesX;
     const uint32_t bh = min(8u, tilesY - band * 8u);
     const uint32_t tx = within / bh, ty = band * 8u + within % bh;
-    const uint32_t lx = tx * 16u + (threadIdx.x & 15u), ly = ty * 16u + (threadIdx.x >> 4);
+    const uint32_t lx = tx * TS + (threadIdx.x & (TS - 1u)), ly = ty * TS + (threadIdx.x >> LOG_TS);
     if (lx >= fr.ww || ly >= fr.wh) return false;
     li = ly * fr.ww + lx;
     gi = (fr.y0 + ly) * fr.W + (fr.x0 + lx);
@@ -519,12 +555,14 @@ __device__ bool lm_shade_indirect(const LmSurface& s, uint32_t gi, uint32_t seed
     return true;
 }
 
-// depth 0 continuation: reads the G-buffer written by lm_k_extract0 (one block per 16x16 tile)
-extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+// depth 0 continuation: reads the G-buffer written by lm_k_extract0 (one 1024-thread block per 32x32 pixel tile; the
+// survivors of a block are appended with ONE atomic)
+extern "C" __global__ void __launch_bounds__(1024)
 KN(lm_k_shade_indirect0)(LmFrame fr, int cur, uint32_t seed2, int outQ, uint32_t* outCount)
 {
+    __shared__ uint32_t s_tmp[17];
     uint32_t li = 0, gi = 0;
-    const bool valid = lm_tile_pixel(fr, li, gi);
+    const bool valid = lm_tile_pixel<5>(fr, li, gi);
     bool emit = false;
     lf3 o = v3(0.f), d = v3(0.f), c = v3(0.f);
     if (valid) {
@@ -532,7 +570,7 @@ KN(lm_k_shade_indirect0)(LmFrame fr, int cur, uint32_t seed2, int outQ, uint32_t
         lm_gbuf_load(fr.gbuf[cur], li, s);
         emit = lm_shade_indirect(s, gi, seed2, o, d, c);
     }
-    const uint32_t slot = lm_append_slot(outCount, emit);
+    const uint32_t slot = lm_append_slot_block(outCount, emit, s_tmp);
     if (emit) {
         fr.rayO[outQ][slot] = v4(o, 0.f);
         fr.rayD[outQ][slot] = v4(d, u2f(li));
@@ -541,16 +579,17 @@ KN(lm_k_shade_indirect0)(LmFrame fr, int cur, uint32_t seed2, int outQ, uint32_t
 }
 
 // depth >= 1: extraction + NEE + continuation fused (no SurfaceData round trip through HBM)
-extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+extern "C" __global__ void __launch_bounds__(1024)
 KN(lm_k_shade_wave)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict__ inCount, uint32_t seed, uint32_t seed2, int doIndirect,
                 uint32_t* outCount, uint32_t* shadowCount)
 {
+    __shared__ uint32_t s_tmp[17];
     const uint32_t n = *inCount;
-    const uint32_t stride = gridDim.x * LM_BLOCK;
+    const uint32_t stride = gridDim.x * 1024u;
     const uint32_t nIter = (n + stride - 1u) / stride;
     const int outQ = inQ ^ 1;
     for (uint32_t it = 0; it < nIter; it++) {
-        const uint32_t i = it * stride + blockIdx.x * LM_BLOCK + threadIdx.x;
+        const uint32_t i = it * stride + blockIdx.x * 1024u + threadIdx.x;
         bool emitShadow = false, emitRay = false;
         lf3 sdir = v3(0.f), srad = v3(0.f), o = v3(0.f), d = v3(0.f), c = v3(0.f), spos = v3(0.f);
         float stmax = 0.f;
@@ -566,13 +605,13 @@ KN(lm_k_shade_wave)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict_
             spos = s.position;
             if (doIndirect) emitRay = lm_shade_indirect(s, gi, seed2, o, d, c);
         }
-        const uint32_t ss = lm_append_slot(shadowCount, emitShadow);
+        const uint32_t ss = lm_append_slot_block(shadowCount, emitShadow, s_tmp);
         if (emitShadow) {
             fr.shO[ss] = v4(spos, stmax);
             fr.shD[ss] = v4(sdir, u2f(li));
             fr.shR[ss] = v4(srad, 0.f);
         }
-        const uint32_t rs = lm_append_slot(outCount, emitRay);
+        const uint32_t rs = lm_append_slot_block(outCount, emitRay, s_tmp);
         if (emitRay) {
             fr.rayO[outQ][rs] = v4(o, 0.f);
             fr.rayD[outQ][rs] = v4(d, u2f(li));
@@ -746,6 +785,7 @@ extern "C" __global__ void __launch_bounds__(LM_BLOCK)
 KN(lm_k_restir_visibility_shade)(LmScene sc, LmFrame fr, int cur, int rc)
 {
     __shared__ int s_stack[LM_STACK_DEPTH * LM_BLOCK];
+    __shared__ uint32_t s_tmp[5];
     int* stack = s_stack + threadIdx.x;
     uint32_t li = 0, gi = 0;
     const bool valid = lm_tile_pixel(fr, li, gi);
@@ -764,7 +804,7 @@ KN(lm_k_restir_visibility_shade)(LmScene sc, LmFrame fr, int cur, int rc)
             shoot = true;
         }
     }
-    lm_count(fr.counters + LM_CNT_RESTIR, shoot);
+    lm_count_block(fr.counters + LM_CNT_RESTIR + (blockIdx.x & 15u), shoot, s_tmp);
     if (shoot) {
         LmHit h;
         if (lm_traverse<true>(sc, pos, toLight, 0.1f, l - 0.05f, stack, h, fr.counters)) { r0.y = 0.f; hot[4u * li] = r0; }
@@ -1025,9 +1065,9 @@ static void l_primary(hipStream_t s, int g, LmFrame fr, LmCamera cam, uint32_t f
 static void l_trace_closest(hipStream_t s, int g, LmScene sc, const float4* o, const float4* d, const uint32_t* cnt, uint4* hits, float tmin, float tmax, uint32_t* counters)
 { hipLaunchKernelGGL(KN(lm_k_trace_closest), LM_GRID(g), sc, o, d, cnt, hits, tmin, tmax, counters); }
 static void l_extract0(hipStream_t s, int g, LmScene sc, LmFrame fr, LmCamera cam, int cur) { hipLaunchKernelGGL(KN(lm_k_extract0), LM_GRID(g), sc, fr, cam, cur); }
-static void l_shade_indirect0(hipStream_t s, int g, LmFrame fr, int cur, uint32_t seed2, int outQ, uint32_t* outCount) { hipLaunchKernelGGL(KN(lm_k_shade_indirect0), LM_GRID(g), fr, cur, seed2, outQ, outCount); }
+static void l_shade_indirect0(hipStream_t s, int g, LmFrame fr, int cur, uint32_t seed2, int outQ, uint32_t* outCount) { hipLaunchKernelGGL(KN(lm_k_shade_indirect0), dim3((unsigned)g), dim3(1024), 0, s, fr, cur, seed2, outQ, outCount); }
 static void l_shade_wave(hipStream_t s, int g, LmScene sc, LmFrame fr, int inQ, const uint32_t* inCount, uint32_t seed, uint32_t seed2, int doIndirect, uint32_t* outCount, uint32_t* shadowCount)
-{ hipLaunchKernelGGL(KN(lm_k_shade_wave), LM_GRID(g), sc, fr, inQ, inCount, seed, seed2, doIndirect, outCount, shadowCount); }
+{ hipLaunchKernelGGL(KN(lm_k_shade_wave), dim3((unsigned)g), dim3(1024), 0, s, sc, fr, inQ, inCount, seed, seed2, doIndirect, outCount, shadowCount); }
 static void l_trace_shadow(hipStream_t s, int g, LmScene sc, LmFrame fr, const uint32_t* cnt, float tmin) { hipLaunchKernelGGL(KN(lm_k_trace_shadow), LM_GRID(g), sc, fr, cnt, tmin); }
 static void l_fill_bags(hipStream_t s, LmScene sc, LmFrame fr, uint32_t seed, uint32_t total) { hipLaunchKernelGGL(KN(lm_k_fill_bags), LM_GRID((total + LM_BLOCK - 1) / LM_BLOCK), sc, fr, seed, total); }
 static void l_pick_primary(hipStream_t s, int tiles, LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_pick_primary), LM_GRID(tiles), sc, fr, cur, rc, seed); }

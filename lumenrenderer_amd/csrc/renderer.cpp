@@ -538,11 +538,11 @@ int traceFrameAsync(R* r)
             K->visibility_shade(st, tiles, r->dscene, fr, currentIndex, cur);
             K->combine(st, tiles, fr, currentIndex, cur, 3, wangHash(rs));
             evEnd(r, ev);
-            if (doIndirect) { evBegin(r, 2, ev); K->shade_indirect0(st, (int)(((fr.ww + 15u) / 16u) * ((fr.wh + 15u) / 16u)), fr, currentIndex, seed2, q ^ 1, outCount); evEnd(r, ev); }
+            if (doIndirect) { evBegin(r, 2, ev); K->shade_indirect0(st, (int)(((fr.ww + 31u) / 32u) * ((fr.wh + 31u) / 32u)), fr, currentIndex, seed2, q ^ 1, outCount); evEnd(r, ev); }
         } else {
             uint32_t* shCount = fr.counters + LM_CNT_SHADOW(depth);
             evBegin(r, 2, ev);
-            K->shade_wave(st, r->numCU * 8, r->dscene, fr, q, inCount, seed, seed2, doIndirect, outCount, shCount);
+            K->shade_wave(st, r->numCU * 2, r->dscene, fr, q, inCount, seed, seed2, doIndirect, outCount, shCount);
             evEnd(r, ev);
             evBegin(r, 1, ev);
             K->trace_shadow(st, traceGrid, r->dscene, fr, shCount, 0.01f);                   // tmin of the intersection launch (:843)
@@ -954,7 +954,7 @@ int lumen_mi_get_counters(lumen_mi_renderer* r, uint64_t* out, uint32_t n)
     uint64_t v[24] = {0};
     const uint32_t* c = r->hostCounters;
     for (uint32_t d = 0; d < r->lastDepth && d < 16; d++) { v[0] += c[LM_CNT_RAYS(d)]; v[4 + d] = c[LM_CNT_RAYS(d)]; v[1] += c[LM_CNT_SHADOW(d)]; }
-    v[2] = c[LM_CNT_RESTIR];
+    for (int k = 0; k < 16; k++) v[2] += c[LM_CNT_RESTIR + k];
     v[3] = r->lastLightCount;
     v[20] = (uint64_t)c[LM_CNT_NODES] | ((uint64_t)c[LM_CNT_NODES + 1] << 32);
     v[21] = (uint64_t)c[LM_CNT_TRIS] | ((uint64_t)c[LM_CNT_TRIS + 1] << 32);
