@@ -200,6 +200,126 @@ __device__ __forceinline__ bool lm_traverse(const LmScene& sc, const lf3& o, con
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Queue traversal with per-lane ray replacement ("persistent threads"): a wavefront owns a chunk of LM_CHUNK consecutive
+// rays at a time (one atomic per chunk on the queue head, not per wave-refill: a single address retires only ~88 returning
+// atomics per microsecond); lanes whose ray has terminated are refilled from the chunk as soon as fewer than LM_REFILL lanes
+// of the wave are still traversing, so incoherent rays of very different length do not leave most of the 64 lanes idle.
+// `done(rayIndex, found, hit)` runs once per ray.  Results are identical to lm_traverse (same tests, same tie-break).
+// ---------------------------------------------------------------------------------------------------------------------
+#define LM_CHUNK 512u
+#ifndef LM_REFILL
+#define LM_REFILL 40
+#endif
+template <bool ANY, class Fetch, class Done>
+__device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, uint32_t* __restrict__ head, int* __restrict__ stack /* LDS, stride LM_BLOCK */,
+                                               uint32_t* cnt, Fetch fetch, Done done)
+{
+    const uint32_t lane = lm_lane();
+    uint32_t chunkNext = 0, chunkEnd = 0;          // wave-uniform
+    bool drained = false;                          // wave-uniform
+    bool active = false;
+    uint32_t rayIdx = 0;
+    lf3 o = v3(0.f), d = v3(0.f);
+    float tmin = 0.f, tmax = 0.f, ax = 0.f, ay = 0.f, az = 0.f, bx = 0.f, by = 0.f, bz = 0.f, hitT = 0.f;
+    uint32_t hitOrder = 0xffffffffu;
+    bool found = false;
+    int sp = 0, cur = 0;
+    LmHit hit; hit.t = -1.f; hit.u = 0.f; hit.v = 0.f; hit.slot = 0;
+#if LM_INSTRUMENT
+    uint32_t nNodes = 0, nTris = 0;
+#endif
+    for (;;) {
+        // ---- refill idle lanes from the wave's chunk
+        unsigned long long need = __ballot(!active);
+        while (need != 0ull && !drained) {
+            if (chunkNext == chunkEnd) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(head, LM_CHUNK);
+                base = (uint32_t)__shfl((int)base, 0, 64);
+                if (base >= n) { drained = true; break; }
+                chunkNext = base; chunkEnd = min(base + LM_CHUNK, n);
+            }
+            const uint32_t want = (uint32_t)__popcll(need), avail = chunkEnd - chunkNext;
+            const uint32_t give = min(want, avail);
+            const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+            if (!active && rank < give) {
+                rayIdx = chunkNext + rank;
+                fetch(rayIdx, o, d, tmin, tmax);
+                const float idx = lm_safe_rcp(d.x), idy = lm_safe_rcp(d.y), idz = lm_safe_rcp(d.z);
+                ax = sc.qstep[0] * idx; ay = sc.qstep[1] * idy; az = sc.qstep[2] * idz;
+                bx = (sc.qmin[0] - o.x) * idx; by = (sc.qmin[1] - o.y) * idy; bz = (sc.qmin[2] - o.z) * idz;
+                hitT = tmax; hitOrder = 0xffffffffu; found = false; sp = 0; cur = 0;
+                active = true;
+            }
+            chunkNext += give;
+            need = __ballot(!active);
+        }
+        if (__ballot(active) == 0ull) break;
+        // ---- traverse until the ray ends or the wave has become too empty
+        while (active) {
+            while (cur >= 0 && cur != 0x7fffffff) {
+                const LmNodeQ* nd = sc.nodes + cur;
+                const uint4 q0 = nd->c0, q1 = nd->c1;
+#if LM_INSTRUMENT
+                nNodes++;
+#endif
+                const float c0lox = fmaf((float)(q0.x & 0xffffu), ax, bx), c0hix = fmaf((float)(q0.x >> 16), ax, bx);
+                const float c0loy = fmaf((float)(q0.y & 0xffffu), ay, by), c0hiy = fmaf((float)(q0.y >> 16), ay, by);
+                const float c0loz = fmaf((float)(q0.z & 0xffffu), az, bz), c0hiz = fmaf((float)(q0.z >> 16), az, bz);
+                const float c1lox = fmaf((float)(q1.x & 0xffffu), ax, bx), c1hix = fmaf((float)(q1.x >> 16), ax, bx);
+                const float c1loy = fmaf((float)(q1.y & 0xffffu), ay, by), c1hiy = fmaf((float)(q1.y >> 16), ay, by);
+                const float c1loz = fmaf((float)(q1.z & 0xffffu), az, bz), c1hiz = fmaf((float)(q1.z >> 16), az, bz);
+                const float tn0 = fmaxf(fmaxf(fminf(c0lox, c0hix), fminf(c0loy, c0hiy)), fmaxf(fminf(c0loz, c0hiz), tmin));
+                const float tf0 = fminf(fminf(fmaxf(c0lox, c0hix), fmaxf(c0loy, c0hiy)), fminf(fmaxf(c0loz, c0hiz), hitT));
+                const float tn1 = fmaxf(fmaxf(fminf(c1lox, c1hix), fminf(c1loy, c1hiy)), fmaxf(fminf(c1loz, c1hiz), tmin));
+                const float tf1 = fminf(fminf(fmaxf(c1lox, c1hix), fmaxf(c1loy, c1hiy)), fminf(fmaxf(c1loz, c1hiz), hitT));
+                const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+                if (!h0 && !h1) {
+                    cur = sp == 0 ? 0x7fffffff : stack[(--sp) * LM_BLOCK];
+                } else {
+                    int first = h0 ? (int)q0.w : (int)q1.w;
+                    if (h0 && h1) {
+                        int second = (int)q1.w;
+                        if (tn1 < tn0) { second = first; first = (int)q1.w; }
+                        stack[(sp++) * LM_BLOCK] = second;
+                    }
+                    cur = first;
+                }
+            }
+            if (cur != 0x7fffffff) {
+                const uint32_t leaf = (uint32_t)(~cur);
+                const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
+                for (uint32_t k = 0; k < count; k++) {
+                    float t, u, v;
+#if LM_INSTRUMENT
+                    nTris++;
+#endif
+                    if (lm_woop(sc.woop, first + k, o, d, tmin, tmax, t, u, v)) {
+                        if (ANY) { found = true; break; }
+                        const uint32_t order = sc.triOrder[first + k];
+                        if (t < hitT || (t == hitT && found && order < hitOrder)) {
+                            hitT = t; hitOrder = order; found = true;
+                            hit.t = t; hit.u = u; hit.v = v; hit.slot = first + k;
+                        }
+                    }
+                }
+                cur = ((ANY && found) || sp == 0) ? 0x7fffffff : stack[(--sp) * LM_BLOCK];
+            }
+            if (cur == 0x7fffffff) {
+                done(rayIdx, found, hit);
+                active = false;
+            } else if (!drained && __popcll(__ballot(true)) < LM_REFILL) {
+                break;                                  // still traversing: go back and let the idle lanes take new rays
+            }
+        }
+    }
+#if LM_INSTRUMENT
+    atomicAdd((unsigned long long*)(cnt + LM_CNT_NODES), (unsigned long long)nNodes);
+    atomicAdd((unsigned long long*)(cnt + LM_CNT_TRIS), (unsigned long long)nTris);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // K1: primary rays — reference GPUGeneratePrimRay.cu:28-82 (Halton(2,3) jitter indexed by frameCount + pixel index).
 // Ray slot i holds the pixel of an 8x8-tile enumeration of the window (every consumer finds the pixel in rayD.w), so one
 // wavefront traces an 8x8 pixel bundle instead of a 64x1 strip.
@@ -247,25 +367,22 @@ KN(lm_k_primary)(LmFrame fr, LmCamera cam, uint32_t frameCount)
 // ---------------------------------------------------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
 KN(lm_k_trace_closest)(LmScene sc, const float4* __restrict__ rayO, const float4* __restrict__ rayD, const uint32_t* __restrict__ countPtr,
-                   uint4* __restrict__ hits, float tmin, float tmax, uint32_t* counters)
+                   uint4* __restrict__ hits, float tmin, float tmax, uint32_t* counters, uint32_t* head)
 {
     __shared__ int s_stack[LM_STACK_DEPTH * LM_BLOCK];
-    int* stack = s_stack + threadIdx.x;
     const uint32_t n = *countPtr;
-    const uint32_t stride = gridDim.x * LM_BLOCK;
-    for (uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x; i < n; i += stride) {
-        const float4 o4 = rayO[i], d4 = rayD[i];
-        LmHit h; h.t = -1.f; h.u = 0.f; h.v = 0.f; h.slot = 0;
-        const bool found = lm_traverse<false>(sc, v3(o4), v3(d4), tmin, tmax, stack, h, counters);
-        uint4 out = make_uint4(0u, 0u, 0u, f2u(-1.f));
-        if (found) {
-            const uint2 id = sc.triId[h.slot];
-            out.x = id.x; out.y = id.y;
-            out.z = lm_f32_to_f16(h.u) | (lm_f32_to_f16(h.v) << 16);      // half2 barycentrics (IntersectionData.h:90)
-            out.w = f2u(h.t);
-        }
-        hits[i] = out;
-    }
+    lm_trace_queue<false>(sc, n, head, s_stack + threadIdx.x, counters,
+        [&](uint32_t i, lf3& o, lf3& d, float& t0, float& t1) { o = v3(rayO[i]); d = v3(rayD[i]); t0 = tmin; t1 = tmax; },
+        [&](uint32_t i, bool found, const LmHit& h) {
+            uint4 out = make_uint4(0u, 0u, 0u, f2u(-1.f));
+            if (found) {
+                const uint2 id = sc.triId[h.slot];
+                out.x = id.x; out.y = id.y;
+                out.z = lm_f32_to_f16(h.u) | (lm_f32_to_f16(h.v) << 16);      // half2 barycentrics (IntersectionData.h:90)
+                out.w = f2u(h.t);
+            }
+            hits[i] = out;
+        });
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -623,24 +740,71 @@ KN(lm_k_shade_wave)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict_
 // K5: NEE shadow rays — reference WaveFrontShaders.cu:114-179 (tmin 0.01; unoccluded => channel += radiance).
 // At most one shadow ray per pixel per wave, so the add is a plain fp32 read-modify-write.
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
-KN(lm_k_trace_shadow)(LmScene sc, LmFrame fr, const uint32_t* __restrict__ countPtr, float tmin)
+KN(lm_k_trace_shadow)(LmScene sc, LmFrame fr, const uint32_t* __restrict__ countPtr, float tmin, uint32_t* head)
 {
     __shared__ int s_stack[LM_STACK_DEPTH * LM_BLOCK];
-    int* stack = s_stack + threadIdx.x;
     const uint32_t n = *countPtr;
-    const uint32_t stride = gridDim.x * LM_BLOCK;
-    for (uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x; i < n; i += stride) {
-        const float4 o4 = fr.shO[i], d4 = fr.shD[i];
-        LmHit h;
-        const bool occluded = lm_traverse<true>(sc, v3(o4), v3(d4), tmin, o4.w, stack, h, fr.counters);
-        if (!occluded) {
-            const uint32_t li = f2u(d4.w);
-            const float4 r = fr.shR[i];
-            float4 px = fr.indirect[li];
-            px.x += r.x; px.y += r.y; px.z += r.z;
-            fr.indirect[li] = px;
+    lm_trace_queue<true>(sc, n, head, s_stack + threadIdx.x, fr.counters,
+        [&](uint32_t i, lf3& o, lf3& d, float& t0, float& t1) { const float4 o4 = fr.shO[i]; o = v3(o4); d = v3(fr.shD[i]); t0 = tmin; t1 = o4.w; },
+        [&](uint32_t i, bool occluded, const LmHit&) {
+            if (!occluded) {
+                const uint32_t li = f2u(fr.shD[i].w);
+                const float4 r = fr.shR[i];
+                float4 px = fr.indirect[li];
+                px.x += r.x; px.y += r.y; px.z += r.z;
+                fr.indirect[li] = px;
+            }
+        });
+}
+
+// K22: ReSTIR visibility-ray generation (ReSTIRKernels.cu:546-582) into the shadow-ray queue; one 1024-thread block per
+// 32x32 pixel tile, one atomic per block.
+extern "C" __global__ void __launch_bounds__(1024)
+KN(lm_k_restir_gen_rays)(LmFrame fr, int cur, int rc, uint32_t* outCount)
+{
+    __shared__ uint32_t s_tmp[17];
+    uint32_t li = 0, gi = 0;
+    const bool valid = lm_tile_pixel<5>(fr, li, gi);
+    bool shoot = false;
+    lf3 pos = v3(0.f), toLight = v3(0.f);
+    float l = 0.f;
+    if (valid && fr.probe[cur][li].w >= 0.f) {
+        const float4* hot = fr.res[rc] + 4u * li;
+        if (hot[0].y > 0.f) {
+            pos = v3(fr.gbuf[cur][8u * li]);
+            toLight = v3(hot[3]) - pos;
+            l = length3(toLight);
+            toLight = toLight / l;
+            shoot = true;
         }
     }
+    const uint32_t slot = lm_append_slot_block(outCount, shoot, s_tmp);
+    if (shoot) {
+        fr.shO[slot] = v4(pos, l - 0.05f);
+        fr.shD[slot] = v4(toLight, u2f(li));
+    }
+}
+// K6 + K23: resolve the visibility rays (tmin 0.1, WaveFrontShaders.cu:181-216: occluded => reservoir weight = 0) and shade
+// the surviving reservoirs into DIRECT with weight / 3 (ReSTIRKernels.cu:600-665)
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_restir_trace_shade)(LmScene sc, LmFrame fr, int rc, const uint32_t* __restrict__ countPtr, uint32_t* head)
+{
+    __shared__ int s_stack[LM_STACK_DEPTH * LM_BLOCK];
+    const uint32_t n = *countPtr;
+    float4* hot = fr.res[rc];
+    lm_trace_queue<true>(sc, n, head, s_stack + threadIdx.x, fr.counters,
+        [&](uint32_t i, lf3& o, lf3& d, float& t0, float& t1) { const float4 o4 = fr.shO[i]; o = v3(o4); d = v3(fr.shD[i]); t0 = 0.1f; t1 = o4.w; },
+        [&](uint32_t i, bool occluded, const LmHit&) {
+            const uint32_t li = f2u(fr.shD[i].w);
+            float4 r0 = hot[4u * li];
+            if (occluded) { r0.y = 0.f; hot[4u * li] = r0; }
+            else {
+                const lf3 add = v3(fr.resC[rc][li]) * (r0.y / 3.f);
+                float4 px = fr.direct[li];
+                px.x += add.x; px.y += add.y; px.z += add.z;
+                fr.direct[li] = px;
+            }
+        });
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -777,44 +941,6 @@ KN(lm_k_pick_primary)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed)
     }
     lm_res_update_weight(fresh);
     lm_res_store(hot, fr.resC[rc], li, fresh);
-}
-
-// K22 + K6 + K23: visibility ray of the pixel's reservoir (tmin 0.1, tmax d - 0.05; ReSTIRKernels.cu:546-582,
-// WaveFrontShaders.cu:181-216), then shade it into DIRECT with weight/3 (ReSTIRKernels.cu:600-665).  One block per 16x16 tile.
-extern "C" __global__ void __launch_bounds__(LM_BLOCK)
-KN(lm_k_restir_visibility_shade)(LmScene sc, LmFrame fr, int cur, int rc)
-{
-    __shared__ int s_stack[LM_STACK_DEPTH * LM_BLOCK];
-    __shared__ uint32_t s_tmp[5];
-    int* stack = s_stack + threadIdx.x;
-    uint32_t li = 0, gi = 0;
-    const bool valid = lm_tile_pixel(fr, li, gi);
-    float4* hot = fr.res[rc];
-    bool shoot = false;
-    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f);
-    lf3 pos = v3(0.f), toLight = v3(0.f);
-    float l = 0.f;
-    if (valid && fr.probe[cur][li].w >= 0.f) {
-        r0 = hot[4u * li];
-        if (r0.y > 0.f) {
-            pos = v3(fr.gbuf[cur][8u * li]);
-            toLight = v3(hot[4u * li + 3u]) - pos;
-            l = length3(toLight);
-            toLight = toLight / l;
-            shoot = true;
-        }
-    }
-    lm_count_block(fr.counters + LM_CNT_RESTIR + (blockIdx.x & 15u), shoot, s_tmp);
-    if (shoot) {
-        LmHit h;
-        if (lm_traverse<true>(sc, pos, toLight, 0.1f, l - 0.05f, stack, h, fr.counters)) { r0.y = 0.f; hot[4u * li] = r0; }
-        if (r0.y > 0.f) {
-            const lf3 add = v3(fr.resC[rc][li]) * (r0.y / 3.f);
-            float4 px = fr.direct[li];
-            px.x += add.x; px.y += add.y; px.z += add.z;
-            fr.direct[li] = px;
-        }
-    }
 }
 
 // K24 temporal reuse — ReSTIRKernels.cu:1015-1121
@@ -1062,16 +1188,17 @@ KN(lm_k_test_math)(uint32_t n, int fn, const float* __restrict__ x, const float*
 #define LM_GRID(g) dim3((unsigned)(g)), dim3(LM_BLOCK), 0, s
 
 static void l_primary(hipStream_t s, int g, LmFrame fr, LmCamera cam, uint32_t frameCount) { hipLaunchKernelGGL(KN(lm_k_primary), LM_GRID(g), fr, cam, frameCount); }
-static void l_trace_closest(hipStream_t s, int g, LmScene sc, const float4* o, const float4* d, const uint32_t* cnt, uint4* hits, float tmin, float tmax, uint32_t* counters)
-{ hipLaunchKernelGGL(KN(lm_k_trace_closest), LM_GRID(g), sc, o, d, cnt, hits, tmin, tmax, counters); }
+static void l_trace_closest(hipStream_t s, int g, LmScene sc, const float4* o, const float4* d, const uint32_t* cnt, uint4* hits, float tmin, float tmax, uint32_t* counters, uint32_t* head)
+{ hipLaunchKernelGGL(KN(lm_k_trace_closest), LM_GRID(g), sc, o, d, cnt, hits, tmin, tmax, counters, head); }
 static void l_extract0(hipStream_t s, int g, LmScene sc, LmFrame fr, LmCamera cam, int cur) { hipLaunchKernelGGL(KN(lm_k_extract0), LM_GRID(g), sc, fr, cam, cur); }
 static void l_shade_indirect0(hipStream_t s, int g, LmFrame fr, int cur, uint32_t seed2, int outQ, uint32_t* outCount) { hipLaunchKernelGGL(KN(lm_k_shade_indirect0), dim3((unsigned)g), dim3(1024), 0, s, fr, cur, seed2, outQ, outCount); }
 static void l_shade_wave(hipStream_t s, int g, LmScene sc, LmFrame fr, int inQ, const uint32_t* inCount, uint32_t seed, uint32_t seed2, int doIndirect, uint32_t* outCount, uint32_t* shadowCount)
 { hipLaunchKernelGGL(KN(lm_k_shade_wave), dim3((unsigned)g), dim3(1024), 0, s, sc, fr, inQ, inCount, seed, seed2, doIndirect, outCount, shadowCount); }
-static void l_trace_shadow(hipStream_t s, int g, LmScene sc, LmFrame fr, const uint32_t* cnt, float tmin) { hipLaunchKernelGGL(KN(lm_k_trace_shadow), LM_GRID(g), sc, fr, cnt, tmin); }
+static void l_trace_shadow(hipStream_t s, int g, LmScene sc, LmFrame fr, const uint32_t* cnt, float tmin, uint32_t* head) { hipLaunchKernelGGL(KN(lm_k_trace_shadow), LM_GRID(g), sc, fr, cnt, tmin, head); }
 static void l_fill_bags(hipStream_t s, LmScene sc, LmFrame fr, uint32_t seed, uint32_t total) { hipLaunchKernelGGL(KN(lm_k_fill_bags), LM_GRID((total + LM_BLOCK - 1) / LM_BLOCK), sc, fr, seed, total); }
 static void l_pick_primary(hipStream_t s, int tiles, LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_pick_primary), LM_GRID(tiles), sc, fr, cur, rc, seed); }
-static void l_visibility_shade(hipStream_t s, int g, LmScene sc, LmFrame fr, int cur, int rc) { hipLaunchKernelGGL(KN(lm_k_restir_visibility_shade), LM_GRID(g), sc, fr, cur, rc); }
+static void l_gen_rays(hipStream_t s, int tiles, LmFrame fr, int cur, int rc, uint32_t* outCount) { hipLaunchKernelGGL(KN(lm_k_restir_gen_rays), dim3((unsigned)tiles), dim3(1024), 0, s, fr, cur, rc, outCount); }
+static void l_trace_shade(hipStream_t s, int g, LmScene sc, LmFrame fr, int rc, const uint32_t* cnt, uint32_t* head) { hipLaunchKernelGGL(KN(lm_k_restir_trace_shade), LM_GRID(g), sc, fr, rc, cnt, head); }
 static void l_temporal(hipStream_t s, int g, LmFrame fr, int cur, int prev, int rc, int rp, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_restir_temporal), LM_GRID(g), fr, cur, prev, rc, rp, seed); }
 static void l_spatial(hipStream_t s, int g, LmFrame fr, int cur, int rin, int rout, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_restir_spatial), LM_GRID(g), fr, cur, rin, rout, seed); }
 static void l_combine(hipStream_t s, int g, LmFrame fr, int cur, int rc, int rs, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_restir_combine), LM_GRID(g), fr, cur, rc, rs, seed); }
@@ -1091,6 +1218,6 @@ extern "C" const LmKernelTable* lm_kernel_table()
 #endif
 {
     static const LmKernelTable t = {l_primary, l_trace_closest, l_extract0, l_shade_indirect0, l_shade_wave, l_trace_shadow, l_fill_bags, l_pick_primary,
-                                    l_visibility_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_test_bsdf, l_test_math};
+                                    l_gen_rays, l_trace_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_test_bsdf, l_test_math};
     return &t;
 }

@@ -99,9 +99,12 @@ struct LmFrame {
 // counter block layout (uint32 each)
 #define LM_CNT_RAYS(d) (d)                       // rays entering wave d            [0, LM_MAX_DEPTH]
 #define LM_CNT_SHADOW(d) (32 + (d))              // NEE shadow rays emitted by wave d
-#define LM_CNT_RESTIR 80                         // ReSTIR visibility rays (both passes), striped over 16 words
+#define LM_CNT_RESTIR(p) (70 + (p))              // ReSTIR visibility rays of pass p (0, 1)
+#define LM_CNT_HEAD_CLOSEST(d) (96 + (d))        // queue heads of the persistent traversal kernels (zeroed every frame)
+#define LM_CNT_HEAD_SHADOW(d) (112 + (d))
+#define LM_CNT_HEAD_RESTIR(p) (128 + (p))
 #define LM_CNT_NODES 66                          // instrumented build only: BVH nodes visited (u64 as 2 words)
 #define LM_CNT_TRIS 68                           // instrumented build only: triangles tested (u64 as 2 words)
-#define LM_CNT_WORDS 96
+#define LM_CNT_WORDS 136
 
 struct LmCamera { float eye[3], U[3], V[3], Wv[3]; float prevViewProj[16]; };

@@ -505,13 +505,13 @@ int traceFrameAsync(R* r)
     K->primary(st, r->gridFor(fr.n, 8), fr, cam, r->frameCount);
     uint32_t seed = wangHash(r->frameCount);                                                  // :685
     int q = 0;
-    const int traceGrid = r->numCU * 12;
+    const int traceGrid = r->numCU * 5;          // persistent: 5 blocks of 256 threads per CU (LDS stack 32 KB per block)
     size_t ev;
     for (uint32_t depth = 0; depth < depthMax; ++depth) {
         uint32_t* inCount = fr.counters + LM_CNT_RAYS(depth);
         uint32_t* outCount = fr.counters + LM_CNT_RAYS(depth + 1);
         evBegin(r, 0, ev);
-        K->trace_closest(st, traceGrid, r->dscene, fr.rayO[q], fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters);   // :678,:703
+        K->trace_closest(st, traceGrid, r->dscene, fr.rayO[q], fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters, fr.counters + LM_CNT_HEAD_CLOSEST(depth));   // :678,:703
         evEnd(r, ev);
         const uint32_t seed2 = wangHash(seed);                                                // CPUShadingKernels.cu:178
         const int doIndirect = depth < depthMax - 1 ? 1 : 0;
@@ -529,13 +529,16 @@ int traceFrameAsync(R* r)
             const uint32_t wtx = (fr.x0 + fr.ww + 15u) / 16u - tx0, wty = (fr.y0 + fr.wh + 15u) / 16u - ty0;
             K->pick_primary(st, (int)(wtx * wty), r->dscene, fr, currentIndex, cur, rs);
             const int tiles = (int)(((fr.ww + 15u) / 16u) * ((fr.wh + 15u) / 16u));
-            K->visibility_shade(st, tiles, r->dscene, fr, currentIndex, cur);
+            const int tiles32 = (int)(((fr.ww + 31u) / 32u) * ((fr.wh + 31u) / 32u));
+            K->gen_rays(st, tiles32, fr, currentIndex, cur, fr.counters + LM_CNT_RESTIR(0));
+            K->trace_shade(st, traceGrid, r->dscene, fr, cur, fr.counters + LM_CNT_RESTIR(0), fr.counters + LM_CNT_HEAD_RESTIR(0));
             rs = wangHash(rs);
             K->temporal(st, tiles, fr, currentIndex, temporalIndex, cur, tmp, rs);
             rs = wangHash(rs);
             K->spatial(st, tiles, fr, currentIndex, cur, 2, rs);
             K->spatial(st, tiles, fr, currentIndex, 2, 3, rs);
-            K->visibility_shade(st, tiles, r->dscene, fr, currentIndex, cur);
+            K->gen_rays(st, tiles32, fr, currentIndex, cur, fr.counters + LM_CNT_RESTIR(1));
+            K->trace_shade(st, traceGrid, r->dscene, fr, cur, fr.counters + LM_CNT_RESTIR(1), fr.counters + LM_CNT_HEAD_RESTIR(1));
             K->combine(st, tiles, fr, currentIndex, cur, 3, wangHash(rs));
             evEnd(r, ev);
             if (doIndirect) { evBegin(r, 2, ev); K->shade_indirect0(st, (int)(((fr.ww + 31u) / 32u) * ((fr.wh + 31u) / 32u)), fr, currentIndex, seed2, q ^ 1, outCount); evEnd(r, ev); }
@@ -545,7 +548,7 @@ int traceFrameAsync(R* r)
             K->shade_wave(st, r->numCU * 2, r->dscene, fr, q, inCount, seed, seed2, doIndirect, outCount, shCount);
             evEnd(r, ev);
             evBegin(r, 1, ev);
-            K->trace_shadow(st, traceGrid, r->dscene, fr, shCount, 0.01f);                   // tmin of the intersection launch (:843)
+            K->trace_shadow(st, traceGrid, r->dscene, fr, shCount, 0.01f, fr.counters + LM_CNT_HEAD_SHADOW(depth));                   // tmin of the intersection launch (:843)
             evEnd(r, ev);
         }
         q ^= 1;
@@ -954,7 +957,7 @@ int lumen_mi_get_counters(lumen_mi_renderer* r, uint64_t* out, uint32_t n)
     uint64_t v[24] = {0};
     const uint32_t* c = r->hostCounters;
     for (uint32_t d = 0; d < r->lastDepth && d < 16; d++) { v[0] += c[LM_CNT_RAYS(d)]; v[4 + d] = c[LM_CNT_RAYS(d)]; v[1] += c[LM_CNT_SHADOW(d)]; }
-    for (int k = 0; k < 16; k++) v[2] += c[LM_CNT_RESTIR + k];
+    v[2] = (uint64_t)c[LM_CNT_RESTIR(0)] + c[LM_CNT_RESTIR(1)];
     v[3] = r->lastLightCount;
     v[20] = (uint64_t)c[LM_CNT_NODES] | ((uint64_t)c[LM_CNT_NODES + 1] << 32);
     v[21] = (uint64_t)c[LM_CNT_TRIS] | ((uint64_t)c[LM_CNT_TRIS + 1] << 32);
