@@ -305,12 +305,15 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, ui
                 }
                 cur = ((ANY && found) || sp == 0) ? 0x7fffffff : stack[(--sp) * LM_BLOCK];
             }
-            if (cur == 0x7fffffff) {
+            const bool fin = cur == 0x7fffffff;
+            if (fin) {
                 done(rayIdx, found, hit);
                 active = false;
-            } else if (!drained && __popcll(__ballot(true)) < LM_REFILL) {
-                break;                                  // still traversing: go back and let the idle lanes take new rays
             }
+            // all lanes still in this loop vote (the ones that just finished included): when too few keep traversing,
+            // they leave the loop with their state intact so that the idle lanes can take new rays
+            const unsigned long long still = __ballot(!fin);
+            if (!fin && !drained && __popcll(still) < LM_REFILL) break;
         }
     }
 #if LM_INSTRUMENT
