@@ -200,23 +200,21 @@ __device__ __forceinline__ bool lm_traverse(const LmScene& sc, const lf3& o, con
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Queue traversal with per-lane ray replacement ("persistent threads"): a wavefront owns a chunk of LM_CHUNK consecutive
-// rays at a time (one atomic per chunk on the queue head, not per wave-refill: a single address retires only ~88 returning
-// atomics per microsecond); lanes whose ray has terminated are refilled from the chunk as soon as fewer than LM_REFILL lanes
-// of the wave are still traversing, so incoherent rays of very different length do not leave most of the 64 lanes idle.
+// Queue traversal with per-lane ray replacement ("persistent threads").  Wavefront w of the launch owns the 64-ray groups
+// w, w + W, w + 2W, ... of the queue (W = wavefronts in the grid; no atomics: one address retires only ~88 returning atomics
+// per microsecond).  When fewer than `refillBelow` lanes of a wave are still traversing, the others take the next rays of
+// the wave's groups, so incoherent rays of very different length do not leave most of the 64 lanes idle; refillBelow <= 1
+// keeps a wave on one group at a time (best for coherent rays: an 8x8 pixel bundle stays together).
 // `done(rayIndex, found, hit)` runs once per ray.  Results are identical to lm_traverse (same tests, same tie-break).
 // ---------------------------------------------------------------------------------------------------------------------
-#define LM_CHUNK 512u
-#ifndef LM_REFILL
-#define LM_REFILL 40
-#endif
 template <bool ANY, class Fetch, class Done>
-__device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, uint32_t* __restrict__ head, int* __restrict__ stack /* LDS, stride LM_BLOCK */,
+__device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, int refillBelow, int* __restrict__ stack /* LDS, stride LM_BLOCK */,
                                                uint32_t* cnt, Fetch fetch, Done done)
 {
     const uint32_t lane = lm_lane();
-    uint32_t chunkNext = 0, chunkEnd = 0;          // wave-uniform
-    bool drained = false;                          // wave-uniform
+    const uint32_t W = gridDim.x * (LM_BLOCK / 64u);
+    uint32_t group = blockIdx.x * (LM_BLOCK / 64u) + (threadIdx.x >> 6);      // wave-uniform
+    uint32_t used = 0;                                                     // rays already handed out from `group` (wave-uniform)
     bool active = false;
     uint32_t rayIdx = 0;
     lf3 o = v3(0.f), d = v3(0.f);
@@ -229,21 +227,17 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, ui
     uint32_t nNodes = 0, nTris = 0;
 #endif
     for (;;) {
-        // ---- refill idle lanes from the wave's chunk
+        // ---- refill idle lanes from the wave's groups
         unsigned long long need = __ballot(!active);
+        bool drained = (unsigned long long)group * 64ull >= (unsigned long long)n;
         while (need != 0ull && !drained) {
-            if (chunkNext == chunkEnd) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(head, LM_CHUNK);
-                base = (uint32_t)__shfl((int)base, 0, 64);
-                if (base >= n) { drained = true; break; }
-                chunkNext = base; chunkEnd = min(base + LM_CHUNK, n);
-            }
-            const uint32_t want = (uint32_t)__popcll(need), avail = chunkEnd - chunkNext;
+            const uint32_t base = group * 64u;
+            const uint32_t avail = min(64u, n - base) - used;
+            const uint32_t want = (uint32_t)__popcll(need);
             const uint32_t give = min(want, avail);
             const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
             if (!active && rank < give) {
-                rayIdx = chunkNext + rank;
+                rayIdx = base + used + rank;
                 fetch(rayIdx, o, d, tmin, tmax);
                 const float idx = lm_safe_rcp(d.x), idy = lm_safe_rcp(d.y), idz = lm_safe_rcp(d.z);
                 ax = sc.qstep[0] * idx; ay = sc.qstep[1] * idy; az = sc.qstep[2] * idz;
@@ -251,7 +245,8 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, ui
                 hitT = tmax; hitOrder = 0xffffffffu; found = false; sp = 0; cur = 0;
                 active = true;
             }
-            chunkNext += give;
+            used += give;
+            if (used == min(64u, n - base)) { group += W; used = 0; drained = (unsigned long long)group * 64ull >= (unsigned long long)n; }
             need = __ballot(!active);
         }
         if (__ballot(active) == 0ull) break;
@@ -313,7 +308,7 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, ui
             // all lanes still in this loop vote (the ones that just finished included): when too few keep traversing,
             // they leave the loop with their state intact so that the idle lanes can take new rays
             const unsigned long long still = __ballot(!fin);
-            if (!fin && !drained && __popcll(still) < LM_REFILL) break;
+            if (!fin && !drained && (int)__popcll(still) < refillBelow) break;
         }
     }
 #if LM_INSTRUMENT
@@ -370,11 +365,11 @@ KN(lm_k_primary)(LmFrame fr, LmCamera cam, uint32_t frameCount)
 // ---------------------------------------------------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
 KN(lm_k_trace_closest)(LmScene sc, const float4* __restrict__ rayO, const float4* __restrict__ rayD, const uint32_t* __restrict__ countPtr,
-                   uint4* __restrict__ hits, float tmin, float tmax, uint32_t* counters, uint32_t* head)
+                   uint4* __restrict__ hits, float tmin, float tmax, uint32_t* counters, int refillBelow)
 {
     __shared__ int s_stack[LM_STACK_DEPTH * LM_BLOCK];
     const uint32_t n = *countPtr;
-    lm_trace_queue<false>(sc, n, head, s_stack + threadIdx.x, counters,
+    lm_trace_queue<false>(sc, n, refillBelow, s_stack + threadIdx.x, counters,
         [&](uint32_t i, lf3& o, lf3& d, float& t0, float& t1) { o = v3(rayO[i]); d = v3(rayD[i]); t0 = tmin; t1 = tmax; },
         [&](uint32_t i, bool found, const LmHit& h) {
             uint4 out = make_uint4(0u, 0u, 0u, f2u(-1.f));
@@ -743,11 +738,11 @@ KN(lm_k_shade_wave)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict_
 // K5: NEE shadow rays — reference WaveFrontShaders.cu:114-179 (tmin 0.01; unoccluded => channel += radiance).
 // At most one shadow ray per pixel per wave, so the add is a plain fp32 read-modify-write.
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
-KN(lm_k_trace_shadow)(LmScene sc, LmFrame fr, const uint32_t* __restrict__ countPtr, float tmin, uint32_t* head)
+KN(lm_k_trace_shadow)(LmScene sc, LmFrame fr, const uint32_t* __restrict__ countPtr, float tmin, int refillBelow)
 {
     __shared__ int s_stack[LM_STACK_DEPTH * LM_BLOCK];
     const uint32_t n = *countPtr;
-    lm_trace_queue<true>(sc, n, head, s_stack + threadIdx.x, fr.counters,
+    lm_trace_queue<true>(sc, n, refillBelow, s_stack + threadIdx.x, fr.counters,
         [&](uint32_t i, lf3& o, lf3& d, float& t0, float& t1) { const float4 o4 = fr.shO[i]; o = v3(o4); d = v3(fr.shD[i]); t0 = tmin; t1 = o4.w; },
         [&](uint32_t i, bool occluded, const LmHit&) {
             if (!occluded) {
@@ -790,12 +785,12 @@ KN(lm_k_restir_gen_rays)(LmFrame fr, int cur, int rc, uint32_t* outCount)
 // K6 + K23: resolve the visibility rays (tmin 0.1, WaveFrontShaders.cu:181-216: occluded => reservoir weight = 0) and shade
 // the surviving reservoirs into DIRECT with weight / 3 (ReSTIRKernels.cu:600-665)
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
-KN(lm_k_restir_trace_shade)(LmScene sc, LmFrame fr, int rc, const uint32_t* __restrict__ countPtr, uint32_t* head)
+KN(lm_k_restir_trace_shade)(LmScene sc, LmFrame fr, int rc, const uint32_t* __restrict__ countPtr, int refillBelow)
 {
     __shared__ int s_stack[LM_STACK_DEPTH * LM_BLOCK];
     const uint32_t n = *countPtr;
     float4* hot = fr.res[rc];
-    lm_trace_queue<true>(sc, n, head, s_stack + threadIdx.x, fr.counters,
+    lm_trace_queue<true>(sc, n, refillBelow, s_stack + threadIdx.x, fr.counters,
         [&](uint32_t i, lf3& o, lf3& d, float& t0, float& t1) { const float4 o4 = fr.shO[i]; o = v3(o4); d = v3(fr.shD[i]); t0 = 0.1f; t1 = o4.w; },
         [&](uint32_t i, bool occluded, const LmHit&) {
             const uint32_t li = f2u(fr.shD[i].w);
@@ -1191,17 +1186,17 @@ KN(lm_k_test_math)(uint32_t n, int fn, const float* __restrict__ x, const float*
 #define LM_GRID(g) dim3((unsigned)(g)), dim3(LM_BLOCK), 0, s
 
 static void l_primary(hipStream_t s, int g, LmFrame fr, LmCamera cam, uint32_t frameCount) { hipLaunchKernelGGL(KN(lm_k_primary), LM_GRID(g), fr, cam, frameCount); }
-static void l_trace_closest(hipStream_t s, int g, LmScene sc, const float4* o, const float4* d, const uint32_t* cnt, uint4* hits, float tmin, float tmax, uint32_t* counters, uint32_t* head)
-{ hipLaunchKernelGGL(KN(lm_k_trace_closest), LM_GRID(g), sc, o, d, cnt, hits, tmin, tmax, counters, head); }
+static void l_trace_closest(hipStream_t s, int g, LmScene sc, const float4* o, const float4* d, const uint32_t* cnt, uint4* hits, float tmin, float tmax, uint32_t* counters, int refillBelow)
+{ hipLaunchKernelGGL(KN(lm_k_trace_closest), LM_GRID(g), sc, o, d, cnt, hits, tmin, tmax, counters, refillBelow); }
 static void l_extract0(hipStream_t s, int g, LmScene sc, LmFrame fr, LmCamera cam, int cur) { hipLaunchKernelGGL(KN(lm_k_extract0), LM_GRID(g), sc, fr, cam, cur); }
 static void l_shade_indirect0(hipStream_t s, int g, LmFrame fr, int cur, uint32_t seed2, int outQ, uint32_t* outCount) { hipLaunchKernelGGL(KN(lm_k_shade_indirect0), dim3((unsigned)g), dim3(1024), 0, s, fr, cur, seed2, outQ, outCount); }
 static void l_shade_wave(hipStream_t s, int g, LmScene sc, LmFrame fr, int inQ, const uint32_t* inCount, uint32_t seed, uint32_t seed2, int doIndirect, uint32_t* outCount, uint32_t* shadowCount)
 { hipLaunchKernelGGL(KN(lm_k_shade_wave), dim3((unsigned)g), dim3(1024), 0, s, sc, fr, inQ, inCount, seed, seed2, doIndirect, outCount, shadowCount); }
-static void l_trace_shadow(hipStream_t s, int g, LmScene sc, LmFrame fr, const uint32_t* cnt, float tmin, uint32_t* head) { hipLaunchKernelGGL(KN(lm_k_trace_shadow), LM_GRID(g), sc, fr, cnt, tmin, head); }
+static void l_trace_shadow(hipStream_t s, int g, LmScene sc, LmFrame fr, const uint32_t* cnt, float tmin, int refillBelow) { hipLaunchKernelGGL(KN(lm_k_trace_shadow), LM_GRID(g), sc, fr, cnt, tmin, refillBelow); }
 static void l_fill_bags(hipStream_t s, LmScene sc, LmFrame fr, uint32_t seed, uint32_t total) { hipLaunchKernelGGL(KN(lm_k_fill_bags), LM_GRID((total + LM_BLOCK - 1) / LM_BLOCK), sc, fr, seed, total); }
 static void l_pick_primary(hipStream_t s, int tiles, LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_pick_primary), LM_GRID(tiles), sc, fr, cur, rc, seed); }
 static void l_gen_rays(hipStream_t s, int tiles, LmFrame fr, int cur, int rc, uint32_t* outCount) { hipLaunchKernelGGL(KN(lm_k_restir_gen_rays), dim3((unsigned)tiles), dim3(1024), 0, s, fr, cur, rc, outCount); }
-static void l_trace_shade(hipStream_t s, int g, LmScene sc, LmFrame fr, int rc, const uint32_t* cnt, uint32_t* head) { hipLaunchKernelGGL(KN(lm_k_restir_trace_shade), LM_GRID(g), sc, fr, rc, cnt, head); }
+static void l_trace_shade(hipStream_t s, int g, LmScene sc, LmFrame fr, int rc, const uint32_t* cnt, int refillBelow) { hipLaunchKernelGGL(KN(lm_k_restir_trace_shade), LM_GRID(g), sc, fr, rc, cnt, refillBelow); }
 static void l_temporal(hipStream_t s, int g, LmFrame fr, int cur, int prev, int rc, int rp, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_restir_temporal), LM_GRID(g), fr, cur, prev, rc, rp, seed); }
 static void l_spatial(hipStream_t s, int g, LmFrame fr, int cur, int rin, int rout, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_restir_spatial), LM_GRID(g), fr, cur, rin, rout, seed); }
 static void l_combine(hipStream_t s, int g, LmFrame fr, int cur, int rc, int rs, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_restir_combine), LM_GRID(g), fr, cur, rc, rs, seed); }

@@ -88,6 +88,7 @@ struct lumen_mi_renderer {
     int numCU = 256;
     const LmKernelTable* K = nullptr;
     bool instrumented = false;
+    int refillBelow = 40, refillVisibility = 0;      // lane-refill thresholds of the queue traversal kernels (tunable via LUMEN_MI_REFILL*)
 
     lumen_mi_settings settings{};
     lumen_mi_settings pending{};
@@ -511,7 +512,7 @@ int traceFrameAsync(R* r)
         uint32_t* inCount = fr.counters + LM_CNT_RAYS(depth);
         uint32_t* outCount = fr.counters + LM_CNT_RAYS(depth + 1);
         evBegin(r, 0, ev);
-        K->trace_closest(st, traceGrid, r->dscene, fr.rayO[q], fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters, fr.counters + LM_CNT_HEAD_CLOSEST(depth));   // :678,:703
+        K->trace_closest(st, traceGrid, r->dscene, fr.rayO[q], fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters, depth == 0 ? 0 : r->refillBelow);   // :678,:703
         evEnd(r, ev);
         const uint32_t seed2 = wangHash(seed);                                                // CPUShadingKernels.cu:178
         const int doIndirect = depth < depthMax - 1 ? 1 : 0;
@@ -531,14 +532,14 @@ int traceFrameAsync(R* r)
             const int tiles = (int)(((fr.ww + 15u) / 16u) * ((fr.wh + 15u) / 16u));
             const int tiles32 = (int)(((fr.ww + 31u) / 32u) * ((fr.wh + 31u) / 32u));
             K->gen_rays(st, tiles32, fr, currentIndex, cur, fr.counters + LM_CNT_RESTIR(0));
-            K->trace_shade(st, traceGrid, r->dscene, fr, cur, fr.counters + LM_CNT_RESTIR(0), fr.counters + LM_CNT_HEAD_RESTIR(0));
+            K->trace_shade(st, traceGrid, r->dscene, fr, cur, fr.counters + LM_CNT_RESTIR(0), r->refillVisibility);
             rs = wangHash(rs);
             K->temporal(st, tiles, fr, currentIndex, temporalIndex, cur, tmp, rs);
             rs = wangHash(rs);
             K->spatial(st, tiles, fr, currentIndex, cur, 2, rs);
             K->spatial(st, tiles, fr, currentIndex, 2, 3, rs);
             K->gen_rays(st, tiles32, fr, currentIndex, cur, fr.counters + LM_CNT_RESTIR(1));
-            K->trace_shade(st, traceGrid, r->dscene, fr, cur, fr.counters + LM_CNT_RESTIR(1), fr.counters + LM_CNT_HEAD_RESTIR(1));
+            K->trace_shade(st, traceGrid, r->dscene, fr, cur, fr.counters + LM_CNT_RESTIR(1), r->refillVisibility);
             K->combine(st, tiles, fr, currentIndex, cur, 3, wangHash(rs));
             evEnd(r, ev);
             if (doIndirect) { evBegin(r, 2, ev); K->shade_indirect0(st, (int)(((fr.ww + 31u) / 32u) * ((fr.wh + 31u) / 32u)), fr, currentIndex, seed2, q ^ 1, outCount); evEnd(r, ev); }
@@ -548,7 +549,7 @@ int traceFrameAsync(R* r)
             K->shade_wave(st, r->numCU * 2, r->dscene, fr, q, inCount, seed, seed2, doIndirect, outCount, shCount);
             evEnd(r, ev);
             evBegin(r, 1, ev);
-            K->trace_shadow(st, traceGrid, r->dscene, fr, shCount, 0.01f, fr.counters + LM_CNT_HEAD_SHADOW(depth));                   // tmin of the intersection launch (:843)
+            K->trace_shadow(st, traceGrid, r->dscene, fr, shCount, 0.01f, r->refillBelow);                   // tmin of the intersection launch (:843)
             evEnd(r, ev);
         }
         q ^= 1;
@@ -606,6 +607,8 @@ int lumen_mi_create(lumen_mi_renderer** out)
     initLut();
     *out = new lumen_mi_renderer();
     (*out)->K = lm_kernel_table();
+    if (const char* e = getenv("LUMEN_MI_REFILL")) (*out)->refillBelow = atoi(e);
+    if (const char* e = getenv("LUMEN_MI_REFILL_VIS")) (*out)->refillVisibility = atoi(e);
     return 0;
 }
 
