@@ -95,6 +95,27 @@ __device__ __forceinline__ float4 lm_mul_m34(const float* m, const lf3& v, float
 // ---------------------------------------------------------------------------------------------------------------------
 struct LmHit { float t, u, v; uint32_t slot; };
 
+// Per-lane traversal stack: the first LM_STACK_LDS entries live in LDS ([level][lane]: one bank per lane), deeper entries
+// (rare) spill to a per-thread global array, so that the LDS footprint (16 KB per 256-thread block) does not cap occupancy.
+struct LmStack { int* lds; int* spill; };
+__device__ __forceinline__ void lm_push(const LmStack& st, int& sp, int v)
+{
+    if (sp < LM_STACK_LDS) st.lds[sp * LM_BLOCK] = v; else st.spill[sp - LM_STACK_LDS] = v;
+    sp++;
+}
+__device__ __forceinline__ int lm_pop(const LmStack& st, int& sp)
+{
+    --sp;
+    return sp < LM_STACK_LDS ? st.lds[sp * LM_BLOCK] : st.spill[sp - LM_STACK_LDS];
+}
+__device__ __forceinline__ LmStack lm_make_stack(int* s_stack, const LmScene& sc)
+{
+    LmStack st;
+    st.lds = s_stack + threadIdx.x;
+    st.spill = sc.spill + (size_t)(blockIdx.x * LM_BLOCK + threadIdx.x) * (LM_STACK_DEPTH - LM_STACK_LDS);
+    return st;
+}
+
 __device__ __forceinline__ bool lm_woop(const LmWoop* __restrict__ woop, uint32_t slot, const lf3& o, const lf3& d,
                                         float tmin, float tmax, float& t, float& u, float& v)
 {
@@ -124,7 +145,7 @@ __device__ __forceinline__ float lm_safe_rcp(float d)
 
 template <bool ANY>
 __device__ __forceinline__ bool lm_traverse(const LmScene& sc, const lf3& o, const lf3& d, float tmin, float tmax,
-                                            int* __restrict__ stack /* LDS, stride LM_BLOCK */, LmHit& hit, uint32_t* cnt)
+                                            const LmStack& stack, LmHit& hit, uint32_t* cnt)
 {
     const float idx = lm_safe_rcp(d.x), idy = lm_safe_rcp(d.y), idz = lm_safe_rcp(d.z);
     // node boxes are 16-bit fixed point: world = qmin + q * qstep, so t = q * (qstep * idir) + (qmin - o) * idir
@@ -159,13 +180,13 @@ __device__ __forceinline__ bool lm_traverse(const LmScene& sc, const lf3& o, con
             const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
             if (!h0 && !h1) {
                 if (sp == 0) { cur = 0x7fffffff; break; }
-                cur = stack[(--sp) * LM_BLOCK];
+                cur = lm_pop(stack, sp);
             } else {
                 int first = h0 ? ref.x : ref.y;
                 if (h0 && h1) {
                     int second = ref.y;
                     if (tn1 < tn0) { second = first; first = ref.y; }
-                    stack[(sp++) * LM_BLOCK] = second;
+                    lm_push(stack, sp, second);
                 }
                 cur = first;
             }
@@ -190,7 +211,7 @@ __device__ __forceinline__ bool lm_traverse(const LmScene& sc, const lf3& o, con
         }
         if (ANY && found) break;
         if (sp == 0) break;
-        cur = stack[(--sp) * LM_BLOCK];
+        cur = lm_pop(stack, sp);
     }
 #if LM_INSTRUMENT
     atomicAdd((unsigned long long*)(cnt + LM_CNT_NODES), (unsigned long long)nNodes);
@@ -208,7 +229,7 @@ __device__ __forceinline__ bool lm_traverse(const LmScene& sc, const lf3& o, con
 // `done(rayIndex, found, hit)` runs once per ray.  Results are identical to lm_traverse (same tests, same tie-break).
 // ---------------------------------------------------------------------------------------------------------------------
 template <bool ANY, class Fetch, class Done>
-__device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, int refillBelow, int* __restrict__ stack /* LDS, stride LM_BLOCK */,
+__device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, int refillBelow, const LmStack& stack,
                                                uint32_t* cnt, Fetch fetch, Done done)
 {
     const uint32_t lane = lm_lane();
@@ -270,13 +291,13 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
                 const float tf1 = fminf(fminf(fmaxf(c1lox, c1hix), fmaxf(c1loy, c1hiy)), fminf(fmaxf(c1loz, c1hiz), hitT));
                 const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
                 if (!h0 && !h1) {
-                    cur = sp == 0 ? 0x7fffffff : stack[(--sp) * LM_BLOCK];
+                    cur = sp == 0 ? 0x7fffffff : lm_pop(stack, sp);
                 } else {
                     int first = h0 ? (int)q0.w : (int)q1.w;
                     if (h0 && h1) {
                         int second = (int)q1.w;
                         if (tn1 < tn0) { second = first; first = (int)q1.w; }
-                        stack[(sp++) * LM_BLOCK] = second;
+                        lm_push(stack, sp, second);
                     }
                     cur = first;
                 }
@@ -298,7 +319,7 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
                         }
                     }
                 }
-                cur = ((ANY && found) || sp == 0) ? 0x7fffffff : stack[(--sp) * LM_BLOCK];
+                cur = ((ANY && found) || sp == 0) ? 0x7fffffff : lm_pop(stack, sp);
             }
             const bool fin = cur == 0x7fffffff;
             if (fin) {
@@ -367,9 +388,9 @@ extern "C" __global__ void __launch_bounds__(LM_BLOCK)
 KN(lm_k_trace_closest)(LmScene sc, const float4* __restrict__ rayO, const float4* __restrict__ rayD, const uint32_t* __restrict__ countPtr,
                    uint4* __restrict__ hits, float tmin, float tmax, uint32_t* counters, int refillBelow)
 {
-    __shared__ int s_stack[LM_STACK_DEPTH * LM_BLOCK];
+    __shared__ int s_stack[LM_STACK_LDS * LM_BLOCK];
     const uint32_t n = *countPtr;
-    lm_trace_queue<false>(sc, n, refillBelow, s_stack + threadIdx.x, counters,
+    lm_trace_queue<false>(sc, n, refillBelow, lm_make_stack(s_stack, sc), counters,
         [&](uint32_t i, lf3& o, lf3& d, float& t0, float& t1) { o = v3(rayO[i]); d = v3(rayD[i]); t0 = tmin; t1 = tmax; },
         [&](uint32_t i, bool found, const LmHit& h) {
             uint4 out = make_uint4(0u, 0u, 0u, f2u(-1.f));
@@ -740,9 +761,9 @@ KN(lm_k_shade_wave)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict_
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
 KN(lm_k_trace_shadow)(LmScene sc, LmFrame fr, const uint32_t* __restrict__ countPtr, float tmin, int refillBelow)
 {
-    __shared__ int s_stack[LM_STACK_DEPTH * LM_BLOCK];
+    __shared__ int s_stack[LM_STACK_LDS * LM_BLOCK];
     const uint32_t n = *countPtr;
-    lm_trace_queue<true>(sc, n, refillBelow, s_stack + threadIdx.x, fr.counters,
+    lm_trace_queue<true>(sc, n, refillBelow, lm_make_stack(s_stack, sc), fr.counters,
         [&](uint32_t i, lf3& o, lf3& d, float& t0, float& t1) { const float4 o4 = fr.shO[i]; o = v3(o4); d = v3(fr.shD[i]); t0 = tmin; t1 = o4.w; },
         [&](uint32_t i, bool occluded, const LmHit&) {
             if (!occluded) {
@@ -787,10 +808,10 @@ KN(lm_k_restir_gen_rays)(LmFrame fr, int cur, int rc, uint32_t* outCount)
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
 KN(lm_k_restir_trace_shade)(LmScene sc, LmFrame fr, int rc, const uint32_t* __restrict__ countPtr, int refillBelow)
 {
-    __shared__ int s_stack[LM_STACK_DEPTH * LM_BLOCK];
+    __shared__ int s_stack[LM_STACK_LDS * LM_BLOCK];
     const uint32_t n = *countPtr;
     float4* hot = fr.res[rc];
-    lm_trace_queue<true>(sc, n, refillBelow, s_stack + threadIdx.x, fr.counters,
+    lm_trace_queue<true>(sc, n, refillBelow, lm_make_stack(s_stack, sc), fr.counters,
         [&](uint32_t i, lf3& o, lf3& d, float& t0, float& t1) { const float4 o4 = fr.shO[i]; o = v3(o4); d = v3(fr.shD[i]); t0 = 0.1f; t1 = o4.w; },
         [&](uint32_t i, bool occluded, const LmHit&) {
             const uint32_t li = f2u(fr.shD[i].w);
@@ -1104,8 +1125,8 @@ extern "C" __global__ void __launch_bounds__(LM_BLOCK)
 KN(lm_k_query_any)(LmScene sc, const float4* __restrict__ rayO /* w = tmax */, const float4* __restrict__ rayD, uint32_t n, float tmin,
                uint32_t* __restrict__ occluded, uint32_t* counters)
 {
-    __shared__ int s_stack[LM_STACK_DEPTH * LM_BLOCK];
-    int* stack = s_stack + threadIdx.x;
+    __shared__ int s_stack[LM_STACK_LDS * LM_BLOCK];
+    const LmStack stack = lm_make_stack(s_stack, sc);
     const uint32_t stride = gridDim.x * LM_BLOCK;
     for (uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x; i < n; i += stride) {
         const float4 o4 = rayO[i], d4 = rayD[i];
@@ -1117,8 +1138,8 @@ extern "C" __global__ void __launch_bounds__(LM_BLOCK)
 KN(lm_k_query_closest_raw)(LmScene sc, const float4* __restrict__ rayO, const float4* __restrict__ rayD, uint32_t n, float tmin, float tmax,
                        uint4* __restrict__ idOut, float4* __restrict__ uvtOut, uint32_t* counters)
 {
-    __shared__ int s_stack[LM_STACK_DEPTH * LM_BLOCK];
-    int* stack = s_stack + threadIdx.x;
+    __shared__ int s_stack[LM_STACK_LDS * LM_BLOCK];
+    const LmStack stack = lm_make_stack(s_stack, sc);
     const uint32_t stride = gridDim.x * LM_BLOCK;
     for (uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x; i < n; i += stride) {
         LmHit h; h.t = -1.f; h.u = 0.f; h.v = 0.f; h.slot = 0;

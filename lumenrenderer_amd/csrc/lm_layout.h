@@ -8,7 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define LM_STACK_DEPTH 32        // traversal stack entries per lane; the BVH builder bounds the tree depth to this
+#define LM_STACK_DEPTH 48        // traversal stack entries per lane; the BVH builder bounds the tree depth to this
+#define LM_STACK_LDS 16          // of which in LDS; deeper entries spill to a per-thread global array
 #define LM_MAX_LEAF 8            // triangles per leaf representable in a leaf reference
 #define LM_MAX_DEPTH 16          // path depth the counter block is sized for
 
@@ -69,6 +70,7 @@ struct LmScene {
     const float* srgbLut;       // 256 entries
     const LmLight* lights;      // sorted by mean radiance
     const float* cdf;
+    int* spill;                 // per-thread stack overflow area: (LM_STACK_DEPTH - LM_STACK_LDS) ints per thread of the largest trace grid
     uint32_t numLights;
     float cdfSum;
 };

@@ -128,7 +128,7 @@ struct lumen_mi_renderer {
     // device scene
     DevBuf<LmNodeQ> dNodes; DevBuf<LmWoop> dWoop; DevBuf<uint2> dTriId; DevBuf<uint32_t> dTriOrder;
     DevBuf<float4> dVerts; DevBuf<uint32_t> dIndices; DevBuf<LmEntry> dEntries; DevBuf<LmDevMaterial> dMaterials;
-    DevBuf<LmTexDesc> dTexDesc; DevBuf<uint32_t> dTexels; DevBuf<float> dLut; DevBuf<LmLight> dLights; DevBuf<float> dCdf;
+    DevBuf<int> dSpill; DevBuf<LmTexDesc> dTexDesc; DevBuf<uint32_t> dTexels; DevBuf<float> dLut; DevBuf<LmLight> dLights; DevBuf<float> dCdf;
     LmScene dscene{};
 
     // device frame
@@ -151,6 +151,7 @@ struct lumen_mi_renderer {
     // render thread
     std::thread renderThread; std::atomic<bool> stopFlag{false};
 
+    int traceGrid() const { return numCU * 8; }
     int gridFor(uint32_t n, int perCU) const { const int full = (int)((n + 255u) / 256u); return std::max(1, std::min(full, numCU * perCU)); }
 };
 
@@ -258,6 +259,8 @@ int flatten(R* r)
         return fail(LUMEN_MI_ERR_DEVICE, "scene upload failed (hipMalloc/hipMemcpy)");
     if (hipStreamSynchronize(st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "scene upload sync failed");
     for (int k = 0; k < 3; k++) { r->dscene.qmin[k] = r->bvh.qmin[k]; r->dscene.qstep[k] = r->bvh.qstep[k]; }
+    if (r->dSpill.ensure((size_t)r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS))) return fail(LUMEN_MI_ERR_DEVICE, "stack spill allocation failed");
+    r->dscene.spill = r->dSpill.p;
     r->dscene.nodes = r->dNodes.p; r->dscene.woop = r->dWoop.p; r->dscene.triId = r->dTriId.p; r->dscene.triOrder = r->dTriOrder.p;
     r->dscene.verts = r->dVerts.p; r->dscene.indices = r->dIndices.p; r->dscene.entries = r->dEntries.p;
     r->sceneDirty = false;
@@ -506,7 +509,7 @@ int traceFrameAsync(R* r)
     K->primary(st, r->gridFor(fr.n, 8), fr, cam, r->frameCount);
     uint32_t seed = wangHash(r->frameCount);                                                  // :685
     int q = 0;
-    const int traceGrid = r->numCU * 5;          // persistent: 5 blocks of 256 threads per CU (LDS stack 32 KB per block)
+    const int traceGrid = r->traceGrid();        // persistent: 8 blocks of 256 threads per CU (16 KB of LDS stack each)
     size_t ev;
     for (uint32_t depth = 0; depth < depthMax; ++depth) {
         uint32_t* inCount = fr.counters + LM_CNT_RAYS(depth);
@@ -639,7 +642,7 @@ int lumen_mi_destroy(lumen_mi_renderer* r)
     if (r->initialised) {
         (void)hipSetDevice(r->device);
         (void)hipStreamSynchronize(r->stream);
-        r->dNodes.release(); r->dWoop.release(); r->dTriId.release(); r->dTriOrder.release(); r->dVerts.release(); r->dIndices.release();
+        r->dSpill.release(); r->dNodes.release(); r->dWoop.release(); r->dTriId.release(); r->dTriOrder.release(); r->dVerts.release(); r->dIndices.release();
         r->dEntries.release(); r->dMaterials.release(); r->dTexDesc.release(); r->dTexels.release(); r->dLut.release(); r->dLights.release(); r->dCdf.release();
         for (auto& b : r->dRay) b.release(); for (auto& b : r->dSh) b.release(); for (auto& b : r->dGbuf) b.release(); for (auto& b : r->dProbe) b.release(); for (auto& b : r->dRes) b.release(); for (auto& b : r->dResC) b.release();
         r->dDirect.release(); r->dIndirect.release(); r->dCombined.release(); r->dHits.release(); r->dMotion.release(); r->dCounters.release(); r->dOutput.release(); r->dBags.release();
@@ -1009,7 +1012,7 @@ int lumen_mi_query_closest(lumen_mi_renderer* r, uint32_t n, const float* o, con
     for (uint32_t i = 0; i < n; i++) { ho[i] = make_float4(o[3*i], o[3*i+1], o[3*i+2], 0.f); hd[i] = make_float4(d[3*i], d[3*i+1], d[3*i+2], 0.f); }
     DevBuf<float4> dO, dD, dU; DevBuf<uint4> dI;
     if (dO.upload(ho, r->stream) || dD.upload(hd, r->stream) || dU.ensure(n) || dI.ensure(n)) return fail(LUMEN_MI_ERR_DEVICE, "query allocation failed");
-    r->K->query_closest(r->stream, r->numCU * 12, r->dscene, dO.p, dD.p, n, tmin, tmax, dI.p, dU.p, r->dCounters.p);
+    r->K->query_closest(r->stream, r->traceGrid(), r->dscene, dO.p, dD.p, n, tmin, tmax, dI.p, dU.p, r->dCounters.p);
     std::vector<uint4> hi(n); std::vector<float4> hu(n);
     LM_HIP(hipStreamSynchronize(r->stream));
     LM_HIP(hipMemcpy(hi.data(), dI.p, (size_t)n * 16, hipMemcpyDeviceToHost));
@@ -1027,7 +1030,7 @@ int lumen_mi_query_any(lumen_mi_renderer* r, uint32_t n, const float* o, const f
     for (uint32_t i = 0; i < n; i++) { ho[i] = make_float4(o[3*i], o[3*i+1], o[3*i+2], tmax[i]); hd[i] = make_float4(d[3*i], d[3*i+1], d[3*i+2], 0.f); }
     DevBuf<float4> dO, dD; DevBuf<uint32_t> dR;
     if (dO.upload(ho, r->stream) || dD.upload(hd, r->stream) || dR.ensure(n)) return fail(LUMEN_MI_ERR_DEVICE, "query allocation failed");
-    r->K->query_any(r->stream, r->numCU * 12, r->dscene, dO.p, dD.p, n, tmin, dR.p, r->dCounters.p);
+    r->K->query_any(r->stream, r->traceGrid(), r->dscene, dO.p, dD.p, n, tmin, dR.p, r->dCounters.p);
     std::vector<uint32_t> hr(n);
     LM_HIP(hipStreamSynchronize(r->stream));
     LM_HIP(hipMemcpy(hr.data(), dR.p, (size_t)n * 4, hipMemcpyDeviceToHost));
