@@ -799,8 +799,8 @@ KN(lm_k_restir_gen_rays)(LmFrame fr, int cur, int rc, uint32_t* outCount)
     }
     const uint32_t slot = lm_append_slot_block(outCount, shoot, s_tmp);
     if (shoot) {
-        fr.shO[slot] = v4(pos, l - 0.05f);
-        fr.shD[slot] = v4(toLight, u2f(li));
+        fr.visO[slot] = v4(pos, l - 0.05f);
+        fr.visD[slot] = v4(toLight, u2f(li));
     }
 }
 // K6 + K23: resolve the visibility rays (tmin 0.1, WaveFrontShaders.cu:181-216: occluded => reservoir weight = 0) and shade
@@ -812,9 +812,9 @@ KN(lm_k_restir_trace_shade)(LmScene sc, LmFrame fr, int rc, const uint32_t* __re
     const uint32_t n = *countPtr;
     float4* hot = fr.res[rc];
     lm_trace_queue<true>(sc, n, refillBelow, lm_make_stack(s_stack, sc), fr.counters,
-        [&](uint32_t i, lf3& o, lf3& d, float& t0, float& t1) { const float4 o4 = fr.shO[i]; o = v3(o4); d = v3(fr.shD[i]); t0 = 0.1f; t1 = o4.w; },
+        [&](uint32_t i, lf3& o, lf3& d, float& t0, float& t1) { const float4 o4 = fr.visO[i]; o = v3(o4); d = v3(fr.visD[i]); t0 = 0.1f; t1 = o4.w; },
         [&](uint32_t i, bool occluded, const LmHit&) {
-            const uint32_t li = f2u(fr.shD[i].w);
+            const uint32_t li = f2u(fr.visD[i].w);
             float4 r0 = hot[4u * li];
             if (occluded) { r0.y = 0.f; hot[4u * li] = r0; }
             else {

@@ -85,6 +85,10 @@ struct lumen_mi_renderer {
     bool initialised = false;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t aux = nullptr;              // second stream: the indirect waves run beside ReSTIR (both depend only on the depth-0 G-buffer)
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
+    bool overlap = true;
+    int traceBlocksMain = 8, traceBlocksAux = 8;
     int numCU = 256;
     const LmKernelTable* K = nullptr;
     bool instrumented = false;
@@ -134,7 +138,7 @@ struct lumen_mi_renderer {
     // device frame
     LmFrame fr{};
     uint32_t allocN = 0, allocDepth = 0;
-    DevBuf<float4> dRay[6], dSh[3], dGbuf[2], dProbe[2], dRes[4], dResC[4], dDirect, dIndirect, dCombined;
+    DevBuf<float4> dRay[6], dSh[3], dSh2[2], dGbuf[2], dProbe[2], dRes[4], dResC[4], dDirect, dIndirect, dCombined;
     DevBuf<uint4> dHits; DevBuf<uint32_t> dMotion, dCounters; DevBuf<uchar4> dOutput; DevBuf<uint2> dBags;
     uint32_t hostCounters[LM_CNT_WORDS] = {0};
     bool countersValid = false;
@@ -259,7 +263,7 @@ int flatten(R* r)
         return fail(LUMEN_MI_ERR_DEVICE, "scene upload failed (hipMalloc/hipMemcpy)");
     if (hipStreamSynchronize(st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "scene upload sync failed");
     for (int k = 0; k < 3; k++) { r->dscene.qmin[k] = r->bvh.qmin[k]; r->dscene.qstep[k] = r->bvh.qstep[k]; }
-    if (r->dSpill.ensure((size_t)r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS))) return fail(LUMEN_MI_ERR_DEVICE, "stack spill allocation failed");
+    if (r->dSpill.ensure((size_t)2 * r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS)))      // one area per stream return fail(LUMEN_MI_ERR_DEVICE, "stack spill allocation failed");
     r->dscene.spill = r->dSpill.p;
     r->dscene.nodes = r->dNodes.p; r->dscene.woop = r->dWoop.p; r->dscene.triId = r->dTriId.p; r->dscene.triOrder = r->dTriOrder.p;
     r->dscene.verts = r->dVerts.p; r->dscene.indices = r->dIndices.p; r->dscene.entries = r->dEntries.p;
@@ -405,6 +409,7 @@ int ensureFrameBuffers(R* r)
     int bad = 0;
     for (int i = 0; i < 6; i++) bad |= r->dRay[i].ensure(n);
     for (int i = 0; i < 3; i++) bad |= r->dSh[i].ensure(n);
+    for (int i = 0; i < 2; i++) bad |= r->dSh2[i].ensure(n);
     for (int i = 0; i < 2; i++) bad |= r->dGbuf[i].ensure((size_t)8 * n) | r->dProbe[i].ensure(n);
     for (int i = 0; i < 4; i++) bad |= r->dRes[i].ensure((size_t)4 * n) | r->dResC[i].ensure(n);
     bad |= r->dDirect.ensure(n) | r->dIndirect.ensure(n) | r->dCombined.ensure(n) | r->dHits.ensure(n) | r->dMotion.ensure(n) | r->dOutput.ensure(n);
@@ -412,6 +417,7 @@ int ensureFrameBuffers(R* r)
     if (bad) return fail(LUMEN_MI_ERR_DEVICE, "frame buffer allocation failed");
     for (int q = 0; q < 2; q++) { f.rayO[q] = r->dRay[3 * q].p; f.rayD[q] = r->dRay[3 * q + 1].p; f.rayC[q] = r->dRay[3 * q + 2].p; }
     f.shO = r->dSh[0].p; f.shD = r->dSh[1].p; f.shR = r->dSh[2].p;
+    f.visO = r->dSh2[0].p; f.visD = r->dSh2[1].p;
     f.hits = r->dHits.p;
     for (int i = 0; i < 2; i++) { f.gbuf[i] = r->dGbuf[i].p; f.probe[i] = r->dProbe[i].p; }
     for (int i = 0; i < 4; i++) { f.res[i] = r->dRes[i].p; f.resC[i] = r->dResC[i].p; }
@@ -463,6 +469,16 @@ void evBegin(R* r, int cls, size_t& slot)
     (void)hipEventRecord(r->evPool[slot].a, r->stream);
 }
 void evEnd(R* r, size_t slot) { if (slot != (size_t)-1) (void)hipEventRecord(r->evPool[slot].b, r->stream); }
+void evBegin2(R* r, int cls, size_t& slot, hipStream_t s)
+{
+    slot = (size_t)-1;
+    if (!r->timing) return;
+    if (r->evUsed == r->evPool.size()) { R::EvPair p; if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return; p.cls = 0; r->evPool.push_back(p); }
+    slot = r->evUsed++;
+    r->evPool[slot].cls = cls;
+    (void)hipEventRecord(r->evPool[slot].a, s);
+}
+void evEnd2(R* r, size_t slot, hipStream_t s) { if (slot != (size_t)-1) (void)hipEventRecord(r->evPool[slot].b, s); }
 
 int traceFrameAsync(R* r)
 {
@@ -508,22 +524,29 @@ int traceFrameAsync(R* r)
     ++r->frameCount;                                                                          // :593
     K->primary(st, r->gridFor(fr.n, 8), fr, cam, r->frameCount);
     uint32_t seed = wangHash(r->frameCount);                                                  // :685
+    const bool overlap = r->overlap && r->aux != nullptr;
+    hipStream_t sx = overlap ? r->aux : st;                                                   // stream of the indirect waves
+    LmScene scx = r->dscene;                                                                  // same scene, its own stack-spill area
+    if (overlap) scx.spill += (size_t)r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS);
+    const int gridMain = r->numCU * r->traceBlocksMain, gridAux = r->numCU * (overlap ? r->traceBlocksAux : r->traceBlocksMain);
+    const int tiles = (int)(((fr.ww + 15u) / 16u) * ((fr.wh + 15u) / 16u));
+    const int tiles32 = (int)(((fr.ww + 31u) / 32u) * ((fr.wh + 31u) / 32u));
     int q = 0;
-    const int traceGrid = r->traceGrid();        // persistent: 8 blocks of 256 threads per CU (16 KB of LDS stack each)
     size_t ev;
     for (uint32_t depth = 0; depth < depthMax; ++depth) {
         uint32_t* inCount = fr.counters + LM_CNT_RAYS(depth);
         uint32_t* outCount = fr.counters + LM_CNT_RAYS(depth + 1);
-        evBegin(r, 0, ev);
-        K->trace_closest(st, traceGrid, r->dscene, fr.rayO[q], fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters, depth == 0 ? 0 : r->refillBelow);   // :678,:703
-        evEnd(r, ev);
         const uint32_t seed2 = wangHash(seed);                                                // CPUShadingKernels.cu:178
         const int doIndirect = depth < depthMax - 1 ? 1 : 0;
         if (depth == 0) {
+            evBegin(r, 0, ev);
+            K->trace_closest(st, gridMain, r->dscene, fr.rayO[q], fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters, 0);    // :678,:703
+            evEnd(r, ev);
             evBegin(r, 2, ev);
             K->extract0(st, r->gridFor(fr.n, 8), r->dscene, fr, cam, currentIndex);
             evEnd(r, ev);
-            // ReSTIR::Run (Framework/ReSTIR.cpp:65-233)
+            if (overlap) { LM_HIP(hipEventRecord(r->evFork, st)); LM_HIP(hipStreamWaitEvent(sx, r->evFork, 0)); }
+            // ReSTIR::Run (Framework/ReSTIR.cpp:65-233) — stays on the main stream
             evBegin(r, 3, ev);
             const int cur = r->swapChainIndex, tmp = cur == 1 ? 0 : 1;
             uint32_t rs = wangHash(seed);
@@ -532,33 +555,36 @@ int traceFrameAsync(R* r)
             const uint32_t tx0 = fr.x0 / 16u, ty0 = fr.y0 / 16u;
             const uint32_t wtx = (fr.x0 + fr.ww + 15u) / 16u - tx0, wty = (fr.y0 + fr.wh + 15u) / 16u - ty0;
             K->pick_primary(st, (int)(wtx * wty), r->dscene, fr, currentIndex, cur, rs);
-            const int tiles = (int)(((fr.ww + 15u) / 16u) * ((fr.wh + 15u) / 16u));
-            const int tiles32 = (int)(((fr.ww + 31u) / 32u) * ((fr.wh + 31u) / 32u));
             K->gen_rays(st, tiles32, fr, currentIndex, cur, fr.counters + LM_CNT_RESTIR(0));
-            K->trace_shade(st, traceGrid, r->dscene, fr, cur, fr.counters + LM_CNT_RESTIR(0), r->refillVisibility);
+            K->trace_shade(st, gridMain, r->dscene, fr, cur, fr.counters + LM_CNT_RESTIR(0), r->refillVisibility);
             rs = wangHash(rs);
             K->temporal(st, tiles, fr, currentIndex, temporalIndex, cur, tmp, rs);
             rs = wangHash(rs);
             K->spatial(st, tiles, fr, currentIndex, cur, 2, rs);
             K->spatial(st, tiles, fr, currentIndex, 2, 3, rs);
             K->gen_rays(st, tiles32, fr, currentIndex, cur, fr.counters + LM_CNT_RESTIR(1));
-            K->trace_shade(st, traceGrid, r->dscene, fr, cur, fr.counters + LM_CNT_RESTIR(1), r->refillVisibility);
+            K->trace_shade(st, gridMain, r->dscene, fr, cur, fr.counters + LM_CNT_RESTIR(1), r->refillVisibility);
             K->combine(st, tiles, fr, currentIndex, cur, 3, wangHash(rs));
             evEnd(r, ev);
-            if (doIndirect) { evBegin(r, 2, ev); K->shade_indirect0(st, (int)(((fr.ww + 31u) / 32u) * ((fr.wh + 31u) / 32u)), fr, currentIndex, seed2, q ^ 1, outCount); evEnd(r, ev); }
+            // path continuation: depends only on the G-buffer, runs beside ReSTIR on the second stream
+            if (doIndirect) { evBegin2(r, 2, ev, sx); K->shade_indirect0(sx, tiles32, fr, currentIndex, seed2, q ^ 1, outCount); evEnd2(r, ev, sx); }
         } else {
             uint32_t* shCount = fr.counters + LM_CNT_SHADOW(depth);
-            evBegin(r, 2, ev);
-            K->shade_wave(st, r->numCU * 2, r->dscene, fr, q, inCount, seed, seed2, doIndirect, outCount, shCount);
-            evEnd(r, ev);
-            evBegin(r, 1, ev);
-            K->trace_shadow(st, traceGrid, r->dscene, fr, shCount, 0.01f, r->refillBelow);                   // tmin of the intersection launch (:843)
-            evEnd(r, ev);
+            evBegin2(r, 0, ev, sx);
+            K->trace_closest(sx, gridAux, scx, fr.rayO[q], fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters, r->refillBelow);
+            evEnd2(r, ev, sx);
+            evBegin2(r, 2, ev, sx);
+            K->shade_wave(sx, r->numCU * 2, scx, fr, q, inCount, seed, seed2, doIndirect, outCount, shCount);
+            evEnd2(r, ev, sx);
+            evBegin2(r, 1, ev, sx);
+            K->trace_shadow(sx, gridAux, scx, fr, shCount, 0.01f, r->refillBelow);     // tmin of the intersection launch (:843)
+            evEnd2(r, ev, sx);
         }
         q ^= 1;
         r->swapChainIndex = r->swapChainIndex + 1 >= 2 ? 0 : r->swapChainIndex + 1;         // ReSTIR::SwapBuffers once per wave (:827)
         seed = wangHash(seed);                                                               // :830
     }
+    if (overlap) { LM_HIP(hipEventRecord(r->evJoin, sx)); LM_HIP(hipStreamWaitEvent(st, r->evJoin, 0)); }
     K->merge(st, r->gridFor(fr.n, 8), fr, blend ? 1 : 0, r->blendCounter);
     evEnd(r, evAll);
     LM_HIP(hipGetLastError());
@@ -631,6 +657,14 @@ int lumen_mi_init(lumen_mi_renderer* r, const lumen_mi_settings* s)
     if (r->settings.depth == 0) { r->settings.depth = 5; r->pending.depth = 5; }
     r->pending.output_width = r->settings.output_width = s->output_width ? s->output_width : s->render_width;
     r->pending.output_height = r->settings.output_height = s->output_height ? s->output_height : s->render_height;
+    if (const char* e = getenv("LUMEN_MI_SINGLE_STREAM")) r->overlap = atoi(e) == 0;
+    if (const char* e = getenv("LUMEN_MI_TRACE_BLOCKS_MAIN")) r->traceBlocksMain = std::max(1, std::min(8, atoi(e)));
+    if (const char* e = getenv("LUMEN_MI_TRACE_BLOCKS_AUX")) r->traceBlocksAux = std::max(1, std::min(8, atoi(e)));
+    if (!r->aux) {
+        LM_HIP(hipStreamCreateWithFlags(&r->aux, hipStreamNonBlocking));
+        LM_HIP(hipEventCreateWithFlags(&r->evFork, hipEventDisableTiming));
+        LM_HIP(hipEventCreateWithFlags(&r->evJoin, hipEventDisableTiming));
+    }
     r->initialised = true;
     return 0;
 }
@@ -642,9 +676,10 @@ int lumen_mi_destroy(lumen_mi_renderer* r)
     if (r->initialised) {
         (void)hipSetDevice(r->device);
         (void)hipStreamSynchronize(r->stream);
+        if (r->aux) { (void)hipStreamSynchronize(r->aux); (void)hipStreamDestroy(r->aux); (void)hipEventDestroy(r->evFork); (void)hipEventDestroy(r->evJoin); }
         r->dSpill.release(); r->dNodes.release(); r->dWoop.release(); r->dTriId.release(); r->dTriOrder.release(); r->dVerts.release(); r->dIndices.release();
         r->dEntries.release(); r->dMaterials.release(); r->dTexDesc.release(); r->dTexels.release(); r->dLut.release(); r->dLights.release(); r->dCdf.release();
-        for (auto& b : r->dRay) b.release(); for (auto& b : r->dSh) b.release(); for (auto& b : r->dGbuf) b.release(); for (auto& b : r->dProbe) b.release(); for (auto& b : r->dRes) b.release(); for (auto& b : r->dResC) b.release();
+        for (auto& b : r->dRay) b.release(); for (auto& b : r->dSh) b.release(); for (auto& b : r->dSh2) b.release(); for (auto& b : r->dGbuf) b.release(); for (auto& b : r->dProbe) b.release(); for (auto& b : r->dRes) b.release(); for (auto& b : r->dResC) b.release();
         r->dDirect.release(); r->dIndirect.release(); r->dCombined.release(); r->dHits.release(); r->dMotion.release(); r->dCounters.release(); r->dOutput.release(); r->dBags.release();
         for (auto& e : r->evPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     }
