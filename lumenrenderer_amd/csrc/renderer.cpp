@@ -86,7 +86,10 @@ struct lumen_mi_renderer {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;              // second stream: the indirect waves run beside ReSTIR (both depend only on the depth-0 G-buffer)
-    hipEvent_t evFork = nullptr, evJoin = nullptr;
+    hipStream_t aux2 = nullptr;             // third stream: NEE shadow rays of wave d run beside the closest-hit launch of wave d+1
+    hipEvent_t evFork = nullptr, evJoin = nullptr, evJoin2 = nullptr;
+    std::vector<hipEvent_t> evShade;        // per wave: shade_wave(d) done
+    int auxPriority = 1;                    // 1: highest priority for the aux streams, 0: default
     bool overlap = true;
     int traceBlocksMain = 8, traceBlocksAux = 8;
     int numCU = 256;
@@ -263,7 +266,7 @@ int flatten(R* r)
         return fail(LUMEN_MI_ERR_DEVICE, "scene upload failed (hipMalloc/hipMemcpy)");
     if (hipStreamSynchronize(st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "scene upload sync failed");
     for (int k = 0; k < 3; k++) { r->dscene.qmin[k] = r->bvh.qmin[k]; r->dscene.qstep[k] = r->bvh.qstep[k]; }
-    if (r->dSpill.ensure((size_t)2 * r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS)))      // one area per stream return fail(LUMEN_MI_ERR_DEVICE, "stack spill allocation failed");
+    if (r->dSpill.ensure((size_t)3 * r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS)))      // one area per stream return fail(LUMEN_MI_ERR_DEVICE, "stack spill allocation failed");
     r->dscene.spill = r->dSpill.p;
     r->dscene.nodes = r->dNodes.p; r->dscene.woop = r->dWoop.p; r->dscene.triId = r->dTriId.p; r->dscene.triOrder = r->dTriOrder.p;
     r->dscene.verts = r->dVerts.p; r->dscene.indices = r->dIndices.p; r->dscene.entries = r->dEntries.p;
@@ -573,18 +576,25 @@ int traceFrameAsync(R* r)
             evBegin2(r, 0, ev, sx);
             K->trace_closest(sx, gridAux, scx, fr.rayO[q], fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters, r->refillBelow);
             evEnd2(r, ev, sx);
+            if (overlap && depth > 1) LM_HIP(hipStreamWaitEvent(sx, r->evJoin2, 0));      // previous wave's shadow rays consumed
             evBegin2(r, 2, ev, sx);
             K->shade_wave(sx, r->numCU * 2, scx, fr, q, inCount, seed, seed2, doIndirect, outCount, shCount);
             evEnd2(r, ev, sx);
-            evBegin2(r, 1, ev, sx);
-            K->trace_shadow(sx, gridAux, scx, fr, shCount, 0.01f, r->refillBelow);     // tmin of the intersection launch (:843)
-            evEnd2(r, ev, sx);
+            // NEE shadow rays of this wave: third stream, beside the next wave's closest-hit launch.  The shadow queue is
+            // rewritten by the NEXT shade_wave, which therefore waits for this launch (evShade / stream order below).
+            hipStream_t ss = overlap ? r->aux2 : sx;
+            LmScene scs = scx;
+            if (overlap) { scs.spill += (size_t)r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS); LM_HIP(hipEventRecord(r->evShade[depth], sx)); LM_HIP(hipStreamWaitEvent(ss, r->evShade[depth], 0)); }
+            evBegin2(r, 1, ev, ss);
+            K->trace_shadow(ss, gridAux, scs, fr, shCount, 0.01f, r->refillBelow);     // tmin of the intersection launch (:843)
+            evEnd2(r, ev, ss);
+            if (overlap) { LM_HIP(hipEventRecord(r->evJoin2, ss)); }
         }
         q ^= 1;
         r->swapChainIndex = r->swapChainIndex + 1 >= 2 ? 0 : r->swapChainIndex + 1;         // ReSTIR::SwapBuffers once per wave (:827)
         seed = wangHash(seed);                                                               // :830
     }
-    if (overlap) { LM_HIP(hipEventRecord(r->evJoin, sx)); LM_HIP(hipStreamWaitEvent(st, r->evJoin, 0)); }
+    if (overlap) { LM_HIP(hipEventRecord(r->evJoin, sx)); LM_HIP(hipStreamWaitEvent(st, r->evJoin, 0)); if (depthMax > 1) LM_HIP(hipStreamWaitEvent(st, r->evJoin2, 0)); }
     K->merge(st, r->gridFor(fr.n, 8), fr, blend ? 1 : 0, r->blendCounter);
     evEnd(r, evAll);
     LM_HIP(hipGetLastError());
@@ -660,8 +670,15 @@ int lumen_mi_init(lumen_mi_renderer* r, const lumen_mi_settings* s)
     if (const char* e = getenv("LUMEN_MI_SINGLE_STREAM")) r->overlap = atoi(e) == 0;
     if (const char* e = getenv("LUMEN_MI_TRACE_BLOCKS_MAIN")) r->traceBlocksMain = std::max(1, std::min(8, atoi(e)));
     if (const char* e = getenv("LUMEN_MI_TRACE_BLOCKS_AUX")) r->traceBlocksAux = std::max(1, std::min(8, atoi(e)));
+    if (const char* e = getenv("LUMEN_MI_AUX_PRIORITY")) r->auxPriority = atoi(e);
     if (!r->aux) {
-        LM_HIP(hipStreamCreateWithFlags(&r->aux, hipStreamNonBlocking));
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);         // numerically lower = higher priority
+        LM_HIP(hipStreamCreateWithPriority(&r->aux, hipStreamNonBlocking, r->auxPriority ? hi : lo));
+        LM_HIP(hipStreamCreateWithPriority(&r->aux2, hipStreamNonBlocking, r->auxPriority ? hi : lo));
+        LM_HIP(hipEventCreateWithFlags(&r->evJoin2, hipEventDisableTiming));
+        r->evShade.resize(LM_MAX_DEPTH + 1);
+        for (auto& e : r->evShade) LM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         LM_HIP(hipEventCreateWithFlags(&r->evFork, hipEventDisableTiming));
         LM_HIP(hipEventCreateWithFlags(&r->evJoin, hipEventDisableTiming));
     }
@@ -676,7 +693,7 @@ int lumen_mi_destroy(lumen_mi_renderer* r)
     if (r->initialised) {
         (void)hipSetDevice(r->device);
         (void)hipStreamSynchronize(r->stream);
-        if (r->aux) { (void)hipStreamSynchronize(r->aux); (void)hipStreamDestroy(r->aux); (void)hipEventDestroy(r->evFork); (void)hipEventDestroy(r->evJoin); }
+        if (r->aux) { (void)hipStreamSynchronize(r->aux); (void)hipStreamSynchronize(r->aux2); (void)hipStreamDestroy(r->aux2); (void)hipEventDestroy(r->evJoin2); for (auto& e : r->evShade) (void)hipEventDestroy(e); (void)hipStreamDestroy(r->aux); (void)hipEventDestroy(r->evFork); (void)hipEventDestroy(r->evJoin); }
         r->dSpill.release(); r->dNodes.release(); r->dWoop.release(); r->dTriId.release(); r->dTriOrder.release(); r->dVerts.release(); r->dIndices.release();
         r->dEntries.release(); r->dMaterials.release(); r->dTexDesc.release(); r->dTexels.release(); r->dLut.release(); r->dLights.release(); r->dCdf.release();
         for (auto& b : r->dRay) b.release(); for (auto& b : r->dSh) b.release(); for (auto& b : r->dSh2) b.release(); for (auto& b : r->dGbuf) b.release(); for (auto& b : r->dProbe) b.release(); for (auto& b : r->dRes) b.release(); for (auto& b : r->dResC) b.release();

@@ -9,7 +9,6 @@ cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --
 cd $R
 f=$(find gpurun_out/$tag/prof -name "*kernel_stats.csv" | head -1)
 cp "$f" gpurun_out/$tag/kernel_stats.csv 2>/dev/null
-rm -rf gpurun_out/$tag/prof/*/*kernel_trace.csv
 cat gpurun_out/$tag/pytest.log
 python3 - <<PY
 import json,csv
@@ -19,4 +18,16 @@ try:
 except Exception as e: print("bench parse failed",e, open("gpurun_out/$tag/bench.err").read()[-2000:])
 rows=[r for r in csv.DictReader(open("gpurun_out/$tag/kernel_stats.csv")) if not r["Name"].endswith("_inst")]
 for r in rows[:14]: print(f'{r["Name"][:34]:34s} calls {r["Calls"]:>4s} avg_us {float(r["AverageNs"])/1e3:9.1f} pct {r["Percentage"]}')
+import glob
+tf=glob.glob("gpurun_out/$tag/prof/*/*kernel_trace.csv")
+if tf:
+    tr=list(csv.DictReader(open(tf[0])))
+    tr=[r for r in tr if r["Kernel_Name"].startswith("lm_k") and not r["Kernel_Name"].endswith("_inst")]
+    tr.sort(key=lambda r:int(r["Start_Timestamp"]))
+    s=[i for i,r in enumerate(tr) if r["Kernel_Name"]=="lm_k_primary"][-1]
+    t0=int(tr[s]["Start_Timestamp"])
+    print("--- timeline of the last TraceFrame (start_us dur_us stream kernel)")
+    for r in tr[s:]:
+        print(f'{(int(r["Start_Timestamp"])-t0)/1e3:9.1f} {(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3:8.1f} q{r["Queue_Id"]} {r["Kernel_Name"]}')
 PY
+rm -rf gpurun_out/$tag/prof
