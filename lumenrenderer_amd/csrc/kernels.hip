@@ -715,17 +715,17 @@ KN(lm_k_shade_indirect0)(LmFrame fr, int cur, uint32_t seed2, int outQ, uint32_t
 }
 
 // depth >= 1: extraction + NEE + continuation fused (no SurfaceData round trip through HBM)
-extern "C" __global__ void __launch_bounds__(1024)
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
 KN(lm_k_shade_wave)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict__ inCount, uint32_t seed, uint32_t seed2, int doIndirect,
                 uint32_t* outCount, uint32_t* shadowCount)
 {
-    __shared__ uint32_t s_tmp[17];
+    __shared__ uint32_t s_tmp[5];
     const uint32_t n = *inCount;
-    const uint32_t stride = gridDim.x * 1024u;
+    const uint32_t stride = gridDim.x * LM_BLOCK;
     const uint32_t nIter = (n + stride - 1u) / stride;
     const int outQ = inQ ^ 1;
     for (uint32_t it = 0; it < nIter; it++) {
-        const uint32_t i = it * stride + blockIdx.x * 1024u + threadIdx.x;
+        const uint32_t i = it * stride + blockIdx.x * LM_BLOCK + threadIdx.x;
         bool emitShadow = false, emitRay = false;
         lf3 sdir = v3(0.f), srad = v3(0.f), o = v3(0.f), d = v3(0.f), c = v3(0.f), spos = v3(0.f);
         float stmax = 0.f;
@@ -1212,7 +1212,7 @@ static void l_trace_closest(hipStream_t s, int g, LmScene sc, const float4* o, c
 static void l_extract0(hipStream_t s, int g, LmScene sc, LmFrame fr, LmCamera cam, int cur) { hipLaunchKernelGGL(KN(lm_k_extract0), LM_GRID(g), sc, fr, cam, cur); }
 static void l_shade_indirect0(hipStream_t s, int g, LmFrame fr, int cur, uint32_t seed2, int outQ, uint32_t* outCount) { hipLaunchKernelGGL(KN(lm_k_shade_indirect0), dim3((unsigned)g), dim3(1024), 0, s, fr, cur, seed2, outQ, outCount); }
 static void l_shade_wave(hipStream_t s, int g, LmScene sc, LmFrame fr, int inQ, const uint32_t* inCount, uint32_t seed, uint32_t seed2, int doIndirect, uint32_t* outCount, uint32_t* shadowCount)
-{ hipLaunchKernelGGL(KN(lm_k_shade_wave), dim3((unsigned)g), dim3(1024), 0, s, sc, fr, inQ, inCount, seed, seed2, doIndirect, outCount, shadowCount); }
+{ hipLaunchKernelGGL(KN(lm_k_shade_wave), LM_GRID(g), sc, fr, inQ, inCount, seed, seed2, doIndirect, outCount, shadowCount); }
 static void l_trace_shadow(hipStream_t s, int g, LmScene sc, LmFrame fr, const uint32_t* cnt, float tmin, int refillBelow) { hipLaunchKernelGGL(KN(lm_k_trace_shadow), LM_GRID(g), sc, fr, cnt, tmin, refillBelow); }
 static void l_fill_bags(hipStream_t s, LmScene sc, LmFrame fr, uint32_t seed, uint32_t total) { hipLaunchKernelGGL(KN(lm_k_fill_bags), LM_GRID((total + LM_BLOCK - 1) / LM_BLOCK), sc, fr, seed, total); }
 static void l_pick_primary(hipStream_t s, int tiles, LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_pick_primary), LM_GRID(tiles), sc, fr, cur, rc, seed); }

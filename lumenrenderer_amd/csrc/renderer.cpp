@@ -548,6 +548,9 @@ int traceFrameAsync(R* r)
             evBegin(r, 2, ev);
             K->extract0(st, r->gridFor(fr.n, 8), r->dscene, fr, cam, currentIndex);
             evEnd(r, ev);
+            // path continuation of depth 0 first (0.24 ms alone; its 1024-thread blocks starve when co-scheduled with ReSTIR),
+            // then fork: the indirect waves run beside ReSTIR, both depend only on the G-buffer
+            if (doIndirect) { evBegin(r, 2, ev); K->shade_indirect0(st, tiles32, fr, currentIndex, seed2, q ^ 1, outCount); evEnd(r, ev); }
             if (overlap) { LM_HIP(hipEventRecord(r->evFork, st)); LM_HIP(hipStreamWaitEvent(sx, r->evFork, 0)); }
             // ReSTIR::Run (Framework/ReSTIR.cpp:65-233) — stays on the main stream
             evBegin(r, 3, ev);
@@ -569,8 +572,6 @@ int traceFrameAsync(R* r)
             K->trace_shade(st, gridMain, r->dscene, fr, cur, fr.counters + LM_CNT_RESTIR(1), r->refillVisibility);
             K->combine(st, tiles, fr, currentIndex, cur, 3, wangHash(rs));
             evEnd(r, ev);
-            // path continuation: depends only on the G-buffer, runs beside ReSTIR on the second stream
-            if (doIndirect) { evBegin2(r, 2, ev, sx); K->shade_indirect0(sx, tiles32, fr, currentIndex, seed2, q ^ 1, outCount); evEnd2(r, ev, sx); }
         } else {
             uint32_t* shCount = fr.counters + LM_CNT_SHADOW(depth);
             evBegin2(r, 0, ev, sx);
@@ -578,7 +579,7 @@ int traceFrameAsync(R* r)
             evEnd2(r, ev, sx);
             if (overlap && depth > 1) LM_HIP(hipStreamWaitEvent(sx, r->evJoin2, 0));      // previous wave's shadow rays consumed
             evBegin2(r, 2, ev, sx);
-            K->shade_wave(sx, r->numCU * 2, scx, fr, q, inCount, seed, seed2, doIndirect, outCount, shCount);
+            K->shade_wave(sx, r->numCU * 8, scx, fr, q, inCount, seed, seed2, doIndirect, outCount, shCount);
             evEnd2(r, ev, sx);
             // NEE shadow rays of this wave: third stream, beside the next wave's closest-hit launch.  The shadow queue is
             // rewritten by the NEXT shade_wave, which therefore waits for this launch (evShade / stream order below).
