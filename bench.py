@@ -41,6 +41,34 @@ def algorithmic_bytes_closest(rays, nodes, tris):
     return 56.0 * rays + 64.0 * nodes + 48.0 * tris
 
 
+def algorithmic_bytes_traceframe(c, depth, npix, nodes_all, tris_all, blend=True):
+    """SURVEY.md §8 d4, whole TraceFrame: the fixed per-event accounting of the reference's data flow (AoS-equivalent minimum
+    traffic), independent of how many bytes this implementation really moves.  c = lumen_mi_get_counters()."""
+    waves = [c[4 + d] for d in range(depth)]
+    closest, shadow, restir = c[0], c[1], c[2]
+    b = 40.0 * npix                                         # primary generation
+    b += 56.0 * closest + 420.0 * closest                   # closest-hit launches + surface extraction (one per traced ray)
+    live = sum(waves[:max(0, depth - 1)])                   # path vertices that go through ShadeIndirect (depth < maxDepth-1)
+    emitted = sum(waves[1:depth])
+    b += 176.0 * live + 40.0 * emitted                      # ShadeIndirect: read 176, write 40 when the path survives
+    b += 300.0 * sum(waves[1:depth])                        # ShadeDirect at depth >= 1
+    b += 64.0 * shadow                                      # NEE shadow launches
+    b += 5196.0 * npix + 180.0 * npix                       # ReSTIR passes + motion vectors
+    b += (48.0 if blend else 40.0) * npix                   # merge
+    b += 64.0 * nodes_all + 48.0 * tris_all                 # traversal of every ray type (measured node / triangle visits)
+    return b
+
+
+def load_traffic():
+    """HBM bytes per launch from PMC counters (separate rocprofv3 --pmc passes, tools_traffic.sh); None when not measured."""
+    path = os.path.join(ROOT, "profiles", "r01_c2_hbm_traffic_pmc.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except OSError:
+        return None
+
+
 def cpu_baseline(kind, kw, depth, spp, full):
     """The CPU oracle ("port") timed on this box's host cores on a bounded sample of the same workload: the same scene,
     `spp` blended frames, at the largest of a few resolutions expected to need <= ~25 s (probed at 480x270 first).
@@ -178,6 +206,9 @@ def main():
         launches_per_tf = closest_launches / n_traceframes
         per_launch_ms = closest_ms / max(1, closest_launches)
         achieved = (alg / max(1.0, launches_per_tf)) / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        traffic = load_traffic() if args.workload == "c2" and world == 1 else None
+        traffic_closest = traffic.get("lm_k_trace_closest", {}).get("hbm_bytes_per_launch_corrected") if traffic else None
+        alg_tf = algorithmic_bytes_traceframe(c, depth, (win[2] - win[0]) * (win[3] - win[1]), ci[20], ci[21])
         out = {
             "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -185,9 +216,12 @@ def main():
             "config": {"workload": f"{args.workload}: {kind} stand-in, {W}x{H}, {spp} spp (blended TraceFrames), depth {depth}, ReSTIR DI on",
                        "triangles": desc.triangle_count(), "rays_per_frame": int(rays_per_frame), "ms_per_frame": round(ms_per_step, 4),
                        "tiles": f"{tiles.grid_for(world, W, H)[0]}x{tiles.grid_for(world, W, H)[1]} + {tiles.HALO}px halo" if world > 1 else "1x1",
-                       "nodes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2)},
+                       "nodes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2),
+                       "rays_per_wave": [int(c[4 + d]) for d in range(depth)], "nee_shadow_rays": int(c[1]), "restir_shadow_rays": int(c[2]),
+                       "algorithmic_bytes_per_traceframe": int(alg_tf),
+                       "hbm_fraction_by_algorithmic_bytes": round(alg_tf * spp / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9), 4) if world == 1 else None},
             "roofline": {"bound": "hbm", "kernel": "lm_k_trace_closest", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic_closest,
                          "launch_ms": round(per_launch_ms, 4), "launches_per_traceframe": launches_per_tf,
                          "algorithmic_bytes_per_launch": int(alg / max(1.0, launches_per_tf))},
             "device_ms_per_traceframe": {"closest": round(closest_ms / n_traceframes, 3), "shadow": round(shadow_ms / n_traceframes, 3),

@@ -11,6 +11,9 @@
 #include "lm_bsdf.h"
 
 #define LM_BLOCK 256
+#ifndef LM_RESTIR_WAVES
+#define LM_RESTIR_WAVES 1        // __launch_bounds__ minimum waves per SIMD for the ALU-heavy ReSTIR kernels (tuning knob)
+#endif
 #ifndef LM_INSTRUMENT
 #define LM_INSTRUMENT 0
 #endif
@@ -918,7 +921,7 @@ KN(lm_k_fill_bags)(LmScene sc, LmFrame fr, uint32_t seed, uint32_t total)
 // K21 PickPrimarySamples — ReSTIRKernels.cu:402-522.  One 16x16 pixel tile (aligned to the GLOBAL 16x16 grid) shares a light
 // bag (the reference keys the bag on the hardware SM id, which is not reproducible: DESIGN.md decision D2); the bag's 1000
 // (index, pdf) pairs are staged in LDS once per tile.
-extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
 KN(lm_k_pick_primary)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed)
 {
     __shared__ uint2 s_bag[1000];
@@ -963,7 +966,7 @@ KN(lm_k_pick_primary)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed)
 }
 
 // K24 temporal reuse — ReSTIRKernels.cu:1015-1121
-extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
 KN(lm_k_restir_temporal)(LmFrame fr, int cur, int prev, int rc, int rp, uint32_t seed)
 {
     uint32_t li = 0, gi = 0;
@@ -1002,7 +1005,7 @@ KN(lm_k_restir_temporal)(LmFrame fr, int cur, int prev, int rc, int rp, uint32_t
 // K25 spatial reuse — ReSTIRKernels.cu:787-980 (biased branch).  The five candidate probes are issued together (one
 // 16-byte gather each from the probe plane) and the accepted candidates' 64-byte reservoir records are fetched one
 // iteration ahead of their re-evaluation, so the kernel is not a chain of dependent L2 round trips.
-extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
 KN(lm_k_restir_spatial)(LmFrame fr, int cur, int rin, int rout, uint32_t seed)
 {
     uint32_t li = 0, gi = 0;
@@ -1065,7 +1068,7 @@ KN(lm_k_restir_spatial)(LmFrame fr, int cur, int rin, int rout, uint32_t seed)
 }
 
 // K26 CombineReservoirBuffers — ReSTIRKernels.cu:1407-1436
-extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
 KN(lm_k_restir_combine)(LmFrame fr, int cur, int rc, int rs, uint32_t seed)
 {
     uint32_t li = 0, gi = 0;
