@@ -809,15 +809,17 @@ KN(lm_k_restir_gen_rays)(LmFrame fr, int cur, int rc, uint32_t* outCount)
 // K6 + K23: resolve the visibility rays (tmin 0.1, WaveFrontShaders.cu:181-216: occluded => reservoir weight = 0) and shade
 // the surviving reservoirs into DIRECT with weight / 3 (ReSTIRKernels.cu:600-665)
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
-KN(lm_k_restir_trace_shade)(LmScene sc, LmFrame fr, int rc, const uint32_t* __restrict__ countPtr, int refillBelow)
+KN(lm_k_restir_trace_shade)(LmScene sc, LmFrame fr, int rc, const uint32_t* __restrict__ countPtr, int refillBelow, int pass)
 {
     __shared__ int s_stack[LM_STACK_LDS * LM_BLOCK];
     const uint32_t n = *countPtr;
     float4* hot = fr.res[rc];
+    const float4* __restrict__ qO = pass ? fr.vis2O : fr.visO;
+    const float4* __restrict__ qD = pass ? fr.vis2D : fr.visD;
     lm_trace_queue<true>(sc, n, refillBelow, lm_make_stack(s_stack, sc), fr.counters,
-        [&](uint32_t i, lf3& o, lf3& d, float& t0, float& t1) { const float4 o4 = fr.visO[i]; o = v3(o4); d = v3(fr.visD[i]); t0 = 0.1f; t1 = o4.w; },
+        [&](uint32_t i, lf3& o, lf3& d, float& t0, float& t1) { const float4 o4 = qO[i]; o = v3(o4); d = v3(qD[i]); t0 = 0.1f; t1 = o4.w; },
         [&](uint32_t i, bool occluded, const LmHit&) {
-            const uint32_t li = f2u(fr.visD[i].w);
+            const uint32_t li = f2u(qD[i].w);
             float4 r0 = hot[4u * li];
             if (occluded) { r0.y = 0.f; hot[4u * li] = r0; }
             else {
@@ -922,9 +924,10 @@ KN(lm_k_fill_bags)(LmScene sc, LmFrame fr, uint32_t seed, uint32_t total)
 // bag (the reference keys the bag on the hardware SM id, which is not reproducible: DESIGN.md decision D2); the bag's 1000
 // (index, pdf) pairs are staged in LDS once per tile.
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
-KN(lm_k_pick_primary)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed)
+KN(lm_k_pick_primary)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount)
 {
     __shared__ uint2 s_bag[1000];
+    __shared__ uint32_t s_tmp[5];
     const uint32_t tilesX = (fr.W + 15u) / 16u;
     const uint32_t tx0 = fr.x0 / 16u, ty0 = fr.y0 / 16u;
     const uint32_t wtx = (fr.x0 + fr.ww + 15u) / 16u - tx0;
@@ -935,71 +938,119 @@ KN(lm_k_pick_primary)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed)
     for (uint32_t k = threadIdx.x; k < 1000u; k += LM_BLOCK) s_bag[k] = fr.bags[(uint32_t)bagIndex * 1000u + k];
     __syncthreads();
     const uint32_t px = tileX * 16u + (threadIdx.x & 15u), py = tileY * 16u + (threadIdx.x >> 4);
-    if (px < fr.x0 || py < fr.y0 || px >= fr.x0 + fr.ww || py >= fr.y0 + fr.wh) return;
-    const uint32_t li = (py - fr.y0) * fr.ww + (px - fr.x0);
-    const uint32_t gi = py * fr.W + px;
-    float4* hot = fr.res[rc];
-    LmSurface pixel;
-    lm_gbuf_load(fr.gbuf[cur], li, pixel);
-    if (pixel.flags) { float4 a = hot[4u * li]; a.y = 0.f; hot[4u * li] = a; return; }
-    uint32_t s = lm_wang_hash(seed + lm_wang_hash(gi));
-    LmReservoir fresh; lm_res_fresh(fresh);
-    for (int smp = 0; smp < 32; smp++) {
-        const float r = lm_random_float(s);
-        const int pick = (int)roundf((float)(1000 - 1) * r);
-        const uint2 entry = s_bag[pick];
-        const LmTriLight light = lm_load_light(sc.lights, entry.x);
-        const float initialPdf = u2f(entry.y);
-        const float u = lm_random_float(s);
-        const float v = lm_random_float(s) * (1.f - u);
-        LmSample ls; lm_sample_zero(ls);
-        ls.radiance = light.radiance; ls.normal = light.normal; ls.area = light.area;
-        const lf3 arm1 = light.p1 - light.p0, arm2 = light.p2 - light.p0;
-        ls.position = light.p0 + (arm1 * u) + (arm2 * v);
-        LmSample rs;
-        lm_resample(ls, pixel, rs);
-        const float pdf = rs.pdf / initialPdf;
-        lm_res_update(fresh, rs, pdf, s);
+    const bool inside = !(px < fr.x0 || py < fr.y0 || px >= fr.x0 + fr.ww || py >= fr.y0 + fr.wh);
+    uint32_t li = 0;
+    bool shoot = false;
+    lf3 vpos = v3(0.f), vdir = v3(0.f);
+    float vlen = 0.f;
+    if (inside) {
+        li = (py - fr.y0) * fr.ww + (px - fr.x0);
+        const uint32_t gi = py * fr.W + px;
+        float4* hot = fr.res[rc];
+        LmSurface pixel;
+        lm_gbuf_load(fr.gbuf[cur], li, pixel);
+        if (pixel.flags) { float4 a = hot[4u * li]; a.y = 0.f; hot[4u * li] = a; }
+        else {
+            uint32_t s = lm_wang_hash(seed + lm_wang_hash(gi));
+            LmReservoir fresh; lm_res_fresh(fresh);
+            for (int smp = 0; smp < 32; smp++) {
+                const float r = lm_random_float(s);
+                const int pick = (int)roundf((float)(1000 - 1) * r);
+                const uint2 entry = s_bag[pick];
+                const LmTriLight light = lm_load_light(sc.lights, entry.x);
+                const float initialPdf = u2f(entry.y);
+                const float u = lm_random_float(s);
+                const float v = lm_random_float(s) * (1.f - u);
+                LmSample ls; lm_sample_zero(ls);
+                ls.radiance = light.radiance; ls.normal = light.normal; ls.area = light.area;
+                const lf3 arm1 = light.p1 - light.p0, arm2 = light.p2 - light.p0;
+                ls.position = light.p0 + (arm1 * u) + (arm2 * v);
+                LmSample rs;
+                lm_resample(ls, pixel, rs);
+                const float pdf = rs.pdf / initialPdf;
+                lm_res_update(fresh, rs, pdf, s);
+            }
+            lm_res_update_weight(fresh);
+            lm_res_store(hot, fr.resC[rc], li, fresh);
+            // K22 GenerateShadowRay fused (ReSTIRKernels.cu:546-582): the visibility ray of the fresh reservoir
+            if (fresh.weight > 0.f) {
+                vpos = pixel.position;
+                vdir = fresh.s.position - vpos;
+                vlen = length3(vdir);
+                vdir = vdir / vlen;
+                shoot = true;
+            }
+        }
     }
-    lm_res_update_weight(fresh);
-    lm_res_store(hot, fr.resC[rc], li, fresh);
+    const uint32_t slot = lm_append_slot_block(visCount, shoot, s_tmp);
+    if (shoot) {
+        fr.visO[slot] = v4(vpos, vlen - 0.05f);
+        fr.visD[slot] = v4(vdir, u2f(li));
+    }
 }
 
 // K24 temporal reuse — ReSTIRKernels.cu:1015-1121
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
-KN(lm_k_restir_temporal)(LmFrame fr, int cur, int prev, int rc, int rp, uint32_t seed)
+KN(lm_k_restir_temporal)(LmFrame fr, int cur, int prev, int rc, int rp, uint32_t seed, uint32_t* visCount)
 {
+    __shared__ uint32_t s_tmp[5];
     uint32_t li = 0, gi = 0;
-    if (!lm_tile_pixel(fr, li, gi)) return;
-    const int ly = (int)(li / fr.ww), lx = (int)(li - (uint32_t)ly * fr.ww);
-    const uint32_t mv = fr.motion[li];
-    const float vx = lm_f16_to_f32(mv & 0xffffu), vy = lm_f16_to_f32(mv >> 16);
-    const int movedX = (int)roundf((float)fr.W * vx), movedY = (int)roundf((float)fr.H * vy);
-    const int ty = ly + movedY, tx = lx + movedX;
-    uint32_t tli = li;
-    if (ty >= 0 && ty < (int)fr.wh && tx >= 0 && tx < (int)fr.ww) tli = (uint32_t)ty * fr.ww + (uint32_t)tx;
-    const float4 pn = fr.probe[prev][tli], cn = fr.probe[cur][li];
-    if (pn.w < 0.f || cn.w < 0.f) return;                      // flagged surface on either side
-    const float d1 = pn.w, d2 = cn.w;
-    const float depthDif = fabsf(d1 - d2) / ((d1 + d2) / 2.f);
-    const float angle = dot3(v3(pn), v3(cn));
-    if (!(depthDif < 0.10f && angle > 0.72222222223f)) return;
-    LmReservoir rpv, rcv;
-    lm_res_load(fr.res[rp], fr.resC[rp], tli, rpv);
-    lm_res_load(fr.res[rc], fr.resC[rc], li, rcv);
-    if (rpv.weight > 0.f) {                                     // ShadeReservoirs on the PREVIOUS reservoir
-        const lf3 add = rpv.s.contribution * (rpv.weight / 3.f);
-        float4 px = fr.direct[li];
-        px.x += add.x; px.y += add.y; px.z += add.z;
-        fr.direct[li] = px;
+    const bool valid = lm_tile_pixel(fr, li, gi);
+    bool shoot = false;
+    lf3 vpos = v3(0.f), vtarget = v3(1.f);
+    if (valid) {
+        const float4 cn = fr.probe[cur][li];
+        if (cn.w >= 0.f) {                                         // unflagged current surface
+            const int ly = (int)(li / fr.ww), lx = (int)(li - (uint32_t)ly * fr.ww);
+            const uint32_t mv = fr.motion[li];
+            const float vx = lm_f16_to_f32(mv & 0xffffu), vy = lm_f16_to_f32(mv >> 16);
+            const int movedX = (int)roundf((float)fr.W * vx), movedY = (int)roundf((float)fr.H * vy);
+            const int ty = ly + movedY, tx = lx + movedX;
+            uint32_t tli = li;
+            if (ty >= 0 && ty < (int)fr.wh && tx >= 0 && tx < (int)fr.ww) tli = (uint32_t)ty * fr.ww + (uint32_t)tx;
+            const float4 pn = fr.probe[prev][tli];
+            bool merged = false;
+            float weight = 0.f;
+            if (pn.w >= 0.f) {
+                const float d1 = pn.w, d2 = cn.w;
+                const float depthDif = fabsf(d1 - d2) / ((d1 + d2) / 2.f);
+                const float angle = dot3(v3(pn), v3(cn));
+                if (depthDif < 0.10f && angle > 0.72222222223f) {
+                    LmReservoir rpv, rcv;
+                    lm_res_load(fr.res[rp], fr.resC[rp], tli, rpv);
+                    lm_res_load(fr.res[rc], fr.resC[rc], li, rcv);
+                    if (rpv.weight > 0.f) {                        // ShadeReservoirs on the PREVIOUS reservoir
+                        const lf3 add = rpv.s.contribution * (rpv.weight / 3.f);
+                        float4 px = fr.direct[li];
+                        px.x += add.x; px.y += add.y; px.z += add.z;
+                        fr.direct[li] = px;
+                    }
+                    const long long cap = rcv.count * 20;
+                    if (cap < rpv.count) rpv.count = cap;
+                    LmSurface s;
+                    lm_gbuf_load(fr.gbuf[cur], li, s);
+                    LmReservoir out;
+                    lm_combine2(out, rpv, rcv, s, lm_wang_hash(seed + gi));
+                    lm_res_store(fr.res[rc], fr.resC[rc], li, out);
+                    merged = true; weight = out.weight; vtarget = out.s.position; vpos = s.position;
+                }
+            }
+            if (!merged) {
+                const float4* h = fr.res[rc] + 4u * li;
+                weight = h[0].y;
+                if (weight > 0.f) { vtarget = v3(h[3]); vpos = v3(fr.gbuf[cur][8u * li]); }
+            }
+            shoot = weight > 0.f;                                  // second GenerateShadowRay pass (ReSTIR.cpp:211), fused
+        }
     }
-    const long long cap = rcv.count * 20;
-    if (cap < rpv.count) rpv.count = cap;
-    LmSurface s;
-    lm_gbuf_load(fr.gbuf[cur], li, s);
-    LmReservoir out;
-    lm_combine2(out, rpv, rcv, s, lm_wang_hash(seed + gi));
-    lm_res_store(fr.res[rc], fr.resC[rc], li, out);
+    lf3 vdir = vtarget - vpos;
+    const float vlen = length3(vdir);
+    vdir = vdir / vlen;
+    const uint32_t slot = lm_append_slot_block(visCount, shoot, s_tmp);
+    if (shoot) {
+        fr.vis2O[slot] = v4(vpos, vlen - 0.05f);
+        fr.vis2D[slot] = v4(vdir, u2f(li));
+    }
 }
 
 // K25 spatial reuse — ReSTIRKernels.cu:787-980 (biased branch).  The five candidate probes are issued together (one
@@ -1218,10 +1269,10 @@ static void l_shade_wave(hipStream_t s, int g, LmScene sc, LmFrame fr, int inQ, 
 { hipLaunchKernelGGL(KN(lm_k_shade_wave), LM_GRID(g), sc, fr, inQ, inCount, seed, seed2, doIndirect, outCount, shadowCount); }
 static void l_trace_shadow(hipStream_t s, int g, LmScene sc, LmFrame fr, const uint32_t* cnt, float tmin, int refillBelow) { hipLaunchKernelGGL(KN(lm_k_trace_shadow), LM_GRID(g), sc, fr, cnt, tmin, refillBelow); }
 static void l_fill_bags(hipStream_t s, LmScene sc, LmFrame fr, uint32_t seed, uint32_t total) { hipLaunchKernelGGL(KN(lm_k_fill_bags), LM_GRID((total + LM_BLOCK - 1) / LM_BLOCK), sc, fr, seed, total); }
-static void l_pick_primary(hipStream_t s, int tiles, LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_pick_primary), LM_GRID(tiles), sc, fr, cur, rc, seed); }
+static void l_pick_primary(hipStream_t s, int tiles, LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount) { hipLaunchKernelGGL(KN(lm_k_pick_primary), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount); }
 static void l_gen_rays(hipStream_t s, int tiles, LmFrame fr, int cur, int rc, uint32_t* outCount) { hipLaunchKernelGGL(KN(lm_k_restir_gen_rays), dim3((unsigned)tiles), dim3(1024), 0, s, fr, cur, rc, outCount); }
-static void l_trace_shade(hipStream_t s, int g, LmScene sc, LmFrame fr, int rc, const uint32_t* cnt, int refillBelow) { hipLaunchKernelGGL(KN(lm_k_restir_trace_shade), LM_GRID(g), sc, fr, rc, cnt, refillBelow); }
-static void l_temporal(hipStream_t s, int g, LmFrame fr, int cur, int prev, int rc, int rp, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_restir_temporal), LM_GRID(g), fr, cur, prev, rc, rp, seed); }
+static void l_trace_shade(hipStream_t s, int g, LmScene sc, LmFrame fr, int rc, const uint32_t* cnt, int refillBelow, int pass) { hipLaunchKernelGGL(KN(lm_k_restir_trace_shade), LM_GRID(g), sc, fr, rc, cnt, refillBelow, pass); }
+static void l_temporal(hipStream_t s, int g, LmFrame fr, int cur, int prev, int rc, int rp, uint32_t seed, uint32_t* visCount) { hipLaunchKernelGGL(KN(lm_k_restir_temporal), LM_GRID(g), fr, cur, prev, rc, rp, seed, visCount); }
 static void l_spatial(hipStream_t s, int g, LmFrame fr, int cur, int rin, int rout, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_restir_spatial), LM_GRID(g), fr, cur, rin, rout, seed); }
 static void l_combine(hipStream_t s, int g, LmFrame fr, int cur, int rc, int rs, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_restir_combine), LM_GRID(g), fr, cur, rc, rs, seed); }
 static void l_clear(hipStream_t s, int g, float4* p, uint32_t n) { hipLaunchKernelGGL(KN(lm_k_clear_f4), LM_GRID(g), p, n); }

@@ -10,10 +10,10 @@ struct LmKernelTable {
     void (*shade_wave)(hipStream_t, int grid, LmScene, LmFrame, int inQ, const uint32_t* inCount, uint32_t seed, uint32_t seed2, int doIndirect, uint32_t* outCount, uint32_t* shadowCount);
     void (*trace_shadow)(hipStream_t, int grid, LmScene, LmFrame, const uint32_t* count, float tmin, int refillBelow);
     void (*fill_bags)(hipStream_t, LmScene, LmFrame, uint32_t seed, uint32_t total);
-    void (*pick_primary)(hipStream_t, int tiles, LmScene, LmFrame, int cur, int rc, uint32_t seed);
+    void (*pick_primary)(hipStream_t, int tiles, LmScene, LmFrame, int cur, int rc, uint32_t seed, uint32_t* visCount);
     void (*gen_rays)(hipStream_t, int tiles32, LmFrame, int cur, int rc, uint32_t* outCount);
-    void (*trace_shade)(hipStream_t, int grid, LmScene, LmFrame, int rc, const uint32_t* count, int refillBelow);
-    void (*temporal)(hipStream_t, int tiles, LmFrame, int cur, int prev, int rc, int rp, uint32_t seed);
+    void (*trace_shade)(hipStream_t, int grid, LmScene, LmFrame, int rc, const uint32_t* count, int refillBelow, int pass);
+    void (*temporal)(hipStream_t, int tiles, LmFrame, int cur, int prev, int rc, int rp, uint32_t seed, uint32_t* visCount);
     void (*spatial)(hipStream_t, int tiles, LmFrame, int cur, int rin, int rout, uint32_t seed);
     void (*combine)(hipStream_t, int tiles, LmFrame, int cur, int rc, int rs, uint32_t seed);
     void (*clear)(hipStream_t, int grid, float4* p, uint32_t n);

@@ -85,7 +85,8 @@ struct LmFrame {
     uint4* hits;                // entry, prim, half2 barycentrics, t bits
     // shadow-ray queue of the current wave: origin.xyz + tmax | dir.xyz + pixel | radiance.xyz
     float4 *shO, *shD, *shR;
-    float4 *visO, *visD;        // ReSTIR visibility-ray queue (own buffers: runs concurrently with the NEE shadow queue)
+    float4 *visO, *visD;        // ReSTIR visibility-ray queue, pass 1 (own buffers: runs concurrently with the NEE shadow queue)
+    float4 *vis2O, *vis2D;      // pass 2 (filled by the temporal kernel, traced beside the second spatial pass)
     // depth-0 surface data, two frames: one 128-byte record (8 float4) per pixel + a 16-byte reuse-probe plane (kernels.hip)
     float4* gbuf[2];
     float4* probe[2];

@@ -86,8 +86,9 @@ struct lumen_mi_renderer {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;              // second stream: the indirect waves run beside ReSTIR (both depend only on the depth-0 G-buffer)
+    hipStream_t aux3 = nullptr;             // fourth stream: second ReSTIR visibility pass beside the second spatial pass
     hipStream_t aux2 = nullptr;             // third stream: NEE shadow rays of wave d run beside the closest-hit launch of wave d+1
-    hipEvent_t evFork = nullptr, evJoin = nullptr, evJoin2 = nullptr;
+    hipEvent_t evFork = nullptr, evJoin = nullptr, evJoin2 = nullptr, evVis = nullptr, evVisDone = nullptr;
     std::vector<hipEvent_t> evShade;        // per wave: shade_wave(d) done
     int auxPriority = 1;                    // 1: highest priority for the aux streams, 0: default
     bool overlap = true;
@@ -141,7 +142,7 @@ struct lumen_mi_renderer {
     // device frame
     LmFrame fr{};
     uint32_t allocN = 0, allocDepth = 0;
-    DevBuf<float4> dRay[6], dSh[3], dSh2[2], dGbuf[2], dProbe[2], dRes[4], dResC[4], dDirect, dIndirect, dCombined;
+    DevBuf<float4> dRay[6], dSh[3], dSh2[4], dGbuf[2], dProbe[2], dRes[4], dResC[4], dDirect, dIndirect, dCombined;
     DevBuf<uint4> dHits; DevBuf<uint32_t> dMotion, dCounters; DevBuf<uchar4> dOutput; DevBuf<uint2> dBags;
     uint32_t hostCounters[LM_CNT_WORDS] = {0};
     bool countersValid = false;
@@ -266,7 +267,7 @@ int flatten(R* r)
         return fail(LUMEN_MI_ERR_DEVICE, "scene upload failed (hipMalloc/hipMemcpy)");
     if (hipStreamSynchronize(st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "scene upload sync failed");
     for (int k = 0; k < 3; k++) { r->dscene.qmin[k] = r->bvh.qmin[k]; r->dscene.qstep[k] = r->bvh.qstep[k]; }
-    if (r->dSpill.ensure((size_t)3 * r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS)))      // one area per stream return fail(LUMEN_MI_ERR_DEVICE, "stack spill allocation failed");
+    if (r->dSpill.ensure((size_t)4 * r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS)))      // one area per stream return fail(LUMEN_MI_ERR_DEVICE, "stack spill allocation failed");
     r->dscene.spill = r->dSpill.p;
     r->dscene.nodes = r->dNodes.p; r->dscene.woop = r->dWoop.p; r->dscene.triId = r->dTriId.p; r->dscene.triOrder = r->dTriOrder.p;
     r->dscene.verts = r->dVerts.p; r->dscene.indices = r->dIndices.p; r->dscene.entries = r->dEntries.p;
@@ -412,7 +413,7 @@ int ensureFrameBuffers(R* r)
     int bad = 0;
     for (int i = 0; i < 6; i++) bad |= r->dRay[i].ensure(n);
     for (int i = 0; i < 3; i++) bad |= r->dSh[i].ensure(n);
-    for (int i = 0; i < 2; i++) bad |= r->dSh2[i].ensure(n);
+    for (int i = 0; i < 4; i++) bad |= r->dSh2[i].ensure(n);
     for (int i = 0; i < 2; i++) bad |= r->dGbuf[i].ensure((size_t)8 * n) | r->dProbe[i].ensure(n);
     for (int i = 0; i < 4; i++) bad |= r->dRes[i].ensure((size_t)4 * n) | r->dResC[i].ensure(n);
     bad |= r->dDirect.ensure(n) | r->dIndirect.ensure(n) | r->dCombined.ensure(n) | r->dHits.ensure(n) | r->dMotion.ensure(n) | r->dOutput.ensure(n);
@@ -420,7 +421,7 @@ int ensureFrameBuffers(R* r)
     if (bad) return fail(LUMEN_MI_ERR_DEVICE, "frame buffer allocation failed");
     for (int q = 0; q < 2; q++) { f.rayO[q] = r->dRay[3 * q].p; f.rayD[q] = r->dRay[3 * q + 1].p; f.rayC[q] = r->dRay[3 * q + 2].p; }
     f.shO = r->dSh[0].p; f.shD = r->dSh[1].p; f.shR = r->dSh[2].p;
-    f.visO = r->dSh2[0].p; f.visD = r->dSh2[1].p;
+    f.visO = r->dSh2[0].p; f.visD = r->dSh2[1].p; f.vis2O = r->dSh2[2].p; f.vis2D = r->dSh2[3].p;
     f.hits = r->dHits.p;
     for (int i = 0; i < 2; i++) { f.gbuf[i] = r->dGbuf[i].p; f.probe[i] = r->dProbe[i].p; }
     for (int i = 0; i < 4; i++) { f.res[i] = r->dRes[i].p; f.resC[i] = r->dResC[i].p; }
@@ -560,16 +561,24 @@ int traceFrameAsync(R* r)
             rs = wangHash(rs);
             const uint32_t tx0 = fr.x0 / 16u, ty0 = fr.y0 / 16u;
             const uint32_t wtx = (fr.x0 + fr.ww + 15u) / 16u - tx0, wty = (fr.y0 + fr.wh + 15u) / 16u - ty0;
-            K->pick_primary(st, (int)(wtx * wty), r->dscene, fr, currentIndex, cur, rs);
-            K->gen_rays(st, tiles32, fr, currentIndex, cur, fr.counters + LM_CNT_RESTIR(0));
-            K->trace_shade(st, gridMain, r->dscene, fr, cur, fr.counters + LM_CNT_RESTIR(0), r->refillVisibility);
+            K->pick_primary(st, (int)(wtx * wty), r->dscene, fr, currentIndex, cur, rs, fr.counters + LM_CNT_RESTIR(0));     // + visibility rays, pass 1
+            K->trace_shade(st, gridMain, r->dscene, fr, cur, fr.counters + LM_CNT_RESTIR(0), r->refillVisibility, 0);
             rs = wangHash(rs);
-            K->temporal(st, tiles, fr, currentIndex, temporalIndex, cur, tmp, rs);
+            K->temporal(st, tiles, fr, currentIndex, temporalIndex, cur, tmp, rs, fr.counters + LM_CNT_RESTIR(1));                // + visibility rays, pass 2
             rs = wangHash(rs);
             K->spatial(st, tiles, fr, currentIndex, cur, 2, rs);
+            // second visibility pass (ReSTIR.cpp:211-212) works on the CURRENT buffer, which the second spatial pass does not
+            // touch: trace it beside that pass.  (It must follow the first spatial pass, which reads the current buffer.)
+            hipStream_t sv = overlap ? r->aux3 : st;
+            LmScene scv = r->dscene;
+            if (overlap) {
+                scv.spill += (size_t)3 * r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS);
+                LM_HIP(hipEventRecord(r->evVis, st)); LM_HIP(hipStreamWaitEvent(sv, r->evVis, 0));
+            }
+            K->trace_shade(sv, gridMain, scv, fr, cur, fr.counters + LM_CNT_RESTIR(1), r->refillVisibility, 1);
+            if (overlap) LM_HIP(hipEventRecord(r->evVisDone, sv));
             K->spatial(st, tiles, fr, currentIndex, 2, 3, rs);
-            K->gen_rays(st, tiles32, fr, currentIndex, cur, fr.counters + LM_CNT_RESTIR(1));
-            K->trace_shade(st, gridMain, r->dscene, fr, cur, fr.counters + LM_CNT_RESTIR(1), r->refillVisibility);
+            if (overlap) LM_HIP(hipStreamWaitEvent(st, r->evVisDone, 0));
             K->combine(st, tiles, fr, currentIndex, cur, 3, wangHash(rs));
             evEnd(r, ev);
         } else {
@@ -677,7 +686,10 @@ int lumen_mi_init(lumen_mi_renderer* r, const lumen_mi_settings* s)
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);         // numerically lower = higher priority
         LM_HIP(hipStreamCreateWithPriority(&r->aux, hipStreamNonBlocking, r->auxPriority ? hi : lo));
         LM_HIP(hipStreamCreateWithPriority(&r->aux2, hipStreamNonBlocking, r->auxPriority ? hi : lo));
+        LM_HIP(hipStreamCreateWithPriority(&r->aux3, hipStreamNonBlocking, hi));
         LM_HIP(hipEventCreateWithFlags(&r->evJoin2, hipEventDisableTiming));
+        LM_HIP(hipEventCreateWithFlags(&r->evVis, hipEventDisableTiming));
+        LM_HIP(hipEventCreateWithFlags(&r->evVisDone, hipEventDisableTiming));
         r->evShade.resize(LM_MAX_DEPTH + 1);
         for (auto& e : r->evShade) LM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         LM_HIP(hipEventCreateWithFlags(&r->evFork, hipEventDisableTiming));
@@ -694,7 +706,7 @@ int lumen_mi_destroy(lumen_mi_renderer* r)
     if (r->initialised) {
         (void)hipSetDevice(r->device);
         (void)hipStreamSynchronize(r->stream);
-        if (r->aux) { (void)hipStreamSynchronize(r->aux); (void)hipStreamSynchronize(r->aux2); (void)hipStreamDestroy(r->aux2); (void)hipEventDestroy(r->evJoin2); for (auto& e : r->evShade) (void)hipEventDestroy(e); (void)hipStreamDestroy(r->aux); (void)hipEventDestroy(r->evFork); (void)hipEventDestroy(r->evJoin); }
+        if (r->aux) { (void)hipStreamSynchronize(r->aux); (void)hipStreamSynchronize(r->aux2); (void)hipStreamDestroy(r->aux2); (void)hipStreamSynchronize(r->aux3); (void)hipStreamDestroy(r->aux3); (void)hipEventDestroy(r->evVis); (void)hipEventDestroy(r->evVisDone); (void)hipEventDestroy(r->evJoin2); for (auto& e : r->evShade) (void)hipEventDestroy(e); (void)hipStreamDestroy(r->aux); (void)hipEventDestroy(r->evFork); (void)hipEventDestroy(r->evJoin); }
         r->dSpill.release(); r->dNodes.release(); r->dWoop.release(); r->dTriId.release(); r->dTriOrder.release(); r->dVerts.release(); r->dIndices.release();
         r->dEntries.release(); r->dMaterials.release(); r->dTexDesc.release(); r->dTexels.release(); r->dLut.release(); r->dLights.release(); r->dCdf.release();
         for (auto& b : r->dRay) b.release(); for (auto& b : r->dSh) b.release(); for (auto& b : r->dSh2) b.release(); for (auto& b : r->dGbuf) b.release(); for (auto& b : r->dProbe) b.release(); for (auto& b : r->dRes) b.release(); for (auto& b : r->dResC) b.release();
