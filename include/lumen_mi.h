@@ -126,7 +126,8 @@ int lumen_mi_get_gbuffer(lumen_mi_renderer*, float* planes8x4, size_t capacity_b
 /* FrameStats (LumenRenderer.h:29-34, GetLastFrameStats :203): key/value pairs in microseconds under the reference's key names */
 int lumen_mi_get_frame_stat(lumen_mi_renderer*, const char* key, uint64_t* microseconds);
 /* counters of the last completed frame: [0] closest-hit rays, [1] NEE shadow rays, [2] ReSTIR shadow rays, [3] lights,
- * [4..4+depth) rays per wave, [20] BVH nodes visited, [21] triangles tested (both only in the instrumented build) */
+ * [4..4+depth) rays per wave, [20] BVH nodes visited in binary-node equivalents (= [22] / 2), [21] triangles tested,
+ * [22] child boxes slab-tested by the 4-wide traversal ([20]..[22] only in the instrumented build) */
 int lumen_mi_get_counters(lumen_mi_renderer*, uint64_t* out, uint32_t n);
 /* device time of one kernel class, summed over every frame traced since timing was enabled, measured with HIP events
  * on the renderer's stream; `launches` = number of timed launches (class 4: number of frames).

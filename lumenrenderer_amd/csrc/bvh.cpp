@@ -50,7 +50,7 @@ struct Builder {
         for (uint32_t i = first; i < first + count; i++) { box.grow(tbox[ids[i]]); cbox.grow(&cen[3 * ids[i]]); }
         if (count <= 2) return makeLeaf(first, count, box);
         // depth guard: from here a median split is guaranteed to finish within the traversal stack
-        const bool forceMedian = (int)depth + ilog2ceil(count) + 2 >= LM_STACK_DEPTH - 2;
+        const bool forceMedian = (int)depth + ilog2ceil(count) + 2 >= LM_BVH2_MAX_DEPTH - 2;
         uint32_t mid = 0;
         bool split = false;
         if (!forceMedian) {
@@ -201,7 +201,6 @@ void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out)
         out->qmin[k] = smin[k];
         out->qstep[k] = (smax[k] - smin[k]) / 65535.0f;
     }
-    const int sentinelLeaf = ~(int)(((uint32_t)nSlots << 3) | 0u);
     auto quant = [&](float lo, float hi, int k, uint32_t& packed) {
         const double inv = 1.0 / (double)out->qstep[k];
         long long ql = (long long)std::floor(((double)lo - (double)out->qmin[k]) * inv) - 1;
@@ -209,19 +208,55 @@ void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out)
         ql = std::max(0LL, std::min(65535LL, ql)); qh = std::max(0LL, std::min(65535LL, qh));
         packed = (uint32_t)ql | ((uint32_t)qh << 16);
     };
-    out->qnodes.resize(out->nodes.size());
-    for (size_t i = 0; i < out->nodes.size(); i++) {
-        const LmNode& n = out->nodes[i];
-        LmNodeQ q;
+    // ---- collapse to 4-wide nodes: starting from a binary node's two children, repeatedly replace the inner child of
+    // largest surface area by its own two children until there are four (or only leaves are left)
+    struct Child { int ref; float b[6]; };      // padded box: lo.x hi.x lo.y hi.y lo.z hi.z
+    auto childrenOf = [&](int node, Child* c) {
+        const LmNode& n = out->nodes[node];
         const float c0[6] = {n.n0.x, n.n0.y, n.n0.z, n.n0.w, n.n2.x, n.n2.y}, c1[6] = {n.n1.x, n.n1.y, n.n1.z, n.n1.w, n.n2.z, n.n2.w};
-        uint32_t p0[3], p1[3];
-        const bool e0 = c0[0] != c0[0], e1 = c1[0] != c1[0];
-        for (int k = 0; k < 3; k++) {
-            if (e0) p0[k] = 0xffffffffu; else quant(c0[2 * k], c0[2 * k + 1], k, p0[k]);
-            if (e1) p1[k] = 0xffffffffu; else quant(c1[2 * k], c1[2 * k + 1], k, p1[k]);
+        int k = 0;
+        if (c0[0] == c0[0]) { c[k].ref = n.ref.x; memcpy(c[k].b, c0, sizeof c0); k++; }
+        if (c1[0] == c1[0]) { c[k].ref = n.ref.y; memcpy(c[k].b, c1, sizeof c1); k++; }
+        return k;
+    };
+    auto areaOf = [](const Child& c) { const float dx = c.b[1] - c.b[0], dy = c.b[3] - c.b[2], dz = c.b[5] - c.b[4]; return dx * dy + dy * dz + dz * dx; };
+    out->nodes4.clear();
+    out->nodes4.reserve(out->nodes.size() / 2 + 1);
+    out->maxStack = 1;
+    struct Work { int node2; int node4; uint32_t stack; };
+    std::vector<Work> work;
+    out->nodes4.emplace_back();
+    work.push_back({0, 0, 0});
+    while (!work.empty()) {
+        const Work w = work.back(); work.pop_back();
+        Child c[4];
+        int n = childrenOf(w.node2, c);
+        while (n < 4) {
+            int best = -1; float bestArea = -1.f;
+            for (int i = 0; i < n; i++) if (c[i].ref >= 0) { const float a = areaOf(c[i]); if (a > bestArea) { bestArea = a; best = i; } }
+            if (best < 0) break;
+            Child g[2];
+            const int m = childrenOf(c[best].ref, g);
+            if (n - 1 + m > 4) break;
+            c[best] = g[0];
+            if (m > 1) c[n++] = g[1];
         }
-        q.c0 = make_uint4(p0[0], p0[1], p0[2], (uint32_t)(e0 ? sentinelLeaf : n.ref.x));
-        q.c1 = make_uint4(p1[0], p1[1], p1[2], (uint32_t)(e1 ? sentinelLeaf : n.ref.y));
-        out->qnodes[i] = q;
+        const uint32_t stackBelow = w.stack + (uint32_t)(n > 0 ? n - 1 : 0);
+        out->maxStack = std::max(out->maxStack, stackBelow + 1u);
+        LmNode4 q;
+        for (int i = 0; i < 4; i++) {
+            if (i >= n) { q.c[i] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, (uint32_t)LM_REF_NONE); continue; }
+            uint32_t p[3];
+            for (int k = 0; k < 3; k++) quant(c[i].b[2 * k], c[i].b[2 * k + 1], k, p[k]);
+            int ref = c[i].ref;
+            if (ref >= 0) {
+                const int id4 = (int)out->nodes4.size();
+                out->nodes4.emplace_back();
+                work.push_back({ref, id4, stackBelow});
+                ref = id4;
+            }
+            q.c[i] = make_uint4(p[0], p[1], p[2], (uint32_t)ref);
+        }
+        out->nodes4[w.node4] = q;
     }
 }

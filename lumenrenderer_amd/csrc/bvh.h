@@ -1,15 +1,16 @@
-// bvh.h — host BVH2 builder interface (see bvh.cpp).
+// bvh.h — host BVH builder interface (see bvh.cpp): binned-SAH binary tree, collapsed to the 4-wide tree the kernels read.
 #pragma once
 #include "lm_layout.h"
 #include <vector>
 
 struct LmBvh {
     std::vector<LmNode> nodes;          // node 0 is the root and always an inner node
-    std::vector<LmNodeQ> qnodes;        // the same tree with 16-bit boxes (what the kernels read)
+    std::vector<LmNode4> nodes4;        // the tree collapsed to 4-wide nodes with 16-bit boxes (what the kernels read); node 0 = root
     float qmin[3] = {0, 0, 0}, qstep[3] = {1, 1, 1};
     std::vector<uint32_t> order;        // BVH triangle slot -> input triangle index
     std::vector<LmWoop> woop;           // per slot, plus one all-zero sentinel packet at index order.size()
-    uint32_t maxDepth = 0;
+    uint32_t maxDepth = 0;              // of the binary tree
+    uint32_t maxStack = 0;              // worst-case traversal stack occupancy of the 4-wide tree
     float pad = 0.f;
 };
 // tris: 9 floats per triangle (world space)

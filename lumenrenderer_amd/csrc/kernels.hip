@@ -146,14 +146,60 @@ __device__ __forceinline__ float lm_safe_rcp(float d)
     return 1.0f / (fabsf(d) > ooeps ? d : copysignf(ooeps, d));
 }
 
+// One step through a 4-wide node: slab-test the four quantised child boxes against [tmin, hitT], continue with the nearest
+// hit child and push the others far-to-near (closest-hit) or in node order (any-hit).  Returns the next node / leaf
+// reference, or LM_REF_NONE when the stack is empty.  `boxes` counts child boxes tested (instrumented build).
+struct LmRayQ { float ax, ay, az, bx, by, bz; };      // t = q * a + b per axis (dequantisation folded into the slab test)
+__device__ __forceinline__ void lm_slab(const uint4& q, const LmRayQ& r, float tmin, float hitT, uint32_t& key)
+{
+    const float lox = fmaf((float)(q.x & 0xffffu), r.ax, r.bx), hix = fmaf((float)(q.x >> 16), r.ax, r.bx);
+    const float loy = fmaf((float)(q.y & 0xffffu), r.ay, r.by), hiy = fmaf((float)(q.y >> 16), r.ay, r.by);
+    const float loz = fmaf((float)(q.z & 0xffffu), r.az, r.bz), hiz = fmaf((float)(q.z >> 16), r.az, r.bz);
+    const float tn = fmaxf(fmaxf(fminf(lox, hix), fminf(loy, hiy)), fmaxf(fminf(loz, hiz), tmin));
+    const float tf = fminf(fminf(fmaxf(lox, hix), fmaxf(loy, hiy)), fminf(fmaxf(loz, hiz), hitT));
+    key = (tn <= tf && (int)q.w != LM_REF_NONE) ? f2u(tn) : 0xffffffffu;       // tn >= tmin >= 0: the bit pattern orders like the value
+}
+__device__ __forceinline__ void lm_cex(uint32_t& ka, int& ra, uint32_t& kb, int& rb)
+{
+    const bool sw = kb < ka;
+    const uint32_t k0 = min(ka, kb), k1 = max(ka, kb);
+    const int r0 = sw ? rb : ra, r1 = sw ? ra : rb;
+    ka = k0; kb = k1; ra = r0; rb = r1;
+}
+template <bool ANY>
+__device__ __forceinline__ int lm_node_step(const LmScene& sc, int cur, const LmRayQ& rq, float tmin, float hitT, const LmStack& stack, int& sp)
+{
+    const uint4* nd = sc.nodes[cur].c;
+    const uint4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+    uint32_t k0, k1, k2, k3;
+    lm_slab(q0, rq, tmin, hitT, k0); lm_slab(q1, rq, tmin, hitT, k1); lm_slab(q2, rq, tmin, hitT, k2); lm_slab(q3, rq, tmin, hitT, k3);
+    int r0 = (int)q0.w, r1 = (int)q1.w, r2 = (int)q2.w, r3 = (int)q3.w;
+    if (!ANY) {     // order the children by entry distance (a 5-comparator network; misses carry the largest key)
+        lm_cex(k0, r0, k1, r1); lm_cex(k2, r2, k3, r3); lm_cex(k0, r0, k2, r2); lm_cex(k1, r1, k3, r3); lm_cex(k1, r1, k2, r2);
+        if (k0 == 0xffffffffu) return sp == 0 ? LM_REF_NONE : lm_pop(stack, sp);
+        if (k3 != 0xffffffffu) lm_push(stack, sp, r3);
+        if (k2 != 0xffffffffu) lm_push(stack, sp, r2);
+        if (k1 != 0xffffffffu) lm_push(stack, sp, r1);
+        return r0;
+    }
+    int next = LM_REF_NONE;
+    if (k3 != 0xffffffffu) next = r3;
+    if (k2 != 0xffffffffu) { if (next != LM_REF_NONE) lm_push(stack, sp, next); next = r2; }
+    if (k1 != 0xffffffffu) { if (next != LM_REF_NONE) lm_push(stack, sp, next); next = r1; }
+    if (k0 != 0xffffffffu) { if (next != LM_REF_NONE) lm_push(stack, sp, next); next = r0; }
+    if (next == LM_REF_NONE) return sp == 0 ? LM_REF_NONE : lm_pop(stack, sp);
+    return next;
+}
+
 template <bool ANY>
 __device__ __forceinline__ bool lm_traverse(const LmScene& sc, const lf3& o, const lf3& d, float tmin, float tmax,
                                             const LmStack& stack, LmHit& hit, uint32_t* cnt)
 {
     const float idx = lm_safe_rcp(d.x), idy = lm_safe_rcp(d.y), idz = lm_safe_rcp(d.z);
     // node boxes are 16-bit fixed point: world = qmin + q * qstep, so t = q * (qstep * idir) + (qmin - o) * idir
-    const float ax = sc.qstep[0] * idx, ay = sc.qstep[1] * idy, az = sc.qstep[2] * idz;
-    const float bx = (sc.qmin[0] - o.x) * idx, by = (sc.qmin[1] - o.y) * idy, bz = (sc.qmin[2] - o.z) * idz;
+    LmRayQ rq;
+    rq.ax = sc.qstep[0] * idx; rq.ay = sc.qstep[1] * idy; rq.az = sc.qstep[2] * idz;
+    rq.bx = (sc.qmin[0] - o.x) * idx; rq.by = (sc.qmin[1] - o.y) * idy; rq.bz = (sc.qmin[2] - o.z) * idz;
     float hitT = tmax;
     uint32_t hitOrder = 0xffffffffu;
     bool found = false;
@@ -163,36 +209,11 @@ __device__ __forceinline__ bool lm_traverse(const LmScene& sc, const lf3& o, con
     uint32_t nNodes = 0, nTris = 0;
 #endif
     for (;;) {
-        while (cur >= 0) {
-            const LmNodeQ* nd = sc.nodes + cur;
-            const uint4 q0 = nd->c0, q1 = nd->c1;
+        while (cur >= 0 && cur != LM_REF_NONE) {
 #if LM_INSTRUMENT
-            nNodes++;
+            for (int k = 0; k < 4; k++) nNodes += (int)sc.nodes[cur].c[k].w != LM_REF_NONE;      // child boxes tested
 #endif
-            const float c0lox = fmaf((float)(q0.x & 0xffffu), ax, bx), c0hix = fmaf((float)(q0.x >> 16), ax, bx);
-            const float c0loy = fmaf((float)(q0.y & 0xffffu), ay, by), c0hiy = fmaf((float)(q0.y >> 16), ay, by);
-            const float c0loz = fmaf((float)(q0.z & 0xffffu), az, bz), c0hiz = fmaf((float)(q0.z >> 16), az, bz);
-            const float c1lox = fmaf((float)(q1.x & 0xffffu), ax, bx), c1hix = fmaf((float)(q1.x >> 16), ax, bx);
-            const float c1loy = fmaf((float)(q1.y & 0xffffu), ay, by), c1hiy = fmaf((float)(q1.y >> 16), ay, by);
-            const float c1loz = fmaf((float)(q1.z & 0xffffu), az, bz), c1hiz = fmaf((float)(q1.z >> 16), az, bz);
-            const float tn0 = fmaxf(fmaxf(fminf(c0lox, c0hix), fminf(c0loy, c0hiy)), fmaxf(fminf(c0loz, c0hiz), tmin));
-            const float tf0 = fminf(fminf(fmaxf(c0lox, c0hix), fmaxf(c0loy, c0hiy)), fminf(fmaxf(c0loz, c0hiz), hitT));
-            const float tn1 = fmaxf(fmaxf(fminf(c1lox, c1hix), fminf(c1loy, c1hiy)), fmaxf(fminf(c1loz, c1hiz), tmin));
-            const float tf1 = fminf(fminf(fmaxf(c1lox, c1hix), fmaxf(c1loy, c1hiy)), fminf(fmaxf(c1loz, c1hiz), hitT));
-            const int2 ref = make_int2((int)q0.w, (int)q1.w);
-            const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-            if (!h0 && !h1) {
-                if (sp == 0) { cur = 0x7fffffff; break; }
-                cur = lm_pop(stack, sp);
-            } else {
-                int first = h0 ? ref.x : ref.y;
-                if (h0 && h1) {
-                    int second = ref.y;
-                    if (tn1 < tn0) { second = first; first = ref.y; }
-                    lm_push(stack, sp, second);
-                }
-                cur = first;
-            }
+            cur = lm_node_step<ANY>(sc, cur, rq, tmin, hitT, stack, sp);
         }
         if (cur == 0x7fffffff) break;
         // leaf
@@ -242,7 +263,8 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
     bool active = false;
     uint32_t rayIdx = 0;
     lf3 o = v3(0.f), d = v3(0.f);
-    float tmin = 0.f, tmax = 0.f, ax = 0.f, ay = 0.f, az = 0.f, bx = 0.f, by = 0.f, bz = 0.f, hitT = 0.f;
+    float tmin = 0.f, tmax = 0.f, hitT = 0.f;
+    LmRayQ rq = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     uint32_t hitOrder = 0xffffffffu;
     bool found = false;
     int sp = 0, cur = 0;
@@ -264,8 +286,8 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
                 rayIdx = base + used + rank;
                 fetch(rayIdx, o, d, tmin, tmax);
                 const float idx = lm_safe_rcp(d.x), idy = lm_safe_rcp(d.y), idz = lm_safe_rcp(d.z);
-                ax = sc.qstep[0] * idx; ay = sc.qstep[1] * idy; az = sc.qstep[2] * idz;
-                bx = (sc.qmin[0] - o.x) * idx; by = (sc.qmin[1] - o.y) * idy; bz = (sc.qmin[2] - o.z) * idz;
+                rq.ax = sc.qstep[0] * idx; rq.ay = sc.qstep[1] * idy; rq.az = sc.qstep[2] * idz;
+                rq.bx = (sc.qmin[0] - o.x) * idx; rq.by = (sc.qmin[1] - o.y) * idy; rq.bz = (sc.qmin[2] - o.z) * idz;
                 hitT = tmax; hitOrder = 0xffffffffu; found = false; sp = 0; cur = 0;
                 active = true;
             }
@@ -277,33 +299,10 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
         // ---- traverse until the ray ends or the wave has become too empty
         while (active) {
             while (cur >= 0 && cur != 0x7fffffff) {
-                const LmNodeQ* nd = sc.nodes + cur;
-                const uint4 q0 = nd->c0, q1 = nd->c1;
 #if LM_INSTRUMENT
-                nNodes++;
+                for (int k = 0; k < 4; k++) nNodes += (int)sc.nodes[cur].c[k].w != LM_REF_NONE;  // child boxes tested
 #endif
-                const float c0lox = fmaf((float)(q0.x & 0xffffu), ax, bx), c0hix = fmaf((float)(q0.x >> 16), ax, bx);
-                const float c0loy = fmaf((float)(q0.y & 0xffffu), ay, by), c0hiy = fmaf((float)(q0.y >> 16), ay, by);
-                const float c0loz = fmaf((float)(q0.z & 0xffffu), az, bz), c0hiz = fmaf((float)(q0.z >> 16), az, bz);
-                const float c1lox = fmaf((float)(q1.x & 0xffffu), ax, bx), c1hix = fmaf((float)(q1.x >> 16), ax, bx);
-                const float c1loy = fmaf((float)(q1.y & 0xffffu), ay, by), c1hiy = fmaf((float)(q1.y >> 16), ay, by);
-                const float c1loz = fmaf((float)(q1.z & 0xffffu), az, bz), c1hiz = fmaf((float)(q1.z >> 16), az, bz);
-                const float tn0 = fmaxf(fmaxf(fminf(c0lox, c0hix), fminf(c0loy, c0hiy)), fmaxf(fminf(c0loz, c0hiz), tmin));
-                const float tf0 = fminf(fminf(fmaxf(c0lox, c0hix), fmaxf(c0loy, c0hiy)), fminf(fmaxf(c0loz, c0hiz), hitT));
-                const float tn1 = fmaxf(fmaxf(fminf(c1lox, c1hix), fminf(c1loy, c1hiy)), fmaxf(fminf(c1loz, c1hiz), tmin));
-                const float tf1 = fminf(fminf(fmaxf(c1lox, c1hix), fmaxf(c1loy, c1hiy)), fminf(fmaxf(c1loz, c1hiz), hitT));
-                const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-                if (!h0 && !h1) {
-                    cur = sp == 0 ? 0x7fffffff : lm_pop(stack, sp);
-                } else {
-                    int first = h0 ? (int)q0.w : (int)q1.w;
-                    if (h0 && h1) {
-                        int second = (int)q1.w;
-                        if (tn1 < tn0) { second = first; first = (int)q1.w; }
-                        lm_push(stack, sp, second);
-                    }
-                    cur = first;
-                }
+                cur = lm_node_step<ANY>(sc, cur, rq, tmin, hitT, stack, sp);
             }
             if (cur != 0x7fffffff) {
                 const uint32_t leaf = (uint32_t)(~cur);

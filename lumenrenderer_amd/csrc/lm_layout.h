@@ -8,8 +8,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define LM_STACK_DEPTH 48        // traversal stack entries per lane; the BVH builder bounds the tree depth to this
+#define LM_STACK_DEPTH 64        // traversal stack entries per lane; the BVH builder bounds the tree so that this suffices
 #define LM_STACK_LDS 16          // of which in LDS; deeper entries spill to a per-thread global array
+#define LM_BVH2_MAX_DEPTH 40     // depth bound of the binary tree the 4-wide tree is collapsed from: a 4-wide node spans >= 2 binary
+                                 // levels per 3 pushes, so the stack need is <= 1.5 * 40 + 1 <= LM_STACK_DEPTH
+#define LM_REF_NONE 0x7fffffff   // absent child of a 4-wide node (also the traversal's "finished" marker; never followed)
 #define LM_MAX_LEAF 8            // triangles per leaf representable in a leaf reference
 #define LM_MAX_DEPTH 16          // path depth the counter block is sized for
 
@@ -26,12 +29,11 @@ struct LmNode {
     float4 n2;      // c0.lo.z c0.hi.z c1.lo.z c1.hi.z
     int4 ref;       // c0, c1, unused, unused
 };
-// BVH2 node as the GPU traverses it: 32 bytes.  Child boxes are 16-bit fixed point relative to the scene box, rounded
-// outward (lo | hi << 16 per axis), so a node step moves half the bytes of the fp32 node; boxes only cull, so the hit
-// record is unchanged.  An absent child references the sentinel (never hit) triangle packet.
-struct LmNodeQ {
-    uint4 c0;       // x: lo.x | hi.x << 16   y: lo.y | hi.y << 16   z: lo.z | hi.z << 16   w: reference
-    uint4 c1;
+// 4-wide node as the GPU traverses it: 64 bytes, the binary tree collapsed by surface area (bvh.cpp).  Child boxes are
+// 16-bit fixed point relative to the scene box, rounded outward (lo | hi << 16 per axis); boxes only cull, so the hit
+// record does not depend on them.  An absent child has reference LM_REF_NONE.
+struct LmNode4 {
+    uint4 c[4];     // per child  x: lo.x | hi.x << 16   y: lo.y | hi.y << 16   z: lo.z | hi.z << 16   w: reference
 };
 // Woop unit-triangle packet, 48 bytes: rows of the affine map world -> (u, v, w)
 struct LmWoop { float4 r0, r1, r2; };
@@ -56,7 +58,7 @@ struct LmTexDesc { uint32_t offset, w, h, srgb; };
 struct LmLight { float4 a, b, c, d; };   // a = p0.xyz p1.x | b = p1.yz p2.xy | c = p2.z n.xyz | d = radiance.xyz area
 
 struct LmScene {
-    const LmNodeQ* nodes;
+    const LmNode4* nodes;
     float qmin[3], qstep[3];    // dequantisation of node boxes: world = qmin + q * qstep
     const LmWoop* woop;
     const uint2* triId;         // per BVH triangle slot: (table entry, primitive-local triangle), .x|0x80000000 never used
@@ -107,7 +109,7 @@ struct LmFrame {
 #define LM_CNT_HEAD_CLOSEST(d) (96 + (d))        // queue heads of the persistent traversal kernels (zeroed every frame)
 #define LM_CNT_HEAD_SHADOW(d) (112 + (d))
 #define LM_CNT_HEAD_RESTIR(p) (128 + (p))
-#define LM_CNT_NODES 66                          // instrumented build only: BVH nodes visited (u64 as 2 words)
+#define LM_CNT_NODES 66                          // instrumented build only: child boxes slab-tested (u64 as 2 words); 2 boxes = one binary node of SURVEY 8 d4
 #define LM_CNT_TRIS 68                           // instrumented build only: triangles tested (u64 as 2 words)
 #define LM_CNT_WORDS 136
 

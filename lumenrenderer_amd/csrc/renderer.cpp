@@ -134,7 +134,7 @@ struct lumen_mi_renderer {
     bool lightsDirty = true;
 
     // device scene
-    DevBuf<LmNodeQ> dNodes; DevBuf<LmWoop> dWoop; DevBuf<uint2> dTriId; DevBuf<uint32_t> dTriOrder;
+    DevBuf<LmNode4> dNodes; DevBuf<LmWoop> dWoop; DevBuf<uint2> dTriId; DevBuf<uint32_t> dTriOrder;
     DevBuf<float4> dVerts; DevBuf<uint32_t> dIndices; DevBuf<LmEntry> dEntries; DevBuf<LmDevMaterial> dMaterials;
     DevBuf<int> dSpill; DevBuf<LmTexDesc> dTexDesc; DevBuf<uint32_t> dTexels; DevBuf<float> dLut; DevBuf<LmLight> dLights; DevBuf<float> dCdf;
     LmScene dscene{};
@@ -259,15 +259,17 @@ int flatten(R* r)
     }
     const uint32_t nt = (uint32_t)r->triEntry.size();
     lm_build_bvh(r->worldTris.data(), nt, &r->bvh);
+    if (r->bvh.maxStack > LM_STACK_DEPTH) return fail(LUMEN_MI_ERR_STATE, "BVH needs a deeper traversal stack than LM_STACK_DEPTH");
     std::vector<uint2> triId(nt);
     for (uint32_t s = 0; s < nt; s++) triId[s] = make_uint2(r->triEntry[r->bvh.order[s]], r->triPrim[r->bvh.order[s]]);
     hipStream_t st = r->stream;
-    if (r->dNodes.upload(r->bvh.qnodes, st) || r->dWoop.upload(r->bvh.woop, st) || r->dTriId.upload(triId, st) || r->dTriOrder.upload(r->bvh.order, st) ||
+    if (r->dNodes.upload(r->bvh.nodes4, st) || r->dWoop.upload(r->bvh.woop, st) || r->dTriId.upload(triId, st) || r->dTriOrder.upload(r->bvh.order, st) ||
         r->dVerts.upload(verts, st) || r->dIndices.upload(indices, st) || r->dEntries.upload(r->entries, st))
         return fail(LUMEN_MI_ERR_DEVICE, "scene upload failed (hipMalloc/hipMemcpy)");
     if (hipStreamSynchronize(st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "scene upload sync failed");
     for (int k = 0; k < 3; k++) { r->dscene.qmin[k] = r->bvh.qmin[k]; r->dscene.qstep[k] = r->bvh.qstep[k]; }
-    if (r->dSpill.ensure((size_t)4 * r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS)))      // one area per stream return fail(LUMEN_MI_ERR_DEVICE, "stack spill allocation failed");
+    if (r->dSpill.ensure((size_t)4 * r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS)))      // one area per stream
+        return fail(LUMEN_MI_ERR_DEVICE, "stack spill allocation failed");
     r->dscene.spill = r->dSpill.p;
     r->dscene.nodes = r->dNodes.p; r->dscene.woop = r->dWoop.p; r->dscene.triId = r->dTriId.p; r->dscene.triOrder = r->dTriOrder.p;
     r->dscene.verts = r->dVerts.p; r->dscene.indices = r->dIndices.p; r->dscene.entries = r->dEntries.p;
@@ -1030,7 +1032,8 @@ int lumen_mi_get_counters(lumen_mi_renderer* r, uint64_t* out, uint32_t n)
     for (uint32_t d = 0; d < r->lastDepth && d < 16; d++) { v[0] += c[LM_CNT_RAYS(d)]; v[4 + d] = c[LM_CNT_RAYS(d)]; v[1] += c[LM_CNT_SHADOW(d)]; }
     v[2] = (uint64_t)c[LM_CNT_RESTIR(0)] + c[LM_CNT_RESTIR(1)];
     v[3] = r->lastLightCount;
-    v[20] = (uint64_t)c[LM_CNT_NODES] | ((uint64_t)c[LM_CNT_NODES + 1] << 32);
+    v[22] = (uint64_t)c[LM_CNT_NODES] | ((uint64_t)c[LM_CNT_NODES + 1] << 32);     // child boxes slab-tested
+    v[20] = v[22] / 2;                                                                 // = binary-node equivalents (2 boxes per node)
     v[21] = (uint64_t)c[LM_CNT_TRIS] | ((uint64_t)c[LM_CNT_TRIS + 1] << 32);
     for (uint32_t i = 0; i < n && i < 24; i++) out[i] = v[i];
     return 0;
