@@ -88,7 +88,10 @@ struct lumen_mi_renderer {
     hipStream_t aux = nullptr;              // second stream: the indirect waves run beside ReSTIR (both depend only on the depth-0 G-buffer)
     hipStream_t aux3 = nullptr;             // fourth stream: second ReSTIR visibility pass beside the second spatial pass
     hipStream_t aux2 = nullptr;             // third stream: NEE shadow rays of wave d run beside the closest-hit launch of wave d+1
-    hipEvent_t evFork = nullptr, evJoin = nullptr, evJoin2 = nullptr, evVis = nullptr, evVisDone = nullptr;
+    hipEvent_t evJoin = nullptr, evJoin2 = nullptr, evVis = nullptr, evVisDone = nullptr;
+    hipEvent_t evFront = nullptr, evTemporal = nullptr, evTop = nullptr, evMerge[2] = {nullptr, nullptr};   // cross-frame pipelining (traceFrameAsync)
+    int framePar = 0;                       // parity of the frame being enqueued: selects the channel buffers and the counter block
+    bool fenceNeeded = true;                // main-stream work (uploads, memsets) the frame front on the aux stream must wait for
     std::vector<hipEvent_t> evShade;        // per wave: shade_wave(d) done
     int auxPriority = 1;                    // 1: highest priority for the aux streams, 0: default
     bool overlap = true;
@@ -142,7 +145,7 @@ struct lumen_mi_renderer {
     // device frame
     LmFrame fr{};
     uint32_t allocN = 0, allocDepth = 0;
-    DevBuf<float4> dRay[6], dSh[3], dSh2[4], dGbuf[2], dProbe[2], dRes[4], dResC[4], dDirect, dIndirect, dCombined;
+    DevBuf<float4> dRay[6], dSh[3], dSh2[4], dGbuf[2], dProbe[2], dRes[4], dResC[4], dDirect[2], dIndirect[2], dCombined;
     DevBuf<uint4> dHits; DevBuf<uint32_t> dMotion, dCounters; DevBuf<uchar4> dOutput; DevBuf<uint2> dBags;
     uint32_t hostCounters[LM_CNT_WORDS] = {0};
     bool countersValid = false;
@@ -418,8 +421,9 @@ int ensureFrameBuffers(R* r)
     for (int i = 0; i < 4; i++) bad |= r->dSh2[i].ensure(n);
     for (int i = 0; i < 2; i++) bad |= r->dGbuf[i].ensure((size_t)8 * n) | r->dProbe[i].ensure(n);
     for (int i = 0; i < 4; i++) bad |= r->dRes[i].ensure((size_t)4 * n) | r->dResC[i].ensure(n);
-    bad |= r->dDirect.ensure(n) | r->dIndirect.ensure(n) | r->dCombined.ensure(n) | r->dHits.ensure(n) | r->dMotion.ensure(n) | r->dOutput.ensure(n);
-    bad |= r->dCounters.ensure(LM_CNT_WORDS) | r->dBags.ensure(50 * 1000);
+    for (int i = 0; i < 2; i++) bad |= r->dDirect[i].ensure(n) | r->dIndirect[i].ensure(n);
+    bad |= r->dCombined.ensure(n) | r->dHits.ensure(n) | r->dMotion.ensure(n) | r->dOutput.ensure(n);
+    bad |= r->dCounters.ensure(2 * LM_CNT_WORDS) | r->dBags.ensure(50 * 1000);
     if (bad) return fail(LUMEN_MI_ERR_DEVICE, "frame buffer allocation failed");
     for (int q = 0; q < 2; q++) { f.rayO[q] = r->dRay[3 * q].p; f.rayD[q] = r->dRay[3 * q + 1].p; f.rayC[q] = r->dRay[3 * q + 2].p; }
     f.shO = r->dSh[0].p; f.shD = r->dSh[1].p; f.shR = r->dSh[2].p;
@@ -427,7 +431,7 @@ int ensureFrameBuffers(R* r)
     f.hits = r->dHits.p;
     for (int i = 0; i < 2; i++) { f.gbuf[i] = r->dGbuf[i].p; f.probe[i] = r->dProbe[i].p; }
     for (int i = 0; i < 4; i++) { f.res[i] = r->dRes[i].p; f.resC[i] = r->dResC[i].p; }
-    f.motion = r->dMotion.p; f.direct = r->dDirect.p; f.indirect = r->dIndirect.p; f.combined = r->dCombined.p; f.output = r->dOutput.p;
+    f.motion = r->dMotion.p; f.direct = r->dDirect[0].p; f.indirect = r->dIndirect[0].p; f.combined = r->dCombined.p; f.output = r->dOutput.p;
     f.counters = r->dCounters.p; f.bags = r->dBags.p;
     // ResizeBuffers (WaveFrontRenderer.cpp:1424-1540): history is dropped; reservoirs reset (ReSTIRKernels.cu:36-47)
     hipStream_t st = r->stream;
@@ -436,6 +440,7 @@ int ensureFrameBuffers(R* r)
     if (hipMemsetAsync(f.combined, 0, (size_t)n * sizeof(float4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
     if (hipMemsetAsync(f.output, 0, (size_t)n * sizeof(uchar4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
     r->allocN = n;
+    r->fenceNeeded = true;
     r->blendCounter = 0; r->frameIndex = 0; r->swapChainIndex = 0;
     return 0;
 }
@@ -524,14 +529,28 @@ int traceFrameAsync(R* r)
         for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { float s = 0.f; for (int k = 0; k < 4; k++) s += proj[i * 4 + k] * invPrev[k * 4 + j]; cam.prevViewProj[i * 4 + j] = s; }
     }
 
-    size_t evAll; evBegin(r, 4, evAll);
-    LM_HIP(hipMemsetAsync(fr.counters, 0, LM_CNT_WORDS * sizeof(uint32_t), st));
+    // ---- frame graph.  Streams: main `st` (ReSTIR chain, merge), `sx` (frame front + indirect waves), aux2 (NEE shadow
+    // rays), aux3 (second ReSTIR visibility pass).  Frames are software-pipelined: the front of frame i+1 (primary rays,
+    // first closest-hit launch, surface extraction, first continuation) is queued on `sx` behind the waves of frame i and
+    // runs beside the ReSTIR tail of frame i on `st`.  What that needs: DIRECT / INDIRECT and the counter block are
+    // double-buffered by frame parity; extraction waits for frame i's temporal pass (the last reader of the G-buffer /
+    // probe plane / motion vectors it overwrites); a frame's front waits for the merge of the frame two back (owner of
+    // the same parity buffers).  Accumulation order per pixel is unchanged, so results equal the serial order bit for bit.
+    const bool overlap = r->overlap && r->aux != nullptr;
+    hipStream_t sx = overlap ? r->aux : st;
+    const int par = r->framePar; r->framePar ^= 1;
+    fr.direct = r->dDirect[par].p; fr.indirect = r->dIndirect[par].p; fr.counters = r->dCounters.p + (size_t)par * LM_CNT_WORDS;
+    if (overlap) {
+        if (r->fenceNeeded) { LM_HIP(hipEventRecord(r->evTop, st)); LM_HIP(hipStreamWaitEvent(sx, r->evTop, 0)); }
+        LM_HIP(hipStreamWaitEvent(sx, r->evMerge[par], 0));
+    }
+    r->fenceNeeded = false;
+    size_t evAll; evBegin2(r, 4, evAll, sx);
+    LM_HIP(hipMemsetAsync(fr.counters, 0, LM_CNT_WORDS * sizeof(uint32_t), sx));
     if (!blend) K->clear(st, r->gridFor(fr.n, 8), fr.combined, fr.n);                        // :559
     ++r->frameCount;                                                                          // :593
-    K->primary(st, r->gridFor(fr.n, 8), fr, cam, r->frameCount);
+    K->primary(sx, r->gridFor(fr.n, 8), fr, cam, r->frameCount);
     uint32_t seed = wangHash(r->frameCount);                                                  // :685
-    const bool overlap = r->overlap && r->aux != nullptr;
-    hipStream_t sx = overlap ? r->aux : st;                                                   // stream of the indirect waves
     LmScene scx = r->dscene;                                                                  // same scene, its own stack-spill area
     if (overlap) scx.spill += (size_t)r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS);
     const int gridMain = r->numCU * r->traceBlocksMain, gridAux = r->numCU * (overlap ? r->traceBlocksAux : r->traceBlocksMain);
@@ -545,16 +564,17 @@ int traceFrameAsync(R* r)
         const uint32_t seed2 = wangHash(seed);                                                // CPUShadingKernels.cu:178
         const int doIndirect = depth < depthMax - 1 ? 1 : 0;
         if (depth == 0) {
-            evBegin(r, 0, ev);
-            K->trace_closest(st, gridMain, r->dscene, fr.rayO[q], fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters, 0);    // :678,:703
-            evEnd(r, ev);
-            evBegin(r, 2, ev);
-            K->extract0(st, r->gridFor(fr.n, 8), r->dscene, fr, cam, currentIndex);
-            evEnd(r, ev);
-            // path continuation of depth 0 first (0.24 ms alone; its 1024-thread blocks starve when co-scheduled with ReSTIR),
-            // then fork: the indirect waves run beside ReSTIR, both depend only on the G-buffer
-            if (doIndirect) { evBegin(r, 2, ev); K->shade_indirect0(st, tiles32, fr, currentIndex, seed2, q ^ 1, outCount); evEnd(r, ev); }
-            if (overlap) { LM_HIP(hipEventRecord(r->evFork, st)); LM_HIP(hipStreamWaitEvent(sx, r->evFork, 0)); }
+            evBegin2(r, 0, ev, sx);
+            K->trace_closest(sx, gridMain, scx, fr.rayO[q], fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters, 0);    // :678,:703
+            evEnd2(r, ev, sx);
+            if (overlap) LM_HIP(hipStreamWaitEvent(sx, r->evTemporal, 0));               // previous frame's temporal pass has read what extraction overwrites
+            evBegin2(r, 2, ev, sx);
+            K->extract0(sx, r->gridFor(fr.n, 8), r->dscene, fr, cam, currentIndex);
+            evEnd2(r, ev, sx);
+            // path continuation of depth 0, then the indirect waves follow on the same stream beside ReSTIR on the main
+            // stream: both depend only on the G-buffer
+            if (doIndirect) { evBegin2(r, 2, ev, sx); K->shade_indirect0(sx, tiles32, fr, currentIndex, seed2, q ^ 1, outCount); evEnd2(r, ev, sx); }
+            if (overlap) { LM_HIP(hipEventRecord(r->evFront, sx)); LM_HIP(hipStreamWaitEvent(st, r->evFront, 0)); }
             // ReSTIR::Run (Framework/ReSTIR.cpp:65-233) — stays on the main stream
             evBegin(r, 3, ev);
             const int cur = r->swapChainIndex, tmp = cur == 1 ? 0 : 1;
@@ -567,6 +587,7 @@ int traceFrameAsync(R* r)
             K->trace_shade(st, gridMain, r->dscene, fr, cur, fr.counters + LM_CNT_RESTIR(0), r->refillVisibility, 0);
             rs = wangHash(rs);
             K->temporal(st, tiles, fr, currentIndex, temporalIndex, cur, tmp, rs, fr.counters + LM_CNT_RESTIR(1));                // + visibility rays, pass 2
+            if (overlap) LM_HIP(hipEventRecord(r->evTemporal, st));
             rs = wangHash(rs);
             K->spatial(st, tiles, fr, currentIndex, cur, 2, rs);
             // second visibility pass (ReSTIR.cpp:211-212) works on the CURRENT buffer, which the second spatial pass does not
@@ -588,7 +609,7 @@ int traceFrameAsync(R* r)
             evBegin2(r, 0, ev, sx);
             K->trace_closest(sx, gridAux, scx, fr.rayO[q], fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters, r->refillBelow);
             evEnd2(r, ev, sx);
-            if (overlap && depth > 1) LM_HIP(hipStreamWaitEvent(sx, r->evJoin2, 0));      // previous wave's shadow rays consumed
+            if (overlap) LM_HIP(hipStreamWaitEvent(sx, r->evJoin2, 0));                   // previous wave's (or frame's) shadow rays consumed
             evBegin2(r, 2, ev, sx);
             K->shade_wave(sx, r->numCU * 8, scx, fr, q, inCount, seed, seed2, doIndirect, outCount, shCount);
             evEnd2(r, ev, sx);
@@ -608,6 +629,7 @@ int traceFrameAsync(R* r)
     }
     if (overlap) { LM_HIP(hipEventRecord(r->evJoin, sx)); LM_HIP(hipStreamWaitEvent(st, r->evJoin, 0)); if (depthMax > 1) LM_HIP(hipStreamWaitEvent(st, r->evJoin2, 0)); }
     K->merge(st, r->gridFor(fr.n, 8), fr, blend ? 1 : 0, r->blendCounter);
+    if (overlap) LM_HIP(hipEventRecord(r->evMerge[par], st));
     evEnd(r, evAll);
     LM_HIP(hipGetLastError());
     r->lastDepth = depthMax;
@@ -694,7 +716,10 @@ int lumen_mi_init(lumen_mi_renderer* r, const lumen_mi_settings* s)
         LM_HIP(hipEventCreateWithFlags(&r->evVisDone, hipEventDisableTiming));
         r->evShade.resize(LM_MAX_DEPTH + 1);
         for (auto& e : r->evShade) LM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        LM_HIP(hipEventCreateWithFlags(&r->evFork, hipEventDisableTiming));
+        LM_HIP(hipEventCreateWithFlags(&r->evFront, hipEventDisableTiming));
+        LM_HIP(hipEventCreateWithFlags(&r->evTemporal, hipEventDisableTiming));
+        LM_HIP(hipEventCreateWithFlags(&r->evTop, hipEventDisableTiming));
+        for (auto& e : r->evMerge) LM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         LM_HIP(hipEventCreateWithFlags(&r->evJoin, hipEventDisableTiming));
     }
     r->initialised = true;
@@ -708,11 +733,11 @@ int lumen_mi_destroy(lumen_mi_renderer* r)
     if (r->initialised) {
         (void)hipSetDevice(r->device);
         (void)hipStreamSynchronize(r->stream);
-        if (r->aux) { (void)hipStreamSynchronize(r->aux); (void)hipStreamSynchronize(r->aux2); (void)hipStreamDestroy(r->aux2); (void)hipStreamSynchronize(r->aux3); (void)hipStreamDestroy(r->aux3); (void)hipEventDestroy(r->evVis); (void)hipEventDestroy(r->evVisDone); (void)hipEventDestroy(r->evJoin2); for (auto& e : r->evShade) (void)hipEventDestroy(e); (void)hipStreamDestroy(r->aux); (void)hipEventDestroy(r->evFork); (void)hipEventDestroy(r->evJoin); }
+        if (r->aux) { (void)hipStreamSynchronize(r->aux); (void)hipStreamSynchronize(r->aux2); (void)hipStreamDestroy(r->aux2); (void)hipStreamSynchronize(r->aux3); (void)hipStreamDestroy(r->aux3); (void)hipEventDestroy(r->evVis); (void)hipEventDestroy(r->evVisDone); (void)hipEventDestroy(r->evJoin2); for (auto& e : r->evShade) (void)hipEventDestroy(e); (void)hipStreamDestroy(r->aux); (void)hipEventDestroy(r->evFront); (void)hipEventDestroy(r->evTemporal); (void)hipEventDestroy(r->evTop); for (auto& e : r->evMerge) (void)hipEventDestroy(e); (void)hipEventDestroy(r->evJoin); }
         r->dSpill.release(); r->dNodes.release(); r->dWoop.release(); r->dTriId.release(); r->dTriOrder.release(); r->dVerts.release(); r->dIndices.release();
         r->dEntries.release(); r->dMaterials.release(); r->dTexDesc.release(); r->dTexels.release(); r->dLut.release(); r->dLights.release(); r->dCdf.release();
         for (auto& b : r->dRay) b.release(); for (auto& b : r->dSh) b.release(); for (auto& b : r->dSh2) b.release(); for (auto& b : r->dGbuf) b.release(); for (auto& b : r->dProbe) b.release(); for (auto& b : r->dRes) b.release(); for (auto& b : r->dResC) b.release();
-        r->dDirect.release(); r->dIndirect.release(); r->dCombined.release(); r->dHits.release(); r->dMotion.release(); r->dCounters.release(); r->dOutput.release(); r->dBags.release();
+        for (int i = 0; i < 2; i++) { r->dDirect[i].release(); r->dIndirect[i].release(); } r->dCombined.release(); r->dHits.release(); r->dMotion.release(); r->dCounters.release(); r->dOutput.release(); r->dBags.release();
         for (auto& e : r->evPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     }
     delete r;
@@ -1067,7 +1092,7 @@ static int prepareScene(lumen_mi_renderer* r)
     int rc;
     if ((rc = uploadResources(r))) return rc;
     if ((rc = flatten(r))) return rc;
-    if ((rc = r->dCounters.ensure(LM_CNT_WORDS))) return fail(LUMEN_MI_ERR_DEVICE, "counter allocation failed");
+    if ((rc = r->dCounters.ensure(2 * LM_CNT_WORDS))) return fail(LUMEN_MI_ERR_DEVICE, "counter allocation failed");
     return 0;
 }
 
