@@ -579,40 +579,6 @@ __device__ __forceinline__ bool lm_tile_pixel(const LmFrame& fr, uint32_t& li, u
     return true;
 }
 
-// K7 (depth 0) + K9 motion vectors (MotionVectors.cu:8-55) + K10 ResolveDirectLightHits (GPUShadeDirect.cu:11-40) + channel clear
-extern "C" __global__ void __launch_bounds__(LM_BLOCK)
-KN(lm_k_extract0)(LmScene sc, LmFrame fr, LmCamera cam, int cur)
-{
-    const uint32_t stride = gridDim.x * LM_BLOCK;
-    for (uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x; i < fr.n; i += stride) {
-        const float4 o4 = fr.rayO[0][i], d4 = fr.rayD[0][i], c4 = fr.rayC[0][i];
-        const uint32_t li = f2u(d4.w);
-        LmSurface s;
-        lm_extract(sc, fr.hits[i], v3(o4), v3(d4), v3(c4), s);
-        lm_gbuf_store(fr.gbuf[cur], fr.probe[cur], li, s);
-        // motion vector
-        const uint32_t ly = li / fr.ww, lx = li - ly * fr.ww;
-        const uint32_t px = fr.x0 + lx, py = fr.y0 + ly;
-        uint32_t mv = 0u;
-        if (s.t > 0.f) {
-            float csx = (float)(int)px, csy = (float)(int)py;
-            csx += 0.5f; csy += 0.5f;
-            csx /= (float)fr.W; csy /= (float)fr.H;
-            const float* M = cam.prevViewProj;
-            const float cx = M[0] * s.position.x + M[1] * s.position.y + M[2] * s.position.z + M[3] * 1.0f;
-            const float cy = M[4] * s.position.x + M[5] * s.position.y + M[6] * s.position.z + M[7] * 1.0f;
-            const float cz = M[8] * s.position.x + M[9] * s.position.y + M[10] * s.position.z + M[11] * 1.0f;
-            const float cw = M[12] * s.position.x + M[13] * s.position.y + M[14] * s.position.z + M[15] * 1.0f;
-            const lf3 ndc = v3(cx, cy, cz) / cw;
-            const float psx = ndc.x * 0.5f + 0.5f, psy = ndc.y * 0.5f + 0.5f;
-            mv = lm_f32_to_f16(psx - csx) | (lm_f32_to_f16(psy - csy) << 16);
-        }
-        fr.motion[li] = mv;
-        fr.direct[li] = (s.flags & LM_SF_EMISSIVE) ? s.mat.color : make_float4(0.f, 0.f, 0.f, 0.f);
-        fr.indirect[li] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // lights / CDF — reference ReSTIRData.h:230-306 (CDF::Get, BinarySearch)
 // ---------------------------------------------------------------------------------------------------------------------
@@ -693,28 +659,63 @@ __device__ bool lm_shade_indirect(const LmSurface& s, uint32_t gi, uint32_t seed
     return true;
 }
 
-// depth 0 continuation: reads the G-buffer written by lm_k_extract0 (one 1024-thread block per 32x32 pixel tile; the
-// survivors of a block are appended with ONE atomic)
-extern "C" __global__ void __launch_bounds__(1024)
-KN(lm_k_shade_indirect0)(LmFrame fr, int cur, uint32_t seed2, int outQ, uint32_t* outCount)
+// K7 (depth 0) + K9 motion vectors (MotionVectors.cu:8-55) + K10 ResolveDirectLightHits (GPUShadeDirect.cu:11-40) + channel clear
+// + K12 at depth 0 (GPUShadeIndirect.cu:7-146): the path continuation is sampled from the surface while it is still in
+// registers; survivors of a block iteration are appended to the wave-1 queue with ONE atomic.
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_extract0)(LmScene sc, LmFrame fr, LmCamera cam, int cur, uint32_t seed2, int doIndirect, int outQ, uint32_t* outCount)
 {
-    __shared__ uint32_t s_tmp[17];
-    uint32_t li = 0, gi = 0;
-    const bool valid = lm_tile_pixel<5>(fr, li, gi);
-    bool emit = false;
-    lf3 o = v3(0.f), d = v3(0.f), c = v3(0.f);
-    if (valid) {
+    __shared__ uint32_t s_tmp[5];
+    const uint32_t stride = gridDim.x * LM_BLOCK;
+    const uint32_t nIter = (fr.n + stride - 1u) / stride;
+    for (uint32_t it = 0; it < nIter; it++) {
+        const uint32_t i = it * stride + blockIdx.x * LM_BLOCK + threadIdx.x;
+        bool emit = false;
+        lf3 bo = v3(0.f), bd = v3(0.f), bc = v3(0.f);
+        uint32_t liOut = 0u;
+        if (i < fr.n) {
+        const float4 o4 = fr.rayO[0][i], d4 = fr.rayD[0][i], c4 = fr.rayC[0][i];
+        const uint32_t li = f2u(d4.w);
         LmSurface s;
-        lm_gbuf_load(fr.gbuf[cur], li, s);
-        emit = lm_shade_indirect(s, gi, seed2, o, d, c);
-    }
-    const uint32_t slot = lm_append_slot_block(outCount, emit, s_tmp);
-    if (emit) {
-        fr.rayO[outQ][slot] = v4(o, 0.f);
-        fr.rayD[outQ][slot] = v4(d, u2f(li));
-        fr.rayC[outQ][slot] = v4(c, 0.f);
+        lm_extract(sc, fr.hits[i], v3(o4), v3(d4), v3(c4), s);
+        lm_gbuf_store(fr.gbuf[cur], fr.probe[cur], li, s);
+        // motion vector
+        const uint32_t ly = li / fr.ww, lx = li - ly * fr.ww;
+        const uint32_t px = fr.x0 + lx, py = fr.y0 + ly;
+        uint32_t mv = 0u;
+        if (s.t > 0.f) {
+            float csx = (float)(int)px, csy = (float)(int)py;
+            csx += 0.5f; csy += 0.5f;
+            csx /= (float)fr.W; csy /= (float)fr.H;
+            const float* M = cam.prevViewProj;
+            const float cx = M[0] * s.position.x + M[1] * s.position.y + M[2] * s.position.z + M[3] * 1.0f;
+            const float cy = M[4] * s.position.x + M[5] * s.position.y + M[6] * s.position.z + M[7] * 1.0f;
+            const float cz = M[8] * s.position.x + M[9] * s.position.y + M[10] * s.position.z + M[11] * 1.0f;
+            const float cw = M[12] * s.position.x + M[13] * s.position.y + M[14] * s.position.z + M[15] * 1.0f;
+            const lf3 ndc = v3(cx, cy, cz) / cw;
+            const float psx = ndc.x * 0.5f + 0.5f, psy = ndc.y * 0.5f + 0.5f;
+            mv = lm_f32_to_f16(psx - csx) | (lm_f32_to_f16(psy - csy) << 16);
+        }
+        fr.motion[li] = mv;
+        fr.direct[li] = (s.flags & LM_SF_EMISSIVE) ? s.mat.color : make_float4(0.f, 0.f, 0.f, 0.f);
+        fr.indirect[li] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (doIndirect) {
+            s.transport = v3(1.f, 1.f, 1.f);                       // what a G-buffer reload yields (lm_gbuf_load)
+            liOut = li;
+            emit = lm_shade_indirect(s, py * fr.W + px, seed2, bo, bd, bc);
+        }
+        }
+        if (doIndirect) {                                          // uniform per block
+            const uint32_t slot = lm_append_slot_block(outCount, emit, s_tmp);
+            if (emit) {
+                fr.rayO[outQ][slot] = v4(bo, 0.f);
+                fr.rayD[outQ][slot] = v4(bd, u2f(liOut));
+                fr.rayC[outQ][slot] = v4(bc, 0.f);
+            }
+        }
     }
 }
+
 
 // depth >= 1: extraction + NEE + continuation fused (no SurfaceData round trip through HBM)
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
@@ -778,33 +779,6 @@ KN(lm_k_trace_shadow)(LmScene sc, LmFrame fr, const uint32_t* __restrict__ count
         });
 }
 
-// K22: ReSTIR visibility-ray generation (ReSTIRKernels.cu:546-582) into the shadow-ray queue; one 1024-thread block per
-// 32x32 pixel tile, one atomic per block.
-extern "C" __global__ void __launch_bounds__(1024)
-KN(lm_k_restir_gen_rays)(LmFrame fr, int cur, int rc, uint32_t* outCount)
-{
-    __shared__ uint32_t s_tmp[17];
-    uint32_t li = 0, gi = 0;
-    const bool valid = lm_tile_pixel<5>(fr, li, gi);
-    bool shoot = false;
-    lf3 pos = v3(0.f), toLight = v3(0.f);
-    float l = 0.f;
-    if (valid && fr.probe[cur][li].w >= 0.f) {
-        const float4* hot = fr.res[rc] + 4u * li;
-        if (hot[0].y > 0.f) {
-            pos = v3(fr.gbuf[cur][8u * li]);
-            toLight = v3(hot[3]) - pos;
-            l = length3(toLight);
-            toLight = toLight / l;
-            shoot = true;
-        }
-    }
-    const uint32_t slot = lm_append_slot_block(outCount, shoot, s_tmp);
-    if (shoot) {
-        fr.visO[slot] = v4(pos, l - 0.05f);
-        fr.visD[slot] = v4(toLight, u2f(li));
-    }
-}
 // K6 + K23: resolve the visibility rays (tmin 0.1, WaveFrontShaders.cu:181-216: occluded => reservoir weight = 0) and shade
 // the surviving reservoirs into DIRECT with weight / 3 (ReSTIRKernels.cu:600-665)
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
@@ -1055,7 +1029,10 @@ KN(lm_k_restir_temporal)(LmFrame fr, int cur, int prev, int rc, int rp, uint32_t
 // K25 spatial reuse — ReSTIRKernels.cu:787-980 (biased branch).  The five candidate probes are issued together (one
 // 16-byte gather each from the probe plane) and the accepted candidates' 64-byte reservoir records are fetched one
 // iteration ahead of their re-evaluation, so the kernel is not a chain of dependent L2 round trips.
-extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
+#ifndef LM_SPATIAL_WAVES
+#define LM_SPATIAL_WAVES 3      // <= 168 VGPRs: three waves per SIMD instead of two (the kernel is gather-latency bound)
+#endif
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_SPATIAL_WAVES)
 KN(lm_k_restir_spatial)(LmFrame fr, int cur, int rin, int rout, uint32_t seed)
 {
     uint32_t li = 0, gi = 0;
@@ -1078,27 +1055,31 @@ KN(lm_k_restir_spatial)(LmFrame fr, int cur, int rin, int rout, uint32_t seed)
     }
 #pragma unroll
     for (int k = 0; k < 5; k++) pr[k] = probe[cand[k] != 0xffffffffu ? cand[k] : li];
-    uint32_t nb[5];
-    int count = 0;
+    // accepted candidates as a bit mask; they are visited in candidate order (no dynamically indexed array: registers only)
+    uint32_t mask = 0u;
 #pragma unroll
     for (int k = 0; k < 5; k++) {
         if (cand[k] == 0xffffffffu || pr[k].w < 0.f) continue;
         const float d1 = pr[k].w;
         const float depthDif = fabsf(d1 - ct) / ((d1 + ct) / 2.f);
         const float angle = dot3(v3(pr[k]), v3(cn));
-        if (depthDif < 0.10f && angle > 0.72222222223f) nb[count++] = cand[k];
+        if (depthDif < 0.10f && angle > 0.72222222223f) mask |= 1u << k;
     }
+    auto candAt = [&](uint32_t k) { return k == 0u ? cand[0] : k == 1u ? cand[1] : k == 2u ? cand[2] : k == 3u ? cand[3] : cand[4]; };
     float4* hotOut = fr.res[rout];
-    if (count > 1) {
-        const float4* h = hotIn + 4u * nb[0];
+    if (__popc(mask) > 1) {
+        const uint32_t nb0 = candAt((uint32_t)__ffs((int)mask) - 1u);
+        mask &= mask - 1u;
+        const float4* h = hotIn + 4u * nb0;
         float4 a = h[0], p1 = h[1], p2 = h[2], p3 = h[3];
         LmSurface s0;
-        lm_gbuf_load(fr.gbuf[cur], nb[0], s0);                  // every candidate is re-evaluated at the FIRST neighbour's surface (reference :883)
+        lm_gbuf_load(fr.gbuf[cur], nb0, s0);                    // every candidate is re-evaluated at the FIRST neighbour's surface (reference :883)
         LmReservoir out; lm_res_fresh(out);
         long long sum = 0;
-        for (int k = 0; k < count; k++) {
+        for (;;) {
             float4 na = a, np1 = p1, np2 = p2, np3 = p3;
-            if (k + 1 < count) { const float4* hn = hotIn + 4u * nb[k + 1]; na = hn[0]; np1 = hn[1]; np2 = hn[2]; np3 = hn[3]; }   // prefetch
+            const bool more = mask != 0u;
+            if (more) { const float4* hn = hotIn + 4u * candAt((uint32_t)__ffs((int)mask) - 1u); mask &= mask - 1u; na = hn[0]; np1 = hn[1]; np2 = hn[2]; np3 = hn[3]; }   // prefetch
             LmSample in; lm_sample_zero(in);
             in.radiance = v3(p1); in.area = p1.w; in.normal = v3(p2); in.position = v3(p3);
             const long long cnt = (long long)f2u(a.z);
@@ -1106,6 +1087,7 @@ KN(lm_k_restir_spatial)(LmFrame fr, int cur, int rin, int rout, uint32_t seed)
             lm_resample(in, s0, rs);
             lm_res_update(out, rs, (float)cnt * a.y * rs.pdf, seed);   // global seed: same draw for all pixels (reference quirk)
             sum += cnt;
+            if (!more) break;
             a = na; p1 = np1; p2 = np2; p3 = np3;
         }
         out.count = sum;
@@ -1262,14 +1244,13 @@ KN(lm_k_test_math)(uint32_t n, int fn, const float* __restrict__ x, const float*
 static void l_primary(hipStream_t s, int g, LmFrame fr, LmCamera cam, uint32_t frameCount) { hipLaunchKernelGGL(KN(lm_k_primary), LM_GRID(g), fr, cam, frameCount); }
 static void l_trace_closest(hipStream_t s, int g, LmScene sc, const float4* o, const float4* d, const uint32_t* cnt, uint4* hits, float tmin, float tmax, uint32_t* counters, int refillBelow)
 { hipLaunchKernelGGL(KN(lm_k_trace_closest), LM_GRID(g), sc, o, d, cnt, hits, tmin, tmax, counters, refillBelow); }
-static void l_extract0(hipStream_t s, int g, LmScene sc, LmFrame fr, LmCamera cam, int cur) { hipLaunchKernelGGL(KN(lm_k_extract0), LM_GRID(g), sc, fr, cam, cur); }
-static void l_shade_indirect0(hipStream_t s, int g, LmFrame fr, int cur, uint32_t seed2, int outQ, uint32_t* outCount) { hipLaunchKernelGGL(KN(lm_k_shade_indirect0), dim3((unsigned)g), dim3(1024), 0, s, fr, cur, seed2, outQ, outCount); }
+static void l_extract0(hipStream_t s, int g, LmScene sc, LmFrame fr, LmCamera cam, int cur, uint32_t seed2, int doIndirect, int outQ, uint32_t* outCount)
+{ hipLaunchKernelGGL(KN(lm_k_extract0), LM_GRID(g), sc, fr, cam, cur, seed2, doIndirect, outQ, outCount); }
 static void l_shade_wave(hipStream_t s, int g, LmScene sc, LmFrame fr, int inQ, const uint32_t* inCount, uint32_t seed, uint32_t seed2, int doIndirect, uint32_t* outCount, uint32_t* shadowCount)
 { hipLaunchKernelGGL(KN(lm_k_shade_wave), LM_GRID(g), sc, fr, inQ, inCount, seed, seed2, doIndirect, outCount, shadowCount); }
 static void l_trace_shadow(hipStream_t s, int g, LmScene sc, LmFrame fr, const uint32_t* cnt, float tmin, int refillBelow) { hipLaunchKernelGGL(KN(lm_k_trace_shadow), LM_GRID(g), sc, fr, cnt, tmin, refillBelow); }
 static void l_fill_bags(hipStream_t s, LmScene sc, LmFrame fr, uint32_t seed, uint32_t total) { hipLaunchKernelGGL(KN(lm_k_fill_bags), LM_GRID((total + LM_BLOCK - 1) / LM_BLOCK), sc, fr, seed, total); }
 static void l_pick_primary(hipStream_t s, int tiles, LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount) { hipLaunchKernelGGL(KN(lm_k_pick_primary), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount); }
-static void l_gen_rays(hipStream_t s, int tiles, LmFrame fr, int cur, int rc, uint32_t* outCount) { hipLaunchKernelGGL(KN(lm_k_restir_gen_rays), dim3((unsigned)tiles), dim3(1024), 0, s, fr, cur, rc, outCount); }
 static void l_trace_shade(hipStream_t s, int g, LmScene sc, LmFrame fr, int rc, const uint32_t* cnt, int refillBelow, int pass) { hipLaunchKernelGGL(KN(lm_k_restir_trace_shade), LM_GRID(g), sc, fr, rc, cnt, refillBelow, pass); }
 static void l_temporal(hipStream_t s, int g, LmFrame fr, int cur, int prev, int rc, int rp, uint32_t seed, uint32_t* visCount) { hipLaunchKernelGGL(KN(lm_k_restir_temporal), LM_GRID(g), fr, cur, prev, rc, rp, seed, visCount); }
 static void l_spatial(hipStream_t s, int g, LmFrame fr, int cur, int rin, int rout, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_restir_spatial), LM_GRID(g), fr, cur, rin, rout, seed); }
@@ -1289,7 +1270,7 @@ extern "C" const LmKernelTable* lm_kernel_table_instrumented()
 extern "C" const LmKernelTable* lm_kernel_table()
 #endif
 {
-    static const LmKernelTable t = {l_primary, l_trace_closest, l_extract0, l_shade_indirect0, l_shade_wave, l_trace_shadow, l_fill_bags, l_pick_primary,
-                                    l_gen_rays, l_trace_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_test_bsdf, l_test_math};
+    static const LmKernelTable t = {l_primary, l_trace_closest, l_extract0, l_shade_wave, l_trace_shadow, l_fill_bags, l_pick_primary,
+                                    l_trace_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_test_bsdf, l_test_math};
     return &t;
 }

@@ -5,13 +5,11 @@
 struct LmKernelTable {
     void (*primary)(hipStream_t, int grid, LmFrame, LmCamera, uint32_t frameCount);
     void (*trace_closest)(hipStream_t, int grid, LmScene, const float4* o, const float4* d, const uint32_t* count, uint4* hits, float tmin, float tmax, uint32_t* counters, int refillBelow);
-    void (*extract0)(hipStream_t, int grid, LmScene, LmFrame, LmCamera, int cur);
-    void (*shade_indirect0)(hipStream_t, int tiles, LmFrame, int cur, uint32_t seed2, int outQ, uint32_t* outCount);
+    void (*extract0)(hipStream_t, int grid, LmScene, LmFrame, LmCamera, int cur, uint32_t seed2, int doIndirect, int outQ, uint32_t* outCount);
     void (*shade_wave)(hipStream_t, int grid, LmScene, LmFrame, int inQ, const uint32_t* inCount, uint32_t seed, uint32_t seed2, int doIndirect, uint32_t* outCount, uint32_t* shadowCount);
     void (*trace_shadow)(hipStream_t, int grid, LmScene, LmFrame, const uint32_t* count, float tmin, int refillBelow);
     void (*fill_bags)(hipStream_t, LmScene, LmFrame, uint32_t seed, uint32_t total);
     void (*pick_primary)(hipStream_t, int tiles, LmScene, LmFrame, int cur, int rc, uint32_t seed, uint32_t* visCount);
-    void (*gen_rays)(hipStream_t, int tiles32, LmFrame, int cur, int rc, uint32_t* outCount);
     void (*trace_shade)(hipStream_t, int grid, LmScene, LmFrame, int rc, const uint32_t* count, int refillBelow, int pass);
     void (*temporal)(hipStream_t, int tiles, LmFrame, int cur, int prev, int rc, int rp, uint32_t seed, uint32_t* visCount);
     void (*spatial)(hipStream_t, int tiles, LmFrame, int cur, int rin, int rout, uint32_t seed);

@@ -555,7 +555,6 @@ int traceFrameAsync(R* r)
     if (overlap) scx.spill += (size_t)r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS);
     const int gridMain = r->numCU * r->traceBlocksMain, gridAux = r->numCU * (overlap ? r->traceBlocksAux : r->traceBlocksMain);
     const int tiles = (int)(((fr.ww + 15u) / 16u) * ((fr.wh + 15u) / 16u));
-    const int tiles32 = (int)(((fr.ww + 31u) / 32u) * ((fr.wh + 31u) / 32u));
     int q = 0;
     size_t ev;
     for (uint32_t depth = 0; depth < depthMax; ++depth) {
@@ -569,11 +568,9 @@ int traceFrameAsync(R* r)
             evEnd2(r, ev, sx);
             if (overlap) LM_HIP(hipStreamWaitEvent(sx, r->evTemporal, 0));               // previous frame's temporal pass has read what extraction overwrites
             evBegin2(r, 2, ev, sx);
-            K->extract0(sx, r->gridFor(fr.n, 8), r->dscene, fr, cam, currentIndex);
+            K->extract0(sx, r->gridFor(fr.n, 8), r->dscene, fr, cam, currentIndex, seed2, doIndirect, q ^ 1, outCount);   // + depth-0 continuation
             evEnd2(r, ev, sx);
-            // path continuation of depth 0, then the indirect waves follow on the same stream beside ReSTIR on the main
-            // stream: both depend only on the G-buffer
-            if (doIndirect) { evBegin2(r, 2, ev, sx); K->shade_indirect0(sx, tiles32, fr, currentIndex, seed2, q ^ 1, outCount); evEnd2(r, ev, sx); }
+            // the indirect waves follow on the same stream beside ReSTIR on the main stream: both depend only on the G-buffer
             if (overlap) { LM_HIP(hipEventRecord(r->evFront, sx)); LM_HIP(hipStreamWaitEvent(st, r->evFront, 0)); }
             // ReSTIR::Run (Framework/ReSTIR.cpp:65-233) — stays on the main stream
             evBegin(r, 3, ev);
