@@ -180,6 +180,58 @@ def test_sponza_with_1024_emissive_triangles_matches_oracle():
     r.close(); o.close()
 
 
+def test_pipelined_async_frames_match_oracle():
+    """Frames enqueued back to back (TraceFrameAsync, one Synchronize at the end) run software-pipelined on four streams:
+    the next frame's front overlaps the ReSTIR tail of the current one.  The blended result must still be the oracle's."""
+    from lumenrenderer_amd.scenes import sponza_standin
+    for d, (w, h, depth), frames in ((cornell(), (160, 120, 5), 5), (sponza_standin(), (192, 108, 6), 4), (cornell(), (96, 64, 3), 3)):
+        r = product_from(d, w, h, depth, blend=True); o = oracle_from(d, w, h, depth, blend=True)
+        for _ in range(frames):
+            assert r.TraceFrameAsync() is True
+            assert o.trace_frame() == 0
+        r.Synchronize()
+        assert np.array_equal(r.GetRadiance().view(np.uint32), o.radiance().view(np.uint32))
+        for ch in (0, 1):
+            assert np.array_equal(r.GetChannel(ch).view(np.uint32), o.channel(ch).view(np.uint32)), ch
+        c, s = r.GetCounters(), o.stats(24)
+        assert list(c[:4]) == list(s[:4])
+        assert np.array_equal(r.GetGBuffer().view(np.uint32), o.gbuffer().view(np.uint32))
+        assert np.array_equal(r.GetOutputTexturePixels(), o.output_pixels())
+        r.close(); o.close()
+
+
+def test_deep_traversal_stack_spills_to_global_memory():
+    """A stack of large overlapping sheets seen edge-on keeps many 4-wide-node children pending at once: the per-lane stack
+    grows past its LDS part (LM_STACK_LDS = 16) and uses the global spill area.  Hits must still equal brute force."""
+    from lumenrenderer_amd.scenes import SceneDescription, interleave
+    rng = np.random.default_rng(11)
+    n_sheets = 3000
+    pos = np.zeros((n_sheets * 3, 3), np.float32)
+    z = np.linspace(0.0, 30.0, n_sheets, dtype=np.float32)
+    for k in range(n_sheets):                            # long thin triangles, all crossing the same corridor along +z
+        a = rng.uniform(-1, 1, 2).astype(np.float32) * 0.2
+        pos[3 * k + 0] = (-40 + a[0], -40 + a[1], z[k])
+        pos[3 * k + 1] = (40 + a[0], -40 + a[1], z[k] + 0.004)
+        pos[3 * k + 2] = (a[0], 40 + a[1], z[k] + 0.002)
+    d = SceneDescription()
+    m = d.add_material(emission=(1.0, 1.0, 1.0))
+    v = interleave(pos, None, np.tile(np.float32([0, 0, -1]), (len(pos), 1)), np.tile(np.float32([1, 0, 0, 1]), (len(pos), 1)))
+    d.add_instance(d.add_mesh([d.add_primitive(v, np.arange(len(pos), dtype=np.uint32), m)]))
+    r = product_from(d, 16, 16, 2); o = oracle_from(d, 16, 16, 2)
+    nr = 4096
+    org = np.concatenate([rng.uniform(-30, 30, (nr, 2)), rng.uniform(-5, 35, (nr, 1))], axis=1).astype(np.float32)
+    dr = rng.normal(size=(nr, 3)).astype(np.float32); dr[:, 2] *= 4.0
+    dr /= np.linalg.norm(dr, axis=1, keepdims=True)
+    ip, uvt = r.QueryClosest(org, dr); oip, ouvt = o.trace_closest(org, dr, use_bvh=False)
+    assert np.array_equal(uvt.view(np.uint32), ouvt.view(np.uint32)) and np.array_equal(ip, oip)
+    assert (uvt[:, 2] > 0).sum() > nr // 4
+    tmax = np.full(nr, 100.0, np.float32)
+    assert np.array_equal(r.QueryAny(org, dr, tmax=tmax), o.trace_any(org, dr, tmax))
+    info = r.GetBvhInfo()
+    assert info["triangles"] == n_sheets
+    r.close(); o.close()
+
+
 # ---- size-independent properties at the full BASELINE size (no oracle run: it would take minutes) -----------------------
 def test_full_size_properties_1440p():
     from lumenrenderer_amd.scenes import sponza_standin
