@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--emulate-rank", default="", help="R/N: on ONE GPU render only rank R's window of an N-GPU tile grid (no gather); "
+                    "design aid for the per-rank time of the tiled path, never the reported benchmark line")
     args = ap.parse_args()
 
     import torch
@@ -134,8 +136,11 @@ def main():
     r.Init(depth=depth, render_resolution=(W, H), blend_output=True, device=local_rank)
     r.set_stream(torch.cuda.current_stream().cuda_stream)
     r.LoadSceneDescription(desc)
-    tile = tiles.tile_rect(rank, world, W, H)
-    win = tiles.window_rect(tile, W, H) if world > 1 else (0, 0, W, H)
+    emu = tuple(int(x) for x in args.emulate_rank.split("/")) if args.emulate_rank else None
+    if emu and world != 1:
+        raise SystemExit("--emulate-rank is a single-GPU design aid")
+    tile = tiles.tile_rect(*emu, W, H) if emu else tiles.tile_rect(rank, world, W, H)
+    win = tiles.window_rect(tile, W, H) if (world > 1 or emu) else (0, 0, W, H)
     r.SetWindow(*win)
     wh, ww = win[3] - win[1], win[2] - win[0]
     window_buf = torch.empty((wh, ww, 4), dtype=torch.float32, device=dev)
@@ -146,7 +151,7 @@ def main():
             r.TraceFrameAsync()
         r.CopyRadianceToDevice(window_buf.data_ptr())
         local = window_buf[tile[1] - win[1]: tile[3] - win[1], tile[0] - win[0]: tile[2] - win[0]]
-        return tiles.gather_tiles(local, rank, world, W, H, dist)
+        return local if emu else tiles.gather_tiles(local, rank, world, W, H, dist)
 
     def barrier():
         torch.cuda.synchronize()
@@ -187,13 +192,16 @@ def main():
     total_ms, n_traceframes = r.GetKernelTime(4)
     n_traceframes = max(1, n_traceframes)
 
-    stats = torch.tensor([dt, float(rays_last)], dtype=torch.float64, device=dev)
+    # a rank's counters include the rays of its halo pixels; those are redundant work (the neighbour owns the pixels), so
+    # only the tile's share is counted: rays scale with pixels to within RNG noise
+    tile_share = ((tile[2] - tile[0]) * (tile[3] - tile[1])) / float(ww * wh)
+    stats = torch.tensor([dt, float(rays_last) * tile_share], dtype=torch.float64, device=dev)
     if world > 1:
         tmax = stats.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = stats.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt = float(tmax[0]); rays_last_all = float(tsum[1])
     else:
-        rays_last_all = float(rays_last)
+        rays_last_all = float(rays_last) * tile_share
     if rank == 0:
         # rays/frame: the spp TraceFrame()s of one step trace (to within RNG noise) the same number of rays each
         rays_per_frame = rays_last_all * spp
@@ -230,6 +238,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kind, kw, depth, spp, (W, H))
+        if emu:
+            out["emulated_rank"] = {"rank": emu[0], "of": emu[1], "window": list(win), "tile": list(tile),
+                                    "note": "per-rank time of the tiled path on one GPU; value counts the tile's rays only"}
         print(json.dumps(out), flush=True)
     r.close()
     if world > 1:

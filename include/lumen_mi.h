@@ -127,7 +127,8 @@ int lumen_mi_get_gbuffer(lumen_mi_renderer*, float* planes8x4, size_t capacity_b
 int lumen_mi_get_frame_stat(lumen_mi_renderer*, const char* key, uint64_t* microseconds);
 /* counters of the last completed frame: [0] closest-hit rays, [1] NEE shadow rays, [2] ReSTIR shadow rays, [3] lights,
  * [4..4+depth) rays per wave, [20] BVH nodes visited in binary-node equivalents (= [22] / 2), [21] triangles tested,
- * [22] child boxes slab-tested by the 4-wide traversal ([20]..[22] only in the instrumented build) */
+ * [22] child boxes slab-tested by the 4-wide traversal, [24..40) histogram of per-ray traversal steps in log2 buckets,
+ * [40] the longest per-ray traversal in steps ([20]..[40] only in the instrumented build) */
 int lumen_mi_get_counters(lumen_mi_renderer*, uint64_t* out, uint32_t n);
 /* device time of one kernel class, summed over every frame traced since timing was enabled, measured with HIP events
  * on the renderer's stream; `launches` = number of timed launches (class 4: number of frames).
@@ -135,6 +136,10 @@ int lumen_mi_get_counters(lumen_mi_renderer*, uint64_t* out, uint32_t n);
 int lumen_mi_get_kernel_time(lumen_mi_renderer*, int which, float* milliseconds, uint32_t* launches);
 int lumen_mi_enable_kernel_timing(lumen_mi_renderer*, int enable);
 int lumen_mi_set_instrumented(lumen_mi_renderer*, int enable);   /* use the node/triangle counting traversal kernels */
+/* Scheduling knobs (no reference equivalent; none of them changes a result).  Keys: "tail_below" (waves expected to hold fewer rays run
+ * as one path-tail launch; 0 = off, -1 = automatic), "tail_lanes" (paths per wavefront in that launch, 1..64), "single_stream" (1 = no stream
+ * overlap, no frame pipelining), "refill" / "refill_visibility" (lane-refill thresholds of the queue traversal). */
+int lumen_mi_set_tuning(lumen_mi_renderer*, const char* key, int value);
 
 /* ---- tile sharding (new functionality: the reference is single-GPU) */
 /* render only [x0,x1) x [y0,y1) of the image; RNG streams stay those of the full image */

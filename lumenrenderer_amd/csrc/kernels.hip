@@ -119,20 +119,21 @@ __device__ __forceinline__ LmStack lm_make_stack(int* s_stack, const LmScene& sc
     return st;
 }
 
+// The whole 48-byte packet is fetched up front (three independent 16-byte loads, one wait) instead of row by row behind
+// the early-outs: a leaf visit then costs one memory round trip per triangle, not up to three.
 __device__ __forceinline__ bool lm_woop(const LmWoop* __restrict__ woop, uint32_t slot, const lf3& o, const lf3& d,
                                         float tmin, float tmax, float& t, float& u, float& v)
 {
-    const float4 r2 = woop[slot].r2;
+    float4 r2 = woop[slot].r2, r0 = woop[slot].r0, r1 = woop[slot].r1;
+    asm volatile("" : "+v"(r0.x), "+v"(r1.x), "+v"(r2.x));     // keep the three loads together (the compiler would sink two behind the early-outs)
     const float Oz = fmaf(r2.x, o.x, fmaf(r2.y, o.y, fmaf(r2.z, o.z, r2.w)));
     const float Dz = fmaf(r2.x, d.x, fmaf(r2.y, d.y, r2.z * d.z));
     t = -Oz / Dz;
     if (!(t > tmin && t < tmax)) return false;
-    const float4 r0 = woop[slot].r0;
     const float Ox = fmaf(r0.x, o.x, fmaf(r0.y, o.y, fmaf(r0.z, o.z, r0.w)));
     const float Dx = fmaf(r0.x, d.x, fmaf(r0.y, d.y, r0.z * d.z));
     u = fmaf(t, Dx, Ox);
     if (!(u >= 0.0f)) return false;
-    const float4 r1 = woop[slot].r1;
     const float Oy = fmaf(r1.x, o.x, fmaf(r1.y, o.y, fmaf(r1.z, o.z, r1.w)));
     const float Dy = fmaf(r1.x, d.x, fmaf(r1.y, d.y, r1.z * d.z));
     v = fmaf(t, Dy, Oy);
@@ -252,10 +253,16 @@ __device__ __forceinline__ bool lm_traverse(const LmScene& sc, const lf3& o, con
 // keeps a wave on one group at a time (best for coherent rays: an 8x8 pixel bundle stays together).
 // `done(rayIndex, found, hit)` runs once per ray.  Results are identical to lm_traverse (same tests, same tie-break).
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef LM_PRIO_RAYS
+#define LM_PRIO_RAYS 1048576u
+#endif
 template <bool ANY, class Fetch, class Done>
 __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, int refillBelow, const LmStack& stack,
                                                uint32_t* cnt, Fetch fetch, Done done)
 {
+    // A small queue cannot fill the machine: its launch time is one wave's dependent chain, which stretches when the wave
+    // shares its SIMD with VALU-bound kernels of the other streams.  Such waves ask the SIMD arbiter for priority.
+    if (n < LM_PRIO_RAYS) __builtin_amdgcn_s_setprio(3);
     const uint32_t lane = lm_lane();
     const uint32_t W = gridDim.x * (LM_BLOCK / 64u);
     uint32_t group = blockIdx.x * (LM_BLOCK / 64u) + (threadIdx.x >> 6);      // wave-uniform
@@ -270,7 +277,7 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
     int sp = 0, cur = 0;
     LmHit hit; hit.t = -1.f; hit.u = 0.f; hit.v = 0.f; hit.slot = 0;
 #if LM_INSTRUMENT
-    uint32_t nNodes = 0, nTris = 0;
+    uint32_t nNodes = 0, nTris = 0, raySteps = 0;
 #endif
     for (;;) {
         // ---- refill idle lanes from the wave's groups
@@ -290,6 +297,9 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
                 rq.bx = (sc.qmin[0] - o.x) * idx; rq.by = (sc.qmin[1] - o.y) * idy; rq.bz = (sc.qmin[2] - o.z) * idz;
                 hitT = tmax; hitOrder = 0xffffffffu; found = false; sp = 0; cur = 0;
                 active = true;
+#if LM_INSTRUMENT
+                raySteps = 0;
+#endif
             }
             used += give;
             if (used == min(64u, n - base)) { group += W; used = 0; drained = (unsigned long long)group * 64ull >= (unsigned long long)n; }
@@ -301,6 +311,7 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
             while (cur >= 0 && cur != 0x7fffffff) {
 #if LM_INSTRUMENT
                 for (int k = 0; k < 4; k++) nNodes += (int)sc.nodes[cur].c[k].w != LM_REF_NONE;  // child boxes tested
+                raySteps++;
 #endif
                 cur = lm_node_step<ANY>(sc, cur, rq, tmin, hitT, stack, sp);
             }
@@ -310,7 +321,7 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
                 for (uint32_t k = 0; k < count; k++) {
                     float t, u, v;
 #if LM_INSTRUMENT
-                    nTris++;
+                    nTris++; raySteps++;
 #endif
                     if (lm_woop(sc.woop, first + k, o, d, tmin, tmax, t, u, v)) {
                         if (ANY) { found = true; break; }
@@ -327,6 +338,11 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
             if (fin) {
                 done(rayIdx, found, hit);
                 active = false;
+#if LM_INSTRUMENT
+                // per-ray step histogram (4-wide nodes visited + triangles tested), log2 buckets, and the maximum
+                atomicAdd(cnt + LM_CNT_STEP_HIST + min(15, 31 - __clz((int)(raySteps | 1u))), 1u);
+                atomicMax(cnt + LM_CNT_STEP_MAX, raySteps);
+#endif
             }
             // all lanes still in this loop vote (the ones that just finished included): when too few keep traversing,
             // they leave the loop with their state intact so that the idle lanes can take new rays
@@ -755,6 +771,70 @@ KN(lm_k_shade_wave)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict_
             fr.rayO[outQ][rs] = v4(o, 0.f);
             fr.rayD[outQ][rs] = v4(d, u2f(li));
             fr.rayC[outQ][rs] = v4(c, 0.f);
+        }
+    }
+}
+
+// Path tail: waves `depth0 .. depthMax-1` of the rays left in the queue, one path per lane, in ONE launch (closest hit ->
+// extraction + NEE + continuation -> shadow ray -> next depth).  Deep waves hold too few rays to fill the machine, so a
+// wave-per-launch schedule pays, per depth, the dependent chain of the longest ray of the whole queue (K2-K5 + K7 + K11 +
+// K12 three launches per depth).  Here a wavefront only waits for its own `lanesPerWave` paths.  Arithmetic, RNG streams
+// and the order of the INDIRECT adds per pixel are those of the per-wave kernels (same device functions), so the result
+// is identical; ray counters are accumulated per depth like the queue appends do.
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_path_tail)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict__ inCount, int depth0, int depthMax, uint32_t seed0, int lanesPerWave)
+{
+    __shared__ int s_stack[LM_STACK_LDS * LM_BLOCK];
+    const LmStack stack = lm_make_stack(s_stack, sc);
+    const uint32_t n = *inCount;
+    __builtin_amdgcn_s_setprio(3);
+    const uint32_t lane = lm_lane(), L = (uint32_t)lanesPerWave;
+    const uint32_t W = gridDim.x * (LM_BLOCK / 64u);
+    for (uint32_t base = (blockIdx.x * (LM_BLOCK / 64u) + (threadIdx.x >> 6)) * L; base < n; base += W * L) {     // wave-uniform
+        const uint32_t i = base + lane;
+        bool alive = lane < L && i < n;
+        lf3 o = v3(0.f), d = v3(0.f), c = v3(0.f);
+        uint32_t li = 0u;
+        if (alive) {
+            const float4 o4 = fr.rayO[inQ][i], d4 = fr.rayD[inQ][i], c4 = fr.rayC[inQ][i];
+            o = v3(o4); d = v3(d4); c = v3(c4); li = f2u(d4.w);
+        }
+        uint32_t seed = seed0;
+        for (int depth = depth0; depth < depthMax; depth++) {
+            if (depth > depth0) lm_count(fr.counters + LM_CNT_RAYS(depth), alive);         // LM_CNT_RAYS(depth0) was written by the producer of the queue
+            if (__ballot(alive) == 0ull) break;
+            const uint32_t seed2 = lm_wang_hash(seed);
+            bool emitShadow = false, emitRay = false;
+            lf3 sdir = v3(0.f), srad = v3(0.f), spos = v3(0.f), o2 = v3(0.f), d2 = v3(0.f), c2 = v3(0.f);
+            float stmax = 0.f;
+            if (alive) {
+                LmHit h; h.t = -1.f; h.u = 0.f; h.v = 0.f; h.slot = 0;
+                const bool found = lm_traverse<false>(sc, o, d, 0.01f, 5000.f, stack, h, fr.counters);
+                uint4 rec = make_uint4(0u, 0u, 0u, f2u(-1.f));
+                if (found) {
+                    const uint2 id = sc.triId[h.slot];
+                    rec = make_uint4(id.x, id.y, lm_f32_to_f16(h.u) | (lm_f32_to_f16(h.v) << 16), f2u(h.t));
+                }
+                LmSurface s;
+                lm_extract(sc, rec, o, d, c, s);
+                const uint32_t ly = li / fr.ww, lx = li - ly * fr.ww;
+                const uint32_t gi = (fr.y0 + ly) * fr.W + (fr.x0 + lx);
+                emitShadow = lm_shade_direct(sc, s, gi, seed, sdir, stmax, srad);
+                spos = s.position;
+                if (depth < depthMax - 1) emitRay = lm_shade_indirect(s, gi, seed2, o2, d2, c2);
+            }
+            lm_count(fr.counters + LM_CNT_SHADOW(depth), emitShadow);
+            if (emitShadow) {
+                LmHit hs;
+                if (!lm_traverse<true>(sc, spos, sdir, 0.01f, stmax, stack, hs, fr.counters)) {
+                    float4 px = fr.indirect[li];
+                    px.x += srad.x; px.y += srad.y; px.z += srad.z;
+                    fr.indirect[li] = px;
+                }
+            }
+            alive = emitRay;
+            o = o2; d = d2; c = c2;
+            seed = lm_wang_hash(seed);
         }
     }
 }
@@ -1248,6 +1328,8 @@ static void l_extract0(hipStream_t s, int g, LmScene sc, LmFrame fr, LmCamera ca
 { hipLaunchKernelGGL(KN(lm_k_extract0), LM_GRID(g), sc, fr, cam, cur, seed2, doIndirect, outQ, outCount); }
 static void l_shade_wave(hipStream_t s, int g, LmScene sc, LmFrame fr, int inQ, const uint32_t* inCount, uint32_t seed, uint32_t seed2, int doIndirect, uint32_t* outCount, uint32_t* shadowCount)
 { hipLaunchKernelGGL(KN(lm_k_shade_wave), LM_GRID(g), sc, fr, inQ, inCount, seed, seed2, doIndirect, outCount, shadowCount); }
+static void l_path_tail(hipStream_t s, int g, LmScene sc, LmFrame fr, int inQ, const uint32_t* inCount, int depth0, int depthMax, uint32_t seed0, int lanesPerWave)
+{ hipLaunchKernelGGL(KN(lm_k_path_tail), LM_GRID(g), sc, fr, inQ, inCount, depth0, depthMax, seed0, lanesPerWave); }
 static void l_trace_shadow(hipStream_t s, int g, LmScene sc, LmFrame fr, const uint32_t* cnt, float tmin, int refillBelow) { hipLaunchKernelGGL(KN(lm_k_trace_shadow), LM_GRID(g), sc, fr, cnt, tmin, refillBelow); }
 static void l_fill_bags(hipStream_t s, LmScene sc, LmFrame fr, uint32_t seed, uint32_t total) { hipLaunchKernelGGL(KN(lm_k_fill_bags), LM_GRID((total + LM_BLOCK - 1) / LM_BLOCK), sc, fr, seed, total); }
 static void l_pick_primary(hipStream_t s, int tiles, LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount) { hipLaunchKernelGGL(KN(lm_k_pick_primary), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount); }
@@ -1270,7 +1352,7 @@ extern "C" const LmKernelTable* lm_kernel_table_instrumented()
 extern "C" const LmKernelTable* lm_kernel_table()
 #endif
 {
-    static const LmKernelTable t = {l_primary, l_trace_closest, l_extract0, l_shade_wave, l_trace_shadow, l_fill_bags, l_pick_primary,
+    static const LmKernelTable t = {l_primary, l_trace_closest, l_extract0, l_shade_wave, l_trace_shadow, l_path_tail, l_fill_bags, l_pick_primary,
                                     l_trace_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_test_bsdf, l_test_math};
     return &t;
 }

@@ -8,6 +8,7 @@ struct LmKernelTable {
     void (*extract0)(hipStream_t, int grid, LmScene, LmFrame, LmCamera, int cur, uint32_t seed2, int doIndirect, int outQ, uint32_t* outCount);
     void (*shade_wave)(hipStream_t, int grid, LmScene, LmFrame, int inQ, const uint32_t* inCount, uint32_t seed, uint32_t seed2, int doIndirect, uint32_t* outCount, uint32_t* shadowCount);
     void (*trace_shadow)(hipStream_t, int grid, LmScene, LmFrame, const uint32_t* count, float tmin, int refillBelow);
+    void (*path_tail)(hipStream_t, int grid, LmScene, LmFrame, int inQ, const uint32_t* inCount, int depth0, int depthMax, uint32_t seed0, int lanesPerWave);
     void (*fill_bags)(hipStream_t, LmScene, LmFrame, uint32_t seed, uint32_t total);
     void (*pick_primary)(hipStream_t, int tiles, LmScene, LmFrame, int cur, int rc, uint32_t seed, uint32_t* visCount);
     void (*trace_shade)(hipStream_t, int grid, LmScene, LmFrame, int rc, const uint32_t* count, int refillBelow, int pass);

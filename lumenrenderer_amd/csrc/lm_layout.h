@@ -106,9 +106,8 @@ struct LmFrame {
 #define LM_CNT_RAYS(d) (d)                       // rays entering wave d            [0, LM_MAX_DEPTH]
 #define LM_CNT_SHADOW(d) (32 + (d))              // NEE shadow rays emitted by wave d
 #define LM_CNT_RESTIR(p) (70 + (p))              // ReSTIR visibility rays of pass p (0, 1)
-#define LM_CNT_HEAD_CLOSEST(d) (96 + (d))        // queue heads of the persistent traversal kernels (zeroed every frame)
-#define LM_CNT_HEAD_SHADOW(d) (112 + (d))
-#define LM_CNT_HEAD_RESTIR(p) (128 + (p))
+#define LM_CNT_STEP_HIST 96                       // instrumented build only: 16 log2 buckets of per-ray traversal steps (queue kernels)
+#define LM_CNT_STEP_MAX 112                       // instrumented build only: longest per-ray traversal (steps)
 #define LM_CNT_NODES 66                          // instrumented build only: child boxes slab-tested (u64 as 2 words); 2 boxes = one binary node of SURVEY 8 d4
 #define LM_CNT_TRIS 68                           // instrumented build only: triangles tested (u64 as 2 words)
 #define LM_CNT_WORDS 136

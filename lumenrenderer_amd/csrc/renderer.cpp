@@ -99,6 +99,11 @@ struct lumen_mi_renderer {
     int numCU = 256;
     const LmKernelTable* K = nullptr;
     bool instrumented = false;
+    int tailBelow = -1;                     // waves expected to hold fewer rays than this run as one path-tail launch (0 = off,
+                                            // -1 = auto: 65536 for windows under 2 Mpixel, where the wave chain is the critical path, else 16384) ...
+    int tailLanes = 16;                     // ... with this many paths per wavefront
+    uint32_t* pinnedCounters[2] = {nullptr, nullptr}; hipEvent_t evCnt[2] = {nullptr, nullptr}; bool cntPending[2] = {false, false};
+    uint32_t estRays[LM_MAX_DEPTH + 1] = {0}; bool haveEst = false;     // rays per wave of the most recent frame that has been read back
     int refillBelow = 40, refillVisibility = 0;      // lane-refill thresholds of the queue traversal kernels (tunable via LUMEN_MI_REFILL*)
 
     lumen_mi_settings settings{};
@@ -441,6 +446,7 @@ int ensureFrameBuffers(R* r)
     if (hipMemsetAsync(f.output, 0, (size_t)n * sizeof(uchar4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
     r->allocN = n;
     r->fenceNeeded = true;
+    r->haveEst = false; r->cntPending[0] = r->cntPending[1] = false;
     r->blendCounter = 0; r->frameIndex = 0; r->swapChainIndex = 0;
     return 0;
 }
@@ -555,6 +561,19 @@ int traceFrameAsync(R* r)
     if (overlap) scx.spill += (size_t)r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS);
     const int gridMain = r->numCU * r->traceBlocksMain, gridAux = r->numCU * (overlap ? r->traceBlocksAux : r->traceBlocksMain);
     const int tiles = (int)(((fr.ww + 15u) / 16u) * ((fr.wh + 15u) / 16u));
+    // Deep waves hold too few rays to fill the machine; from the first wave expected to be shorter than `tailBelow` rays the
+    // remaining depths run as one launch.  The expectation comes from the counters of the most recent frame whose
+    // asynchronous read-back has already landed (no host synchronisation; any choice gives the same image).
+    for (int p : {par ^ 1, par}) {
+        if (r->cntPending[p] && hipEventQuery(r->evCnt[p]) == hipSuccess) {
+            for (uint32_t dd = 0; dd <= LM_MAX_DEPTH; dd++) r->estRays[dd] = r->pinnedCounters[p][LM_CNT_RAYS(dd)];
+            r->haveEst = true; r->cntPending[p] = false;
+            break;
+        }
+    }
+    int tailDepth = (int)depthMax;
+    const uint32_t tailBelow = r->tailBelow >= 0 ? (uint32_t)r->tailBelow : (fr.n < (1u << 21) ? 65536u : 16384u);
+    if (tailBelow && r->haveEst) for (uint32_t dd = 1; dd < depthMax; dd++) if (r->estRays[dd] < tailBelow) { tailDepth = (int)dd; break; }
     int q = 0;
     size_t ev;
     for (uint32_t depth = 0; depth < depthMax; ++depth) {
@@ -601,6 +620,15 @@ int traceFrameAsync(R* r)
             if (overlap) LM_HIP(hipStreamWaitEvent(st, r->evVisDone, 0));
             K->combine(st, tiles, fr, currentIndex, cur, 3, wangHash(rs));
             evEnd(r, ev);
+        } else if ((int)depth >= tailDepth) {
+            // path tail: the remaining waves in one launch (kernels.hip lm_k_path_tail); its INDIRECT adds follow the previous
+            // wave's NEE adds (third stream)
+            if (overlap) LM_HIP(hipStreamWaitEvent(sx, r->evJoin2, 0));
+            evBegin2(r, 0, ev, sx);
+            K->path_tail(sx, r->numCU * 8, scx, fr, q, inCount, (int)depth, (int)depthMax, seed, r->tailLanes);
+            evEnd2(r, ev, sx);
+            for (uint32_t dd = depth; dd < depthMax; ++dd) r->swapChainIndex = r->swapChainIndex + 1 >= 2 ? 0 : r->swapChainIndex + 1;   // one SwapBuffers per wave (:827)
+            break;
         } else {
             uint32_t* shCount = fr.counters + LM_CNT_SHADOW(depth);
             evBegin2(r, 0, ev, sx);
@@ -627,6 +655,11 @@ int traceFrameAsync(R* r)
     if (overlap) { LM_HIP(hipEventRecord(r->evJoin, sx)); LM_HIP(hipStreamWaitEvent(st, r->evJoin, 0)); if (depthMax > 1) LM_HIP(hipStreamWaitEvent(st, r->evJoin2, 0)); }
     K->merge(st, r->gridFor(fr.n, 8), fr, blend ? 1 : 0, r->blendCounter);
     if (overlap) LM_HIP(hipEventRecord(r->evMerge[par], st));
+    if (r->pinnedCounters[par]) {     // asynchronous counter read-back: feeds the next frames' schedule (above)
+        LM_HIP(hipMemcpyAsync(r->pinnedCounters[par], fr.counters, LM_CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        LM_HIP(hipEventRecord(r->evCnt[par], st));
+        r->cntPending[par] = true;
+    }
     evEnd(r, evAll);
     LM_HIP(hipGetLastError());
     r->lastDepth = depthMax;
@@ -679,6 +712,8 @@ int lumen_mi_create(lumen_mi_renderer** out)
     (*out)->K = lm_kernel_table();
     if (const char* e = getenv("LUMEN_MI_REFILL")) (*out)->refillBelow = atoi(e);
     if (const char* e = getenv("LUMEN_MI_REFILL_VIS")) (*out)->refillVisibility = atoi(e);
+    if (const char* e = getenv("LUMEN_MI_TAIL_BELOW")) (*out)->tailBelow = atoi(e);
+    if (const char* e = getenv("LUMEN_MI_TAIL_LANES")) (*out)->tailLanes = std::max(1, std::min(64, atoi(e)));
     return 0;
 }
 
@@ -717,6 +752,7 @@ int lumen_mi_init(lumen_mi_renderer* r, const lumen_mi_settings* s)
         LM_HIP(hipEventCreateWithFlags(&r->evTemporal, hipEventDisableTiming));
         LM_HIP(hipEventCreateWithFlags(&r->evTop, hipEventDisableTiming));
         for (auto& e : r->evMerge) LM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (int i = 0; i < 2; i++) { LM_HIP(hipEventCreateWithFlags(&r->evCnt[i], hipEventDisableTiming)); LM_HIP(hipHostMalloc((void**)&r->pinnedCounters[i], LM_CNT_WORDS * sizeof(uint32_t), hipHostMallocDefault)); }
         LM_HIP(hipEventCreateWithFlags(&r->evJoin, hipEventDisableTiming));
     }
     r->initialised = true;
@@ -730,7 +766,7 @@ int lumen_mi_destroy(lumen_mi_renderer* r)
     if (r->initialised) {
         (void)hipSetDevice(r->device);
         (void)hipStreamSynchronize(r->stream);
-        if (r->aux) { (void)hipStreamSynchronize(r->aux); (void)hipStreamSynchronize(r->aux2); (void)hipStreamDestroy(r->aux2); (void)hipStreamSynchronize(r->aux3); (void)hipStreamDestroy(r->aux3); (void)hipEventDestroy(r->evVis); (void)hipEventDestroy(r->evVisDone); (void)hipEventDestroy(r->evJoin2); for (auto& e : r->evShade) (void)hipEventDestroy(e); (void)hipStreamDestroy(r->aux); (void)hipEventDestroy(r->evFront); (void)hipEventDestroy(r->evTemporal); (void)hipEventDestroy(r->evTop); for (auto& e : r->evMerge) (void)hipEventDestroy(e); (void)hipEventDestroy(r->evJoin); }
+        if (r->aux) { (void)hipStreamSynchronize(r->aux); (void)hipStreamSynchronize(r->aux2); (void)hipStreamDestroy(r->aux2); (void)hipStreamSynchronize(r->aux3); (void)hipStreamDestroy(r->aux3); (void)hipEventDestroy(r->evVis); (void)hipEventDestroy(r->evVisDone); (void)hipEventDestroy(r->evJoin2); for (auto& e : r->evShade) (void)hipEventDestroy(e); (void)hipStreamDestroy(r->aux); (void)hipEventDestroy(r->evFront); (void)hipEventDestroy(r->evTemporal); (void)hipEventDestroy(r->evTop); for (auto& e : r->evMerge) (void)hipEventDestroy(e); for (int i = 0; i < 2; i++) { (void)hipEventDestroy(r->evCnt[i]); (void)hipHostFree(r->pinnedCounters[i]); r->pinnedCounters[i] = nullptr; } (void)hipEventDestroy(r->evJoin); }
         r->dSpill.release(); r->dNodes.release(); r->dWoop.release(); r->dTriId.release(); r->dTriOrder.release(); r->dVerts.release(); r->dIndices.release();
         r->dEntries.release(); r->dMaterials.release(); r->dTexDesc.release(); r->dTexels.release(); r->dLut.release(); r->dLights.release(); r->dCdf.release();
         for (auto& b : r->dRay) b.release(); for (auto& b : r->dSh) b.release(); for (auto& b : r->dSh2) b.release(); for (auto& b : r->dGbuf) b.release(); for (auto& b : r->dProbe) b.release(); for (auto& b : r->dRes) b.release(); for (auto& b : r->dResC) b.release();
@@ -1049,7 +1085,7 @@ int lumen_mi_get_counters(lumen_mi_renderer* r, uint64_t* out, uint32_t n)
 {
     if (!r || !out) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
     { std::lock_guard<std::mutex> lk(r->frameMutex); int rc = syncAndCollect(r); if (rc) return rc; }
-    uint64_t v[24] = {0};
+    uint64_t v[48] = {0};
     const uint32_t* c = r->hostCounters;
     for (uint32_t d = 0; d < r->lastDepth && d < 16; d++) { v[0] += c[LM_CNT_RAYS(d)]; v[4 + d] = c[LM_CNT_RAYS(d)]; v[1] += c[LM_CNT_SHADOW(d)]; }
     v[2] = (uint64_t)c[LM_CNT_RESTIR(0)] + c[LM_CNT_RESTIR(1)];
@@ -1057,7 +1093,9 @@ int lumen_mi_get_counters(lumen_mi_renderer* r, uint64_t* out, uint32_t n)
     v[22] = (uint64_t)c[LM_CNT_NODES] | ((uint64_t)c[LM_CNT_NODES + 1] << 32);     // child boxes slab-tested
     v[20] = v[22] / 2;                                                                 // = binary-node equivalents (2 boxes per node)
     v[21] = (uint64_t)c[LM_CNT_TRIS] | ((uint64_t)c[LM_CNT_TRIS + 1] << 32);
-    for (uint32_t i = 0; i < n && i < 24; i++) out[i] = v[i];
+    for (int k = 0; k < 16; k++) v[24 + k] = c[LM_CNT_STEP_HIST + k];
+    v[40] = c[LM_CNT_STEP_MAX];
+    for (uint32_t i = 0; i < n && i < 48; i++) out[i] = v[i];
     return 0;
 }
 int lumen_mi_get_kernel_time(lumen_mi_renderer* r, int which, float* ms, uint32_t* launches)
@@ -1071,6 +1109,19 @@ int lumen_mi_enable_kernel_timing(lumen_mi_renderer* r, int e)
     if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer");
     if (e) { for (int c = 0; c < 5; c++) { r->classMs[c] = 0.f; r->classLaunches[c] = 0; } }      // enabling starts a new accumulation window
     r->timing = e != 0;
+    return 0;
+}
+int lumen_mi_set_tuning(lumen_mi_renderer* r, const char* key, int value)
+{
+    if (!r || !key) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lk(r->frameMutex);
+    const std::string k = key;
+    if (k == "tail_below") r->tailBelow = value;
+    else if (k == "tail_lanes") r->tailLanes = std::max(1, std::min(64, value));
+    else if (k == "single_stream") { if (r->initialised) { int rc = syncAndCollect(r); if (rc) return rc; } r->overlap = value == 0; }
+    else if (k == "refill") r->refillBelow = value;
+    else if (k == "refill_visibility") r->refillVisibility = value;
+    else return fail(LUMEN_MI_ERR_INVALID, std::string("unknown tuning key: ") + key);
     return 0;
 }
 int lumen_mi_set_instrumented(lumen_mi_renderer* r, int e) { if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer"); r->instrumented = e != 0; r->K = e ? lm_kernel_table_instrumented() : lm_kernel_table(); return 0; }

@@ -239,6 +239,7 @@ class LumenRendererMI:
 
     def EnableKernelTiming(self, on=True): check(self.lib, self.lib.lumen_mi_enable_kernel_timing(self.h, int(on)))
     def SetInstrumented(self, on=True): check(self.lib, self.lib.lumen_mi_set_instrumented(self.h, int(on)))
+    def SetTuning(self, key, value): check(self.lib, self.lib.lumen_mi_set_tuning(self.h, key.encode(), int(value)))
 
     def GetKernelTime(self, which):
         ms, n = C.c_float(), C.c_uint32(); check(self.lib, self.lib.lumen_mi_get_kernel_time(self.h, which, C.byref(ms), C.byref(n))); return ms.value, n.value

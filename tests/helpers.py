@@ -35,7 +35,7 @@ def oracle_from(desc, width, height, depth, blend=False, threads=None, window=No
     return o
 
 
-def product_from(desc, width, height, depth, blend=False, window=None, device=0):
+def product_from(desc, width, height, depth, blend=False, window=None, device=0, tuning=None):
     from lumenrenderer_amd import LumenRendererMI
     r = LumenRendererMI()
     r.Init(depth=depth, render_resolution=(width, height), blend_output=blend, device=device)
@@ -44,6 +44,8 @@ def product_from(desc, width, height, depth, blend=False, window=None, device=0)
         r.SetBlendMode(True)
     if window:
         r.SetWindow(*window)
+    for k, v in (tuning or {}).items():
+        r.SetTuning(k, v)
     return r
 
 

@@ -180,6 +180,23 @@ def test_sponza_with_1024_emissive_triangles_matches_oracle():
     r.close(); o.close()
 
 
+TUNINGS = [{"tail_below": 0}, {"tail_below": 1 << 30}, {"tail_below": 6000}, {"tail_below": 6000, "tail_lanes": 64},
+           {"single_stream": 1, "tail_below": 0}, {"single_stream": 1}, {"refill": 0, "tail_below": 0}]
+
+
+@pytest.mark.parametrize("tuning", TUNINGS, ids=lambda t: ",".join(f"{k}={v}" for k, v in t.items()))
+def test_schedules_do_not_change_results(tuning):
+    """Per-wave kernels vs the one-launch path tail (chosen on the device from the queue length), stream overlap on/off,
+    lane refill: every schedule must reproduce the oracle bit for bit, counters included."""
+    from lumenrenderer_amd.scenes import sponza_standin
+    for d, (w, h, depth), frames in ((cornell(), (160, 120, 5), 3), (sponza_standin(), (192, 108, 6), 2)):
+        r = product_from(d, w, h, depth, blend=True, tuning=tuning); o = oracle_from(d, w, h, depth, blend=True)
+        _compare_frames(r, o, frames, check_gbuffer=False)
+        c, s = r.GetCounters(), o.stats(24)
+        assert list(c[4:4 + depth]) == list(s[4:4 + depth]), (c[4:4 + depth], s[4:4 + depth])     # rays per wave
+        r.close(); o.close()
+
+
 def test_pipelined_async_frames_match_oracle():
     """Frames enqueued back to back (TraceFrameAsync, one Synchronize at the end) run software-pipelined on four streams:
     the next frame's front overlaps the ReSTIR tail of the current one.  The blended result must still be the oracle's."""
