@@ -6,6 +6,7 @@
 // every transform change anyway, PTScene.cpp:145-153).  Node boxes are padded by 2^-15 * (largest |coordinate|)
 // so that box tests are conservative with respect to the fp32 Woop triangle test (DESIGN.md "Traversal").
 #include "bvh.h"
+#include "lm_woop.h"
 
 #include <algorithm>
 #include <cmath>
@@ -126,31 +127,6 @@ struct Builder {
 
 }  // namespace
 
-LmWoop lm_make_woop(const float* t)
-{
-    const double v0[3] = {t[0], t[1], t[2]};
-    const double e1[3] = {(double)t[3] - t[0], (double)t[4] - t[1], (double)t[5] - t[2]};
-    const double e2[3] = {(double)t[6] - t[0], (double)t[7] - t[1], (double)t[8] - t[2]};
-    const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
-    const double det = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
-    LmWoop w;
-    memset(&w, 0, sizeof w);
-    if (!(det > 0.0) || !std::isfinite(det)) return w;         // degenerate triangle: the zero packet never reports a hit
-    const double ru[3] = {e2[1] * n[2] - e2[2] * n[1], e2[2] * n[0] - e2[0] * n[2], e2[0] * n[1] - e2[1] * n[0]};
-    const double rv[3] = {n[1] * e1[2] - n[2] * e1[1], n[2] * e1[0] - n[0] * e1[2], n[0] * e1[1] - n[1] * e1[0]};
-    float r0[4], r1[4], r2[4];
-    double du = 0, dv = 0, dw = 0;
-    for (int i = 0; i < 3; i++) {
-        r0[i] = (float)(ru[i] / det); r1[i] = (float)(rv[i] / det); r2[i] = (float)(n[i] / det);
-        du -= ru[i] / det * v0[i]; dv -= rv[i] / det * v0[i]; dw -= n[i] / det * v0[i];
-    }
-    r0[3] = (float)du; r1[3] = (float)dv; r2[3] = (float)dw;
-    w.r0 = make_float4(r0[0], r0[1], r0[2], r0[3]);
-    w.r1 = make_float4(r1[0], r1[1], r1[2], r1[3]);
-    w.r2 = make_float4(r2[0], r2[1], r2[2], r2[3]);
-    return w;
-}
-
 void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out)
 {
     out->nodes.clear(); out->order.clear(); out->woop.clear();
@@ -223,10 +199,12 @@ void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out)
     out->nodes4.clear();
     out->nodes4.reserve(out->nodes.size() / 2 + 1);
     out->maxStack = 1;
-    struct Work { int node2; int node4; uint32_t stack; };
+    struct Work { int node2; int node4; uint32_t stack; uint32_t depth; };
+    std::vector<uint32_t> depthOf;
     std::vector<Work> work;
     out->nodes4.emplace_back();
-    work.push_back({0, 0, 0});
+    work.push_back({0, 0, 0, 0});
+    depthOf.push_back(0);
     while (!work.empty()) {
         const Work w = work.back(); work.pop_back();
         Child c[4];
@@ -252,11 +230,21 @@ void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out)
             if (ref >= 0) {
                 const int id4 = (int)out->nodes4.size();
                 out->nodes4.emplace_back();
-                work.push_back({ref, id4, stackBelow});
+                work.push_back({ref, id4, stackBelow, w.depth + 1});
+                depthOf.push_back(w.depth + 1);
                 ref = id4;
             }
             q.c[i] = make_uint4(p[0], p[1], p[2], (uint32_t)ref);
         }
         out->nodes4[w.node4] = q;
     }
+    // nodes grouped by depth (deepest level first): the order in which a bottom-up refit visits them
+    uint32_t maxD = 0;
+    for (uint32_t d : depthOf) maxD = std::max(maxD, d);
+    out->levelStart.assign(maxD + 2, 0);
+    for (uint32_t d : depthOf) out->levelStart[maxD - d + 1]++;
+    for (uint32_t l = 0; l <= maxD; l++) out->levelStart[l + 1] += out->levelStart[l];
+    out->levelNodes.resize(depthOf.size());
+    std::vector<uint32_t> fill(out->levelStart.begin(), out->levelStart.end() - 1);
+    for (uint32_t i = 0; i < depthOf.size(); i++) out->levelNodes[fill[maxD - depthOf[i]]++] = i;
 }

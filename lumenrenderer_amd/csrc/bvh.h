@@ -12,7 +12,8 @@ struct LmBvh {
     uint32_t maxDepth = 0;              // of the binary tree
     uint32_t maxStack = 0;              // worst-case traversal stack occupancy of the 4-wide tree
     float pad = 0.f;
+    std::vector<uint32_t> levelNodes;   // 4-wide node indices grouped by depth, deepest level first ...
+    std::vector<uint32_t> levelStart;   // ... level l = levelNodes[levelStart[l] .. levelStart[l + 1])   (GPU refit order)
 };
 // tris: 9 floats per triangle (world space)
 void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out);
-LmWoop lm_make_woop(const float* tri9);

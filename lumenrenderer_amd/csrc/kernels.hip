@@ -9,6 +9,7 @@
 // grid-stride over device-side counters so a frame needs no host round trip.
 #include "lm_layout.h"
 #include "lm_bsdf.h"
+#include "lm_woop.h"
 
 #define LM_BLOCK 256
 #ifndef LM_RESTIR_WAVES
@@ -199,8 +200,8 @@ __device__ __forceinline__ bool lm_traverse(const LmScene& sc, const lf3& o, con
     const float idx = lm_safe_rcp(d.x), idy = lm_safe_rcp(d.y), idz = lm_safe_rcp(d.z);
     // node boxes are 16-bit fixed point: world = qmin + q * qstep, so t = q * (qstep * idir) + (qmin - o) * idir
     LmRayQ rq;
-    rq.ax = sc.qstep[0] * idx; rq.ay = sc.qstep[1] * idy; rq.az = sc.qstep[2] * idz;
-    rq.bx = (sc.qmin[0] - o.x) * idx; rq.by = (sc.qmin[1] - o.y) * idy; rq.bz = (sc.qmin[2] - o.z) * idz;
+    rq.ax = sc.quant[3] * idx; rq.ay = sc.quant[4] * idy; rq.az = sc.quant[5] * idz;
+    rq.bx = (sc.quant[0] - o.x) * idx; rq.by = (sc.quant[1] - o.y) * idy; rq.bz = (sc.quant[2] - o.z) * idz;
     float hitT = tmax;
     uint32_t hitOrder = 0xffffffffu;
     bool found = false;
@@ -293,8 +294,8 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
                 rayIdx = base + used + rank;
                 fetch(rayIdx, o, d, tmin, tmax);
                 const float idx = lm_safe_rcp(d.x), idy = lm_safe_rcp(d.y), idz = lm_safe_rcp(d.z);
-                rq.ax = sc.qstep[0] * idx; rq.ay = sc.qstep[1] * idy; rq.az = sc.qstep[2] * idz;
-                rq.bx = (sc.qmin[0] - o.x) * idx; rq.by = (sc.qmin[1] - o.y) * idy; rq.bz = (sc.qmin[2] - o.z) * idz;
+                rq.ax = sc.quant[3] * idx; rq.ay = sc.quant[4] * idy; rq.az = sc.quant[5] * idz;
+                rq.bx = (sc.quant[0] - o.x) * idx; rq.by = (sc.quant[1] - o.y) * idy; rq.bz = (sc.quant[2] - o.z) * idz;
                 hitT = tmax; hitOrder = 0xffffffffu; found = false; sp = 0; cur = 0;
                 active = true;
 #if LM_INSTRUMENT
@@ -1319,6 +1320,105 @@ KN(lm_k_test_math)(uint32_t n, int fn, const float* __restrict__ x, const float*
 // launch table: this file is compiled twice (LM_INSTRUMENT = 0 / 1); the renderer picks a table at run time
 // ---------------------------------------------------------------------------------------------------------------------
 #include "lm_launch.h"
+// ---------------------------------------------------------------------------------------------------------------------
+// BVH refit for moved instances (reference: the per-frame instance acceleration-structure rebuild of PTScene.cpp:74-156,
+// PTMeshInstance.cpp:123-178).  Topology and leaf contents stay; triangles are re-transformed, Woop packets recomputed
+// (bit-identical to the host builder: lm_woop.h), boxes propagated bottom-up level by level and re-quantised against the
+// new scene box.  Boxes only cull, so the hit records equal those of a freshly built tree.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lm_ordered(float f) { const uint32_t u = f2u(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float lm_unordered(uint32_t u) { return u2f((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+__device__ __forceinline__ float lm_wave_min(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ float lm_wave_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
+// bounds[0..2] min, [3..5] max (order-preserving encoding), [6] max |coordinate| (bits of a non-negative float)
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_refit_tris)(LmScene sc, uint32_t nSlots, float4* __restrict__ triBox, uint32_t* bounds)
+{
+    const uint32_t s = blockIdx.x * LM_BLOCK + threadIdx.x;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, maxAbs = 0.f;
+    if (s < nSlots) {
+        const uint2 id = sc.triId[s];
+        const LmEntry e = sc.entries[id.x];
+        float tri[9];
+        for (int k = 0; k < 3; k++) {
+            const uint32_t vi = sc.indices[e.idxBase + 3u * id.y + (uint32_t)k];
+            const float4 p = sc.verts[3u * (e.vertBase + vi)];
+            // rows 0..2 of the world matrix, operation order of the host flatten (sutil Matrix4x4 * float4)
+            tri[3 * k + 0] = e.m[0] * p.x + e.m[1] * p.y + e.m[2] * p.z + e.m[3] * 1.f;
+            tri[3 * k + 1] = e.m[4] * p.x + e.m[5] * p.y + e.m[6] * p.z + e.m[7] * 1.f;
+            tri[3 * k + 2] = e.m[8] * p.x + e.m[9] * p.y + e.m[10] * p.z + e.m[11] * 1.f;
+        }
+        sc.woop[s] = lm_make_woop(tri);
+        for (int k = 0; k < 9; k++) { lo[k % 3] = fminf(lo[k % 3], tri[k]); hi[k % 3] = fmaxf(hi[k % 3], tri[k]); maxAbs = fmaxf(maxAbs, fabsf(tri[k])); }
+        triBox[2u * s] = make_float4(lo[0], lo[1], lo[2], 0.f);
+        triBox[2u * s + 1u] = make_float4(hi[0], hi[1], hi[2], 0.f);
+    }
+    for (int k = 0; k < 3; k++) { lo[k] = lm_wave_min(lo[k]); hi[k] = lm_wave_max(hi[k]); }
+    maxAbs = lm_wave_max(maxAbs);
+    if (lm_lane() == 0u && lo[0] <= hi[0]) {
+        for (int k = 0; k < 3; k++) { atomicMin(bounds + k, lm_ordered(lo[k])); atomicMax(bounds + 3 + k, lm_ordered(hi[k])); }
+        atomicMax(bounds + 6, f2u(maxAbs));
+    }
+}
+// scene box -> quantisation frame (the formulas of lm_build_bvh), then re-arm the bounds for the next refit
+extern "C" __global__ void KN(lm_k_refit_quant)(uint32_t* bounds, float* quant)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const float pad = u2f(bounds[6]) * (1.0f / 32768.0f);
+    for (int k = 0; k < 3; k++) {
+        float smin = lm_unordered(bounds[k]), smax = lm_unordered(bounds[3 + k]);
+        if (!(smin <= smax)) { smin = 0.f; smax = 1.f; }
+        const float m = 4.f * pad + 1e-6f * fmaxf(fabsf(smin), fabsf(smax)) + 1e-30f;
+        smin -= m; smax += m;
+        quant[k] = smin;
+        quant[3 + k] = (smax - smin) / 65535.0f;
+        bounds[k] = 0xffffffffu; bounds[3 + k] = 0u;
+    }
+    quant[6] = pad;
+    bounds[6] = 0u;
+}
+__device__ __forceinline__ uint32_t lm_quant_axis(float lo, float hi, float qmin, float qstep)
+{
+    const double inv = 1.0 / (double)qstep;
+    long long ql = (long long)floor(((double)lo - (double)qmin) * inv) - 1;
+    long long qh = (long long)ceil(((double)hi - (double)qmin) * inv) + 1;
+    ql = ql < 0 ? 0 : (ql > 65535 ? 65535 : ql); qh = qh < 0 ? 0 : (qh > 65535 ? 65535 : qh);
+    return (uint32_t)ql | ((uint32_t)qh << 16);
+}
+// one depth level of the 4-wide tree (children of these nodes are leaves or nodes of deeper, already refitted levels)
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_refit_level)(LmScene sc, const uint32_t* __restrict__ levelNodes, uint32_t count, const float4* __restrict__ triBox, float4* nodeBox)
+{
+    const uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t n = levelNodes[i];
+    const float pad = sc.quant[6];
+    lf3 nlo = v3(INFINITY), nhi = v3(-INFINITY);
+    for (int k = 0; k < 4; k++) {
+        uint4 c = sc.nodes[n].c[k];
+        const int ref = (int)c.w;
+        if (ref == LM_REF_NONE) continue;
+        lf3 lo = v3(INFINITY), hi = v3(-INFINITY);
+        if (ref < 0) {
+            const uint32_t leaf = (uint32_t)(~ref), first = leaf >> 3, cnt = (leaf & 7u) + 1u;
+            for (uint32_t t = 0; t < cnt; t++) {
+                const float4 a = triBox[2u * (first + t)], b = triBox[2u * (first + t) + 1u];
+                lo = v3(fminf(lo.x, a.x), fminf(lo.y, a.y), fminf(lo.z, a.z)); hi = v3(fmaxf(hi.x, b.x), fmaxf(hi.y, b.y), fmaxf(hi.z, b.z));
+            }
+        } else {
+            const float4 a = nodeBox[2u * (uint32_t)ref], b = nodeBox[2u * (uint32_t)ref + 1u];
+            lo = v3(a); hi = v3(b);
+        }
+        nlo = v3(fminf(nlo.x, lo.x), fminf(nlo.y, lo.y), fminf(nlo.z, lo.z)); nhi = v3(fmaxf(nhi.x, hi.x), fmaxf(nhi.y, hi.y), fmaxf(nhi.z, hi.z));
+        c.x = lm_quant_axis(lo.x - pad, hi.x + pad, sc.quant[0], sc.quant[3]);
+        c.y = lm_quant_axis(lo.y - pad, hi.y + pad, sc.quant[1], sc.quant[4]);
+        c.z = lm_quant_axis(lo.z - pad, hi.z + pad, sc.quant[2], sc.quant[5]);
+        sc.nodes[n].c[k] = c;
+    }
+    nodeBox[2u * n] = v4(nlo, 0.f);
+    nodeBox[2u * n + 1u] = v4(nhi, 0.f);
+}
+
 #define LM_GRID(g) dim3((unsigned)(g)), dim3(LM_BLOCK), 0, s
 
 static void l_primary(hipStream_t s, int g, LmFrame fr, LmCamera cam, uint32_t frameCount) { hipLaunchKernelGGL(KN(lm_k_primary), LM_GRID(g), fr, cam, frameCount); }
@@ -1342,6 +1442,9 @@ static void l_merge(hipStream_t s, int g, LmFrame fr, int blend, uint32_t blendC
 static void l_query_any(hipStream_t s, int g, LmScene sc, const float4* o, const float4* d, uint32_t n, float tmin, uint32_t* occ, uint32_t* counters) { hipLaunchKernelGGL(KN(lm_k_query_any), LM_GRID(g), sc, o, d, n, tmin, occ, counters); }
 static void l_query_closest(hipStream_t s, int g, LmScene sc, const float4* o, const float4* d, uint32_t n, float tmin, float tmax, uint4* id, float4* uvt, uint32_t* counters)
 { hipLaunchKernelGGL(KN(lm_k_query_closest_raw), LM_GRID(g), sc, o, d, n, tmin, tmax, id, uvt, counters); }
+static void l_refit_tris(hipStream_t s, LmScene sc, uint32_t nSlots, float4* triBox, uint32_t* bounds) { hipLaunchKernelGGL(KN(lm_k_refit_tris), LM_GRID((nSlots + LM_BLOCK - 1) / LM_BLOCK), sc, nSlots, triBox, bounds); }
+static void l_refit_quant(hipStream_t s, uint32_t* bounds, float* quant) { hipLaunchKernelGGL(KN(lm_k_refit_quant), dim3(1), dim3(64), 0, s, bounds, quant); }
+static void l_refit_level(hipStream_t s, LmScene sc, const uint32_t* levelNodes, uint32_t count, const float4* triBox, float4* nodeBox) { hipLaunchKernelGGL(KN(lm_k_refit_level), LM_GRID((count + LM_BLOCK - 1) / LM_BLOCK), sc, levelNodes, count, triBox, nodeBox); }
 static void l_test_bsdf(hipStream_t s, uint32_t n, int mode, const float* mat, const float* N, const float* T, const float* wo, const float* aux, float* out)
 { hipLaunchKernelGGL(KN(lm_k_test_bsdf), LM_GRID((n + LM_BLOCK - 1) / LM_BLOCK), n, mode, mat, N, T, wo, aux, out); }
 static void l_test_math(hipStream_t s, uint32_t n, int fn, const float* x, const float* y, float* out) { hipLaunchKernelGGL(KN(lm_k_test_math), LM_GRID((n + LM_BLOCK - 1) / LM_BLOCK), n, fn, x, y, out); }
@@ -1353,6 +1456,6 @@ extern "C" const LmKernelTable* lm_kernel_table()
 #endif
 {
     static const LmKernelTable t = {l_primary, l_trace_closest, l_extract0, l_shade_wave, l_trace_shadow, l_path_tail, l_fill_bags, l_pick_primary,
-                                    l_trace_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_test_bsdf, l_test_math};
+                                    l_trace_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_refit_tris, l_refit_quant, l_refit_level, l_test_bsdf, l_test_math};
     return &t;
 }

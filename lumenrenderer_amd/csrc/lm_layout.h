@@ -58,9 +58,10 @@ struct LmTexDesc { uint32_t offset, w, h, srgb; };
 struct LmLight { float4 a, b, c, d; };   // a = p0.xyz p1.x | b = p1.yz p2.xy | c = p2.z n.xyz | d = radiance.xyz area
 
 struct LmScene {
-    const LmNode4* nodes;
-    float qmin[3], qstep[3];    // dequantisation of node boxes: world = qmin + q * qstep
-    const LmWoop* woop;
+    LmNode4* nodes;             // written only by the refit kernels
+    const float* quant;         // dequantisation of node boxes, in device memory so that a refit can move it without a host
+                                // round trip: [0..2] qmin, [3..5] qstep (world = qmin + q * qstep), [6] box padding
+    LmWoop* woop;               // written only by the refit kernels
     const uint2* triId;         // per BVH triangle slot: (table entry, primitive-local triangle), .x|0x80000000 never used
     const uint32_t* triOrder;   // per BVH triangle slot: global triangle index (tie-break key)
     const float4* verts;        // 3 float4 per vertex: (pos.xyz, uv.x) (uv.y, n.xyz) (tangent.xyzw)

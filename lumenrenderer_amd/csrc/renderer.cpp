@@ -118,6 +118,9 @@ struct lumen_mi_renderer {
     std::vector<Instance> instances;
     long activeScene = -1;
     bool sceneDirty = true, texturesDirty = true, materialsDirty = true;
+    bool transformsDirty = false;           // only instance matrices changed since the last build: the BVH is refitted on the GPU
+    uint32_t refits = 0;                    // refits since the last full build
+    int refitEnabled = 1;                   // 0: every transform change triggers a full host rebuild
 
     // camera
     float camPos[3] = {0, 0, 0}, camRight[3] = {-1, 0, 0}, camUp[3] = {0, 1, 0}, camFwd[3] = {0, 0, 1};
@@ -144,6 +147,7 @@ struct lumen_mi_renderer {
     // device scene
     DevBuf<LmNode4> dNodes; DevBuf<LmWoop> dWoop; DevBuf<uint2> dTriId; DevBuf<uint32_t> dTriOrder;
     DevBuf<float4> dVerts; DevBuf<uint32_t> dIndices; DevBuf<LmEntry> dEntries; DevBuf<LmDevMaterial> dMaterials;
+    DevBuf<float> dQuant; DevBuf<float4> dTriBox, dNodeBox; DevBuf<uint32_t> dLevelNodes, dRefitBounds;
     DevBuf<int> dSpill; DevBuf<LmTexDesc> dTexDesc; DevBuf<uint32_t> dTexels; DevBuf<float> dLut; DevBuf<LmLight> dLights; DevBuf<float> dCdf;
     LmScene dscene{};
 
@@ -222,9 +226,40 @@ void findEmissives(const R* r, Primitive& p)
 }
 
 // scene data table + world-space triangle soup + BVH — replaces PTScene/PTMeshInstance/OptixWrapper AS builds
+// instance matrices changed, nothing else: refresh the scene data table and refit the BVH on the GPU (kernels.hip "BVH refit").
+// Everything is enqueued on the main stream; no host synchronisation.
+int refit(R* r)
+{
+    const Scene& sc = r->scenes[r->activeScene];
+    for (size_t ii : sc.instances) {
+        const Instance& mi = r->instances[ii];
+        for (uint32_t e : mi.entries) memcpy(r->entries[e].m, mi.M, sizeof r->entries[e].m);
+    }
+    hipStream_t st = r->stream;
+    if (r->dEntries.upload(r->entries, st)) return fail(LUMEN_MI_ERR_DEVICE, "scene table upload failed");
+    const LmKernelTable* K = r->K;
+    const uint32_t nt = (uint32_t)r->bvh.order.size();
+    K->refit_tris(st, r->dscene, nt, r->dTriBox.p, r->dRefitBounds.p);
+    K->refit_quant(st, r->dRefitBounds.p, r->dQuant.p);
+    for (size_t l = 0; l + 1 < r->bvh.levelStart.size(); l++) {
+        const uint32_t a = r->bvh.levelStart[l], b = r->bvh.levelStart[l + 1];
+        if (b > a) K->refit_level(st, r->dscene, r->dLevelNodes.p + a, b - a, r->dTriBox.p, r->dNodeBox.p);
+    }
+    LM_HIP(hipGetLastError());
+    r->transformsDirty = false;
+    r->lightsDirty = true;
+    r->fenceNeeded = true;
+    ++r->refits;
+    return 0;
+}
+
 int flatten(R* r)
 {
-    if (!r->sceneDirty) return 0;
+    if (!r->sceneDirty) {
+        if (!r->transformsDirty) return 0;
+        if (r->refitEnabled && r->activeScene >= 0 && !r->entries.empty()) return refit(r);
+        r->sceneDirty = true;
+    }
     if (r->activeScene < 0) return fail(LUMEN_MI_ERR_STATE, "no scene set (lumen_mi_set_scene)");
     Scene& sc = r->scenes[r->activeScene];
     r->entries.clear(); r->entryPrim.clear(); r->worldTris.clear(); r->triEntry.clear(); r->triPrim.clear();
@@ -275,13 +310,22 @@ int flatten(R* r)
         r->dVerts.upload(verts, st) || r->dIndices.upload(indices, st) || r->dEntries.upload(r->entries, st))
         return fail(LUMEN_MI_ERR_DEVICE, "scene upload failed (hipMalloc/hipMemcpy)");
     if (hipStreamSynchronize(st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "scene upload sync failed");
-    for (int k = 0; k < 3; k++) { r->dscene.qmin[k] = r->bvh.qmin[k]; r->dscene.qstep[k] = r->bvh.qstep[k]; }
+    {
+        std::vector<float> quant = {r->bvh.qmin[0], r->bvh.qmin[1], r->bvh.qmin[2], r->bvh.qstep[0], r->bvh.qstep[1], r->bvh.qstep[2], r->bvh.pad, 0.f};
+        std::vector<uint32_t> bounds = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
+        if (r->dQuant.upload(quant, st) || r->dRefitBounds.upload(bounds, st) || r->dLevelNodes.upload(r->bvh.levelNodes, st) ||
+            r->dTriBox.ensure(2 * (size_t)nt + 2) || r->dNodeBox.ensure(2 * r->bvh.nodes4.size()))
+            return fail(LUMEN_MI_ERR_DEVICE, "refit buffer allocation failed");
+        if (hipStreamSynchronize(st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "scene upload sync failed");
+        r->dscene.quant = r->dQuant.p;
+    }
     if (r->dSpill.ensure((size_t)4 * r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS)))      // one area per stream
         return fail(LUMEN_MI_ERR_DEVICE, "stack spill allocation failed");
     r->dscene.spill = r->dSpill.p;
     r->dscene.nodes = r->dNodes.p; r->dscene.woop = r->dWoop.p; r->dscene.triId = r->dTriId.p; r->dscene.triOrder = r->dTriOrder.p;
     r->dscene.verts = r->dVerts.p; r->dscene.indices = r->dIndices.p; r->dscene.entries = r->dEntries.p;
     r->sceneDirty = false;
+    r->transformsDirty = false;
     r->lightsDirty = true;
     return 0;
 }
@@ -768,6 +812,7 @@ int lumen_mi_destroy(lumen_mi_renderer* r)
         (void)hipStreamSynchronize(r->stream);
         if (r->aux) { (void)hipStreamSynchronize(r->aux); (void)hipStreamSynchronize(r->aux2); (void)hipStreamDestroy(r->aux2); (void)hipStreamSynchronize(r->aux3); (void)hipStreamDestroy(r->aux3); (void)hipEventDestroy(r->evVis); (void)hipEventDestroy(r->evVisDone); (void)hipEventDestroy(r->evJoin2); for (auto& e : r->evShade) (void)hipEventDestroy(e); (void)hipStreamDestroy(r->aux); (void)hipEventDestroy(r->evFront); (void)hipEventDestroy(r->evTemporal); (void)hipEventDestroy(r->evTop); for (auto& e : r->evMerge) (void)hipEventDestroy(e); for (int i = 0; i < 2; i++) { (void)hipEventDestroy(r->evCnt[i]); (void)hipHostFree(r->pinnedCounters[i]); r->pinnedCounters[i] = nullptr; } (void)hipEventDestroy(r->evJoin); }
         r->dSpill.release(); r->dNodes.release(); r->dWoop.release(); r->dTriId.release(); r->dTriOrder.release(); r->dVerts.release(); r->dIndices.release();
+        r->dQuant.release(); r->dTriBox.release(); r->dNodeBox.release(); r->dLevelNodes.release(); r->dRefitBounds.release();
         r->dEntries.release(); r->dMaterials.release(); r->dTexDesc.release(); r->dTexels.release(); r->dLut.release(); r->dLights.release(); r->dCdf.release();
         for (auto& b : r->dRay) b.release(); for (auto& b : r->dSh) b.release(); for (auto& b : r->dSh2) b.release(); for (auto& b : r->dGbuf) b.release(); for (auto& b : r->dProbe) b.release(); for (auto& b : r->dRes) b.release(); for (auto& b : r->dResC) b.release();
         for (int i = 0; i < 2; i++) { r->dDirect[i].release(); r->dIndirect[i].release(); } r->dCombined.release(); r->dHits.release(); r->dMotion.release(); r->dCounters.release(); r->dOutput.release(); r->dBags.release();
@@ -957,7 +1002,7 @@ int lumen_mi_instance_set_transform(lumen_mi_renderer* r, lumen_mi_handle inst, 
 {
     size_t i;
     if (!r || !m || !unh(inst, H_INSTANCE, r->instances.size(), i)) return fail(LUMEN_MI_ERR_INVALID, "bad instance handle");
-    if (memcmp(r->instances[i].M, m, 64) != 0) { memcpy(r->instances[i].M, m, 64); r->sceneDirty = true; }   // polled every frame by the adapter
+    if (memcmp(r->instances[i].M, m, 64) != 0) { memcpy(r->instances[i].M, m, 64); r->transformsDirty = true; }   // polled every frame by the adapter
     return 0;
 }
 
@@ -1119,6 +1164,7 @@ int lumen_mi_set_tuning(lumen_mi_renderer* r, const char* key, int value)
     if (k == "tail_below") r->tailBelow = value;
     else if (k == "tail_lanes") r->tailLanes = std::max(1, std::min(64, value));
     else if (k == "single_stream") { if (r->initialised) { int rc = syncAndCollect(r); if (rc) return rc; } r->overlap = value == 0; }
+    else if (k == "refit") r->refitEnabled = value;
     else if (k == "refill") r->refillBelow = value;
     else if (k == "refill_visibility") r->refillVisibility = value;
     else return fail(LUMEN_MI_ERR_INVALID, std::string("unknown tuning key: ") + key);

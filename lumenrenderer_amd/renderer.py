@@ -305,6 +305,7 @@ class LumenRendererMI:
                 mi.SetOverrideMaterial(mats[inst["override_material"]])
             mi.SetEmissiveness(inst["emission_mode"], inst["override_radiance"], inst["scale"])
         self.SetScene(scene)
+        self.m_Scene = scene
         cam = desc.camera
         self.SetCamera(cam["position"], cam["right"], cam["up"], cam["forward"], cam["fov"])
         return scene

@@ -118,6 +118,9 @@ class Oracle:
         t = f32(np.eye(4) if transform is None else transform).reshape(16); r = f32(override_radiance)
         return self.L.orc_add_instance(self.h, mesh, fptr(t), emission_mode, fptr(r), float(scale), override_material)
 
+    def set_instance_transform(self, inst, transform):
+        t = f32(transform).reshape(16); self.L.orc_set_instance_transform(self.h, inst, fptr(t))
+
     def set_camera(self, pos, right, up, forward, fov=90.0):
         self.L.orc_set_camera(self.h, fptr(f32(pos)), fptr(f32(right)), fptr(f32(up)), fptr(f32(forward)), float(fov))
 

@@ -19,16 +19,10 @@ try:
 except Exception as e: print("bench parse failed",e, open("gpurun_out/$tag/bench.err").read()[-2000:])
 rows=[r for r in csv.DictReader(open("gpurun_out/$tag/kernel_stats.csv")) if not r["Name"].endswith("_inst")]
 for r in rows[:14]: print(f'{r["Name"][:34]:34s} calls {r["Calls"]:>4s} avg_us {float(r["AverageNs"])/1e3:9.1f} pct {r["Percentage"]}')
-import glob
+import glob, subprocess
 tf=glob.glob("gpurun_out/$tag/prof/*/*kernel_trace.csv")
 if tf:
-    tr=list(csv.DictReader(open(tf[0])))
-    tr=[r for r in tr if r["Kernel_Name"].startswith("lm_k") and not r["Kernel_Name"].endswith("_inst")]
-    tr.sort(key=lambda r:int(r["Start_Timestamp"]))
-    s=[i for i,r in enumerate(tr) if r["Kernel_Name"]=="lm_k_primary"][-1]
-    t0=int(tr[s]["Start_Timestamp"])
-    print("--- timeline of the last TraceFrame (start_us dur_us stream kernel)")
-    for r in tr[s:]:
-        print(f'{(int(r["Start_Timestamp"])-t0)/1e3:9.1f} {(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3:8.1f} q{r["Queue_Id"]} {r["Kernel_Name"]}')
+    print("--- steady-state timeline, two TraceFrames (start_us dur_us | one column per stream)")
+    subprocess.run(["python3","tools_timeline.py",tf[0]])
 PY
 rm -rf gpurun_out/$tag/prof
