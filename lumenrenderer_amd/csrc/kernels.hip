@@ -1116,6 +1116,9 @@ KN(lm_k_restir_temporal)(LmFrame fr, int cur, int prev, int rc, int rp, uint32_t
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_SPATIAL_WAVES)
 KN(lm_k_restir_spatial)(LmFrame fr, int cur, int rin, int rout, uint32_t seed)
 {
+#ifdef LM_SPATIAL_PRIO
+    __builtin_amdgcn_s_setprio(LM_SPATIAL_PRIO);
+#endif
     uint32_t li = 0, gi = 0;
     if (!lm_tile_pixel(fr, li, gi)) return;
     const float4* probe = fr.probe[cur];
