@@ -313,6 +313,8 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
 #if LM_INSTRUMENT
                 for (int k = 0; k < 4; k++) nNodes += (int)sc.nodes[cur].c[k].w != LM_REF_NONE;  // child boxes tested
                 raySteps++;
+                { const unsigned long long m = __ballot(true);           // lane occupancy of this node-step issue
+                  if ((int)lane == __ffsll((long long)m) - 1) { atomicAdd((unsigned long long*)(cnt + LM_CNT_OCC), (unsigned long long)__popcll(m)); atomicAdd((unsigned long long*)(cnt + LM_CNT_OCC + 2), 64ull); } }
 #endif
                 cur = lm_node_step<ANY>(sc, cur, rq, tmin, hitT, stack, sp);
             }
@@ -323,6 +325,8 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
                     float t, u, v;
 #if LM_INSTRUMENT
                     nTris++; raySteps++;
+                    { const unsigned long long m = __ballot(true);       // lane occupancy of this triangle-test issue
+                      if ((int)lane == __ffsll((long long)m) - 1) { atomicAdd((unsigned long long*)(cnt + LM_CNT_OCC + 4), (unsigned long long)__popcll(m)); atomicAdd((unsigned long long*)(cnt + LM_CNT_OCC + 6), 64ull); } }
 #endif
                     if (lm_woop(sc.woop, first + k, o, d, tmin, tmax, t, u, v)) {
                         if (ANY) { found = true; break; }

@@ -111,6 +111,7 @@ struct LmFrame {
 #define LM_CNT_STEP_MAX 112                       // instrumented build only: longest per-ray traversal (steps)
 #define LM_CNT_NODES 66                          // instrumented build only: child boxes slab-tested (u64 as 2 words); 2 boxes = one binary node of SURVEY 8 d4
 #define LM_CNT_TRIS 68                           // instrumented build only: triangles tested (u64 as 2 words)
+#define LM_CNT_OCC 120                            // instrumented build only, u64 each: active lanes / lane slots of node steps, of triangle tests
 #define LM_CNT_WORDS 136
 
 struct LmCamera { float eye[3], U[3], V[3], Wv[3]; float prevViewProj[16]; };

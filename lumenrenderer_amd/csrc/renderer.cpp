@@ -100,11 +100,11 @@ struct lumen_mi_renderer {
     const LmKernelTable* K = nullptr;
     bool instrumented = false;
     int tailBelow = -1;                     // waves expected to hold fewer rays than this run as one path-tail launch (0 = off,
-                                            // -1 = auto: 65536 for windows under 2 Mpixel, where the wave chain is the critical path, else 16384) ...
+                                            // -1 = auto: 65536 for windows under 1 Mpixel, where the wave chain is the critical path, else 16384) ...
     int tailLanes = 16;                     // ... with this many paths per wavefront
     uint32_t* pinnedCounters[2] = {nullptr, nullptr}; hipEvent_t evCnt[2] = {nullptr, nullptr}; bool cntPending[2] = {false, false};
     uint32_t estRays[LM_MAX_DEPTH + 1] = {0}; bool haveEst = false;     // rays per wave of the most recent frame that has been read back
-    int refillBelow = 40, refillVisibility = 0;      // lane-refill thresholds of the queue traversal kernels (tunable via LUMEN_MI_REFILL*)
+    int refillBelow = 40, refillVisibility = 0, refillPrimary = 0;      // lane-refill thresholds of the queue traversal kernels (tunable via LUMEN_MI_REFILL*)
 
     lumen_mi_settings settings{};
     lumen_mi_settings pending{};
@@ -154,6 +154,8 @@ struct lumen_mi_renderer {
     // device frame
     LmFrame fr{};
     uint32_t allocN = 0, allocDepth = 0;
+    DevBuf<float4> dTailRay[6];             // ray queue of the path tail, double-buffered by frame parity (3 planes each)
+    hipEvent_t evTail = nullptr;
     DevBuf<float4> dRay[6], dSh[3], dSh2[4], dGbuf[2], dProbe[2], dRes[4], dResC[4], dDirect[2], dIndirect[2], dCombined;
     DevBuf<uint4> dHits; DevBuf<uint32_t> dMotion, dCounters; DevBuf<uchar4> dOutput; DevBuf<uint2> dBags;
     uint32_t hostCounters[LM_CNT_WORDS] = {0};
@@ -465,7 +467,7 @@ int ensureFrameBuffers(R* r)
     f.W = W; f.H = H; f.x0 = r->wx0; f.y0 = r->wy0; f.ww = ww; f.wh = wh; f.n = n;
     if (!realloc) return 0;
     int bad = 0;
-    for (int i = 0; i < 6; i++) bad |= r->dRay[i].ensure(n);
+    for (int i = 0; i < 6; i++) bad |= r->dRay[i].ensure(n) | r->dTailRay[i].ensure(n);
     for (int i = 0; i < 3; i++) bad |= r->dSh[i].ensure(n);
     for (int i = 0; i < 4; i++) bad |= r->dSh2[i].ensure(n);
     for (int i = 0; i < 2; i++) bad |= r->dGbuf[i].ensure((size_t)8 * n) | r->dProbe[i].ensure(n);
@@ -616,10 +618,17 @@ int traceFrameAsync(R* r)
         }
     }
     int tailDepth = (int)depthMax;
-    const uint32_t tailBelow = r->tailBelow >= 0 ? (uint32_t)r->tailBelow : (fr.n < (1u << 21) ? 65536u : 16384u);
+    const uint32_t tailBelow = r->tailBelow >= 0 ? (uint32_t)r->tailBelow : (fr.n < (1u << 20) ? 65536u : 16384u);
     if (tailBelow && r->haveEst) for (uint32_t dd = 1; dd < depthMax; dd++) if (r->estRays[dd] < tailBelow) { tailDepth = (int)dd; break; }
     int q = 0;
     size_t ev;
+    bool tailLaunched = false;
+    // the queue the path tail reads is its own (double-buffered by frame parity), so that the tail can run on the shadow
+    // stream while the wave stream already enqueues the next frame's front into the regular ray queues
+    auto withTailQueue = [&](LmFrame f, int queue) {
+        f.rayO[queue] = r->dTailRay[3 * par].p; f.rayD[queue] = r->dTailRay[3 * par + 1].p; f.rayC[queue] = r->dTailRay[3 * par + 2].p;
+        return f;
+    };
     for (uint32_t depth = 0; depth < depthMax; ++depth) {
         uint32_t* inCount = fr.counters + LM_CNT_RAYS(depth);
         uint32_t* outCount = fr.counters + LM_CNT_RAYS(depth + 1);
@@ -627,11 +636,11 @@ int traceFrameAsync(R* r)
         const int doIndirect = depth < depthMax - 1 ? 1 : 0;
         if (depth == 0) {
             evBegin2(r, 0, ev, sx);
-            K->trace_closest(sx, gridMain, scx, fr.rayO[q], fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters, 0);    // :678,:703
+            K->trace_closest(sx, gridMain, scx, fr.rayO[q], fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters, r->refillPrimary);    // :678,:703
             evEnd2(r, ev, sx);
             if (overlap) LM_HIP(hipStreamWaitEvent(sx, r->evTemporal, 0));               // previous frame's temporal pass has read what extraction overwrites
             evBegin2(r, 2, ev, sx);
-            K->extract0(sx, r->gridFor(fr.n, 8), r->dscene, fr, cam, currentIndex, seed2, doIndirect, q ^ 1, outCount);   // + depth-0 continuation
+            K->extract0(sx, r->gridFor(fr.n, 8), r->dscene, (int)depth + 1 == tailDepth ? withTailQueue(fr, q ^ 1) : fr, cam, currentIndex, seed2, doIndirect, q ^ 1, outCount);   // + depth-0 continuation
             evEnd2(r, ev, sx);
             // the indirect waves follow on the same stream beside ReSTIR on the main stream: both depend only on the G-buffer
             if (overlap) { LM_HIP(hipEventRecord(r->evFront, sx)); LM_HIP(hipStreamWaitEvent(st, r->evFront, 0)); }
@@ -665,12 +674,19 @@ int traceFrameAsync(R* r)
             K->combine(st, tiles, fr, currentIndex, cur, 3, wangHash(rs));
             evEnd(r, ev);
         } else if ((int)depth >= tailDepth) {
-            // path tail: the remaining waves in one launch (kernels.hip lm_k_path_tail); its INDIRECT adds follow the previous
-            // wave's NEE adds (third stream)
-            if (overlap) LM_HIP(hipStreamWaitEvent(sx, r->evJoin2, 0));
-            evBegin2(r, 0, ev, sx);
-            K->path_tail(sx, r->numCU * 8, scx, fr, q, inCount, (int)depth, (int)depthMax, seed, r->tailLanes);
-            evEnd2(r, ev, sx);
+            // path tail: the remaining waves in one launch (kernels.hip lm_k_path_tail) on the shadow stream: its INDIRECT adds
+            // follow the previous wave's NEE adds by stream order, and the wave stream is free for the next frame's front
+            hipStream_t stl = overlap ? r->aux2 : sx;
+            LmScene sct = scx;
+            if (overlap) {
+                sct.spill += (size_t)r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS);
+                LM_HIP(hipEventRecord(r->evShade[depth], sx)); LM_HIP(hipStreamWaitEvent(stl, r->evShade[depth], 0));     // the queue's producer is done
+            }
+            evBegin2(r, 0, ev, stl);
+            K->path_tail(stl, r->numCU * 8, sct, withTailQueue(fr, q), q, inCount, (int)depth, (int)depthMax, seed, r->tailLanes);
+            evEnd2(r, ev, stl);
+            if (overlap) LM_HIP(hipEventRecord(r->evTail, stl));
+            tailLaunched = true;
             for (uint32_t dd = depth; dd < depthMax; ++dd) r->swapChainIndex = r->swapChainIndex + 1 >= 2 ? 0 : r->swapChainIndex + 1;   // one SwapBuffers per wave (:827)
             break;
         } else {
@@ -680,7 +696,7 @@ int traceFrameAsync(R* r)
             evEnd2(r, ev, sx);
             if (overlap) LM_HIP(hipStreamWaitEvent(sx, r->evJoin2, 0));                   // previous wave's (or frame's) shadow rays consumed
             evBegin2(r, 2, ev, sx);
-            K->shade_wave(sx, r->numCU * 8, scx, fr, q, inCount, seed, seed2, doIndirect, outCount, shCount);
+            K->shade_wave(sx, r->numCU * 8, scx, (int)depth + 1 == tailDepth ? withTailQueue(fr, q ^ 1) : fr, q, inCount, seed, seed2, doIndirect, outCount, shCount);
             evEnd2(r, ev, sx);
             // NEE shadow rays of this wave: third stream, beside the next wave's closest-hit launch.  The shadow queue is
             // rewritten by the NEXT shade_wave, which therefore waits for this launch (evShade / stream order below).
@@ -696,7 +712,11 @@ int traceFrameAsync(R* r)
         r->swapChainIndex = r->swapChainIndex + 1 >= 2 ? 0 : r->swapChainIndex + 1;         // ReSTIR::SwapBuffers once per wave (:827)
         seed = wangHash(seed);                                                               // :830
     }
-    if (overlap) { LM_HIP(hipEventRecord(r->evJoin, sx)); LM_HIP(hipStreamWaitEvent(st, r->evJoin, 0)); if (depthMax > 1) LM_HIP(hipStreamWaitEvent(st, r->evJoin2, 0)); }
+    if (overlap) {
+        LM_HIP(hipEventRecord(r->evJoin, sx)); LM_HIP(hipStreamWaitEvent(st, r->evJoin, 0));
+        if (depthMax > 1) LM_HIP(hipStreamWaitEvent(st, r->evJoin2, 0));
+        if (tailLaunched) LM_HIP(hipStreamWaitEvent(st, r->evTail, 0));
+    }
     K->merge(st, r->gridFor(fr.n, 8), fr, blend ? 1 : 0, r->blendCounter);
     if (overlap) LM_HIP(hipEventRecord(r->evMerge[par], st));
     if (r->pinnedCounters[par]) {     // asynchronous counter read-back: feeds the next frames' schedule (above)
@@ -756,6 +776,7 @@ int lumen_mi_create(lumen_mi_renderer** out)
     (*out)->K = lm_kernel_table();
     if (const char* e = getenv("LUMEN_MI_REFILL")) (*out)->refillBelow = atoi(e);
     if (const char* e = getenv("LUMEN_MI_REFILL_VIS")) (*out)->refillVisibility = atoi(e);
+    if (const char* e = getenv("LUMEN_MI_REFILL_PRIMARY")) (*out)->refillPrimary = atoi(e);
     if (const char* e = getenv("LUMEN_MI_TAIL_BELOW")) (*out)->tailBelow = atoi(e);
     if (const char* e = getenv("LUMEN_MI_TAIL_LANES")) (*out)->tailLanes = std::max(1, std::min(64, atoi(e)));
     return 0;
@@ -794,6 +815,7 @@ int lumen_mi_init(lumen_mi_renderer* r, const lumen_mi_settings* s)
         for (auto& e : r->evShade) LM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         LM_HIP(hipEventCreateWithFlags(&r->evFront, hipEventDisableTiming));
         LM_HIP(hipEventCreateWithFlags(&r->evTemporal, hipEventDisableTiming));
+        LM_HIP(hipEventCreateWithFlags(&r->evTail, hipEventDisableTiming));
         LM_HIP(hipEventCreateWithFlags(&r->evTop, hipEventDisableTiming));
         for (auto& e : r->evMerge) LM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (int i = 0; i < 2; i++) { LM_HIP(hipEventCreateWithFlags(&r->evCnt[i], hipEventDisableTiming)); LM_HIP(hipHostMalloc((void**)&r->pinnedCounters[i], LM_CNT_WORDS * sizeof(uint32_t), hipHostMallocDefault)); }
@@ -810,11 +832,11 @@ int lumen_mi_destroy(lumen_mi_renderer* r)
     if (r->initialised) {
         (void)hipSetDevice(r->device);
         (void)hipStreamSynchronize(r->stream);
-        if (r->aux) { (void)hipStreamSynchronize(r->aux); (void)hipStreamSynchronize(r->aux2); (void)hipStreamDestroy(r->aux2); (void)hipStreamSynchronize(r->aux3); (void)hipStreamDestroy(r->aux3); (void)hipEventDestroy(r->evVis); (void)hipEventDestroy(r->evVisDone); (void)hipEventDestroy(r->evJoin2); for (auto& e : r->evShade) (void)hipEventDestroy(e); (void)hipStreamDestroy(r->aux); (void)hipEventDestroy(r->evFront); (void)hipEventDestroy(r->evTemporal); (void)hipEventDestroy(r->evTop); for (auto& e : r->evMerge) (void)hipEventDestroy(e); for (int i = 0; i < 2; i++) { (void)hipEventDestroy(r->evCnt[i]); (void)hipHostFree(r->pinnedCounters[i]); r->pinnedCounters[i] = nullptr; } (void)hipEventDestroy(r->evJoin); }
+        if (r->aux) { (void)hipStreamSynchronize(r->aux); (void)hipStreamSynchronize(r->aux2); (void)hipStreamDestroy(r->aux2); (void)hipStreamSynchronize(r->aux3); (void)hipStreamDestroy(r->aux3); (void)hipEventDestroy(r->evVis); (void)hipEventDestroy(r->evVisDone); (void)hipEventDestroy(r->evJoin2); for (auto& e : r->evShade) (void)hipEventDestroy(e); (void)hipStreamDestroy(r->aux); (void)hipEventDestroy(r->evFront); (void)hipEventDestroy(r->evTemporal); (void)hipEventDestroy(r->evTail); (void)hipEventDestroy(r->evTop); for (auto& e : r->evMerge) (void)hipEventDestroy(e); for (int i = 0; i < 2; i++) { (void)hipEventDestroy(r->evCnt[i]); (void)hipHostFree(r->pinnedCounters[i]); r->pinnedCounters[i] = nullptr; } (void)hipEventDestroy(r->evJoin); }
         r->dSpill.release(); r->dNodes.release(); r->dWoop.release(); r->dTriId.release(); r->dTriOrder.release(); r->dVerts.release(); r->dIndices.release();
         r->dQuant.release(); r->dTriBox.release(); r->dNodeBox.release(); r->dLevelNodes.release(); r->dRefitBounds.release();
         r->dEntries.release(); r->dMaterials.release(); r->dTexDesc.release(); r->dTexels.release(); r->dLut.release(); r->dLights.release(); r->dCdf.release();
-        for (auto& b : r->dRay) b.release(); for (auto& b : r->dSh) b.release(); for (auto& b : r->dSh2) b.release(); for (auto& b : r->dGbuf) b.release(); for (auto& b : r->dProbe) b.release(); for (auto& b : r->dRes) b.release(); for (auto& b : r->dResC) b.release();
+        for (auto& b : r->dRay) b.release(); for (auto& b : r->dTailRay) b.release(); for (auto& b : r->dSh) b.release(); for (auto& b : r->dSh2) b.release(); for (auto& b : r->dGbuf) b.release(); for (auto& b : r->dProbe) b.release(); for (auto& b : r->dRes) b.release(); for (auto& b : r->dResC) b.release();
         for (int i = 0; i < 2; i++) { r->dDirect[i].release(); r->dIndirect[i].release(); } r->dCombined.release(); r->dHits.release(); r->dMotion.release(); r->dCounters.release(); r->dOutput.release(); r->dBags.release();
         for (auto& e : r->evPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     }
@@ -1140,6 +1162,7 @@ int lumen_mi_get_counters(lumen_mi_renderer* r, uint64_t* out, uint32_t n)
     v[21] = (uint64_t)c[LM_CNT_TRIS] | ((uint64_t)c[LM_CNT_TRIS + 1] << 32);
     for (int k = 0; k < 16; k++) v[24 + k] = c[LM_CNT_STEP_HIST + k];
     v[40] = c[LM_CNT_STEP_MAX];
+    for (int k = 0; k < 4; k++) v[41 + k] = (uint64_t)c[LM_CNT_OCC + 2 * k] | ((uint64_t)c[LM_CNT_OCC + 2 * k + 1] << 32);
     for (uint32_t i = 0; i < n && i < 48; i++) out[i] = v[i];
     return 0;
 }
@@ -1167,6 +1190,7 @@ int lumen_mi_set_tuning(lumen_mi_renderer* r, const char* key, int value)
     else if (k == "refit") r->refitEnabled = value;
     else if (k == "refill") r->refillBelow = value;
     else if (k == "refill_visibility") r->refillVisibility = value;
+    else if (k == "refill_primary") r->refillPrimary = value;
     else return fail(LUMEN_MI_ERR_INVALID, std::string("unknown tuning key: ") + key);
     return 0;
 }
