@@ -10,7 +10,12 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <thread>
+#include <chrono>
+#include <cstdio>
 
 namespace {
 
@@ -22,23 +27,42 @@ struct Box {
     float area() const { const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2]; return (dx < 0 || dy < 0 || dz < 0) ? 0.f : 2.f * (dx * dy + dy * dz + dz * dx); }
 };
 
+// parallel-for over [0, n) in contiguous chunks (used for the few very large nodes at the top of the tree)
+template <class F> void parallelChunks(size_t n, unsigned threads, F f)
+{
+    threads = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, n / 65536 + 1));
+    if (threads == 1) { f(0u, (size_t)0, n); return; }
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; t++) pool.emplace_back([=] { f(t, n * t / threads, n * (t + 1) / threads); });
+    for (auto& th : pool) th.join();
+}
+
+struct Task { uint32_t first, count, depth; };
+
+// One builder instance = one output arena (nodes + leaf order with LOCAL indices).  The top-level instance cuts subtrees of
+// at most `taskThreshold` triangles into tasks; the task builders run in parallel on disjoint ranges of the shared index
+// array, and the arenas are concatenated in task order afterwards (so the result does not depend on thread scheduling).
 struct Builder {
-    const float* tris;                 // 9 floats per triangle
-    std::vector<Box> tbox;
-    std::vector<float> cen;            // 3 per triangle
-    std::vector<uint32_t> ids;
-    LmBvh* out;
-    float pad;
+    const Box* tbox = nullptr;         // per triangle
+    const float* cen = nullptr;        // 3 per triangle
+    uint32_t* ids = nullptr;           // shared permutation; a builder only touches its own range
+    std::vector<LmNode> nodes;
+    std::vector<uint32_t> order;
+    std::vector<Task>* tasks = nullptr;
+    uint32_t taskThreshold = 0;
+    unsigned threads = 1;
+    float pad = 0.f;
     uint32_t maxDepth = 0;
 
     struct Ref { int ref; Box box; };
+    static constexpr int TASK_REF = 0x40000000;        // placeholder reference: TASK_REF + task index
 
     static int ilog2ceil(uint32_t v) { int r = 0; while ((1u << r) < v) r++; return r; }
 
     Ref makeLeaf(uint32_t first, uint32_t count, const Box& box)
     {
-        const uint32_t start = (uint32_t)out->order.size();
-        for (uint32_t i = 0; i < count; i++) out->order.push_back(ids[first + i]);
+        const uint32_t start = (uint32_t)order.size();
+        for (uint32_t i = 0; i < count; i++) order.push_back(ids[first + i]);
         Ref r; r.ref = ~(int)((start << 3) | (count - 1u)); r.box = box;
         return r;
     }
@@ -46,9 +70,27 @@ struct Builder {
     Ref build(uint32_t first, uint32_t count, uint32_t depth)
     {
         maxDepth = std::max(maxDepth, depth);
+        const bool big = tasks != nullptr && threads > 1 && count >= 65536u;
         Box box; box.reset();
         Box cbox; cbox.reset();
-        for (uint32_t i = first; i < first + count; i++) { box.grow(tbox[ids[i]]); cbox.grow(&cen[3 * ids[i]]); }
+        if (big) {
+            std::vector<Box> pb(threads), pc(threads);
+            for (auto& x : pb) x.reset();
+            for (auto& x : pc) x.reset();
+            parallelChunks(count, threads, [&](unsigned t, size_t lo, size_t hi) {
+                Box b0, c0; b0.reset(); c0.reset();
+                for (size_t i = first + lo; i < first + hi; i++) { b0.grow(tbox[ids[i]]); c0.grow(&cen[3 * (size_t)ids[i]]); }
+                pb[t] = b0; pc[t] = c0;
+            });
+            for (unsigned t = 0; t < threads; t++) { if (pb[t].lo[0] <= pb[t].hi[0]) box.grow(pb[t]); if (pc[t].lo[0] <= pc[t].hi[0]) cbox.grow(pc[t]); }
+        } else {
+            for (uint32_t i = first; i < first + count; i++) { box.grow(tbox[ids[i]]); cbox.grow(&cen[3 * (size_t)ids[i]]); }
+        }
+        if (tasks && depth > 0 && count <= taskThreshold && count > 2) {
+            Ref r; r.ref = TASK_REF + (int)tasks->size(); r.box = box;
+            tasks->push_back(Task{first, count, depth});
+            return r;
+        }
         if (count <= 2) return makeLeaf(first, count, box);
         // depth guard: from here a median split is guaranteed to finish within the traversal stack
         const bool forceMedian = (int)depth + ilog2ceil(count) + 2 >= LM_BVH2_MAX_DEPTH - 2;
@@ -57,38 +99,55 @@ struct Builder {
         if (!forceMedian) {
             const int NB = 16;
             float bestCost = INFINITY; int bestAxis = -1, bestBin = -1;
-            for (int axis = 0; axis < 3; axis++) {
-                const float lo = cbox.lo[axis], ext = cbox.hi[axis] - lo;
-                if (!(ext > 0.f)) continue;
-                Box bb[NB]; uint32_t bc[NB];
-                for (int b = 0; b < NB; b++) { bb[b].reset(); bc[b] = 0; }
-                const float scale = (float)NB / ext;
-                for (uint32_t i = first; i < first + count; i++) {
-                    int b = (int)((cen[3 * ids[i] + axis] - lo) * scale);
-                    b = std::min(NB - 1, std::max(0, b));
-                    bb[b].grow(tbox[ids[i]]); bc[b]++;
+            // bins of all three axes in one pass (per thread for big nodes, merged in thread order)
+            struct Bins { Box bb[3][NB]; uint32_t bc[3][NB]; };
+            auto clearBins = [&](Bins& B) { for (int a = 0; a < 3; a++) for (int k = 0; k < NB; k++) { B.bb[a][k].reset(); B.bc[a][k] = 0; } };
+            float lo3[3], scale3[3]; bool use[3];
+            for (int axis = 0; axis < 3; axis++) { lo3[axis] = cbox.lo[axis]; const float ext = cbox.hi[axis] - lo3[axis]; use[axis] = ext > 0.f; scale3[axis] = use[axis] ? (float)NB / ext : 0.f; }
+            auto binRange = [&](Bins& B, size_t a0, size_t a1) {
+                for (size_t i = a0; i < a1; i++) {
+                    const uint32_t t = ids[i];
+                    for (int axis = 0; axis < 3; axis++) {
+                        if (!use[axis]) continue;
+                        int k = (int)((cen[3 * (size_t)t + axis] - lo3[axis]) * scale3[axis]);
+                        k = std::min(NB - 1, std::max(0, k));
+                        B.bb[axis][k].grow(tbox[t]); B.bc[axis][k]++;
+                    }
                 }
+            };
+            Bins all; clearBins(all);
+            if (big) {
+                std::vector<Bins> part(threads);
+                for (auto& x : part) clearBins(x);
+                parallelChunks(count, threads, [&](unsigned t, size_t lo, size_t hi) { binRange(part[t], first + lo, first + hi); });
+                for (unsigned t = 0; t < threads; t++) for (int a = 0; a < 3; a++) for (int k = 0; k < NB; k++) if (part[t].bc[a][k]) { all.bb[a][k].grow(part[t].bb[a][k]); all.bc[a][k] += part[t].bc[a][k]; }
+            } else {
+                binRange(all, first, (size_t)first + count);
+            }
+            for (int axis = 0; axis < 3; axis++) {
+                if (!use[axis]) continue;
+                const Box* bb = all.bb[axis]; const uint32_t* bc = all.bc[axis];
                 float rightArea[NB]; uint32_t rightCount[NB];
                 Box acc; acc.reset(); uint32_t cnt = 0;
-                for (int b = NB - 1; b > 0; b--) { acc.grow(bb[b]); cnt += bc[b]; rightArea[b] = acc.area(); rightCount[b] = cnt; }
+                for (int k = NB - 1; k > 0; k--) { acc.grow(bb[k]); cnt += bc[k]; rightArea[k] = acc.area(); rightCount[k] = cnt; }
                 acc.reset(); cnt = 0;
-                for (int b = 0; b < NB - 1; b++) {
-                    acc.grow(bb[b]); cnt += bc[b];
-                    if (cnt == 0 || rightCount[b + 1] == 0) continue;
-                    const float cost = acc.area() * (float)cnt + rightArea[b + 1] * (float)rightCount[b + 1];
-                    if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestBin = b; }
+                for (int k = 0; k < NB - 1; k++) {
+                    acc.grow(bb[k]); cnt += bc[k];
+                    if (cnt == 0 || rightCount[k + 1] == 0) continue;
+                    const float cost = acc.area() * (float)cnt + rightArea[k + 1] * (float)rightCount[k + 1];
+                    if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestBin = k; }
                 }
             }
             const float leafCost = box.area() * (float)count;
             if (bestAxis >= 0 && (count > 4 || bestCost + box.area() * 1.0f < leafCost)) {
                 const float lo = cbox.lo[bestAxis], ext = cbox.hi[bestAxis] - lo;
                 const float scale = 16.f / ext;
-                auto it = std::partition(ids.begin() + first, ids.begin() + first + count, [&](uint32_t t) {
-                    int b = (int)((cen[3 * t + bestAxis] - lo) * scale);
-                    b = std::min(15, std::max(0, b));
-                    return b <= bestBin;
+                auto it = std::partition(ids + first, ids + first + count, [&](uint32_t t) {
+                    int k = (int)((cen[3 * (size_t)t + bestAxis] - lo) * scale);
+                    k = std::min(15, std::max(0, k));
+                    return k <= bestBin;
                 });
-                mid = (uint32_t)(it - ids.begin());
+                mid = (uint32_t)(it - ids);
                 split = mid > first && mid < first + count;
             } else if (count <= 4) {
                 return makeLeaf(first, count, box);
@@ -100,13 +159,13 @@ struct Builder {
             int axis = 0;
             for (int k = 1; k < 3; k++) if (cbox.hi[k] - cbox.lo[k] > cbox.hi[axis] - cbox.lo[axis]) axis = k;
             mid = first + count / 2;
-            std::nth_element(ids.begin() + first, ids.begin() + mid, ids.begin() + first + count, [&](uint32_t a, uint32_t b) {
-                const float ka = cen[3 * a + axis], kb = cen[3 * b + axis];
+            std::nth_element(ids + first, ids + mid, ids + first + count, [&](uint32_t a, uint32_t b) {
+                const float ka = cen[3 * (size_t)a + axis], kb = cen[3 * (size_t)b + axis];
                 return ka < kb || (ka == kb && a < b);
             });
         }
-        const int self = (int)out->nodes.size();
-        out->nodes.emplace_back();
+        const int self = (int)nodes.size();
+        nodes.emplace_back();
         const Ref l = build(first, mid - first, depth + 1);
         const Ref r = build(mid, first + count - mid, depth + 1);
         setNode(self, l, r);
@@ -116,7 +175,7 @@ struct Builder {
 
     void setNode(int idx, const Ref& l, const Ref& r)
     {
-        LmNode& n = out->nodes[idx];
+        LmNode& n = nodes[idx];
         auto P = [&](float v, float s) { return v + s * pad; };
         n.n0 = make_float4(P(l.box.lo[0], -1), P(l.box.hi[0], 1), P(l.box.lo[1], -1), P(l.box.hi[1], 1));
         n.n1 = make_float4(P(r.box.lo[0], -1), P(r.box.hi[0], 1), P(r.box.lo[1], -1), P(r.box.hi[1], 1));
@@ -130,46 +189,99 @@ struct Builder {
 void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out)
 {
     out->nodes.clear(); out->order.clear(); out->woop.clear();
-    Builder b;
-    b.tris = tris; b.out = out;
-    b.tbox.resize(nTris); b.cen.resize(3 * (size_t)nTris); b.ids.resize(nTris);
-    float maxAbs = 0.f;
-    for (uint32_t t = 0; t < nTris; t++) {
-        b.tbox[t].reset();
-        for (int v = 0; v < 3; v++) {
-            const float* p = tris + 9 * (size_t)t + 3 * v;
-            b.tbox[t].grow(p);
-            for (int k = 0; k < 3; k++) maxAbs = std::max(maxAbs, std::fabs(p[k]));
+    const bool timing = getenv("LUMEN_MI_BUILD_TIMING") != nullptr;
+    auto tLast = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (!timing) return; const auto now = std::chrono::steady_clock::now(); fprintf(stderr, "[bvh] %-28s %.3f s\n", what, std::chrono::duration<double>(now - tLast).count()); tLast = now; };
+    unsigned threads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    if (const char* e = getenv("LUMEN_MI_BUILD_THREADS")) threads = (unsigned)std::max(1, atoi(e));
+    std::vector<Box> tbox(nTris); std::vector<float> cen(3 * (size_t)nTris); std::vector<uint32_t> ids(nTris);
+    std::vector<float> partMax(threads, 0.f);
+    parallelChunks(nTris, threads, [&](unsigned tt, size_t lo, size_t hi) {
+        float m = 0.f;
+        for (size_t t = lo; t < hi; t++) {
+            tbox[t].reset();
+            for (int v = 0; v < 3; v++) {
+                const float* p = tris + 9 * t + 3 * v;
+                tbox[t].grow(p);
+                for (int k = 0; k < 3; k++) m = std::max(m, std::fabs(p[k]));
+            }
+            for (int k = 0; k < 3; k++) cen[3 * t + k] = 0.5f * (tbox[t].lo[k] + tbox[t].hi[k]);
+            ids[t] = (uint32_t)t;
         }
-        for (int k = 0; k < 3; k++) b.cen[3 * (size_t)t + k] = 0.5f * (b.tbox[t].lo[k] + b.tbox[t].hi[k]);
-        b.ids[t] = t;
-    }
+        partMax[tt] = m;
+    });
+    float maxAbs = 0.f;
+    for (float m : partMax) maxAbs = std::max(maxAbs, m);
+    lap("triangle boxes");
+    Builder b;
+    b.tbox = tbox.data(); b.cen = cen.data(); b.ids = ids.data(); b.threads = threads;
     b.pad = maxAbs * (1.0f / 32768.0f);
     out->pad = b.pad;
-    // absent child: marked by NaN boxes here; the quantised tree points it at the sentinel (never hit) triangle packet
+    std::vector<Task> tasks;
+    if (threads > 1 && nTris >= 65536u) { b.tasks = &tasks; b.taskThreshold = std::max(4096u, nTris / (2u * threads)); }
+    // absent child: marked by NaN boxes here; the quantised tree gives it the reference LM_REF_NONE
     Builder::Ref empty; empty.ref = ~0;
     for (int k = 0; k < 3; k++) { empty.box.lo[k] = NAN; empty.box.hi[k] = NAN; }
     if (nTris == 0) {
-        out->nodes.emplace_back();
+        b.nodes.emplace_back();
         b.setNode(0, empty, empty);
     } else {
-        out->nodes.reserve(nTris);
-        out->order.reserve(nTris);
         Builder::Ref root = b.build(0, nTris, 0);
         if (root.ref < 0) {                                    // whole scene fits one leaf: node 0 must still be an inner node
-            out->nodes.emplace_back();
+            b.nodes.emplace_back();
             b.setNode(0, root, empty);
         }
     }
+    lap("top levels");
+    // ---- subtrees in parallel, then concatenation in task order
+    std::vector<Builder> sub(tasks.size());
+    std::vector<Builder::Ref> subRoot(tasks.size());
+    if (!tasks.empty()) {
+        std::atomic<size_t> next{0};
+        auto worker = [&] {
+            for (size_t t; (t = next.fetch_add(1)) < tasks.size();) {
+                Builder& w = sub[t];
+                w.tbox = tbox.data(); w.cen = cen.data(); w.ids = ids.data(); w.pad = b.pad;
+                subRoot[t] = w.build(tasks[t].first, tasks[t].count, tasks[t].depth);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < std::min<size_t>(threads, tasks.size()); t++) pool.emplace_back(worker);
+        for (auto& th : pool) th.join();
+    }
+    lap("subtrees (parallel)");
+    out->nodes = std::move(b.nodes);
+    out->order = std::move(b.order);
+    std::vector<int> rootRef(tasks.size());
+    for (size_t t = 0; t < tasks.size(); t++) {
+        const int nodeBase = (int)out->nodes.size();
+        const uint32_t slotBase = (uint32_t)out->order.size();
+        auto fix = [&](int ref) {
+            if (ref >= 0) return ref + nodeBase;
+            const uint32_t leaf = (uint32_t)(~ref);
+            return ~(int)((((leaf >> 3) + slotBase) << 3) | (leaf & 7u));
+        };
+        for (LmNode n : sub[t].nodes) { n.ref.x = fix(n.ref.x); n.ref.y = fix(n.ref.y); out->nodes.push_back(n); }
+        out->order.insert(out->order.end(), sub[t].order.begin(), sub[t].order.end());
+        rootRef[t] = fix(subRoot[t].ref);
+        b.maxDepth = std::max(b.maxDepth, sub[t].maxDepth);
+        sub[t].nodes.clear(); sub[t].nodes.shrink_to_fit(); sub[t].order.clear(); sub[t].order.shrink_to_fit();
+    }
+    for (LmNode& n : out->nodes) {
+        if (n.ref.x >= Builder::TASK_REF) n.ref.x = rootRef[n.ref.x - Builder::TASK_REF];
+        if (n.ref.y >= Builder::TASK_REF) n.ref.y = rootRef[n.ref.y - Builder::TASK_REF];
+    }
+    lap("concatenation");
     out->maxDepth = b.maxDepth + 1;
     const size_t nSlots = out->order.size();
     out->woop.resize(nSlots + 1);
-    for (size_t s = 0; s < nSlots; s++) out->woop[s] = lm_make_woop(tris + 9 * (size_t)out->order[s]);
+    parallelChunks(nSlots, threads, [&](unsigned, size_t lo, size_t hi) { for (size_t s = lo; s < hi; s++) out->woop[s] = lm_make_woop(tris + 9 * (size_t)out->order[s]); });
     memset(&out->woop[nSlots], 0, sizeof(LmWoop));               // sentinel packet: t = -0/0 = NaN, never a hit
 
+    lap("woop packets");
     // ---- 16-bit quantisation relative to the (padded) scene box, rounded outward by one extra step
     float smin[3] = {INFINITY, INFINITY, INFINITY}, smax[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (uint32_t t = 0; t < nTris; t++) for (int k = 0; k < 3; k++) { smin[k] = std::min(smin[k], b.tbox[t].lo[k]); smax[k] = std::max(smax[k], b.tbox[t].hi[k]); }
+    for (uint32_t t = 0; t < nTris; t++) for (int k = 0; k < 3; k++) { smin[k] = std::min(smin[k], tbox[t].lo[k]); smax[k] = std::max(smax[k], tbox[t].hi[k]); }
     for (int k = 0; k < 3; k++) {
         if (!(smin[k] <= smax[k])) { smin[k] = 0.f; smax[k] = 1.f; }
         const float m = 4.f * b.pad + 1e-6f * std::max(std::fabs(smin[k]), std::fabs(smax[k])) + 1e-30f;
@@ -186,28 +298,24 @@ void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out)
     };
     // ---- collapse to 4-wide nodes: starting from a binary node's two children, repeatedly replace the inner child of
     // largest surface area by its own two children until there are four (or only leaves are left)
-    struct Child { int ref; float b[6]; };      // padded box: lo.x hi.x lo.y hi.y lo.z hi.z
+    struct Child { int ref; float b[6]; uint32_t src; };      // padded box: lo.x hi.x lo.y hi.y lo.z hi.z; src = (binary node << 1) | side
     auto childrenOf = [&](int node, Child* c) {
         const LmNode& n = out->nodes[node];
         const float c0[6] = {n.n0.x, n.n0.y, n.n0.z, n.n0.w, n.n2.x, n.n2.y}, c1[6] = {n.n1.x, n.n1.y, n.n1.z, n.n1.w, n.n2.z, n.n2.w};
         int k = 0;
-        if (c0[0] == c0[0]) { c[k].ref = n.ref.x; memcpy(c[k].b, c0, sizeof c0); k++; }
-        if (c1[0] == c1[0]) { c[k].ref = n.ref.y; memcpy(c[k].b, c1, sizeof c1); k++; }
+        if (c0[0] == c0[0]) { c[k].ref = n.ref.x; memcpy(c[k].b, c0, sizeof c0); c[k].src = (uint32_t)node << 1; k++; }
+        if (c1[0] == c1[0]) { c[k].ref = n.ref.y; memcpy(c[k].b, c1, sizeof c1); c[k].src = ((uint32_t)node << 1) | 1u; k++; }
         return k;
     };
     auto areaOf = [](const Child& c) { const float dx = c.b[1] - c.b[0], dy = c.b[3] - c.b[2], dz = c.b[5] - c.b[4]; return dx * dy + dy * dz + dz * dx; };
-    out->nodes4.clear();
-    out->nodes4.reserve(out->nodes.size() / 2 + 1);
-    out->maxStack = 1;
+    // The collapse is a top-down walk whose subtrees are independent.  It runs sequentially until enough subtrees are
+    // pending, then every pending subtree is (1) counted and (2) written by a worker into its own index range — the
+    // prefix sum over the counts keeps the node numbering independent of thread scheduling.
     struct Work { int node2; int node4; uint32_t stack; uint32_t depth; };
     std::vector<uint32_t> depthOf;
-    std::vector<Work> work;
-    out->nodes4.emplace_back();
-    work.push_back({0, 0, 0, 0});
-    depthOf.push_back(0);
-    while (!work.empty()) {
-        const Work w = work.back(); work.pop_back();
-        Child c[4];
+    out->maxStack = 1;
+    // expands one work item: children + the number of 4-wide children it creates
+    auto expand = [&](const Work& w, Child* c) {
         int n = childrenOf(w.node2, c);
         while (n < 4) {
             int best = -1; float bestArea = -1.f;
@@ -219,25 +327,89 @@ void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out)
             c[best] = g[0];
             if (m > 1) c[n++] = g[1];
         }
+        return n;
+    };
+    // writes node w.node4 and pushes its inner children (indices taken from `nextId`) on `stack`
+    auto emit = [&](const Work& w, std::vector<Work>& stack, int& nextId, uint32_t& maxStack) {
+        Child c[4];
+        const int n = expand(w, c);
         const uint32_t stackBelow = w.stack + (uint32_t)(n > 0 ? n - 1 : 0);
-        out->maxStack = std::max(out->maxStack, stackBelow + 1u);
+        maxStack = std::max(maxStack, stackBelow + 1u);
         LmNode4 q;
         for (int i = 0; i < 4; i++) {
             if (i >= n) { q.c[i] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, (uint32_t)LM_REF_NONE); continue; }
-            uint32_t p[3];
-            for (int k = 0; k < 3; k++) quant(c[i].b[2 * k], c[i].b[2 * k + 1], k, p[k]);
             int ref = c[i].ref;
             if (ref >= 0) {
-                const int id4 = (int)out->nodes4.size();
-                out->nodes4.emplace_back();
-                work.push_back({ref, id4, stackBelow, w.depth + 1});
-                depthOf.push_back(w.depth + 1);
+                const int id4 = nextId++;
+                stack.push_back({ref, id4, stackBelow, w.depth + 1});
+                depthOf[id4] = w.depth + 1;
                 ref = id4;
             }
-            q.c[i] = make_uint4(p[0], p[1], p[2], (uint32_t)ref);
+            q.c[i] = make_uint4(c[i].src, 0u, 0u, (uint32_t)ref);        // .x = where the box comes from; quantised below
         }
         out->nodes4[w.node4] = q;
+    };
+    out->nodes4.assign(1, LmNode4{});
+    depthOf.assign(1, 0);
+    std::vector<Work> work;
+    work.push_back({0, 0, 0, 0});
+    int nextId = 1;
+    while (!work.empty() && (threads <= 1 || work.size() < 8u * threads)) {   // sequential part (the whole tree when single-threaded)
+        const Work w = work.back(); work.pop_back();
+        if (out->nodes4.size() < (size_t)nextId + 4) { out->nodes4.resize(2 * (size_t)nextId + 4); depthOf.resize(2 * (size_t)nextId + 4); }
+        emit(w, work, nextId, out->maxStack);
     }
+    if (!work.empty()) {
+        std::vector<uint32_t> cnt(work.size(), 0);
+        auto countSubtree = [&](const Work& root) {                 // 4-wide nodes strictly below `root`
+            uint32_t total = 0;
+            std::vector<int> st{root.node2};
+            while (!st.empty()) {
+                Work w{st.back(), 0, 0, 0}; st.pop_back();
+                Child c[4];
+                const int n = expand(w, c);
+                for (int i = 0; i < n; i++) if (c[i].ref >= 0) { total++; st.push_back(c[i].ref); }
+            }
+            return total;
+        };
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < threads; t++) pool.emplace_back([&] { for (size_t i; (i = next.fetch_add(1)) < work.size();) cnt[i] = countSubtree(work[i]); });
+        for (auto& th : pool) th.join();
+        std::vector<int> base(work.size());
+        for (size_t i = 0; i < work.size(); i++) { base[i] = nextId; nextId += (int)cnt[i]; }
+        out->nodes4.resize((size_t)nextId); depthOf.resize((size_t)nextId);
+        std::vector<uint32_t> tmax(threads, 1u);
+        next = 0; pool.clear();
+        for (unsigned t = 0; t < threads; t++) pool.emplace_back([&, t] {
+            std::vector<Work> st;
+            uint32_t localMax = 1u;                                 // (a shared array element here would be falsely shared)
+            for (size_t i; (i = next.fetch_add(1)) < work.size();) {
+                int id = base[i];
+                st.clear(); st.push_back(work[i]);
+                while (!st.empty()) { const Work w = st.back(); st.pop_back(); emit(w, st, id, localMax); }
+            }
+            tmax[t] = localMax;
+        });
+        for (auto& th : pool) th.join();
+        for (uint32_t m : tmax) out->maxStack = std::max(out->maxStack, m);
+    }
+    out->nodes4.resize((size_t)nextId);
+    depthOf.resize((size_t)nextId);
+    lap("collapse");
+    parallelChunks(out->nodes4.size(), threads, [&](unsigned, size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) for (int k = 0; k < 4; k++) {
+            uint4& ch = out->nodes4[i].c[k];
+            if ((int)ch.w == LM_REF_NONE) continue;
+            const LmNode& n = out->nodes[ch.x >> 1];
+            const float c0[6] = {n.n0.x, n.n0.y, n.n0.z, n.n0.w, n.n2.x, n.n2.y}, c1[6] = {n.n1.x, n.n1.y, n.n1.z, n.n1.w, n.n2.z, n.n2.w};
+            const float* bx = (ch.x & 1u) ? c1 : c0;
+            uint32_t p[3];
+            for (int a = 0; a < 3; a++) quant(bx[2 * a], bx[2 * a + 1], a, p[a]);
+            ch.x = p[0]; ch.y = p[1]; ch.z = p[2];
+        }
+    });
+    lap("quantise");
     // nodes grouped by depth (deepest level first): the order in which a bottom-up refit visits them
     uint32_t maxD = 0;
     for (uint32_t d : depthOf) maxD = std::max(maxD, d);
