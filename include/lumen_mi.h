@@ -123,6 +123,11 @@ int lumen_mi_copy_radiance_device(lumen_mi_renderer*, void* device_rgba32f);    
 int lumen_mi_get_channel(lumen_mi_renderer*, int channel, float* rgba32f, size_t capacity_bytes);   /* 0 DIRECT, 1 INDIRECT */
 int lumen_mi_get_gbuffer(lumen_mi_renderer*, float* planes8x4, size_t capacity_bytes);   /* depth-0 surface data of the last frame, pixel-major [n][8][4] */
 
+/* denoiser / upscaler inputs of the last frame (ExtractNRD_DLSSdata GPUExtractNRD_DLSSdata.cu:6-89, ExtractDepthData
+ * GPUExtractDepthData.cu:6-72, GenerateMotionVector MotionVectors.cu:8-55): depth normalised to [min,max] render distance
+ * (Camera.h:60 default {0.1, 1000}) as fp32, normal.xyz + roughness as half4, motion vector as half2; any pointer may be NULL */
+int lumen_mi_get_denoiser_inputs(lumen_mi_renderer*, float min_distance, float max_distance, float* depth, uint16_t* normal_roughness_half4, uint16_t* motion_half2);
+
 /* FrameStats (LumenRenderer.h:29-34, GetLastFrameStats :203): key/value pairs in microseconds under the reference's key names */
 int lumen_mi_get_frame_stat(lumen_mi_renderer*, const char* key, uint64_t* microseconds);
 /* counters of the last completed frame: [0] closest-hit rays, [1] NEE shadow rays, [2] ReSTIR shadow rays, [3] lights,

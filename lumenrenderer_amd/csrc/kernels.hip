@@ -1327,6 +1327,27 @@ KN(lm_k_test_math)(uint32_t n, int fn, const float* __restrict__ x, const float*
 // launch table: this file is compiled twice (LM_INSTRUMENT = 0 / 1); the renderer picks a table at run time
 // ---------------------------------------------------------------------------------------------------------------------
 #include "lm_launch.h"
+// Denoiser / upscaler inputs from the depth-0 G-buffer — reference GPUExtractNRD_DLSSdata.cu:6-89 (depth normalised to the
+// camera's render-distance range, fp32; half4 normal + roughness), GPUExtractDepthData.cu:6-72.  Pixels without a hit
+// (t < 0) get depth 0 and keep their previous normal-roughness value, as in the reference.
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_export_aux)(LmFrame fr, int cur, float minD, float maxD, float* __restrict__ depth, uint2* __restrict__ normalRoughness)
+{
+    const uint32_t stride = gridDim.x * LM_BLOCK;
+    for (uint32_t li = blockIdx.x * LM_BLOCK + threadIdx.x; li < fr.n; li += stride) {
+        const float4* rec = fr.gbuf[cur] + 8u * li;
+        const float4 a = rec[0], b = rec[1];
+        const float t = a.w;
+        if (t < 0.f) { if (depth) depth[li] = 0.f; continue; }
+        if (depth) depth[li] = (t - fminf(minD, t)) / (fmaxf(maxD, t) - fminf(minD, t));
+        if (normalRoughness) {
+            LmMaterial m; m.p0 = f2u(rec[7].x); m.p1 = 0u; m.p2 = 0u;
+            const float rough = LM_P_ROUGHNESS(m);
+            normalRoughness[li] = make_uint2(lm_f32_to_f16(b.x) | (lm_f32_to_f16(b.y) << 16), lm_f32_to_f16(b.z) | (lm_f32_to_f16(rough) << 16));
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // BVH refit for moved instances (reference: the per-frame instance acceleration-structure rebuild of PTScene.cpp:74-156,
 // PTMeshInstance.cpp:123-178).  Topology and leaf contents stay; triangles are re-transformed, Woop packets recomputed
@@ -1449,6 +1470,7 @@ static void l_merge(hipStream_t s, int g, LmFrame fr, int blend, uint32_t blendC
 static void l_query_any(hipStream_t s, int g, LmScene sc, const float4* o, const float4* d, uint32_t n, float tmin, uint32_t* occ, uint32_t* counters) { hipLaunchKernelGGL(KN(lm_k_query_any), LM_GRID(g), sc, o, d, n, tmin, occ, counters); }
 static void l_query_closest(hipStream_t s, int g, LmScene sc, const float4* o, const float4* d, uint32_t n, float tmin, float tmax, uint4* id, float4* uvt, uint32_t* counters)
 { hipLaunchKernelGGL(KN(lm_k_query_closest_raw), LM_GRID(g), sc, o, d, n, tmin, tmax, id, uvt, counters); }
+static void l_export_aux(hipStream_t s, int g, LmFrame fr, int cur, float minD, float maxD, float* depth, uint2* nr) { hipLaunchKernelGGL(KN(lm_k_export_aux), LM_GRID(g), fr, cur, minD, maxD, depth, nr); }
 static void l_refit_tris(hipStream_t s, LmScene sc, uint32_t nSlots, float4* triBox, uint32_t* bounds) { hipLaunchKernelGGL(KN(lm_k_refit_tris), LM_GRID((nSlots + LM_BLOCK - 1) / LM_BLOCK), sc, nSlots, triBox, bounds); }
 static void l_refit_quant(hipStream_t s, uint32_t* bounds, float* quant) { hipLaunchKernelGGL(KN(lm_k_refit_quant), dim3(1), dim3(64), 0, s, bounds, quant); }
 static void l_refit_level(hipStream_t s, LmScene sc, const uint32_t* levelNodes, uint32_t count, const float4* triBox, float4* nodeBox) { hipLaunchKernelGGL(KN(lm_k_refit_level), LM_GRID((count + LM_BLOCK - 1) / LM_BLOCK), sc, levelNodes, count, triBox, nodeBox); }
@@ -1463,6 +1485,6 @@ extern "C" const LmKernelTable* lm_kernel_table()
 #endif
 {
     static const LmKernelTable t = {l_primary, l_trace_closest, l_extract0, l_shade_wave, l_trace_shadow, l_path_tail, l_fill_bags, l_pick_primary,
-                                    l_trace_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_refit_tris, l_refit_quant, l_refit_level, l_test_bsdf, l_test_math};
+                                    l_trace_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_export_aux, l_refit_tris, l_refit_quant, l_refit_level, l_test_bsdf, l_test_math};
     return &t;
 }

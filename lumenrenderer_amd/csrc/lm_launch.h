@@ -19,6 +19,7 @@ struct LmKernelTable {
     void (*merge)(hipStream_t, int grid, LmFrame, int blend, uint32_t blendCount);
     void (*query_any)(hipStream_t, int grid, LmScene, const float4* o, const float4* d, uint32_t n, float tmin, uint32_t* occluded, uint32_t* counters);
     void (*query_closest)(hipStream_t, int grid, LmScene, const float4* o, const float4* d, uint32_t n, float tmin, float tmax, uint4* id, float4* uvt, uint32_t* counters);
+    void (*export_aux)(hipStream_t, int grid, LmFrame, int cur, float minD, float maxD, float* depth, uint2* normalRoughness);
     void (*refit_tris)(hipStream_t, LmScene, uint32_t nSlots, float4* triBox, uint32_t* bounds);
     void (*refit_quant)(hipStream_t, uint32_t* bounds, float* quant);
     void (*refit_level)(hipStream_t, LmScene, const uint32_t* levelNodes, uint32_t count, const float4* triBox, float4* nodeBox);

@@ -1140,6 +1140,27 @@ int lumen_mi_get_gbuffer(lumen_mi_renderer* r, float* out, size_t cap)
     return copyOut(r, r->fr.gbuf[last], (size_t)n * 128, out, cap);
 }
 
+int lumen_mi_get_denoiser_inputs(lumen_mi_renderer* r, float minD, float maxD, float* depth, uint16_t* normalRoughness, uint16_t* motion)
+{
+    if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer");
+    std::lock_guard<std::mutex> lk(r->frameMutex);
+    int rc = syncAndCollect(r); if (rc) return rc;
+    const uint32_t n = r->fr.n;
+    if (!n || !r->fr.gbuf[0]) return fail(LUMEN_MI_ERR_STATE, "no frame has been traced");
+    const int last = r->frameIndex == 0 ? 1 : 0;
+    DevBuf<float> dDepth; DevBuf<uint2> dNr;
+    if ((depth && dDepth.ensure(n)) || (normalRoughness && dNr.ensure(n))) return fail(LUMEN_MI_ERR_DEVICE, "export allocation failed");
+    if (normalRoughness) LM_HIP(hipMemsetAsync(dNr.p, 0, (size_t)n * sizeof(uint2), r->stream));
+    r->K->export_aux(r->stream, r->gridFor(n, 8), r->fr, last, minD, maxD, depth ? dDepth.p : nullptr, normalRoughness ? dNr.p : nullptr);
+    LM_HIP(hipGetLastError());
+    LM_HIP(hipStreamSynchronize(r->stream));
+    if (depth) LM_HIP(hipMemcpy(depth, dDepth.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    if (normalRoughness) LM_HIP(hipMemcpy(normalRoughness, dNr.p, (size_t)n * sizeof(uint2), hipMemcpyDeviceToHost));
+    if (motion) LM_HIP(hipMemcpy(motion, r->fr.motion, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    dDepth.release(); dNr.release();
+    return 0;
+}
+
 int lumen_mi_get_frame_stat(lumen_mi_renderer* r, const char* key, uint64_t* us)
 {
     if (!r || !key || !us) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");

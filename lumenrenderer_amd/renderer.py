@@ -234,6 +234,14 @@ class LumenRendererMI:
     def GetCounters(self, n=24):
         out = (C.c_uint64 * n)(); check(self.lib, self.lib.lumen_mi_get_counters(self.h, out, n)); return list(out)
 
+    def GetDenoiserInputs(self, min_distance=0.1, max_distance=1000.0):
+        """(depth [h,w] f32, normal_roughness [h,w,4] f16 bits, motion [h,w,2] f16 bits) of the last frame's window."""
+        h, w = self._window_shape(); n = h * w
+        depth = np.zeros(n, np.float32); nr = np.zeros((n, 4), np.uint16); mv = np.zeros((n, 2), np.uint16)
+        check(self.lib, self.lib.lumen_mi_get_denoiser_inputs(self.h, min_distance, max_distance, _fp(depth),
+                                                              nr.ctypes.data_as(C.POINTER(C.c_uint16)), mv.ctypes.data_as(C.POINTER(C.c_uint16))))
+        return depth.reshape(h, w), nr.reshape(h, w, 4), mv.reshape(h, w, 2)
+
     def GetLastFrameStat(self, key):
         v = C.c_uint64(); check(self.lib, self.lib.lumen_mi_get_frame_stat(self.h, key.encode(), C.byref(v))); return v.value
 

@@ -1296,6 +1296,24 @@ uint32_t orc_lights(orc_ctx* c, float* out, float* cdf)
     if (cdf) memcpy(cdf, c->cdf.data(), c->cdf.size() * sizeof(float));
     return (uint32_t)c->lights.size();
 }
+// denoiser / upscaler inputs of the last frame — CUDAKernels/WaveFrontKernels/GPUExtractNRD_DLSSdata.cu:6-89 (normalised depth,
+// half4 normal + roughness), GPUExtractDepthData.cu:6-72, motion vectors as stored (half2, MotionVectors.cu:8-55)
+void orc_get_denoiser_inputs(orc_ctx* c, float minD, float maxD, float* depth, uint16_t* normalRoughness, uint16_t* motion)
+{
+    const int last = c->frameIndex == 0 ? 1 : 0;
+    const std::vector<Surface>& S = c->surface[last];
+    for (size_t i = 0; i < S.size(); i++) {
+        const Surface& s = S[i];
+        float t = s.t;
+        const bool hit = !(t < 0.f);
+        if (depth) depth[i] = hit ? (t - fminf(minD, t)) / (fmaxf(maxD, t) - fminf(minD, t)) : 0.f;
+        if (normalRoughness && hit) {
+            normalRoughness[4 * i + 0] = f32_to_f16(s.normal.x); normalRoughness[4 * i + 1] = f32_to_f16(s.normal.y);
+            normalRoughness[4 * i + 2] = f32_to_f16(s.normal.z); normalRoughness[4 * i + 3] = f32_to_f16(mat_get(s.mat, P_ROUGHNESS));
+        }
+        if (motion) { motion[2 * i] = f32_to_f16(c->motion[i].x); motion[2 * i + 1] = f32_to_f16(c->motion[i].y); }
+    }
+}
 void orc_get_gbuffer(orc_ctx* c, float* out)
 {
     // planes: 0 (pos, t) 1 (normal, flags) 2 (tangent, 0) 3 (incoming, 0) 4 color 5 (tint, lum) 6 (transmittance, eta) 7 (params.xyz as bits, 0)

@@ -41,6 +41,7 @@ def lib():
             ("orc_add_mesh", [C.c_void_p, i32p, C.c_uint32], C.c_int),
             ("orc_add_instance", [C.c_void_p, C.c_int, fp, C.c_int, fp, C.c_float, C.c_int], C.c_int),
             ("orc_set_instance_transform", [C.c_void_p, C.c_int, fp], None),
+            ("orc_get_denoiser_inputs", [C.c_void_p, C.c_float, C.c_float, fp, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16)], None),
             ("orc_set_camera", [C.c_void_p, fp, fp, fp, fp, C.c_float], None),
             ("orc_set_resolution", [C.c_void_p, C.c_uint32, C.c_uint32], None),
             ("orc_set_depth", [C.c_void_p, C.c_uint32], None), ("orc_set_blend", [C.c_void_p, C.c_int], None),
@@ -143,6 +144,12 @@ class Oracle:
 
     def stats(self, n=16):
         out = (C.c_uint64 * n)(); self.L.orc_get_stats(self.h, out, n); return list(out)
+
+    def denoiser_inputs(self, min_distance=0.1, max_distance=1000.0):
+        n = self.h_ * self.w
+        depth = np.zeros(n, np.float32); nr = np.zeros((n, 4), np.uint16); mv = np.zeros((n, 2), np.uint16)
+        self.L.orc_get_denoiser_inputs(self.h, min_distance, max_distance, fptr(depth), nr.ctypes.data_as(C.POINTER(C.c_uint16)), mv.ctypes.data_as(C.POINTER(C.c_uint16)))
+        return depth, nr, mv
 
     def gbuffer(self):
         out = np.zeros((self.h_, self.w, 8, 4), np.float32); self.L.orc_get_gbuffer(self.h, fptr(out)); return out

@@ -143,6 +143,20 @@ def test_cornell_c1_frame_bit_exact():
     r.close(); o.close()
 
 
+def test_denoiser_inputs_match_oracle():
+    """depth / normal-roughness / motion exports (GPUExtractNRD_DLSSdata.cu, GPUExtractDepthData.cu)."""
+    from lumenrenderer_amd.scenes import sponza_standin
+    for d, (w, h) in ((cornell(), (96, 64)), (sponza_standin(), (160, 90))):
+        r = product_from(d, w, h, 3, blend=True); o = oracle_from(d, w, h, 3, blend=True)
+        for _ in range(2):
+            assert r.TraceFrame() and o.trace_frame() == 0
+        depth, nr, mv = r.GetDenoiserInputs(0.1, 1000.0); od, onr, omv = o.denoiser_inputs(0.1, 1000.0)
+        assert np.array_equal(depth.ravel().view(np.uint32), od.view(np.uint32))
+        assert np.array_equal(nr.reshape(-1, 4), onr) and np.array_equal(mv.reshape(-1, 2), omv)
+        assert depth.max() > 0 and nr.any()
+        r.close(); o.close()
+
+
 def test_cornell_blended_frames_depth5():
     d = cornell()
     r = product_from(d, 160, 120, 5, blend=True); o = oracle_from(d, 160, 120, 5, blend=True)
