@@ -1047,9 +1047,12 @@ KN(lm_k_pick_primary)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, ui
     }
 }
 
+// K24 temporal reuse.  `rf` = where this frame's fresh candidates live: the current buffer `rc` itself, or — when candidate
+// generation of the NEXT frame runs ahead on its own stream — a separate buffer, so that it does not have to wait for this
+// frame's spatial passes; the result lands in `rc` either way.
 // K24 temporal reuse — ReSTIRKernels.cu:1015-1121
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
-KN(lm_k_restir_temporal)(LmFrame fr, int cur, int prev, int rc, int rp, uint32_t seed, uint32_t* visCount)
+KN(lm_k_restir_temporal)(LmFrame fr, int cur, int prev, int rc, int rp, int rf, uint32_t seed, uint32_t* visCount)
 {
     __shared__ uint32_t s_tmp[5];
     uint32_t li = 0, gi = 0;
@@ -1076,7 +1079,7 @@ KN(lm_k_restir_temporal)(LmFrame fr, int cur, int prev, int rc, int rp, uint32_t
                 if (depthDif < 0.10f && angle > 0.72222222223f) {
                     LmReservoir rpv, rcv;
                     lm_res_load(fr.res[rp], fr.resC[rp], tli, rpv);
-                    lm_res_load(fr.res[rc], fr.resC[rc], li, rcv);
+                    lm_res_load(fr.res[rf], fr.resC[rf], li, rcv);
                     if (rpv.weight > 0.f) {                        // ShadeReservoirs on the PREVIOUS reservoir
                         const lf3 add = rpv.s.contribution * (rpv.weight / 3.f);
                         float4 px = fr.direct[li];
@@ -1093,10 +1096,16 @@ KN(lm_k_restir_temporal)(LmFrame fr, int cur, int prev, int rc, int rp, uint32_t
                     merged = true; weight = out.weight; vtarget = out.s.position; vpos = s.position;
                 }
             }
-            if (!merged) {
-                const float4* h = fr.res[rc] + 4u * li;
-                weight = h[0].y;
-                if (weight > 0.f) { vtarget = v3(h[3]); vpos = v3(fr.gbuf[cur][8u * li]); }
+            if (!merged) {                                         // the fresh reservoir becomes the current one unchanged
+                const float4* h = fr.res[rf] + 4u * li;
+                const float4 h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3];
+                if (rf != rc) {
+                    float4* o = fr.res[rc] + 4u * li;
+                    o[0] = h0; o[1] = h1; o[2] = h2; o[3] = h3;
+                    fr.resC[rc][li] = fr.resC[rf][li];
+                }
+                weight = h0.y;
+                if (weight > 0.f) { vtarget = v3(h3); vpos = v3(fr.gbuf[cur][8u * li]); }
             }
             shoot = weight > 0.f;                                  // second GenerateShadowRay pass (ReSTIR.cpp:211), fused
         }
@@ -1462,7 +1471,7 @@ static void l_trace_shadow(hipStream_t s, int g, LmScene sc, LmFrame fr, const u
 static void l_fill_bags(hipStream_t s, LmScene sc, LmFrame fr, uint32_t seed, uint32_t total) { hipLaunchKernelGGL(KN(lm_k_fill_bags), LM_GRID((total + LM_BLOCK - 1) / LM_BLOCK), sc, fr, seed, total); }
 static void l_pick_primary(hipStream_t s, int tiles, LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount) { hipLaunchKernelGGL(KN(lm_k_pick_primary), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount); }
 static void l_trace_shade(hipStream_t s, int g, LmScene sc, LmFrame fr, int rc, const uint32_t* cnt, int refillBelow, int pass) { hipLaunchKernelGGL(KN(lm_k_restir_trace_shade), LM_GRID(g), sc, fr, rc, cnt, refillBelow, pass); }
-static void l_temporal(hipStream_t s, int g, LmFrame fr, int cur, int prev, int rc, int rp, uint32_t seed, uint32_t* visCount) { hipLaunchKernelGGL(KN(lm_k_restir_temporal), LM_GRID(g), fr, cur, prev, rc, rp, seed, visCount); }
+static void l_temporal(hipStream_t s, int g, LmFrame fr, int cur, int prev, int rc, int rp, int rf, uint32_t seed, uint32_t* visCount) { hipLaunchKernelGGL(KN(lm_k_restir_temporal), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); }
 static void l_spatial(hipStream_t s, int g, LmFrame fr, int cur, int rin, int rout, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_restir_spatial), LM_GRID(g), fr, cur, rin, rout, seed); }
 static void l_combine(hipStream_t s, int g, LmFrame fr, int cur, int rc, int rs, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_restir_combine), LM_GRID(g), fr, cur, rc, rs, seed); }
 static void l_clear(hipStream_t s, int g, float4* p, uint32_t n) { hipLaunchKernelGGL(KN(lm_k_clear_f4), LM_GRID(g), p, n); }

@@ -93,9 +93,10 @@ struct LmFrame {
     // depth-0 surface data, two frames: one 128-byte record (8 float4) per pixel + a 16-byte reuse-probe plane (kernels.hip)
     float4* gbuf[2];
     float4* probe[2];
-    // reservoirs, 4 buffers: one 64-byte hot record (4 float4) per pixel + a contribution plane
-    float4* res[4];
-    float4* resC[4];
+    // reservoirs, 5 buffers (the reference's two swap-chain and two spatial buffers + [4], fresh candidates when candidate
+    // generation runs ahead on its own stream): one 64-byte hot record (4 float4) per pixel + a contribution plane
+    float4* res[5];
+    float4* resC[5];
     uint32_t* motion;           // half2 motion vector per pixel
     float4 *direct, *indirect;  // fp32 light channels
     float4* combined;           // merged / blended radiance

@@ -89,6 +89,8 @@ struct lumen_mi_renderer {
     hipStream_t aux3 = nullptr;             // fourth stream: second ReSTIR visibility pass beside the second spatial pass
     hipStream_t aux2 = nullptr;             // third stream: NEE shadow rays of wave d run beside the closest-hit launch of wave d+1
     hipEvent_t evJoin = nullptr, evJoin2 = nullptr, evVis = nullptr, evVisDone = nullptr;
+    hipEvent_t evPick = nullptr;
+    int pickAhead = -1;                     // -1 automatic (windows under 1 Mpixel), 0 off, 1 on
     hipEvent_t evFront = nullptr, evTemporal = nullptr, evTop = nullptr, evMerge[2] = {nullptr, nullptr};   // cross-frame pipelining (traceFrameAsync)
     int framePar = 0;                       // parity of the frame being enqueued: selects the channel buffers and the counter block
     bool fenceNeeded = true;                // main-stream work (uploads, memsets) the frame front on the aux stream must wait for
@@ -156,7 +158,7 @@ struct lumen_mi_renderer {
     uint32_t allocN = 0, allocDepth = 0;
     DevBuf<float4> dTailRay[6];             // ray queue of the path tail, double-buffered by frame parity (3 planes each)
     hipEvent_t evTail = nullptr;
-    DevBuf<float4> dRay[6], dSh[3], dSh2[4], dGbuf[2], dProbe[2], dRes[4], dResC[4], dDirect[2], dIndirect[2], dCombined;
+    DevBuf<float4> dRay[6], dSh[3], dSh2[4], dGbuf[2], dProbe[2], dRes[5], dResC[5], dDirect[2], dIndirect[2], dCombined;
     DevBuf<uint4> dHits; DevBuf<uint32_t> dMotion, dCounters; DevBuf<uchar4> dOutput; DevBuf<uint2> dBags;
     uint32_t hostCounters[LM_CNT_WORDS] = {0};
     bool countersValid = false;
@@ -471,7 +473,7 @@ int ensureFrameBuffers(R* r)
     for (int i = 0; i < 3; i++) bad |= r->dSh[i].ensure(n);
     for (int i = 0; i < 4; i++) bad |= r->dSh2[i].ensure(n);
     for (int i = 0; i < 2; i++) bad |= r->dGbuf[i].ensure((size_t)8 * n) | r->dProbe[i].ensure(n);
-    for (int i = 0; i < 4; i++) bad |= r->dRes[i].ensure((size_t)4 * n) | r->dResC[i].ensure(n);
+    for (int i = 0; i < 5; i++) bad |= r->dRes[i].ensure((size_t)4 * n) | r->dResC[i].ensure(n);
     for (int i = 0; i < 2; i++) bad |= r->dDirect[i].ensure(n) | r->dIndirect[i].ensure(n);
     bad |= r->dCombined.ensure(n) | r->dHits.ensure(n) | r->dMotion.ensure(n) | r->dOutput.ensure(n);
     bad |= r->dCounters.ensure(2 * LM_CNT_WORDS) | r->dBags.ensure(50 * 1000);
@@ -481,13 +483,13 @@ int ensureFrameBuffers(R* r)
     f.visO = r->dSh2[0].p; f.visD = r->dSh2[1].p; f.vis2O = r->dSh2[2].p; f.vis2D = r->dSh2[3].p;
     f.hits = r->dHits.p;
     for (int i = 0; i < 2; i++) { f.gbuf[i] = r->dGbuf[i].p; f.probe[i] = r->dProbe[i].p; }
-    for (int i = 0; i < 4; i++) { f.res[i] = r->dRes[i].p; f.resC[i] = r->dResC[i].p; }
+    for (int i = 0; i < 5; i++) { f.res[i] = r->dRes[i].p; f.resC[i] = r->dResC[i].p; }
     f.motion = r->dMotion.p; f.direct = r->dDirect[0].p; f.indirect = r->dIndirect[0].p; f.combined = r->dCombined.p; f.output = r->dOutput.p;
     f.counters = r->dCounters.p; f.bags = r->dBags.p;
     // ResizeBuffers (WaveFrontRenderer.cpp:1424-1540): history is dropped; reservoirs reset (ReSTIRKernels.cu:36-47)
     hipStream_t st = r->stream;
     for (int i = 0; i < 2; i++) if (hipMemsetAsync(f.gbuf[i], 0, (size_t)8 * n * sizeof(float4), st) != hipSuccess || hipMemsetAsync(f.probe[i], 0, (size_t)n * sizeof(float4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
-    for (int i = 0; i < 4; i++) if (hipMemsetAsync(f.res[i], 0, (size_t)4 * n * sizeof(float4), st) != hipSuccess || hipMemsetAsync(f.resC[i], 0, (size_t)n * sizeof(float4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
+    for (int i = 0; i < 5; i++) if (hipMemsetAsync(f.res[i], 0, (size_t)4 * n * sizeof(float4), st) != hipSuccess || hipMemsetAsync(f.resC[i], 0, (size_t)n * sizeof(float4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
     if (hipMemsetAsync(f.combined, 0, (size_t)n * sizeof(float4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
     if (hipMemsetAsync(f.output, 0, (size_t)n * sizeof(uchar4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
     r->allocN = n;
@@ -643,34 +645,42 @@ int traceFrameAsync(R* r)
             K->extract0(sx, r->gridFor(fr.n, 8), r->dscene, (int)depth + 1 == tailDepth ? withTailQueue(fr, q ^ 1) : fr, cam, currentIndex, seed2, doIndirect, q ^ 1, outCount);   // + depth-0 continuation
             evEnd2(r, ev, sx);
             // the indirect waves follow on the same stream beside ReSTIR on the main stream: both depend only on the G-buffer
-            if (overlap) { LM_HIP(hipEventRecord(r->evFront, sx)); LM_HIP(hipStreamWaitEvent(st, r->evFront, 0)); }
-            // ReSTIR::Run (Framework/ReSTIR.cpp:65-233) — stays on the main stream
-            evBegin(r, 3, ev);
-            const int cur = r->swapChainIndex, tmp = cur == 1 ? 0 : 1;
+            // ReSTIR::Run (Framework/ReSTIR.cpp:65-233) on the main stream.  Candidate generation and the first visibility pass
+            // only need this frame's G-buffer; for small windows (multi-GPU tiles, where the dependency chain and not the
+            // machine's throughput bounds the frame) they run on their own stream into the fresh-candidate buffer [4], beside
+            // the previous frame's spatial passes; the temporal pass picks them up from there.
+            const bool pickAhead = overlap && (r->pickAhead >= 0 ? r->pickAhead != 0 : fr.n < (1u << 20));
+            hipStream_t sp = pickAhead ? r->aux3 : st;      // (HIP multiplexes streams onto 4 hardware queues by default: no fifth stream)
+            if (overlap) { LM_HIP(hipEventRecord(r->evFront, sx)); LM_HIP(hipStreamWaitEvent(sp, r->evFront, 0)); }
+            evBegin2(r, 3, ev, sp);
+            const int cur = r->swapChainIndex, tmp = cur == 1 ? 0 : 1, fresh = pickAhead ? 4 : cur;
             uint32_t rs = wangHash(seed);
-            K->fill_bags(st, r->dscene, fr, seed, 50u * 1000u);
+            K->fill_bags(sp, r->dscene, fr, seed, 50u * 1000u);
             rs = wangHash(rs);
             const uint32_t tx0 = fr.x0 / 16u, ty0 = fr.y0 / 16u;
             const uint32_t wtx = (fr.x0 + fr.ww + 15u) / 16u - tx0, wty = (fr.y0 + fr.wh + 15u) / 16u - ty0;
-            K->pick_primary(st, (int)(wtx * wty), r->dscene, fr, currentIndex, cur, rs, fr.counters + LM_CNT_RESTIR(0));     // + visibility rays, pass 1
-            K->trace_shade(st, gridMain, r->dscene, fr, cur, fr.counters + LM_CNT_RESTIR(0), r->refillVisibility, 0);
+            K->pick_primary(sp, (int)(wtx * wty), r->dscene, fr, currentIndex, fresh, rs, fr.counters + LM_CNT_RESTIR(0));   // + visibility rays, pass 1
+            K->trace_shade(sp, gridMain, r->dscene, fr, fresh, fr.counters + LM_CNT_RESTIR(0), r->refillVisibility, 0);
+            evEnd2(r, ev, sp);
+            if (pickAhead) { LM_HIP(hipEventRecord(r->evPick, sp)); LM_HIP(hipStreamWaitEvent(st, r->evPick, 0)); }
+            evBegin(r, 3, ev);
             rs = wangHash(rs);
-            K->temporal(st, tiles, fr, currentIndex, temporalIndex, cur, tmp, rs, fr.counters + LM_CNT_RESTIR(1));                // + visibility rays, pass 2
+            K->temporal(st, tiles, fr, currentIndex, temporalIndex, cur, tmp, fresh, rs, fr.counters + LM_CNT_RESTIR(1));         // + visibility rays, pass 2
             if (overlap) LM_HIP(hipEventRecord(r->evTemporal, st));
             rs = wangHash(rs);
             K->spatial(st, tiles, fr, currentIndex, cur, 2, rs);
             // second visibility pass (ReSTIR.cpp:211-212) works on the CURRENT buffer, which the second spatial pass does not
             // touch: trace it beside that pass.  (It must follow the first spatial pass, which reads the current buffer.)
-            hipStream_t sv = overlap ? r->aux3 : st;
+            hipStream_t sv = (overlap && !pickAhead) ? r->aux3 : st;
             LmScene scv = r->dscene;
-            if (overlap) {
+            if (sv != st) {
                 scv.spill += (size_t)3 * r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS);
                 LM_HIP(hipEventRecord(r->evVis, st)); LM_HIP(hipStreamWaitEvent(sv, r->evVis, 0));
             }
             K->trace_shade(sv, gridMain, scv, fr, cur, fr.counters + LM_CNT_RESTIR(1), r->refillVisibility, 1);
-            if (overlap) LM_HIP(hipEventRecord(r->evVisDone, sv));
+            if (sv != st) LM_HIP(hipEventRecord(r->evVisDone, sv));
             K->spatial(st, tiles, fr, currentIndex, 2, 3, rs);
-            if (overlap) LM_HIP(hipStreamWaitEvent(st, r->evVisDone, 0));
+            if (sv != st) LM_HIP(hipStreamWaitEvent(st, r->evVisDone, 0));
             K->combine(st, tiles, fr, currentIndex, cur, 3, wangHash(rs));
             evEnd(r, ev);
         } else if ((int)depth >= tailDepth) {
@@ -808,6 +818,7 @@ int lumen_mi_init(lumen_mi_renderer* r, const lumen_mi_settings* s)
         LM_HIP(hipStreamCreateWithPriority(&r->aux, hipStreamNonBlocking, r->auxPriority ? hi : lo));
         LM_HIP(hipStreamCreateWithPriority(&r->aux2, hipStreamNonBlocking, r->auxPriority ? hi : lo));
         LM_HIP(hipStreamCreateWithPriority(&r->aux3, hipStreamNonBlocking, hi));
+        LM_HIP(hipEventCreateWithFlags(&r->evPick, hipEventDisableTiming));
         LM_HIP(hipEventCreateWithFlags(&r->evJoin2, hipEventDisableTiming));
         LM_HIP(hipEventCreateWithFlags(&r->evVis, hipEventDisableTiming));
         LM_HIP(hipEventCreateWithFlags(&r->evVisDone, hipEventDisableTiming));
@@ -832,7 +843,7 @@ int lumen_mi_destroy(lumen_mi_renderer* r)
     if (r->initialised) {
         (void)hipSetDevice(r->device);
         (void)hipStreamSynchronize(r->stream);
-        if (r->aux) { (void)hipStreamSynchronize(r->aux); (void)hipStreamSynchronize(r->aux2); (void)hipStreamDestroy(r->aux2); (void)hipStreamSynchronize(r->aux3); (void)hipStreamDestroy(r->aux3); (void)hipEventDestroy(r->evVis); (void)hipEventDestroy(r->evVisDone); (void)hipEventDestroy(r->evJoin2); for (auto& e : r->evShade) (void)hipEventDestroy(e); (void)hipStreamDestroy(r->aux); (void)hipEventDestroy(r->evFront); (void)hipEventDestroy(r->evTemporal); (void)hipEventDestroy(r->evTail); (void)hipEventDestroy(r->evTop); for (auto& e : r->evMerge) (void)hipEventDestroy(e); for (int i = 0; i < 2; i++) { (void)hipEventDestroy(r->evCnt[i]); (void)hipHostFree(r->pinnedCounters[i]); r->pinnedCounters[i] = nullptr; } (void)hipEventDestroy(r->evJoin); }
+        if (r->aux) { (void)hipStreamSynchronize(r->aux); (void)hipStreamSynchronize(r->aux2); (void)hipStreamDestroy(r->aux2); (void)hipStreamSynchronize(r->aux3); (void)hipStreamDestroy(r->aux3); (void)hipEventDestroy(r->evPick); (void)hipEventDestroy(r->evVis); (void)hipEventDestroy(r->evVisDone); (void)hipEventDestroy(r->evJoin2); for (auto& e : r->evShade) (void)hipEventDestroy(e); (void)hipStreamDestroy(r->aux); (void)hipEventDestroy(r->evFront); (void)hipEventDestroy(r->evTemporal); (void)hipEventDestroy(r->evTail); (void)hipEventDestroy(r->evTop); for (auto& e : r->evMerge) (void)hipEventDestroy(e); for (int i = 0; i < 2; i++) { (void)hipEventDestroy(r->evCnt[i]); (void)hipHostFree(r->pinnedCounters[i]); r->pinnedCounters[i] = nullptr; } (void)hipEventDestroy(r->evJoin); }
         r->dSpill.release(); r->dNodes.release(); r->dWoop.release(); r->dTriId.release(); r->dTriOrder.release(); r->dVerts.release(); r->dIndices.release();
         r->dQuant.release(); r->dTriBox.release(); r->dNodeBox.release(); r->dLevelNodes.release(); r->dRefitBounds.release();
         r->dEntries.release(); r->dMaterials.release(); r->dTexDesc.release(); r->dTexels.release(); r->dLut.release(); r->dLights.release(); r->dCdf.release();
@@ -1209,6 +1220,7 @@ int lumen_mi_set_tuning(lumen_mi_renderer* r, const char* key, int value)
     else if (k == "tail_lanes") r->tailLanes = std::max(1, std::min(64, value));
     else if (k == "single_stream") { if (r->initialised) { int rc = syncAndCollect(r); if (rc) return rc; } r->overlap = value == 0; }
     else if (k == "refit") r->refitEnabled = value;
+    else if (k == "pick_ahead") { if (r->initialised) { int rc = syncAndCollect(r); if (rc) return rc; } r->pickAhead = value; }
     else if (k == "refill") r->refillBelow = value;
     else if (k == "refill_visibility") r->refillVisibility = value;
     else if (k == "refill_primary") r->refillPrimary = value;
