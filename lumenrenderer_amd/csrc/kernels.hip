@@ -257,6 +257,9 @@ __device__ __forceinline__ bool lm_traverse(const LmScene& sc, const lf3& o, con
 #ifndef LM_PRIO_RAYS
 #define LM_PRIO_RAYS 1048576u
 #endif
+#ifndef LM_NODE_EXIT
+#define LM_NODE_EXIT 14
+#endif
 template <bool ANY, class Fetch, class Done>
 __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, int refillBelow, const LmStack& stack,
                                                uint32_t* cnt, Fetch fetch, Done done)
@@ -309,7 +312,15 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
         if (__ballot(active) == 0ull) break;
         // ---- traverse until the ray ends or the wave has become too empty
         while (active) {
+#if LM_NODE_EXIT
+            const int roundLanes = (int)__popcll(__ballot(true));
+#endif
             while (cur >= 0 && cur != 0x7fffffff) {
+#if LM_NODE_EXIT
+                // leave the node loop once few lanes are still descending while others wait with a leaf (or a finished ray):
+                // those test their triangles and rejoin, instead of idling until the slowest lane has found its leaf
+                { const int descending = (int)__popcll(__ballot(true)); if (descending < LM_NODE_EXIT && descending < roundLanes) break; }
+#endif
 #if LM_INSTRUMENT
                 for (int k = 0; k < 4; k++) nNodes += (int)sc.nodes[cur].c[k].w != LM_REF_NONE;  // child boxes tested
                 raySteps++;
@@ -318,7 +329,7 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
 #endif
                 cur = lm_node_step<ANY>(sc, cur, rq, tmin, hitT, stack, sp);
             }
-            if (cur != 0x7fffffff) {
+            if (cur < 0) {
                 const uint32_t leaf = (uint32_t)(~cur);
                 const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
                 for (uint32_t k = 0; k < count; k++) {

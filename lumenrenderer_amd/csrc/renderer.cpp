@@ -106,7 +106,7 @@ struct lumen_mi_renderer {
     int tailLanes = 16;                     // ... with this many paths per wavefront
     uint32_t* pinnedCounters[2] = {nullptr, nullptr}; hipEvent_t evCnt[2] = {nullptr, nullptr}; bool cntPending[2] = {false, false};
     uint32_t estRays[LM_MAX_DEPTH + 1] = {0}; bool haveEst = false;     // rays per wave of the most recent frame that has been read back
-    int refillBelow = 40, refillVisibility = 0, refillPrimary = 0;      // lane-refill thresholds of the queue traversal kernels (tunable via LUMEN_MI_REFILL*)
+    int refillBelow = 40, refillVisibility = 32, refillPrimary = 0;      // lane-refill thresholds of the queue traversal kernels (tunable via LUMEN_MI_REFILL*)
 
     lumen_mi_settings settings{};
     lumen_mi_settings pending{};
