@@ -101,7 +101,8 @@ struct LmHit { float t, u, v; uint32_t slot; };
 
 // Per-lane traversal stack: the first LM_STACK_LDS entries live in LDS ([level][lane]: one bank per lane), deeper entries
 // (rare) spill to a per-thread global array, so that the LDS footprint (16 KB per 256-thread block) does not cap occupancy.
-struct LmStack { int* lds; int* spill; };
+typedef __attribute__((address_space(3))) int lm_lds_int;      // explicit LDS pointer: ds_read / ds_write, never flat accesses
+struct LmStack { lm_lds_int* lds; int* spill; };
 __device__ __forceinline__ void lm_push(const LmStack& st, int& sp, int v)
 {
     if (sp < LM_STACK_LDS) st.lds[sp * LM_BLOCK] = v; else st.spill[sp - LM_STACK_LDS] = v;
@@ -110,12 +111,16 @@ __device__ __forceinline__ void lm_push(const LmStack& st, int& sp, int v)
 __device__ __forceinline__ int lm_pop(const LmStack& st, int& sp)
 {
     --sp;
-    return sp < LM_STACK_LDS ? st.lds[sp * LM_BLOCK] : st.spill[sp - LM_STACK_LDS];
+    // the LDS slot is read unconditionally (clamped index) and the spill slot only under a branch: a select between the
+    // two POINTERS would turn every pop into a flat load, which is slower than ds_read and waits on both counters
+    int v = st.lds[min(sp, LM_STACK_LDS - 1) * LM_BLOCK];
+    if (sp >= LM_STACK_LDS) v = st.spill[sp - LM_STACK_LDS];
+    return v;
 }
 __device__ __forceinline__ LmStack lm_make_stack(int* s_stack, const LmScene& sc)
 {
     LmStack st;
-    st.lds = s_stack + threadIdx.x;
+    st.lds = (lm_lds_int*)(s_stack + threadIdx.x);
     st.spill = sc.spill + (size_t)(blockIdx.x * LM_BLOCK + threadIdx.x) * (LM_STACK_DEPTH - LM_STACK_LDS);
     return st;
 }
@@ -418,7 +423,10 @@ KN(lm_k_primary)(LmFrame fr, LmCamera cam, uint32_t frameCount)
 // ---------------------------------------------------------------------------------------------------------------------
 // K2-K4: closest-hit query — reference WaveFrontShaders.cu:42-76,301-340 (tmin 0.01, tmax 5000, miss => t = -1)
 // ---------------------------------------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+#ifndef LM_TRACE_WAVES
+#define LM_TRACE_WAVES 8      // <= 64 VGPRs: eight waves per SIMD
+#endif
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_TRACE_WAVES)
 KN(lm_k_trace_closest)(LmScene sc, const float4* __restrict__ rayO, const float4* __restrict__ rayD, const uint32_t* __restrict__ countPtr,
                    uint4* __restrict__ hits, float tmin, float tmax, uint32_t* counters, int refillBelow)
 {
