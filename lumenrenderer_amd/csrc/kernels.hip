@@ -883,11 +883,20 @@ KN(lm_k_trace_shadow)(LmScene sc, LmFrame fr, const uint32_t* __restrict__ count
         });
 }
 
+// reservoir buffer behind an LM_RES_* code (lm_layout.h)
+__device__ __forceinline__ int lm_res_idx(const LmFrame& fr, int code)
+{
+    if (code >= 0) return code;
+    const int cur = *fr.swap & 1;
+    return code == LM_RES_CUR ? cur : cur ^ 1;
+}
+
 // K6 + K23: resolve the visibility rays (tmin 0.1, WaveFrontShaders.cu:181-216: occluded => reservoir weight = 0) and shade
 // the surviving reservoirs into DIRECT with weight / 3 (ReSTIRKernels.cu:600-665)
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
 KN(lm_k_restir_trace_shade)(LmScene sc, LmFrame fr, int rc, const uint32_t* __restrict__ countPtr, int refillBelow, int pass)
 {
+    rc = lm_res_idx(fr, rc);
     __shared__ int s_stack[LM_STACK_LDS * LM_BLOCK];
     const uint32_t n = *countPtr;
     float4* hot = fr.res[rc];
@@ -1003,6 +1012,7 @@ KN(lm_k_fill_bags)(LmScene sc, LmFrame fr, uint32_t seed, uint32_t total)
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
 KN(lm_k_pick_primary)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount)
 {
+    rc = lm_res_idx(fr, rc);
     __shared__ uint2 s_bag[1000];
     __shared__ uint32_t s_tmp[5];
     const uint32_t tilesX = (fr.W + 15u) / 16u;
@@ -1073,6 +1083,9 @@ KN(lm_k_pick_primary)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, ui
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
 KN(lm_k_restir_temporal)(LmFrame fr, int cur, int prev, int rc, int rp, int rf, uint32_t seed, uint32_t* visCount)
 {
+    rc = lm_res_idx(fr, rc);
+    rp = lm_res_idx(fr, rp);
+    rf = lm_res_idx(fr, rf);
     __shared__ uint32_t s_tmp[5];
     uint32_t li = 0, gi = 0;
     const bool valid = lm_tile_pixel(fr, li, gi);
@@ -1127,6 +1140,12 @@ KN(lm_k_restir_temporal)(LmFrame fr, int cur, int prev, int rc, int rp, int rf, 
                 if (weight > 0.f) { vtarget = v3(h3); vpos = v3(fr.gbuf[cur][8u * li]); }
             }
             shoot = weight > 0.f;                                  // second GenerateShadowRay pass (ReSTIR.cpp:211), fused
+        } else if (rf != rc) {
+            // flagged pixel: the candidate pick only zeroes the weight of the CURRENT reservoir and leaves the rest stale
+            // (ReSTIRKernels.cu:441-447); when the pick wrote to its own buffer, do that here — a later frame may read this
+            // entry as "previous" through a probe plane of a different age
+            float4* h = fr.res[rc] + 4u * li;
+            float4 a = h[0]; a.y = 0.f; h[0] = a;
         }
     }
     lf3 vdir = vtarget - vpos;
@@ -1148,6 +1167,8 @@ KN(lm_k_restir_temporal)(LmFrame fr, int cur, int prev, int rc, int rp, int rf, 
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_SPATIAL_WAVES)
 KN(lm_k_restir_spatial)(LmFrame fr, int cur, int rin, int rout, uint32_t seed)
 {
+    rin = lm_res_idx(fr, rin);
+    rout = lm_res_idx(fr, rout);
 #ifdef LM_SPATIAL_PRIO
     __builtin_amdgcn_s_setprio(LM_SPATIAL_PRIO);
 #endif
@@ -1219,6 +1240,8 @@ KN(lm_k_restir_spatial)(LmFrame fr, int cur, int rin, int rout, uint32_t seed)
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
 KN(lm_k_restir_combine)(LmFrame fr, int cur, int rc, int rs, uint32_t seed)
 {
+    rc = lm_res_idx(fr, rc);
+    rs = lm_res_idx(fr, rs);
     uint32_t li = 0, gi = 0;
     if (!lm_tile_pixel(fr, li, gi)) return;
     if (fr.probe[cur][li].w < 0.f) return;
@@ -1241,8 +1264,13 @@ KN(lm_k_clear_f4)(float4* __restrict__ p, uint32_t n)
 // K13 + K14: channel merge with optional running-mean blend (GPUMergeOutputChannels.cu:5-88, fp32) and sRGB8 output
 // (GPUShadingKernels.cu:28-56, vendor/Include/Cuda/cuda/helpers.h:35-66)
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
-KN(lm_k_merge_output)(LmFrame fr, int blend, uint32_t blendCount)
+KN(lm_k_merge_output)(LmFrame fr, int blend, uint32_t blendCount, int depthMax)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {     // ReSTIR::SwapBuffers once per executed wave (WaveFrontRenderer.cpp:697,827)
+        int executed = 0;
+        for (int d = 0; d < depthMax; d++) executed += fr.counters[LM_CNT_RAYS(d)] > 0u;
+        *fr.swap = (*fr.swap + executed) & 1;
+    }
     const uint32_t stride = gridDim.x * LM_BLOCK;
     for (uint32_t li = blockIdx.x * LM_BLOCK + threadIdx.x; li < fr.n; li += stride) {
         float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1494,7 +1522,7 @@ static void l_temporal(hipStream_t s, int g, LmFrame fr, int cur, int prev, int 
 static void l_spatial(hipStream_t s, int g, LmFrame fr, int cur, int rin, int rout, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_restir_spatial), LM_GRID(g), fr, cur, rin, rout, seed); }
 static void l_combine(hipStream_t s, int g, LmFrame fr, int cur, int rc, int rs, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_restir_combine), LM_GRID(g), fr, cur, rc, rs, seed); }
 static void l_clear(hipStream_t s, int g, float4* p, uint32_t n) { hipLaunchKernelGGL(KN(lm_k_clear_f4), LM_GRID(g), p, n); }
-static void l_merge(hipStream_t s, int g, LmFrame fr, int blend, uint32_t blendCount) { hipLaunchKernelGGL(KN(lm_k_merge_output), LM_GRID(g), fr, blend, blendCount); }
+static void l_merge(hipStream_t s, int g, LmFrame fr, int blend, uint32_t blendCount, int depthMax) { hipLaunchKernelGGL(KN(lm_k_merge_output), LM_GRID(g), fr, blend, blendCount, depthMax); }
 static void l_query_any(hipStream_t s, int g, LmScene sc, const float4* o, const float4* d, uint32_t n, float tmin, uint32_t* occ, uint32_t* counters) { hipLaunchKernelGGL(KN(lm_k_query_any), LM_GRID(g), sc, o, d, n, tmin, occ, counters); }
 static void l_query_closest(hipStream_t s, int g, LmScene sc, const float4* o, const float4* d, uint32_t n, float tmin, float tmax, uint4* id, float4* uvt, uint32_t* counters)
 { hipLaunchKernelGGL(KN(lm_k_query_closest_raw), LM_GRID(g), sc, o, d, n, tmin, tmax, id, uvt, counters); }

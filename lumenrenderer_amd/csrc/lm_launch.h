@@ -16,7 +16,7 @@ struct LmKernelTable {
     void (*spatial)(hipStream_t, int tiles, LmFrame, int cur, int rin, int rout, uint32_t seed);
     void (*combine)(hipStream_t, int tiles, LmFrame, int cur, int rc, int rs, uint32_t seed);
     void (*clear)(hipStream_t, int grid, float4* p, uint32_t n);
-    void (*merge)(hipStream_t, int grid, LmFrame, int blend, uint32_t blendCount);
+    void (*merge)(hipStream_t, int grid, LmFrame, int blend, uint32_t blendCount, int depthMax);
     void (*query_any)(hipStream_t, int grid, LmScene, const float4* o, const float4* d, uint32_t n, float tmin, uint32_t* occluded, uint32_t* counters);
     void (*query_closest)(hipStream_t, int grid, LmScene, const float4* o, const float4* d, uint32_t n, float tmin, float tmax, uint4* id, float4* uvt, uint32_t* counters);
     void (*export_aux)(hipStream_t, int grid, LmFrame, int cur, float minD, float maxD, float* depth, uint2* normalRoughness);

@@ -102,8 +102,14 @@ struct LmFrame {
     float4* combined;           // merged / blended radiance
     uchar4* output;             // sRGB8
     uint32_t* counters;         // see LM_CNT_*
+    int* swap;                  // ReSTIR swap-chain index (ReSTIR::m_SwapChainIndex), on the device: it advances once per EXECUTED
+                                // wave, and the wave loop ends when a wave's queue is empty (WaveFrontRenderer.cpp:697,827) — a count only
+                                // the device knows without a host round trip.  Kernels take buffer indices as LM_RES_* codes.
     uint2* bags;                // 50 x 1000 light-bag entries: (light index, pdf bits)
 };
+// reservoir buffer index codes of the ReSTIR kernels: a literal index >= 0, or the swap-chain front / back buffer
+#define LM_RES_CUR (-1)
+#define LM_RES_PREV (-2)
 // counter block layout (uint32 each)
 #define LM_CNT_RAYS(d) (d)                       // rays entering wave d            [0, LM_MAX_DEPTH]
 #define LM_CNT_SHADOW(d) (32 + (d))              // NEE shadow rays emitted by wave d

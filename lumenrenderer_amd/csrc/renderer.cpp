@@ -134,7 +134,8 @@ struct lumen_mi_renderer {
 
     // persistent state (WaveFrontRenderer members)
     uint32_t frameCount = 0, blendCounter = 0;
-    int frameIndex = 0, swapChainIndex = 0;
+    int frameIndex = 0;
+    DevBuf<int> dSwap;                      // ReSTIR swap-chain index lives on the device (LmFrame::swap)
 
     // flattened scene (host)
     std::vector<LmEntry> entries;
@@ -495,7 +496,9 @@ int ensureFrameBuffers(R* r)
     r->allocN = n;
     r->fenceNeeded = true;
     r->haveEst = false; r->cntPending[0] = r->cntPending[1] = false;
-    r->blendCounter = 0; r->frameIndex = 0; r->swapChainIndex = 0;
+    if (r->dSwap.ensure(1) || hipMemsetAsync(r->dSwap.p, 0, sizeof(int), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "swap index allocation failed");
+    f.swap = r->dSwap.p;
+    r->blendCounter = 0; r->frameIndex = 0;
     return 0;
 }
 
@@ -653,7 +656,7 @@ int traceFrameAsync(R* r)
             hipStream_t sp = pickAhead ? r->aux3 : st;      // (HIP multiplexes streams onto 4 hardware queues by default: no fifth stream)
             if (overlap) { LM_HIP(hipEventRecord(r->evFront, sx)); LM_HIP(hipStreamWaitEvent(sp, r->evFront, 0)); }
             evBegin2(r, 3, ev, sp);
-            const int cur = r->swapChainIndex, tmp = cur == 1 ? 0 : 1, fresh = pickAhead ? 4 : cur;
+            const int cur = LM_RES_CUR, tmp = LM_RES_PREV, fresh = pickAhead ? 4 : LM_RES_CUR;
             uint32_t rs = wangHash(seed);
             K->fill_bags(sp, r->dscene, fr, seed, 50u * 1000u);
             rs = wangHash(rs);
@@ -697,7 +700,6 @@ int traceFrameAsync(R* r)
             evEnd2(r, ev, stl);
             if (overlap) LM_HIP(hipEventRecord(r->evTail, stl));
             tailLaunched = true;
-            for (uint32_t dd = depth; dd < depthMax; ++dd) r->swapChainIndex = r->swapChainIndex + 1 >= 2 ? 0 : r->swapChainIndex + 1;   // one SwapBuffers per wave (:827)
             break;
         } else {
             uint32_t* shCount = fr.counters + LM_CNT_SHADOW(depth);
@@ -719,7 +721,6 @@ int traceFrameAsync(R* r)
             if (overlap) { LM_HIP(hipEventRecord(r->evJoin2, ss)); }
         }
         q ^= 1;
-        r->swapChainIndex = r->swapChainIndex + 1 >= 2 ? 0 : r->swapChainIndex + 1;         // ReSTIR::SwapBuffers once per wave (:827)
         seed = wangHash(seed);                                                               // :830
     }
     if (overlap) {
@@ -727,7 +728,7 @@ int traceFrameAsync(R* r)
         if (depthMax > 1) LM_HIP(hipStreamWaitEvent(st, r->evJoin2, 0));
         if (tailLaunched) LM_HIP(hipStreamWaitEvent(st, r->evTail, 0));
     }
-    K->merge(st, r->gridFor(fr.n, 8), fr, blend ? 1 : 0, r->blendCounter);
+    K->merge(st, r->gridFor(fr.n, 8), fr, blend ? 1 : 0, r->blendCounter, (int)depthMax);     // + ReSTIR::SwapBuffers per executed wave
     if (overlap) LM_HIP(hipEventRecord(r->evMerge[par], st));
     if (r->pinnedCounters[par]) {     // asynchronous counter read-back: feeds the next frames' schedule (above)
         LM_HIP(hipMemcpyAsync(r->pinnedCounters[par], fr.counters, LM_CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -848,7 +849,7 @@ int lumen_mi_destroy(lumen_mi_renderer* r)
         r->dQuant.release(); r->dTriBox.release(); r->dNodeBox.release(); r->dLevelNodes.release(); r->dRefitBounds.release();
         r->dEntries.release(); r->dMaterials.release(); r->dTexDesc.release(); r->dTexels.release(); r->dLut.release(); r->dLights.release(); r->dCdf.release();
         for (auto& b : r->dRay) b.release(); for (auto& b : r->dTailRay) b.release(); for (auto& b : r->dSh) b.release(); for (auto& b : r->dSh2) b.release(); for (auto& b : r->dGbuf) b.release(); for (auto& b : r->dProbe) b.release(); for (auto& b : r->dRes) b.release(); for (auto& b : r->dResC) b.release();
-        for (int i = 0; i < 2; i++) { r->dDirect[i].release(); r->dIndirect[i].release(); } r->dCombined.release(); r->dHits.release(); r->dMotion.release(); r->dCounters.release(); r->dOutput.release(); r->dBags.release();
+        for (int i = 0; i < 2; i++) { r->dDirect[i].release(); r->dIndirect[i].release(); } r->dCombined.release(); r->dHits.release(); r->dMotion.release(); r->dCounters.release(); r->dSwap.release(); r->dOutput.release(); r->dBags.release();
         for (auto& e : r->evPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     }
     delete r;

@@ -143,6 +143,19 @@ def test_cornell_c1_frame_bit_exact():
     r.close(); o.close()
 
 
+@pytest.mark.parametrize("w,h,depth", [(37, 23, 1), (1, 1, 3), (250, 3, 2), (61, 67, 16), (128, 128, 7)])
+def test_ragged_sizes_and_depth_limits(w, h, depth):
+    """Window sizes that are not multiples of the 8x8 / 16x16 tiles, a single pixel, depth 1 (no indirect wave), the deepest
+    path the counter block allows (16: the rays run out after 4-5 waves, so the wave loop ends early and the ReSTIR swap chain
+    advances by the number of EXECUTED waves, WaveFrontRenderer.cpp:697,827) and an odd depth (the swap chain alternates)."""
+    d = cornell()
+    r = product_from(d, w, h, depth, blend=True); o = oracle_from(d, w, h, depth, blend=True)
+    _compare_frames(r, o, 6)
+    c, s = r.GetCounters(), o.stats(24)
+    assert list(c[4:4 + min(depth, 16)]) == list(s[4:4 + min(depth, 16)])
+    r.close(); o.close()
+
+
 def test_denoiser_inputs_match_oracle():
     """depth / normal-roughness / motion exports (GPUExtractNRD_DLSSdata.cu, GPUExtractDepthData.cu)."""
     from lumenrenderer_amd.scenes import sponza_standin
@@ -197,6 +210,18 @@ def test_sponza_with_1024_emissive_triangles_matches_oracle():
 TUNINGS = [{"tail_below": 0}, {"tail_below": 1 << 30}, {"tail_below": 6000}, {"tail_below": 6000, "tail_lanes": 64},
            {"single_stream": 1, "tail_below": 0}, {"single_stream": 1}, {"refill": 0, "tail_below": 0},
            {"pick_ahead": 0}, {"pick_ahead": 1, "tail_below": 0}]
+DEEP = [{}, {"pick_ahead": 0, "tail_below": 0}, {"pick_ahead": 1, "tail_below": 1 << 30}, {"single_stream": 1}]
+
+
+@pytest.mark.parametrize("tuning", DEEP, ids=lambda t: ",".join(f"{k}={v}" for k, v in t.items()) or "default")
+def test_early_wave_loop_exit_under_every_schedule(tuning):
+    """Depth 16 on a small image: every frame executes a different number of waves (the queue runs empty), so the swap chain
+    parity and the age of the 'previous' reservoirs change from frame to frame."""
+    d = cornell()
+    r = product_from(d, 61, 67, 16, blend=True, tuning=tuning); o = oracle_from(d, 61, 67, 16, blend=True)
+    _compare_frames(r, o, 7, check_gbuffer=False)
+    r.close(); o.close()
+
 
 
 @pytest.mark.parametrize("tuning", TUNINGS, ids=lambda t: ",".join(f"{k}={v}" for k, v in t.items()))
