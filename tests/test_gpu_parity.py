@@ -156,6 +156,59 @@ def test_ragged_sizes_and_depth_limits(w, h, depth):
     r.close(); o.close()
 
 
+def test_moving_camera_and_setting_changes_between_frames():
+    """Camera motion drives the motion vectors and the temporal reprojection (MotionVectors.cu, ReSTIRKernels.cu:1015-1121);
+    depth, blend mode and resolution change between frames as the reference's setters allow (WaveFrontRenderer.cpp:480-505).
+    Frames are enqueued asynchronously in groups, so the pipelined schedule sees every change as well."""
+    d = cornell()
+    r = product_from(d, 112, 80, 4, blend=True); o = oracle_from(d, 112, 80, 4, blend=True)
+
+    def cam(k):
+        a = 0.05 * k
+        fwd = np.float32([np.sin(a), -0.03 * k, -np.cos(a)]); fwd /= np.linalg.norm(fwd)
+        up0 = np.float32([0, 1, 0]); right = np.cross(up0, fwd); right /= np.linalg.norm(right); up = np.cross(fwd, right)
+        pos = np.float32([0.08 * k, 1.0 + 0.03 * k, 3.4 - 0.1 * k])
+        return pos, right.astype(np.float32), up.astype(np.float32), fwd
+
+    def check(tag):
+        r.Synchronize()
+        assert np.array_equal(r.GetRadiance().view(np.uint32), o.radiance().view(np.uint32)), tag
+        assert np.array_equal(r.GetGBuffer().view(np.uint32), o.gbuffer().view(np.uint32)), tag
+        _, nr, mv = r.GetDenoiserInputs(); _, onr, omv = o.denoiser_inputs()
+        assert np.array_equal(mv.reshape(-1, 2), omv), tag
+        c, s = r.GetCounters(), o.stats(24)
+        assert list(c[:4]) == list(s[:4]), (tag, c[:4], s[:4])
+
+    for k in range(5):                                   # moving camera, frames enqueued back to back
+        p = cam(k)
+        r.SetCamera(*p); o.set_camera(*p)
+        assert r.TraceFrameAsync(); assert o.trace_frame() == 0
+        if k in (0, 2, 4):
+            check(("move", k))
+    assert mv_nonzero(r)
+    r.SetDepth(3); o.set_depth(3)
+    for k in range(2):
+        assert r.TraceFrameAsync(); assert o.trace_frame() == 0
+    check("depth 3")
+    r.SetBlendMode(False); o.set_blend(False)
+    assert r.TraceFrameAsync(); assert o.trace_frame() == 0
+    r.SetBlendMode(True); o.set_blend(True)
+    for k in range(2):
+        p = cam(5 + k); r.SetCamera(*p); o.set_camera(*p)
+        assert r.TraceFrameAsync(); assert o.trace_frame() == 0
+    check("blend toggled")
+    r.SetRenderResolution(90, 70); o.set_resolution(90, 70)
+    for k in range(3):
+        assert r.TraceFrameAsync(); assert o.trace_frame() == 0
+    check("resolution changed")
+    r.close(); o.close()
+
+
+def mv_nonzero(r):
+    _, _, mv = r.GetDenoiserInputs()
+    return bool(mv.any())
+
+
 def test_denoiser_inputs_match_oracle():
     """depth / normal-roughness / motion exports (GPUExtractNRD_DLSSdata.cu, GPUExtractDepthData.cu)."""
     from lumenrenderer_amd.scenes import sponza_standin
@@ -185,6 +238,20 @@ def test_cornell_window_matches_oracle_window():
         assert r.TraceFrame() and o.trace_frame() == 0
         want = o.radiance()[win[1]:win[3], win[0]:win[2]]
         assert np.array_equal(r.GetRadiance().view(np.uint32), np.ascontiguousarray(want).view(np.uint32))
+    r.close(); o.close()
+
+
+def test_unaligned_window_async_frames():
+    """A render window whose origin and size are not multiples of the 8 / 16 pixel tiles (what an odd tile grid produces),
+    several frames enqueued back to back: tile schedule (path tail, pick-ahead) on a window with halo semantics."""
+    d = cornell()
+    win = (37, 19, 151, 103)
+    r = product_from(d, 192, 128, 4, blend=True, window=win); o = oracle_from(d, 192, 128, 4, blend=True, window=win)
+    for _ in range(4):
+        assert r.TraceFrameAsync() and o.trace_frame() == 0
+    r.Synchronize()
+    want = o.radiance()[win[1]:win[3], win[0]:win[2]]
+    assert np.array_equal(r.GetRadiance().view(np.uint32), np.ascontiguousarray(want).view(np.uint32))
     r.close(); o.close()
 
 
