@@ -121,6 +121,7 @@ struct lumen_mi_renderer {
     long activeScene = -1;
     bool sceneDirty = true, texturesDirty = true, materialsDirty = true;
     bool transformsDirty = false;           // only instance matrices changed since the last build: the BVH is refitted on the GPU
+    bool entriesDirty = false;              // emissive mode / radiance / override material of an instance changed: scene table + lights only
     uint32_t refits = 0;                    // refits since the last full build
     int refitEnabled = 1;                   // 0: every transform change triggers a full host rebuild
 
@@ -231,38 +232,49 @@ void findEmissives(const R* r, Primitive& p)
 }
 
 // scene data table + world-space triangle soup + BVH — replaces PTScene/PTMeshInstance/OptixWrapper AS builds
-// instance matrices changed, nothing else: refresh the scene data table and refit the BVH on the GPU (kernels.hip "BVH refit").
-// Everything is enqueued on the main stream; no host synchronisation.
-int refit(R* r)
+// Instance state changed (matrices, emissive mode / radiance, override material) but not the set of instances: refresh the
+// scene data table and, if something moved, refit the BVH on the GPU (kernels.hip "BVH refit").  Everything is enqueued on
+// the main stream; no host synchronisation.
+int refreshEntries(R* r)
 {
     const Scene& sc = r->scenes[r->activeScene];
     for (size_t ii : sc.instances) {
         const Instance& mi = r->instances[ii];
-        for (uint32_t e : mi.entries) memcpy(r->entries[e].m, mi.M, sizeof r->entries[e].m);
+        const std::vector<size_t>& prims = r->meshes[mi.mesh].prims;
+        for (size_t k = 0; k < mi.entries.size() && k < prims.size(); k++) {
+            LmEntry& e = r->entries[mi.entries[k]];
+            memcpy(e.m, mi.M, sizeof e.m);
+            e.material = (uint32_t)(mi.overrideMaterial >= 0 ? (size_t)mi.overrideMaterial : r->prims[prims[k]].material);
+            e.mode = (uint32_t)mi.mode;
+            e.emissive = make_float4(mi.radiance[0], mi.radiance[1], mi.radiance[2], mi.scale);
+        }
     }
     hipStream_t st = r->stream;
     if (r->dEntries.upload(r->entries, st)) return fail(LUMEN_MI_ERR_DEVICE, "scene table upload failed");
-    const LmKernelTable* K = r->K;
-    const uint32_t nt = (uint32_t)r->bvh.order.size();
-    K->refit_tris(st, r->dscene, nt, r->dTriBox.p, r->dRefitBounds.p);
-    K->refit_quant(st, r->dRefitBounds.p, r->dQuant.p);
-    for (size_t l = 0; l + 1 < r->bvh.levelStart.size(); l++) {
-        const uint32_t a = r->bvh.levelStart[l], b = r->bvh.levelStart[l + 1];
-        if (b > a) K->refit_level(st, r->dscene, r->dLevelNodes.p + a, b - a, r->dTriBox.p, r->dNodeBox.p);
+    if (r->transformsDirty) {
+        const LmKernelTable* K = r->K;
+        const uint32_t nt = (uint32_t)r->bvh.order.size();
+        K->refit_tris(st, r->dscene, nt, r->dTriBox.p, r->dRefitBounds.p);
+        K->refit_quant(st, r->dRefitBounds.p, r->dQuant.p);
+        for (size_t l = 0; l + 1 < r->bvh.levelStart.size(); l++) {
+            const uint32_t a = r->bvh.levelStart[l], b = r->bvh.levelStart[l + 1];
+            if (b > a) K->refit_level(st, r->dscene, r->dLevelNodes.p + a, b - a, r->dTriBox.p, r->dNodeBox.p);
+        }
+        LM_HIP(hipGetLastError());
+        ++r->refits;
     }
-    LM_HIP(hipGetLastError());
     r->transformsDirty = false;
+    r->entriesDirty = false;
     r->lightsDirty = true;
     r->fenceNeeded = true;
-    ++r->refits;
     return 0;
 }
 
 int flatten(R* r)
 {
     if (!r->sceneDirty) {
-        if (!r->transformsDirty) return 0;
-        if (r->refitEnabled && r->activeScene >= 0 && !r->entries.empty()) return refit(r);
+        if (!r->transformsDirty && !r->entriesDirty) return 0;
+        if (r->refitEnabled && r->activeScene >= 0 && !r->entries.empty()) return refreshEntries(r);
         r->sceneDirty = true;
     }
     if (r->activeScene < 0) return fail(LUMEN_MI_ERR_STATE, "no scene set (lumen_mi_set_scene)");
@@ -331,6 +343,7 @@ int flatten(R* r)
     r->dscene.verts = r->dVerts.p; r->dscene.indices = r->dIndices.p; r->dscene.entries = r->dEntries.p;
     r->sceneDirty = false;
     r->transformsDirty = false;
+    r->entriesDirty = false;
     r->lightsDirty = true;
     return 0;
 }
@@ -1045,7 +1058,7 @@ int lumen_mi_instance_set_emissiveness(lumen_mi_renderer* r, lumen_mi_handle ins
     size_t i;
     if (!r || !rad || mode < 0 || mode > 2 || !unh(inst, H_INSTANCE, r->instances.size(), i)) return fail(LUMEN_MI_ERR_INVALID, "bad emissiveness arguments");
     Instance& x = r->instances[i];
-    if (x.mode != mode || x.radiance[0] != rad[0] || x.radiance[1] != rad[1] || x.radiance[2] != rad[2] || x.scale != scale) r->sceneDirty = true;
+    if (x.mode != mode || x.radiance[0] != rad[0] || x.radiance[1] != rad[1] || x.radiance[2] != rad[2] || x.scale != scale) r->entriesDirty = true;
     x.mode = mode; x.radiance[0] = rad[0]; x.radiance[1] = rad[1]; x.radiance[2] = rad[2]; x.scale = scale;
     return 0;
 }
@@ -1054,7 +1067,8 @@ int lumen_mi_instance_set_override_material(lumen_mi_renderer* r, lumen_mi_handl
 {
     size_t i, m;
     if (!r || !unh(inst, H_INSTANCE, r->instances.size(), i) || !unh(mat, H_MATERIAL, r->materials.size(), m)) return fail(LUMEN_MI_ERR_INVALID, "bad handle");
-    r->instances[i].overrideMaterial = (long)m; r->sceneDirty = true;
+    if (r->instances[i].overrideMaterial != (long)m) r->entriesDirty = true;
+    r->instances[i].overrideMaterial = (long)m;
     return 0;
 }
 

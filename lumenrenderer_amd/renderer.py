@@ -314,6 +314,7 @@ class LumenRendererMI:
             mi.SetEmissiveness(inst["emission_mode"], inst["override_radiance"], inst["scale"])
         self.SetScene(scene)
         self.m_Scene = scene
+        self.m_Materials = mats
         cam = desc.camera
         self.SetCamera(cam["position"], cam["right"], cam["up"], cam["forward"], cam["fov"])
         return scene

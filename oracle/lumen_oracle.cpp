@@ -1204,6 +1204,13 @@ int orc_add_instance(orc_ctx* c, int mesh, const float transform[16], int mode, 
     return (int)c->instances.size() - 1;
 }
 void orc_set_instance_transform(orc_ctx* c, int inst, const float transform[16]) { memcpy(c->instances[inst].M, transform, 64); c->sceneDirty = true; }
+// MeshInstance::SetEmissiveness / SetOverrideMaterial (MeshInstance.h:57-98): picked up at the top of the next frame
+void orc_set_instance_emissiveness(orc_ctx* c, int inst, int mode, const float rad[3], float scale)
+{
+    MeshInstance& mi = c->instances[inst];
+    mi.mode = mode; mi.overrideRadiance = f3{rad[0], rad[1], rad[2]}; mi.scale = scale; c->sceneDirty = true;
+}
+void orc_set_instance_override_material(orc_ctx* c, int inst, int material) { c->instances[inst].overrideMaterial = material; c->sceneDirty = true; }
 void orc_set_camera(orc_ctx* c, const float pos[3], const float right[3], const float up[3], const float fwd[3], float fov)
 {
     c->camPos = f3{pos[0], pos[1], pos[2]}; c->camRight = f3{right[0], right[1], right[2]};

@@ -44,6 +44,8 @@ int  orc_add_mesh(orc_ctx*, const int* primitives, uint32_t n);
 /* transform: row-major 4x4 world matrix. emission_mode: 0 ENABLED, 1 DISABLED, 2 OVERRIDE (MeshInstance.h:14-19) */
 int  orc_add_instance(orc_ctx*, int mesh, const float transform[16], int emission_mode, const float override_radiance[3], float scale, int override_material);
 void orc_set_instance_transform(orc_ctx*, int instance, const float transform[16]);
+void orc_set_instance_emissiveness(orc_ctx*, int instance, int emission_mode, const float override_radiance[3], float scale);
+void orc_set_instance_override_material(orc_ctx*, int instance, int material);
 void orc_get_denoiser_inputs(orc_ctx*, float min_distance, float max_distance, float* depth, uint16_t* normal_roughness_half4, uint16_t* motion_half2);
 
 /* camera: position + rotation matrix columns right/up/forward (Camera.cpp:122-140), vertical fov in degrees */

@@ -41,6 +41,8 @@ def lib():
             ("orc_add_mesh", [C.c_void_p, i32p, C.c_uint32], C.c_int),
             ("orc_add_instance", [C.c_void_p, C.c_int, fp, C.c_int, fp, C.c_float, C.c_int], C.c_int),
             ("orc_set_instance_transform", [C.c_void_p, C.c_int, fp], None),
+            ("orc_set_instance_emissiveness", [C.c_void_p, C.c_int, C.c_int, fp, C.c_float], None),
+            ("orc_set_instance_override_material", [C.c_void_p, C.c_int, C.c_int], None),
             ("orc_get_denoiser_inputs", [C.c_void_p, C.c_float, C.c_float, fp, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16)], None),
             ("orc_set_camera", [C.c_void_p, fp, fp, fp, fp, C.c_float], None),
             ("orc_set_resolution", [C.c_void_p, C.c_uint32, C.c_uint32], None),
@@ -121,6 +123,11 @@ class Oracle:
 
     def set_instance_transform(self, inst, transform):
         t = f32(transform).reshape(16); self.L.orc_set_instance_transform(self.h, inst, fptr(t))
+
+    def set_instance_emissiveness(self, inst, mode, override_radiance=(0, 0, 0), scale=1.0):
+        self.L.orc_set_instance_emissiveness(self.h, inst, mode, fptr(f32(override_radiance)), float(scale))
+
+    def set_instance_override_material(self, inst, material): self.L.orc_set_instance_override_material(self.h, inst, material)
 
     def set_camera(self, pos, right, up, forward, fov=90.0):
         self.L.orc_set_camera(self.h, fptr(f32(pos)), fptr(f32(right)), fptr(f32(up)), fptr(f32(forward)), float(fov))
