@@ -110,7 +110,9 @@ struct lumen_mi_renderer {
 
     lumen_mi_settings settings{};
     lumen_mi_settings pending{};
-    std::mutex settingsMutex, frameMutex;
+    std::mutex settingsMutex;
+    std::recursive_mutex frameMutex;        // every entry point that touches scene / frame state takes it (factories call each other)
+    std::atomic<int> waiters{0};            // callers queued on frameMutex: the render thread lets them in between two frames
 
     std::vector<Texture> textures;
     std::vector<Material> materials;
@@ -179,6 +181,14 @@ struct lumen_mi_renderer {
 
     int traceGrid() const { return numCU * 8; }
     int gridFor(uint32_t n, int perCU) const { const int full = (int)((n + 255u) / 256u); return std::max(1, std::min(full, numCU * perCU)); }
+};
+
+// frame mutex with a waiter count: std::mutex is not fair, and the render thread re-acquires it back to back
+struct ApiLock {
+    lumen_mi_renderer* r;
+    explicit ApiLock(lumen_mi_renderer* r_) : r(r_) { r->waiters.fetch_add(1); r->frameMutex.lock(); r->waiters.fetch_sub(1); }
+    ~ApiLock() { r->frameMutex.unlock(); }
+    ApiLock(const ApiLock&) = delete; ApiLock& operator=(const ApiLock&) = delete;
 };
 
 namespace {
@@ -869,11 +879,12 @@ int lumen_mi_destroy(lumen_mi_renderer* r)
     return 0;
 }
 
-int lumen_mi_set_stream(lumen_mi_renderer* r, void* s) { if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer"); r->stream = (hipStream_t)s; return 0; }
+int lumen_mi_set_stream(lumen_mi_renderer* r, void* s) { if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer"); ApiLock lk(r); r->stream = (hipStream_t)s; return 0; }
 
 int lumen_mi_create_texture(lumen_mi_renderer* r, const void* rgba8, uint32_t w, uint32_t h, int normalize, lumen_mi_handle* out)
 {
     if (!r || !rgba8 || !out || w == 0 || h == 0) return fail(LUMEN_MI_ERR_INVALID, "bad texture arguments");
+    ApiLock lk(r);
     Texture t; t.w = w; t.h = h; t.srgb = normalize != 0;          // a_Normalize selects sRGB decode (PTTexture.cpp:57-73)
     t.px.resize((size_t)w * h);
     memcpy(t.px.data(), rgba8, (size_t)w * h * 4);
@@ -885,6 +896,7 @@ int lumen_mi_create_texture(lumen_mi_renderer* r, const void* rgba8, uint32_t w,
 
 int lumen_mi_create_default_resources(lumen_mi_renderer* r, lumen_mi_handle* white, lumen_mi_handle* normal, lumen_mi_handle* diffuse)
 {
+    ApiLock lk(r);
     // LumenRenderer::CreateDefaultResources (Lumen/src/Lumen/Renderer/LumenRenderer.cpp:50-58): three 1x1 textures, normalize = false
     const uint8_t w[4] = {255, 255, 255, 255}, n[4] = {128, 128, 255, 0}, d[4] = {255, 255, 255, 255};
     lumen_mi_handle hw, hn, hd; int rc;
@@ -934,6 +946,7 @@ static int fillMaterial(lumen_mi_renderer* r, const lumen_mi_material_data* d, M
 int lumen_mi_create_material(lumen_mi_renderer* r, const lumen_mi_material_data* d, lumen_mi_handle* out)
 {
     if (!r || !d || !out) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    ApiLock lk(r);
     Material m;
     const int rc = fillMaterial(r, d, m);
     if (rc) return rc;
@@ -950,7 +963,7 @@ int lumen_mi_update_material(lumen_mi_renderer* r, lumen_mi_handle material, con
     Material m;
     const int rc = fillMaterial(r, d, m);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(r->frameMutex);
+    ApiLock lk(r);
     r->materials[idx] = m;
     r->materialsDirty = true;
     // the emissive classification of primitives is a function of their material (FindEmissives at CreatePrimitive time in the
@@ -963,6 +976,7 @@ int lumen_mi_update_material(lumen_mi_renderer* r, lumen_mi_handle material, con
 int lumen_mi_create_primitive(lumen_mi_renderer* r, const lumen_mi_primitive_data* d, lumen_mi_handle* out, uint32_t* numLights)
 {
     if (!r || !d || !out) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    ApiLock lk(r);
     size_t mat;
     if (!unh(d->material, H_MATERIAL, r->materials.size(), mat)) return fail(LUMEN_MI_ERR_INVALID, "bad material handle");
     if (d->n_vertices == 0 || d->n_indices < 3 || !d->index_binary || (d->index_size != 2 && d->index_size != 4)) return fail(LUMEN_MI_ERR_INVALID, "bad primitive data");
@@ -998,6 +1012,7 @@ int lumen_mi_create_primitive(lumen_mi_renderer* r, const lumen_mi_primitive_dat
 int lumen_mi_create_mesh(lumen_mi_renderer* r, const lumen_mi_handle* prims, uint32_t n, lumen_mi_handle* out)
 {
     if (!r || !prims || !out || n == 0) return fail(LUMEN_MI_ERR_INVALID, "bad mesh arguments");
+    ApiLock lk(r);
     Mesh m;
     for (uint32_t i = 0; i < n; i++) { size_t p; if (!unh(prims[i], H_PRIMITIVE, r->prims.size(), p)) return fail(LUMEN_MI_ERR_INVALID, "bad primitive handle"); m.prims.push_back(p); }
     r->meshes.push_back(m);
@@ -1008,6 +1023,7 @@ int lumen_mi_create_mesh(lumen_mi_renderer* r, const lumen_mi_handle* prims, uin
 int lumen_mi_create_scene(lumen_mi_renderer* r, lumen_mi_handle* out)
 {
     if (!r || !out) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    ApiLock lk(r);
     r->scenes.emplace_back();
     *out = mkh(H_SCENE, r->scenes.size() - 1);
     return 0;
@@ -1017,6 +1033,7 @@ int lumen_mi_set_scene(lumen_mi_renderer* r, lumen_mi_handle scene)
 {
     size_t s;
     if (!r || !unh(scene, H_SCENE, r->scenes.size(), s)) return fail(LUMEN_MI_ERR_INVALID, "bad scene handle");
+    ApiLock lk(r);
     r->activeScene = (long)s; r->sceneDirty = true;
     return 0;
 }
@@ -1025,6 +1042,7 @@ int lumen_mi_scene_add_mesh(lumen_mi_renderer* r, lumen_mi_handle scene, lumen_m
 {
     size_t s, m;
     if (!r || !inst || !unh(scene, H_SCENE, r->scenes.size(), s) || !unh(mesh, H_MESH, r->meshes.size(), m)) return fail(LUMEN_MI_ERR_INVALID, "bad scene/mesh handle");
+    ApiLock lk(r);
     Instance i;
     i.scene = s; i.mesh = m;
     const float id[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
@@ -1041,6 +1059,7 @@ int lumen_mi_scene_clear(lumen_mi_renderer* r, lumen_mi_handle scene)
 {
     size_t s;
     if (!r || !unh(scene, H_SCENE, r->scenes.size(), s)) return fail(LUMEN_MI_ERR_INVALID, "bad scene handle");
+    ApiLock lk(r);
     r->scenes[s].instances.clear(); r->sceneDirty = true;
     return 0;
 }
@@ -1049,6 +1068,7 @@ int lumen_mi_instance_set_transform(lumen_mi_renderer* r, lumen_mi_handle inst, 
 {
     size_t i;
     if (!r || !m || !unh(inst, H_INSTANCE, r->instances.size(), i)) return fail(LUMEN_MI_ERR_INVALID, "bad instance handle");
+    ApiLock lk(r);
     if (memcmp(r->instances[i].M, m, 64) != 0) { memcpy(r->instances[i].M, m, 64); r->transformsDirty = true; }   // polled every frame by the adapter
     return 0;
 }
@@ -1057,6 +1077,7 @@ int lumen_mi_instance_set_emissiveness(lumen_mi_renderer* r, lumen_mi_handle ins
 {
     size_t i;
     if (!r || !rad || mode < 0 || mode > 2 || !unh(inst, H_INSTANCE, r->instances.size(), i)) return fail(LUMEN_MI_ERR_INVALID, "bad emissiveness arguments");
+    ApiLock lk(r);
     Instance& x = r->instances[i];
     if (x.mode != mode || x.radiance[0] != rad[0] || x.radiance[1] != rad[1] || x.radiance[2] != rad[2] || x.scale != scale) r->entriesDirty = true;
     x.mode = mode; x.radiance[0] = rad[0]; x.radiance[1] = rad[1]; x.radiance[2] = rad[2]; x.scale = scale;
@@ -1067,6 +1088,7 @@ int lumen_mi_instance_set_override_material(lumen_mi_renderer* r, lumen_mi_handl
 {
     size_t i, m;
     if (!r || !unh(inst, H_INSTANCE, r->instances.size(), i) || !unh(mat, H_MATERIAL, r->materials.size(), m)) return fail(LUMEN_MI_ERR_INVALID, "bad handle");
+    ApiLock lk(r);
     if (r->instances[i].overrideMaterial != (long)m) r->entriesDirty = true;
     r->instances[i].overrideMaterial = (long)m;
     return 0;
@@ -1075,6 +1097,7 @@ int lumen_mi_instance_set_override_material(lumen_mi_renderer* r, lumen_mi_handl
 int lumen_mi_camera_set(lumen_mi_renderer* r, const float p[3], const float right[3], const float up[3], const float fwd[3], float fov)
 {
     if (!r || !p || !right || !up || !fwd) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    ApiLock lk(r);
     for (int k = 0; k < 3; k++) { r->camPos[k] = p[k]; r->camRight[k] = right[k]; r->camUp[k] = up[k]; r->camFwd[k] = fwd[k]; }
     r->fovY = fov;
     return 0;
@@ -1101,12 +1124,12 @@ int lumen_mi_set_blend_mode(lumen_mi_renderer* r, int b) { if (!r) return fail(L
 int lumen_mi_get_blend_mode(lumen_mi_renderer* r, int* b) { if (!r || !b) return fail(LUMEN_MI_ERR_INVALID, "NULL argument"); *b = r->pending.blend_output; return 0; }
 int lumen_mi_set_depth(lumen_mi_renderer* r, uint32_t d) { if (!r || d == 0 || d > LM_MAX_DEPTH) return fail(LUMEN_MI_ERR_INVALID, "depth must be in [1, 16]"); r->pending.depth = d; return 0; }
 
-int lumen_mi_trace_frame_async(lumen_mi_renderer* r) { if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer"); std::lock_guard<std::mutex> lk(r->frameMutex); return traceFrameAsync(r); }
-int lumen_mi_synchronize(lumen_mi_renderer* r) { if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer"); std::lock_guard<std::mutex> lk(r->frameMutex); return syncAndCollect(r); }
+int lumen_mi_trace_frame_async(lumen_mi_renderer* r) { if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer"); ApiLock lk(r); return traceFrameAsync(r); }
+int lumen_mi_synchronize(lumen_mi_renderer* r) { if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer"); ApiLock lk(r); return syncAndCollect(r); }
 int lumen_mi_trace_frame(lumen_mi_renderer* r)
 {
     if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer");
-    std::lock_guard<std::mutex> lk(r->frameMutex);
+    ApiLock lk(r);
     const int rc = traceFrameAsync(r);
     if (rc) return rc;
     return syncAndCollect(r);
@@ -1116,7 +1139,12 @@ int lumen_mi_start_rendering(lumen_mi_renderer* r)
     if (!r || !r->initialised) return fail(LUMEN_MI_ERR_STATE, "not initialised");
     if (r->renderThread.joinable()) return 0;
     r->stopFlag = false;
-    r->renderThread = std::thread([r] { while (!r->stopFlag.load()) { if (lumen_mi_trace_frame(r) != 0) std::this_thread::sleep_for(std::chrono::milliseconds(5)); } });
+    r->renderThread = std::thread([r] {
+        while (!r->stopFlag.load()) {
+            while (r->waiters.load() > 0 && !r->stopFlag.load()) std::this_thread::yield();      // main-thread calls go first
+            if (lumen_mi_trace_frame(r) != 0) std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        }
+    });
     return 0;
 }
 int lumen_mi_stop_rendering(lumen_mi_renderer* r)
@@ -1132,7 +1160,7 @@ static int copyOut(lumen_mi_renderer* r, const void* dev, size_t bytes, void* ho
     if (!r || !host) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
     if (!dev) return fail(LUMEN_MI_ERR_STATE, "no frame has been traced yet");
     if (capacity < bytes) return fail(LUMEN_MI_ERR_INVALID, "buffer too small");
-    std::lock_guard<std::mutex> lk(r->frameMutex);
+    ApiLock lk(r);
     int rc = syncAndCollect(r);
     if (rc) return rc;
     LM_HIP(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
@@ -1153,6 +1181,7 @@ int lumen_mi_get_channel(lumen_mi_renderer* r, int ch, float* out, size_t cap)
 int lumen_mi_copy_radiance_device(lumen_mi_renderer* r, void* dst)
 {
     if (!r || !dst) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    ApiLock lk(r);
     if (!r->fr.combined) return fail(LUMEN_MI_ERR_STATE, "no frame has been traced yet");
     LM_HIP(hipMemcpyAsync(dst, r->fr.combined, (size_t)r->fr.n * 16, hipMemcpyDeviceToDevice, r->stream));
     return 0;
@@ -1169,7 +1198,7 @@ int lumen_mi_get_gbuffer(lumen_mi_renderer* r, float* out, size_t cap)
 int lumen_mi_get_denoiser_inputs(lumen_mi_renderer* r, float minD, float maxD, float* depth, uint16_t* normalRoughness, uint16_t* motion)
 {
     if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer");
-    std::lock_guard<std::mutex> lk(r->frameMutex);
+    ApiLock lk(r);
     int rc = syncAndCollect(r); if (rc) return rc;
     const uint32_t n = r->fr.n;
     if (!n || !r->fr.gbuf[0]) return fail(LUMEN_MI_ERR_STATE, "no frame has been traced");
@@ -1198,7 +1227,7 @@ int lumen_mi_get_frame_stat(lumen_mi_renderer* r, const char* key, uint64_t* us)
 int lumen_mi_get_counters(lumen_mi_renderer* r, uint64_t* out, uint32_t n)
 {
     if (!r || !out) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
-    { std::lock_guard<std::mutex> lk(r->frameMutex); int rc = syncAndCollect(r); if (rc) return rc; }
+    { ApiLock lk(r); int rc = syncAndCollect(r); if (rc) return rc; }
     uint64_t v[48] = {0};
     const uint32_t* c = r->hostCounters;
     for (uint32_t d = 0; d < r->lastDepth && d < 16; d++) { v[0] += c[LM_CNT_RAYS(d)]; v[4 + d] = c[LM_CNT_RAYS(d)]; v[1] += c[LM_CNT_SHADOW(d)]; }
@@ -1222,6 +1251,7 @@ int lumen_mi_get_kernel_time(lumen_mi_renderer* r, int which, float* ms, uint32_
 int lumen_mi_enable_kernel_timing(lumen_mi_renderer* r, int e)
 {
     if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer");
+    ApiLock lk(r);
     if (e) { for (int c = 0; c < 5; c++) { r->classMs[c] = 0.f; r->classLaunches[c] = 0; } }      // enabling starts a new accumulation window
     r->timing = e != 0;
     return 0;
@@ -1229,7 +1259,7 @@ int lumen_mi_enable_kernel_timing(lumen_mi_renderer* r, int e)
 int lumen_mi_set_tuning(lumen_mi_renderer* r, const char* key, int value)
 {
     if (!r || !key) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
-    std::lock_guard<std::mutex> lk(r->frameMutex);
+    ApiLock lk(r);
     const std::string k = key;
     if (k == "tail_below") r->tailBelow = value;
     else if (k == "tail_lanes") r->tailLanes = std::max(1, std::min(64, value));
@@ -1242,11 +1272,12 @@ int lumen_mi_set_tuning(lumen_mi_renderer* r, const char* key, int value)
     else return fail(LUMEN_MI_ERR_INVALID, std::string("unknown tuning key: ") + key);
     return 0;
 }
-int lumen_mi_set_instrumented(lumen_mi_renderer* r, int e) { if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer"); r->instrumented = e != 0; r->K = e ? lm_kernel_table_instrumented() : lm_kernel_table(); return 0; }
+int lumen_mi_set_instrumented(lumen_mi_renderer* r, int e) { if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer"); ApiLock lk(r); r->instrumented = e != 0; r->K = e ? lm_kernel_table_instrumented() : lm_kernel_table(); return 0; }
 
 int lumen_mi_set_window(lumen_mi_renderer* r, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1)
 {
     if (!r || x0 >= x1 || y0 >= y1) return fail(LUMEN_MI_ERR_INVALID, "empty window");
+    ApiLock lk(r);
     r->wx0 = x0; r->wy0 = y0; r->wx1 = x1; r->wy1 = y1; r->windowSet = true;
     return 0;
 }
@@ -1265,7 +1296,7 @@ static int prepareScene(lumen_mi_renderer* r)
 int lumen_mi_query_closest(lumen_mi_renderer* r, uint32_t n, const float* o, const float* d, float tmin, float tmax, uint32_t* ip, float* uvt)
 {
     if (!r || !o || !d || !ip || !uvt) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
-    std::lock_guard<std::mutex> lk(r->frameMutex);
+    ApiLock lk(r);
     int rc = prepareScene(r); if (rc) return rc;
     std::vector<float4> ho(n), hd(n);
     for (uint32_t i = 0; i < n; i++) { ho[i] = make_float4(o[3*i], o[3*i+1], o[3*i+2], 0.f); hd[i] = make_float4(d[3*i], d[3*i+1], d[3*i+2], 0.f); }
@@ -1283,7 +1314,7 @@ int lumen_mi_query_closest(lumen_mi_renderer* r, uint32_t n, const float* o, con
 int lumen_mi_query_any(lumen_mi_renderer* r, uint32_t n, const float* o, const float* d, float tmin, const float* tmax, uint8_t* occ)
 {
     if (!r || !o || !d || !tmax || !occ) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
-    std::lock_guard<std::mutex> lk(r->frameMutex);
+    ApiLock lk(r);
     int rc = prepareScene(r); if (rc) return rc;
     std::vector<float4> ho(n), hd(n);
     for (uint32_t i = 0; i < n; i++) { ho[i] = make_float4(o[3*i], o[3*i+1], o[3*i+2], tmax[i]); hd[i] = make_float4(d[3*i], d[3*i+1], d[3*i+2], 0.f); }
@@ -1331,7 +1362,7 @@ int lumen_mi_test_math(lumen_mi_renderer* r, uint32_t n, int fn, const float* x,
 int lumen_mi_get_world_triangles(lumen_mi_renderer* r, float* out, uint32_t cap, uint32_t* count)
 {
     if (!r || !count) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
-    std::lock_guard<std::mutex> lk(r->frameMutex);
+    ApiLock lk(r);
     int rc = prepareScene(r); if (rc) return rc;
     *count = (uint32_t)r->triEntry.size();
     if (out) { if (cap < *count) return fail(LUMEN_MI_ERR_INVALID, "buffer too small"); memcpy(out, r->worldTris.data(), r->worldTris.size() * 4); }
@@ -1340,7 +1371,7 @@ int lumen_mi_get_world_triangles(lumen_mi_renderer* r, float* out, uint32_t cap,
 int lumen_mi_get_lights(lumen_mi_renderer* r, float* lights16, float* cdf, uint32_t cap, uint32_t* count)
 {
     if (!r || !count) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
-    std::lock_guard<std::mutex> lk(r->frameMutex);
+    ApiLock lk(r);
     int rc = prepareScene(r); if (rc) return rc;
     if ((rc = buildLights(r))) return rc;
     *count = (uint32_t)r->lights.size();
@@ -1354,7 +1385,7 @@ int lumen_mi_get_lights(lumen_mi_renderer* r, float* lights16, float* cdf, uint3
 int lumen_mi_get_bvh_info(lumen_mi_renderer* r, uint32_t* nodes, uint32_t* tris, uint32_t* maxDepth)
 {
     if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer");
-    std::lock_guard<std::mutex> lk(r->frameMutex);
+    ApiLock lk(r);
     int rc = prepareScene(r); if (rc) return rc;
     if (nodes) *nodes = (uint32_t)r->bvh.nodes.size(); if (tris) *tris = (uint32_t)r->bvh.order.size(); if (maxDepth) *maxDepth = r->bvh.maxDepth;
     return 0;

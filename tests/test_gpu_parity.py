@@ -429,6 +429,44 @@ def test_emissiveness_and_override_material_changes_between_frames():
     r.close(); o.close()
 
 
+def test_render_thread_with_concurrent_scene_edits():
+    """StartRendering() (WaveFrontRenderer.cpp:1109-1117): the render thread traces frames while the main thread moves an
+    instance, the camera and the light, reads pixels back and creates resources.  No oracle here (the number of frames the
+    thread gets to is not deterministic): the run must stay alive and every read-back must be a complete, finite frame."""
+    import time
+    soup = random_soup(2000, 33, extent=6.0, size=0.7)
+    d = cornell()
+    p = soup.primitives[0]
+    v = np.array(p["vertices"], np.float32).reshape(-1, 12).copy(); v[:, 0:3] *= np.float32(0.07)
+    mat = d.add_material(diffuse_color=(0.6, 0.6, 0.2, 1.0), roughness_factor=0.5, metallic_factor=0.0)
+    inst = d.add_instance(d.add_mesh([d.add_primitive(v, p["indices"], mat)]), _rigid(0.0, (0.0, 1.0, 0.0)))
+    r = product_from(d, 160, 120, 4, blend=False)
+    mi = r.m_Scene.m_MeshInstances[inst]
+    r.StartRendering()
+    t0 = time.time(); k = 0
+    while time.time() - t0 < 1.0:
+        k += 1
+        mi.SetTransform(_rigid(0.1 * k, (0.3 * np.sin(0.2 * k), 1.0, 0.2 * np.cos(0.2 * k))))
+        if k % 3 == 0:
+            mi.SetEmissiveness(2 if (k // 3) % 2 else 0, (2.0, 2.0, 2.0), 1.0)
+        if k % 5 == 0:
+            r.SetCamera((0.02 * (k % 7), 1.0, 3.4), (-1, 0, 0), (0, 1, 0), (0, 0, -1))
+        if k % 4 == 0:
+            r.CreateTexture(np.full((2, 2, 4), 200, np.uint8), normalize=False)
+        rad = r.GetRadiance()
+        assert np.isfinite(rad).all() and rad.shape == (120, 160, 4)
+        px = r.GetOutputTexturePixels()
+        assert px.shape[:2] == (120, 160)
+    r.StopRendering()
+    assert k > 10
+    c = r.GetCounters()
+    assert c[4] == 160 * 120 and c[0] >= c[4]
+    # the renderer is still consistent: a synchronous frame after the thread has stopped renders the final scene state
+    assert r.TraceFrame() is True
+    assert np.isfinite(r.GetRadiance()).all() and r.GetRadiance()[..., :3].max() > 0
+    r.close()
+
+
 # ---- size-independent properties at the full BASELINE size (no oracle run: it would take minutes) -----------------------
 def test_full_size_properties_1440p():
     from lumenrenderer_amd.scenes import sponza_standin
