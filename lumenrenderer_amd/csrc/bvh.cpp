@@ -39,6 +39,10 @@ template <class F> void parallelChunks(size_t n, unsigned threads, F f)
 
 struct Task { uint32_t first, count, depth; };
 
+// SAH constants (tunable for experiments through LUMEN_MI_BVH_TRAV_COST / LUMEN_MI_BVH_LEAF_MAX)
+float g_travCost = 1.0f;       // cost of one node step relative to one triangle test
+uint32_t g_leafMax = 4;        // largest leaf the SAH may choose (LM_MAX_LEAF = 8 is the format's limit)
+
 // One builder instance = one output arena (nodes + leaf order with LOCAL indices).  The top-level instance cuts subtrees of
 // at most `taskThreshold` triangles into tasks; the task builders run in parallel on disjoint ranges of the shared index
 // array, and the arenas are concatenated in task order afterwards (so the result does not depend on thread scheduling).
@@ -139,7 +143,7 @@ struct Builder {
                 }
             }
             const float leafCost = box.area() * (float)count;
-            if (bestAxis >= 0 && (count > 4 || bestCost + box.area() * 1.0f < leafCost)) {
+            if (bestAxis >= 0 && (count > g_leafMax || bestCost + box.area() * g_travCost < leafCost)) {
                 const float lo = cbox.lo[bestAxis], ext = cbox.hi[bestAxis] - lo;
                 const float scale = 16.f / ext;
                 auto it = std::partition(ids + first, ids + first + count, [&](uint32_t t) {
@@ -149,13 +153,13 @@ struct Builder {
                 });
                 mid = (uint32_t)(it - ids);
                 split = mid > first && mid < first + count;
-            } else if (count <= 4) {
+            } else if (count <= g_leafMax) {
                 return makeLeaf(first, count, box);
             }
         }
         if (!split) {
             if (count <= LM_MAX_LEAF && !forceMedian) return makeLeaf(first, count, box);
-            if (count <= 4) return makeLeaf(first, count, box);
+            if (count <= g_leafMax) return makeLeaf(first, count, box);
             int axis = 0;
             for (int k = 1; k < 3; k++) if (cbox.hi[k] - cbox.lo[k] > cbox.hi[axis] - cbox.lo[axis]) axis = k;
             mid = first + count / 2;
@@ -194,6 +198,8 @@ void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out)
     auto lap = [&](const char* what) { if (!timing) return; const auto now = std::chrono::steady_clock::now(); fprintf(stderr, "[bvh] %-28s %.3f s\n", what, std::chrono::duration<double>(now - tLast).count()); tLast = now; };
     unsigned threads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
     if (const char* e = getenv("LUMEN_MI_BUILD_THREADS")) threads = (unsigned)std::max(1, atoi(e));
+    if (const char* e = getenv("LUMEN_MI_BVH_TRAV_COST")) g_travCost = (float)atof(e);
+    if (const char* e = getenv("LUMEN_MI_BVH_LEAF_MAX")) g_leafMax = (uint32_t)std::max(1, std::min((int)LM_MAX_LEAF, atoi(e)));
     std::vector<Box> tbox(nTris); std::vector<float> cen(3 * (size_t)nTris); std::vector<uint32_t> ids(nTris);
     std::vector<float> partMax(threads, 0.f);
     parallelChunks(nTris, threads, [&](unsigned tt, size_t lo, size_t hi) {

@@ -156,6 +156,9 @@ __device__ __forceinline__ float lm_safe_rcp(float d)
 // One step through a 4-wide node: slab-test the four quantised child boxes against [tmin, hitT], continue with the nearest
 // hit child and push the others far-to-near (closest-hit) or in node order (any-hit).  Returns the next node / leaf
 // reference, or LM_REF_NONE when the stack is empty.  `boxes` counts child boxes tested (instrumented build).
+#ifndef LM_ANY_ORDERED
+#define LM_ANY_ORDERED 0      // 1: any-hit queries also visit children near to far (finds close occluders sooner, costs the sort)
+#endif
 struct LmRayQ { float ax, ay, az, bx, by, bz; };      // t = q * a + b per axis (dequantisation folded into the slab test)
 __device__ __forceinline__ void lm_slab(const uint4& q, const LmRayQ& r, float tmin, float hitT, uint32_t& key)
 {
@@ -181,7 +184,7 @@ __device__ __forceinline__ int lm_node_step(const LmScene& sc, int cur, const Lm
     uint32_t k0, k1, k2, k3;
     lm_slab(q0, rq, tmin, hitT, k0); lm_slab(q1, rq, tmin, hitT, k1); lm_slab(q2, rq, tmin, hitT, k2); lm_slab(q3, rq, tmin, hitT, k3);
     int r0 = (int)q0.w, r1 = (int)q1.w, r2 = (int)q2.w, r3 = (int)q3.w;
-    if (!ANY) {     // order the children by entry distance (a 5-comparator network; misses carry the largest key)
+    if (!ANY || LM_ANY_ORDERED) {     // order the children by entry distance (a 5-comparator network; misses carry the largest key)
         lm_cex(k0, r0, k1, r1); lm_cex(k2, r2, k3, r3); lm_cex(k0, r0, k2, r2); lm_cex(k1, r1, k3, r3); lm_cex(k1, r1, k2, r2);
         if (k0 == 0xffffffffu) return sp == 0 ? LM_REF_NONE : lm_pop(stack, sp);
         if (k3 != 0xffffffffu) lm_push(stack, sp, r3);
