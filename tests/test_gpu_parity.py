@@ -467,6 +467,35 @@ def test_render_thread_with_concurrent_scene_edits():
     r.close()
 
 
+@pytest.mark.parametrize("n_ranks", [2, 4, 8])
+def test_stitched_tiles_equal_the_single_gpu_frame(n_ranks):
+    """The multi-GPU decomposition on one GPU: every rank's window (tile + 60-pixel halo, lumenrenderer_amd/tiles.py) is
+    rendered by its own renderer and the tiles are stitched.  With an even path depth the swap-chain quirk leaves no
+    cross-frame ReSTIR history, so the stitched image must equal the full-frame render bit for bit on EVERY blended frame;
+    with an odd depth the first frame must."""
+    from lumenrenderer_amd import tiles
+    from lumenrenderer_amd.scenes import sponza_standin
+    W, H = 416, 232
+    d = sponza_standin()
+    for depth, frames in ((4, 3), (3, 1)):
+        full = product_from(d, W, H, depth, blend=True)
+        for _ in range(frames):
+            assert full.TraceFrameAsync()
+        full.Synchronize()
+        want = full.GetRadiance().copy(); full.close()
+        got = np.zeros_like(want)
+        for rank in range(n_ranks):
+            tile = tiles.tile_rect(rank, n_ranks, W, H); win = tiles.window_rect(tile, W, H)
+            r = product_from(d, W, H, depth, blend=True, window=win)
+            for _ in range(frames):
+                assert r.TraceFrameAsync()
+            r.Synchronize()
+            rad = r.GetRadiance()
+            got[tile[1]:tile[3], tile[0]:tile[2]] = rad[tile[1] - win[1]: tile[3] - win[1], tile[0] - win[0]: tile[2] - win[0]]
+            r.close()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (depth, int(np.sum(got != want)))
+
+
 # ---- size-independent properties at the full BASELINE size (no oracle run: it would take minutes) -----------------------
 def test_full_size_properties_1440p():
     from lumenrenderer_amd.scenes import sponza_standin
