@@ -14,6 +14,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The frame graph keeps four HIP streams busy; the RCCL communicator of a multi-GPU run adds its own.  HIP multiplexes streams
+# onto 4 hardware queues by default, and two busy streams sharing a queue serialise (measured: -11 %): ask for 8 before HIP starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 

@@ -85,6 +85,9 @@ def load_library():
     if not os.path.exists(path):
         raise LumenMIError(ERR_STATE, f"{path} is missing - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                       "(make -C lumenrenderer_amd/csrc); the HIP library is the only implementation")
+    # four busy HIP streams + whatever the host adds (RCCL): HIP's default of 4 hardware queues makes busy streams share one and
+    # serialise; takes effect only if HIP has not been initialised in this process yet
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     lib = C.CDLL(path)
     for name, args in SYMBOLS.items():
         f = getattr(lib, name)
