@@ -96,6 +96,7 @@ struct lumen_mi_renderer {
     bool fenceNeeded = true;                // main-stream work (uploads, memsets) the frame front on the aux stream must wait for
     std::vector<hipEvent_t> evShade;        // per wave: shade_wave(d) done
     int auxPriority = 1;                    // 1: highest priority for the aux streams, 0: default
+    int aux3Priority = 0;                   // the visibility / pick-ahead stream runs at default priority (pick-ahead must not starve the main chain)
     bool overlap = true;
     int traceBlocksMain = 8, traceBlocksAux = 8;
     int numCU = 256;
@@ -836,12 +837,13 @@ int lumen_mi_init(lumen_mi_renderer* r, const lumen_mi_settings* s)
     if (const char* e = getenv("LUMEN_MI_TRACE_BLOCKS_MAIN")) r->traceBlocksMain = std::max(1, std::min(8, atoi(e)));
     if (const char* e = getenv("LUMEN_MI_TRACE_BLOCKS_AUX")) r->traceBlocksAux = std::max(1, std::min(8, atoi(e)));
     if (const char* e = getenv("LUMEN_MI_AUX_PRIORITY")) r->auxPriority = atoi(e);
+    if (const char* e = getenv("LUMEN_MI_AUX3_PRIORITY")) r->aux3Priority = atoi(e);
     if (!r->aux) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);         // numerically lower = higher priority
         LM_HIP(hipStreamCreateWithPriority(&r->aux, hipStreamNonBlocking, r->auxPriority ? hi : lo));
         LM_HIP(hipStreamCreateWithPriority(&r->aux2, hipStreamNonBlocking, r->auxPriority ? hi : lo));
-        LM_HIP(hipStreamCreateWithPriority(&r->aux3, hipStreamNonBlocking, hi));
+        LM_HIP(hipStreamCreateWithPriority(&r->aux3, hipStreamNonBlocking, r->aux3Priority ? hi : lo));
         LM_HIP(hipEventCreateWithFlags(&r->evPick, hipEventDisableTiming));
         LM_HIP(hipEventCreateWithFlags(&r->evJoin2, hipEventDisableTiming));
         LM_HIP(hipEventCreateWithFlags(&r->evVis, hipEventDisableTiming));
