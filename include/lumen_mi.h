@@ -134,7 +134,8 @@ int lumen_mi_get_frame_stat(lumen_mi_renderer*, const char* key, uint64_t* micro
  * [4..4+depth) rays per wave, [20] BVH nodes visited in binary-node equivalents (= [22] / 2), [21] triangles tested,
  * [22] child boxes slab-tested by the 4-wide traversal, [24..40) histogram of per-ray traversal steps in log2 buckets,
  * [40] the longest per-ray traversal in steps, [41]/[42] active lanes / lane slots over all node steps, [43]/[44] the same
- * over all triangle tests ([20]..[44] only in the instrumented build) */
+ * over all triangle tests, [45]/[46] traversal-stack pushes into LDS / into the global spill area
+ * ([20]..[46] only in the instrumented build) */
 int lumen_mi_get_counters(lumen_mi_renderer*, uint64_t* out, uint32_t n);
 /* device time of one kernel class, summed over every frame traced since timing was enabled, measured with HIP events
  * on the renderer's stream; `launches` = number of timed launches (class 4: number of frames).

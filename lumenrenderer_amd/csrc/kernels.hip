@@ -103,8 +103,14 @@ struct LmHit { float t, u, v; uint32_t slot; };
 // (rare) spill to a per-thread global array, so that the LDS footprint (16 KB per 256-thread block) does not cap occupancy.
 typedef __attribute__((address_space(3))) int lm_lds_int;      // explicit LDS pointer: ds_read / ds_write, never flat accesses
 struct LmStack { lm_lds_int* lds; int* spill; };
+#if LM_INSTRUMENT
+__device__ unsigned long long g_lmPushes[2];       // counting build: [0] stack pushes, [1] of which went to the global spill area
+#endif
 __device__ __forceinline__ void lm_push(const LmStack& st, int& sp, int v)
 {
+#if LM_INSTRUMENT
+    atomicAdd(&g_lmPushes[sp < LM_STACK_LDS ? 0 : 1], 1ull);
+#endif
     if (sp < LM_STACK_LDS) st.lds[sp * LM_BLOCK] = v; else st.spill[sp - LM_STACK_LDS] = v;
     sp++;
 }
@@ -1257,6 +1263,10 @@ KN(lm_k_restir_combine)(LmFrame fr, int cur, int rc, int rs, uint32_t seed)
     lm_res_store(fr.res[rc], fr.resC[rc], li, out);
 }
 
+#if LM_INSTRUMENT
+extern "C" __global__ void lm_k_read_pushes(unsigned long long* out) { out[0] = g_lmPushes[0]; out[1] = g_lmPushes[1]; g_lmPushes[0] = 0; g_lmPushes[1] = 0; }
+extern "C" void lm_read_pushes(hipStream_t s, unsigned long long* out) { hipLaunchKernelGGL(lm_k_read_pushes, dim3(1), dim3(1), 0, s, out); }
+#endif
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
 KN(lm_k_clear_f4)(float4* __restrict__ p, uint32_t n)
 {

@@ -23,6 +23,8 @@
 #include <thread>
 #include <vector>
 
+extern "C" void lm_read_pushes(hipStream_t s, unsigned long long* out);
+
 namespace {
 
 thread_local std::string g_lastError;
@@ -1240,6 +1242,10 @@ int lumen_mi_get_counters(lumen_mi_renderer* r, uint64_t* out, uint32_t n)
     v[21] = (uint64_t)c[LM_CNT_TRIS] | ((uint64_t)c[LM_CNT_TRIS + 1] << 32);
     for (int k = 0; k < 16; k++) v[24 + k] = c[LM_CNT_STEP_HIST + k];
     v[40] = c[LM_CNT_STEP_MAX];
+    if (r->instrumented) {     // stack pushes of the counting build: total in LDS / in the global spill area since the last call
+        DevBuf<unsigned long long> d; unsigned long long h[2] = {0, 0};
+        if (!d.ensure(2)) { lm_read_pushes(r->stream, d.p); if (hipMemcpy(h, d.p, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) { v[45] = h[0]; v[46] = h[1]; } d.release(); }
+    }
     for (int k = 0; k < 4; k++) v[41 + k] = (uint64_t)c[LM_CNT_OCC + 2 * k] | ((uint64_t)c[LM_CNT_OCC + 2 * k + 1] << 32);
     for (uint32_t i = 0; i < n && i < 48; i++) out[i] = v[i];
     return 0;

@@ -10,5 +10,6 @@ c = r.GetCounters(48)
 print("depth", depth, "rays closest/nee/restir", c[0], c[1], c[2], "per wave", c[4:4 + depth])
 print("hist log2(steps):", {f"<{2 ** (k + 1)}": int(c[24 + k]) for k in range(16) if c[24 + k]})
 print("max steps per ray", c[40])
+print("stack pushes: %d in LDS, %d spilled to global (%.3f %%)" % (c[45], c[46], 100.0 * c[46] / max(1, c[45] + c[46])))
 print("lane occupancy: node steps %.3f (%d wave-issues), triangle tests %.3f (%d wave-issues)" % (c[41] / max(1, c[42]), c[42] // 64, c[43] / max(1, c[44]), c[44] // 64))
 r.close()
