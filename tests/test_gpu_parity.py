@@ -209,6 +209,54 @@ def mv_nonzero(r):
     return bool(mv.any())
 
 
+def _rigid(angle_y, t):
+    c, s = np.cos(angle_y), np.sin(angle_y)
+    m = np.eye(4, dtype=np.float32)
+    m[0, 0], m[0, 2], m[2, 0], m[2, 2] = c, s, -s, c
+    m[:3, 3] = t
+    return m
+
+
+def _textured_scene(seed=7):
+    """Cornell box + a UV-mapped triangle soup whose material uses every texture slot with multi-texel images of different,
+    non-power-of-two sizes (bilinear filtering, wrap addressing, sRGB decode of base colour / emissive: PTTexture.cpp:57-73,
+    GPUExtractSurfaceData.cu:59-181), + a transmissive clear-coated material."""
+    rng = np.random.default_rng(seed)
+    d = cornell()
+    def tex(w, h, srgb, lo=0, hi=256):
+        return d.add_texture(rng.integers(lo, hi, (h, w, 4), dtype=np.uint8), srgb)
+    nm = rng.integers(96, 160, (20, 24, 4), dtype=np.uint8); nm[..., 2] = 255
+    mr = rng.integers(1, 256, (9, 33, 4), dtype=np.uint8)
+    mat = d.add_material(diffuse_color=(0.9, 0.8, 0.7, 1.0), roughness_factor=0.7, metallic_factor=0.6,
+                         diffuse_texture=tex(37, 29, True), normal_map=d.add_texture(nm, False), metallic_roughness_texture=d.add_texture(mr, False),
+                         emissive_texture=tex(8, 8, True), emission=(0.0, 0.0, 0.0), transmission_texture=tex(5, 7, False),
+                         clearcoat_texture=tex(6, 3, False), clearcoat_roughness_texture=tex(4, 4, False), tint_texture=tex(16, 2, False),
+                         sheen_factor=0.4, sheen_tint_factor=0.5, specular_factor=0.5, specular_tint_factor=0.3, subsurface_factor=0.2)
+    glass = d.add_material(diffuse_color=(0.8, 0.9, 1.0, 1.0), roughness_factor=0.2, metallic_factor=0.0, transmission_factor=0.8,
+                           index_of_refraction=1.45, clearcoat_factor=0.7, clearcoat_roughness_factor=0.3, transmittance=(0.2, 0.1, 0.05),
+                           tint_factor=(0.9, 0.8, 0.7), luminance=0.6, diffuse_texture=tex(13, 11, True), transmission_texture=tex(7, 5, False, 128, 256))
+    glow = d.add_material(diffuse_color=(1, 1, 1, 1), emission=(2.0, 1.5, 1.0), emissive_texture=tex(12, 10, True, 64, 256))
+    for k, (m, n, scale, off) in enumerate(((mat, 300, 0.11, (0.0, 1.0, 0.0)), (glass, 120, 0.08, (0.4, 0.6, 0.3)), (glow, 24, 0.04, (-0.4, 1.5, -0.2)))):
+        soup = random_soup(n, seed + 10 + k, extent=6.0, size=1.0)
+        p = soup.primitives[0]
+        v = np.array(p["vertices"], np.float32).reshape(-1, 12).copy()
+        v[:, 0:3] *= np.float32(scale)
+        v[:, 3:5] = rng.uniform(-1.5, 2.5, (len(v), 2)).astype(np.float32)          # UVs outside [0,1]: wrap addressing
+        d.add_instance(d.add_mesh([d.add_primitive(v, p["indices"], m)]), _rigid(0.2 * k, off))
+    return d
+
+
+def test_textured_materials_match_oracle():
+    d = _textured_scene()
+    r = product_from(d, 144, 112, 5, blend=True); o = oracle_from(d, 144, 112, 5, blend=True)
+    _compare_frames(r, o, 3)
+    g = r.GetGBuffer()
+    assert len(np.unique(g[..., 4, :3].reshape(-1, 3), axis=0)) > 50         # many distinct albedo values: the textures are really sampled
+    lights, cdf = r.GetLights(); ol, ocdf = o.lights()
+    assert np.array_equal(lights.view(np.uint32), ol.view(np.uint32)) and np.array_equal(cdf.view(np.uint32), ocdf.view(np.uint32))
+    r.close(); o.close()
+
+
 def test_denoiser_inputs_match_oracle():
     """depth / normal-roughness / motion exports (GPUExtractNRD_DLSSdata.cu, GPUExtractDepthData.cu)."""
     from lumenrenderer_amd.scenes import sponza_standin
@@ -354,14 +402,6 @@ def test_deep_traversal_stack_spills_to_global_memory():
     info = r.GetBvhInfo()
     assert info["triangles"] == n_sheets
     r.close(); o.close()
-
-
-def _rigid(angle_y, t):
-    c, s = np.cos(angle_y), np.sin(angle_y)
-    m = np.eye(4, dtype=np.float32)
-    m[0, 0], m[0, 2], m[2, 0], m[2, 2] = c, s, -s, c
-    m[:3, 3] = t
-    return m
 
 
 @pytest.mark.parametrize("refit", [1, 0], ids=["gpu-refit", "host-rebuild"])
