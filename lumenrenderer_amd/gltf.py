@@ -6,8 +6,9 @@ glTF -> .ollad -> renderer factories; LumenPT/src/Tools/LumenPTModelConverter.cp
   * 16-bit indices stay 16-bit in the file and are widened by CreatePrimitive;
   * materials: baseColor/emissive/metallic factors, roughness clamped to >= 0.01 (:399), Disney extras at their
     .ollad defaults (luminance 1, transmittance 0, tint 0, ior 1, ...), KHR_materials_{transmission,sheen,ior,
-    clearcoat,specular} factors; textures (sRGB decode only for base colour and emissive, :130-133) are decoded by the
-    caller-supplied ``image_loader`` (PNG/JPEG decoding is outside this package; the Cornell box has no images);
+    clearcoat,specular} factors; textures (sRGB decode only for base colour and emissive, :130-133) are decoded by
+    ``image_loader`` (default: Pillow when importable; the reference uses stb_image), from files, data URIs or buffer views;
+  * .gltf (external / embedded buffers) and .glb containers; triangle primitives only, indexed or not;
   * node hierarchy: local = T*R*S or the given matrix, world = parent*local (Transform.cpp:265-308); every node with
     a mesh becomes one mesh instance with EmissionMode::ENABLED; the glTF camera is ignored (as in the reference).
 """
@@ -25,15 +26,44 @@ _NCOMP = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4, "MAT4": 16}
 
 def _accessor(doc, buffers, idx):
     acc = doc["accessors"][idx]
-    bv = doc["bufferViews"][acc["bufferView"]]
     dt, nc = np.dtype(_COMP[acc["componentType"]]), _NCOMP[acc["type"]]
+    count = acc["count"]
+    if "bufferView" not in acc:                                             # no buffer view: zeros (glTF 2.0, 3.6.2.3)
+        return np.zeros((count, nc), dt)
+    bv = doc["bufferViews"][acc["bufferView"]]
     off = bv.get("byteOffset", 0) + acc.get("byteOffset", 0)
     stride = bv.get("byteStride", 0) or dt.itemsize * nc
-    raw = buffers[bv["buffer"]]
-    out = np.zeros((acc["count"], nc), dt)
-    for i in range(acc["count"]):
-        out[i] = np.frombuffer(raw, dt, nc, off + i * stride)
-    return out
+    raw = np.frombuffer(buffers[bv["buffer"]], np.uint8)
+    if count == 0:
+        return np.zeros((0, nc), dt)
+    rows = np.lib.stride_tricks.as_strided(raw[off:], shape=(count, dt.itemsize * nc), strides=(stride, 1))
+    return np.ascontiguousarray(rows).view(dt).reshape(count, nc).copy()
+
+
+def _pil_loader(src):
+    """Default image decoder (PNG / JPEG -> RGBA8); the reference decodes with stb_image (LumenPTModelConverter.cpp:117)."""
+    import io
+    from PIL import Image
+    img = Image.open(io.BytesIO(src) if isinstance(src, (bytes, bytearray)) else src)
+    return np.asarray(img.convert("RGBA"), np.uint8)
+
+
+def _read_container(path):
+    """(json document, [binary chunk] or None) of a .gltf or a .glb file."""
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:4] != b"glTF":
+        return json.loads(data.decode("utf-8")), None
+    import struct
+    _, _, total = struct.unpack_from("<III", data, 0)
+    off, doc, blob = 12, None, None
+    while off < total:
+        n, kind = struct.unpack_from("<II", data, off)
+        chunk = data[off + 8: off + 8 + n]
+        if kind == 0x4E4F534A: doc = json.loads(chunk.decode("utf-8"))
+        elif kind == 0x004E4942 and blob is None: blob = chunk
+        off += 8 + n
+    return doc, blob
 
 
 def _node_local(node):
@@ -53,16 +83,24 @@ def _node_local(node):
 
 
 def load_gltf(path, image_loader=None):
-    with open(path) as f:
-        doc = json.load(f)
+    doc, glb_blob = _read_container(path)
     base = os.path.dirname(path)
+    if image_loader is None:
+        try:
+            import PIL  # noqa: F401
+            image_loader = _pil_loader
+        except ImportError:
+            image_loader = None
     buffers = []
     for b in doc.get("buffers", []):
-        uri = b["uri"]
-        if uri.startswith("data:"):
+        uri = b.get("uri")
+        if uri is None:
+            buffers.append(glb_blob)
+        elif uri.startswith("data:"):
             buffers.append(base64.b64decode(uri.split(",", 1)[1]))
         else:
-            with open(os.path.join(base, uri), "rb") as fb:
+            from urllib.parse import unquote
+            with open(os.path.join(base, unquote(uri)), "rb") as fb:
                 buffers.append(fb.read())
     d = SceneDescription()
     tex_cache = {}
@@ -76,7 +114,15 @@ def load_gltf(path, image_loader=None):
             if image_loader is None:
                 raise ValueError("glTF image needs an image_loader(path_or_bytes) -> HxWx4 uint8")
             img = doc["images"][src]
-            px = np.array(image_loader(os.path.join(base, img["uri"])), np.uint8)
+            if "uri" in img and img["uri"].startswith("data:"):
+                source = base64.b64decode(img["uri"].split(",", 1)[1])
+            elif "uri" in img:
+                from urllib.parse import unquote
+                source = os.path.join(base, unquote(img["uri"]))
+            else:
+                bv = doc["bufferViews"][img["bufferView"]]
+                source = bytes(buffers[bv["buffer"]][bv.get("byteOffset", 0): bv.get("byteOffset", 0) + bv["byteLength"]])
+            px = np.array(image_loader(source), np.uint8)
             if metal_rough:
                 px[..., 1] = np.maximum(px[..., 1], 1)                       # roughness >= 1/255 (LumenPTModelConverter.cpp:121-128)
             tex_cache[key] = d.add_texture(px, srgb)
@@ -107,6 +153,7 @@ def load_gltf(path, image_loader=None):
             kw["specular_factor"] = ext["KHR_materials_specular"].get("specularFactor", 0.0); kw["specular_tint_factor"] = 1.0
         mats.append(d.add_material(**kw))
     meshes = []
+    default_material = [None]
     for mesh in doc.get("meshes", []):
         prims = []
         for p in mesh["primitives"]:
@@ -114,14 +161,26 @@ def load_gltf(path, image_loader=None):
             pos = _accessor(doc, buffers, at["POSITION"]).astype(np.float32)
             nrm = _accessor(doc, buffers, at["NORMAL"]).astype(np.float32) if "NORMAL" in at else None
             uv = _accessor(doc, buffers, at["TEXCOORD_0"]).astype(np.float32) if "TEXCOORD_0" in at else None
-            idx = _accessor(doc, buffers, p["indices"])
-            index_size = idx.dtype.itemsize if idx.dtype.itemsize in (2, 4) else 4
-            idx = idx.astype(np.uint32).ravel()
+            if p.get("mode", 4) != 4:
+                continue                                                    # triangles only, as the reference's converter
+            if "indices" in p:
+                idx = _accessor(doc, buffers, p["indices"])
+                index_size = idx.dtype.itemsize if idx.dtype.itemsize in (2, 4) else 4
+                idx = idx.astype(np.uint32).ravel()
+            else:
+                idx, index_size = np.arange(len(pos), dtype=np.uint32), 4
+            idx = idx[: 3 * (len(idx) // 3)]
             if "TANGENT" in at:
                 tang = _accessor(doc, buffers, at["TANGENT"]).astype(np.float32)
             else:
                 tang = generate_tangents(pos, nrm if nrm is not None else np.tile(np.float32([0, 1, 0]), (len(pos), 1)), uv, idx)
-            prims.append(d.add_primitive(interleave(pos, uv, nrm, tang), idx, mats[p["material"]], index_size))
+            if "material" in p:
+                material = mats[p["material"]]
+            else:
+                if default_material[0] is None:
+                    default_material[0] = d.add_material()                  # glTF default material: white, metallic 1, roughness 1
+                material = default_material[0]
+            prims.append(d.add_primitive(interleave(pos, uv, nrm, tang), idx, material, index_size))
         meshes.append(d.add_mesh(prims))
 
     def walk(ni, parent):
@@ -132,7 +191,7 @@ def load_gltf(path, image_loader=None):
         for c in node.get("children", []):
             walk(c, world)
 
-    scene = doc["scenes"][doc.get("scene", 0)]
-    for n in scene["nodes"]:
+    scenes = doc.get("scenes") or [{"nodes": list(range(len(doc.get("nodes", []))))}]
+    for n in scenes[doc.get("scene", 0)].get("nodes", []):
         walk(n, np.eye(4))
     return d
