@@ -257,6 +257,38 @@ def test_textured_materials_match_oracle():
     r.close(); o.close()
 
 
+@pytest.mark.parametrize("fixture", ["ref_cube_textured.npz", "ref_milk_truck.npz"])
+def test_reference_sample_assets_match_oracle(fixture):
+    """Two of the reference's own textured sample models (ingested in the build container by tests/golden/
+    make_textured_fixture.py: 512x512 / 2048x2048 PNG textures, node hierarchy, several materials), lit by a quad light."""
+    from lumenrenderer_amd.scenes import scene_from_npz, interleave
+    d = scene_from_npz(os.path.join(GOLDEN, fixture))
+    lo = np.full(3, np.inf); hi = np.full(3, -np.inf)
+    for inst in d.instances:
+        M = np.asarray(inst["transform"], np.float64).reshape(4, 4)
+        for pi in d.meshes[inst["mesh"]]:
+            v = np.asarray(d.primitives[pi]["vertices"], np.float64).reshape(-1, 12)[:, :3]
+            w = v @ M[:3, :3].T + M[:3, 3]
+            lo = np.minimum(lo, w.min(0)); hi = np.maximum(hi, w.max(0))
+    c, e = (lo + hi) / 2, float(np.max(hi - lo))
+    # a quad light above and in front of the model, facing down
+    y = hi[1] + 0.6 * e
+    quad = np.float32([[c[0] - e, y, c[2] - e], [c[0] + e, y, c[2] - e], [c[0] + e, y, c[2] + e], [c[0] - e, y, c[2] + e]])
+    v = interleave(quad, None, np.tile(np.float32([0, -1, 0]), (4, 1)), np.tile(np.float32([1, 0, 0, 1]), (4, 1)))
+    m = d.add_material(diffuse_color=(1, 1, 1, 1), emission=(1.0, 1.0, 1.0))     # emissive material: the frame is skipped when the
+    # primitives' material-based light count is zero (WaveFrontRenderer.cpp:456-464), whatever the instance override says
+    d.add_instance(d.add_mesh([d.add_primitive(v, np.uint32([0, 2, 1, 0, 3, 2, 0, 1, 2, 0, 2, 3]), m)]), None, emission_mode=2, override_radiance=(6.0, 5.5, 5.0), scale=1.0)
+    eye = c + np.float64([0.35 * e, 0.25 * e, 1.3 * e])
+    fwd = c - eye; fwd /= np.linalg.norm(fwd)
+    right = np.cross([0.0, 1.0, 0.0], fwd); right /= np.linalg.norm(right); up = np.cross(fwd, right)
+    d.set_camera(eye, right, up, fwd, 70.0)
+    r = product_from(d, 160, 120, 4, blend=True); o = oracle_from(d, 160, 120, 4, blend=True)
+    _compare_frames(r, o, 2)
+    g = r.GetGBuffer()
+    assert (g[..., 0, 3] > 0).mean() > 0.15                                  # the model covers a good part of the image
+    r.close(); o.close()
+
+
 def test_denoiser_inputs_match_oracle():
     """depth / normal-roughness / motion exports (GPUExtractNRD_DLSSdata.cu, GPUExtractDepthData.cu)."""
     from lumenrenderer_amd.scenes import sponza_standin
