@@ -129,10 +129,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
 
+    if os.environ.get("LUMEN_BENCH_FORCE_PG", "") == "before":      # A/B aid: communicator (and its stream) BEFORE the renderer's streams
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        warm = torch.zeros(1, device=dev); dist.all_reduce(warm); torch.cuda.synchronize()
     kind, kw, W, H, depth, spp = WORKLOADS[args.workload]
     desc = make_scene(kind, kw)
     r = LumenRendererMI()
@@ -147,6 +148,17 @@ def main():
     r.SetWindow(*win)
     wh, ww = win[3] - win[1], win[2] - win[0]
     window_buf = torch.empty((wh, ww, 4), dtype=torch.float32, device=dev)
+    # The renderer's four streams are created and used once BEFORE the RCCL communicator brings its own stream: HIP maps
+    # streams onto 4 hardware queues, and two busy streams that end up sharing one serialise (measured -11 % at N = 1 with an
+    # idle fifth stream created first).  RCCL's stream only works between frames, when the renderer's streams are idle.
+    r.SetBlendMode(True)
+    r.TraceFrame()
+    force_pg = os.environ.get("LUMEN_BENCH_FORCE_PG", "")          # A/B aid: "before" / "after" create a 1-rank communicator at N = 1
+    if (world > 1 or force_pg) and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        warm = torch.zeros(1, device=dev); dist.all_reduce(warm)                                   # communicator + stream exist now
+        torch.cuda.synchronize()
 
     def frame():
         r.SetBlendMode(True)                              # a fresh 4-spp accumulation per displayed frame
@@ -158,7 +170,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -244,9 +256,14 @@ def main():
         if emu:
             out["emulated_rank"] = {"rank": emu[0], "of": emu[1], "window": list(win), "tile": list(tile),
                                     "note": "per-rank time of the tiled path on one GPU; value counts the tile's rays only"}
+        try:                                   # RCCL writes a version banner through C stdio: flush it first so that the JSON is the last line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     r.close()
-    if world > 1:
+    if world > 1 or force_pg:
         dist.destroy_process_group()
 
 

@@ -92,7 +92,7 @@ struct lumen_mi_renderer {
     hipStream_t aux2 = nullptr;             // third stream: NEE shadow rays of wave d run beside the closest-hit launch of wave d+1
     hipEvent_t evJoin = nullptr, evJoin2 = nullptr, evVis = nullptr, evVisDone = nullptr;
     hipEvent_t evPick = nullptr;
-    int pickAhead = -1;                     // -1 automatic (windows under 1 Mpixel), 0 off, 1 on
+    int pickAhead = 1;                      // 1 on (default), 0 off, -1 only for windows under 1 Mpixel
     hipEvent_t evFront = nullptr, evTemporal = nullptr, evTop = nullptr, evMerge[2] = {nullptr, nullptr};   // cross-frame pipelining (traceFrameAsync)
     int framePar = 0;                       // parity of the frame being enqueued: selects the channel buffers and the counter block
     bool fenceNeeded = true;                // main-stream work (uploads, memsets) the frame front on the aux stream must wait for
@@ -679,7 +679,9 @@ int traceFrameAsync(R* r)
             // machine's throughput bounds the frame) they run on their own stream into the fresh-candidate buffer [4], beside
             // the previous frame's spatial passes; the temporal pass picks them up from there.
             const bool pickAhead = overlap && (r->pickAhead >= 0 ? r->pickAhead != 0 : fr.n < (1u << 20));
-            hipStream_t sp = pickAhead ? r->aux3 : st;      // (HIP multiplexes streams onto 4 hardware queues by default: no fifth stream)
+            // (four streams in total: HIP multiplexes streams onto 4 hardware queues, and a fifth stream cost 11-18 % through false
+            // serialisation in every variant tried, also with GPU_MAX_HW_QUEUES=8)
+            hipStream_t sp = pickAhead ? r->aux3 : st;
             if (overlap) { LM_HIP(hipEventRecord(r->evFront, sx)); LM_HIP(hipStreamWaitEvent(sp, r->evFront, 0)); }
             evBegin2(r, 3, ev, sp);
             const int cur = LM_RES_CUR, tmp = LM_RES_PREV, fresh = pickAhead ? 4 : LM_RES_CUR;
@@ -815,6 +817,7 @@ int lumen_mi_create(lumen_mi_renderer** out)
     if (const char* e = getenv("LUMEN_MI_REFILL_VIS")) (*out)->refillVisibility = atoi(e);
     if (const char* e = getenv("LUMEN_MI_REFILL_PRIMARY")) (*out)->refillPrimary = atoi(e);
     if (const char* e = getenv("LUMEN_MI_TAIL_BELOW")) (*out)->tailBelow = atoi(e);
+    if (const char* e = getenv("LUMEN_MI_PICK_AHEAD")) (*out)->pickAhead = atoi(e);
     if (const char* e = getenv("LUMEN_MI_TAIL_LANES")) (*out)->tailLanes = std::max(1, std::min(64, atoi(e)));
     return 0;
 }
