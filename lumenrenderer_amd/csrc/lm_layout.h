@@ -90,14 +90,15 @@ struct LmFrame {
     float4 *shO, *shD, *shR;
     float4 *visO, *visD;        // ReSTIR visibility-ray queue, pass 1 (own buffers: runs concurrently with the NEE shadow queue)
     float4 *vis2O, *vis2D;      // pass 2 (filled by the temporal kernel, traced beside the second spatial pass)
-    // depth-0 surface data, two frames: one 128-byte record (8 float4) per pixel + a 16-byte reuse-probe plane (kernels.hip)
-    float4* gbuf[2];
-    float4* probe[2];
+    // depth-0 surface data: one 128-byte record (8 float4) per pixel + a 16-byte reuse-probe plane (kernels.hip).  Three sets
+    // (current, previous, and the one the NEXT frame's extraction already fills while this frame's temporal pass still reads)
+    float4* gbuf[3];
+    float4* probe[3];
     // reservoirs, 5 buffers (the reference's two swap-chain and two spatial buffers + [4], fresh candidates when candidate
     // generation runs ahead on its own stream): one 64-byte hot record (4 float4) per pixel + a contribution plane
     float4* res[5];
     float4* resC[5];
-    uint32_t* motion;           // half2 motion vector per pixel
+    uint32_t* motion;           // half2 motion vector per pixel (of this frame; double-buffered by frame parity on the host side)
     float4 *direct, *indirect;  // fp32 light channels
     float4* combined;           // merged / blended radiance
     uchar4* output;             // sRGB8

@@ -93,7 +93,7 @@ struct lumen_mi_renderer {
     hipEvent_t evJoin = nullptr, evJoin2 = nullptr, evVis = nullptr, evVisDone = nullptr;
     hipEvent_t evPick = nullptr;
     int pickAhead = 1;                      // 1 on (default), 0 off, -1 only for windows under 1 Mpixel
-    hipEvent_t evFront = nullptr, evTemporal = nullptr, evTop = nullptr, evMerge[2] = {nullptr, nullptr};   // cross-frame pipelining (traceFrameAsync)
+    hipEvent_t evFront = nullptr, evTemporal[2] = {nullptr, nullptr}, evTop = nullptr, evMerge[2] = {nullptr, nullptr};   // cross-frame pipelining (traceFrameAsync)
     int framePar = 0;                       // parity of the frame being enqueued: selects the channel buffers and the counter block
     bool fenceNeeded = true;                // main-stream work (uploads, memsets) the frame front on the aux stream must wait for
     std::vector<hipEvent_t> evShade;        // per wave: shade_wave(d) done
@@ -141,6 +141,7 @@ struct lumen_mi_renderer {
     // persistent state (WaveFrontRenderer members)
     uint32_t frameCount = 0, blendCounter = 0;
     int frameIndex = 0;
+    int gbufIndex = 0, lastGbuf = 0;        // physical G-buffer set of the frame being enqueued / of the last enqueued frame (3 sets)
     DevBuf<int> dSwap;                      // ReSTIR swap-chain index lives on the device (LmFrame::swap)
 
     // flattened scene (host)
@@ -165,8 +166,8 @@ struct lumen_mi_renderer {
     uint32_t allocN = 0, allocDepth = 0;
     DevBuf<float4> dTailRay[6];             // ray queue of the path tail, double-buffered by frame parity (3 planes each)
     hipEvent_t evTail = nullptr;
-    DevBuf<float4> dRay[6], dSh[3], dSh2[4], dGbuf[2], dProbe[2], dRes[5], dResC[5], dDirect[2], dIndirect[2], dCombined;
-    DevBuf<uint4> dHits; DevBuf<uint32_t> dMotion, dCounters; DevBuf<uchar4> dOutput; DevBuf<uint2> dBags;
+    DevBuf<float4> dRay[6], dSh[3], dSh2[4], dGbuf[3], dProbe[3], dRes[5], dResC[5], dDirect[2], dIndirect[2], dCombined;
+    DevBuf<uint4> dHits; DevBuf<uint32_t> dMotion[2], dCounters; DevBuf<uchar4> dOutput; DevBuf<uint2> dBags;
     uint32_t hostCounters[LM_CNT_WORDS] = {0};
     bool countersValid = false;
     uint32_t lastDepth = 0;
@@ -499,23 +500,24 @@ int ensureFrameBuffers(R* r)
     for (int i = 0; i < 6; i++) bad |= r->dRay[i].ensure(n) | r->dTailRay[i].ensure(n);
     for (int i = 0; i < 3; i++) bad |= r->dSh[i].ensure(n);
     for (int i = 0; i < 4; i++) bad |= r->dSh2[i].ensure(n);
-    for (int i = 0; i < 2; i++) bad |= r->dGbuf[i].ensure((size_t)8 * n) | r->dProbe[i].ensure(n);
+    for (int i = 0; i < 3; i++) bad |= r->dGbuf[i].ensure((size_t)8 * n) | r->dProbe[i].ensure(n);
+    for (int i = 0; i < 2; i++) bad |= r->dMotion[i].ensure(n);
     for (int i = 0; i < 5; i++) bad |= r->dRes[i].ensure((size_t)4 * n) | r->dResC[i].ensure(n);
     for (int i = 0; i < 2; i++) bad |= r->dDirect[i].ensure(n) | r->dIndirect[i].ensure(n);
-    bad |= r->dCombined.ensure(n) | r->dHits.ensure(n) | r->dMotion.ensure(n) | r->dOutput.ensure(n);
+    bad |= r->dCombined.ensure(n) | r->dHits.ensure(n) | r->dOutput.ensure(n);
     bad |= r->dCounters.ensure(2 * LM_CNT_WORDS) | r->dBags.ensure(50 * 1000);
     if (bad) return fail(LUMEN_MI_ERR_DEVICE, "frame buffer allocation failed");
     for (int q = 0; q < 2; q++) { f.rayO[q] = r->dRay[3 * q].p; f.rayD[q] = r->dRay[3 * q + 1].p; f.rayC[q] = r->dRay[3 * q + 2].p; }
     f.shO = r->dSh[0].p; f.shD = r->dSh[1].p; f.shR = r->dSh[2].p;
     f.visO = r->dSh2[0].p; f.visD = r->dSh2[1].p; f.vis2O = r->dSh2[2].p; f.vis2D = r->dSh2[3].p;
     f.hits = r->dHits.p;
-    for (int i = 0; i < 2; i++) { f.gbuf[i] = r->dGbuf[i].p; f.probe[i] = r->dProbe[i].p; }
+    for (int i = 0; i < 3; i++) { f.gbuf[i] = r->dGbuf[i].p; f.probe[i] = r->dProbe[i].p; }
     for (int i = 0; i < 5; i++) { f.res[i] = r->dRes[i].p; f.resC[i] = r->dResC[i].p; }
-    f.motion = r->dMotion.p; f.direct = r->dDirect[0].p; f.indirect = r->dIndirect[0].p; f.combined = r->dCombined.p; f.output = r->dOutput.p;
+    f.motion = r->dMotion[0].p; f.direct = r->dDirect[0].p; f.indirect = r->dIndirect[0].p; f.combined = r->dCombined.p; f.output = r->dOutput.p;
     f.counters = r->dCounters.p; f.bags = r->dBags.p;
     // ResizeBuffers (WaveFrontRenderer.cpp:1424-1540): history is dropped; reservoirs reset (ReSTIRKernels.cu:36-47)
     hipStream_t st = r->stream;
-    for (int i = 0; i < 2; i++) if (hipMemsetAsync(f.gbuf[i], 0, (size_t)8 * n * sizeof(float4), st) != hipSuccess || hipMemsetAsync(f.probe[i], 0, (size_t)n * sizeof(float4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
+    for (int i = 0; i < 3; i++) if (hipMemsetAsync(f.gbuf[i], 0, (size_t)8 * n * sizeof(float4), st) != hipSuccess || hipMemsetAsync(f.probe[i], 0, (size_t)n * sizeof(float4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
     for (int i = 0; i < 5; i++) if (hipMemsetAsync(f.res[i], 0, (size_t)4 * n * sizeof(float4), st) != hipSuccess || hipMemsetAsync(f.resC[i], 0, (size_t)n * sizeof(float4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
     if (hipMemsetAsync(f.combined, 0, (size_t)n * sizeof(float4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
     if (hipMemsetAsync(f.output, 0, (size_t)n * sizeof(uchar4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
@@ -524,7 +526,7 @@ int ensureFrameBuffers(R* r)
     r->haveEst = false; r->cntPending[0] = r->cntPending[1] = false;
     if (r->dSwap.ensure(1) || hipMemsetAsync(r->dSwap.p, 0, sizeof(int), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "swap index allocation failed");
     f.swap = r->dSwap.p;
-    r->blendCounter = 0; r->frameIndex = 0;
+    r->blendCounter = 0; r->frameIndex = 0; r->gbufIndex = 0; r->lastGbuf = 0;
     return 0;
 }
 
@@ -590,7 +592,9 @@ int traceFrameAsync(R* r)
     hipStream_t st = r->stream;
     LmFrame& fr = r->fr;
     const uint32_t depthMax = std::min<uint32_t>(r->settings.depth, LM_MAX_DEPTH);
-    const int currentIndex = r->frameIndex, temporalIndex = r->frameIndex == 1 ? 0 : 1;
+    // "current" / "previous" surface data (the reference toggles two buffers, WaveFrontRenderer.cpp:1045-1049); here three physical
+    // sets rotate, so that the next frame's extraction does not wait for this frame's temporal pass
+    const int currentIndex = r->gbufIndex, temporalIndex = (r->gbufIndex + 2) % 3;
     const bool blend = r->settings.blend_output != 0;
 
     // camera (Camera.cpp:79-93,122-140; aspect = render W/H, WaveFrontRenderer.cpp:577)
@@ -622,6 +626,7 @@ int traceFrameAsync(R* r)
     const bool overlap = r->overlap && r->aux != nullptr;
     hipStream_t sx = overlap ? r->aux : st;
     const int par = r->framePar; r->framePar ^= 1;
+    fr.motion = r->dMotion[par].p;
     fr.direct = r->dDirect[par].p; fr.indirect = r->dIndirect[par].p; fr.counters = r->dCounters.p + (size_t)par * LM_CNT_WORDS;
     if (overlap) {
         if (r->fenceNeeded) { LM_HIP(hipEventRecord(r->evTop, st)); LM_HIP(hipStreamWaitEvent(sx, r->evTop, 0)); }
@@ -669,7 +674,7 @@ int traceFrameAsync(R* r)
             evBegin2(r, 0, ev, sx);
             K->trace_closest(sx, gridMain, scx, fr.rayO[q], fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters, r->refillPrimary);    // :678,:703
             evEnd2(r, ev, sx);
-            if (overlap) LM_HIP(hipStreamWaitEvent(sx, r->evTemporal, 0));               // previous frame's temporal pass has read what extraction overwrites
+            if (overlap) LM_HIP(hipStreamWaitEvent(sx, r->evTemporal[par], 0));          // the temporal pass two frames back has read what extraction overwrites
             evBegin2(r, 2, ev, sx);
             K->extract0(sx, r->gridFor(fr.n, 8), r->dscene, (int)depth + 1 == tailDepth ? withTailQueue(fr, q ^ 1) : fr, cam, currentIndex, seed2, doIndirect, q ^ 1, outCount);   // + depth-0 continuation
             evEnd2(r, ev, sx);
@@ -697,7 +702,7 @@ int traceFrameAsync(R* r)
             evBegin(r, 3, ev);
             rs = wangHash(rs);
             K->temporal(st, tiles, fr, currentIndex, temporalIndex, cur, tmp, fresh, rs, fr.counters + LM_CNT_RESTIR(1));         // + visibility rays, pass 2
-            if (overlap) LM_HIP(hipEventRecord(r->evTemporal, st));
+            if (overlap) LM_HIP(hipEventRecord(r->evTemporal[par], st));
             rs = wangHash(rs);
             K->spatial(st, tiles, fr, currentIndex, cur, 2, rs);
             // second visibility pass (ReSTIR.cpp:211-212) works on the CURRENT buffer, which the second spatial pass does not
@@ -769,6 +774,7 @@ int traceFrameAsync(R* r)
     r->lastLightCount = r->lights.size();
     if (blend) ++r->blendCounter;                                                            // :1039-1042
     r->frameIndex = r->frameIndex + 1 == 2 ? 0 : r->frameIndex + 1;                          // :1045-1049
+    r->lastGbuf = r->gbufIndex; r->gbufIndex = (r->gbufIndex + 1) % 3;
     memcpy(r->prevCamWorld, camWorld, sizeof camWorld);                                      // :1051
     ++r->frameCount;                                                                         // :1052
     return 0;
@@ -856,7 +862,7 @@ int lumen_mi_init(lumen_mi_renderer* r, const lumen_mi_settings* s)
         r->evShade.resize(LM_MAX_DEPTH + 1);
         for (auto& e : r->evShade) LM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         LM_HIP(hipEventCreateWithFlags(&r->evFront, hipEventDisableTiming));
-        LM_HIP(hipEventCreateWithFlags(&r->evTemporal, hipEventDisableTiming));
+        for (auto& e : r->evTemporal) LM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         LM_HIP(hipEventCreateWithFlags(&r->evTail, hipEventDisableTiming));
         LM_HIP(hipEventCreateWithFlags(&r->evTop, hipEventDisableTiming));
         for (auto& e : r->evMerge) LM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -874,12 +880,12 @@ int lumen_mi_destroy(lumen_mi_renderer* r)
     if (r->initialised) {
         (void)hipSetDevice(r->device);
         (void)hipStreamSynchronize(r->stream);
-        if (r->aux) { (void)hipStreamSynchronize(r->aux); (void)hipStreamSynchronize(r->aux2); (void)hipStreamDestroy(r->aux2); (void)hipStreamSynchronize(r->aux3); (void)hipStreamDestroy(r->aux3); (void)hipEventDestroy(r->evPick); (void)hipEventDestroy(r->evVis); (void)hipEventDestroy(r->evVisDone); (void)hipEventDestroy(r->evJoin2); for (auto& e : r->evShade) (void)hipEventDestroy(e); (void)hipStreamDestroy(r->aux); (void)hipEventDestroy(r->evFront); (void)hipEventDestroy(r->evTemporal); (void)hipEventDestroy(r->evTail); (void)hipEventDestroy(r->evTop); for (auto& e : r->evMerge) (void)hipEventDestroy(e); for (int i = 0; i < 2; i++) { (void)hipEventDestroy(r->evCnt[i]); (void)hipHostFree(r->pinnedCounters[i]); r->pinnedCounters[i] = nullptr; } (void)hipEventDestroy(r->evJoin); }
+        if (r->aux) { (void)hipStreamSynchronize(r->aux); (void)hipStreamSynchronize(r->aux2); (void)hipStreamDestroy(r->aux2); (void)hipStreamSynchronize(r->aux3); (void)hipStreamDestroy(r->aux3); (void)hipEventDestroy(r->evPick); (void)hipEventDestroy(r->evVis); (void)hipEventDestroy(r->evVisDone); (void)hipEventDestroy(r->evJoin2); for (auto& e : r->evShade) (void)hipEventDestroy(e); (void)hipStreamDestroy(r->aux); (void)hipEventDestroy(r->evFront); for (auto& e : r->evTemporal) (void)hipEventDestroy(e); (void)hipEventDestroy(r->evTail); (void)hipEventDestroy(r->evTop); for (auto& e : r->evMerge) (void)hipEventDestroy(e); for (int i = 0; i < 2; i++) { (void)hipEventDestroy(r->evCnt[i]); (void)hipHostFree(r->pinnedCounters[i]); r->pinnedCounters[i] = nullptr; } (void)hipEventDestroy(r->evJoin); }
         r->dSpill.release(); r->dNodes.release(); r->dWoop.release(); r->dTriId.release(); r->dTriOrder.release(); r->dVerts.release(); r->dIndices.release();
         r->dQuant.release(); r->dTriBox.release(); r->dNodeBox.release(); r->dLevelNodes.release(); r->dRefitBounds.release();
         r->dEntries.release(); r->dMaterials.release(); r->dTexDesc.release(); r->dTexels.release(); r->dLut.release(); r->dLights.release(); r->dCdf.release();
         for (auto& b : r->dRay) b.release(); for (auto& b : r->dTailRay) b.release(); for (auto& b : r->dSh) b.release(); for (auto& b : r->dSh2) b.release(); for (auto& b : r->dGbuf) b.release(); for (auto& b : r->dProbe) b.release(); for (auto& b : r->dRes) b.release(); for (auto& b : r->dResC) b.release();
-        for (int i = 0; i < 2; i++) { r->dDirect[i].release(); r->dIndirect[i].release(); } r->dCombined.release(); r->dHits.release(); r->dMotion.release(); r->dCounters.release(); r->dSwap.release(); r->dOutput.release(); r->dBags.release();
+        for (int i = 0; i < 2; i++) { r->dDirect[i].release(); r->dIndirect[i].release(); } r->dCombined.release(); r->dHits.release(); for (auto& b : r->dMotion) b.release(); r->dCounters.release(); r->dSwap.release(); r->dOutput.release(); r->dBags.release();
         for (auto& e : r->evPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     }
     delete r;
@@ -1198,7 +1204,7 @@ int lumen_mi_get_gbuffer(lumen_mi_renderer* r, float* out, size_t cap)
     if (!r || !out) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
     const uint32_t n = r->fr.n;
     if (cap < (size_t)n * 128) return fail(LUMEN_MI_ERR_INVALID, "buffer too small");
-    const int last = r->frameIndex == 0 ? 1 : 0;
+    const int last = r->lastGbuf;
     return copyOut(r, r->fr.gbuf[last], (size_t)n * 128, out, cap);
 }
 
@@ -1209,7 +1215,7 @@ int lumen_mi_get_denoiser_inputs(lumen_mi_renderer* r, float minD, float maxD, f
     int rc = syncAndCollect(r); if (rc) return rc;
     const uint32_t n = r->fr.n;
     if (!n || !r->fr.gbuf[0]) return fail(LUMEN_MI_ERR_STATE, "no frame has been traced");
-    const int last = r->frameIndex == 0 ? 1 : 0;
+    const int last = r->lastGbuf;
     DevBuf<float> dDepth; DevBuf<uint2> dNr;
     if ((depth && dDepth.ensure(n)) || (normalRoughness && dNr.ensure(n))) return fail(LUMEN_MI_ERR_DEVICE, "export allocation failed");
     if (normalRoughness) LM_HIP(hipMemsetAsync(dNr.p, 0, (size_t)n * sizeof(uint2), r->stream));
