@@ -146,6 +146,8 @@ def main():
     tile = tiles.tile_rect(*emu, W, H) if emu else tiles.tile_rect(rank, world, W, H)
     win = tiles.window_rect(tile, W, H) if (world > 1 or emu) else (0, 0, W, H)
     r.SetWindow(*win)
+    if world > 1 or emu:
+        r.SetTile(*tile)                                  # halo pixels only get the work the tile's ReSTIR reuse needs
     wh, ww = win[3] - win[1], win[2] - win[0]
     window_buf = torch.empty((wh, ww, 4), dtype=torch.float32, device=dev)
     # The renderer's four streams are created and used once BEFORE the RCCL communicator brings its own stream: HIP maps
@@ -198,7 +200,7 @@ def main():
     r.EnableKernelTiming(False)
     # counters of the LAST TraceFrame (every TraceFrame of a step traces the same number of rays to within RNG noise);
     # kernel times are HIP-event sums over the whole timed region, on the stream the kernels were launched on
-    c = r.GetCounters()
+    c = r.GetCounters(50)
     rays_last = c[0] + c[1] + c[2]
     closest_ms, closest_launches = r.GetKernelTime(0)
     shadow_ms, _ = r.GetKernelTime(1)
@@ -210,13 +212,16 @@ def main():
     # a rank's counters include the rays of its halo pixels; those are redundant work (the neighbour owns the pixels), so
     # only the tile's share is counted: rays scale with pixels to within RNG noise
     tile_share = ((tile[2] - tile[0]) * (tile[3] - tile[1])) / float(ww * wh)
-    stats = torch.tensor([dt, float(rays_last) * tile_share], dtype=torch.float64, device=dev)
+    # primary rays and the first ReSTIR visibility pass cover the whole window (scaled to the tile); indirect waves, NEE and
+    # the second visibility pass only run for tile pixels already (lumen_mi_set_tile)
+    rays_tile = (c[4] + c[48]) * tile_share + (c[0] - c[4]) + c[1] + c[49] if (world > 1 or emu) else float(rays_last)
+    stats = torch.tensor([dt, float(rays_tile)], dtype=torch.float64, device=dev)
     if world > 1:
         tmax = stats.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = stats.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt = float(tmax[0]); rays_last_all = float(tsum[1])
     else:
-        rays_last_all = float(rays_last) * tile_share
+        rays_last_all = float(rays_tile)
     if rank == 0:
         # rays/frame: the spp TraceFrame()s of one step trace (to within RNG noise) the same number of rays each
         rays_per_frame = rays_last_all * spp

@@ -135,7 +135,7 @@ int lumen_mi_get_frame_stat(lumen_mi_renderer*, const char* key, uint64_t* micro
  * [22] child boxes slab-tested by the 4-wide traversal, [24..40) histogram of per-ray traversal steps in log2 buckets,
  * [40] the longest per-ray traversal in steps, [41]/[42] active lanes / lane slots over all node steps, [43]/[44] the same
  * over all triangle tests, [45]/[46] traversal-stack pushes into LDS / into the global spill area
- * ([20]..[46] only in the instrumented build) */
+ * ([20]..[46] only in the instrumented build), [48]/[49] ReSTIR visibility rays of pass 1 / pass 2 */
 int lumen_mi_get_counters(lumen_mi_renderer*, uint64_t* out, uint32_t n);
 /* device time of one kernel class, summed over every frame traced since timing was enabled, measured with HIP events
  * on the renderer's stream; `launches` = number of timed launches (class 4: number of frames).
@@ -152,6 +152,11 @@ int lumen_mi_set_tuning(lumen_mi_renderer*, const char* key, int value);
 /* ---- tile sharding (new functionality: the reference is single-GPU) */
 /* render only [x0,x1) x [y0,y1) of the image; RNG streams stay those of the full image */
 int lumen_mi_set_window(lumen_mi_renderer*, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1);
+/* The part of the render window this renderer OWNS (global pixel coordinates, inside the window; an empty rectangle = the whole
+ * window).  Pixels of the window outside it are halo: they are rendered as far as the owned pixels' ReSTIR reuse needs them (surface
+ * data, candidates, temporal pass, first reuse pass within 30 pixels), but get no indirect light, no second reuse pass and no
+ * combine, and their radiance is undefined.  Owned pixels are unaffected (no reference equivalent: the reference is single-GPU). */
+int lumen_mi_set_tile(lumen_mi_renderer*, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1);
 
 /* ---- ray-query seam (OptixWrapper::TraceRays, LumenPT/src/Framework/OptixWrapper.h:58-81): host arrays in, host arrays out */
 int lumen_mi_query_closest(lumen_mi_renderer*, uint32_t n, const float* origins3, const float* directions3, float tmin, float tmax,

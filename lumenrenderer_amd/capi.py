@@ -68,6 +68,7 @@ SYMBOLS = {
     "lumen_mi_set_tuning": [_R, C.c_char_p, C.c_int],
     "lumen_mi_get_denoiser_inputs": [_R, C.c_float, C.c_float, _FP, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16)],
     "lumen_mi_set_window": [_R, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32],
+    "lumen_mi_set_tile": [_R, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32],
     "lumen_mi_query_closest": [_R, C.c_uint32, _FP, _FP, C.c_float, C.c_float, _U32P, _FP],
     "lumen_mi_query_any": [_R, C.c_uint32, _FP, _FP, C.c_float, _FP, _U8P],
     "lumen_mi_test_bsdf": [_R, C.c_uint32, C.c_int, _FP, _FP, _FP, _FP, _FP, _FP], "lumen_mi_test_math": [_R, C.c_uint32, C.c_int, _FP, _FP, _FP],

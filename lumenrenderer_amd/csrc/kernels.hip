@@ -708,6 +708,13 @@ __device__ bool lm_shade_indirect(const LmSurface& s, uint32_t gi, uint32_t seed
     return true;
 }
 
+// inside the owned tile grown by `margin` pixels? (window-local pixel index)
+__device__ __forceinline__ bool lm_owned(const LmFrame& fr, uint32_t li, int margin)
+{
+    const int ly = (int)(li / fr.ww), lx = (int)(li - (uint32_t)ly * fr.ww);
+    return lx >= (int)fr.tx0 - margin && lx < (int)fr.tx1 + margin && ly >= (int)fr.ty0 - margin && ly < (int)fr.ty1 + margin;
+}
+
 // K7 (depth 0) + K9 motion vectors (MotionVectors.cu:8-55) + K10 ResolveDirectLightHits (GPUShadeDirect.cu:11-40) + channel clear
 // + K12 at depth 0 (GPUShadeIndirect.cu:7-146): the path continuation is sampled from the surface while it is still in
 // registers; survivors of a block iteration are appended to the wave-1 queue with ONE atomic.
@@ -748,7 +755,7 @@ KN(lm_k_extract0)(LmScene sc, LmFrame fr, LmCamera cam, int cur, uint32_t seed2,
         fr.motion[li] = mv;
         fr.direct[li] = (s.flags & LM_SF_EMISSIVE) ? s.mat.color : make_float4(0.f, 0.f, 0.f, 0.f);
         fr.indirect[li] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (doIndirect) {
+        if (doIndirect && lm_owned(fr, li, 0)) {                  // halo pixels need no indirect light: their radiance is discarded
             s.transport = v3(1.f, 1.f, 1.f);                       // what a G-buffer reload yields (lm_gbuf_load)
             liOut = li;
             emit = lm_shade_indirect(s, py * fr.W + px, seed2, bo, bd, bc);
@@ -1148,7 +1155,7 @@ KN(lm_k_restir_temporal)(LmFrame fr, int cur, int prev, int rc, int rp, int rf, 
                 weight = h0.y;
                 if (weight > 0.f) { vtarget = v3(h3); vpos = v3(fr.gbuf[cur][8u * li]); }
             }
-            shoot = weight > 0.f;                                  // second GenerateShadowRay pass (ReSTIR.cpp:211), fused
+            shoot = weight > 0.f && lm_owned(fr, li, 0);           // second GenerateShadowRay pass (ReSTIR.cpp:211), fused; only owned pixels are combined
         } else if (rf != rc) {
             // flagged pixel: the candidate pick only zeroes the weight of the CURRENT reservoir and leaves the rest stale
             // (ReSTIRKernels.cu:441-447); when the pick wrote to its own buffer, do that here — a later frame may read this
@@ -1174,7 +1181,7 @@ KN(lm_k_restir_temporal)(LmFrame fr, int cur, int prev, int rc, int rp, int rf, 
 #define LM_SPATIAL_WAVES 3      // <= 168 VGPRs: three waves per SIMD instead of two (the kernel is gather-latency bound)
 #endif
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_SPATIAL_WAVES)
-KN(lm_k_restir_spatial)(LmFrame fr, int cur, int rin, int rout, uint32_t seed)
+KN(lm_k_restir_spatial)(LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin)
 {
     rin = lm_res_idx(fr, rin);
     rout = lm_res_idx(fr, rout);
@@ -1183,6 +1190,7 @@ KN(lm_k_restir_spatial)(LmFrame fr, int cur, int rin, int rout, uint32_t seed)
 #endif
     uint32_t li = 0, gi = 0;
     if (!lm_tile_pixel(fr, li, gi)) return;
+    if (!lm_owned(fr, li, margin)) return;                       // pass 1 feeds pass 2 within 30 pixels of the owned tile, pass 2 only the tile
     const float4* probe = fr.probe[cur];
     const float4* hotIn = fr.res[rin];
     const float4 cn = probe[li];
@@ -1253,6 +1261,7 @@ KN(lm_k_restir_combine)(LmFrame fr, int cur, int rc, int rs, uint32_t seed)
     rs = lm_res_idx(fr, rs);
     uint32_t li = 0, gi = 0;
     if (!lm_tile_pixel(fr, li, gi)) return;
+    if (!lm_owned(fr, li, 0)) return;
     if (fr.probe[cur][li].w < 0.f) return;
     LmSurface s;
     lm_gbuf_load(fr.gbuf[cur], li, s);
@@ -1532,7 +1541,7 @@ static void l_fill_bags(hipStream_t s, LmScene sc, LmFrame fr, uint32_t seed, ui
 static void l_pick_primary(hipStream_t s, int tiles, LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount) { hipLaunchKernelGGL(KN(lm_k_pick_primary), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount); }
 static void l_trace_shade(hipStream_t s, int g, LmScene sc, LmFrame fr, int rc, const uint32_t* cnt, int refillBelow, int pass) { hipLaunchKernelGGL(KN(lm_k_restir_trace_shade), LM_GRID(g), sc, fr, rc, cnt, refillBelow, pass); }
 static void l_temporal(hipStream_t s, int g, LmFrame fr, int cur, int prev, int rc, int rp, int rf, uint32_t seed, uint32_t* visCount) { hipLaunchKernelGGL(KN(lm_k_restir_temporal), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); }
-static void l_spatial(hipStream_t s, int g, LmFrame fr, int cur, int rin, int rout, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_restir_spatial), LM_GRID(g), fr, cur, rin, rout, seed); }
+static void l_spatial(hipStream_t s, int g, LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin) { hipLaunchKernelGGL(KN(lm_k_restir_spatial), LM_GRID(g), fr, cur, rin, rout, seed, margin); }
 static void l_combine(hipStream_t s, int g, LmFrame fr, int cur, int rc, int rs, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_restir_combine), LM_GRID(g), fr, cur, rc, rs, seed); }
 static void l_clear(hipStream_t s, int g, float4* p, uint32_t n) { hipLaunchKernelGGL(KN(lm_k_clear_f4), LM_GRID(g), p, n); }
 static void l_merge(hipStream_t s, int g, LmFrame fr, int blend, uint32_t blendCount, int depthMax) { hipLaunchKernelGGL(KN(lm_k_merge_output), LM_GRID(g), fr, blend, blendCount, depthMax); }

@@ -13,7 +13,7 @@ struct LmKernelTable {
     void (*pick_primary)(hipStream_t, int tiles, LmScene, LmFrame, int cur, int rc, uint32_t seed, uint32_t* visCount);
     void (*trace_shade)(hipStream_t, int grid, LmScene, LmFrame, int rc, const uint32_t* count, int refillBelow, int pass);
     void (*temporal)(hipStream_t, int tiles, LmFrame, int cur, int prev, int rc, int rp, int rf, uint32_t seed, uint32_t* visCount);
-    void (*spatial)(hipStream_t, int tiles, LmFrame, int cur, int rin, int rout, uint32_t seed);
+    void (*spatial)(hipStream_t, int tiles, LmFrame, int cur, int rin, int rout, uint32_t seed, int margin);
     void (*combine)(hipStream_t, int tiles, LmFrame, int cur, int rc, int rs, uint32_t seed);
     void (*clear)(hipStream_t, int grid, float4* p, uint32_t n);
     void (*merge)(hipStream_t, int grid, LmFrame, int blend, uint32_t blendCount, int depthMax);

@@ -82,6 +82,8 @@ struct LmScene {
 struct LmFrame {
     uint32_t W, H;              // full image
     uint32_t x0, y0, ww, wh;    // render window (tile + halo) inside the image
+    uint32_t tx0, ty0, tx1, ty1; // the tile this renderer owns, window-local [tx0,tx1) x [ty0,ty1) (= the window when not tiled): work whose
+                                // result is only needed for owned pixels (indirect waves, second reuse pass, ...) is skipped in the halo
     uint32_t n;                 // ww * wh
     // ray queues (ping-pong): origin.xyz | dir.xyz + local pixel index | contribution.xyz
     float4 *rayO[2], *rayD[2], *rayC[2];

@@ -137,6 +137,7 @@ struct lumen_mi_renderer {
 
     // window
     uint32_t wx0 = 0, wy0 = 0, wx1 = 0, wy1 = 0; bool windowSet = false;
+    uint32_t ox0 = 0, oy0 = 0, ox1 = 0, oy1 = 0; bool tileSet = false;      // owned tile inside the window (global pixel coordinates)
 
     // persistent state (WaveFrontRenderer members)
     uint32_t frameCount = 0, blendCounter = 0;
@@ -495,6 +496,8 @@ int ensureFrameBuffers(R* r)
     LmFrame& f = r->fr;
     const bool realloc = n != r->allocN || f.W != W || f.H != H || f.x0 != r->wx0 || f.y0 != r->wy0 || f.ww != ww;
     f.W = W; f.H = H; f.x0 = r->wx0; f.y0 = r->wy0; f.ww = ww; f.wh = wh; f.n = n;
+    if (r->tileSet && (r->ox0 < r->wx0 || r->oy0 < r->wy0 || r->ox1 > r->wx1 || r->oy1 > r->wy1)) return fail(LUMEN_MI_ERR_INVALID, "owned tile outside the render window");
+    f.tx0 = r->tileSet ? r->ox0 - r->wx0 : 0; f.ty0 = r->tileSet ? r->oy0 - r->wy0 : 0; f.tx1 = r->tileSet ? r->ox1 - r->wx0 : ww; f.ty1 = r->tileSet ? r->oy1 - r->wy0 : wh;
     if (!realloc) return 0;
     int bad = 0;
     for (int i = 0; i < 6; i++) bad |= r->dRay[i].ensure(n) | r->dTailRay[i].ensure(n);
@@ -704,7 +707,7 @@ int traceFrameAsync(R* r)
             K->temporal(st, tiles, fr, currentIndex, temporalIndex, cur, tmp, fresh, rs, fr.counters + LM_CNT_RESTIR(1));         // + visibility rays, pass 2
             if (overlap) LM_HIP(hipEventRecord(r->evTemporal[par], st));
             rs = wangHash(rs);
-            K->spatial(st, tiles, fr, currentIndex, cur, 2, rs);
+            K->spatial(st, tiles, fr, currentIndex, cur, 2, rs, 30);
             // second visibility pass (ReSTIR.cpp:211-212) works on the CURRENT buffer, which the second spatial pass does not
             // touch: trace it beside that pass.  (It must follow the first spatial pass, which reads the current buffer.)
             hipStream_t sv = (overlap && !pickAhead) ? r->aux3 : st;
@@ -715,7 +718,7 @@ int traceFrameAsync(R* r)
             }
             K->trace_shade(sv, gridMain, scv, fr, cur, fr.counters + LM_CNT_RESTIR(1), r->refillVisibility, 1);
             if (sv != st) LM_HIP(hipEventRecord(r->evVisDone, sv));
-            K->spatial(st, tiles, fr, currentIndex, 2, 3, rs);
+            K->spatial(st, tiles, fr, currentIndex, 2, 3, rs, 0);
             if (sv != st) LM_HIP(hipStreamWaitEvent(st, r->evVisDone, 0));
             K->combine(st, tiles, fr, currentIndex, cur, 3, wangHash(rs));
             evEnd(r, ev);
@@ -1241,7 +1244,7 @@ int lumen_mi_get_counters(lumen_mi_renderer* r, uint64_t* out, uint32_t n)
 {
     if (!r || !out) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
     { ApiLock lk(r); int rc = syncAndCollect(r); if (rc) return rc; }
-    uint64_t v[48] = {0};
+    uint64_t v[64] = {0};
     const uint32_t* c = r->hostCounters;
     for (uint32_t d = 0; d < r->lastDepth && d < 16; d++) { v[0] += c[LM_CNT_RAYS(d)]; v[4 + d] = c[LM_CNT_RAYS(d)]; v[1] += c[LM_CNT_SHADOW(d)]; }
     v[2] = (uint64_t)c[LM_CNT_RESTIR(0)] + c[LM_CNT_RESTIR(1)];
@@ -1256,7 +1259,8 @@ int lumen_mi_get_counters(lumen_mi_renderer* r, uint64_t* out, uint32_t n)
         if (!d.ensure(2)) { lm_read_pushes(r->stream, d.p); if (hipMemcpy(h, d.p, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) { v[45] = h[0]; v[46] = h[1]; } d.release(); }
     }
     for (int k = 0; k < 4; k++) v[41 + k] = (uint64_t)c[LM_CNT_OCC + 2 * k] | ((uint64_t)c[LM_CNT_OCC + 2 * k + 1] << 32);
-    for (uint32_t i = 0; i < n && i < 48; i++) out[i] = v[i];
+    v[48] = c[LM_CNT_RESTIR(0)]; v[49] = c[LM_CNT_RESTIR(1)];
+    for (uint32_t i = 0; i < n && i < 64; i++) out[i] = v[i];
     return 0;
 }
 int lumen_mi_get_kernel_time(lumen_mi_renderer* r, int which, float* ms, uint32_t* launches)
@@ -1290,6 +1294,15 @@ int lumen_mi_set_tuning(lumen_mi_renderer* r, const char* key, int value)
     return 0;
 }
 int lumen_mi_set_instrumented(lumen_mi_renderer* r, int e) { if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer"); ApiLock lk(r); r->instrumented = e != 0; r->K = e ? lm_kernel_table_instrumented() : lm_kernel_table(); return 0; }
+
+int lumen_mi_set_tile(lumen_mi_renderer* r, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1)
+{
+    if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer");
+    ApiLock lk(r);
+    if (x0 >= x1 || y0 >= y1) { r->tileSet = false; return 0; }          // an empty rectangle: the whole window is owned again
+    r->ox0 = x0; r->oy0 = y0; r->ox1 = x1; r->oy1 = y1; r->tileSet = true;
+    return 0;
+}
 
 int lumen_mi_set_window(lumen_mi_renderer* r, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1)
 {

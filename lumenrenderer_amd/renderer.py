@@ -181,6 +181,7 @@ class LumenRendererMI:
         b = C.c_int(); check(self.lib, self.lib.lumen_mi_get_blend_mode(self.h, C.byref(b))); return bool(b.value)
 
     def SetWindow(self, x0, y0, x1, y1): check(self.lib, self.lib.lumen_mi_set_window(self.h, x0, y0, x1, y1))
+    def SetTile(self, x0, y0, x1, y1): check(self.lib, self.lib.lumen_mi_set_tile(self.h, x0, y0, x1, y1))
 
     # ---- rendering -------------------------------------------------------------------------------------------------
     def TraceFrame(self):
