@@ -14,16 +14,22 @@ HALO = 60
 
 
 def grid_for(n, width, height):
-    """cols x rows with cols*rows == n, minimising the halo area."""
+    """cols x rows with cols*rows == n whose LARGEST rank window (tile + halo, clipped to the image) is smallest: the frame time
+    of the slowest rank is what the gather waits for."""
     best = None
     for cols in range(1, n + 1):
         if n % cols:
             continue
         rows = n // cols
-        tw, th = math.ceil(width / cols), math.ceil(height / rows)
-        cost = (min(width, tw + 2 * HALO) * min(height, th + 2 * HALO)) / float(tw * th)
-        if best is None or cost < best[0]:
-            best = (cost, cols, rows)
+        worst = 0
+        for cy in range(rows):
+            for cx in range(cols):
+                x0, x1 = (width * cx) // cols, (width * (cx + 1)) // cols
+                y0, y1 = (height * cy) // rows, (height * (cy + 1)) // rows
+                wx0, wy0, wx1, wy1 = max(0, x0 - HALO), max(0, y0 - HALO), min(width, x1 + HALO), min(height, y1 + HALO)
+                worst = max(worst, (wx1 - wx0) * (wy1 - wy0))
+        if best is None or worst < best[0]:
+            best = (worst, cols, rows)
     return best[1], best[2]
 
 
