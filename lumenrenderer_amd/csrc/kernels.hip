@@ -271,6 +271,9 @@ __device__ __forceinline__ bool lm_traverse(const LmScene& sc, const lf3& o, con
 #ifndef LM_PRIO_RAYS
 #define LM_PRIO_RAYS 1048576u
 #endif
+#ifndef LM_NODE_EXIT_FRAC
+#define LM_NODE_EXIT_FRAC 3      // leave the node loop when fewer than a third of the round's lanes still descend (0: use the absolute LM_NODE_EXIT)
+#endif
 #ifndef LM_NODE_EXIT
 #define LM_NODE_EXIT 14
 #endif
@@ -333,7 +336,11 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
 #if LM_NODE_EXIT
                 // leave the node loop once few lanes are still descending while others wait with a leaf (or a finished ray):
                 // those test their triangles and rejoin, instead of idling until the slowest lane has found its leaf
+#if LM_NODE_EXIT_FRAC
+                { const int descending = (int)__popcll(__ballot(true)); if (descending * LM_NODE_EXIT_FRAC < roundLanes) break; }
+#else
                 { const int descending = (int)__popcll(__ballot(true)); if (descending < LM_NODE_EXIT && descending < roundLanes) break; }
+#endif
 #endif
 #if LM_INSTRUMENT
                 for (int k = 0; k < 4; k++) nNodes += (int)sc.nodes[cur].c[k].w != LM_REF_NONE;  // child boxes tested
