@@ -691,6 +691,9 @@ int traceFrameAsync(R* r)
             // serialisation in every variant tried, also with GPU_MAX_HW_QUEUES=8)
             hipStream_t sp = pickAhead ? r->aux3 : st;
             if (overlap) { LM_HIP(hipEventRecord(r->evFront, sx)); LM_HIP(hipStreamWaitEvent(sp, r->evFront, 0)); }
+            // the fresh-candidate buffer is single: the PREVIOUS frame's temporal pass must have consumed it before this frame's
+            // candidates overwrite it (the front no longer waits for that pass since the G-buffer rotates through three sets)
+            if (pickAhead) LM_HIP(hipStreamWaitEvent(sp, r->evTemporal[par ^ 1], 0));
             evBegin2(r, 3, ev, sp);
             const int cur = LM_RES_CUR, tmp = LM_RES_PREV, fresh = pickAhead ? 4 : LM_RES_CUR;
             uint32_t rs = wangHash(seed);

@@ -539,6 +539,28 @@ def test_render_thread_with_concurrent_scene_edits():
     r.close()
 
 
+def test_full_size_overlapped_schedule_equals_the_serial_one():
+    """At the benchmark size the kernels are long enough for real overlap: four streams, two frames in flight, candidates picked
+    ahead.  Eight blended frames enqueued back to back must equal, bit for bit, the same frames rendered on one stream with a
+    synchronisation after every frame (no oracle at this size: it would take minutes)."""
+    from lumenrenderer_amd.scenes import sponza_standin
+    W, H, D = 2560, 1440, 6
+    out = []
+    for tuning, sync_each in (({}, False), ({"single_stream": 1, "tail_below": 0, "pick_ahead": 0}, True), ({"tail_below": 1 << 30}, False)):
+        r = product_from(sponza_standin(), W, H, D, blend=True, tuning=tuning)
+        for _ in range(8):
+            assert r.TraceFrameAsync()
+            if sync_each:
+                r.Synchronize()
+        r.Synchronize()
+        out.append((r.GetRadiance().copy(), r.GetChannel(0).copy(), r.GetChannel(1).copy(), list(r.GetCounters()[:20])))
+        r.close()
+    for k in (1, 2):
+        for a, b in zip(out[0][:3], out[k][:3]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), k
+        assert out[0][3] == out[k][3], k
+
+
 @pytest.mark.parametrize("n_ranks", [2, 4, 8])
 def test_stitched_tiles_equal_the_single_gpu_frame(n_ranks):
     """The multi-GPU decomposition on one GPU: every rank's window (tile + 60-pixel halo, lumenrenderer_amd/tiles.py) is
