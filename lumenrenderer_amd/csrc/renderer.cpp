@@ -702,7 +702,9 @@ int traceFrameAsync(R* r)
             const uint32_t tx0 = fr.x0 / 16u, ty0 = fr.y0 / 16u;
             const uint32_t wtx = (fr.x0 + fr.ww + 15u) / 16u - tx0, wty = (fr.y0 + fr.wh + 15u) / 16u - ty0;
             K->pick_primary(sp, (int)(wtx * wty), r->dscene, fr, currentIndex, fresh, rs, fr.counters + LM_CNT_RESTIR(0));   // + visibility rays, pass 1
-            K->trace_shade(sp, gridMain, r->dscene, fr, fresh, fr.counters + LM_CNT_RESTIR(0), r->refillVisibility, 0);
+            LmScene scp = r->dscene;                                 // the pick-ahead stream traces with its own stack-spill area
+            if (sp != st) scp.spill += (size_t)3 * r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS);
+            K->trace_shade(sp, gridMain, scp, fr, fresh, fr.counters + LM_CNT_RESTIR(0), r->refillVisibility, 0);
             evEnd2(r, ev, sp);
             if (pickAhead) { LM_HIP(hipEventRecord(r->evPick, sp)); LM_HIP(hipStreamWaitEvent(st, r->evPick, 0)); }
             evBegin(r, 3, ev);
@@ -768,12 +770,13 @@ int traceFrameAsync(R* r)
         if (tailLaunched) LM_HIP(hipStreamWaitEvent(st, r->evTail, 0));
     }
     K->merge(st, r->gridFor(fr.n, 8), fr, blend ? 1 : 0, r->blendCounter, (int)depthMax);     // + ReSTIR::SwapBuffers per executed wave
-    if (overlap) LM_HIP(hipEventRecord(r->evMerge[par], st));
-    if (r->pinnedCounters[par]) {     // asynchronous counter read-back: feeds the next frames' schedule (above)
+    if (r->pinnedCounters[par]) {     // asynchronous counter read-back: feeds the next frames' schedule (above); before evMerge, which
+        // releases this counter block to the frame after next
         LM_HIP(hipMemcpyAsync(r->pinnedCounters[par], fr.counters, LM_CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         LM_HIP(hipEventRecord(r->evCnt[par], st));
         r->cntPending[par] = true;
     }
+    if (overlap) LM_HIP(hipEventRecord(r->evMerge[par], st));
     evEnd(r, evAll);
     LM_HIP(hipGetLastError());
     r->lastDepth = depthMax;
