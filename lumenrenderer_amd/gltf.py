@@ -82,6 +82,20 @@ def _node_local(node):
     return T @ R @ S
 
 
+def compose(parent, local):
+    """world = parent * local in float32 with the operation order of glm's mat4 product (the reference composes its node
+    hierarchy in glm floats, Transform.cpp:282-308): C[r][c] = ((A[r][0]*B[0][c] + A[r][1]*B[1][c]) + A[r][2]*B[2][c]) + A[r][3]*B[3][c]."""
+    a, b = np.asarray(parent, np.float32), np.asarray(local, np.float32)
+    out = np.zeros((4, 4), np.float32)
+    for r in range(4):
+        for c in range(4):
+            acc = np.float32(a[r, 0] * b[0, c])
+            for k in (1, 2, 3):
+                acc = np.float32(acc + np.float32(a[r, k] * b[k, c]))
+            out[r, c] = acc
+    return out
+
+
 def load_gltf(path, image_loader=None):
     doc, glb_blob = _read_container(path)
     base = os.path.dirname(path)
@@ -185,13 +199,13 @@ def load_gltf(path, image_loader=None):
 
     def walk(ni, parent):
         node = doc["nodes"][ni]
-        world = parent @ _node_local(node)
+        world = compose(parent, _node_local(node).astype(np.float32))      # local matrices are stored as floats (.ollad node header)
         if "mesh" in node:
-            d.add_instance(meshes[node["mesh"]], world.astype(np.float32))
+            d.add_instance(meshes[node["mesh"]], world)
         for c in node.get("children", []):
             walk(c, world)
 
     scenes = doc.get("scenes") or [{"nodes": list(range(len(doc.get("nodes", []))))}]
     for n in scenes[doc.get("scene", 0)].get("nodes", []):
-        walk(n, np.eye(4))
+        walk(n, np.eye(4, dtype=np.float32))
     return d

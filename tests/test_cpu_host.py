@@ -240,3 +240,93 @@ def test_gltf_ingest_of_the_reference_sample_assets(asset):
     o.trace_frame()
     assert np.isfinite(o.radiance()).all()
     o.close()
+
+
+def _same_scene(a, b):
+    """Two SceneDescriptions describe the same scene (texture / material ids may be numbered differently)."""
+    assert len(a.instances) == len(b.instances) and a.triangle_count() == b.triangle_count()
+    def tex(d, i): return (d.textures[i]["pixels"].tobytes(), d.textures[i]["pixels"].shape, d.textures[i]["srgb"])
+    for ia, ib in zip(a.instances, b.instances):
+        assert np.array_equal(np.asarray(ia["transform"], np.float32), np.asarray(ib["transform"], np.float32))
+        assert ia["emission_mode"] == ib["emission_mode"]
+        pa, pb = a.meshes[ia["mesh"]], b.meshes[ib["mesh"]]
+        assert len(pa) == len(pb)
+        for xa, xb in zip(pa, pb):
+            qa, qb = a.primitives[xa], b.primitives[xb]
+            assert np.array_equal(np.asarray(qa["vertices"], np.float32).view(np.uint32), np.asarray(qb["vertices"], np.float32).view(np.uint32))
+            assert np.array_equal(np.asarray(qa["indices"]), np.asarray(qb["indices"]))
+            ma, mb = a.materials[qa["material"]], b.materials[qb["material"]]
+            for k in ma:
+                if k.endswith("_texture") or k == "normal_map":
+                    assert tex(a, ma[k]) == tex(b, mb[k]), k
+                else:
+                    assert np.allclose(np.float32(ma[k]), np.float32(mb[k]), rtol=0, atol=0), k
+
+
+def _tiny_textured_gltf(tmp_path):
+    """A self-contained glTF written on the fly: two nodes (matrix / TRS), a textured and an untextured material, 16-bit indices,
+    a PNG file and an embedded data-URI buffer."""
+    import base64, io, json
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    pos = np.float32([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1]])
+    nrm = np.tile(np.float32([0, 0, 1]), (6, 1)); uv = rng.random((6, 2)).astype(np.float32)
+    idx = np.uint16([0, 1, 2, 0, 2, 3, 1, 5, 2, 0, 4, 1])
+    blob = pos.tobytes() + nrm.tobytes() + uv.tobytes() + idx.tobytes()
+    Image.fromarray(rng.integers(0, 256, (5, 7, 3), dtype=np.uint8), "RGB").save(tmp_path / "albedo.png")
+    buf = io.BytesIO(); Image.fromarray(rng.integers(0, 256, (4, 4, 4), dtype=np.uint8), "RGBA").save(buf, "PNG")
+    doc = {"asset": {"version": "2.0"}, "scene": 0, "scenes": [{"name": "main", "nodes": [0]}],
+           "nodes": [{"name": "root", "children": [1], "translation": [0.5, 0.25, -1.0], "rotation": [0.0, 0.3826834, 0.0, 0.9238795], "scale": [1.0, 2.0, 1.0], "mesh": 0},
+                     {"name": "child", "matrix": [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0.5, 0.5, 2.0, 1], "mesh": 1}],
+           "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "NORMAL": 1, "TEXCOORD_0": 2}, "indices": 3, "material": 0}]},
+                      {"primitives": [{"attributes": {"POSITION": 0, "NORMAL": 1}, "indices": 4, "material": 1}]}],
+           "materials": [{"pbrMetallicRoughness": {"baseColorFactor": [0.9, 0.8, 0.7, 1.0], "metallicFactor": 0.2, "roughnessFactor": 0.0,
+                                                   "baseColorTexture": {"index": 0}, "metallicRoughnessTexture": {"index": 1}},
+                          "emissiveFactor": [0.1, 0.2, 0.3], "extensions": {"KHR_materials_ior": {"ior": 1.4}, "KHR_materials_clearcoat": {"clearcoatFactor": 0.5}}},
+                         {"pbrMetallicRoughness": {"roughnessFactor": 0.6}}],
+           "textures": [{"source": 0}, {"source": 1}],
+           "images": [{"uri": "albedo.png"}, {"uri": "data:image/png;base64," + base64.b64encode(buf.getvalue()).decode()}],
+           "buffers": [{"byteLength": len(blob), "uri": "data:application/octet-stream;base64," + base64.b64encode(blob).decode()}],
+           "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 72}, {"buffer": 0, "byteOffset": 72, "byteLength": 72},
+                           {"buffer": 0, "byteOffset": 144, "byteLength": 48}, {"buffer": 0, "byteOffset": 192, "byteLength": 24}],
+           "accessors": [{"bufferView": 0, "componentType": 5126, "count": 6, "type": "VEC3"}, {"bufferView": 1, "componentType": 5126, "count": 6, "type": "VEC3"},
+                         {"bufferView": 2, "componentType": 5126, "count": 6, "type": "VEC2"}, {"bufferView": 3, "componentType": 5123, "count": 6, "type": "SCALAR"},
+                         {"bufferView": 3, "byteOffset": 12, "componentType": 5123, "count": 6, "type": "SCALAR"}]}
+    path = tmp_path / "tiny.gltf"
+    path.write_text(json.dumps(doc))
+    return str(path)
+
+
+def test_ollad_round_trip_of_a_generated_gltf(tmp_path):
+    """glTF -> .ollad -> scene equals the direct glTF ingest (layout per LumenPTModelConverter.cpp:563-621 / :72-316)."""
+    from lumenrenderer_amd.gltf import load_gltf
+    from lumenrenderer_amd.ollad import write_ollad, read_ollad
+    src = _tiny_textured_gltf(tmp_path)
+    dst = write_ollad(src, str(tmp_path / "tiny.ollad"))
+    a, b = load_gltf(src), read_ollad(dst)
+    _same_scene(a, b)
+    import struct
+    raw = open(dst, "rb").read()
+    (hs,) = struct.unpack_from("<Q", raw, 0)
+    assert struct.unpack_from("<Q", raw, 8)[0] == 2                      # two images
+    assert struct.unpack_from("<3Q", raw, 16)[2] == 1 and struct.unpack_from("<3Q", raw, 40)[2] == 4     # EDiffuse, EMetalRoughness
+    assert 8 + hs < len(raw)
+
+
+@pytest.mark.parametrize("asset", ["CornellBox/scene.gltf", "cube/Cube.gltf", "CesiumMilkTruck/glTF/CesiumMilkTruck.gltf",
+                                   "CesiumMilkTruck/glTF-Binary/CesiumMilkTruck.glb", "Glass/scene.gltf"])
+def test_ollad_round_trip_of_reference_assets(asset, tmp_path):
+    path = os.path.join(REF_MODELS, asset)
+    if not os.path.exists(path):
+        pytest.skip("reference assets are not mounted")
+    from lumenrenderer_amd.gltf import load_gltf
+    from lumenrenderer_amd.ollad import write_ollad, read_ollad
+    from helpers import oracle_from
+    dst = write_ollad(path, str(tmp_path / "asset.ollad"))
+    a, b = load_gltf(path), read_ollad(dst)
+    _same_scene(a, b)
+    rad = []
+    for d in (a, b):                                                   # and the oracle renders both to the same bits
+        d.instances[0]["emission_mode"] = 2; d.instances[0]["override_radiance"] = (4.0, 4.0, 4.0)
+        o = oracle_from(d, 20, 14, 2); o.trace_frame(); rad.append(o.radiance().copy()); o.close()
+    assert np.array_equal(rad[0].view(np.uint32), rad[1].view(np.uint32))
