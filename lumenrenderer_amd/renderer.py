@@ -211,6 +211,11 @@ class LumenRendererMI:
         check(self.lib, self.lib.lumen_mi_get_output_pixels(self.h, out.ctypes.data_as(C.POINTER(C.c_uint8)), out.nbytes, C.byref(w), C.byref(h)))
         return out
 
+    def MakeScreenshot(self, path, gamma=2.2):
+        """Sandbox OutputLayer::MakeScreenshot (OutputLayer.cpp:882-896): gamma-corrected output of the last frame as a PNG file."""
+        from . import screenshot
+        return screenshot.make_screenshot(self, path, gamma)
+
     def GetRadiance(self):
         hh, ww = self._window_shape()
         out = np.zeros((hh, ww, 4), np.float32)

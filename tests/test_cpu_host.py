@@ -330,3 +330,32 @@ def test_ollad_round_trip_of_reference_assets(asset, tmp_path):
         d.instances[0]["emission_mode"] = 2; d.instances[0]["override_radiance"] = (4.0, 4.0, 4.0)
         o = oracle_from(d, 20, 14, 2); o.trace_frame(); rad.append(o.radiance().copy()); o.close()
     assert np.array_equal(rad[0].view(np.uint32), rad[1].view(np.uint32))
+
+
+def test_screenshot_png_round_trip_and_gamma(tmp_path):
+    """MakeScreenshot (OutputLayer.cpp:882-896): per-channel display gamma, alpha untouched, PNG decodes to the same pixels."""
+    from lumenrenderer_amd import screenshot
+    rng = np.random.default_rng(11)
+    px = rng.integers(0, 256, (37, 53, 4), dtype=np.uint8)
+    px[0, 0] = (0, 255, 128, 7)
+    g = screenshot.apply_gamma(px, 2.2)
+    assert (g[..., 3] == px[..., 3]).all()
+    assert tuple(g[0, 0]) == (0, 255, int(np.float32(np.float32(128 / 255.0) ** np.float32(1 / 2.2)) * np.float32(255.0)), 7)
+    assert (screenshot.apply_gamma(px, 1.0) == px).all()                 # gamma 1 is the identity on bytes
+    lut = screenshot.apply_gamma(np.arange(256, dtype=np.uint8).reshape(1, 256, 1).repeat(4, 2), 2.2)[0, :, 0].astype(int)
+    assert (np.diff(lut) >= 0).all() and lut[0] == 0 and lut[255] == 255
+    path = tmp_path / "Screenshots" / "shot.png"                       # parent directory is created like the reference does
+    screenshot.write_png(str(path), g)
+    assert (screenshot.read_png_rgba8(str(path)) == g).all()
+    try:
+        from PIL import Image
+    except ImportError:
+        Image = None
+    if Image is not None:
+        im = Image.open(str(path))
+        assert im.mode == "RGBA" and im.size == (53, 37)
+        assert (np.asarray(im) == g).all()
+    with pytest.raises(ValueError):
+        screenshot.write_png(str(tmp_path / "bad.png"), np.zeros((4, 4, 3), np.uint8))
+    with pytest.raises(ValueError):
+        screenshot.write_png(str(tmp_path / "empty.png"), np.zeros((0, 4, 4), np.uint8))

@@ -143,6 +143,22 @@ def test_cornell_c1_frame_bit_exact():
     r.close(); o.close()
 
 
+def test_screenshot_of_the_output_matches_the_oracle_pixels(tmp_path):
+    """OutputLayer::MakeScreenshot (Sandbox OutputLayer.cpp:882-896) over GetOutputTexturePixels: the PNG holds the oracle's
+    sRGB8 output with the display gamma applied."""
+    from lumenrenderer_amd import screenshot
+    d = cornell()
+    r = product_from(d, 96, 64, 3); o = oracle_from(d, 96, 64, 3)
+    assert r.TraceFrame() is True and o.trace_frame() == 0
+    path = tmp_path / "Screenshots" / "frame.png"
+    written = r.MakeScreenshot(str(path))
+    want = screenshot.apply_gamma(o.output_pixels(), 2.2)
+    assert np.array_equal(written, want)
+    assert np.array_equal(screenshot.read_png_rgba8(str(path)), want)
+    assert want[..., :3].max() > 32 and (want[..., 3] == o.output_pixels()[..., 3]).all()
+    r.close(); o.close()
+
+
 @pytest.mark.parametrize("w,h,depth", [(37, 23, 1), (1, 1, 3), (250, 3, 2), (61, 67, 16), (128, 128, 7)])
 def test_ragged_sizes_and_depth_limits(w, h, depth):
     """Window sizes that are not multiples of the 8x8 / 16x16 tiles, a single pixel, depth 1 (no indirect wave), the deepest
