@@ -841,6 +841,7 @@ int lumen_mi_init(lumen_mi_renderer* r, const lumen_mi_settings* s)
 {
     if (!r || !s) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
     if (s->render_width == 0 || s->render_height == 0 || s->render_width > 65535 || s->render_height > 65535) return fail(LUMEN_MI_ERR_INVALID, "render resolution must be in [1, 65535]");
+    if (s->depth > LM_MAX_DEPTH) return fail(LUMEN_MI_ERR_INVALID, "depth must be in [1, 16] (0 = the reference's default, 5)");
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(LUMEN_MI_ERR_DEVICE, "no HIP device: the MI355X path needs a GPU (there is no CPU fallback)");
     if (s->device < 0 || s->device >= count) return fail(LUMEN_MI_ERR_INVALID, "device ordinal out of range");
