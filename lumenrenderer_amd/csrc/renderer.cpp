@@ -68,6 +68,33 @@ template <class T> struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+template <class T> struct HostBuf {                 // pinned staging memory for asynchronous uploads
+    T* p = nullptr; size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return 0;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        if (hipHostMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T), hipHostMallocDefault) != hipSuccess) return 1;
+        cap = n; return 0;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+// What a moving / edited scene rewrites every frame exists twice.  A frame reads one set; the next scene state is written into
+// the other one (instance table and light list by asynchronous copies from pinned memory, BVH boxes and Woop packets by the
+// refit kernels) on the wave stream, so frames keep overlapping while the scene changes.
+struct SceneSet {
+    DevBuf<LmNode4> nodes; DevBuf<LmWoop> woop; DevBuf<float> quant; DevBuf<LmEntry> entries; DevBuf<LmLight> lights; DevBuf<float> cdf;
+    HostBuf<LmEntry> hEntries; HostBuf<LmLight> hLights; HostBuf<float> hCdf;
+    hipEvent_t evUp = nullptr; bool upPending = false;      // the staging buffers are free again once this event has passed
+    uint64_t entriesVer = 0, geomVer = 0, lightsVer = 0;    // state of the host scene this set holds
+    void release() {
+        nodes.release(); woop.release(); quant.release(); entries.release(); lights.release(); cdf.release();
+        hEntries.release(); hLights.release(); hCdf.release();
+        if (evUp) { (void)hipEventDestroy(evUp); evUp = nullptr; }
+    }
+};
+
 float g_srgbLut[256];
 void initLut() { static bool d = false; if (d) return; for (int i = 0; i < 256; i++) { const double c = i / 255.0; g_srgbLut[i] = (float)(c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4)); } d = true; }
 
@@ -156,10 +183,13 @@ struct lumen_mi_renderer {
     bool lightsDirty = true;
 
     // device scene
-    DevBuf<LmNode4> dNodes; DevBuf<LmWoop> dWoop; DevBuf<uint2> dTriId; DevBuf<uint32_t> dTriOrder;
-    DevBuf<float4> dVerts; DevBuf<uint32_t> dIndices; DevBuf<LmEntry> dEntries; DevBuf<LmDevMaterial> dMaterials;
-    DevBuf<float> dQuant; DevBuf<float4> dTriBox, dNodeBox; DevBuf<uint32_t> dLevelNodes, dRefitBounds;
-    DevBuf<int> dSpill; DevBuf<LmTexDesc> dTexDesc; DevBuf<uint32_t> dTexels; DevBuf<float> dLut; DevBuf<LmLight> dLights; DevBuf<float> dCdf;
+    SceneSet sset[2];                       // sset[sgen] is what the next frame's kernels read
+    int sgen = 0;
+    uint64_t entriesVer = 1, geomVer = 1, lightsVer = 1;      // versions of the host-side scene state (instance table, geometry, light list)
+    DevBuf<uint2> dTriId; DevBuf<uint32_t> dTriOrder;
+    DevBuf<float4> dVerts; DevBuf<uint32_t> dIndices; DevBuf<LmDevMaterial> dMaterials;
+    DevBuf<float4> dTriBox, dNodeBox; DevBuf<uint32_t> dLevelNodes, dRefitBounds;
+    DevBuf<int> dSpill; DevBuf<LmTexDesc> dTexDesc; DevBuf<uint32_t> dTexels; DevBuf<float> dLut;
     LmScene dscene{};
 
     // device frame
@@ -248,8 +278,8 @@ void findEmissives(const R* r, Primitive& p)
 
 // scene data table + world-space triangle soup + BVH — replaces PTScene/PTMeshInstance/OptixWrapper AS builds
 // Instance state changed (matrices, emissive mode / radiance, override material) but not the set of instances: refresh the
-// scene data table and, if something moved, refit the BVH on the GPU (kernels.hip "BVH refit").  Everything is enqueued on
-// the main stream; no host synchronisation.
+// host copy of the scene data table; syncScene() carries it (and, if something moved, a BVH refit on the GPU, kernels.hip
+// "BVH refit") to the device.
 int refreshEntries(R* r)
 {
     const Scene& sc = r->scenes[r->activeScene];
@@ -264,24 +294,65 @@ int refreshEntries(R* r)
             e.emissive = make_float4(mi.radiance[0], mi.radiance[1], mi.radiance[2], mi.scale);
         }
     }
-    hipStream_t st = r->stream;
-    if (r->dEntries.upload(r->entries, st)) return fail(LUMEN_MI_ERR_DEVICE, "scene table upload failed");
-    if (r->transformsDirty) {
-        const LmKernelTable* K = r->K;
-        const uint32_t nt = (uint32_t)r->bvh.order.size();
-        K->refit_tris(st, r->dscene, nt, r->dTriBox.p, r->dRefitBounds.p);
-        K->refit_quant(st, r->dRefitBounds.p, r->dQuant.p);
-        for (size_t l = 0; l + 1 < r->bvh.levelStart.size(); l++) {
-            const uint32_t a = r->bvh.levelStart[l], b = r->bvh.levelStart[l + 1];
-            if (b > a) K->refit_level(st, r->dscene, r->dLevelNodes.p + a, b - a, r->dTriBox.p, r->dNodeBox.p);
-        }
-        LM_HIP(hipGetLastError());
-        ++r->refits;
-    }
+    ++r->entriesVer;
+    if (r->transformsDirty) ++r->geomVer;
     r->transformsDirty = false;
     r->entriesDirty = false;
     r->lightsDirty = true;
-    r->fenceNeeded = true;
+    return 0;
+}
+
+// Bring the device scene up to the host state.  If the set the previous frames read is stale, the other set is written on
+// stream `su` and becomes current: it was last read by a frame at least two back, whose merge `su` has already waited for
+// (traceFrameAsync), so nothing in flight reads what is overwritten here.  No host synchronisation except for the reuse of
+// a staging buffer whose previous copy (two scene states ago) has not finished yet.
+int syncScene(R* r, hipStream_t su)
+{
+    if (r->sset[0].nodes.p == nullptr) return 0;                   // nothing built yet
+    SceneSet& C = r->sset[r->sgen];
+    if (C.entriesVer != r->entriesVer || C.geomVer != r->geomVer || C.lightsVer != r->lightsVer) {
+        SceneSet& T = r->sset[r->sgen ^ 1];
+        if (T.upPending) { LM_HIP(hipEventSynchronize(T.evUp)); T.upPending = false; }
+        if (!T.evUp) LM_HIP(hipEventCreateWithFlags(&T.evUp, hipEventDisableTiming));
+        bool copied = false;
+        if (T.entriesVer != r->entriesVer) {
+            const size_t n = r->entries.size();
+            if (T.hEntries.ensure(n) || T.entries.ensure(n)) return fail(LUMEN_MI_ERR_DEVICE, "scene table allocation failed");
+            if (n) { memcpy(T.hEntries.p, r->entries.data(), n * sizeof(LmEntry)); LM_HIP(hipMemcpyAsync(T.entries.p, T.hEntries.p, n * sizeof(LmEntry), hipMemcpyHostToDevice, su)); copied = true; }
+            T.entriesVer = r->entriesVer;
+        }
+        if (T.lightsVer != r->lightsVer) {
+            const size_t n = r->lights.size();
+            if (T.hLights.ensure(n) || T.hCdf.ensure(n) || T.lights.ensure(n) || T.cdf.ensure(n)) return fail(LUMEN_MI_ERR_DEVICE, "light list allocation failed");
+            if (n) {
+                memcpy(T.hLights.p, r->lights.data(), n * sizeof(LmLight)); memcpy(T.hCdf.p, r->cdf.data(), n * sizeof(float));
+                LM_HIP(hipMemcpyAsync(T.lights.p, T.hLights.p, n * sizeof(LmLight), hipMemcpyHostToDevice, su));
+                LM_HIP(hipMemcpyAsync(T.cdf.p, T.hCdf.p, n * sizeof(float), hipMemcpyHostToDevice, su));
+                copied = true;
+            }
+            T.lightsVer = r->lightsVer;
+        }
+        if (copied) { LM_HIP(hipEventRecord(T.evUp, su)); T.upPending = true; }
+        if (T.geomVer != r->geomVer) {
+            const LmKernelTable* K = r->K;
+            LmScene sc = r->dscene;
+            sc.nodes = T.nodes.p; sc.woop = T.woop.p; sc.quant = T.quant.p; sc.entries = T.entries.p;
+            const uint32_t nt = (uint32_t)r->bvh.order.size();
+            K->refit_tris(su, sc, nt, r->dTriBox.p, r->dRefitBounds.p);
+            K->refit_quant(su, r->dRefitBounds.p, T.quant.p);
+            for (size_t l = 0; l + 1 < r->bvh.levelStart.size(); l++) {
+                const uint32_t a = r->bvh.levelStart[l], b = r->bvh.levelStart[l + 1];
+                if (b > a) K->refit_level(su, sc, r->dLevelNodes.p + a, b - a, r->dTriBox.p, r->dNodeBox.p);
+            }
+            LM_HIP(hipGetLastError());
+            ++r->refits;
+            T.geomVer = r->geomVer;
+        }
+        r->sgen ^= 1;
+    }
+    const SceneSet& S = r->sset[r->sgen];
+    r->dscene.nodes = S.nodes.p; r->dscene.woop = S.woop.p; r->dscene.quant = S.quant.p; r->dscene.entries = S.entries.p;
+    r->dscene.lights = S.lights.p; r->dscene.cdf = S.cdf.p;
     return 0;
 }
 
@@ -338,24 +409,35 @@ int flatten(R* r)
     std::vector<uint2> triId(nt);
     for (uint32_t s = 0; s < nt; s++) triId[s] = make_uint2(r->triEntry[r->bvh.order[s]], r->triPrim[r->bvh.order[s]]);
     hipStream_t st = r->stream;
-    if (r->dNodes.upload(r->bvh.nodes4, st) || r->dWoop.upload(r->bvh.woop, st) || r->dTriId.upload(triId, st) || r->dTriOrder.upload(r->bvh.order, st) ||
-        r->dVerts.upload(verts, st) || r->dIndices.upload(indices, st) || r->dEntries.upload(r->entries, st))
+    // (stream order puts these copies behind the merge of the last frame, which has joined every other stream; the host then
+    // waits for them, so both scene sets are idle and identical afterwards)
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "stream sync failed");
+    for (SceneSet& S : r->sset) if (S.upPending) { (void)hipEventSynchronize(S.evUp); S.upPending = false; }
+    std::vector<float> quant = {r->bvh.qmin[0], r->bvh.qmin[1], r->bvh.qmin[2], r->bvh.qstep[0], r->bvh.qstep[1], r->bvh.qstep[2], r->bvh.pad, 0.f};
+    ++r->entriesVer; ++r->geomVer;
+    for (SceneSet& S : r->sset) {
+        if (S.nodes.upload(r->bvh.nodes4, st) || S.woop.upload(r->bvh.woop, st) || S.entries.upload(r->entries, st) || S.quant.upload(quant, st))
+            return fail(LUMEN_MI_ERR_DEVICE, "scene upload failed (hipMalloc/hipMemcpy)");
+        S.entriesVer = r->entriesVer; S.geomVer = r->geomVer;
+    }
+    if (r->dTriId.upload(triId, st) || r->dTriOrder.upload(r->bvh.order, st) || r->dVerts.upload(verts, st) || r->dIndices.upload(indices, st))
         return fail(LUMEN_MI_ERR_DEVICE, "scene upload failed (hipMalloc/hipMemcpy)");
-    if (hipStreamSynchronize(st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "scene upload sync failed");
     {
-        std::vector<float> quant = {r->bvh.qmin[0], r->bvh.qmin[1], r->bvh.qmin[2], r->bvh.qstep[0], r->bvh.qstep[1], r->bvh.qstep[2], r->bvh.pad, 0.f};
         std::vector<uint32_t> bounds = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
-        if (r->dQuant.upload(quant, st) || r->dRefitBounds.upload(bounds, st) || r->dLevelNodes.upload(r->bvh.levelNodes, st) ||
+        if (r->dRefitBounds.upload(bounds, st) || r->dLevelNodes.upload(r->bvh.levelNodes, st) ||
             r->dTriBox.ensure(2 * (size_t)nt + 2) || r->dNodeBox.ensure(2 * r->bvh.nodes4.size()))
             return fail(LUMEN_MI_ERR_DEVICE, "refit buffer allocation failed");
-        if (hipStreamSynchronize(st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "scene upload sync failed");
-        r->dscene.quant = r->dQuant.p;
     }
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "scene upload sync failed");
     if (r->dSpill.ensure((size_t)4 * r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS)))      // one area per stream
         return fail(LUMEN_MI_ERR_DEVICE, "stack spill allocation failed");
     r->dscene.spill = r->dSpill.p;
-    r->dscene.nodes = r->dNodes.p; r->dscene.woop = r->dWoop.p; r->dscene.triId = r->dTriId.p; r->dscene.triOrder = r->dTriOrder.p;
-    r->dscene.verts = r->dVerts.p; r->dscene.indices = r->dIndices.p; r->dscene.entries = r->dEntries.p;
+    r->dscene.triId = r->dTriId.p; r->dscene.triOrder = r->dTriOrder.p;
+    r->dscene.verts = r->dVerts.p; r->dscene.indices = r->dIndices.p;
+    {
+        const SceneSet& S = r->sset[r->sgen];
+        r->dscene.nodes = S.nodes.p; r->dscene.woop = S.woop.p; r->dscene.quant = S.quant.p; r->dscene.entries = S.entries.p;
+    }
     r->sceneDirty = false;
     r->transformsDirty = false;
     r->entriesDirty = false;
@@ -478,9 +560,7 @@ int buildLights(R* r)
     for (size_t i = 0; i < L.size(); i++) { acc += (double)key(L[i]); r->cdf[i] = (float)acc; }
     r->lights.swap(L);
     r->totalEmissive = total;
-    if (r->dLights.upload(r->lights, r->stream) || r->dCdf.upload(r->cdf, r->stream)) return fail(LUMEN_MI_ERR_DEVICE, "light upload failed");
-    if (hipStreamSynchronize(r->stream) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "light upload sync failed");
-    r->dscene.lights = r->dLights.p; r->dscene.cdf = r->dCdf.p;
+    ++r->lightsVer;                                             // syncScene() uploads the list
     r->dscene.numLights = (uint32_t)r->lights.size();
     r->dscene.cdfSum = r->cdf.empty() ? 0.f : r->cdf.back();
     r->lightsDirty = false;
@@ -590,6 +670,12 @@ int traceFrameAsync(R* r)
     if ((rc = buildLights(r))) return rc;                                                     // :456
     r->countersValid = false;
     if (r->totalEmissive == 0 || r->lights.empty()) return LUMEN_MI_NO_LIGHTS;                // :459-464
+    {   // scene edits since the last frame go to the device on the stream of the frame front, behind the merge of the frame two
+        // back (the last reader of the scene set that is rewritten); see SceneSet
+        hipStream_t su = (r->overlap && r->aux != nullptr) ? r->aux : r->stream;
+        if (su != r->stream) LM_HIP(hipStreamWaitEvent(su, r->evMerge[r->framePar], 0));
+        if ((rc = syncScene(r, su))) return rc;
+    }
     if ((rc = ensureFrameBuffers(r))) return rc;
     const LmKernelTable* K = r->K;
     hipStream_t st = r->stream;
@@ -891,9 +977,10 @@ int lumen_mi_destroy(lumen_mi_renderer* r)
         (void)hipSetDevice(r->device);
         (void)hipStreamSynchronize(r->stream);
         if (r->aux) { (void)hipStreamSynchronize(r->aux); (void)hipStreamSynchronize(r->aux2); (void)hipStreamDestroy(r->aux2); (void)hipStreamSynchronize(r->aux3); (void)hipStreamDestroy(r->aux3); (void)hipEventDestroy(r->evPick); (void)hipEventDestroy(r->evVis); (void)hipEventDestroy(r->evVisDone); (void)hipEventDestroy(r->evJoin2); for (auto& e : r->evShade) (void)hipEventDestroy(e); (void)hipStreamDestroy(r->aux); (void)hipEventDestroy(r->evFront); for (auto& e : r->evTemporal) (void)hipEventDestroy(e); (void)hipEventDestroy(r->evTail); (void)hipEventDestroy(r->evTop); for (auto& e : r->evMerge) (void)hipEventDestroy(e); for (int i = 0; i < 2; i++) { (void)hipEventDestroy(r->evCnt[i]); (void)hipHostFree(r->pinnedCounters[i]); r->pinnedCounters[i] = nullptr; } (void)hipEventDestroy(r->evJoin); }
-        r->dSpill.release(); r->dNodes.release(); r->dWoop.release(); r->dTriId.release(); r->dTriOrder.release(); r->dVerts.release(); r->dIndices.release();
-        r->dQuant.release(); r->dTriBox.release(); r->dNodeBox.release(); r->dLevelNodes.release(); r->dRefitBounds.release();
-        r->dEntries.release(); r->dMaterials.release(); r->dTexDesc.release(); r->dTexels.release(); r->dLut.release(); r->dLights.release(); r->dCdf.release();
+        for (SceneSet& S : r->sset) { if (S.upPending) (void)hipEventSynchronize(S.evUp); S.release(); }
+        r->dSpill.release(); r->dTriId.release(); r->dTriOrder.release(); r->dVerts.release(); r->dIndices.release();
+        r->dTriBox.release(); r->dNodeBox.release(); r->dLevelNodes.release(); r->dRefitBounds.release();
+        r->dMaterials.release(); r->dTexDesc.release(); r->dTexels.release(); r->dLut.release();
         for (auto& b : r->dRay) b.release(); for (auto& b : r->dTailRay) b.release(); for (auto& b : r->dSh) b.release(); for (auto& b : r->dSh2) b.release(); for (auto& b : r->dGbuf) b.release(); for (auto& b : r->dProbe) b.release(); for (auto& b : r->dRes) b.release(); for (auto& b : r->dResC) b.release();
         for (int i = 0; i < 2; i++) { r->dDirect[i].release(); r->dIndirect[i].release(); } r->dCombined.release(); r->dHits.release(); for (auto& b : r->dMotion) b.release(); r->dCounters.release(); r->dSwap.release(); r->dOutput.release(); r->dBags.release();
         for (auto& e : r->evPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -1326,6 +1413,11 @@ static int prepareScene(lumen_mi_renderer* r)
     int rc;
     if ((rc = uploadResources(r))) return rc;
     if ((rc = flatten(r))) return rc;
+    // outside a frame: every frame in flight has to be complete before a scene set is rewritten (the merge on the main stream joins
+    // the other streams)
+    LM_HIP(hipStreamSynchronize(r->stream));
+    if ((rc = syncScene(r, r->stream))) return rc;
+    LM_HIP(hipStreamSynchronize(r->stream));                    // the refit scratch is shared with the refits of later frames
     if ((rc = r->dCounters.ensure(2 * LM_CNT_WORDS))) return fail(LUMEN_MI_ERR_DEVICE, "counter allocation failed");
     return 0;
 }

@@ -671,8 +671,10 @@ def test_stitched_tiles_equal_the_single_gpu_frame(n_ranks):
 
 
 def test_full_size_moving_scene_async_equals_serial():
-    """Refit (BVH rewritten in place on the main stream), scene-table refresh and light rebuild between asynchronously enqueued
-    full-size frames: the overlapped schedule must wait for exactly the right things.  Compared with the serial schedule."""
+    """Refit, scene-table refresh and light rebuild between asynchronously enqueued full-size frames.  The scene exists twice on
+    the device: an edit is written into the set no frame in flight reads (renderer.cpp SceneSet), on the wave stream.  The edit
+    pattern is irregular (moves, a frame without edits, an emissive-only edit, a material-only edit), so every combination of a
+    stale / current set is crossed.  Compared with the serial schedule on a host-rebuilt BVH."""
     from lumenrenderer_amd.scenes import sponza_standin
     W, H, D = 2560, 1440, 6
     out = []
@@ -680,11 +682,16 @@ def test_full_size_moving_scene_async_equals_serial():
         d = sponza_standin()
         base = np.array(d.instances[0]["transform"], np.float32).reshape(4, 4)
         r = product_from(d, W, H, D, blend=True, tuning=tuning)
-        for k in range(6):
-            m = base.copy(); m[1, 3] += 0.002 * k; m[0, 3] -= 0.001 * k
-            r.m_Scene.m_MeshInstances[0].SetTransform(m)
+        for k in range(9):
+            if k in (0, 1, 3, 6, 7):
+                m = base.copy(); m[1, 3] += 0.002 * k; m[0, 3] -= 0.001 * k
+                r.m_Scene.m_MeshInstances[0].SetTransform(m)
             if k == 3:
                 r.m_Scene.m_MeshInstances[1].SetEmissiveness(2, (9.0, 8.0, 7.0), 40.0)
+            if k == 4:
+                r.m_Scene.m_MeshInstances[1].SetEmissiveness(2, (3.0, 8.0, 7.0), 25.0)        # lights only, geometry of the other set is stale
+            if k == 5:
+                r.m_Scene.m_MeshInstances[0].SetOverrideMaterial(r.m_Materials[1])            # scene table only
             assert r.TraceFrameAsync()
             if sync_each:
                 r.Synchronize()
