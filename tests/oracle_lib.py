@@ -20,6 +20,8 @@ class MaterialDesc(C.Structure):
 
 
 def build():
+    if os.environ.get("LUMEN_ORACLE_SO"):                    # e.g. a sanitizer build of the same sources (tests/test_cpu_host.py)
+        return os.environ["LUMEN_ORACLE_SO"]
     so = os.path.join(ORACLE_DIR, "liblumen_oracle.so")
     srcs = [os.path.join(ORACLE_DIR, f) for f in ("lumen_oracle.cpp", "lumen_oracle.h", "orc_math.h", "orc_bsdf.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):

@@ -359,3 +359,46 @@ def test_screenshot_png_round_trip_and_gamma(tmp_path):
         screenshot.write_png(str(tmp_path / "bad.png"), np.zeros((4, 4, 3), np.uint8))
     with pytest.raises(ValueError):
         screenshot.write_png(str(tmp_path / "empty.png"), np.zeros((0, 4, 4), np.uint8))
+
+
+@pytest.mark.parametrize("sanitizer", ["none", "thread", "address,undefined"])
+def test_host_bvh_builder_structure_determinism_and_sanitizers(sanitizer, tmp_path):
+    """The parallel host BVH builder of the product (csrc/bvh.cpp), compiled for the CPU with tests/bvh_check.cpp: tree invariants,
+    Woop packets bit-identical to the function the GPU refit runs, 1 thread == 8 threads byte for byte; repeated under
+    ThreadSanitizer and AddressSanitizer + UBSan (sanitizers run on the CPU build only)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "lumenrenderer_amd", "csrc")
+    exe = str(tmp_path / "bvh_check")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + csrc, "-ffp-contract=off",
+           os.path.join(root, "tests", "bvh_check.cpp"), os.path.join(csrc, "bvh.cpp"), "-o", exe, "-lpthread"]
+    if sanitizer != "none":
+        cmd += ["-fsanitize=" + sanitizer, "-fno-sanitize-recover=undefined"]
+    build = subprocess.run(cmd, capture_output=True, text=True)
+    if build.returncode != 0 and sanitizer != "none" and ("sanitize" in build.stderr or "cannot find" in build.stderr):
+        pytest.skip("sanitizer runtime not installed: " + build.stderr.strip().splitlines()[-1])
+    assert build.returncode == 0, build.stderr[-2000:]
+    sizes = ["0", "1", "2", "3", "5", "17", "1000", "150000" if sanitizer != "none" else "400000"]
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1", ASAN_OPTIONS="detect_leaks=1")
+    run = subprocess.run([exe, "8"] + sizes, capture_output=True, text=True, env=env, timeout=600)
+    assert run.returncode == 0, (run.stdout[-1000:], run.stderr[-3000:])
+    assert run.stdout.count("ok ") == len(sizes) and "WARNING: ThreadSanitizer" not in run.stderr and "runtime error" not in run.stderr
+
+
+def test_oracle_runs_clean_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    """The checker itself must not lean on undefined behaviour or stray reads: the oracle sources built with ASan + UBSan and
+    driven through every entry point the parity tests use (tests/oracle_sanitizer_run.py)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "liblumen_oracle_san.so")
+    build = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-mfma", "-mavx2", "-pthread",
+                            "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-shared", "-o", so,
+                            os.path.join(root, "oracle", "lumen_oracle.cpp")], capture_output=True, text=True)
+    if build.returncode != 0 and ("sanitize" in build.stderr or "cannot find" in build.stderr):
+        pytest.skip("sanitizer runtime not installed")
+    assert build.returncode == 0, build.stderr[-2000:]
+    runtimes = [subprocess.run(["g++", "-print-file-name=" + n], capture_output=True, text=True).stdout.strip() for n in ("libasan.so", "libubsan.so")]
+    if not all(os.path.isabs(p) and os.path.exists(p) for p in runtimes):
+        pytest.skip("shared sanitizer runtimes not found")
+    env = dict(os.environ, LUMEN_ORACLE_SO=so, LD_PRELOAD=" ".join(runtimes), ASAN_OPTIONS="detect_leaks=0:halt_on_error=1")
+    run = subprocess.run([sys.executable, os.path.join(root, "tests", "oracle_sanitizer_run.py")], capture_output=True, text=True, env=env, timeout=900)
+    assert run.returncode == 0 and "oracle sanitizer run ok" in run.stdout, (run.stdout[-500:], run.stderr[-3000:])
+    assert "runtime error" not in run.stderr and "AddressSanitizer" not in run.stderr
