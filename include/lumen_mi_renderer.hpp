@@ -21,6 +21,7 @@
 #include "Lumen/ModelLoading/ILumenScene.h"
 #include "Lumen/ModelLoading/MeshInstance.h"
 #include "Lumen/Renderer/Camera.h"
+#include "Tools/FrameSnapshot.h"            // LumenPT/src: EndSnapshot() returns a unique_ptr of the complete type
 
 #include <glm/glm.hpp>
 #include <glm/gtc/type_ptr.hpp>
