@@ -150,7 +150,8 @@ int lumen_mi_set_instrumented(lumen_mi_renderer*, int enable);   /* use the node
 int lumen_mi_set_tuning(lumen_mi_renderer*, const char* key, int value);
 
 /* ---- tile sharding (new functionality: the reference is single-GPU) */
-/* render only [x0,x1) x [y0,y1) of the image; RNG streams stay those of the full image */
+/* render only [x0,x1) x [y0,y1) of the image; RNG streams stay those of the full image.  The window stays set across resolution
+ * changes (a frame whose window does not fit the image fails with LUMEN_MI_ERR_INVALID); (0,0,0,0) returns to the whole image. */
 int lumen_mi_set_window(lumen_mi_renderer*, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1);
 /* The part of the render window this renderer OWNS (global pixel coordinates, inside the window; an empty rectangle = the whole
  * window).  Pixels of the window outside it are halo: they are rendered as far as the owned pixels' ReSTIR reuse needs them (surface

@@ -1405,7 +1405,9 @@ int lumen_mi_set_tile(lumen_mi_renderer* r, uint32_t x0, uint32_t y0, uint32_t x
 
 int lumen_mi_set_window(lumen_mi_renderer* r, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1)
 {
-    if (!r || x0 >= x1 || y0 >= y1) return fail(LUMEN_MI_ERR_INVALID, "empty window");
+    if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer");
+    if (x0 == 0 && y0 == 0 && x1 == 0 && y1 == 0) { ApiLock lk(r); r->windowSet = false; return 0; }      // back to the whole image
+    if (x0 >= x1 || y0 >= y1) return fail(LUMEN_MI_ERR_INVALID, "empty window");
     ApiLock lk(r);
     r->wx0 = x0; r->wy0 = y0; r->wx1 = x1; r->wy1 = y1; r->windowSet = true;
     return 0;

@@ -165,7 +165,7 @@ def test_c_abi_reports_bad_arguments_and_call_order():
     d = cornell()
     r.LoadSceneDescription(d)
     r.SetWindow(0, 0, 64, 16); fails(1, r.TraceFrame)                  # a window outside the image is reported by the frame that uses it
-    r.SetWindow(0, 0, 32, 32)
+    r.SetWindow(0, 0, 0, 0)                                            # (0,0,0,0): the whole image again
     assert r.TraceFrame() is True
     small = np.full(8, 7.0, np.float32)
     assert lib.lumen_mi_get_radiance(r.h, small.ctypes.data_as(C.POINTER(C.c_float)), small.nbytes) == 1

@@ -1,0 +1,54 @@
+"""Soak run (GPU box): thousands of asynchronous frames with scene / camera / resolution / window edits in between; host and
+device memory must stay flat and the final frames must equal those of a fresh renderer given the same last edits.
+python tools_soak.py [frames]"""
+import sys, time, resource
+import numpy as np
+import torch
+from lumenrenderer_amd import LumenRendererMI
+from lumenrenderer_amd.scenes import sponza_standin
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+W, H = 1280, 720
+desc = sponza_standin()
+base = np.array(desc.instances[0]["transform"], np.float32).reshape(4, 4)
+
+
+def edits(r, k):
+    inst = r.m_Scene.m_MeshInstances
+    if k % 7 == 0:
+        m = base.copy(); m[1, 3] += 0.001 * (k % 50); inst[0].SetTransform(m)
+    if k % 31 == 0:
+        inst[1].SetEmissiveness(2, (9.0, 8.0, 7.0), 20.0 + (k % 5))
+    if k % 53 == 0:
+        r.SetCamera((0.0, 3.0 + 0.01 * (k % 9), 0.0), (1, 0, 0), (0, 1, 0), (0, 0, -1), 80.0)
+    if k % 400 == 399:
+        r.SetRenderResolution(W - 64 * ((k // 400) % 3), H)          # buffers are reallocated
+    if k % 250 == 249:
+        r.SetWindow(16, 8, 1000, 700) if (k // 250) % 2 else r.SetWindow(0, 0, 0, 0)
+
+
+def used():
+    free, total = torch.cuda.mem_get_info()
+    return (total - free) / 2**20
+
+
+r = LumenRendererMI(); r.Init(depth=6, render_resolution=(W, H), blend_output=False)
+r.LoadSceneDescription(desc)
+for k in range(50): r.TraceFrameAsync()
+r.Synchronize()
+dev0, rss0, t0 = used(), resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024, time.perf_counter()
+mid = None
+for k in range(N):
+    edits(r, k)
+    assert r.TraceFrameAsync()
+    if k == N // 2:
+        r.Synchronize(); mid = (used(), resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024)
+r.Synchronize()
+t1 = time.perf_counter()
+dev1, rss1 = used(), resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024
+print(f"{N} frames in {t1 - t0:.1f} s ({(t1 - t0) / N * 1e3:.2f} ms per TraceFrame incl. edits)")
+print(f"device memory in use: start {dev0:.0f} MiB, middle {mid[0]:.0f} MiB, end {dev1:.0f} MiB;  host max RSS: start {rss0:.0f} MiB, middle {mid[1]:.0f} MiB, end {rss1:.0f} MiB")
+assert np.isfinite(r.GetRadiance()).all()
+assert dev1 - mid[0] < 64 and rss1 - mid[1] < 64, "memory grows"
+print("soak ok")
+r.close()
