@@ -1,0 +1,342 @@
+// frame.cpp — frame buffers and the frame graph of one TraceFrame (streams, events, cross-frame pipelining).
+// Follows WaveFrontRenderer::TraceFrame (WaveFrontRenderer.cpp:435-1089) for order of operations, seed evolution and counters,
+// but enqueues the whole frame without host round trips (the reference synchronises ~40 times per frame).
+#include "renderer_state.h"
+
+namespace lmr {
+
+int ensureFrameBuffers(R* r)
+{
+    const uint32_t W = r->settings.render_width, H = r->settings.render_height;
+    if (!r->windowSet) { r->wx0 = 0; r->wy0 = 0; r->wx1 = W; r->wy1 = H; }
+    if (r->wx1 > W || r->wy1 > H || r->wx0 >= r->wx1 || r->wy0 >= r->wy1) return fail(LUMEN_MI_ERR_INVALID, "render window outside the image");
+    const uint32_t ww = r->wx1 - r->wx0, wh = r->wy1 - r->wy0, n = ww * wh;
+    LmFrame& f = r->fr;
+    const bool realloc = n != r->allocN || f.W != W || f.H != H || f.x0 != r->wx0 || f.y0 != r->wy0 || f.ww != ww;
+    f.W = W; f.H = H; f.x0 = r->wx0; f.y0 = r->wy0; f.ww = ww; f.wh = wh; f.n = n;
+    if (r->tileSet && (r->ox0 < r->wx0 || r->oy0 < r->wy0 || r->ox1 > r->wx1 || r->oy1 > r->wy1)) return fail(LUMEN_MI_ERR_INVALID, "owned tile outside the render window");
+    f.tx0 = r->tileSet ? r->ox0 - r->wx0 : 0; f.ty0 = r->tileSet ? r->oy0 - r->wy0 : 0; f.tx1 = r->tileSet ? r->ox1 - r->wx0 : ww; f.ty1 = r->tileSet ? r->oy1 - r->wy0 : wh;
+    if (!realloc) return 0;
+    int bad = 0;
+    for (int i = 0; i < 6; i++) bad |= r->dRay[i].ensure(n) | r->dTailRay[i].ensure(n);
+    for (int i = 0; i < 3; i++) bad |= r->dSh[i].ensure(n);
+    for (int i = 0; i < 4; i++) bad |= r->dSh2[i].ensure(n);
+    for (int i = 0; i < 3; i++) bad |= r->dGbuf[i].ensure((size_t)8 * n) | r->dProbe[i].ensure(n);
+    for (int i = 0; i < 2; i++) bad |= r->dMotion[i].ensure(n);
+    for (int i = 0; i < 5; i++) bad |= r->dRes[i].ensure((size_t)4 * n) | r->dResC[i].ensure(n);
+    for (int i = 0; i < 2; i++) bad |= r->dDirect[i].ensure(n) | r->dIndirect[i].ensure(n);
+    bad |= r->dCombined.ensure(n) | r->dHits.ensure(n) | r->dOutput.ensure(n);
+    bad |= r->dCounters.ensure(2 * LM_CNT_WORDS) | r->dBags.ensure(50 * 1000);
+    if (bad) return fail(LUMEN_MI_ERR_DEVICE, "frame buffer allocation failed");
+    for (int q = 0; q < 2; q++) { f.rayO[q] = r->dRay[3 * q].p; f.rayD[q] = r->dRay[3 * q + 1].p; f.rayC[q] = r->dRay[3 * q + 2].p; }
+    f.shO = r->dSh[0].p; f.shD = r->dSh[1].p; f.shR = r->dSh[2].p;
+    f.visO = r->dSh2[0].p; f.visD = r->dSh2[1].p; f.vis2O = r->dSh2[2].p; f.vis2D = r->dSh2[3].p;
+    f.hits = r->dHits.p;
+    for (int i = 0; i < 3; i++) { f.gbuf[i] = r->dGbuf[i].p; f.probe[i] = r->dProbe[i].p; }
+    for (int i = 0; i < 5; i++) { f.res[i] = r->dRes[i].p; f.resC[i] = r->dResC[i].p; }
+    f.motion = r->dMotion[0].p; f.direct = r->dDirect[0].p; f.indirect = r->dIndirect[0].p; f.combined = r->dCombined.p; f.output = r->dOutput.p;
+    f.counters = r->dCounters.p; f.bags = r->dBags.p;
+    // ResizeBuffers (WaveFrontRenderer.cpp:1424-1540): history is dropped; reservoirs reset (ReSTIRKernels.cu:36-47)
+    hipStream_t st = r->stream;
+    for (int i = 0; i < 3; i++) if (hipMemsetAsync(f.gbuf[i], 0, (size_t)8 * n * sizeof(float4), st) != hipSuccess || hipMemsetAsync(f.probe[i], 0, (size_t)n * sizeof(float4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
+    for (int i = 0; i < 5; i++) if (hipMemsetAsync(f.res[i], 0, (size_t)4 * n * sizeof(float4), st) != hipSuccess || hipMemsetAsync(f.resC[i], 0, (size_t)n * sizeof(float4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
+    if (hipMemsetAsync(f.combined, 0, (size_t)n * sizeof(float4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
+    if (hipMemsetAsync(f.output, 0, (size_t)n * sizeof(uchar4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
+    r->allocN = n;
+    r->fenceNeeded = true;
+    r->haveEst = false; r->cntPending[0] = r->cntPending[1] = false;
+    if (r->dSwap.ensure(1) || hipMemsetAsync(r->dSwap.p, 0, sizeof(int), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "swap index allocation failed");
+    f.swap = r->dSwap.p;
+    r->blendCounter = 0; r->frameIndex = 0; r->gbufIndex = 0; r->lastGbuf = 0;
+    return 0;
+}
+
+void invert4(const float* m, float* out)
+{
+    double a[16], inv[16];
+    for (int i = 0; i < 16; i++) a[i] = m[i];
+    inv[0] = a[5]*a[10]*a[15] - a[5]*a[11]*a[14] - a[9]*a[6]*a[15] + a[9]*a[7]*a[14] + a[13]*a[6]*a[11] - a[13]*a[7]*a[10];
+    inv[4] = -a[4]*a[10]*a[15] + a[4]*a[11]*a[14] + a[8]*a[6]*a[15] - a[8]*a[7]*a[14] - a[12]*a[6]*a[11] + a[12]*a[7]*a[10];
+    inv[8] = a[4]*a[9]*a[15] - a[4]*a[11]*a[13] - a[8]*a[5]*a[15] + a[8]*a[7]*a[13] + a[12]*a[5]*a[11] - a[12]*a[7]*a[9];
+    inv[12] = -a[4]*a[9]*a[14] + a[4]*a[10]*a[13] + a[8]*a[5]*a[14] - a[8]*a[6]*a[13] - a[12]*a[5]*a[10] + a[12]*a[6]*a[9];
+    inv[1] = -a[1]*a[10]*a[15] + a[1]*a[11]*a[14] + a[9]*a[2]*a[15] - a[9]*a[3]*a[14] - a[13]*a[2]*a[11] + a[13]*a[3]*a[10];
+    inv[5] = a[0]*a[10]*a[15] - a[0]*a[11]*a[14] - a[8]*a[2]*a[15] + a[8]*a[3]*a[14] + a[12]*a[2]*a[11] - a[12]*a[3]*a[10];
+    inv[9] = -a[0]*a[9]*a[15] + a[0]*a[11]*a[13] + a[8]*a[1]*a[15] - a[8]*a[3]*a[13] - a[12]*a[1]*a[11] + a[12]*a[3]*a[9];
+    inv[13] = a[0]*a[9]*a[14] - a[0]*a[10]*a[13] - a[8]*a[1]*a[14] + a[8]*a[2]*a[13] + a[12]*a[1]*a[10] - a[12]*a[2]*a[9];
+    inv[2] = a[1]*a[6]*a[15] - a[1]*a[7]*a[14] - a[5]*a[2]*a[15] + a[5]*a[3]*a[14] + a[13]*a[2]*a[7] - a[13]*a[3]*a[6];
+    inv[6] = -a[0]*a[6]*a[15] + a[0]*a[7]*a[14] + a[4]*a[2]*a[15] - a[4]*a[3]*a[14] - a[12]*a[2]*a[7] + a[12]*a[3]*a[6];
+    inv[10] = a[0]*a[5]*a[15] - a[0]*a[7]*a[13] - a[4]*a[1]*a[15] + a[4]*a[3]*a[13] + a[12]*a[1]*a[7] - a[12]*a[3]*a[5];
+    inv[14] = -a[0]*a[5]*a[14] + a[0]*a[6]*a[13] + a[4]*a[1]*a[14] - a[4]*a[2]*a[13] - a[12]*a[1]*a[6] + a[12]*a[2]*a[5];
+    inv[3] = -a[1]*a[6]*a[11] + a[1]*a[7]*a[10] + a[5]*a[2]*a[11] - a[5]*a[3]*a[10] - a[9]*a[2]*a[7] + a[9]*a[3]*a[6];
+    inv[7] = a[0]*a[6]*a[11] - a[0]*a[7]*a[10] - a[4]*a[2]*a[11] + a[4]*a[3]*a[10] + a[8]*a[2]*a[7] - a[8]*a[3]*a[6];
+    inv[11] = -a[0]*a[5]*a[11] + a[0]*a[7]*a[9] + a[4]*a[1]*a[11] - a[4]*a[3]*a[9] - a[8]*a[1]*a[7] + a[8]*a[3]*a[5];
+    inv[15] = a[0]*a[5]*a[10] - a[0]*a[6]*a[9] - a[4]*a[1]*a[10] + a[4]*a[2]*a[9] + a[8]*a[1]*a[6] - a[8]*a[2]*a[5];
+    const double det = a[0]*inv[0] + a[1]*inv[4] + a[2]*inv[8] + a[3]*inv[12];
+    for (int i = 0; i < 16; i++) out[i] = (float)(inv[i] / det);
+}
+
+// timing helpers: HIP events on the renderer's own stream
+void evBegin(R* r, int cls, size_t& slot)
+{
+    slot = (size_t)-1;
+    if (!r->timing) return;
+    if (r->evUsed == r->evPool.size()) { R::EvPair p; if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return; p.cls = 0; r->evPool.push_back(p); }
+    slot = r->evUsed++;
+    r->evPool[slot].cls = cls;
+    (void)hipEventRecord(r->evPool[slot].a, r->stream);
+}
+void evEnd(R* r, size_t slot) { if (slot != (size_t)-1) (void)hipEventRecord(r->evPool[slot].b, r->stream); }
+void evBegin2(R* r, int cls, size_t& slot, hipStream_t s)
+{
+    slot = (size_t)-1;
+    if (!r->timing) return;
+    if (r->evUsed == r->evPool.size()) { R::EvPair p; if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return; p.cls = 0; r->evPool.push_back(p); }
+    slot = r->evUsed++;
+    r->evPool[slot].cls = cls;
+    (void)hipEventRecord(r->evPool[slot].a, s);
+}
+void evEnd2(R* r, size_t slot, hipStream_t s) { if (slot != (size_t)-1) (void)hipEventRecord(r->evPool[slot].b, s); }
+
+int traceFrameAsync(R* r)
+{
+    if (!r->initialised) return fail(LUMEN_MI_ERR_STATE, "lumen_mi_init has not been called");
+    { std::lock_guard<std::mutex> lk(r->settingsMutex); r->settings = r->pending; }          // WaveFrontRenderer.cpp:480-505
+    if (hipSetDevice(r->device) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "hipSetDevice failed");
+    int rc;
+    if ((rc = uploadResources(r))) return rc;
+    if ((rc = flatten(r))) return rc;
+    if ((rc = buildLights(r))) return rc;                                                     // :456
+    r->countersValid = false;
+    if (r->totalEmissive == 0 || r->lights.empty()) return LUMEN_MI_NO_LIGHTS;                // :459-464
+    {   // scene edits since the last frame go to the device on the stream of the frame front, behind the merge of the frame two
+        // back (the last reader of the scene set that is rewritten); see SceneSet
+        hipStream_t su = (r->overlap && r->aux != nullptr) ? r->aux : r->stream;
+        if (su != r->stream) LM_HIP(hipStreamWaitEvent(su, r->evMerge[r->framePar], 0));
+        if ((rc = syncScene(r, su))) return rc;
+    }
+    if ((rc = ensureFrameBuffers(r))) return rc;
+    const LmKernelTable* K = r->K;
+    hipStream_t st = r->stream;
+    LmFrame& fr = r->fr;
+    const uint32_t depthMax = std::min<uint32_t>(r->settings.depth, LM_MAX_DEPTH);
+    // "current" / "previous" surface data (the reference toggles two buffers, WaveFrontRenderer.cpp:1045-1049); here three physical
+    // sets rotate, so that the next frame's extraction does not wait for this frame's temporal pass
+    const int currentIndex = r->gbufIndex, temporalIndex = (r->gbufIndex + 2) % 3;
+    const bool blend = r->settings.blend_output != 0;
+
+    // camera (Camera.cpp:79-93,122-140; aspect = render W/H, WaveFrontRenderer.cpp:577)
+    LmCamera cam;
+    const float aspect = (float)fr.W / (float)fr.H;
+    const float halfY = 1.0f * (float)tan((double)(r->fovY * 0.01745329251994329576923690768489f) * 0.5);
+    const float halfX = halfY * aspect;
+    for (int k = 0; k < 3; k++) { cam.eye[k] = r->camPos[k]; cam.U[k] = r->camRight[k] * halfX; cam.V[k] = r->camUp[k] * halfY; cam.Wv[k] = r->camFwd[k] * 1.0f; }
+    float camWorld[16] = {r->camRight[0], r->camUp[0], r->camFwd[0], r->camPos[0], r->camRight[1], r->camUp[1], r->camFwd[1], r->camPos[1],
+                          r->camRight[2], r->camUp[2], r->camFwd[2], r->camPos[2], 0, 0, 0, 1};
+    if (!r->havePrev) { memcpy(r->prevCamWorld, camWorld, sizeof camWorld); r->havePrev = true; }
+    {   // M = projection(fovY, aspect, 0.5, 10000) * inverse(previous camera world matrix)   (WaveFrontRenderer.cpp:763-776)
+        float proj[16] = {0}, invPrev[16];
+        const float tanHalf = (float)tan((double)(r->fovY * 0.01745329251994329576923690768489f) / 2.0);
+        const float zn = 0.5f, zf = 10000.f;
+        proj[0] = 1.0f / (aspect * tanHalf); proj[5] = 1.0f / tanHalf;
+        proj[10] = -(zf + zn) / (zf - zn); proj[11] = -(2.0f * zf * zn) / (zf - zn); proj[14] = -1.0f;
+        invert4(r->prevCamWorld, invPrev);
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { float s = 0.f; for (int k = 0; k < 4; k++) s += proj[i * 4 + k] * invPrev[k * 4 + j]; cam.prevViewProj[i * 4 + j] = s; }
+    }
+
+    // ---- frame graph.  Streams: main `st` (ReSTIR chain, merge), `sx` (frame front + indirect waves), aux2 (NEE shadow
+    // rays), aux3 (second ReSTIR visibility pass).  Frames are software-pipelined: the front of frame i+1 (primary rays,
+    // first closest-hit launch, surface extraction, first continuation) is queued on `sx` behind the waves of frame i and
+    // runs beside the ReSTIR tail of frame i on `st`.  What that needs: DIRECT / INDIRECT and the counter block are
+    // double-buffered by frame parity; extraction waits for frame i's temporal pass (the last reader of the G-buffer /
+    // probe plane / motion vectors it overwrites); a frame's front waits for the merge of the frame two back (owner of
+    // the same parity buffers).  Accumulation order per pixel is unchanged, so results equal the serial order bit for bit.
+    const bool overlap = r->overlap && r->aux != nullptr;
+    hipStream_t sx = overlap ? r->aux : st;
+    const int par = r->framePar; r->framePar ^= 1;
+    fr.motion = r->dMotion[par].p;
+    fr.direct = r->dDirect[par].p; fr.indirect = r->dIndirect[par].p; fr.counters = r->dCounters.p + (size_t)par * LM_CNT_WORDS;
+    if (overlap) {
+        if (r->fenceNeeded) { LM_HIP(hipEventRecord(r->evTop, st)); LM_HIP(hipStreamWaitEvent(sx, r->evTop, 0)); }
+        LM_HIP(hipStreamWaitEvent(sx, r->evMerge[par], 0));
+    }
+    r->fenceNeeded = false;
+    size_t evAll; evBegin2(r, 4, evAll, sx);
+    LM_HIP(hipMemsetAsync(fr.counters, 0, LM_CNT_WORDS * sizeof(uint32_t), sx));
+    if (!blend) K->clear(st, r->gridFor(fr.n, 8), fr.combined, fr.n);                        // :559
+    ++r->frameCount;                                                                          // :593
+    K->primary(sx, r->gridFor(fr.n, 8), fr, cam, r->frameCount);
+    uint32_t seed = wangHash(r->frameCount);                                                  // :685
+    LmScene scx = r->dscene;                                                                  // same scene, its own stack-spill area
+    if (overlap) scx.spill += (size_t)r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS);
+    const int gridMain = r->numCU * r->traceBlocksMain, gridAux = r->numCU * (overlap ? r->traceBlocksAux : r->traceBlocksMain);
+    const int tiles = (int)(((fr.ww + 15u) / 16u) * ((fr.wh + 15u) / 16u));
+    // Deep waves hold too few rays to fill the machine; from the first wave expected to be shorter than `tailBelow` rays the
+    // remaining depths run as one launch.  The expectation comes from the counters of the most recent frame whose
+    // asynchronous read-back has already landed (no host synchronisation; any choice gives the same image).
+    for (int p : {par ^ 1, par}) {
+        if (r->cntPending[p] && hipEventQuery(r->evCnt[p]) == hipSuccess) {
+            for (uint32_t dd = 0; dd <= LM_MAX_DEPTH; dd++) r->estRays[dd] = r->pinnedCounters[p][LM_CNT_RAYS(dd)];
+            r->haveEst = true; r->cntPending[p] = false;
+            break;
+        }
+    }
+    int tailDepth = (int)depthMax;
+    const uint32_t tailBelow = r->tailBelow >= 0 ? (uint32_t)r->tailBelow : (fr.n < (1u << 20) ? 65536u : 16384u);
+    if (tailBelow && r->haveEst) for (uint32_t dd = 1; dd < depthMax; dd++) if (r->estRays[dd] < tailBelow) { tailDepth = (int)dd; break; }
+    int q = 0;
+    size_t ev;
+    bool tailLaunched = false;
+    // the queue the path tail reads is its own (double-buffered by frame parity), so that the tail can run on the shadow
+    // stream while the wave stream already enqueues the next frame's front into the regular ray queues
+    auto withTailQueue = [&](LmFrame f, int queue) {
+        f.rayO[queue] = r->dTailRay[3 * par].p; f.rayD[queue] = r->dTailRay[3 * par + 1].p; f.rayC[queue] = r->dTailRay[3 * par + 2].p;
+        return f;
+    };
+    for (uint32_t depth = 0; depth < depthMax; ++depth) {
+        uint32_t* inCount = fr.counters + LM_CNT_RAYS(depth);
+        uint32_t* outCount = fr.counters + LM_CNT_RAYS(depth + 1);
+        const uint32_t seed2 = wangHash(seed);                                                // CPUShadingKernels.cu:178
+        const int doIndirect = depth < depthMax - 1 ? 1 : 0;
+        if (depth == 0) {
+            evBegin2(r, 0, ev, sx);
+            K->trace_closest(sx, gridMain, scx, fr.rayO[q], fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters, r->refillPrimary);    // :678,:703
+            evEnd2(r, ev, sx);
+            if (overlap) LM_HIP(hipStreamWaitEvent(sx, r->evTemporal[par], 0));          // the temporal pass two frames back has read what extraction overwrites
+            evBegin2(r, 2, ev, sx);
+            K->extract0(sx, r->gridFor(fr.n, 8), r->dscene, (int)depth + 1 == tailDepth ? withTailQueue(fr, q ^ 1) : fr, cam, currentIndex, seed2, doIndirect, q ^ 1, outCount);   // + depth-0 continuation
+            evEnd2(r, ev, sx);
+            // the indirect waves follow on the same stream beside ReSTIR on the main stream: both depend only on the G-buffer
+            // ReSTIR::Run (Framework/ReSTIR.cpp:65-233) on the main stream.  Candidate generation and the first visibility pass
+            // only need this frame's G-buffer; for small windows (multi-GPU tiles, where the dependency chain and not the
+            // machine's throughput bounds the frame) they run on their own stream into the fresh-candidate buffer [4], beside
+            // the previous frame's spatial passes; the temporal pass picks them up from there.
+            const bool pickAhead = overlap && (r->pickAhead >= 0 ? r->pickAhead != 0 : fr.n < (1u << 20));
+            // (four streams in total: HIP multiplexes streams onto 4 hardware queues, and a fifth stream cost 11-18 % through false
+            // serialisation in every variant tried, also with GPU_MAX_HW_QUEUES=8)
+            hipStream_t sp = pickAhead ? r->aux3 : st;
+            if (overlap) { LM_HIP(hipEventRecord(r->evFront, sx)); LM_HIP(hipStreamWaitEvent(sp, r->evFront, 0)); }
+            // the fresh-candidate buffer is single: the PREVIOUS frame's temporal pass must have consumed it before this frame's
+            // candidates overwrite it (the front no longer waits for that pass since the G-buffer rotates through three sets)
+            if (pickAhead) LM_HIP(hipStreamWaitEvent(sp, r->evTemporal[par ^ 1], 0));
+            evBegin2(r, 3, ev, sp);
+            const int cur = LM_RES_CUR, tmp = LM_RES_PREV, fresh = pickAhead ? 4 : LM_RES_CUR;
+            uint32_t rs = wangHash(seed);
+            K->fill_bags(sp, r->dscene, fr, seed, 50u * 1000u);
+            rs = wangHash(rs);
+            const uint32_t tx0 = fr.x0 / 16u, ty0 = fr.y0 / 16u;
+            const uint32_t wtx = (fr.x0 + fr.ww + 15u) / 16u - tx0, wty = (fr.y0 + fr.wh + 15u) / 16u - ty0;
+            K->pick_primary(sp, (int)(wtx * wty), r->dscene, fr, currentIndex, fresh, rs, fr.counters + LM_CNT_RESTIR(0));   // + visibility rays, pass 1
+            LmScene scp = r->dscene;                                 // the pick-ahead stream traces with its own stack-spill area
+            if (sp != st) scp.spill += (size_t)3 * r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS);
+            K->trace_shade(sp, gridMain, scp, fr, fresh, fr.counters + LM_CNT_RESTIR(0), r->refillVisibility, 0);
+            evEnd2(r, ev, sp);
+            if (pickAhead) { LM_HIP(hipEventRecord(r->evPick, sp)); LM_HIP(hipStreamWaitEvent(st, r->evPick, 0)); }
+            evBegin(r, 3, ev);
+            rs = wangHash(rs);
+            K->temporal(st, tiles, fr, currentIndex, temporalIndex, cur, tmp, fresh, rs, fr.counters + LM_CNT_RESTIR(1));         // + visibility rays, pass 2
+            if (overlap) LM_HIP(hipEventRecord(r->evTemporal[par], st));
+            rs = wangHash(rs);
+            K->spatial(st, tiles, fr, currentIndex, cur, 2, rs, 30);
+            // second visibility pass (ReSTIR.cpp:211-212) works on the CURRENT buffer, which the second spatial pass does not
+            // touch: trace it beside that pass.  (It must follow the first spatial pass, which reads the current buffer.)
+            hipStream_t sv = (overlap && !pickAhead) ? r->aux3 : st;
+            LmScene scv = r->dscene;
+            if (sv != st) {
+                scv.spill += (size_t)3 * r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS);
+                LM_HIP(hipEventRecord(r->evVis, st)); LM_HIP(hipStreamWaitEvent(sv, r->evVis, 0));
+            }
+            K->trace_shade(sv, gridMain, scv, fr, cur, fr.counters + LM_CNT_RESTIR(1), r->refillVisibility, 1);
+            if (sv != st) LM_HIP(hipEventRecord(r->evVisDone, sv));
+            K->spatial(st, tiles, fr, currentIndex, 2, 3, rs, 0);
+            if (sv != st) LM_HIP(hipStreamWaitEvent(st, r->evVisDone, 0));
+            K->combine(st, tiles, fr, currentIndex, cur, 3, wangHash(rs));
+            evEnd(r, ev);
+        } else if ((int)depth >= tailDepth) {
+            // path tail: the remaining waves in one launch (kernels.hip lm_k_path_tail) on the shadow stream: its INDIRECT adds
+            // follow the previous wave's NEE adds by stream order, and the wave stream is free for the next frame's front
+            hipStream_t stl = overlap ? r->aux2 : sx;
+            LmScene sct = scx;
+            if (overlap) {
+                sct.spill += (size_t)r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS);
+                LM_HIP(hipEventRecord(r->evShade[depth], sx)); LM_HIP(hipStreamWaitEvent(stl, r->evShade[depth], 0));     // the queue's producer is done
+            }
+            evBegin2(r, 0, ev, stl);
+            K->path_tail(stl, r->numCU * 8, sct, withTailQueue(fr, q), q, inCount, (int)depth, (int)depthMax, seed, r->tailLanes);
+            evEnd2(r, ev, stl);
+            if (overlap) LM_HIP(hipEventRecord(r->evTail, stl));
+            tailLaunched = true;
+            break;
+        } else {
+            uint32_t* shCount = fr.counters + LM_CNT_SHADOW(depth);
+            evBegin2(r, 0, ev, sx);
+            K->trace_closest(sx, gridAux, scx, fr.rayO[q], fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters, r->refillBelow);
+            evEnd2(r, ev, sx);
+            if (overlap) LM_HIP(hipStreamWaitEvent(sx, r->evJoin2, 0));                   // previous wave's (or frame's) shadow rays consumed
+            evBegin2(r, 2, ev, sx);
+            K->shade_wave(sx, r->numCU * 8, scx, (int)depth + 1 == tailDepth ? withTailQueue(fr, q ^ 1) : fr, q, inCount, seed, seed2, doIndirect, outCount, shCount);
+            evEnd2(r, ev, sx);
+            // NEE shadow rays of this wave: third stream, beside the next wave's closest-hit launch.  The shadow queue is
+            // rewritten by the NEXT shade_wave, which therefore waits for this launch (evJoin2).  (`shadow_on_wave` 1 keeps them on
+            // the wave stream: equal at full size and for the windows of 4 / 8 ranks, 8 % slower for those of 2 ranks.)
+            const bool shadowOnWave = r->shadowOnWave != 0;
+            hipStream_t ss = (overlap && !shadowOnWave) ? r->aux2 : sx;
+            LmScene scs = scx;
+            if (ss != sx) { scs.spill += (size_t)r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS); LM_HIP(hipEventRecord(r->evShade[depth], sx)); LM_HIP(hipStreamWaitEvent(ss, r->evShade[depth], 0)); }
+            evBegin2(r, 1, ev, ss);
+            K->trace_shadow(ss, gridAux, scs, fr, shCount, 0.01f, r->refillBelow);     // tmin of the intersection launch (:843)
+            evEnd2(r, ev, ss);
+            if (overlap) { LM_HIP(hipEventRecord(r->evJoin2, ss)); }
+        }
+        q ^= 1;
+        seed = wangHash(seed);                                                               // :830
+    }
+    if (overlap) {
+        LM_HIP(hipEventRecord(r->evJoin, sx)); LM_HIP(hipStreamWaitEvent(st, r->evJoin, 0));
+        if (depthMax > 1) LM_HIP(hipStreamWaitEvent(st, r->evJoin2, 0));
+        if (tailLaunched) LM_HIP(hipStreamWaitEvent(st, r->evTail, 0));
+    }
+    K->merge(st, r->gridFor(fr.n, 8), fr, blend ? 1 : 0, r->blendCounter, (int)depthMax);     // + ReSTIR::SwapBuffers per executed wave
+    if (r->pinnedCounters[par]) {     // asynchronous counter read-back: feeds the next frames' schedule (above); before evMerge, which
+        // releases this counter block to the frame after next
+        LM_HIP(hipMemcpyAsync(r->pinnedCounters[par], fr.counters, LM_CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        LM_HIP(hipEventRecord(r->evCnt[par], st));
+        r->cntPending[par] = true;
+    }
+    if (overlap) LM_HIP(hipEventRecord(r->evMerge[par], st));
+    evEnd(r, evAll);
+    LM_HIP(hipGetLastError());
+    r->lastDepth = depthMax;
+    r->lastLightCount = r->lights.size();
+    if (blend) ++r->blendCounter;                                                            // :1039-1042
+    r->frameIndex = r->frameIndex + 1 == 2 ? 0 : r->frameIndex + 1;                          // :1045-1049
+    r->lastGbuf = r->gbufIndex; r->gbufIndex = (r->gbufIndex + 1) % 3;
+    memcpy(r->prevCamWorld, camWorld, sizeof camWorld);                                      // :1051
+    ++r->frameCount;                                                                         // :1052
+    return 0;
+}
+
+int syncAndCollect(R* r)
+{
+    if (!r->initialised) return fail(LUMEN_MI_ERR_STATE, "not initialised");
+    LM_HIP(hipStreamSynchronize(r->stream));
+    if (!r->countersValid && r->fr.counters) {
+        LM_HIP(hipMemcpy(r->hostCounters, r->fr.counters, sizeof r->hostCounters, hipMemcpyDeviceToHost));
+        r->countersValid = true;
+    }
+    if (r->evUsed) {
+        // accumulate over every frame enqueued since the last lumen_mi_enable_kernel_timing(1)
+        for (size_t i = 0; i < r->evUsed; i++) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, r->evPool[i].a, r->evPool[i].b) == hipSuccess) { r->classMs[r->evPool[i].cls] += ms; r->classLaunches[r->evPool[i].cls]++; }
+        }
+        r->evUsed = 0;
+        const float frames = (float)std::max<uint32_t>(1u, r->classLaunches[4]);
+        r->frameStats["Wavefront Iteration"] = (uint64_t)((r->classMs[0] + r->classMs[2] + r->classMs[3]) * 1000.f / frames);
+        r->frameStats["Shadow Rays"] = (uint64_t)(r->classMs[1] * 1000.f / frames);
+        r->frameStats["ReSTIR"] = (uint64_t)(r->classMs[3] * 1000.f / frames);
+        r->frameStats["Total Frame Time"] = (uint64_t)(r->classMs[4] * 1000.f / frames);
+    }
+    return 0;
+}
+
+}  // namespace lmr

@@ -1,0 +1,244 @@
+// renderer_state.h — internal to liblumen_mi.so: the renderer object behind the opaque `lumen_mi_renderer*` of
+// include/lumen_mi.h, its host-side resource tables and device buffers, and the functions the three host translation units
+// share (scene.cpp: flattening, BVH / scene-set upload, light list; frame.cpp: frame buffers and the frame graph;
+// renderer.cpp: the C ABI).  Not installed; include/lumen_mi.h is the only public header.
+#pragma once
+#include "../../include/lumen_mi.h"
+#include "bvh.h"
+#include "lm_launch.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+extern "C" void lm_read_pushes(hipStream_t s, unsigned long long* out);
+
+namespace lmr {
+
+inline thread_local std::string g_lastError;
+inline int fail(int code, const std::string& msg) { g_lastError = msg; return code; }
+
+#define LM_HIP(expr)                                                                                              \
+    do {                                                                                                          \
+        hipError_t e_ = (expr);                                                                                   \
+        if (e_ != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// ---- handles: type tag in the top byte ---------------------------------------------------------------------
+enum HType : uint64_t { H_TEXTURE = 1, H_MATERIAL = 2, H_PRIMITIVE = 3, H_MESH = 4, H_SCENE = 5, H_INSTANCE = 6 };
+inline lumen_mi_handle mkh(HType t, size_t idx) { return ((uint64_t)t << 56) | (uint64_t)(idx + 1); }
+inline bool unh(lumen_mi_handle h, HType t, size_t n, size_t& idx) { if ((h >> 56) != (uint64_t)t) return false; idx = (size_t)(h & 0x00ffffffffffffffull); if (idx == 0 || idx > n) return false; idx--; return true; }
+
+struct Vertex48 { float pos[3]; float uv[2]; float normal[3]; float tangent[4]; };
+static_assert(sizeof(Vertex48) == 48, "Vertex layout (ModelStructs.h:21-28)");
+
+struct Texture { uint32_t w, h; bool srgb; std::vector<uint32_t> px; };
+struct Material { LmDevMaterial dev; float emissiveColor[3]; };
+struct Primitive { std::vector<Vertex48> verts; std::vector<uint32_t> idx; size_t material; std::vector<uint8_t> emissive; uint32_t numLights = 0; bool containEmissive = false; };
+struct Mesh { std::vector<size_t> prims; };
+struct Instance { size_t scene; size_t mesh; float M[16]; int mode; float radiance[3]; float scale; long overrideMaterial; std::vector<uint32_t> entries; };
+struct Scene { std::vector<size_t> instances; };
+
+template <class T> struct DevBuf {
+    T* p = nullptr; size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        if (hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return 1;
+        cap = n; return 0;
+    }
+    int upload(const std::vector<T>& v, hipStream_t s) {
+        if (ensure(v.size())) return 1;
+        if (!v.empty() && hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s) != hipSuccess) return 1;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+template <class T> struct HostBuf {                 // pinned staging memory for asynchronous uploads
+    T* p = nullptr; size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return 0;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        if (hipHostMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T), hipHostMallocDefault) != hipSuccess) return 1;
+        cap = n; return 0;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+// What a moving / edited scene rewrites every frame exists twice.  A frame reads one set; the next scene state is written into
+// the other one (instance table and light list by asynchronous copies from pinned memory, BVH boxes and Woop packets by the
+// refit kernels) on the wave stream, so frames keep overlapping while the scene changes.
+struct SceneSet {
+    DevBuf<LmNode4> nodes; DevBuf<LmWoop> woop; DevBuf<float> quant; DevBuf<LmEntry> entries; DevBuf<LmLight> lights; DevBuf<float> cdf;
+    HostBuf<LmEntry> hEntries; HostBuf<LmLight> hLights; HostBuf<float> hCdf;
+    hipEvent_t evUp = nullptr; bool upPending = false;      // the staging buffers are free again once this event has passed
+    uint64_t entriesVer = 0, geomVer = 0, lightsVer = 0;    // state of the host scene this set holds
+    void release() {
+        nodes.release(); woop.release(); quant.release(); entries.release(); lights.release(); cdf.release();
+        hEntries.release(); hLights.release(); hCdf.release();
+        if (evUp) { (void)hipEventDestroy(evUp); evUp = nullptr; }
+    }
+};
+
+inline float g_srgbLut[256];
+inline void initLut() { static bool d = false; if (d) return; for (int i = 0; i < 256; i++) { const double c = i / 255.0; g_srgbLut[i] = (float)(c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4)); } d = true; }
+
+inline uint32_t wangHash(uint32_t s) { s = (s ^ 61u) ^ (s >> 16); s *= 9u; s = s ^ (s >> 4); s *= 0x27d4eb2du; s = s ^ (s >> 15); return s; }
+inline void pack8(uint32_t& w, uint32_t shift, float v) { const uint32_t q = (uint32_t)(v * 255.f); w &= ~(255u << shift); w |= q << shift; }
+
+inline void mulPoint(const float* m, const float* v, float w, float* out)     // rows 0..2, operation order of sutil Matrix4x4 * float4
+{
+    out[0] = m[0] * v[0] + m[1] * v[1] + m[2] * v[2] + m[3] * w;
+    out[1] = m[4] * v[0] + m[5] * v[1] + m[6] * v[2] + m[7] * w;
+    out[2] = m[8] * v[0] + m[9] * v[1] + m[10] * v[2] + m[11] * w;
+}
+
+}  // namespace lmr
+using namespace lmr;            // internal header: only the host translation units of this library include it
+
+struct lumen_mi_renderer {
+    bool initialised = false;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t aux = nullptr;              // second stream: the indirect waves run beside ReSTIR (both depend only on the depth-0 G-buffer)
+    hipStream_t aux3 = nullptr;             // fourth stream: second ReSTIR visibility pass beside the second spatial pass
+    hipStream_t aux2 = nullptr;             // third stream: NEE shadow rays of wave d run beside the closest-hit launch of wave d+1
+    hipEvent_t evJoin = nullptr, evJoin2 = nullptr, evVis = nullptr, evVisDone = nullptr;
+    hipEvent_t evPick = nullptr;
+    int pickAhead = 1;                      // 1 on (default), 0 off, -1 only for windows under 1 Mpixel
+    int shadowOnWave = 0;                   // 1: NEE shadow rays on the wave stream (the path tail then has the third stream to itself); measured: 8 % slower for half-frame windows, equal elsewhere
+    hipEvent_t evFront = nullptr, evTemporal[2] = {nullptr, nullptr}, evTop = nullptr, evMerge[2] = {nullptr, nullptr};   // cross-frame pipelining (traceFrameAsync)
+    int framePar = 0;                       // parity of the frame being enqueued: selects the channel buffers and the counter block
+    bool fenceNeeded = true;                // main-stream work (uploads, memsets) the frame front on the aux stream must wait for
+    std::vector<hipEvent_t> evShade;        // per wave: shade_wave(d) done
+    int auxPriority = 1;                    // 1: highest priority for the aux streams, 0: default
+    int aux3Priority = 0;                   // the visibility / pick-ahead stream runs at default priority (pick-ahead must not starve the main chain)
+    bool overlap = true;
+    int traceBlocksMain = 8, traceBlocksAux = 8;
+    int numCU = 256;
+    const LmKernelTable* K = nullptr;
+    bool instrumented = false;
+    int tailBelow = -1;                     // waves expected to hold fewer rays than this run as one path-tail launch (0 = off,
+                                            // -1 = auto: 65536 for windows under 1 Mpixel, where the wave chain is the critical path, else 16384) ...
+    int tailLanes = 16;                     // ... with this many paths per wavefront
+    uint32_t* pinnedCounters[2] = {nullptr, nullptr}; hipEvent_t evCnt[2] = {nullptr, nullptr}; bool cntPending[2] = {false, false};
+    uint32_t estRays[LM_MAX_DEPTH + 1] = {0}; bool haveEst = false;     // rays per wave of the most recent frame that has been read back
+    int refillBelow = 40, refillVisibility = 32, refillPrimary = 0;      // lane-refill thresholds of the queue traversal kernels (tunable via LUMEN_MI_REFILL*)
+
+    lumen_mi_settings settings{};
+    lumen_mi_settings pending{};
+    std::mutex settingsMutex;
+    std::recursive_mutex frameMutex;        // every entry point that touches scene / frame state takes it (factories call each other)
+    std::atomic<int> waiters{0};            // callers queued on frameMutex: the render thread lets them in between two frames
+
+    std::vector<Texture> textures;
+    std::vector<Material> materials;
+    std::vector<Primitive> prims;
+    std::vector<Mesh> meshes;
+    std::vector<Scene> scenes;
+    std::vector<Instance> instances;
+    long activeScene = -1;
+    bool sceneDirty = true, texturesDirty = true, materialsDirty = true;
+    bool transformsDirty = false;           // only instance matrices changed since the last build: the BVH is refitted on the GPU
+    bool entriesDirty = false;              // emissive mode / radiance / override material of an instance changed: scene table + lights only
+    uint32_t refits = 0;                    // refits since the last full build
+    int refitEnabled = 1;                   // 0: every transform change triggers a full host rebuild
+
+    // camera
+    float camPos[3] = {0, 0, 0}, camRight[3] = {-1, 0, 0}, camUp[3] = {0, 1, 0}, camFwd[3] = {0, 0, 1};
+    float fovY = 90.f;
+    float prevCamWorld[16]; bool havePrev = false;
+
+    // window
+    uint32_t wx0 = 0, wy0 = 0, wx1 = 0, wy1 = 0; bool windowSet = false;
+    uint32_t ox0 = 0, oy0 = 0, ox1 = 0, oy1 = 0; bool tileSet = false;      // owned tile inside the window (global pixel coordinates)
+
+    // persistent state (WaveFrontRenderer members)
+    uint32_t frameCount = 0, blendCounter = 0;
+    int frameIndex = 0;
+    int gbufIndex = 0, lastGbuf = 0;        // physical G-buffer set of the frame being enqueued / of the last enqueued frame (3 sets)
+    DevBuf<int> dSwap;                      // ReSTIR swap-chain index lives on the device (LmFrame::swap)
+
+    // flattened scene (host)
+    std::vector<LmEntry> entries;
+    std::vector<size_t> entryPrim;          // table entry -> primitive
+    std::vector<float> worldTris;
+    std::vector<uint32_t> triEntry, triPrim;
+    LmBvh bvh;
+    std::vector<LmLight> lights; std::vector<float> cdf;
+    uint32_t totalEmissive = 0;
+    bool lightsDirty = true;
+
+    // device scene
+    SceneSet sset[2];                       // sset[sgen] is what the next frame's kernels read
+    int sgen = 0;
+    uint64_t entriesVer = 1, geomVer = 1, lightsVer = 1;      // versions of the host-side scene state (instance table, geometry, light list)
+    DevBuf<uint2> dTriId; DevBuf<uint32_t> dTriOrder;
+    DevBuf<float4> dVerts; DevBuf<uint32_t> dIndices; DevBuf<LmDevMaterial> dMaterials;
+    DevBuf<float4> dTriBox, dNodeBox; DevBuf<uint32_t> dLevelNodes, dRefitBounds;
+    DevBuf<int> dSpill; DevBuf<LmTexDesc> dTexDesc; DevBuf<uint32_t> dTexels; DevBuf<float> dLut;
+    LmScene dscene{};
+
+    // device frame
+    LmFrame fr{};
+    uint32_t allocN = 0, allocDepth = 0;
+    DevBuf<float4> dTailRay[6];             // ray queue of the path tail, double-buffered by frame parity (3 planes each)
+    hipEvent_t evTail = nullptr;
+    DevBuf<float4> dRay[6], dSh[3], dSh2[4], dGbuf[3], dProbe[3], dRes[5], dResC[5], dDirect[2], dIndirect[2], dCombined;
+    DevBuf<uint4> dHits; DevBuf<uint32_t> dMotion[2], dCounters; DevBuf<uchar4> dOutput; DevBuf<uint2> dBags;
+    uint32_t hostCounters[LM_CNT_WORDS] = {0};
+    bool countersValid = false;
+    uint32_t lastDepth = 0;
+    size_t lastLightCount = 0;
+
+    // timing
+    bool timing = false;
+    struct EvPair { hipEvent_t a, b; int cls; };
+    std::vector<EvPair> evPool; size_t evUsed = 0;
+    float classMs[5] = {0}; uint32_t classLaunches[5] = {0};
+    std::map<std::string, uint64_t> frameStats;
+
+    // render thread
+    std::thread renderThread; std::atomic<bool> stopFlag{false};
+
+    int traceGrid() const { return numCU * 8; }
+    int gridFor(uint32_t n, int perCU) const { const int full = (int)((n + 255u) / 256u); return std::max(1, std::min(full, numCU * perCU)); }
+};
+
+// frame mutex with a waiter count: std::mutex is not fair, and the render thread re-acquires it back to back
+struct ApiLock {
+    lumen_mi_renderer* r;
+    explicit ApiLock(lumen_mi_renderer* r_) : r(r_) { r->waiters.fetch_add(1); r->frameMutex.lock(); r->waiters.fetch_sub(1); }
+    ~ApiLock() { r->frameMutex.unlock(); }
+    ApiLock(const ApiLock&) = delete; ApiLock& operator=(const ApiLock&) = delete;
+};
+
+namespace lmr {
+
+using R = lumen_mi_renderer;
+
+// scene.cpp
+void findEmissives(const R* r, Primitive& p);
+int flatten(R* r);
+int syncScene(R* r, hipStream_t su);
+int uploadResources(R* r);
+int buildLights(R* r);
+// frame.cpp
+int ensureFrameBuffers(R* r);
+int traceFrameAsync(R* r);
+int syncAndCollect(R* r);
+
+}  // namespace lmr

@@ -1,0 +1,345 @@
+// scene.cpp — host side of the scene: emissive classification, flattening into the scene data table + world-space triangle soup,
+// BVH build and upload, the double-buffered scene sets (edits / GPU refit), resource upload and the light list.
+// Reference: PTScene.cpp:74-156, PTMeshInstance.cpp:123-178, LightDataBuffer.cpp:37-125, GPUDataBufferKernels.cu:9-186.
+#include "renderer_state.h"
+
+namespace lmr {
+
+// ---- host texture fetch (light-list build only; same definition as the device fetch) -------------------------
+void texel(const Texture& t, int x, int y, float out[4])
+{
+    const uint32_t p = t.px[(size_t)y * t.w + x];
+    const uint32_t r = p & 255u, g = (p >> 8) & 255u, b = (p >> 16) & 255u, a = p >> 24;
+    if (t.srgb) { out[0] = g_srgbLut[r]; out[1] = g_srgbLut[g]; out[2] = g_srgbLut[b]; } else { out[0] = (float)r / 255.0f; out[1] = (float)g / 255.0f; out[2] = (float)b / 255.0f; }
+    out[3] = (float)a / 255.0f;
+}
+int wrapi(int i, int n) { const int m = i % n; return m < 0 ? m + n : m; }
+void tex2D(const R* r, int id, float u, float v, float out[4])
+{
+    if (id < 0) { out[0] = out[1] = out[2] = out[3] = 0.f; return; }
+    const Texture& t = r->textures[id];
+    if (t.w == 1 && t.h == 1) { texel(t, 0, 0, out); return; }
+    const float x = u * (float)t.w - 0.5f, y = v * (float)t.h - 0.5f;
+    const float fx0 = floorf(x), fy0 = floorf(y);
+    const float ax = x - fx0, ay = y - fy0;
+    const int x0 = wrapi((int)fx0, (int)t.w), y0 = wrapi((int)fy0, (int)t.h);
+    const int x1 = wrapi(x0 + 1, (int)t.w), y1 = wrapi(y0 + 1, (int)t.h);
+    float t00[4], t10[4], t01[4], t11[4];
+    texel(t, x0, y0, t00); texel(t, x1, y0, t10); texel(t, x0, y1, t01); texel(t, x1, y1, t11);
+    for (int k = 0; k < 4; k++) {
+        const float a = t00[k] + ax * (t10[k] - t00[k]);
+        const float b = t01[k] + ax * (t11[k] - t01[k]);
+        out[k] = a + ay * (b - a);
+    }
+}
+
+// FindEmissives — reference GPUEmissiveLookup.cu:13-109, gate WaveFrontRenderer.cpp:1192-1210
+void findEmissives(const R* r, Primitive& p)
+{
+    const Material& m = r->materials[p.material];
+    p.emissive.assign(p.idx.size() / 3, 0);
+    p.numLights = 0;
+    if (m.emissiveColor[0] == 0.f && m.emissiveColor[1] == 0.f && m.emissiveColor[2] == 0.f) { p.containEmissive = false; return; }
+    for (size_t b = 0; b + 2 < p.idx.size(); b += 3) {
+        const Vertex48 &v0 = p.verts[p.idx[b]], &v1 = p.verts[p.idx[b + 1]], &v2 = p.verts[p.idx[b + 2]];
+        constexpr float oneThird = 1.f / 3.f;
+        const float uvx = (v0.uv[0] + v1.uv[0] + v2.uv[0]) * oneThird, uvy = (v0.uv[1] + v1.uv[1] + v2.uv[1]) * oneThird;
+        float e[4] = {m.dev.emissive.x, m.dev.emissive.y, m.dev.emissive.z, m.dev.emissive.w};
+        if (m.dev.tex[4] >= 0) { float t[4]; tex2D(r, m.dev.tex[4], uvx, uvy, t); for (int k = 0; k < 4; k++) e[k] = e[k] * t[k]; }
+        if (e[0] > 0.0f || e[1] > 0.0f || e[2] > 0.0f) { p.emissive[b / 3] = 1; p.numLights++; }
+    }
+    p.containEmissive = p.numLights > 0;
+}
+
+// scene data table + world-space triangle soup + BVH — replaces PTScene/PTMeshInstance/OptixWrapper AS builds
+// Instance state changed (matrices, emissive mode / radiance, override material) but not the set of instances: refresh the
+// host copy of the scene data table; syncScene() carries it (and, if something moved, a BVH refit on the GPU, kernels.hip
+// "BVH refit") to the device.
+int refreshEntries(R* r)
+{
+    const Scene& sc = r->scenes[r->activeScene];
+    for (size_t ii : sc.instances) {
+        const Instance& mi = r->instances[ii];
+        const std::vector<size_t>& prims = r->meshes[mi.mesh].prims;
+        for (size_t k = 0; k < mi.entries.size() && k < prims.size(); k++) {
+            LmEntry& e = r->entries[mi.entries[k]];
+            memcpy(e.m, mi.M, sizeof e.m);
+            e.material = (uint32_t)(mi.overrideMaterial >= 0 ? (size_t)mi.overrideMaterial : r->prims[prims[k]].material);
+            e.mode = (uint32_t)mi.mode;
+            e.emissive = make_float4(mi.radiance[0], mi.radiance[1], mi.radiance[2], mi.scale);
+        }
+    }
+    ++r->entriesVer;
+    if (r->transformsDirty) ++r->geomVer;
+    r->transformsDirty = false;
+    r->entriesDirty = false;
+    r->lightsDirty = true;
+    return 0;
+}
+
+// Bring the device scene up to the host state.  If the set the previous frames read is stale, the other set is written on
+// stream `su` and becomes current: it was last read by a frame at least two back, whose merge `su` has already waited for
+// (traceFrameAsync), so nothing in flight reads what is overwritten here.  No host synchronisation except for the reuse of
+// a staging buffer whose previous copy (two scene states ago) has not finished yet.
+int syncScene(R* r, hipStream_t su)
+{
+    if (r->sset[0].nodes.p == nullptr) return 0;                   // nothing built yet
+    SceneSet& C = r->sset[r->sgen];
+    if (C.entriesVer != r->entriesVer || C.geomVer != r->geomVer || C.lightsVer != r->lightsVer) {
+        SceneSet& T = r->sset[r->sgen ^ 1];
+        if (T.upPending) { LM_HIP(hipEventSynchronize(T.evUp)); T.upPending = false; }
+        if (!T.evUp) LM_HIP(hipEventCreateWithFlags(&T.evUp, hipEventDisableTiming));
+        bool copied = false;
+        if (T.entriesVer != r->entriesVer) {
+            const size_t n = r->entries.size();
+            if (T.hEntries.ensure(n) || T.entries.ensure(n)) return fail(LUMEN_MI_ERR_DEVICE, "scene table allocation failed");
+            if (n) { memcpy(T.hEntries.p, r->entries.data(), n * sizeof(LmEntry)); LM_HIP(hipMemcpyAsync(T.entries.p, T.hEntries.p, n * sizeof(LmEntry), hipMemcpyHostToDevice, su)); copied = true; }
+            T.entriesVer = r->entriesVer;
+        }
+        if (T.lightsVer != r->lightsVer) {
+            const size_t n = r->lights.size();
+            if (T.hLights.ensure(n) || T.hCdf.ensure(n) || T.lights.ensure(n) || T.cdf.ensure(n)) return fail(LUMEN_MI_ERR_DEVICE, "light list allocation failed");
+            if (n) {
+                memcpy(T.hLights.p, r->lights.data(), n * sizeof(LmLight)); memcpy(T.hCdf.p, r->cdf.data(), n * sizeof(float));
+                LM_HIP(hipMemcpyAsync(T.lights.p, T.hLights.p, n * sizeof(LmLight), hipMemcpyHostToDevice, su));
+                LM_HIP(hipMemcpyAsync(T.cdf.p, T.hCdf.p, n * sizeof(float), hipMemcpyHostToDevice, su));
+                copied = true;
+            }
+            T.lightsVer = r->lightsVer;
+        }
+        if (copied) { LM_HIP(hipEventRecord(T.evUp, su)); T.upPending = true; }
+        if (T.geomVer != r->geomVer) {
+            const LmKernelTable* K = r->K;
+            LmScene sc = r->dscene;
+            sc.nodes = T.nodes.p; sc.woop = T.woop.p; sc.quant = T.quant.p; sc.entries = T.entries.p;
+            const uint32_t nt = (uint32_t)r->bvh.order.size();
+            K->refit_tris(su, sc, nt, r->dTriBox.p, r->dRefitBounds.p);
+            K->refit_quant(su, r->dRefitBounds.p, T.quant.p);
+            for (size_t l = 0; l + 1 < r->bvh.levelStart.size(); l++) {
+                const uint32_t a = r->bvh.levelStart[l], b = r->bvh.levelStart[l + 1];
+                if (b > a) K->refit_level(su, sc, r->dLevelNodes.p + a, b - a, r->dTriBox.p, r->dNodeBox.p);
+            }
+            LM_HIP(hipGetLastError());
+            ++r->refits;
+            T.geomVer = r->geomVer;
+        }
+        r->sgen ^= 1;
+    }
+    const SceneSet& S = r->sset[r->sgen];
+    r->dscene.nodes = S.nodes.p; r->dscene.woop = S.woop.p; r->dscene.quant = S.quant.p; r->dscene.entries = S.entries.p;
+    r->dscene.lights = S.lights.p; r->dscene.cdf = S.cdf.p;
+    return 0;
+}
+
+int flatten(R* r)
+{
+    if (!r->sceneDirty) {
+        if (!r->transformsDirty && !r->entriesDirty) return 0;
+        if (r->refitEnabled && r->activeScene >= 0 && !r->entries.empty()) return refreshEntries(r);
+        r->sceneDirty = true;
+    }
+    if (r->activeScene < 0) return fail(LUMEN_MI_ERR_STATE, "no scene set (lumen_mi_set_scene)");
+    Scene& sc = r->scenes[r->activeScene];
+    r->entries.clear(); r->entryPrim.clear(); r->worldTris.clear(); r->triEntry.clear(); r->triPrim.clear();
+    // vertex / index pools: one slot range per primitive
+    std::vector<uint32_t> vertBase(r->prims.size()), idxBase(r->prims.size());
+    std::vector<float4> verts; std::vector<uint32_t> indices;
+    for (size_t p = 0; p < r->prims.size(); p++) {
+        vertBase[p] = (uint32_t)(verts.size() / 3); idxBase[p] = (uint32_t)indices.size();
+        for (const Vertex48& v : r->prims[p].verts) {
+            verts.push_back(make_float4(v.pos[0], v.pos[1], v.pos[2], v.uv[0]));
+            verts.push_back(make_float4(v.uv[1], v.normal[0], v.normal[1], v.normal[2]));
+            verts.push_back(make_float4(v.tangent[0], v.tangent[1], v.tangent[2], v.tangent[3]));
+        }
+        indices.insert(indices.end(), r->prims[p].idx.begin(), r->prims[p].idx.end());
+    }
+    for (size_t ii : sc.instances) {
+        Instance& mi = r->instances[ii];
+        mi.entries.clear();
+        for (size_t p : r->meshes[mi.mesh].prims) {
+            LmEntry e;
+            memcpy(e.m, mi.M, sizeof e.m);
+            e.vertBase = vertBase[p]; e.idxBase = idxBase[p];
+            e.material = (uint32_t)(mi.overrideMaterial >= 0 ? (size_t)mi.overrideMaterial : r->prims[p].material);
+            e.mode = (uint32_t)mi.mode;
+            e.emissive = make_float4(mi.radiance[0], mi.radiance[1], mi.radiance[2], mi.scale);
+            const uint32_t entryIdx = (uint32_t)r->entries.size();
+            mi.entries.push_back(entryIdx);
+            r->entries.push_back(e);
+            r->entryPrim.push_back(p);
+            const Primitive& pr = r->prims[p];
+            for (size_t t = 0; t + 2 < pr.idx.size(); t += 3) {
+                for (int k = 0; k < 3; k++) {
+                    float w[3];
+                    mulPoint(e.m, pr.verts[pr.idx[t + k]].pos, 1.f, w);
+                    r->worldTris.push_back(w[0]); r->worldTris.push_back(w[1]); r->worldTris.push_back(w[2]);
+                }
+                r->triEntry.push_back(entryIdx); r->triPrim.push_back((uint32_t)(t / 3));
+            }
+        }
+    }
+    const uint32_t nt = (uint32_t)r->triEntry.size();
+    lm_build_bvh(r->worldTris.data(), nt, &r->bvh);
+    if (r->bvh.maxStack > LM_STACK_DEPTH) return fail(LUMEN_MI_ERR_STATE, "BVH needs a deeper traversal stack than LM_STACK_DEPTH");
+    std::vector<uint2> triId(nt);
+    for (uint32_t s = 0; s < nt; s++) triId[s] = make_uint2(r->triEntry[r->bvh.order[s]], r->triPrim[r->bvh.order[s]]);
+    hipStream_t st = r->stream;
+    // (stream order puts these copies behind the merge of the last frame, which has joined every other stream; the host then
+    // waits for them, so both scene sets are idle and identical afterwards)
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "stream sync failed");
+    for (SceneSet& S : r->sset) if (S.upPending) { (void)hipEventSynchronize(S.evUp); S.upPending = false; }
+    std::vector<float> quant = {r->bvh.qmin[0], r->bvh.qmin[1], r->bvh.qmin[2], r->bvh.qstep[0], r->bvh.qstep[1], r->bvh.qstep[2], r->bvh.pad, 0.f};
+    ++r->entriesVer; ++r->geomVer;
+    for (SceneSet& S : r->sset) {
+        if (S.nodes.upload(r->bvh.nodes4, st) || S.woop.upload(r->bvh.woop, st) || S.entries.upload(r->entries, st) || S.quant.upload(quant, st))
+            return fail(LUMEN_MI_ERR_DEVICE, "scene upload failed (hipMalloc/hipMemcpy)");
+        S.entriesVer = r->entriesVer; S.geomVer = r->geomVer;
+    }
+    if (r->dTriId.upload(triId, st) || r->dTriOrder.upload(r->bvh.order, st) || r->dVerts.upload(verts, st) || r->dIndices.upload(indices, st))
+        return fail(LUMEN_MI_ERR_DEVICE, "scene upload failed (hipMalloc/hipMemcpy)");
+    {
+        std::vector<uint32_t> bounds = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
+        if (r->dRefitBounds.upload(bounds, st) || r->dLevelNodes.upload(r->bvh.levelNodes, st) ||
+            r->dTriBox.ensure(2 * (size_t)nt + 2) || r->dNodeBox.ensure(2 * r->bvh.nodes4.size()))
+            return fail(LUMEN_MI_ERR_DEVICE, "refit buffer allocation failed");
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "scene upload sync failed");
+    if (r->dSpill.ensure((size_t)4 * r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS)))      // one area per stream
+        return fail(LUMEN_MI_ERR_DEVICE, "stack spill allocation failed");
+    r->dscene.spill = r->dSpill.p;
+    r->dscene.triId = r->dTriId.p; r->dscene.triOrder = r->dTriOrder.p;
+    r->dscene.verts = r->dVerts.p; r->dscene.indices = r->dIndices.p;
+    {
+        const SceneSet& S = r->sset[r->sgen];
+        r->dscene.nodes = S.nodes.p; r->dscene.woop = S.woop.p; r->dscene.quant = S.quant.p; r->dscene.entries = S.entries.p;
+    }
+    r->sceneDirty = false;
+    r->transformsDirty = false;
+    r->entriesDirty = false;
+    r->lightsDirty = true;
+    return 0;
+}
+
+int uploadResources(R* r)
+{
+    hipStream_t st = r->stream;
+    if (r->texturesDirty) {
+        std::vector<LmTexDesc> desc; std::vector<uint32_t> texels;
+        for (const Texture& t : r->textures) { desc.push_back(LmTexDesc{(uint32_t)texels.size(), t.w, t.h, t.srgb ? 1u : 0u}); texels.insert(texels.end(), t.px.begin(), t.px.end()); }
+        std::vector<float> lut(g_srgbLut, g_srgbLut + 256);
+        if (r->dTexDesc.upload(desc, st) || r->dTexels.upload(texels, st) || r->dLut.upload(lut, st)) return fail(LUMEN_MI_ERR_DEVICE, "texture upload failed");
+        if (hipStreamSynchronize(st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "texture upload sync failed");
+        r->dscene.texDesc = r->dTexDesc.p; r->dscene.texels = r->dTexels.p; r->dscene.srgbLut = r->dLut.p;
+        r->texturesDirty = false;
+    }
+    if (r->materialsDirty) {
+        std::vector<LmDevMaterial> m;
+        for (const Material& x : r->materials) m.push_back(x.dev);
+        if (r->dMaterials.upload(m, st)) return fail(LUMEN_MI_ERR_DEVICE, "material upload failed");
+        if (hipStreamSynchronize(st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "material upload sync failed");
+        r->dscene.materials = r->dMaterials.p;
+        r->materialsDirty = false;
+    }
+    return 0;
+}
+
+// light list + CDF — reference LightDataBuffer.cpp:37-125, GPUDataBufferKernels.cu:9-186 (launch shape
+// CPUDataBufferKernels.cu:35-56), ReSTIRKernels.cu:49-130 (sort by mean radiance, weights, inclusive scan).
+// Built on the host and cached while the scene is unchanged (the reference rebuilds both every frame).
+int buildLights(R* r)
+{
+    if (!r->lightsDirty) return 0;
+    struct LID { uint32_t tableIndex, numTriangles, numEmissives; };
+    std::vector<LID> lid;
+    uint32_t numEmissivePrims = 0, total = 0;
+    float avg = 0;
+    const Scene& sc = r->scenes[r->activeScene];
+    for (size_t ii : sc.instances) {
+        const Instance& mi = r->instances[ii];
+        bool meshEmissive = false;
+        for (size_t p : r->meshes[mi.mesh].prims) meshEmissive |= r->prims[p].containEmissive;
+        if (mi.mode != 1 && ((mi.mode == 0 && meshEmissive) || mi.mode == 2)) {
+            for (size_t k = 0; k < r->meshes[mi.mesh].prims.size(); k++) {
+                const Primitive& pr = r->prims[r->meshes[mi.mesh].prims[k]];
+                if (pr.containEmissive || mi.mode == 2) {
+                    const uint32_t numTriangles = (uint32_t)(pr.idx.size() / 3);
+                    avg = ((avg * (float)numEmissivePrims) + (float)numTriangles) / (float)(numEmissivePrims + 1);
+                    numEmissivePrims++;
+                    total += pr.numLights;
+                    lid.push_back(LID{mi.entries[k], numTriangles, pr.numLights});
+                }
+            }
+        }
+    }
+    const uint32_t bufferSize = 1000000u;                       // LightDataBuffer(1'000'000), WaveFrontRenderer.cpp:295
+    if (total > bufferSize) {
+        size_t keep = lid.size();
+        while (keep > 0) { total -= lid[keep - 1].numEmissives; keep--; if (total < bufferSize) break; }
+        lid.resize(keep);
+    }
+    const uint32_t avgTri = (uint32_t)roundf(avg);
+    const uint32_t gridH = (uint32_t)ceilf((float)avgTri / 64.f);
+    const uint32_t threadsY = gridH * 64u;
+    std::vector<LmLight> L;
+    for (const LID& d : lid) {
+        if (threadsY == 0) break;
+        const uint32_t perThread = (uint32_t)ceilf((float)d.numTriangles / (float)threadsY);
+        const LmEntry& e = r->entries[d.tableIndex];
+        const Primitive& pr = r->prims[r->entryPrim[d.tableIndex]];
+        const Material& mat = r->materials[e.material];
+        for (uint32_t ty = 0; ty < threadsY; ty++) {
+            const uint32_t start = ty * perThread;
+            if (!(start < d.numTriangles - 1u)) continue;      // reference behaviour: a slice that starts at the last triangle is dropped (GPUDataBufferKernels.cu:37)
+            const uint32_t num = (start + perThread) < d.numTriangles ? perThread : d.numTriangles - start;
+            for (uint32_t k = 0; k < num; k++) {
+                const uint32_t tri = start + k;
+                LmLight out; memset(&out, 0, sizeof out);       // reserved slot that is never set: zero light
+                if ((e.mode == 0u && pr.emissive[tri]) || e.mode == 2u) {
+                    const Vertex48 &v0 = pr.verts[pr.idx[tri * 3]], &v1 = pr.verts[pr.idx[tri * 3 + 1]], &v2 = pr.verts[pr.idx[tri * 3 + 2]];
+                    float p0[3], p1[3], p2[3];
+                    mulPoint(e.m, v0.pos, 1.f, p0); mulPoint(e.m, v1.pos, 1.f, p1); mulPoint(e.m, v2.pos, 1.f, p2);
+                    constexpr float oneThird = 1.f / 3.f;
+                    const float uvx = (v0.uv[0] + v1.uv[0] + v2.uv[0]) * oneThird, uvy = (v0.uv[1] + v1.uv[1] + v2.uv[1]) * oneThird;
+                    float em[4] = {0, 0, 0, 0};
+                    if (e.mode == 0u) {
+                        float t[4]; tex2D(r, mat.dev.tex[4], uvx, uvy, t);
+                        const float me[4] = {mat.dev.emissive.x * e.emissive.w, mat.dev.emissive.y * e.emissive.w, mat.dev.emissive.z * e.emissive.w, mat.dev.emissive.w * e.emissive.w};
+                        for (int q = 0; q < 4; q++) em[q] = t[q] * me[q];
+                    } else {
+                        em[0] = e.emissive.x * e.emissive.w; em[1] = e.emissive.y * e.emissive.w; em[2] = e.emissive.z * e.emissive.w; em[3] = e.emissive.w * e.emissive.w;
+                    }
+                    if (em[0] > 0.f || em[1] > 0.f || em[2] > 0.f) {
+                        const float nl[3] = {(v0.normal[0] + v1.normal[0] + v2.normal[0]) * oneThird, (v0.normal[1] + v1.normal[1] + v2.normal[1]) * oneThird,
+                                             (v0.normal[2] + v1.normal[2] + v2.normal[2]) * oneThird};
+                        float nw[3];
+                        mulPoint(e.m, nl, 0.f, nw);
+                        const float inv = 1.0f / sqrtf(nw[0] * nw[0] + nw[1] * nw[1] + nw[2] * nw[2]);
+                        nw[0] *= inv; nw[1] *= inv; nw[2] *= inv;
+                        const float a[3] = {p0[0] - p1[0], p0[1] - p1[1], p0[2] - p1[2]}, b[3] = {p0[0] - p2[0], p0[1] - p2[1], p0[2] - p2[2]};
+                        const float cx = (a[1] * b[2] - b[1] * a[2]), cy = (a[0] * b[2] - b[0] * a[2]), cz = (a[0] * b[1] - b[0] * a[1]);
+                        const float area = sqrtf(cx * cx + cy * cy + cz * cz) / 2.0f;
+                        out.a = make_float4(p0[0], p0[1], p0[2], p1[0]);
+                        out.b = make_float4(p1[1], p1[2], p2[0], p2[1]);
+                        out.c = make_float4(p2[2], nw[0], nw[1], nw[2]);
+                        out.d = make_float4(em[0], em[1], em[2], area);
+                    }
+                }
+                L.push_back(out);
+            }
+        }
+    }
+    auto key = [](const LmLight& l) { return (l.d.x + l.d.y + l.d.z) / 3.f; };
+    std::stable_sort(L.begin(), L.end(), [&](const LmLight& a, const LmLight& b) { return key(a) < key(b); });
+    r->cdf.resize(L.size());
+    double acc = 0;
+    for (size_t i = 0; i < L.size(); i++) { acc += (double)key(L[i]); r->cdf[i] = (float)acc; }
+    r->lights.swap(L);
+    r->totalEmissive = total;
+    ++r->lightsVer;                                             // syncScene() uploads the list
+    r->dscene.numLights = (uint32_t)r->lights.size();
+    r->dscene.cdfSum = r->cdf.empty() ? 0.f : r->cdf.back();
+    r->lightsDirty = false;
+    return 0;
+}
+
+}  // namespace lmr

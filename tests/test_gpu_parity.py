@@ -672,7 +672,7 @@ def test_stitched_tiles_equal_the_single_gpu_frame(n_ranks):
 
 def test_full_size_moving_scene_async_equals_serial():
     """Refit, scene-table refresh and light rebuild between asynchronously enqueued full-size frames.  The scene exists twice on
-    the device: an edit is written into the set no frame in flight reads (renderer.cpp SceneSet), on the wave stream.  The edit
+    the device: an edit is written into the set no frame in flight reads (scene.cpp syncScene), on the wave stream.  The edit
     pattern is irregular (moves, a frame without edits, an emissive-only edit, a material-only edit), so every combination of a
     stale / current set is crossed.  Compared with the serial schedule on a host-rebuilt BVH."""
     from lumenrenderer_amd.scenes import sponza_standin
