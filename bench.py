@@ -227,7 +227,7 @@ def main():
         rays_per_frame = rays_last_all * spp
         ms_per_step = dt * 1e3 / args.steps
         value = rays_per_frame / (ms_per_step * 1e-3) / 1e6
-        # roofline of the dominant kernel (closest-hit BVH2 traversal) on rank 0: algorithmic bytes / measured device time
+        # roofline of the dominant kernel (closest-hit traversal) on rank 0: algorithmic bytes / measured device time
         nodes_c = ci[20] * (c[0] / max(1, ci[0] + ci[1] + ci[2]))       # share of instrumented counts attributed to closest-hit rays
         tris_c = ci[21] * (c[0] / max(1, ci[0] + ci[1] + ci[2]))
         alg = algorithmic_bytes_closest(c[0], nodes_c, tris_c)              # per TraceFrame (all `depth` closest-hit launches)

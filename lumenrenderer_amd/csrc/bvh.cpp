@@ -1,8 +1,8 @@
-// bvh.cpp — host-side BVH2 builder (binned SAH) and Woop triangle packets.
+// bvh.cpp — host-side BVH builder: binned-SAH binary tree collapsed to the 4-wide tree the kernels read, Woop triangle packets.
 //
 // Replaces the reference's two opaque calls OptixWrapper::BuildGeometryAccelerationStructure /
 // BuildInstanceAccelerationStructure (LumenPT/src/Framework/OptixWrapper.cpp:46-131): instance transforms are
-// baked, the whole scene becomes ONE BVH2 over world-space triangles (the reference rebuilds its instance AS on
+// baked, the whole scene becomes ONE tree over world-space triangles (the reference rebuilds its instance AS on
 // every transform change anyway, PTScene.cpp:145-153).  Node boxes are padded by 2^-15 * (largest |coordinate|)
 // so that box tests are conservative with respect to the fp32 Woop triangle test (DESIGN.md "Traversal").
 #include "bvh.h"

@@ -1,6 +1,6 @@
 // kernels.hip — hand-written HIP kernels (gfx950) of the wavefront path tracer.
 //
-// One frame = primary-ray generation, then per wave: closest-hit BVH2 traversal, surface extraction + shading
+// One frame = primary-ray generation, then per wave: closest-hit traversal of the 4-wide BVH, surface extraction + shading
 // (ReSTIR DI at depth 0, CDF next-event estimation afterwards), Russian-roulette continuation with wavefront
 // ballot/prefix-sum compaction, any-hit shadow rays, and finally channel merge + output.  Behaviour follows the
 // reference kernels cited at each function (paths relative to /root/reference/Lumen_Engine/LumenPT/src);
@@ -93,305 +93,7 @@ __device__ __forceinline__ float4 lm_mul_m34(const float* m, const lf3& v, float
     return r;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// BVH2 traversal with Woop unit-triangle test.  Per-lane stack lives in LDS, interleaved by lane (bank-conflict free).
-// Closest hit: minimum t in (tmin, tmax); equal t -> lower global triangle index (order independent).
-// ---------------------------------------------------------------------------------------------------------------------
-struct LmHit { float t, u, v; uint32_t slot; };
-
-// Per-lane traversal stack: the first LM_STACK_LDS entries live in LDS ([level][lane]: one bank per lane), deeper entries
-// (rare) spill to a per-thread global array, so that the LDS footprint (16 KB per 256-thread block) does not cap occupancy.
-typedef __attribute__((address_space(3))) int lm_lds_int;      // explicit LDS pointer: ds_read / ds_write, never flat accesses
-struct LmStack { lm_lds_int* lds; int* spill; };
-#if LM_INSTRUMENT
-__device__ unsigned long long g_lmPushes[2];       // counting build: [0] stack pushes, [1] of which went to the global spill area
-#endif
-__device__ __forceinline__ void lm_push(const LmStack& st, int& sp, int v)
-{
-#if LM_INSTRUMENT
-    atomicAdd(&g_lmPushes[sp < LM_STACK_LDS ? 0 : 1], 1ull);
-#endif
-    if (sp < LM_STACK_LDS) st.lds[sp * LM_BLOCK] = v; else st.spill[sp - LM_STACK_LDS] = v;
-    sp++;
-}
-__device__ __forceinline__ int lm_pop(const LmStack& st, int& sp)
-{
-    --sp;
-    // the LDS slot is read unconditionally (clamped index) and the spill slot only under a branch: a select between the
-    // two POINTERS would turn every pop into a flat load, which is slower than ds_read and waits on both counters
-    int v = st.lds[min(sp, LM_STACK_LDS - 1) * LM_BLOCK];
-    if (sp >= LM_STACK_LDS) v = st.spill[sp - LM_STACK_LDS];
-    return v;
-}
-__device__ __forceinline__ LmStack lm_make_stack(int* s_stack, const LmScene& sc)
-{
-    LmStack st;
-    st.lds = (lm_lds_int*)(s_stack + threadIdx.x);
-    st.spill = sc.spill + (size_t)(blockIdx.x * LM_BLOCK + threadIdx.x) * (LM_STACK_DEPTH - LM_STACK_LDS);
-    return st;
-}
-
-// The whole 48-byte packet is fetched up front (three independent 16-byte loads, one wait) instead of row by row behind
-// the early-outs: a leaf visit then costs one memory round trip per triangle, not up to three.
-__device__ __forceinline__ bool lm_woop(const LmWoop* __restrict__ woop, uint32_t slot, const lf3& o, const lf3& d,
-                                        float tmin, float tmax, float& t, float& u, float& v)
-{
-    float4 r2 = woop[slot].r2, r0 = woop[slot].r0, r1 = woop[slot].r1;
-    asm volatile("" : "+v"(r0.x), "+v"(r1.x), "+v"(r2.x));     // keep the three loads together (the compiler would sink two behind the early-outs)
-    const float Oz = fmaf(r2.x, o.x, fmaf(r2.y, o.y, fmaf(r2.z, o.z, r2.w)));
-    const float Dz = fmaf(r2.x, d.x, fmaf(r2.y, d.y, r2.z * d.z));
-    t = -Oz / Dz;
-    if (!(t > tmin && t < tmax)) return false;
-    const float Ox = fmaf(r0.x, o.x, fmaf(r0.y, o.y, fmaf(r0.z, o.z, r0.w)));
-    const float Dx = fmaf(r0.x, d.x, fmaf(r0.y, d.y, r0.z * d.z));
-    u = fmaf(t, Dx, Ox);
-    if (!(u >= 0.0f)) return false;
-    const float Oy = fmaf(r1.x, o.x, fmaf(r1.y, o.y, fmaf(r1.z, o.z, r1.w)));
-    const float Dy = fmaf(r1.x, d.x, fmaf(r1.y, d.y, r1.z * d.z));
-    v = fmaf(t, Dy, Oy);
-    if (!(v >= 0.0f)) return false;
-    return u + v <= 1.0f;
-}
-
-__device__ __forceinline__ float lm_safe_rcp(float d)
-{
-    const float ooeps = 1e-20f;
-    return 1.0f / (fabsf(d) > ooeps ? d : copysignf(ooeps, d));
-}
-
-// One step through a 4-wide node: slab-test the four quantised child boxes against [tmin, hitT], continue with the nearest
-// hit child and push the others far-to-near (closest-hit) or in node order (any-hit).  Returns the next node / leaf
-// reference, or LM_REF_NONE when the stack is empty.  `boxes` counts child boxes tested (instrumented build).
-#ifndef LM_ANY_ORDERED
-#define LM_ANY_ORDERED 0      // 1: any-hit queries also visit children near to far (finds close occluders sooner, costs the sort)
-#endif
-struct LmRayQ { float ax, ay, az, bx, by, bz; };      // t = q * a + b per axis (dequantisation folded into the slab test)
-__device__ __forceinline__ void lm_slab(const uint4& q, const LmRayQ& r, float tmin, float hitT, uint32_t& key)
-{
-    const float lox = fmaf((float)(q.x & 0xffffu), r.ax, r.bx), hix = fmaf((float)(q.x >> 16), r.ax, r.bx);
-    const float loy = fmaf((float)(q.y & 0xffffu), r.ay, r.by), hiy = fmaf((float)(q.y >> 16), r.ay, r.by);
-    const float loz = fmaf((float)(q.z & 0xffffu), r.az, r.bz), hiz = fmaf((float)(q.z >> 16), r.az, r.bz);
-    const float tn = fmaxf(fmaxf(fminf(lox, hix), fminf(loy, hiy)), fmaxf(fminf(loz, hiz), tmin));
-    const float tf = fminf(fminf(fmaxf(lox, hix), fmaxf(loy, hiy)), fminf(fmaxf(loz, hiz), hitT));
-    key = (tn <= tf && (int)q.w != LM_REF_NONE) ? f2u(tn) : 0xffffffffu;       // tn >= tmin >= 0: the bit pattern orders like the value
-}
-__device__ __forceinline__ void lm_cex(uint32_t& ka, int& ra, uint32_t& kb, int& rb)
-{
-    const bool sw = kb < ka;
-    const uint32_t k0 = min(ka, kb), k1 = max(ka, kb);
-    const int r0 = sw ? rb : ra, r1 = sw ? ra : rb;
-    ka = k0; kb = k1; ra = r0; rb = r1;
-}
-template <bool ANY>
-__device__ __forceinline__ int lm_node_step(const LmScene& sc, int cur, const LmRayQ& rq, float tmin, float hitT, const LmStack& stack, int& sp)
-{
-    const uint4* nd = sc.nodes[cur].c;
-    const uint4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
-    uint32_t k0, k1, k2, k3;
-    lm_slab(q0, rq, tmin, hitT, k0); lm_slab(q1, rq, tmin, hitT, k1); lm_slab(q2, rq, tmin, hitT, k2); lm_slab(q3, rq, tmin, hitT, k3);
-    int r0 = (int)q0.w, r1 = (int)q1.w, r2 = (int)q2.w, r3 = (int)q3.w;
-    if (!ANY || LM_ANY_ORDERED) {     // order the children by entry distance (a 5-comparator network; misses carry the largest key)
-        lm_cex(k0, r0, k1, r1); lm_cex(k2, r2, k3, r3); lm_cex(k0, r0, k2, r2); lm_cex(k1, r1, k3, r3); lm_cex(k1, r1, k2, r2);
-        if (k0 == 0xffffffffu) return sp == 0 ? LM_REF_NONE : lm_pop(stack, sp);
-        if (k3 != 0xffffffffu) lm_push(stack, sp, r3);
-        if (k2 != 0xffffffffu) lm_push(stack, sp, r2);
-        if (k1 != 0xffffffffu) lm_push(stack, sp, r1);
-        return r0;
-    }
-    int next = LM_REF_NONE;
-    if (k3 != 0xffffffffu) next = r3;
-    if (k2 != 0xffffffffu) { if (next != LM_REF_NONE) lm_push(stack, sp, next); next = r2; }
-    if (k1 != 0xffffffffu) { if (next != LM_REF_NONE) lm_push(stack, sp, next); next = r1; }
-    if (k0 != 0xffffffffu) { if (next != LM_REF_NONE) lm_push(stack, sp, next); next = r0; }
-    if (next == LM_REF_NONE) return sp == 0 ? LM_REF_NONE : lm_pop(stack, sp);
-    return next;
-}
-
-template <bool ANY>
-__device__ __forceinline__ bool lm_traverse(const LmScene& sc, const lf3& o, const lf3& d, float tmin, float tmax,
-                                            const LmStack& stack, LmHit& hit, uint32_t* cnt)
-{
-    const float idx = lm_safe_rcp(d.x), idy = lm_safe_rcp(d.y), idz = lm_safe_rcp(d.z);
-    // node boxes are 16-bit fixed point: world = qmin + q * qstep, so t = q * (qstep * idir) + (qmin - o) * idir
-    LmRayQ rq;
-    rq.ax = sc.quant[3] * idx; rq.ay = sc.quant[4] * idy; rq.az = sc.quant[5] * idz;
-    rq.bx = (sc.quant[0] - o.x) * idx; rq.by = (sc.quant[1] - o.y) * idy; rq.bz = (sc.quant[2] - o.z) * idz;
-    float hitT = tmax;
-    uint32_t hitOrder = 0xffffffffu;
-    bool found = false;
-    int sp = 0;
-    int cur = 0;
-#if LM_INSTRUMENT
-    uint32_t nNodes = 0, nTris = 0;
-#endif
-    for (;;) {
-        while (cur >= 0 && cur != LM_REF_NONE) {
-#if LM_INSTRUMENT
-            for (int k = 0; k < 4; k++) nNodes += (int)sc.nodes[cur].c[k].w != LM_REF_NONE;      // child boxes tested
-#endif
-            cur = lm_node_step<ANY>(sc, cur, rq, tmin, hitT, stack, sp);
-        }
-        if (cur == 0x7fffffff) break;
-        // leaf
-        const uint32_t leaf = (uint32_t)(~cur);
-        const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
-        for (uint32_t k = 0; k < count; k++) {
-            float t, u, v;
-#if LM_INSTRUMENT
-            nTris++;
-#endif
-            if (lm_woop(sc.woop, first + k, o, d, tmin, tmax, t, u, v)) {
-                if (ANY) { found = true; break; }
-                const uint32_t order = sc.triOrder[first + k];
-                if (t < hitT || (t == hitT && found && order < hitOrder)) {
-                    hitT = t; hitOrder = order; found = true;
-                    hit.t = t; hit.u = u; hit.v = v; hit.slot = first + k;
-                }
-            }
-        }
-        if (ANY && found) break;
-        if (sp == 0) break;
-        cur = lm_pop(stack, sp);
-    }
-#if LM_INSTRUMENT
-    atomicAdd((unsigned long long*)(cnt + LM_CNT_NODES), (unsigned long long)nNodes);
-    atomicAdd((unsigned long long*)(cnt + LM_CNT_TRIS), (unsigned long long)nTris);
-#endif
-    return found;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Queue traversal with per-lane ray replacement ("persistent threads").  Wavefront w of the launch owns the 64-ray groups
-// w, w + W, w + 2W, ... of the queue (W = wavefronts in the grid; no atomics: one address retires only ~88 returning atomics
-// per microsecond).  When fewer than `refillBelow` lanes of a wave are still traversing, the others take the next rays of
-// the wave's groups, so incoherent rays of very different length do not leave most of the 64 lanes idle; refillBelow <= 1
-// keeps a wave on one group at a time (best for coherent rays: an 8x8 pixel bundle stays together).
-// `done(rayIndex, found, hit)` runs once per ray.  Results are identical to lm_traverse (same tests, same tie-break).
-// ---------------------------------------------------------------------------------------------------------------------
-#ifndef LM_PRIO_RAYS
-#define LM_PRIO_RAYS 1048576u
-#endif
-#ifndef LM_NODE_EXIT_FRAC
-#define LM_NODE_EXIT_FRAC 3      // leave the node loop when fewer than a third of the round's lanes still descend (0: use the absolute LM_NODE_EXIT)
-#endif
-#ifndef LM_NODE_EXIT
-#define LM_NODE_EXIT 14
-#endif
-template <bool ANY, class Fetch, class Done>
-__device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, int refillBelow, const LmStack& stack,
-                                               uint32_t* cnt, Fetch fetch, Done done)
-{
-    // A small queue cannot fill the machine: its launch time is one wave's dependent chain, which stretches when the wave
-    // shares its SIMD with VALU-bound kernels of the other streams.  Such waves ask the SIMD arbiter for priority.
-    if (n < LM_PRIO_RAYS) __builtin_amdgcn_s_setprio(3);
-    const uint32_t lane = lm_lane();
-    const uint32_t W = gridDim.x * (LM_BLOCK / 64u);
-    uint32_t group = blockIdx.x * (LM_BLOCK / 64u) + (threadIdx.x >> 6);      // wave-uniform
-    uint32_t used = 0;                                                     // rays already handed out from `group` (wave-uniform)
-    bool active = false;
-    uint32_t rayIdx = 0;
-    lf3 o = v3(0.f), d = v3(0.f);
-    float tmin = 0.f, tmax = 0.f, hitT = 0.f;
-    LmRayQ rq = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    uint32_t hitOrder = 0xffffffffu;
-    bool found = false;
-    int sp = 0, cur = 0;
-    LmHit hit; hit.t = -1.f; hit.u = 0.f; hit.v = 0.f; hit.slot = 0;
-#if LM_INSTRUMENT
-    uint32_t nNodes = 0, nTris = 0, raySteps = 0;
-#endif
-    for (;;) {
-        // ---- refill idle lanes from the wave's groups
-        unsigned long long need = __ballot(!active);
-        bool drained = (unsigned long long)group * 64ull >= (unsigned long long)n;
-        while (need != 0ull && !drained) {
-            const uint32_t base = group * 64u;
-            const uint32_t avail = min(64u, n - base) - used;
-            const uint32_t want = (uint32_t)__popcll(need);
-            const uint32_t give = min(want, avail);
-            const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-            if (!active && rank < give) {
-                rayIdx = base + used + rank;
-                fetch(rayIdx, o, d, tmin, tmax);
-                const float idx = lm_safe_rcp(d.x), idy = lm_safe_rcp(d.y), idz = lm_safe_rcp(d.z);
-                rq.ax = sc.quant[3] * idx; rq.ay = sc.quant[4] * idy; rq.az = sc.quant[5] * idz;
-                rq.bx = (sc.quant[0] - o.x) * idx; rq.by = (sc.quant[1] - o.y) * idy; rq.bz = (sc.quant[2] - o.z) * idz;
-                hitT = tmax; hitOrder = 0xffffffffu; found = false; sp = 0; cur = 0;
-                active = true;
-#if LM_INSTRUMENT
-                raySteps = 0;
-#endif
-            }
-            used += give;
-            if (used == min(64u, n - base)) { group += W; used = 0; drained = (unsigned long long)group * 64ull >= (unsigned long long)n; }
-            need = __ballot(!active);
-        }
-        if (__ballot(active) == 0ull) break;
-        // ---- traverse until the ray ends or the wave has become too empty
-        while (active) {
-#if LM_NODE_EXIT
-            const int roundLanes = (int)__popcll(__ballot(true));
-#endif
-            while (cur >= 0 && cur != 0x7fffffff) {
-#if LM_NODE_EXIT
-                // leave the node loop once few lanes are still descending while others wait with a leaf (or a finished ray):
-                // those test their triangles and rejoin, instead of idling until the slowest lane has found its leaf
-#if LM_NODE_EXIT_FRAC
-                { const int descending = (int)__popcll(__ballot(true)); if (descending * LM_NODE_EXIT_FRAC < roundLanes) break; }
-#else
-                { const int descending = (int)__popcll(__ballot(true)); if (descending < LM_NODE_EXIT && descending < roundLanes) break; }
-#endif
-#endif
-#if LM_INSTRUMENT
-                for (int k = 0; k < 4; k++) nNodes += (int)sc.nodes[cur].c[k].w != LM_REF_NONE;  // child boxes tested
-                raySteps++;
-                { const unsigned long long m = __ballot(true);           // lane occupancy of this node-step issue
-                  if ((int)lane == __ffsll((long long)m) - 1) { atomicAdd((unsigned long long*)(cnt + LM_CNT_OCC), (unsigned long long)__popcll(m)); atomicAdd((unsigned long long*)(cnt + LM_CNT_OCC + 2), 64ull); } }
-#endif
-                cur = lm_node_step<ANY>(sc, cur, rq, tmin, hitT, stack, sp);
-            }
-            if (cur < 0) {
-                const uint32_t leaf = (uint32_t)(~cur);
-                const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
-                for (uint32_t k = 0; k < count; k++) {
-                    float t, u, v;
-#if LM_INSTRUMENT
-                    nTris++; raySteps++;
-                    { const unsigned long long m = __ballot(true);       // lane occupancy of this triangle-test issue
-                      if ((int)lane == __ffsll((long long)m) - 1) { atomicAdd((unsigned long long*)(cnt + LM_CNT_OCC + 4), (unsigned long long)__popcll(m)); atomicAdd((unsigned long long*)(cnt + LM_CNT_OCC + 6), 64ull); } }
-#endif
-                    if (lm_woop(sc.woop, first + k, o, d, tmin, tmax, t, u, v)) {
-                        if (ANY) { found = true; break; }
-                        const uint32_t order = sc.triOrder[first + k];
-                        if (t < hitT || (t == hitT && found && order < hitOrder)) {
-                            hitT = t; hitOrder = order; found = true;
-                            hit.t = t; hit.u = u; hit.v = v; hit.slot = first + k;
-                        }
-                    }
-                }
-                cur = ((ANY && found) || sp == 0) ? 0x7fffffff : lm_pop(stack, sp);
-            }
-            const bool fin = cur == 0x7fffffff;
-            if (fin) {
-                done(rayIdx, found, hit);
-                active = false;
-#if LM_INSTRUMENT
-                // per-ray step histogram (4-wide nodes visited + triangles tested), log2 buckets, and the maximum
-                atomicAdd(cnt + LM_CNT_STEP_HIST + min(15, 31 - __clz((int)(raySteps | 1u))), 1u);
-                atomicMax(cnt + LM_CNT_STEP_MAX, raySteps);
-#endif
-            }
-            // all lanes still in this loop vote (the ones that just finished included): when too few keep traversing,
-            // they leave the loop with their state intact so that the idle lanes can take new rays
-            const unsigned long long still = __ballot(!fin);
-            if (!fin && !drained && (int)__popcll(still) < refillBelow) break;
-        }
-    }
-#if LM_INSTRUMENT
-    atomicAdd((unsigned long long*)(cnt + LM_CNT_NODES), (unsigned long long)nNodes);
-    atomicAdd((unsigned long long*)(cnt + LM_CNT_TRIS), (unsigned long long)nTris);
-#endif
-}
+#include "lm_traverse.h"
 
 // ---------------------------------------------------------------------------------------------------------------------
 // K1: primary rays — reference GPUGeneratePrimRay.cu:28-82 (Halton(2,3) jitter indexed by frameCount + pixel index).
@@ -462,265 +164,7 @@ KN(lm_k_trace_closest)(LmScene sc, const float4* __restrict__ rayO, const float4
         });
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// texture fetch: RGBA8, bilinear, wrap, normalised coordinates, optional sRGB decode (reference PTTexture.cpp:35-74)
-// ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float4 lm_texel(const LmScene& sc, const LmTexDesc& t, int x, int y)
-{
-    const uint32_t p = sc.texels[t.offset + (uint32_t)y * t.w + (uint32_t)x];
-    const uint32_t r = p & 255u, g = (p >> 8) & 255u, b = (p >> 16) & 255u, a = p >> 24;
-    if (t.srgb) return make_float4(sc.srgbLut[r], sc.srgbLut[g], sc.srgbLut[b], (float)a / 255.0f);
-    return make_float4((float)r / 255.0f, (float)g / 255.0f, (float)b / 255.0f, (float)a / 255.0f);
-}
-__device__ __forceinline__ int lm_wrapi(int i, int n) { const int m = i % n; return m < 0 ? m + n : m; }
-__device__ float4 lm_tex2D(const LmScene& sc, int id, float u, float v)
-{
-    if (id < 0) return make_float4(0.f, 0.f, 0.f, 0.f);
-    const LmTexDesc t = sc.texDesc[id];
-    if (t.w == 1u && t.h == 1u) return lm_texel(sc, t, 0, 0);           // lerp(a, a, w) == a exactly
-    const float x = u * (float)t.w - 0.5f, y = v * (float)t.h - 0.5f;
-    const float fx0 = floorf(x), fy0 = floorf(y);
-    const float ax = x - fx0, ay = y - fy0;
-    const int x0 = lm_wrapi((int)fx0, (int)t.w), y0 = lm_wrapi((int)fy0, (int)t.h);
-    const int x1 = lm_wrapi(x0 + 1, (int)t.w), y1 = lm_wrapi(y0 + 1, (int)t.h);
-    const float4 t00 = lm_texel(sc, t, x0, y0), t10 = lm_texel(sc, t, x1, y0), t01 = lm_texel(sc, t, x0, y1), t11 = lm_texel(sc, t, x1, y1);
-    float4 r;
-    r.x = lerpf(lerpf(t00.x, t10.x, ax), lerpf(t01.x, t11.x, ax), ay);
-    r.y = lerpf(lerpf(t00.y, t10.y, ax), lerpf(t01.y, t11.y, ax), ay);
-    r.z = lerpf(lerpf(t00.z, t10.z, ax), lerpf(t01.z, t11.z, ax), ay);
-    r.w = lerpf(lerpf(t00.w, t10.w, ax), lerpf(t01.w, t11.w, ax), ay);
-    return r;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// surface extraction — reference GPUExtractSurfaceData.cu:8-228
-// ---------------------------------------------------------------------------------------------------------------------
-struct LmSurface {
-    lf3 position, normal, tangent, incoming, transport;
-    float t;
-    uint32_t flags;
-    LmMaterial mat;
-};
-struct LmVertex { lf3 pos; lf2 uv; lf3 normal; float4 tangent; };
-__device__ __forceinline__ LmVertex lm_load_vertex(const float4* __restrict__ verts, uint32_t v)
-{
-    const float4 a = verts[3u * v], b = verts[3u * v + 1u], c = verts[3u * v + 2u];
-    LmVertex r;
-    r.pos = v3(a.x, a.y, a.z); r.uv.x = a.w; r.uv.y = b.x; r.normal = v3(b.y, b.z, b.w); r.tangent = c;
-    return r;
-}
-
-__device__ void lm_extract(const LmScene& sc, const uint4 hit, const lf3& ro, const lf3& rd, const lf3& rc, LmSurface& s)
-{
-    s.position = v3(0.f); s.normal = v3(0.f); s.tangent = v3(0.f); s.incoming = v3(0.f); s.transport = v3(0.f);
-    s.t = 0.f; s.flags = 0u;
-    s.mat.color = make_float4(0.f, 0.f, 0.f, 0.f); s.mat.transmittance = s.mat.color; s.mat.tint = s.mat.color;
-    s.mat.p0 = s.mat.p1 = s.mat.p2 = 0u;
-    const float t = u2f(hit.w);
-    if (!(t > 0.f)) { s.flags = LM_SF_NON_INTERSECT; return; }
-    const LmEntry e = sc.entries[hit.x];
-    const LmDevMaterial* mat = sc.materials + e.material;
-    const uint32_t i0 = sc.indices[e.idxBase + 3u * hit.y], i1 = sc.indices[e.idxBase + 3u * hit.y + 1u], i2 = sc.indices[e.idxBase + 3u * hit.y + 2u];
-    const LmVertex A = lm_load_vertex(sc.verts, e.vertBase + i0), B = lm_load_vertex(sc.verts, e.vertBase + i1), C = lm_load_vertex(sc.verts, e.vertBase + i2);
-    const float U = lm_f16_to_f32(hit.z & 0xffffu), V = lm_f16_to_f32(hit.z >> 16), Wt = 1.f - (U + V);
-    const float uvx = A.uv.x * Wt + B.uv.x * U + C.uv.x * V;
-    const float uvy = A.uv.y * Wt + B.uv.y * U + C.uv.y * V;
-    const float flip = A.tangent.w;
-    const float4 normalMap = lm_tex2D(sc, mat->tex[6], uvx, uvy);
-    const float4 texColor = lm_tex2D(sc, mat->tex[3], uvx, uvy);
-    float4 emissive = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (e.mode == 0u) { emissive = mat->emissive * e.emissive.w; emissive = emissive * lm_tex2D(sc, mat->tex[4], uvx, uvy); }
-    else if (e.mode == 2u) emissive = e.emissive * e.emissive.w;
-
-    const lf3 localNormal = normalize3(A.normal * Wt + B.normal * U + C.normal * V);
-    const lf3 localTangent = normalize3(v3(A.tangent) * Wt + v3(B.tangent) * U + v3(C.tangent) * V);
-    const lf3 normalWorld = normalize3(v3(lm_mul_m34(e.m, localNormal, 0.f)));
-    const lf3 tangentWorld = normalize3(v3(lm_mul_m34(e.m, localTangent, 0.f)));
-    const lf3 bitangentWorld = cross3(normalWorld, tangentWorld) * flip;
-    lf3 nm = v3(normalMap.x, normalMap.y, normalMap.z);
-    nm = nm * 2.f - 1.f;
-    nm = normalize3(nm);
-    nm = normalize3(v3(nm.x * tangentWorld.x + nm.y * bitangentWorld.x + nm.z * normalWorld.x,
-                       nm.x * tangentWorld.y + nm.y * bitangentWorld.y + nm.z * normalWorld.y,
-                       nm.x * tangentWorld.z + nm.y * bitangentWorld.z + nm.z * normalWorld.z));
-    s.t = t;
-    s.normal = nm;
-    if (emissive.x > 0.f || emissive.y > 0.f || emissive.z > 0.f) {
-        const float maximum = fmaxf(emissive.x, fmaxf(emissive.y, emissive.z));
-        const float inv = 1.0f / maximum;
-        s.mat.color = emissive * inv;
-        s.flags = LM_SF_EMISSIVE;
-        return;
-    }
-    if (texColor.w < 0.51f) {
-        s.flags = LM_SF_ALPHA;
-        s.position = ro + rd * t;
-        s.incoming = rd;
-        s.transport = rc;
-        return;
-    }
-    const float eta = 1.f / mat->transmittance.w;
-    s.position = ro + rd * t;
-    s.incoming = rd;
-    s.transport = rc;
-    s.tangent = tangentWorld;
-    s.mat.color = mat->color; s.mat.transmittance = mat->transmittance; s.mat.tint = mat->tint;
-    s.mat.p0 = mat->p[0]; s.mat.p1 = mat->p[1]; s.mat.p2 = mat->p[2];
-    const float4 mr = lm_tex2D(sc, mat->tex[5], uvx, uvy);
-    const float baseMetal = lm_unpack8(mat->p[0], 0), baseRough = lm_unpack8(mat->p[0], 24);
-    lm_pack8(s.mat.p0, 0, mr.z * baseMetal);
-    lm_pack8(s.mat.p0, 24, mr.y * baseRough);
-    s.mat.color = texColor * mat->color;
-    const float4 cc = lm_tex2D(sc, mat->tex[0], uvx, uvy);
-    const float4 ccr = lm_tex2D(sc, mat->tex[1], uvx, uvy);
-    const float4 tr = lm_tex2D(sc, mat->tex[2], uvx, uvy);
-    const float4 tint = lm_tex2D(sc, mat->tex[7], uvx, uvy);
-    const lf3 finalTint = v3(tint.x, tint.y, tint.z) * v3(mat->tint);
-    const float finalClearCoat = lm_unpack8(mat->p[2], 0) * cc.x;
-    const float gloss = lm_unpack8(mat->p[2], 8) * (1.f - ccr.x);
-    const float finalTransmission = lm_unpack8(mat->p[2], 16) * tr.x;
-    lm_pack8(s.mat.p2, 0, finalClearCoat);
-    lm_pack8(s.mat.p2, 8, gloss);
-    s.mat.tint = make_float4(finalTint.x, finalTint.y, finalTint.z, s.mat.tint.w);
-    lm_pack8(s.mat.p2, 16, finalTransmission);
-    s.mat.transmittance.w = eta;
-}
-
-// Depth-0 surface data ("G-buffer"): one 128-byte record per pixel = exactly one cache line, because ReSTIR gathers whole
-// records of OTHER pixels (spatial / temporal reuse):  float4[8] =
-//   0 (position, t)   1 (normal, flags bits)   2 (tangent, 0)   3 (incoming, 0)
-//   4 color           5 (tint, luminance)      6 (transmittance, eta)   7 (p0, p1, p2 bits, 0)
-// plus a separate 16-byte "reuse probe" plane (normal, flags ? -1 : t): all that the similarity tests need.
-__device__ __forceinline__ void lm_gbuf_store(float4* __restrict__ g, float4* __restrict__ probe, uint32_t li, const LmSurface& s)
-{
-    float4* r = g + 8u * li;
-    r[0] = v4(s.position, s.t);
-    r[1] = v4(s.normal, u2f(s.flags));
-    r[2] = v4(s.tangent, 0.f);
-    r[3] = v4(s.incoming, 0.f);
-    r[4] = s.mat.color;
-    r[5] = s.mat.tint;
-    r[6] = s.mat.transmittance;
-    r[7] = make_float4(u2f(s.mat.p0), u2f(s.mat.p1), u2f(s.mat.p2), 0.f);
-    probe[li] = v4(s.normal, s.flags ? -1.f : s.t);
-}
-__device__ __forceinline__ void lm_gbuf_load(const float4* __restrict__ g, uint32_t li, LmSurface& s)
-{
-    const float4* r = g + 8u * li;
-    const float4 a = r[0], b = r[1], c = r[2], d = r[3];
-    s.position = v3(a); s.t = a.w; s.normal = v3(b); s.flags = f2u(b.w); s.tangent = v3(c); s.incoming = v3(d);
-    s.mat.color = r[4]; s.mat.tint = r[5]; s.mat.transmittance = r[6];
-    const float4 p = r[7];
-    s.mat.p0 = f2u(p.x); s.mat.p1 = f2u(p.y); s.mat.p2 = f2u(p.z);
-    s.transport = v3(1.f, 1.f, 1.f);
-}
-
-// per-pixel kernels: one 256-thread block = one 16x16 pixel tile of the window.  Tiles are enumerated in bands of 8 tile
-// rows, column-major inside a band, and each XCD (blocks b, b+8, ... share one) gets a contiguous run of that order, so the
-// tiles resident on one XCD form a compact patch and neighbour gathers (+-30 px) hit that XCD's L2.  Speed only.
-template <uint32_t LOG_TS = 4>   // tile edge = 1 << LOG_TS: 16 for 256-thread blocks, 32 for 1024-thread blocks
-__device__ __forceinline__ bool lm_tile_pixel(const LmFrame& fr, uint32_t& li, uint32_t& gi)
-{
-    constexpr uint32_t TS = 1u << LOG_TS;
-    const uint32_t tilesX = (fr.ww + TS - 1u) >> LOG_TS, tilesY = (fr.wh + TS - 1u) >> LOG_TS, T = tilesX * tilesY;
-    const uint32_t b = blockIdx.x, q = T >> 3, r = T & 7u, xcd = b & 7u;
-    const uint32_t t = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (b >> 3);
-    const uint32_t band = t / (8u * tilesX), within = t - band * 8u * tilesX;
-    const uint32_t bh = min(8u, tilesY - band * 8u);
-    const uint32_t tx = within / bh, ty = band * 8u + within % bh;
-    const uint32_t lx = tx * TS + (threadIdx.x & (TS - 1u)), ly = ty * TS + (threadIdx.x >> LOG_TS);
-    if (lx >= fr.ww || ly >= fr.wh) return false;
-    li = ly * fr.ww + lx;
-    gi = (fr.y0 + ly) * fr.W + (fr.x0 + lx);
-    return true;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// lights / CDF — reference ReSTIRData.h:230-306 (CDF::Get, BinarySearch)
-// ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void lm_cdf_get(const LmScene& sc, float value, uint32_t& index, float& pdf)
-{
-    const float required = sc.cdfSum * value;
-    int first = 0, last = (int)sc.numLights - 1, center = 0;
-    for (;;) {
-        center = (last + first) / 2;
-        const float higher = sc.cdf[center];
-        const float lower = center != 0 ? sc.cdf[center - 1] : 0.f;
-        if (required < lower && center - 1 >= first) { last = center - 1; continue; }
-        if (required > higher && center + 1 <= last) { first = center + 1; continue; }
-        index = (uint32_t)center;
-        pdf = (higher - lower) / sc.cdfSum;
-        return;
-    }
-}
-struct LmTriLight { lf3 p0, p1, p2, normal, radiance; float area; };
-__device__ __forceinline__ LmTriLight lm_load_light(const LmLight* __restrict__ lights, uint32_t i)
-{
-    const float4 a = lights[i].a, b = lights[i].b, c = lights[i].c, d = lights[i].d;
-    LmTriLight l;
-    l.p0 = v3(a.x, a.y, a.z); l.p1 = v3(a.w, b.x, b.y); l.p2 = v3(b.z, b.w, c.x);
-    l.normal = v3(c.y, c.z, c.w); l.radiance = v3(d.x, d.y, d.z); l.area = d.w;
-    return l;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// NEE (reference GPUShadeDirect.cu:42-153) and continuation (GPUShadeIndirect.cu:7-146) on one surface
-// ---------------------------------------------------------------------------------------------------------------------
-__device__ bool lm_shade_direct(const LmScene& sc, const LmSurface& s, uint32_t gi, uint32_t seedIn, lf3& dir, float& tmaxOut, lf3& radiance)
-{
-    uint32_t seed = lm_wang_hash(seedIn + gi);
-    if (s.flags) return false;
-    uint32_t index; float pdf;
-    lm_cdf_get(sc, lm_random_float(seed), index, pdf);
-    const LmTriLight light = lm_load_light(sc.lights, index);
-    const float u = lm_random_float(seed);
-    const float v = lm_random_float(seed) * (1.f - u);
-    const lf3 arm1 = light.p1 - light.p0, arm2 = light.p2 - light.p0;
-    const lf3 lightCenter = light.p0 + (arm1 * u) + (arm2 * v);
-    lf3 toLight = lightCenter - s.position;
-    const float lDistance = length3(toLight);
-    toLight = toLight / lDistance;
-    const float cosIn = fmaxf(dot3(toLight, s.normal), 0.f);
-    const float cosOut = fmaxf(0.f, dot3(light.normal, -toLight));
-    if (cosIn <= 0.f || lDistance <= 0.01f) return false;
-    const float solidAngle = (cosOut * light.area) / (lDistance * lDistance);
-    float bsdfPdf = 0.f;
-    const lf3 bsdf = lm_evaluate_bsdf(s.mat, s.normal, s.tangent, -s.incoming, toLight, bsdfPdf);
-    if (bsdfPdf <= LM_EPSILON) return false;
-    lf3 contribution = (bsdf / bsdfPdf) * solidAngle * cosIn * light.radiance;
-    contribution = contribution * ((1.f / pdf) * s.transport);
-    dir = toLight; tmaxOut = lDistance - 0.2f; radiance = contribution;
-    return true;
-}
-__device__ bool lm_shade_indirect(const LmSurface& s, uint32_t gi, uint32_t seedIn, lf3& origin, lf3& dir, lf3& contributionOut)
-{
-    uint32_t seed = lm_wang_hash(seedIn + lm_wang_hash(gi));
-    if (s.flags & LM_SF_ALPHA) { origin = s.position; dir = s.incoming; contributionOut = s.transport; return true; }
-    if (s.flags) return false;
-    if (fabsf(dot3(s.normal, s.incoming)) < 3.f * LM_EPSILON) return false;
-    lf3 bounce = v3(0.f);
-    float pdf = 0.f;
-    bool specular = false;
-    const float r0 = lm_random_float(seed), r1 = lm_random_float(seed), r2 = lm_random_float(seed);
-    const lf3 bsdf = lm_sample_bsdf(s.mat, s.normal, s.normal, s.tangent, -s.incoming, 1.f, r0, r1, r2, bounce, pdf, specular);
-    const float chk = pdf + bsdf.x + bsdf.y + bsdf.z;
-    if (pdf <= LM_EPSILON || chk != chk) return false;
-    const float rrWeight = specular ? 1.f : fminf(fmaxf(bsdf.x, fmaxf(bsdf.y, bsdf.z)), 1.f);
-    const float rnd = lm_random_float(seed);
-    if (rrWeight < rnd) return false;
-    const float rrPdf = 1.f / rrWeight;
-    lf3 contribution = s.transport * rrPdf;
-    contribution = contribution * (bsdf * fabsf(dot3(s.normal, bounce)) * (1.f / pdf));
-    origin = s.position; dir = bounce; contributionOut = contribution;
-    return true;
-}
-
-// inside the owned tile grown by `margin` pixels? (window-local pixel index)
-__device__ __forceinline__ bool lm_owned(const LmFrame& fr, uint32_t li, int margin)
-{
-    const int ly = (int)(li / fr.ww), lx = (int)(li - (uint32_t)ly * fr.ww);
-    return lx >= (int)fr.tx0 - margin && lx < (int)fr.tx1 + margin && ly >= (int)fr.ty0 - margin && ly < (int)fr.ty1 + margin;
-}
+#include "lm_shade.h"
 
 // K7 (depth 0) + K9 motion vectors (MotionVectors.cu:8-55) + K10 ResolveDirectLightHits (GPUShadeDirect.cu:11-40) + channel clear
 // + K12 at depth 0 (GPUShadeIndirect.cu:7-146): the path continuation is sampled from the surface while it is still in
@@ -940,81 +384,7 @@ KN(lm_k_restir_trace_shade)(LmScene sc, LmFrame fr, int rc, const uint32_t* __re
         });
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// ReSTIR DI — reference ReSTIRData.h:115-178, ReSTIRKernels.cu, Framework/ReSTIR.cpp:65-233
-// reservoir storage: a 64-byte "hot" record per pixel (what reuse passes gather from other pixels):
-//   0 (weightSum, weight, sampleCount bits, solidAnglePdf)   1 (radiance, area)   2 (normal, 0)   3 (position, 0)
-// plus a separate plane with the unshadowed contribution (only ever read for the pixel being shaded).
-// ---------------------------------------------------------------------------------------------------------------------
-struct LmSample { lf3 radiance, normal, position, contribution; float area, pdf; };
-struct LmReservoir { float weightSum, weight; long long count; LmSample s; };
-
-__device__ __forceinline__ void lm_sample_zero(LmSample& s) { s.radiance = v3(0.f); s.normal = v3(0.f); s.position = v3(0.f); s.contribution = v3(0.f); s.area = 0.f; s.pdf = 0.f; }
-__device__ __forceinline__ void lm_res_fresh(LmReservoir& r) { r.weightSum = 0.f; r.weight = 0.f; r.count = 0; lm_sample_zero(r.s); }
-__device__ __forceinline__ void lm_res_unpack(const float4& a, const float4& p1, const float4& p2, const float4& p3, LmReservoir& r)
-{
-    r.weightSum = a.x; r.weight = a.y; r.count = (long long)f2u(a.z); r.s.pdf = a.w;
-    r.s.radiance = v3(p1); r.s.area = p1.w; r.s.normal = v3(p2); r.s.position = v3(p3);
-}
-__device__ __forceinline__ void lm_res_load(const float4* __restrict__ hot, const float4* __restrict__ contrib, uint32_t li, LmReservoir& r)
-{
-    const float4* h = hot + 4u * li;
-    lm_res_unpack(h[0], h[1], h[2], h[3], r);
-    r.s.contribution = v3(contrib[li]);
-}
-__device__ __forceinline__ void lm_res_store(float4* __restrict__ hot, float4* __restrict__ contrib, uint32_t li, const LmReservoir& r)
-{
-    float4* h = hot + 4u * li;
-    h[0] = make_float4(r.weightSum, r.weight, u2f((uint32_t)r.count), r.s.pdf);
-    h[1] = v4(r.s.radiance, r.s.area);
-    h[2] = v4(r.s.normal, 0.f);
-    h[3] = v4(r.s.position, 0.f);
-    contrib[li] = v4(r.s.contribution, 0.f);
-}
-__device__ __forceinline__ void lm_res_update(LmReservoir& r, const LmSample& s, float w, uint32_t seed /* by value: reference quirk */)
-{
-    r.weightSum += w;
-    ++r.count;
-    const float rnd = lm_random_float(seed);
-    if (rnd <= (w / r.weightSum)) r.s = s;
-}
-__device__ __forceinline__ void lm_res_update_weight(LmReservoir& r)
-{
-    if (r.count == 0 || r.weightSum <= 0.f) { r.weight = 0; return; }
-    r.weight = (1.f / fmaxf(r.s.pdf, 1.1920928955078125e-7f)) * ((1.f / (float)r.count) * r.weightSum);
-}
-// Resample — ReSTIRKernels.cu:1259-1325
-__device__ void lm_resample(const LmSample& in, const LmSurface& px, LmSample& out)
-{
-    out = in;
-    lf3 toLight = in.position - px.position;
-    const float lDistance = length3(toLight);
-    toLight = toLight / lDistance;
-    const float cosIn = fmaxf(dot3(toLight, px.normal), 0.f);
-    const float cosOut = fmaxf(dot3(in.normal, -toLight), 0.f);
-    if (cosIn <= 0 || cosOut <= 0 || lDistance <= 0.01f) { out.pdf = 0; return; }
-    const float solidAngle = (cosOut * in.area) / (lDistance * lDistance);
-    float pdf = 0.f;
-    const lf3 bsdf = lm_evaluate_bsdf(px.mat, px.normal, px.tangent, -px.incoming, toLight, pdf);
-    const float added = pdf + bsdf.x + bsdf.y + bsdf.z;
-    if (pdf <= LM_EPSILON || added != added || fabsf(added) == u2f(0x7f800000u)) { out.contribution = v3(0.f); out.pdf = 0; return; }
-    const lf3 contribution = (bsdf / pdf) * solidAngle * cosIn * out.radiance;
-    out.contribution = contribution;
-    out.pdf = (contribution.x + contribution.y + contribution.z) / 3.f;
-}
-// CombineBiased for two reservoirs — ReSTIRKernels.cu:1200-1257
-__device__ void lm_combine2(LmReservoir& dst, const LmReservoir& a, const LmReservoir& b, const LmSurface& px, uint32_t seed)
-{
-    LmReservoir out; lm_res_fresh(out);
-    LmSample rs;
-    lm_resample(a.s, px, rs);
-    lm_res_update(out, rs, (float)a.count * a.weight * rs.pdf, seed);
-    lm_resample(b.s, px, rs);
-    lm_res_update(out, rs, (float)b.count * b.weight * rs.pdf, seed);
-    out.count = a.count + b.count;
-    lm_res_update_weight(out);
-    dst = out;
-}
+#include "lm_restir.h"
 
 // K20 FillLightBags — ReSTIRKernels.cu:343-370
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)

@@ -1,0 +1,304 @@
+// lm_traverse.h — device code: 4-wide BVH traversal (Woop unit-triangle test, hybrid LDS / global stack) and the queue
+// traversal with per-lane ray replacement.  Included by kernels.hip only (one translation unit, compiled twice: LM_INSTRUMENT).
+#pragma once
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Traversal of the 4-wide BVH (bvh.cpp) with the Woop unit-triangle test.  Per-lane stack: 16 entries in LDS, interleaved by lane
+// (bank-conflict free), deeper entries spill to a per-thread global area.
+// Closest hit: minimum t in (tmin, tmax); equal t -> lower global triangle index (order independent).
+// ---------------------------------------------------------------------------------------------------------------------
+struct LmHit { float t, u, v; uint32_t slot; };
+
+// Per-lane traversal stack: the first LM_STACK_LDS entries live in LDS ([level][lane]: one bank per lane), deeper entries
+// (rare) spill to a per-thread global array, so that the LDS footprint (16 KB per 256-thread block) does not cap occupancy.
+typedef __attribute__((address_space(3))) int lm_lds_int;      // explicit LDS pointer: ds_read / ds_write, never flat accesses
+struct LmStack { lm_lds_int* lds; int* spill; };
+#if LM_INSTRUMENT
+__device__ unsigned long long g_lmPushes[2];       // counting build: [0] stack pushes, [1] of which went to the global spill area
+#endif
+__device__ __forceinline__ void lm_push(const LmStack& st, int& sp, int v)
+{
+#if LM_INSTRUMENT
+    atomicAdd(&g_lmPushes[sp < LM_STACK_LDS ? 0 : 1], 1ull);
+#endif
+    if (sp < LM_STACK_LDS) st.lds[sp * LM_BLOCK] = v; else st.spill[sp - LM_STACK_LDS] = v;
+    sp++;
+}
+__device__ __forceinline__ int lm_pop(const LmStack& st, int& sp)
+{
+    --sp;
+    // the LDS slot is read unconditionally (clamped index) and the spill slot only under a branch: a select between the
+    // two POINTERS would turn every pop into a flat load, which is slower than ds_read and waits on both counters
+    int v = st.lds[min(sp, LM_STACK_LDS - 1) * LM_BLOCK];
+    if (sp >= LM_STACK_LDS) v = st.spill[sp - LM_STACK_LDS];
+    return v;
+}
+__device__ __forceinline__ LmStack lm_make_stack(int* s_stack, const LmScene& sc)
+{
+    LmStack st;
+    st.lds = (lm_lds_int*)(s_stack + threadIdx.x);
+    st.spill = sc.spill + (size_t)(blockIdx.x * LM_BLOCK + threadIdx.x) * (LM_STACK_DEPTH - LM_STACK_LDS);
+    return st;
+}
+
+// The whole 48-byte packet is fetched up front (three independent 16-byte loads, one wait) instead of row by row behind
+// the early-outs: a leaf visit then costs one memory round trip per triangle, not up to three.
+__device__ __forceinline__ bool lm_woop(const LmWoop* __restrict__ woop, uint32_t slot, const lf3& o, const lf3& d,
+                                        float tmin, float tmax, float& t, float& u, float& v)
+{
+    float4 r2 = woop[slot].r2, r0 = woop[slot].r0, r1 = woop[slot].r1;
+    asm volatile("" : "+v"(r0.x), "+v"(r1.x), "+v"(r2.x));     // keep the three loads together (the compiler would sink two behind the early-outs)
+    const float Oz = fmaf(r2.x, o.x, fmaf(r2.y, o.y, fmaf(r2.z, o.z, r2.w)));
+    const float Dz = fmaf(r2.x, d.x, fmaf(r2.y, d.y, r2.z * d.z));
+    t = -Oz / Dz;
+    if (!(t > tmin && t < tmax)) return false;
+    const float Ox = fmaf(r0.x, o.x, fmaf(r0.y, o.y, fmaf(r0.z, o.z, r0.w)));
+    const float Dx = fmaf(r0.x, d.x, fmaf(r0.y, d.y, r0.z * d.z));
+    u = fmaf(t, Dx, Ox);
+    if (!(u >= 0.0f)) return false;
+    const float Oy = fmaf(r1.x, o.x, fmaf(r1.y, o.y, fmaf(r1.z, o.z, r1.w)));
+    const float Dy = fmaf(r1.x, d.x, fmaf(r1.y, d.y, r1.z * d.z));
+    v = fmaf(t, Dy, Oy);
+    if (!(v >= 0.0f)) return false;
+    return u + v <= 1.0f;
+}
+
+__device__ __forceinline__ float lm_safe_rcp(float d)
+{
+    const float ooeps = 1e-20f;
+    return 1.0f / (fabsf(d) > ooeps ? d : copysignf(ooeps, d));
+}
+
+// One step through a 4-wide node: slab-test the four quantised child boxes against [tmin, hitT], continue with the nearest
+// hit child and push the others far-to-near (closest-hit) or in node order (any-hit).  Returns the next node / leaf
+// reference, or LM_REF_NONE when the stack is empty.  `boxes` counts child boxes tested (instrumented build).
+#ifndef LM_ANY_ORDERED
+#define LM_ANY_ORDERED 0      // 1: any-hit queries also visit children near to far (finds close occluders sooner, costs the sort)
+#endif
+struct LmRayQ { float ax, ay, az, bx, by, bz; };      // t = q * a + b per axis (dequantisation folded into the slab test)
+__device__ __forceinline__ void lm_slab(const uint4& q, const LmRayQ& r, float tmin, float hitT, uint32_t& key)
+{
+    const float lox = fmaf((float)(q.x & 0xffffu), r.ax, r.bx), hix = fmaf((float)(q.x >> 16), r.ax, r.bx);
+    const float loy = fmaf((float)(q.y & 0xffffu), r.ay, r.by), hiy = fmaf((float)(q.y >> 16), r.ay, r.by);
+    const float loz = fmaf((float)(q.z & 0xffffu), r.az, r.bz), hiz = fmaf((float)(q.z >> 16), r.az, r.bz);
+    const float tn = fmaxf(fmaxf(fminf(lox, hix), fminf(loy, hiy)), fmaxf(fminf(loz, hiz), tmin));
+    const float tf = fminf(fminf(fmaxf(lox, hix), fmaxf(loy, hiy)), fminf(fmaxf(loz, hiz), hitT));
+    key = (tn <= tf && (int)q.w != LM_REF_NONE) ? f2u(tn) : 0xffffffffu;       // tn >= tmin >= 0: the bit pattern orders like the value
+}
+__device__ __forceinline__ void lm_cex(uint32_t& ka, int& ra, uint32_t& kb, int& rb)
+{
+    const bool sw = kb < ka;
+    const uint32_t k0 = min(ka, kb), k1 = max(ka, kb);
+    const int r0 = sw ? rb : ra, r1 = sw ? ra : rb;
+    ka = k0; kb = k1; ra = r0; rb = r1;
+}
+template <bool ANY>
+__device__ __forceinline__ int lm_node_step(const LmScene& sc, int cur, const LmRayQ& rq, float tmin, float hitT, const LmStack& stack, int& sp)
+{
+    const uint4* nd = sc.nodes[cur].c;
+    const uint4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+    uint32_t k0, k1, k2, k3;
+    lm_slab(q0, rq, tmin, hitT, k0); lm_slab(q1, rq, tmin, hitT, k1); lm_slab(q2, rq, tmin, hitT, k2); lm_slab(q3, rq, tmin, hitT, k3);
+    int r0 = (int)q0.w, r1 = (int)q1.w, r2 = (int)q2.w, r3 = (int)q3.w;
+    if (!ANY || LM_ANY_ORDERED) {     // order the children by entry distance (a 5-comparator network; misses carry the largest key)
+        lm_cex(k0, r0, k1, r1); lm_cex(k2, r2, k3, r3); lm_cex(k0, r0, k2, r2); lm_cex(k1, r1, k3, r3); lm_cex(k1, r1, k2, r2);
+        if (k0 == 0xffffffffu) return sp == 0 ? LM_REF_NONE : lm_pop(stack, sp);
+        if (k3 != 0xffffffffu) lm_push(stack, sp, r3);
+        if (k2 != 0xffffffffu) lm_push(stack, sp, r2);
+        if (k1 != 0xffffffffu) lm_push(stack, sp, r1);
+        return r0;
+    }
+    int next = LM_REF_NONE;
+    if (k3 != 0xffffffffu) next = r3;
+    if (k2 != 0xffffffffu) { if (next != LM_REF_NONE) lm_push(stack, sp, next); next = r2; }
+    if (k1 != 0xffffffffu) { if (next != LM_REF_NONE) lm_push(stack, sp, next); next = r1; }
+    if (k0 != 0xffffffffu) { if (next != LM_REF_NONE) lm_push(stack, sp, next); next = r0; }
+    if (next == LM_REF_NONE) return sp == 0 ? LM_REF_NONE : lm_pop(stack, sp);
+    return next;
+}
+
+template <bool ANY>
+__device__ __forceinline__ bool lm_traverse(const LmScene& sc, const lf3& o, const lf3& d, float tmin, float tmax,
+                                            const LmStack& stack, LmHit& hit, uint32_t* cnt)
+{
+    const float idx = lm_safe_rcp(d.x), idy = lm_safe_rcp(d.y), idz = lm_safe_rcp(d.z);
+    // node boxes are 16-bit fixed point: world = qmin + q * qstep, so t = q * (qstep * idir) + (qmin - o) * idir
+    LmRayQ rq;
+    rq.ax = sc.quant[3] * idx; rq.ay = sc.quant[4] * idy; rq.az = sc.quant[5] * idz;
+    rq.bx = (sc.quant[0] - o.x) * idx; rq.by = (sc.quant[1] - o.y) * idy; rq.bz = (sc.quant[2] - o.z) * idz;
+    float hitT = tmax;
+    uint32_t hitOrder = 0xffffffffu;
+    bool found = false;
+    int sp = 0;
+    int cur = 0;
+#if LM_INSTRUMENT
+    uint32_t nNodes = 0, nTris = 0;
+#endif
+    for (;;) {
+        while (cur >= 0 && cur != LM_REF_NONE) {
+#if LM_INSTRUMENT
+            for (int k = 0; k < 4; k++) nNodes += (int)sc.nodes[cur].c[k].w != LM_REF_NONE;      // child boxes tested
+#endif
+            cur = lm_node_step<ANY>(sc, cur, rq, tmin, hitT, stack, sp);
+        }
+        if (cur == 0x7fffffff) break;
+        // leaf
+        const uint32_t leaf = (uint32_t)(~cur);
+        const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
+        for (uint32_t k = 0; k < count; k++) {
+            float t, u, v;
+#if LM_INSTRUMENT
+            nTris++;
+#endif
+            if (lm_woop(sc.woop, first + k, o, d, tmin, tmax, t, u, v)) {
+                if (ANY) { found = true; break; }
+                const uint32_t order = sc.triOrder[first + k];
+                if (t < hitT || (t == hitT && found && order < hitOrder)) {
+                    hitT = t; hitOrder = order; found = true;
+                    hit.t = t; hit.u = u; hit.v = v; hit.slot = first + k;
+                }
+            }
+        }
+        if (ANY && found) break;
+        if (sp == 0) break;
+        cur = lm_pop(stack, sp);
+    }
+#if LM_INSTRUMENT
+    atomicAdd((unsigned long long*)(cnt + LM_CNT_NODES), (unsigned long long)nNodes);
+    atomicAdd((unsigned long long*)(cnt + LM_CNT_TRIS), (unsigned long long)nTris);
+#endif
+    return found;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Queue traversal with per-lane ray replacement ("persistent threads").  Wavefront w of the launch owns the 64-ray groups
+// w, w + W, w + 2W, ... of the queue (W = wavefronts in the grid; no atomics: one address retires only ~88 returning atomics
+// per microsecond).  When fewer than `refillBelow` lanes of a wave are still traversing, the others take the next rays of
+// the wave's groups, so incoherent rays of very different length do not leave most of the 64 lanes idle; refillBelow <= 1
+// keeps a wave on one group at a time (best for coherent rays: an 8x8 pixel bundle stays together).
+// `done(rayIndex, found, hit)` runs once per ray.  Results are identical to lm_traverse (same tests, same tie-break).
+// ---------------------------------------------------------------------------------------------------------------------
+#ifndef LM_PRIO_RAYS
+#define LM_PRIO_RAYS 1048576u
+#endif
+#ifndef LM_NODE_EXIT_FRAC
+#define LM_NODE_EXIT_FRAC 3      // leave the node loop when fewer than a third of the round's lanes still descend (0: use the absolute LM_NODE_EXIT)
+#endif
+#ifndef LM_NODE_EXIT
+#define LM_NODE_EXIT 14
+#endif
+template <bool ANY, class Fetch, class Done>
+__device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, int refillBelow, const LmStack& stack,
+                                               uint32_t* cnt, Fetch fetch, Done done)
+{
+    // A small queue cannot fill the machine: its launch time is one wave's dependent chain, which stretches when the wave
+    // shares its SIMD with VALU-bound kernels of the other streams.  Such waves ask the SIMD arbiter for priority.
+    if (n < LM_PRIO_RAYS) __builtin_amdgcn_s_setprio(3);
+    const uint32_t lane = lm_lane();
+    const uint32_t W = gridDim.x * (LM_BLOCK / 64u);
+    uint32_t group = blockIdx.x * (LM_BLOCK / 64u) + (threadIdx.x >> 6);      // wave-uniform
+    uint32_t used = 0;                                                     // rays already handed out from `group` (wave-uniform)
+    bool active = false;
+    uint32_t rayIdx = 0;
+    lf3 o = v3(0.f), d = v3(0.f);
+    float tmin = 0.f, tmax = 0.f, hitT = 0.f;
+    LmRayQ rq = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    uint32_t hitOrder = 0xffffffffu;
+    bool found = false;
+    int sp = 0, cur = 0;
+    LmHit hit; hit.t = -1.f; hit.u = 0.f; hit.v = 0.f; hit.slot = 0;
+#if LM_INSTRUMENT
+    uint32_t nNodes = 0, nTris = 0, raySteps = 0;
+#endif
+    for (;;) {
+        // ---- refill idle lanes from the wave's groups
+        unsigned long long need = __ballot(!active);
+        bool drained = (unsigned long long)group * 64ull >= (unsigned long long)n;
+        while (need != 0ull && !drained) {
+            const uint32_t base = group * 64u;
+            const uint32_t avail = min(64u, n - base) - used;
+            const uint32_t want = (uint32_t)__popcll(need);
+            const uint32_t give = min(want, avail);
+            const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+            if (!active && rank < give) {
+                rayIdx = base + used + rank;
+                fetch(rayIdx, o, d, tmin, tmax);
+                const float idx = lm_safe_rcp(d.x), idy = lm_safe_rcp(d.y), idz = lm_safe_rcp(d.z);
+                rq.ax = sc.quant[3] * idx; rq.ay = sc.quant[4] * idy; rq.az = sc.quant[5] * idz;
+                rq.bx = (sc.quant[0] - o.x) * idx; rq.by = (sc.quant[1] - o.y) * idy; rq.bz = (sc.quant[2] - o.z) * idz;
+                hitT = tmax; hitOrder = 0xffffffffu; found = false; sp = 0; cur = 0;
+                active = true;
+#if LM_INSTRUMENT
+                raySteps = 0;
+#endif
+            }
+            used += give;
+            if (used == min(64u, n - base)) { group += W; used = 0; drained = (unsigned long long)group * 64ull >= (unsigned long long)n; }
+            need = __ballot(!active);
+        }
+        if (__ballot(active) == 0ull) break;
+        // ---- traverse until the ray ends or the wave has become too empty
+        while (active) {
+#if LM_NODE_EXIT
+            const int roundLanes = (int)__popcll(__ballot(true));
+#endif
+            while (cur >= 0 && cur != 0x7fffffff) {
+#if LM_NODE_EXIT
+                // leave the node loop once few lanes are still descending while others wait with a leaf (or a finished ray):
+                // those test their triangles and rejoin, instead of idling until the slowest lane has found its leaf
+#if LM_NODE_EXIT_FRAC
+                { const int descending = (int)__popcll(__ballot(true)); if (descending * LM_NODE_EXIT_FRAC < roundLanes) break; }
+#else
+                { const int descending = (int)__popcll(__ballot(true)); if (descending < LM_NODE_EXIT && descending < roundLanes) break; }
+#endif
+#endif
+#if LM_INSTRUMENT
+                for (int k = 0; k < 4; k++) nNodes += (int)sc.nodes[cur].c[k].w != LM_REF_NONE;  // child boxes tested
+                raySteps++;
+                { const unsigned long long m = __ballot(true);           // lane occupancy of this node-step issue
+                  if ((int)lane == __ffsll((long long)m) - 1) { atomicAdd((unsigned long long*)(cnt + LM_CNT_OCC), (unsigned long long)__popcll(m)); atomicAdd((unsigned long long*)(cnt + LM_CNT_OCC + 2), 64ull); } }
+#endif
+                cur = lm_node_step<ANY>(sc, cur, rq, tmin, hitT, stack, sp);
+            }
+            if (cur < 0) {
+                const uint32_t leaf = (uint32_t)(~cur);
+                const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
+                for (uint32_t k = 0; k < count; k++) {
+                    float t, u, v;
+#if LM_INSTRUMENT
+                    nTris++; raySteps++;
+                    { const unsigned long long m = __ballot(true);       // lane occupancy of this triangle-test issue
+                      if ((int)lane == __ffsll((long long)m) - 1) { atomicAdd((unsigned long long*)(cnt + LM_CNT_OCC + 4), (unsigned long long)__popcll(m)); atomicAdd((unsigned long long*)(cnt + LM_CNT_OCC + 6), 64ull); } }
+#endif
+                    if (lm_woop(sc.woop, first + k, o, d, tmin, tmax, t, u, v)) {
+                        if (ANY) { found = true; break; }
+                        const uint32_t order = sc.triOrder[first + k];
+                        if (t < hitT || (t == hitT && found && order < hitOrder)) {
+                            hitT = t; hitOrder = order; found = true;
+                            hit.t = t; hit.u = u; hit.v = v; hit.slot = first + k;
+                        }
+                    }
+                }
+                cur = ((ANY && found) || sp == 0) ? 0x7fffffff : lm_pop(stack, sp);
+            }
+            const bool fin = cur == 0x7fffffff;
+            if (fin) {
+                done(rayIdx, found, hit);
+                active = false;
+#if LM_INSTRUMENT
+                // per-ray step histogram (4-wide nodes visited + triangles tested), log2 buckets, and the maximum
+                atomicAdd(cnt + LM_CNT_STEP_HIST + min(15, 31 - __clz((int)(raySteps | 1u))), 1u);
+                atomicMax(cnt + LM_CNT_STEP_MAX, raySteps);
+#endif
+            }
+            // all lanes still in this loop vote (the ones that just finished included): when too few keep traversing,
+            // they leave the loop with their state intact so that the idle lanes can take new rays
+            const unsigned long long still = __ballot(!fin);
+            if (!fin && !drained && (int)__popcll(still) < refillBelow) break;
+        }
+    }
+#if LM_INSTRUMENT
+    atomicAdd((unsigned long long*)(cnt + LM_CNT_NODES), (unsigned long long)nNodes);
+    atomicAdd((unsigned long long*)(cnt + LM_CNT_TRIS), (unsigned long long)nTris);
+#endif
+}
