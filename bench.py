@@ -63,7 +63,7 @@ def algorithmic_bytes_traceframe(c, depth, npix, nodes_all, tris_all, blend=True
 
 
 def load_traffic():
-    """HBM bytes per launch from PMC counters (separate rocprofv3 --pmc passes, tools_traffic.sh); None when not measured."""
+    """HBM bytes per launch from PMC counters (separate rocprofv3 --pmc passes, tools/traffic.sh); None when not measured."""
     path = os.path.join(ROOT, "profiles", "r01_c2_hbm_traffic_pmc.json")
     try:
         with open(path) as f:

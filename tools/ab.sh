@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: bash tools_ab.sh <tag> "ENV1=a ENV2=b" "ENV1=c" ...   — one bench line per environment setting (A/B runs on one box)
+# usage: bash tools/ab.sh <tag> "ENV1=a ENV2=b" "ENV1=c" ...   — one bench line per environment setting (A/B runs on one box)
 tag=$1; shift
 mkdir -p gpurun_out/$tag
 i=0

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: bash tools_ab2.sh <tag> "<bench args>" "ENV1=a" "ENV2=b" ...
+# usage: bash tools/ab2.sh <tag> "<bench args>" "ENV1=a" "ENV2=b" ...
 tag=$1; shift; args=$1; shift; mkdir -p gpurun_out/$tag
 for cfg in "" "$@"; do
   env $cfg timeout 600 python bench.py --steps 5 --warmup 1 --no-cpu-baseline $args > gpurun_out/$tag/b.json 2> gpurun_out/$tag/b.err

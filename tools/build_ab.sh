@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: bash tools_build_ab.sh <tag> "<EXTRA flags A>" "<EXTRA flags B>" ...  — rebuild the library with each flag set on the GPU box and bench it
+# usage: bash tools/build_ab.sh <tag> "<EXTRA flags A>" "<EXTRA flags B>" ...  — rebuild the library with each flag set on the GPU box and bench it
 tag=$1; shift; mkdir -p gpurun_out/$tag
 for ex in "$@"; do
   make -C lumenrenderer_amd/csrc clean > /dev/null; make -C lumenrenderer_amd/csrc -j8 EXTRA="$ex" 2>&1 | grep -E "error" 

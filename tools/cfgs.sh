@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: bash tools_cfgs.sh <tag>  — one bench line per non-default workload (c3, c4, c5) for the record
+# usage: bash tools/cfgs.sh <tag>  — one bench line per non-default workload (c3, c4, c5) for the record
 tag=${1:-cfg}
 mkdir -p gpurun_out/$tag
 for w in c3 c4 c5; do

@@ -1,4 +1,6 @@
-"""Per-ray traversal-step histogram of one instrumented TraceFrame (GPU box): python tools_hist.py [depth]"""
+"""Per-ray traversal-step histogram of one instrumented TraceFrame (GPU box): python tools/hist.py [depth]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))     # run from anywhere: the package lives in the repo root
 import sys, numpy as np
 from lumenrenderer_amd import LumenRendererMI
 from lumenrenderer_amd.scenes import sponza_standin

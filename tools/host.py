@@ -1,4 +1,6 @@
-"""Host enqueue cost of TraceFrameAsync vs device time, full frame and the window of one rank of 8 (GPU box): python tools_host.py"""
+"""Host enqueue cost of TraceFrameAsync vs device time, full frame and the window of one rank of 8 (GPU box): python tools/host.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))     # run from anywhere: the package lives in the repo root
 import time, numpy as np
 from lumenrenderer_amd import LumenRendererMI, tiles
 from lumenrenderer_amd.scenes import sponza_standin

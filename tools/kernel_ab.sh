@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: bash tools_kernel_ab.sh <tag> <kernel substring> "<EXTRA A>" "<EXTRA B>" ...  — alone-time (single stream) of one kernel per build variant
+# usage: bash tools/kernel_ab.sh <tag> <kernel substring> "<EXTRA A>" "<EXTRA B>" ...  — alone-time (single stream) of one kernel per build variant
 tag=$1; shift; kern=$1; shift; mkdir -p gpurun_out/$tag; R=$PWD
 for ex in "$@"; do
   make -C lumenrenderer_amd/csrc clean > /dev/null; make -C lumenrenderer_amd/csrc -j8 EXTRA="$ex" 2>&1 | grep -E " error"

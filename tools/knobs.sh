@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: bash tools_knobs.sh <tag> "<bench args>" "ENV=.. ENV=.." ...  — bench line per environment setting (knobs of renderer.cpp), two rounds
+# usage: bash tools/knobs.sh <tag> "<bench args>" "ENV=.. ENV=.." ...  — bench line per environment setting (knobs of renderer.cpp), two rounds
 tag=$1; shift; args=$1; shift; mkdir -p gpurun_out/$tag
 for round in 1 2; do
 for e in "$@"; do

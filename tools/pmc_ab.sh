@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: bash tools_pmc_ab.sh <tag> "<EXTRA flags>" ...  — VALU counters of the ReSTIR kernels per build variant (serialised kernels)
+# usage: bash tools/pmc_ab.sh <tag> "<EXTRA flags>" ...  — VALU counters of the ReSTIR kernels per build variant (serialised kernels)
 tag=$1; shift; mkdir -p gpurun_out/$tag; R=$PWD
 for ex in "$@"; do
   make -C lumenrenderer_amd/csrc clean > /dev/null; make -C lumenrenderer_amd/csrc -j8 EXTRA="$ex" 2>&1 | grep -E " error"

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): bash tools_prof.sh <tag>  — parity tests, bench line, rocprofv3 kernel stats
+# usage (on the GPU box, from the repo root): bash tools/prof.sh <tag>  — parity tests, bench line, rocprofv3 kernel stats
 tag=${1:-x}
 mkdir -p gpurun_out/$tag
 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 > gpurun_out/$tag/pytest.log
@@ -23,6 +23,6 @@ import glob, subprocess
 tf=glob.glob("gpurun_out/$tag/prof/*/*kernel_trace.csv")
 if tf:
     print("--- steady-state timeline, two TraceFrames (start_us dur_us | one column per stream)")
-    subprocess.run(["python3","tools_timeline.py",tf[0]])
+    subprocess.run(["python3","tools/timeline.py",tf[0]])
 PY
 rm -rf gpurun_out/$tag/prof

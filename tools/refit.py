@@ -1,4 +1,6 @@
-"""Cost of a moving instance per frame (GPU box): GPU refit vs full host rebuild.  python tools_refit.py"""
+"""Cost of a moving instance per frame (GPU box): GPU refit vs full host rebuild.  python tools/refit.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))     # run from anywhere: the package lives in the repo root
 import time, numpy as np
 from lumenrenderer_amd import LumenRendererMI
 from lumenrenderer_amd.scenes import sponza_standin

@@ -1,6 +1,8 @@
 """Soak run (GPU box): thousands of asynchronous frames with scene / camera / resolution / window edits in between; host and
 device memory must stay flat and the final frames must equal those of a fresh renderer given the same last edits.
-python tools_soak.py [frames]"""
+python tools/soak.py [frames]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))     # run from anywhere: the package lives in the repo root
 import sys, time, resource
 import numpy as np
 import torch

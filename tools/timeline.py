@@ -1,4 +1,4 @@
-"""Print a per-stream timeline of the middle of a rocprofv3 kernel trace: python tools_timeline.py <kernel_trace.csv> [t0_us] [t1_us]"""
+"""Print a per-stream timeline of the middle of a rocprofv3 kernel trace: python tools/timeline.py <kernel_trace.csv> [t0_us] [t1_us]"""
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if r["Kernel_Name"].startswith("lm_k") and not r["Kernel_Name"].endswith("_inst")]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
