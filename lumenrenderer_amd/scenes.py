@@ -544,3 +544,49 @@ def foliage_stress(copies=10000, tris_per_plant=1000):
     up0 = np.array([0.0, 1.0, 0.0]); right = np.cross(up0, fwd); right /= np.linalg.norm(right); up = np.cross(fwd, right)
     d.set_camera((-2.0, 4.0, -2.0), tuple(right), tuple(up), tuple(fwd), 90.0)
     return d
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# flat scene file for callers of the C ABI that are not Python (examples/render_scene.c)
+# ---------------------------------------------------------------------------------------------------------------------
+SCENE_FILE_MAGIC = 0x314D4C53          # "SLM1"
+_MATERIAL_TEXTURES = ("diffuse_texture", "normal_map", "metallic_roughness_texture", "emissive_texture", "transmission_texture",
+                      "clearcoat_texture", "clearcoat_roughness_texture", "tint_texture")
+_MATERIAL_SCALARS = ("transmission_factor", "clearcoat_factor", "clearcoat_roughness_factor", "index_of_refraction", "specular_factor",
+                     "specular_tint_factor", "subsurface_factor", "luminance", "anisotropic", "sheen_factor", "sheen_tint_factor",
+                     "metallic_factor", "roughness_factor")
+
+
+def write_scene_file(desc, path):
+    """Little-endian dump of a SceneDescription, in the order a caller replays it through the factories of include/lumen_mi.h:
+    u32 magic; camera 13 f32 (position, right, up, forward, fov);
+    u32 nTex   { u32 w, h, srgb; w*h*4 bytes RGBA8 };
+    u32 nMat   { f32 diffuse[4], emission[3]; u32 texture index x 8; f32 x 13 scalars (order of lumen_mi_material_data); f32 tint[3], transmittance[3] };
+    u32 nPrim  { u32 material, nVertices, nIndices; nVertices * 48 bytes interleaved vertices; nIndices u32 };
+    u32 nMesh  { u32 nPrims; u32 primitive index x nPrims };
+    u32 nInst  { u32 mesh; f32 transform[16] row-major; i32 emission mode; f32 radiance[3], scale; i32 override material (-1 = none) }."""
+    import struct
+    with open(path, "wb") as f:
+        c = desc.camera
+        f.write(struct.pack("<I13f", SCENE_FILE_MAGIC, *c["position"], *c["right"], *c["up"], *c["forward"], c["fov"]))
+        f.write(struct.pack("<I", len(desc.textures)))
+        for t in desc.textures:
+            px = np.ascontiguousarray(t["pixels"], np.uint8)
+            f.write(struct.pack("<3I", px.shape[1], px.shape[0], int(t["srgb"]))); f.write(px.tobytes())
+        f.write(struct.pack("<I", len(desc.materials)))
+        for m in desc.materials:
+            f.write(struct.pack("<7f", *m["diffuse_color"], *m["emission"]))
+            f.write(struct.pack("<8I", *[m[k] for k in _MATERIAL_TEXTURES]))
+            f.write(struct.pack("<13f", *[m[k] for k in _MATERIAL_SCALARS]))
+            f.write(struct.pack("<6f", *m["tint_factor"], *m["transmittance"]))
+        f.write(struct.pack("<I", len(desc.primitives)))
+        for p in desc.primitives:
+            v = np.ascontiguousarray(p["vertices"], np.float32).reshape(-1, 12); i = np.ascontiguousarray(p["indices"], np.uint32).ravel()
+            f.write(struct.pack("<3I", p["material"], v.shape[0], i.size)); f.write(v.tobytes()); f.write(i.tobytes())
+        f.write(struct.pack("<I", len(desc.meshes)))
+        for m in desc.meshes:
+            f.write(struct.pack("<I", len(m))); f.write(struct.pack("<%dI" % len(m), *m))
+        f.write(struct.pack("<I", len(desc.instances)))
+        for inst in desc.instances:
+            f.write(struct.pack("<I16f", inst["mesh"], *np.asarray(inst["transform"], np.float32).ravel()))
+            f.write(struct.pack("<i4fi", inst["emission_mode"], *inst["override_radiance"], inst["scale"], inst["override_material"]))

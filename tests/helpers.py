@@ -5,6 +5,7 @@ import numpy as np
 from oracle_lib import Oracle
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _TEX = ("diffuse_texture", "normal_map", "metallic_roughness_texture", "emissive_texture", "transmission_texture",
         "clearcoat_texture", "clearcoat_roughness_texture", "tint_texture")
 _ORC = {"diffuse_texture": "tex_diffuse", "normal_map": "tex_normal", "metallic_roughness_texture": "tex_metal_rough", "emissive_texture": "tex_emissive",
@@ -75,3 +76,15 @@ def random_soup(n_tris, seed, extent=10.0, size=1.0):
     tang = generate_tangents_fast(pos, nrm, uv, idx)
     d.add_instance(d.add_mesh([d.add_primitive(interleave(pos, uv, nrm, tang), idx.ravel(), m)]))
     return d
+
+
+def build_c_example(tmp_path):
+    """examples/render_scene.c compiled as strict C99 against include/lumen_mi.h and linked with the product library."""
+    import subprocess
+    exe = str(tmp_path / "render_scene")
+    libdir = os.path.join(ROOT, "lumenrenderer_amd")
+    cmd = ["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-O2", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "render_scene.c"), "-o", exe, "-L" + libdir, "-llumen_mi", "-Wl,-rpath," + libdir]
+    build = subprocess.run(cmd, capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-3000:]
+    return exe

@@ -423,3 +423,27 @@ def test_cpp_adapter_header_compiles_against_the_reference_headers(tmp_path):
     errors = [l for l in run.stderr.splitlines() if " error: " in l]
     assert all(l.startswith(ref) or l.startswith("/usr/include/") for l in errors), errors
     assert len(errors) <= 3, errors            # LumenRenderer.h:166 aggregate default argument, FrameSnapshot.h unique_ptr of an incomplete type (+ Transform.h without -include)
+
+
+def test_c_header_is_c99_and_the_c_example_fails_loudly_without_a_gpu(tmp_path):
+    """include/lumen_mi.h is a C header (the boundary is a C ABI): strict C99 and C++17 syntax checks; examples/render_scene.c
+    (a caller in plain C) builds against it with -Werror and, with no GPU, stops at lumen_mi_init with LUMEN_MI_ERR_DEVICE."""
+    from helpers import build_c_example
+    from lumenrenderer_amd.scenes import write_scene_file
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for compiler, std, name in (("gcc", "-std=c99", "t.c"), ("g++", "-std=c++17", "t.cpp")):
+        src = tmp_path / name
+        src.write_text('#include "lumen_mi.h"\nint main(void) { return LUMEN_MI_OK; }\n')
+        run = subprocess.run([compiler, std, "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I" + os.path.join(root, "include"), str(src)],
+                             capture_output=True, text=True)
+        assert run.returncode == 0, run.stderr
+    exe = build_c_example(tmp_path)
+    scene = str(tmp_path / "cornell.slm")
+    write_scene_file(cornell(), scene)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the run itself is covered by the gpu tests")
+    run = subprocess.run([exe, scene, "32", "32", "2", "1", str(tmp_path / "out.ppm")], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 2 and "no HIP device" in run.stderr and not os.path.exists(tmp_path / "out.ppm")
+    bad = subprocess.run([exe, __file__, "32", "32", "2", "1", str(tmp_path / "out.ppm")], capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 64 and "not a scene file" in bad.stderr

@@ -205,6 +205,33 @@ def test_cornell_c1_frame_bit_exact():
     r.close(); o.close()
 
 
+def test_plain_c_caller_of_the_abi_renders_the_oracle_pixels(tmp_path):
+    """examples/render_scene.c: a C99 program that drives the whole boundary (textures, materials, primitives, meshes, scene,
+    instances, camera, blended frames, read-back) without Python in between; its PPM holds the oracle's sRGB8 output."""
+    import subprocess
+    from helpers import build_c_example
+    from lumenrenderer_amd.scenes import write_scene_file
+    d = cornell()
+    scene = str(tmp_path / "cornell.slm"); out = str(tmp_path / "out.ppm")
+    write_scene_file(d, scene)
+    exe = build_c_example(tmp_path)
+    W, H, depth, frames = 80, 56, 3, 3
+    run = subprocess.run([exe, scene, str(W), str(H), str(depth), str(frames), out], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, (run.stdout, run.stderr)
+    raw = open(out, "rb").read()
+    header = b"P6\n%d %d\n255\n" % (W, H)
+    assert raw.startswith(header) and len(raw) == len(header) + W * H * 3
+    got = np.frombuffer(raw[len(header):], np.uint8).reshape(H, W, 3)
+    o = oracle_from(d, W, H, depth, blend=True)
+    for _ in range(frames):
+        assert o.trace_frame() == 0
+    want = o.output_pixels()
+    assert np.array_equal(got, want[..., :3])
+    s = o.stats(24)
+    assert "%d closest-hit rays, %d shadow rays, %d visibility rays" % (s[0], s[1], s[2]) in run.stdout
+    o.close()
+
+
 def test_screenshot_of_the_output_matches_the_oracle_pixels(tmp_path):
     """OutputLayer::MakeScreenshot (Sandbox OutputLayer.cpp:882-896) over GetOutputTexturePixels: the PNG holds the oracle's
     sRGB8 output with the display gamma applied."""
