@@ -116,6 +116,16 @@ int traceFrameAsync(R* r)
     }
     if ((rc = ensureFrameBuffers(r))) return rc;
     const LmKernelTable* K = r->K;
+    // schedule fuzzing: per frame a random subset of the four streams is slow; three quarters of the launches on a slow stream are
+    // preceded by an idle wavefront of 0 - 1.5 ms (the order of magnitude of the kernels themselves); see lm_k_spin
+    auto fuzzNext = [&]() { uint32_t x = r->fuzz; x ^= x << 13; x ^= x >> 17; x ^= x << 5; r->fuzz = x ? x : 1u; return x; };
+    const uint32_t slowStreams = r->fuzz ? (fuzzNext() >> 7) & 15u : 0u;
+    auto Z = [&](hipStream_t s) {
+        if (!r->fuzz) return;
+        const int which = s == r->stream ? 0 : s == r->aux ? 1 : s == r->aux2 ? 2 : 3;
+        const uint32_t x = fuzzNext();
+        if (((slowStreams >> which) & 1u) && (x & 3u) != 0u) K->spin(s, (x >> 8) % 150000u);
+    };
     hipStream_t st = r->stream;
     LmFrame& fr = r->fr;
     const uint32_t depthMax = std::min<uint32_t>(r->settings.depth, LM_MAX_DEPTH);
@@ -162,9 +172,9 @@ int traceFrameAsync(R* r)
     r->fenceNeeded = false;
     size_t evAll; evBegin2(r, 4, evAll, sx);
     LM_HIP(hipMemsetAsync(fr.counters, 0, LM_CNT_WORDS * sizeof(uint32_t), sx));
-    if (!blend) K->clear(st, r->gridFor(fr.n, 8), fr.combined, fr.n);                        // :559
+    if (!blend) { Z(st); K->clear(st, r->gridFor(fr.n, 8), fr.combined, fr.n); }                        // :559
     ++r->frameCount;                                                                          // :593
-    K->primary(sx, r->gridFor(fr.n, 8), fr, cam, r->frameCount);
+    Z(sx); K->primary(sx, r->gridFor(fr.n, 8), fr, cam, r->frameCount);
     uint32_t seed = wangHash(r->frameCount);                                                  // :685
     LmScene scx = r->dscene;                                                                  // same scene, its own stack-spill area
     if (overlap) scx.spill += (size_t)r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS);
@@ -199,11 +209,11 @@ int traceFrameAsync(R* r)
         const int doIndirect = depth < depthMax - 1 ? 1 : 0;
         if (depth == 0) {
             evBegin2(r, 0, ev, sx);
-            K->trace_closest(sx, gridMain, scx, fr.rayO[q], fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters, r->refillPrimary);    // :678,:703
+            Z(sx); K->trace_closest(sx, gridMain, scx, fr.rayO[q], fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters, r->refillPrimary);    // :678,:703
             evEnd2(r, ev, sx);
             if (overlap) LM_HIP(hipStreamWaitEvent(sx, r->evTemporal[par], 0));          // the temporal pass two frames back has read what extraction overwrites
             evBegin2(r, 2, ev, sx);
-            K->extract0(sx, r->gridFor(fr.n, 8), r->dscene, (int)depth + 1 == tailDepth ? withTailQueue(fr, q ^ 1) : fr, cam, currentIndex, seed2, doIndirect, q ^ 1, outCount);   // + depth-0 continuation
+            Z(sx); K->extract0(sx, r->gridFor(fr.n, 8), r->dscene, (int)depth + 1 == tailDepth ? withTailQueue(fr, q ^ 1) : fr, cam, currentIndex, seed2, doIndirect, q ^ 1, outCount);   // + depth-0 continuation
             evEnd2(r, ev, sx);
             // the indirect waves follow on the same stream beside ReSTIR on the main stream: both depend only on the G-buffer
             // ReSTIR::Run (Framework/ReSTIR.cpp:65-233) on the main stream.  Candidate generation and the first visibility pass
@@ -221,22 +231,22 @@ int traceFrameAsync(R* r)
             evBegin2(r, 3, ev, sp);
             const int cur = LM_RES_CUR, tmp = LM_RES_PREV, fresh = pickAhead ? 4 : LM_RES_CUR;
             uint32_t rs = wangHash(seed);
-            K->fill_bags(sp, r->dscene, fr, seed, 50u * 1000u);
+            Z(sp); K->fill_bags(sp, r->dscene, fr, seed, 50u * 1000u);
             rs = wangHash(rs);
             const uint32_t tx0 = fr.x0 / 16u, ty0 = fr.y0 / 16u;
             const uint32_t wtx = (fr.x0 + fr.ww + 15u) / 16u - tx0, wty = (fr.y0 + fr.wh + 15u) / 16u - ty0;
-            K->pick_primary(sp, (int)(wtx * wty), r->dscene, fr, currentIndex, fresh, rs, fr.counters + LM_CNT_RESTIR(0));   // + visibility rays, pass 1
+            Z(sp); K->pick_primary(sp, (int)(wtx * wty), r->dscene, fr, currentIndex, fresh, rs, fr.counters + LM_CNT_RESTIR(0));   // + visibility rays, pass 1
             LmScene scp = r->dscene;                                 // the pick-ahead stream traces with its own stack-spill area
             if (sp != st) scp.spill += (size_t)3 * r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS);
-            K->trace_shade(sp, gridMain, scp, fr, fresh, fr.counters + LM_CNT_RESTIR(0), r->refillVisibility, 0);
+            Z(sp); K->trace_shade(sp, gridMain, scp, fr, fresh, fr.counters + LM_CNT_RESTIR(0), r->refillVisibility, 0);
             evEnd2(r, ev, sp);
             if (pickAhead) { LM_HIP(hipEventRecord(r->evPick, sp)); LM_HIP(hipStreamWaitEvent(st, r->evPick, 0)); }
             evBegin(r, 3, ev);
             rs = wangHash(rs);
-            K->temporal(st, tiles, fr, currentIndex, temporalIndex, cur, tmp, fresh, rs, fr.counters + LM_CNT_RESTIR(1));         // + visibility rays, pass 2
+            Z(st); K->temporal(st, tiles, fr, currentIndex, temporalIndex, cur, tmp, fresh, rs, fr.counters + LM_CNT_RESTIR(1));         // + visibility rays, pass 2
             if (overlap) LM_HIP(hipEventRecord(r->evTemporal[par], st));
             rs = wangHash(rs);
-            K->spatial(st, tiles, fr, currentIndex, cur, 2, rs, 30);
+            Z(st); K->spatial(st, tiles, fr, currentIndex, cur, 2, rs, 30);
             // second visibility pass (ReSTIR.cpp:211-212) works on the CURRENT buffer, which the second spatial pass does not
             // touch: trace it beside that pass.  (It must follow the first spatial pass, which reads the current buffer.)
             hipStream_t sv = (overlap && !pickAhead) ? r->aux3 : st;
@@ -245,11 +255,11 @@ int traceFrameAsync(R* r)
                 scv.spill += (size_t)3 * r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS);
                 LM_HIP(hipEventRecord(r->evVis, st)); LM_HIP(hipStreamWaitEvent(sv, r->evVis, 0));
             }
-            K->trace_shade(sv, gridMain, scv, fr, cur, fr.counters + LM_CNT_RESTIR(1), r->refillVisibility, 1);
+            Z(sv); K->trace_shade(sv, gridMain, scv, fr, cur, fr.counters + LM_CNT_RESTIR(1), r->refillVisibility, 1);
             if (sv != st) LM_HIP(hipEventRecord(r->evVisDone, sv));
-            K->spatial(st, tiles, fr, currentIndex, 2, 3, rs, 0);
+            Z(st); K->spatial(st, tiles, fr, currentIndex, 2, 3, rs, 0);
             if (sv != st) LM_HIP(hipStreamWaitEvent(st, r->evVisDone, 0));
-            K->combine(st, tiles, fr, currentIndex, cur, 3, wangHash(rs));
+            Z(st); K->combine(st, tiles, fr, currentIndex, cur, 3, wangHash(rs));
             evEnd(r, ev);
         } else if ((int)depth >= tailDepth) {
             // path tail: the remaining waves in one launch (kernels.hip lm_k_path_tail) on the shadow stream: its INDIRECT adds
@@ -261,7 +271,7 @@ int traceFrameAsync(R* r)
                 LM_HIP(hipEventRecord(r->evShade[depth], sx)); LM_HIP(hipStreamWaitEvent(stl, r->evShade[depth], 0));     // the queue's producer is done
             }
             evBegin2(r, 0, ev, stl);
-            K->path_tail(stl, r->numCU * 8, sct, withTailQueue(fr, q), q, inCount, (int)depth, (int)depthMax, seed, r->tailLanes);
+            Z(stl); K->path_tail(stl, r->numCU * 8, sct, withTailQueue(fr, q), q, inCount, (int)depth, (int)depthMax, seed, r->tailLanes);
             evEnd2(r, ev, stl);
             if (overlap) LM_HIP(hipEventRecord(r->evTail, stl));
             tailLaunched = true;
@@ -269,11 +279,11 @@ int traceFrameAsync(R* r)
         } else {
             uint32_t* shCount = fr.counters + LM_CNT_SHADOW(depth);
             evBegin2(r, 0, ev, sx);
-            K->trace_closest(sx, gridAux, scx, fr.rayO[q], fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters, r->refillBelow);
+            Z(sx); K->trace_closest(sx, gridAux, scx, fr.rayO[q], fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters, r->refillBelow);
             evEnd2(r, ev, sx);
             if (overlap) LM_HIP(hipStreamWaitEvent(sx, r->evJoin2, 0));                   // previous wave's (or frame's) shadow rays consumed
             evBegin2(r, 2, ev, sx);
-            K->shade_wave(sx, r->numCU * 8, scx, (int)depth + 1 == tailDepth ? withTailQueue(fr, q ^ 1) : fr, q, inCount, seed, seed2, doIndirect, outCount, shCount);
+            Z(sx); K->shade_wave(sx, r->numCU * 8, scx, (int)depth + 1 == tailDepth ? withTailQueue(fr, q ^ 1) : fr, q, inCount, seed, seed2, doIndirect, outCount, shCount);
             evEnd2(r, ev, sx);
             // NEE shadow rays of this wave: third stream, beside the next wave's closest-hit launch.  The shadow queue is
             // rewritten by the NEXT shade_wave, which therefore waits for this launch (evJoin2).  (`shadow_on_wave` 1 keeps them on
@@ -283,7 +293,7 @@ int traceFrameAsync(R* r)
             LmScene scs = scx;
             if (ss != sx) { scs.spill += (size_t)r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS); LM_HIP(hipEventRecord(r->evShade[depth], sx)); LM_HIP(hipStreamWaitEvent(ss, r->evShade[depth], 0)); }
             evBegin2(r, 1, ev, ss);
-            K->trace_shadow(ss, gridAux, scs, fr, shCount, 0.01f, r->refillBelow);     // tmin of the intersection launch (:843)
+            Z(ss); K->trace_shadow(ss, gridAux, scs, fr, shCount, 0.01f, r->refillBelow);     // tmin of the intersection launch (:843)
             evEnd2(r, ev, ss);
             if (overlap) { LM_HIP(hipEventRecord(r->evJoin2, ss)); }
         }
@@ -295,7 +305,7 @@ int traceFrameAsync(R* r)
         if (depthMax > 1) LM_HIP(hipStreamWaitEvent(st, r->evJoin2, 0));
         if (tailLaunched) LM_HIP(hipStreamWaitEvent(st, r->evTail, 0));
     }
-    K->merge(st, r->gridFor(fr.n, 8), fr, blend ? 1 : 0, r->blendCounter, (int)depthMax);     // + ReSTIR::SwapBuffers per executed wave
+    Z(st); K->merge(st, r->gridFor(fr.n, 8), fr, blend ? 1 : 0, r->blendCounter, (int)depthMax);     // + ReSTIR::SwapBuffers per executed wave
     if (r->pinnedCounters[par]) {     // asynchronous counter read-back: feeds the next frames' schedule (above); before evMerge, which
         // releases this counter block to the frame after next
         LM_HIP(hipMemcpyAsync(r->pinnedCounters[par], fr.counters, LM_CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));

@@ -902,6 +902,14 @@ KN(lm_k_refit_level)(LmScene sc, const uint32_t* __restrict__ levelNodes, uint32
     nodeBox[2u * n + 1u] = v4(nhi, 0.f);
 }
 
+// Schedule fuzzing (tuning key "fuzz"): a single wavefront that holds its stream busy for a while.  Inserted at random in front of
+// the launches of a frame, it shifts what overlaps with what; a missing dependency between streams then shows as a changed image.
+extern "C" __global__ void KN(lm_k_spin)(uint32_t ticks)
+{
+    const uint64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < (uint64_t)ticks) __builtin_amdgcn_s_sleep(8);
+}
+
 #define LM_GRID(g) dim3((unsigned)(g)), dim3(LM_BLOCK), 0, s
 
 static void l_primary(hipStream_t s, int g, LmFrame fr, LmCamera cam, uint32_t frameCount) { hipLaunchKernelGGL(KN(lm_k_primary), LM_GRID(g), fr, cam, frameCount); }
@@ -932,6 +940,7 @@ static void l_refit_level(hipStream_t s, LmScene sc, const uint32_t* levelNodes,
 static void l_test_bsdf(hipStream_t s, uint32_t n, int mode, const float* mat, const float* N, const float* T, const float* wo, const float* aux, float* out)
 { hipLaunchKernelGGL(KN(lm_k_test_bsdf), LM_GRID((n + LM_BLOCK - 1) / LM_BLOCK), n, mode, mat, N, T, wo, aux, out); }
 static void l_test_math(hipStream_t s, uint32_t n, int fn, const float* x, const float* y, float* out) { hipLaunchKernelGGL(KN(lm_k_test_math), LM_GRID((n + LM_BLOCK - 1) / LM_BLOCK), n, fn, x, y, out); }
+static void l_spin(hipStream_t s, uint32_t ticks) { hipLaunchKernelGGL(KN(lm_k_spin), dim3(1), dim3(64), 0, s, ticks); }
 
 #if LM_INSTRUMENT
 extern "C" const LmKernelTable* lm_kernel_table_instrumented()
@@ -940,6 +949,6 @@ extern "C" const LmKernelTable* lm_kernel_table()
 #endif
 {
     static const LmKernelTable t = {l_primary, l_trace_closest, l_extract0, l_shade_wave, l_trace_shadow, l_path_tail, l_fill_bags, l_pick_primary,
-                                    l_trace_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_export_aux, l_refit_tris, l_refit_quant, l_refit_level, l_test_bsdf, l_test_math};
+                                    l_trace_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_export_aux, l_refit_tris, l_refit_quant, l_refit_level, l_test_bsdf, l_test_math, l_spin};
     return &t;
 }

@@ -25,6 +25,7 @@ struct LmKernelTable {
     void (*refit_level)(hipStream_t, LmScene, const uint32_t* levelNodes, uint32_t count, const float4* triBox, float4* nodeBox);
     void (*test_bsdf)(hipStream_t, uint32_t n, int mode, const float* mat, const float* N, const float* T, const float* wo, const float* aux, float* out);
     void (*test_math)(hipStream_t, uint32_t n, int fn, const float* x, const float* y, float* out);
+    void (*spin)(hipStream_t, uint32_t ticks);        // one idle wavefront for `ticks` of the 100 MHz wall clock (schedule fuzzing, frame.cpp)
 };
 extern "C" const LmKernelTable* lm_kernel_table();
 extern "C" const LmKernelTable* lm_kernel_table_instrumented();

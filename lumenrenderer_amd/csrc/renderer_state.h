@@ -119,6 +119,7 @@ struct lumen_mi_renderer {
     hipEvent_t evJoin = nullptr, evJoin2 = nullptr, evVis = nullptr, evVisDone = nullptr;
     hipEvent_t evPick = nullptr;
     int pickAhead = 1;                      // 1 on (default), 0 off, -1 only for windows under 1 Mpixel
+    uint32_t fuzz = 0;                      // != 0: schedule fuzzing (test aid): random idle launches in front of the kernels of a frame, this is the RNG state
     int shadowOnWave = 0;                   // 1: NEE shadow rays on the wave stream (the path tail then has the third stream to itself); measured: 8 % slower for half-frame windows, equal elsewhere
     hipEvent_t evFront = nullptr, evTemporal[2] = {nullptr, nullptr}, evTop = nullptr, evMerge[2] = {nullptr, nullptr};   // cross-frame pipelining (traceFrameAsync)
     int framePar = 0;                       // parity of the frame being enqueued: selects the channel buffers and the counter block

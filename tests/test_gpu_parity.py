@@ -730,6 +730,42 @@ def test_full_size_moving_scene_async_equals_serial():
     assert out[0][3] == out[1][3]
 
 
+@pytest.mark.parametrize("fuzz_seed", list(range(1, 13)))
+def test_schedule_fuzzing_does_not_change_the_image(fuzz_seed):
+    """Tuning key "fuzz": idle wavefronts of random length (0-200 us) in front of a random quarter of the launches of every frame
+    shift what overlaps with what across the four streams and the two frames in flight.  A missing event dependency would show as a
+    changed image; camera and scene move so that every cross-frame hazard (G-buffer rotation, reservoir swap chain, scene sets,
+    motion vectors, tail queue) is live.  Compared with the serial schedule."""
+    from lumenrenderer_amd.scenes import sponza_standin
+    W, H, D = 1280, 720, 5                                           # odd depth: temporal reuse reads real history
+    def run(tuning, sync_each):
+        d = sponza_standin()
+        base = np.array(d.instances[0]["transform"], np.float32).reshape(4, 4)
+        r = product_from(d, W, H, D, blend=True, tuning=tuning)
+        for k in range(10):
+            if k % 3 != 2:
+                m = base.copy(); m[1, 3] += 0.002 * k
+                r.m_Scene.m_MeshInstances[0].SetTransform(m)
+            if k == 4:
+                r.m_Scene.m_MeshInstances[1].SetEmissiveness(2, (9.0, 8.0, 7.0), 30.0)
+            c = d.camera
+            r.SetCamera((c["position"][0] + 0.01 * k, c["position"][1], c["position"][2]), c["right"], c["up"], c["forward"], c["fov"])
+            assert r.TraceFrameAsync()
+            if sync_each:
+                r.Synchronize()
+        r.Synchronize()
+        out = (r.GetRadiance().copy(), r.GetChannel(0).copy(), r.GetChannel(1).copy(), list(r.GetCounters()[:12]))
+        r.close()
+        return out
+    global _FUZZ_REFERENCE
+    if "_FUZZ_REFERENCE" not in globals():
+        _FUZZ_REFERENCE = run({"single_stream": 1, "tail_below": 0, "pick_ahead": 0}, True)
+    got = run({"fuzz": 0x9E3779B1 * fuzz_seed & 0x7fffffff, "tail_below": (0, 1 << 30, 60000)[fuzz_seed % 3]}, False)
+    for a, b in zip(got[:3], _FUZZ_REFERENCE[:3]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), int(np.sum(a != b))
+    assert got[3] == _FUZZ_REFERENCE[3]
+
+
 def test_full_size_stitched_tiles_async():
     """The 8-rank decomposition of the benchmark frame (1440p, depth 6, 4 blended frames enqueued back to back per rank, owned-
     tile restriction on): the rank windows are large enough for real overlap of streams and frames, and the path tail / pick-
