@@ -162,10 +162,16 @@ def main():
         warm = torch.zeros(1, device=dev); dist.all_reduce(warm)                                   # communicator + stream exist now
         torch.cuda.synchronize()
 
+    # temporal history across tile seams: only a path depth with an odd number of waves per frame has any (tiles.history_needed);
+    # then every TraceFrame is followed by one grouped RCCL send / recv of the halo rings' reservoirs
+    hx = tiles.HistoryExchange(r, rank, world, W, H, dev) if (world > 1 and tiles.history_needed(depth)) else None
+
     def frame():
         r.SetBlendMode(True)                              # a fresh 4-spp accumulation per displayed frame
         for _ in range(spp):
             r.TraceFrameAsync()
+            if hx is not None:
+                hx.run(dist)
         r.CopyRadianceToDevice(window_buf.data_ptr())
         local = window_buf[tile[1] - win[1]: tile[3] - win[1], tile[0] - win[0]: tile[2] - win[0]]
         return local if emu else tiles.gather_tiles(local, rank, world, W, H, dist)

@@ -155,6 +155,12 @@ int lumen_mi_set_tuning(lumen_mi_renderer*, const char* key, int value);
 /* render only [x0,x1) x [y0,y1) of the image; RNG streams stay those of the full image.  The window stays set across resolution
  * changes (a frame whose window does not fit the image fails with LUMEN_MI_ERR_INVALID); (0,0,0,0) returns to the whole image. */
 int lumen_mi_set_window(lumen_mi_renderer*, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1);
+/* Temporal history across tile seams.  After a frame, [x0,x1) x [y0,y1) (global pixels inside the window) of the reservoirs the NEXT
+ * frame's temporal reuse reads as "previous" (ReSTIRKernels.cu:1015-1121) is packed to / unpacked from device memory, 80 bytes per
+ * pixel, enqueued on the renderer's stream.  A rank exports the part of its tile that lies in a neighbour's halo and imports its own
+ * halo ring from the owners, so that reuse across seams sees what a single GPU would (lumenrenderer_amd/tiles.py exchange_history). */
+int lumen_mi_export_history(lumen_mi_renderer*, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, void* device_dst);
+int lumen_mi_import_history(lumen_mi_renderer*, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, const void* device_src);
 /* The part of the render window this renderer OWNS (global pixel coordinates, inside the window; an empty rectangle = the whole
  * window).  Pixels of the window outside it are halo: they are rendered as far as the owned pixels' ReSTIR reuse needs them (surface
  * data, candidates, temporal pass, first reuse pass within 30 pixels), but get no indirect light, no second reuse pass and no

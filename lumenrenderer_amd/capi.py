@@ -69,12 +69,35 @@ SYMBOLS = {
     "lumen_mi_get_denoiser_inputs": [_R, C.c_float, C.c_float, _FP, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16)],
     "lumen_mi_set_window": [_R, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32],
     "lumen_mi_set_tile": [_R, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32],
+    "lumen_mi_export_history": [_R, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p],
+    "lumen_mi_import_history": [_R, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p],
     "lumen_mi_query_closest": [_R, C.c_uint32, _FP, _FP, C.c_float, C.c_float, _U32P, _FP],
     "lumen_mi_query_any": [_R, C.c_uint32, _FP, _FP, C.c_float, _FP, _U8P],
     "lumen_mi_test_bsdf": [_R, C.c_uint32, C.c_int, _FP, _FP, _FP, _FP, _FP, _FP], "lumen_mi_test_math": [_R, C.c_uint32, C.c_int, _FP, _FP, _FP],
     "lumen_mi_get_world_triangles": [_R, _FP, C.c_uint32, _U32P], "lumen_mi_get_lights": [_R, _FP, _FP, C.c_uint32, _U32P],
     "lumen_mi_get_bvh_info": [_R, _U32P, _U32P, _U32P],
 }
+
+
+def _share_the_hip_runtime_with_torch():
+    """PyTorch's ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 and load them by a path-qualified name.  If
+    liblumen_mi.so (NEEDED libamdhip64.so.7, found under /opt/rocm/lib) is loaded BEFORE torch, the process ends up with two HIP
+    runtimes and the second one finds no GPU ("No HIP GPUs are available"), and device pointers could not be shared either.
+    Loading torch's copy first (same SONAME) makes both bind to one runtime whichever is imported first.  Without a torch install
+    nothing happens and the system runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    hip = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(hip):
+        try:
+            C.CDLL(hip, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass                                   # fall back to the system runtime; torch, if imported later, reports the clash itself
 
 
 def load_library():
@@ -89,6 +112,7 @@ def load_library():
     # four busy HIP streams + whatever the host adds (RCCL): HIP's default of 4 hardware queues makes busy streams share one and
     # serialise; takes effect only if HIP has not been initialised in this process yet
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    _share_the_hip_runtime_with_torch()
     lib = C.CDLL(path)
     for name, args in SYMBOLS.items():
         f = getattr(lib, name)

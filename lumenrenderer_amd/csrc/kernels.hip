@@ -803,6 +803,26 @@ KN(lm_k_export_aux)(LmFrame fr, int cur, float minD, float maxD, float* __restri
     }
 }
 
+// Multi-GPU seams: pack / unpack a rectangle (window-local pixels) of the reservoirs the NEXT frame's temporal pass reads as
+// "previous" (5 float4 per pixel: the 64-byte hot record + the contribution plane).  Runs after the merge of a frame, which has
+// advanced the swap chain, so LM_RES_PREV already names that buffer.  A rank sends the part of its tile that lies in a
+// neighbour's halo and receives its own halo ring the same way (lumenrenderer_amd/tiles.py exchange_history).
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_history_copy)(LmFrame fr, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, float4* __restrict__ buf, int import)
+{
+    const int rp = lm_res_idx(fr, LM_RES_PREV);
+    float4* hot = fr.res[rp];
+    float4* con = fr.resC[rp];
+    const uint32_t n = w * h, stride = gridDim.x * LM_BLOCK;
+    for (uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x; i < n; i += stride) {
+        const uint32_t yy = i / w, xx = i - yy * w;
+        const uint32_t li = (y0 + yy) * fr.ww + (x0 + xx);
+        float4* b = buf + 5u * i;
+        if (import) { for (uint32_t k = 0; k < 4u; k++) hot[4u * li + k] = b[k]; con[li] = b[4]; }
+        else { for (uint32_t k = 0; k < 4u; k++) b[k] = hot[4u * li + k]; b[4] = con[li]; }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // BVH refit for moved instances (reference: the per-frame instance acceleration-structure rebuild of PTScene.cpp:74-156,
 // PTMeshInstance.cpp:123-178).  Topology and leaf contents stay; triangles are re-transformed, Woop packets recomputed
@@ -940,6 +960,8 @@ static void l_refit_level(hipStream_t s, LmScene sc, const uint32_t* levelNodes,
 static void l_test_bsdf(hipStream_t s, uint32_t n, int mode, const float* mat, const float* N, const float* T, const float* wo, const float* aux, float* out)
 { hipLaunchKernelGGL(KN(lm_k_test_bsdf), LM_GRID((n + LM_BLOCK - 1) / LM_BLOCK), n, mode, mat, N, T, wo, aux, out); }
 static void l_test_math(hipStream_t s, uint32_t n, int fn, const float* x, const float* y, float* out) { hipLaunchKernelGGL(KN(lm_k_test_math), LM_GRID((n + LM_BLOCK - 1) / LM_BLOCK), n, fn, x, y, out); }
+static void l_history_copy(hipStream_t s, int g, LmFrame fr, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, float4* buf, int import)
+{ hipLaunchKernelGGL(KN(lm_k_history_copy), LM_GRID(g), fr, x0, y0, w, h, buf, import); }
 static void l_spin(hipStream_t s, uint32_t ticks) { hipLaunchKernelGGL(KN(lm_k_spin), dim3(1), dim3(64), 0, s, ticks); }
 
 #if LM_INSTRUMENT
@@ -949,6 +971,6 @@ extern "C" const LmKernelTable* lm_kernel_table()
 #endif
 {
     static const LmKernelTable t = {l_primary, l_trace_closest, l_extract0, l_shade_wave, l_trace_shadow, l_path_tail, l_fill_bags, l_pick_primary,
-                                    l_trace_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_export_aux, l_refit_tris, l_refit_quant, l_refit_level, l_test_bsdf, l_test_math, l_spin};
+                                    l_trace_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_export_aux, l_refit_tris, l_refit_quant, l_refit_level, l_test_bsdf, l_test_math, l_spin, l_history_copy};
     return &t;
 }

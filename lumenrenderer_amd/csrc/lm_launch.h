@@ -26,6 +26,7 @@ struct LmKernelTable {
     void (*test_bsdf)(hipStream_t, uint32_t n, int mode, const float* mat, const float* N, const float* T, const float* wo, const float* aux, float* out);
     void (*test_math)(hipStream_t, uint32_t n, int fn, const float* x, const float* y, float* out);
     void (*spin)(hipStream_t, uint32_t ticks);        // one idle wavefront for `ticks` of the 100 MHz wall clock (schedule fuzzing, frame.cpp)
+    void (*history_copy)(hipStream_t, int grid, LmFrame, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, float4* buf, int import);
 };
 extern "C" const LmKernelTable* lm_kernel_table();
 extern "C" const LmKernelTable* lm_kernel_table_instrumented();

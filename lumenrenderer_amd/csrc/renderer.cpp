@@ -418,6 +418,23 @@ int lumen_mi_copy_radiance_device(lumen_mi_renderer* r, void* dst)
     LM_HIP(hipMemcpyAsync(dst, r->fr.combined, (size_t)r->fr.n * 16, hipMemcpyDeviceToDevice, r->stream));
     return 0;
 }
+// multi-GPU seams: see lm_k_history_copy (kernels.hip) and tiles.py exchange_history
+static int historyCopy(lumen_mi_renderer* r, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, void* dev, int import)
+{
+    if (!r || !dev) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    ApiLock lk(r);
+    if (!r->fr.combined || !r->fr.n) return fail(LUMEN_MI_ERR_STATE, "no frame has been traced yet");
+    const LmFrame& f = r->fr;
+    if (x0 >= x1 || y0 >= y1 || x0 < f.x0 || y0 < f.y0 || x1 > f.x0 + f.ww || y1 > f.y0 + f.wh) return fail(LUMEN_MI_ERR_INVALID, "rectangle outside the render window");
+    if (hipSetDevice(r->device) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "hipSetDevice failed");
+    const uint32_t w = x1 - x0, h = y1 - y0;
+    r->K->history_copy(r->stream, r->gridFor(w * h, 8), f, x0 - f.x0, y0 - f.y0, w, h, (float4*)dev, import);
+    LM_HIP(hipGetLastError());
+    return 0;
+}
+int lumen_mi_export_history(lumen_mi_renderer* r, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, void* device_dst) { return historyCopy(r, x0, y0, x1, y1, device_dst, 0); }
+int lumen_mi_import_history(lumen_mi_renderer* r, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, const void* device_src) { return historyCopy(r, x0, y0, x1, y1, (void*)device_src, 1); }
+
 int lumen_mi_get_gbuffer(lumen_mi_renderer* r, float* out, size_t cap)
 {
     if (!r || !out) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");

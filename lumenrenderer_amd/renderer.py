@@ -183,6 +183,13 @@ class LumenRendererMI:
     def SetWindow(self, x0, y0, x1, y1): check(self.lib, self.lib.lumen_mi_set_window(self.h, x0, y0, x1, y1))
     def SetTile(self, x0, y0, x1, y1): check(self.lib, self.lib.lumen_mi_set_tile(self.h, x0, y0, x1, y1))
 
+    def ExportHistory(self, rect, device_ptr):
+        """Pack rect = (x0, y0, x1, y1) of the reservoirs the next frame reads as "previous" into device memory (80 bytes / pixel)."""
+        check(self.lib, self.lib.lumen_mi_export_history(self.h, *[int(v) for v in rect], C.c_void_p(int(device_ptr))))
+
+    def ImportHistory(self, rect, device_ptr):
+        check(self.lib, self.lib.lumen_mi_import_history(self.h, *[int(v) for v in rect], C.c_void_p(int(device_ptr))))
+
     # ---- rendering -------------------------------------------------------------------------------------------------
     def TraceFrame(self):
         """Blocking frame; returns False when the frame was skipped because the scene has no lights."""

@@ -6,7 +6,8 @@ neighbours within +-30 px each (ReSTIRData.h:46-56).  RNG streams, Halton indice
 GLOBAL pixel coordinate, so a tile pixel whose whole 60-px neighbourhood lies inside the window gets exactly the
 single-GPU value for a first frame; across blended frames the temporal history of the outer halo ring is window-local
 (DESIGN.md §Multi-GPU states the seam behaviour).  The only collective is one gather of the final fp32 radiance tiles
-(RCCL over xGMI when the backend is nccl; gloo on CPU in the tests).
+(RCCL over xGMI when the backend is nccl; gloo on CPU in the tests); for path depths with temporal history an additional
+point-to-point exchange of the halo rings' reservoirs after every frame keeps the seams exact (halo_plan, HistoryExchange below).
 """
 import math
 
@@ -70,3 +71,80 @@ def gather_tiles(local_tile, rank, world, width, height, dist, dst=0):
         x0, y0, x1, y1 = tile_rect(r, world, width, height)
         img[y0:y1, x0:x1] = parts[r][: y1 - y0, : x1 - x0]
     return img
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# temporal history across seams (option B for the history only)
+# ---------------------------------------------------------------------------------------------------------------------
+HISTORY_FLOATS = 20        # per pixel: the 64-byte reservoir record + the contribution plane (include/lumen_mi.h lumen_mi_export_history)
+
+
+def _intersect(a, b):
+    x0, y0, x1, y1 = max(a[0], b[0]), max(a[1], b[1]), min(a[2], b[2]), min(a[3], b[3])
+    return (x0, y0, x1, y1) if x0 < x1 and y0 < y1 else None
+
+
+def halo_plan(rank, n, width, height):
+    """What rank exchanges after every frame so that temporal reuse in its halo ring sees the owners' reservoirs: a list of
+    (peer, send_rect, recv_rect) in global pixels — send = my tile inside the peer's window, recv = the peer's tile inside my
+    window (either may be None).  The halo ring of a window is the disjoint union of the recv rectangles."""
+    mine = tile_rect(rank, n, width, height)
+    my_window = window_rect(mine, width, height)
+    plan = []
+    for peer in range(n):
+        if peer == rank:
+            continue
+        theirs = tile_rect(peer, n, width, height)
+        send = _intersect(mine, window_rect(theirs, width, height))
+        recv = _intersect(theirs, my_window)
+        if send or recv:
+            plan.append((peer, send, recv))
+    return plan
+
+
+def history_needed(depth):
+    """With an even number of executed waves per frame the reference's buffer-swap quirk leaves temporal reuse without history
+    (DESIGN.md §7), so there is nothing to exchange; the number of executed waves is the path depth unless the rays run out."""
+    return depth % 2 == 1
+
+
+def exchange_buffers(plan, send_buffers, recv_buffers, dist):
+    """One grouped point-to-point exchange (RCCL send / recv over xGMI with the nccl backend; gloo in the CPU tests).
+    send_buffers / recv_buffers: peer -> contiguous tensor.  Returns when the receives are complete on the current stream."""
+    ops = []
+    for peer, send, recv in plan:
+        if recv is not None:
+            ops.append(dist.P2POp(dist.irecv, recv_buffers[peer], peer))
+        if send is not None:
+            ops.append(dist.P2POp(dist.isend, send_buffers[peer], peer))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+
+class HistoryExchange:
+    """Per-rank state of the seam exchange: the plan and its device staging buffers (allocated once)."""
+
+    def __init__(self, renderer, rank, world, width, height, device):
+        import torch
+        self.r, self.plan = renderer, halo_plan(rank, world, width, height)
+        area = lambda q: (q[2] - q[0]) * (q[3] - q[1])
+        self.send = {p: torch.empty(area(s) * HISTORY_FLOATS, dtype=torch.float32, device=device) for p, s, _ in self.plan if s}
+        self.recv = {p: torch.empty(area(q) * HISTORY_FLOATS, dtype=torch.float32, device=device) for p, _, q in self.plan if q}
+
+    def pack(self):
+        for peer, send, _ in self.plan:
+            if send:
+                self.r.ExportHistory(send, self.send[peer].data_ptr())
+
+    def unpack(self):
+        for peer, _, recv in self.plan:
+            if recv:
+                self.r.ImportHistory(recv, self.recv[peer].data_ptr())
+
+    def run(self, dist):
+        """Call after every TraceFrame(Async): everything is stream-ordered behind the frame's merge and ahead of the next frame's
+        temporal pass (the renderer's stream must be torch's current stream: LumenRendererMI.set_stream)."""
+        self.pack()
+        exchange_buffers(self.plan, self.send, self.recv, dist)
+        self.unpack()

@@ -447,3 +447,73 @@ def test_c_header_is_c99_and_the_c_example_fails_loudly_without_a_gpu(tmp_path):
     assert run.returncode == 2 and "no HIP device" in run.stderr and not os.path.exists(tmp_path / "out.ppm")
     bad = subprocess.run([exe, __file__, "32", "32", "2", "1", str(tmp_path / "out.ppm")], capture_output=True, text=True, timeout=120)
     assert bad.returncode == 64 and "not a scene file" in bad.stderr
+
+
+def test_halo_plan_is_symmetric_and_tiles_the_ring():
+    """tiles.halo_plan: what rank A sends to B is what B expects from A, and a window's halo ring is the disjoint union of what it
+    receives (every ring pixel has exactly one owner)."""
+    from lumenrenderer_amd import tiles
+    for n in (2, 4, 8):
+        for W, H in ((2560, 1440), (3840, 2160), (416, 300), (257, 131)):
+            for r in range(n):
+                tile = tiles.tile_rect(r, n, W, H); win = tiles.window_rect(tile, W, H)
+                cover = np.zeros((H, W), np.int32)
+                for peer, send, recv in tiles.halo_plan(r, n, W, H):
+                    back = [p for p in tiles.halo_plan(peer, n, W, H) if p[0] == r]
+                    assert len(back) == 1 and back[0][1] == recv and back[0][2] == send
+                    if recv:
+                        cover[recv[1]:recv[3], recv[0]:recv[2]] += 1
+                    if send:
+                        assert tile[0] <= send[0] and tile[1] <= send[1] and send[2] <= tile[2] and send[3] <= tile[3]
+                ring = np.zeros((H, W), np.int32); ring[win[1]:win[3], win[0]:win[2]] = 1; ring[tile[1]:tile[3], tile[0]:tile[2]] = 0
+                assert np.array_equal(cover, ring)
+    assert tiles.history_needed(5) and not tiles.history_needed(6)
+
+
+_HALO_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from lumenrenderer_amd import tiles
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+W, H, F = 416, 300, tiles.HISTORY_FLOATS
+def owner_value(r):                                  # what rank r's reservoirs "are": a function of the owner and the global pixel
+    y, x = np.mgrid[0:H, 0:W]
+    return ((y * W + x)[..., None] * F + np.arange(F)[None, None, :] + 1000003 * (r + 1)).astype(np.float32)
+tile = tiles.tile_rect(rank, world, W, H); win = tiles.window_rect(tile, W, H)
+plan = tiles.halo_plan(rank, world, W, H)
+mine = owner_value(rank)
+image = np.full((H, W, F), -1.0, np.float32)
+image[tile[1]:tile[3], tile[0]:tile[2]] = mine[tile[1]:tile[3], tile[0]:tile[2]]
+send = {p: torch.from_numpy(mine[s[1]:s[3], s[0]:s[2]].copy().reshape(-1)) for p, s, _ in plan if s}      # lumen_mi_export_history's layout
+recv = {p: torch.empty((q[2] - q[0]) * (q[3] - q[1]) * F, dtype=torch.float32) for p, _, q in plan if q}
+tiles.exchange_buffers(plan, send, recv, dist)
+for p, _, q in plan:
+    if q:
+        image[q[1]:q[3], q[0]:q[2]] = recv[p].numpy().reshape(q[3] - q[1], q[2] - q[0], F)               # lumen_mi_import_history
+for r in range(world):
+    t = tiles.tile_rect(r, world, W, H)
+    x0, y0, x1, y1 = max(t[0], win[0]), max(t[1], win[1]), min(t[2], win[2]), min(t[3], win[3])
+    if x0 < x1 and y0 < y1:
+        assert np.array_equal(image[y0:y1, x0:x1], owner_value(r)[y0:y1, x0:x1]), (rank, r)
+assert (image[win[1]:win[3], win[0]:win[2]] >= 0).all()
+dist.barrier()
+if rank == 0:
+    open(sys.argv[2], "w").write("ok")
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_seam_history_exchange_gloo(world, tmp_path):
+    """The point-to-point exchange of tiles.exchange_buffers between real processes (gloo on CPU; RCCL on the GPUs): after it, every
+    pixel of a rank's window holds its owner's value."""
+    script = tmp_path / "halo_worker.py"; script.write_text(_HALO_WORKER)
+    out = tmp_path / "ok.txt"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
+           "--master-port", str(29519 + world), str(script), ROOT, str(out)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert os.path.exists(out)

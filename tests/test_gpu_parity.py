@@ -114,6 +114,20 @@ def test_empty_and_degenerate_geometry():
     r.close(); o.close()
 
 
+def test_library_and_torch_share_one_hip_runtime_in_either_import_order():
+    """torch bundles its own HIP runtime; loaded after liblumen_mi.so it used to become a second runtime that finds no GPU.
+    capi.load_library binds both to one copy: a torch tensor's device pointer is usable by the library in both import orders."""
+    import subprocess, sys
+    body = ("r = LumenRendererMI(); r.Init(depth=2, render_resolution=(32, 32)); r.LoadSceneDescription(cornell()); assert r.TraceFrame();"
+            "t = torch.zeros((32, 32, 4), dtype=torch.float32, device='cuda:0'); r.CopyRadianceToDevice(t.data_ptr()); r.Synchronize(); torch.cuda.synchronize();"
+            "import numpy as np; assert np.array_equal(t.cpu().numpy().view(np.uint32), r.GetRadiance().view(np.uint32)) and float(t.abs().sum()) > 0; print('shared ok')")
+    pre = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); from helpers import cornell;" % (os.path.dirname(GOLDEN), os.path.dirname(os.path.dirname(GOLDEN)))
+    for order in ("from lumenrenderer_amd import LumenRendererMI; _r0 = LumenRendererMI(); _r0.Init(depth=1, render_resolution=(8, 8)); import torch;",
+                  "import torch; torch.zeros(1, device='cuda:0'); from lumenrenderer_amd import LumenRendererMI;"):
+        run = subprocess.run([sys.executable, "-c", pre + order + body], capture_output=True, text=True, timeout=600)
+        assert run.returncode == 0 and "shared ok" in run.stdout, (order, run.stdout[-500:], run.stderr[-2000:])
+
+
 def test_c_abi_reports_bad_arguments_and_call_order():
     """Error behaviour at the boundary: what the reference asserts on (or dereferences) comes back as a status + message, and a
     failed call leaves the renderer usable.  Codes: 1 INVALID, 3 STATE (include/lumen_mi.h)."""
@@ -695,6 +709,68 @@ def test_stitched_tiles_equal_the_single_gpu_frame(n_ranks):
             got[tile[1]:tile[3], tile[0]:tile[2]] = rad[tile[1] - win[1]: tile[3] - win[1], tile[0] - win[0]: tile[2] - win[0]]
             r.close()
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (depth, int(np.sum(got != want)))
+
+
+@pytest.mark.parametrize("n_ranks,size", [(2, (416, 232)), (4, (416, 300)), (8, (1280, 720))])
+def test_seam_history_exchange_makes_odd_depth_tiles_exact(n_ranks, size):
+    """Odd path depth: temporal reuse reads real history, and the history of a window's halo ring belongs to the neighbours.  All
+    ranks of the decomposition live in this process (one renderer per window); after every frame each rank exports the part of
+    its tile that lies in a neighbour's halo and imports its own ring (tiles.halo_plan, lumen_mi_export/import_history) -- the
+    same packing the RCCL exchange uses, device to device.  The stitched image then equals the full-frame render bit for bit on
+    every blended frame; without the exchange it does not (asserted, so that this test cannot pass vacuously)."""
+    import torch
+    from lumenrenderer_amd import tiles
+    from lumenrenderer_amd.scenes import sponza_standin
+    W, H = size
+    depth, frames = 5, 4
+    d = sponza_standin()
+    full = product_from(d, W, H, depth, blend=True)
+    want = []
+    for _ in range(frames):
+        assert full.TraceFrameAsync()
+        full.Synchronize(); want.append(full.GetRadiance().copy())
+    full.close()
+
+    def stitched(exchange):
+        ranks = []
+        for rank in range(n_ranks):
+            tile = tiles.tile_rect(rank, n_ranks, W, H); win = tiles.window_rect(tile, W, H)
+            r = product_from(d, W, H, depth, blend=True, window=win)
+            r.SetTile(*tile)
+            ranks.append((r, tile, win, tiles.HistoryExchange(r, rank, n_ranks, W, H, "cuda:0")))
+        images = []
+        for _ in range(frames):
+            for r, _, _, _ in ranks:
+                assert r.TraceFrameAsync()
+            if exchange:
+                for _, _, _, hx in ranks:
+                    hx.pack()
+                for r, _, _, _ in ranks:
+                    r.Synchronize()
+                for rank, (_, _, _, hx) in enumerate(ranks):       # what batch_isend_irecv does between processes
+                    for peer, _, recv in hx.plan:
+                        if recv:
+                            hx.recv[peer].copy_(ranks[peer][3].send[rank])
+                torch.cuda.synchronize()
+                for _, _, _, hx in ranks:
+                    hx.unpack()
+            img = np.zeros_like(want[0])
+            for r, tile, win, _ in ranks:
+                r.Synchronize()
+                rad = r.GetRadiance()
+                img[tile[1]:tile[3], tile[0]:tile[2]] = rad[tile[1] - win[1]: tile[3] - win[1], tile[0] - win[0]: tile[2] - win[0]]
+            images.append(img)
+        for r, _, _, _ in ranks:
+            r.close()
+        return images
+
+    got = stitched(True)
+    for f in range(frames):
+        assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), (f, int(np.sum(got[f] != want[f])))
+    plain = stitched(False)
+    assert np.array_equal(plain[0].view(np.uint32), want[0].view(np.uint32))                  # the first frame has no history
+    assert any(not np.array_equal(plain[f].view(np.uint32), want[f].view(np.uint32)) for f in range(1, frames))
+    assert tiles.history_needed(depth) and not tiles.history_needed(6)
 
 
 def test_full_size_moving_scene_async_equals_serial():
