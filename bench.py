@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exact-seams", choices=["auto", "on", "off"], default="auto",
+                    help="multi-GPU: exchange the halo rings' reservoir history (and the executed-wave count) after every TraceFrame; "
+                         "auto = only for path depths that have temporal history (odd number of waves per frame)")
     ap.add_argument("--emulate-rank", default="", help="R/N: on ONE GPU render only rank R's window of an N-GPU tile grid (no gather); "
                     "design aid for the per-rank time of the tiled path, never the reported benchmark line")
     args = ap.parse_args()
@@ -164,7 +167,8 @@ def main():
 
     # temporal history across tile seams: only a path depth with an odd number of waves per frame has any (tiles.history_needed);
     # then every TraceFrame is followed by one grouped RCCL send / recv of the halo rings' reservoirs
-    hx = tiles.HistoryExchange(r, rank, world, W, H, dev) if (world > 1 and tiles.history_needed(depth)) else None
+    exact = args.exact_seams == "on" or (args.exact_seams == "auto" and tiles.history_needed(depth))
+    hx = tiles.HistoryExchange(r, rank, world, W, H, dev) if (world > 1 and exact) else None
 
     def frame():
         r.SetBlendMode(True)                              # a fresh 4-spp accumulation per displayed frame

@@ -161,6 +161,11 @@ int lumen_mi_set_window(lumen_mi_renderer*, uint32_t x0, uint32_t y0, uint32_t x
  * halo ring from the owners, so that reuse across seams sees what a single GPU would (lumenrenderer_amd/tiles.py exchange_history). */
 int lumen_mi_export_history(lumen_mi_renderer*, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, void* device_dst);
 int lumen_mi_import_history(lumen_mi_renderer*, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, const void* device_src);
+/* The reference swaps its reservoir buffers once per wave that holds a ray anywhere in the image (WaveFrontRenderer.cpp:697,827).  A
+ * rank sees only its window: export writes the number of waves the last frame executed to a device int32, the caller takes the
+ * maximum over the ranks (all-reduce), import advances the swap chain by the difference.  Call before lumen_mi_export_history. */
+int lumen_mi_export_wave_count(lumen_mi_renderer*, void* device_i32);
+int lumen_mi_import_wave_count(lumen_mi_renderer*, const void* device_i32);
 /* The part of the render window this renderer OWNS (global pixel coordinates, inside the window; an empty rectangle = the whole
  * window).  Pixels of the window outside it are halo: they are rendered as far as the owned pixels' ReSTIR reuse needs them (surface
  * data, candidates, temporal pass, first reuse pass within 30 pixels), but get no indirect light, no second reuse pass and no

@@ -71,6 +71,7 @@ SYMBOLS = {
     "lumen_mi_set_tile": [_R, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32],
     "lumen_mi_export_history": [_R, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p],
     "lumen_mi_import_history": [_R, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p],
+    "lumen_mi_export_wave_count": [_R, C.c_void_p], "lumen_mi_import_wave_count": [_R, C.c_void_p],
     "lumen_mi_query_closest": [_R, C.c_uint32, _FP, _FP, C.c_float, C.c_float, _U32P, _FP],
     "lumen_mi_query_any": [_R, C.c_uint32, _FP, _FP, C.c_float, _FP, _U8P],
     "lumen_mi_test_bsdf": [_R, C.c_uint32, C.c_int, _FP, _FP, _FP, _FP, _FP, _FP], "lumen_mi_test_math": [_R, C.c_uint32, C.c_int, _FP, _FP, _FP],

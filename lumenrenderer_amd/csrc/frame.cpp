@@ -45,7 +45,7 @@ int ensureFrameBuffers(R* r)
     r->allocN = n;
     r->fenceNeeded = true;
     r->haveEst = false; r->cntPending[0] = r->cntPending[1] = false;
-    if (r->dSwap.ensure(1) || hipMemsetAsync(r->dSwap.p, 0, sizeof(int), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "swap index allocation failed");
+    if (r->dSwap.ensure(2) || hipMemsetAsync(r->dSwap.p, 0, 2 * sizeof(int), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "swap index allocation failed");
     f.swap = r->dSwap.p;
     r->blendCounter = 0; r->frameIndex = 0; r->gbufIndex = 0; r->lastGbuf = 0;
     return 0;

@@ -669,6 +669,7 @@ KN(lm_k_merge_output)(LmFrame fr, int blend, uint32_t blendCount, int depthMax)
         int executed = 0;
         for (int d = 0; d < depthMax; d++) executed += fr.counters[LM_CNT_RAYS(d)] > 0u;
         *fr.swap = (*fr.swap + executed) & 1;
+        fr.swap[1] = executed;
     }
     const uint32_t stride = gridDim.x * LM_BLOCK;
     for (uint32_t li = blockIdx.x * LM_BLOCK + threadIdx.x; li < fr.n; li += stride) {
@@ -801,6 +802,18 @@ KN(lm_k_export_aux)(LmFrame fr, int cur, float minD, float maxD, float* __restri
             normalRoughness[li] = make_uint2(lm_f32_to_f16(b.x) | (lm_f32_to_f16(b.y) << 16), lm_f32_to_f16(b.z) | (lm_f32_to_f16(rough) << 16));
         }
     }
+}
+
+// Multi-GPU seams: a single GPU advances the reservoir swap chain once per wave that holds a ray ANYWHERE in the image.  A rank
+// only sees its window, so the ranks exchange the number of waves they executed (export), take the maximum (all-reduce) and
+// advance by the difference (import).
+extern "C" __global__ void KN(lm_k_wave_sync)(int* swap, int* io, int import)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    if (!import) { io[0] = swap[1]; return; }
+    const int global = io[0] > swap[1] ? io[0] : swap[1];
+    swap[0] = (swap[0] + (global - swap[1])) & 1;
+    swap[1] = global;
 }
 
 // Multi-GPU seams: pack / unpack a rectangle (window-local pixels) of the reservoirs the NEXT frame's temporal pass reads as
@@ -962,6 +975,7 @@ static void l_test_bsdf(hipStream_t s, uint32_t n, int mode, const float* mat, c
 static void l_test_math(hipStream_t s, uint32_t n, int fn, const float* x, const float* y, float* out) { hipLaunchKernelGGL(KN(lm_k_test_math), LM_GRID((n + LM_BLOCK - 1) / LM_BLOCK), n, fn, x, y, out); }
 static void l_history_copy(hipStream_t s, int g, LmFrame fr, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, float4* buf, int import)
 { hipLaunchKernelGGL(KN(lm_k_history_copy), LM_GRID(g), fr, x0, y0, w, h, buf, import); }
+static void l_wave_sync(hipStream_t s, int* swap, int* io, int import) { hipLaunchKernelGGL(KN(lm_k_wave_sync), dim3(1), dim3(64), 0, s, swap, io, import); }
 static void l_spin(hipStream_t s, uint32_t ticks) { hipLaunchKernelGGL(KN(lm_k_spin), dim3(1), dim3(64), 0, s, ticks); }
 
 #if LM_INSTRUMENT
@@ -971,6 +985,6 @@ extern "C" const LmKernelTable* lm_kernel_table()
 #endif
 {
     static const LmKernelTable t = {l_primary, l_trace_closest, l_extract0, l_shade_wave, l_trace_shadow, l_path_tail, l_fill_bags, l_pick_primary,
-                                    l_trace_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_export_aux, l_refit_tris, l_refit_quant, l_refit_level, l_test_bsdf, l_test_math, l_spin, l_history_copy};
+                                    l_trace_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_export_aux, l_refit_tris, l_refit_quant, l_refit_level, l_test_bsdf, l_test_math, l_spin, l_history_copy, l_wave_sync};
     return &t;
 }

@@ -108,6 +108,7 @@ struct LmFrame {
     int* swap;                  // ReSTIR swap-chain index (ReSTIR::m_SwapChainIndex), on the device: it advances once per EXECUTED
                                 // wave, and the wave loop ends when a wave's queue is empty (WaveFrontRenderer.cpp:697,827) — a count only
                                 // the device knows without a host round trip.  Kernels take buffer indices as LM_RES_* codes.
+                                // swap[1] = waves the last frame executed (multi-GPU: ranks agree on the maximum, lm_k_wave_sync).
     uint2* bags;                // 50 x 1000 light-bag entries: (light index, pdf bits)
 };
 // reservoir buffer index codes of the ReSTIR kernels: a literal index >= 0, or the swap-chain front / back buffer

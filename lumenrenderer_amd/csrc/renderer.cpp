@@ -435,6 +435,19 @@ static int historyCopy(lumen_mi_renderer* r, uint32_t x0, uint32_t y0, uint32_t 
 int lumen_mi_export_history(lumen_mi_renderer* r, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, void* device_dst) { return historyCopy(r, x0, y0, x1, y1, device_dst, 0); }
 int lumen_mi_import_history(lumen_mi_renderer* r, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, const void* device_src) { return historyCopy(r, x0, y0, x1, y1, (void*)device_src, 1); }
 
+static int waveSync(lumen_mi_renderer* r, void* dev, int import)
+{
+    if (!r || !dev) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    ApiLock lk(r);
+    if (!r->fr.swap) return fail(LUMEN_MI_ERR_STATE, "no frame has been traced yet");
+    if (hipSetDevice(r->device) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "hipSetDevice failed");
+    r->K->wave_sync(r->stream, r->fr.swap, (int*)dev, import);
+    LM_HIP(hipGetLastError());
+    return 0;
+}
+int lumen_mi_export_wave_count(lumen_mi_renderer* r, void* device_i32) { return waveSync(r, device_i32, 0); }
+int lumen_mi_import_wave_count(lumen_mi_renderer* r, const void* device_i32) { return waveSync(r, (void*)device_i32, 1); }
+
 int lumen_mi_get_gbuffer(lumen_mi_renderer* r, float* out, size_t cap)
 {
     if (!r || !out) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");

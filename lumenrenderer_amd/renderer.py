@@ -187,6 +187,9 @@ class LumenRendererMI:
         """Pack rect = (x0, y0, x1, y1) of the reservoirs the next frame reads as "previous" into device memory (80 bytes / pixel)."""
         check(self.lib, self.lib.lumen_mi_export_history(self.h, *[int(v) for v in rect], C.c_void_p(int(device_ptr))))
 
+    def ExportWaveCount(self, device_ptr): check(self.lib, self.lib.lumen_mi_export_wave_count(self.h, C.c_void_p(int(device_ptr))))
+    def ImportWaveCount(self, device_ptr): check(self.lib, self.lib.lumen_mi_import_wave_count(self.h, C.c_void_p(int(device_ptr))))
+
     def ImportHistory(self, rect, device_ptr):
         check(self.lib, self.lib.lumen_mi_import_history(self.h, *[int(v) for v in rect], C.c_void_p(int(device_ptr))))
 

@@ -129,6 +129,7 @@ class HistoryExchange:
         import torch
         self.r, self.plan = renderer, halo_plan(rank, world, width, height)
         area = lambda q: (q[2] - q[0]) * (q[3] - q[1])
+        self.waves = torch.zeros(1, dtype=torch.int32, device=device)
         self.send = {p: torch.empty(area(s) * HISTORY_FLOATS, dtype=torch.float32, device=device) for p, s, _ in self.plan if s}
         self.recv = {p: torch.empty(area(q) * HISTORY_FLOATS, dtype=torch.float32, device=device) for p, _, q in self.plan if q}
 
@@ -145,6 +146,9 @@ class HistoryExchange:
     def run(self, dist):
         """Call after every TraceFrame(Async): everything is stream-ordered behind the frame's merge and ahead of the next frame's
         temporal pass (the renderer's stream must be torch's current stream: LumenRendererMI.set_stream)."""
-        self.pack()
+        self.r.ExportWaveCount(self.waves.data_ptr())          # ranks whose rays ran out at different depths agree on the swap chain
+        dist.all_reduce(self.waves, op=dist.ReduceOp.MAX)
+        self.r.ImportWaveCount(self.waves.data_ptr())
+        self.pack()                                            # ... before the buffer the next frame calls "previous" is picked
         exchange_buffers(self.plan, self.send, self.recv, dist)
         self.unpack()

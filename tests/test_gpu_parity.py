@@ -711,25 +711,30 @@ def test_stitched_tiles_equal_the_single_gpu_frame(n_ranks):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (depth, int(np.sum(got != want)))
 
 
-@pytest.mark.parametrize("n_ranks,size", [(2, (416, 232)), (4, (416, 300)), (8, (1280, 720))])
-def test_seam_history_exchange_makes_odd_depth_tiles_exact(n_ranks, size):
+@pytest.mark.parametrize("n_ranks,size,scene,depth", [(2, (416, 232), "sponza", 5), (4, (416, 300), "sponza", 5), (8, (1280, 720), "sponza", 5),
+                                                     (2, (200, 160), "cornell", 16), (4, (200, 160), "cornell", 16)])
+def test_seam_history_exchange_makes_odd_depth_tiles_exact(n_ranks, size, scene, depth):
     """Odd path depth: temporal reuse reads real history, and the history of a window's halo ring belongs to the neighbours.  All
     ranks of the decomposition live in this process (one renderer per window); after every frame each rank exports the part of
     its tile that lies in a neighbour's halo and imports its own ring (tiles.halo_plan, lumen_mi_export/import_history) -- the
     same packing the RCCL exchange uses, device to device.  The stitched image then equals the full-frame render bit for bit on
-    every blended frame; without the exchange it does not (asserted, so that this test cannot pass vacuously)."""
+    every blended frame; without the exchange it does not (asserted, so that this test cannot pass vacuously).
+    Cornell at depth 16: the rays run out after a few waves, at a different depth in every tile and frame; the ranks agree on the
+    number of executed waves (the maximum: lumen_mi_export/import_wave_count) before the swap chain picks the history buffer."""
     import torch
     from lumenrenderer_amd import tiles
     from lumenrenderer_amd.scenes import sponza_standin
     W, H = size
-    depth, frames = 5, 4
-    d = sponza_standin()
+    frames = 4 if scene == "sponza" else 6
+    d = sponza_standin() if scene == "sponza" else cornell()
     full = product_from(d, W, H, depth, blend=True)
     want = []
     for _ in range(frames):
         assert full.TraceFrameAsync()
         full.Synchronize(); want.append(full.GetRadiance().copy())
     full.close()
+
+    executed = []
 
     def stitched(exchange):
         ranks = []
@@ -743,6 +748,15 @@ def test_seam_history_exchange_makes_odd_depth_tiles_exact(n_ranks, size):
             for r, _, _, _ in ranks:
                 assert r.TraceFrameAsync()
             if exchange:
+                for r, _, _, hx in ranks:
+                    r.ExportWaveCount(hx.waves.data_ptr())
+                for r, _, _, _ in ranks:
+                    r.Synchronize()
+                most = max(int(hx.waves.item()) for _, _, _, hx in ranks)                  # dist.all_reduce(MAX) between processes
+                executed.append(sorted(int(hx.waves.item()) for _, _, _, hx in ranks))
+                for r, _, _, hx in ranks:
+                    hx.waves.fill_(most); torch.cuda.synchronize()
+                    r.ImportWaveCount(hx.waves.data_ptr())
                 for _, _, _, hx in ranks:
                     hx.pack()
                 for r, _, _, _ in ranks:
@@ -770,7 +784,9 @@ def test_seam_history_exchange_makes_odd_depth_tiles_exact(n_ranks, size):
     plain = stitched(False)
     assert np.array_equal(plain[0].view(np.uint32), want[0].view(np.uint32))                  # the first frame has no history
     assert any(not np.array_equal(plain[f].view(np.uint32), want[f].view(np.uint32)) for f in range(1, frames))
-    assert tiles.history_needed(depth) and not tiles.history_needed(6)
+    if scene == "cornell":
+        assert any(e[0] != e[-1] for e in executed), executed                                   # the ranks did disagree in some frame
+    assert tiles.history_needed(5) and not tiles.history_needed(6)
 
 
 def test_full_size_moving_scene_async_equals_serial():
