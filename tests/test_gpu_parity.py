@@ -680,6 +680,65 @@ def test_full_size_overlapped_schedule_equals_the_serial_one():
         assert out[0][3] == out[k][3], k
 
 
+def test_c4_4k_depth8_overlapped_schedule_equals_the_serial_one():
+    """BASELINE config C4 at its full size (3840x2160, depth 8, blended frames): the overlapped schedule equals the serial one bit
+    for bit (4K frames are too large for the oracle; the properties the radiance must have are checked as in the 1440p test)."""
+    from lumenrenderer_amd.scenes import sponza_standin
+    W, H, D = 3840, 2160, 8
+    out = []
+    for tuning, sync_each in (({}, False), ({"single_stream": 1, "tail_below": 0, "pick_ahead": 0}, True)):
+        r = product_from(sponza_standin(), W, H, D, blend=True, tuning=tuning)
+        for _ in range(4):
+            assert r.TraceFrameAsync()
+            if sync_each:
+                r.Synchronize()
+        r.Synchronize()
+        out.append((r.GetRadiance().copy(), r.GetChannel(0).copy(), r.GetChannel(1).copy(), list(r.GetCounters()[:20])))
+        r.close()
+    for a, b in zip(out[0][:3], out[1][:3]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert out[0][3] == out[1][3]
+    rad, c = out[0][0], out[0][3]
+    assert rad.shape == (H, W, 4) and np.isfinite(rad).all() and (rad[..., :3] >= 0).all() and rad[..., :3].max() > 0.05
+    assert c[4] == W * H and all(c[4 + d] >= c[5 + d] for d in range(D - 1)) and c[4 + D - 1] > 0        # rays per wave: all pixels, then thinning
+
+
+def test_c5_ten_million_triangles_queries_and_schedules():
+    """BASELINE config C5 (10 M-triangle foliage stand-in, 1080p, depth 6): the parallel host build, the 4-wide tree and its stack
+    bound at that size.  Closest-hit / any-hit queries against the oracle's brute-force loop over all triangles (no BVH on the
+    oracle side), and the overlapped schedule against the serial one."""
+    from lumenrenderer_amd.scenes import foliage_stress
+    d = foliage_stress()
+    assert d.triangle_count() >= 10_000_000
+    W, H, D = 1920, 1080, 6
+    out = []
+    for tuning, sync_each in (({}, False), ({"single_stream": 1, "tail_below": 0, "pick_ahead": 0}, True)):
+        r = product_from(d, W, H, D, blend=True, tuning=tuning)
+        for _ in range(3):
+            assert r.TraceFrameAsync()
+            if sync_each:
+                r.Synchronize()
+        r.Synchronize()
+        out.append((r.GetRadiance().copy(), list(r.GetCounters()[:12])))
+        if not sync_each:
+            info = r.GetBvhInfo()
+            assert info["triangles"] == d.triangle_count() and info["nodes"] > info["triangles"] // 8
+            rng = np.random.default_rng(5)
+            c = d.camera
+            org = np.tile(np.float32(c["position"]), (256, 1)) + rng.uniform(-0.5, 0.5, (256, 3)).astype(np.float32)
+            dr = rng.normal(size=(256, 3)).astype(np.float32); dr /= np.linalg.norm(dr, axis=1, keepdims=True)
+            ip, uvt = r.QueryClosest(org, dr)
+            occ = r.QueryAny(org, dr, np.full(256, 50.0, np.float32))
+            o = oracle_from(d, 16, 16, 2)
+            oip, ouvt = o.trace_closest(org, dr, use_bvh=False)
+            oocc = o.trace_any(org, dr, np.full(256, 50.0, np.float32), use_bvh=False)
+            assert np.array_equal(uvt.view(np.uint32), ouvt.view(np.uint32)) and np.array_equal(ip, oip) and np.array_equal(occ, oocc)
+            assert (uvt[:, 2] > 0).sum() > 32
+            o.close()
+        r.close()
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32)) and out[0][1] == out[1][1]
+
+
 @pytest.mark.parametrize("n_ranks", [2, 4, 8])
 def test_stitched_tiles_equal_the_single_gpu_frame(n_ranks):
     """The multi-GPU decomposition on one GPU: every rank's window (tile + 60-pixel halo, lumenrenderer_amd/tiles.py) is
