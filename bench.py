@@ -251,7 +251,7 @@ def main():
             "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {kind} stand-in, {W}x{H}, {spp} spp (blended TraceFrames), depth {depth}, ReSTIR DI on",
+            "config": {"workload": f"{args.workload}: {'cornell box (the reference asset, tests/golden fixture)' if kind == 'cornell' else kind + ' stand-in'}, {W}x{H}, {spp} spp (blended TraceFrames), depth {depth}, ReSTIR DI on",
                        "triangles": desc.triangle_count(), "rays_per_frame": int(rays_per_frame), "ms_per_frame": round(ms_per_step, 4),
                        "tiles": f"{tiles.grid_for(world, W, H)[0]}x{tiles.grid_for(world, W, H)[1]} + {tiles.HALO}px halo" if world > 1 else "1x1",
                        "nodes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2),
