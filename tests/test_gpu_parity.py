@@ -633,7 +633,15 @@ def test_render_thread_with_concurrent_scene_edits():
     inst = d.add_instance(d.add_mesh([d.add_primitive(v, p["indices"], mat)]), _rigid(0.0, (0.0, 1.0, 0.0)))
     r = product_from(d, 160, 120, 4, blend=False)
     mi = r.m_Scene.m_MeshInstances[inst]
+    from lumenrenderer_amd.capi import LumenMIError
     r.StartRendering()
+    t0 = time.time()
+    while True:                                   # until the thread has produced its first frame a read-back reports "no frame traced yet"
+        try:
+            r.GetRadiance(); break
+        except LumenMIError as e:
+            assert e.code == 3 and time.time() - t0 < 20.0, str(e)
+            time.sleep(0.005)
     t0 = time.time(); k = 0
     while time.time() - t0 < 1.0:
         k += 1
