@@ -78,7 +78,8 @@ def cpu_baseline(kind, kw, depth, spp, full):
     Test infrastructure used as a reported baseline only — never as the measured path."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import oracle_from
-    cores = os.cpu_count() or 1
+    from oracle_lib import usable_cpus
+    cores = usable_cpus()                                 # affinity mask capped by the cgroup CPU quota: the threads that really run
     scene = make_scene(kind, kw)
 
     def run(w, h):

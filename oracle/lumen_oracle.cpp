@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <functional>
 #include <thread>
 #include <vector>
@@ -150,16 +151,34 @@ struct orc_ctx {
     template <class F> void pfor(uint32_t n, F f) const;
 };
 
+// ORC_TIMING=1: wall time of the stages of a frame on stderr (where do 256 host cores spend a CPU-baseline run?)
+static void orc_lap(const char* what)
+{
+    static const bool on = getenv("ORC_TIMING") != nullptr;
+    static auto last = std::chrono::steady_clock::now();
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    if (what) fprintf(stderr, "[oracle] %-22s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+    last = now;
+}
+
+// Parallel loop with dynamic scheduling: the range is cut into fixed chunks (boundaries depend on n only), worker threads pull
+// chunk numbers from an atomic counter, and f(begin, end, chunk) may use the chunk number to keep per-chunk output that is
+// concatenated in chunk order afterwards — so the result does not depend on the number of threads or on who ran which chunk.
+// (Static one-band-per-thread scheduling left most of 256 cores idle: bands of sky cost nothing, bands of geometry everything.)
+static inline uint32_t pfor_chunk(uint32_t n) { return n <= 4096u ? std::max(n, 1u) : std::max(256u, std::min(4096u, n / 2048u)); }
+static inline uint32_t pfor_chunks(uint32_t n) { const uint32_t c = pfor_chunk(n); return (n + c - 1u) / c; }
 template <class F> void orc_ctx::pfor(uint32_t n, F f) const
 {
-    const int nt = std::max(1, std::min<int>(threads, (int)((n + 255) / 256)));
-    if (nt == 1) { f(0u, n, 0); return; }
+    if (n == 0) return;
+    const uint32_t chunk = pfor_chunk(n), chunks = pfor_chunks(n);
+    const int nt = std::max(1, std::min<int>(threads, (int)chunks));
+    if (nt == 1) { for (uint32_t c = 0; c < chunks; c++) f(c * chunk, std::min(n, (c + 1u) * chunk), (int)c); return; }
+    std::atomic<uint32_t> next{0};
+    auto work = [&] { for (uint32_t c; (c = next.fetch_add(1u)) < chunks;) f(c * chunk, std::min(n, (c + 1u) * chunk), (int)c); };
     std::vector<std::thread> th;
-    const uint32_t chunk = (n + nt - 1) / nt;
-    for (int t = 0; t < nt; t++) {
-        const uint32_t b = std::min(n, t * chunk), e = std::min(n, b + chunk);
-        th.emplace_back([=, &f] { f(b, e, t); });
-    }
+    for (int t = 1; t < nt; t++) th.emplace_back(work);
+    work();
     for (auto& t : th) t.join();
 }
 
@@ -767,6 +786,7 @@ static void restir_run(orc_ctx* c, int cur, int prev, uint32_t a_Seed, const std
     std::vector<Reservoir>& RT = c->reservoirs[temporalIndex];
     uint32_t seed = wang_hash(a_Seed);
 
+    orc_lap(nullptr);
     build_cdf(c);                                                           // ReSTIR.cpp:125
     // FillLightBags — ReSTIRKernels.cu:343-370 (seed = a_Seed, ReSTIR.cpp:135-141)
     const uint32_t nBags = 50, perBag = 1000;
@@ -780,6 +800,7 @@ static void restir_run(orc_ctx* c, int cur, int prev, uint32_t a_Seed, const std
             c->bags[i] = LightBagEntry{c->lights[li], pdf};
         }
     });
+    orc_lap("restir cdf+bags");
     // PickPrimarySamples — ReSTIRKernels.cu:402-522
     seed = wang_hash(seed);
     {
@@ -817,9 +838,11 @@ static void restir_run(orc_ctx* c, int cur, int prev, uint32_t a_Seed, const std
             }
         });
     }
+    orc_lap("restir pick");
     c->stats[2] += visibility_check(c, RC, curS, pixels);                   // ReSTIR.cpp:161
-    for (uint32_t i : pixels) shade_reservoir(c, RC[i], i);                 // ReSTIR.cpp:162 (ShadeInternal :600-616)
+    c->pfor((uint32_t)pixels.size(), [&](uint32_t b, uint32_t e, int) { for (uint32_t k = b; k < e; k++) shade_reservoir(c, RC[pixels[k]], pixels[k]); });   // ReSTIR.cpp:162 (ShadeInternal :600-616)
 
+    orc_lap("restir vis1+shade");
     // Temporal — ReSTIRKernels.cu:1015-1121
     seed = wang_hash(seed);
     {
@@ -897,8 +920,10 @@ static void restir_run(orc_ctx* c, int cur, int prev, uint32_t a_Seed, const std
             if (it == 0) { from = &c->reservoirs[2]; to = &c->reservoirs[3]; } else std::swap(from, to);
         }
         std::vector<Reservoir>& neighbour = *from;                           // == reservoirs[3]
+        orc_lap("restir temporal+spatial");
         c->stats[2] += visibility_check(c, RC, curS, pixels);               // ReSTIR.cpp:211 (on the CURRENT buffer, quirk 7)
-        for (uint32_t i : pixels) shade_reservoir(c, RC[i], i);             // ReSTIR.cpp:212
+        c->pfor((uint32_t)pixels.size(), [&](uint32_t b, uint32_t e, int) { for (uint32_t k = b; k < e; k++) shade_reservoir(c, RC[pixels[k]], pixels[k]); });   // ReSTIR.cpp:212
+        orc_lap("restir vis2+shade");
         // CombineReservoirBuffers — ReSTIRKernels.cu:1407-1436, seed WangHash(seed) (ReSTIR.cpp:220)
         const uint32_t s1 = wang_hash(seed);
         c->pfor((uint32_t)pixels.size(), [&](uint32_t b, uint32_t e, int) {
@@ -961,16 +986,22 @@ static int trace_frame(orc_ctx* c)
     const uint32_t W = c->W, H = c->H;
     memset(c->stats, 0, sizeof c->stats);
 
+    orc_lap(nullptr);
     const uint32_t totalEmissive = build_lights(c);                        // :456
     c->stats[3] = c->lights.size();
     if (totalEmissive == 0 || c->lights.empty()) return 1;                 // :459-464 (an empty list would make ReSTIR read garbage: also skipped)
 
     const int currentIndex = c->frameIndex, temporalIndex = c->frameIndex == 1 ? 0 : 1;
     std::vector<uint32_t> pixels;
+    pixels.reserve((size_t)(c->wx1 - c->wx0) * (c->wy1 - c->wy0));
     for (uint32_t y = c->wy0; y < c->wy1; y++) for (uint32_t x = c->wx0; x < c->wx1; x++) pixels.push_back(y * W + x);
 
-    for (auto& ch : c->channel) for (uint32_t i : pixels) ch[i] = f4{0, 0, 0, 0};       // :556
-    if (!c->blend) for (uint32_t i : pixels) c->combined[i] = f4{0, 0, 0, 0};           // :559
+    c->pfor((uint32_t)pixels.size(), [&](uint32_t b, uint32_t e, int) {
+        for (uint32_t k = b; k < e; k++) {
+            for (auto& ch : c->channel) ch[pixels[k]] = f4{0, 0, 0, 0};                 // :556
+            if (!c->blend) c->combined[pixels[k]] = f4{0, 0, 0, 0};                     // :559
+        }
+    });
 
     // camera — Camera.cpp:79-93,122-128 (aspect = render W/H, WaveFrontRenderer.cpp:577)
     const float aspect = (float)W / (float)H;
@@ -982,12 +1013,17 @@ static int trace_frame(orc_ctx* c)
                           c->camRight.z, c->camUp.z, c->camForward.z, c->camPos.z, 0, 0, 0, 1};
     if (!c->havePrev) { memcpy(c->prevCamWorld, camWorld, sizeof camWorld); c->havePrev = true; }
 
+    orc_lap("flatten+lights+setup");
     ++c->frameCount;                                                        // :593
     std::vector<Ray> rays(pixels.size());
     c->pfor((uint32_t)pixels.size(), [&](uint32_t b, uint32_t e, int) {
         for (uint32_t k = b; k < e; k++) rays[k] = primary_ray(c, pixels[k], U, V, Wv, eye, c->frameCount);
     });
-    { Surface zs; memset(&zs, 0, sizeof zs); for (uint32_t i : pixels) c->surface[currentIndex][i] = zs; }   // :652
+    {   // :652
+        Surface zs; memset(&zs, 0, sizeof zs);
+        c->pfor((uint32_t)pixels.size(), [&](uint32_t b, uint32_t e, int) { for (uint32_t k = b; k < e; k++) c->surface[currentIndex][pixels[k]] = zs; });
+    }
+    orc_lap("primary rays");
     std::vector<ShadowRay> shadowRays;
     uint32_t seed = wang_hash(c->frameCount);                               // :685
 
@@ -999,11 +1035,13 @@ static int trace_frame(orc_ctx* c)
         c->pfor(nRays, [&](uint32_t b, uint32_t e, int) {
             for (uint32_t k = b; k < e; k++) hits[k] = trace_ray(c, rays[k].origin, rays[k].dir, 0.01f, 5000.f);   // :678,:703
         });
+        orc_lap("closest hit");
         const int sIdx = depth == 0 ? currentIndex : 2;
         std::vector<Surface>& S = c->surface[sIdx];
         c->pfor(nRays, [&](uint32_t b, uint32_t e, int) {
             for (uint32_t k = b; k < e; k++) extract_surface(c, hits[k], rays[k], S[(uint32_t)rays[k].py * W + rays[k].px]);
         });
+        orc_lap("extract");
         if (depth == 0) {
             // GenerateMotionVectors: M = projection * inverse(previous camera world matrix)
             float proj[16] = {0}, invPrev[16], M[16];
@@ -1039,9 +1077,11 @@ static int trace_frame(orc_ctx* c)
                 const Surface& s = S[i];
                 if (s.flags & SF_EMISSIVE) c->channel[0][i] = s.mat.color;
             }
+            orc_lap("motion+resolve");
             restir_run(c, currentIndex, temporalIndex, seed, pixels);
+            orc_lap("restir combine");
         } else {
-            std::vector<std::vector<ShadowRay>> parts(c->threads + 1);
+            std::vector<std::vector<ShadowRay>> parts(pfor_chunks((uint32_t)active.size()) + 1);
             c->pfor((uint32_t)active.size(), [&](uint32_t b, uint32_t e, int t) {
                 for (uint32_t k = b; k < e; k++) {
                     const uint32_t i = active[k];
@@ -1051,9 +1091,10 @@ static int trace_frame(orc_ctx* c)
             });
             for (auto& p : parts) shadowRays.insert(shadowRays.end(), p.begin(), p.end());
         }
+        if (depth) orc_lap("shade direct");
         const uint32_t seed2 = wang_hash(seed);                             // CPUShadingKernels.cu:178
         if (depth < c->depth - 1) {
-            std::vector<std::vector<Ray>> parts(c->threads + 1);
+            std::vector<std::vector<Ray>> parts(pfor_chunks((uint32_t)active.size()) + 1);
             c->pfor((uint32_t)active.size(), [&](uint32_t b, uint32_t e, int t) {
                 for (uint32_t k = b; k < e; k++) {
                     const uint32_t i = active[k];
@@ -1063,13 +1104,19 @@ static int trace_frame(orc_ctx* c)
             });
             for (auto& p : parts) next.insert(next.end(), p.begin(), p.end());
         }
+        orc_lap("shade indirect");
         rays.swap(next);
-        if (sIdx == 2) { Surface zs; memset(&zs, 0, sizeof zs); for (uint32_t i : active) c->surface[2][i] = zs; }   // :818 (only touched slots can be non-zero)
+        if (sIdx == 2) {                                                    // :818 (only touched slots can be non-zero)
+            Surface zs; memset(&zs, 0, sizeof zs);
+            const std::vector<uint32_t>& act = active;
+            c->pfor((uint32_t)act.size(), [&](uint32_t b, uint32_t e, int) { for (uint32_t k = b; k < e; k++) c->surface[2][act[k]] = zs; });
+        }
         active.resize(rays.size());
-        for (size_t k = 0; k < rays.size(); k++) active[k] = (uint32_t)rays[k].py * W + rays[k].px;
+        c->pfor((uint32_t)rays.size(), [&](uint32_t b, uint32_t e, int) { for (uint32_t k = b; k < e; k++) active[k] = (uint32_t)rays[k].py * W + rays[k].px; });
         c->swapChainIndex = (c->swapChainIndex + 1) >= 2 ? 0 : c->swapChainIndex + 1;                            // ReSTIR::SwapBuffers
         seed = wang_hash(seed);                                             // :830
     }
+    orc_lap("(loop tail)");
     // shadow rays — ShadowRaysRayGen, WaveFrontShaders.cu:114-179 (tmin 0.01, fp32 accumulate in append order, D1)
     c->stats[1] = shadowRays.size();
     {
@@ -1082,8 +1129,10 @@ static int trace_frame(orc_ctx* c)
             px.x += shadowRays[k].radiance.x; px.y += shadowRays[k].radiance.y; px.z += shadowRays[k].radiance.z; px.w += 0.f;
         }
     }
+    orc_lap("shadow rays");
     // MergeOutputChannels — GPUMergeOutputChannels.cu:5-88 (fp32, D1)
-    for (uint32_t i : pixels) {
+    c->pfor((uint32_t)pixels.size(), [&](uint32_t pb, uint32_t pe, int) { for (uint32_t pk = pb; pk < pe; pk++) {
+        const uint32_t i = pixels[pk];
         f4 m{0, 0, 0, 0};
         for (int ch = 0; ch < 3; ch++) m = m + c->channel[ch][i];
         const f4 vol = c->channel[3][i];
@@ -1095,9 +1144,10 @@ static int trace_frame(orc_ctx* c)
             const f4 s = old * k + m;
             c->combined[i] = f4{s.x / k1, s.y / k1, s.z / k1, s.w / k1};
         } else c->combined[i] = m;
-    }
+    } });
     // WriteToOutput — GPUShadingKernels.cu:28-56 + vendor/Include/Cuda/cuda/helpers.h:35-66
-    for (uint32_t i : pixels) {
+    c->pfor((uint32_t)pixels.size(), [&](uint32_t pb, uint32_t pe, int) { for (uint32_t pk = pb; pk < pe; pk++) {
+        const uint32_t i = pixels[pk];
         const f4 cc = c->combined[i];
         const float in[3] = {clampf(cc.x, 0.f, 1.f), clampf(cc.y, 0.f, 1.f), clampf(cc.z, 0.f, 1.f)};
         for (int k = 0; k < 3; k++) {
@@ -1108,7 +1158,8 @@ static int trace_frame(orc_ctx* c)
             c->output[(size_t)i * 4 + k] = (uint8_t)q;
         }
         c->output[(size_t)i * 4 + 3] = 255;
-    }
+    } });
+    orc_lap("merge+output");
     if (c->blend) ++c->blendCounter;                                        // :1039-1042
     c->frameIndex = c->frameIndex + 1 == 2 ? 0 : c->frameIndex + 1;         // :1045-1049
     memcpy(c->prevCamWorld, camWorld, sizeof camWorld);                     // :1051

@@ -89,6 +89,30 @@ def f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota (a container can see 256 CPUs and be
+    allowed the time of 16; more threads than that only add time-slicing)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                  # cgroup v2
+        if q != "max":
+            quota = int(q) / int(period)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())   # v1
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = min(n, max(1, int(quota + 0.999)))
+    return max(1, n)
+
+
 class Oracle:
     """Scene-level handle; mirrors the product's renderer facade closely enough that one scene
     description (lumenrenderer_amd.scenes.SceneDescription) can be replayed into either."""
@@ -96,7 +120,7 @@ class Oracle:
     def __init__(self, threads=None):
         self.L = lib()
         self.h = C.c_void_p(self.L.orc_create())
-        self.L.orc_set_threads(self.h, threads or os.cpu_count() or 1)
+        self.L.orc_set_threads(self.h, threads or usable_cpus())
         self.w = self.h_ = 0
 
     def close(self):
