@@ -8,6 +8,8 @@
 #include "bvh.h"
 #include "lm_woop.h"
 
+#include <sched.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -190,13 +192,36 @@ struct Builder {
 
 }  // namespace
 
+// CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (a container can see 256 CPUs and be granted
+// the time of 16; more threads than that only add time-slicing).
+static unsigned usableCpus()
+{
+    unsigned n = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = (unsigned)CPU_COUNT(&set);
+    double quota = 0.0;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                     // cgroup v2: "<quota|max> <period>"
+        char q[32]; double period = 0.0;
+        if (fscanf(f, "%31s %lf", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0.0) quota = atof(q) / period;
+        fclose(f);
+    } else if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1
+        double q = 0.0, period = 100000.0;
+        if (fscanf(g, "%lf", &q) != 1) q = 0.0;
+        fclose(g);
+        if (FILE* h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lf", &period) != 1) period = 100000.0; fclose(h); }
+        if (q > 0.0 && period > 0.0) quota = q / period;
+    }
+    if (quota > 0.0) n = std::min(n, (unsigned)std::max(1.0, std::ceil(quota)));
+    return std::max(1u, n);
+}
+
 void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out)
 {
     out->nodes.clear(); out->order.clear(); out->woop.clear();
     const bool timing = getenv("LUMEN_MI_BUILD_TIMING") != nullptr;
     auto tLast = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (!timing) return; const auto now = std::chrono::steady_clock::now(); fprintf(stderr, "[bvh] %-28s %.3f s\n", what, std::chrono::duration<double>(now - tLast).count()); tLast = now; };
-    unsigned threads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    unsigned threads = std::max(1u, std::min(64u, usableCpus()));
     if (const char* e = getenv("LUMEN_MI_BUILD_THREADS")) threads = (unsigned)std::max(1, atoi(e));
     if (const char* e = getenv("LUMEN_MI_BVH_TRAV_COST")) g_travCost = (float)atof(e);
     if (const char* e = getenv("LUMEN_MI_BVH_LEAF_MAX")) g_leafMax = (uint32_t)std::max(1, std::min((int)LM_MAX_LEAF, atoi(e)));
