@@ -688,6 +688,32 @@ def test_full_size_overlapped_schedule_equals_the_serial_one():
         assert out[0][3] == out[k][3], k
 
 
+def test_c2_at_full_size_is_bit_exact_against_the_oracle():
+    """BASELINE config C2 at its full size against the ORACLE (not only against another schedule): 2560x1440, depth 6, ReSTIR on,
+    the four blended TraceFrames of one benchmark frame (4 spp) enqueued back to back with the default overlapped schedule.
+    Radiance, both light channels, the sRGB8 output and the ray counters equal the CPU restatement bit for bit on all 3.7 M pixels
+    (the oracle needs about two seconds per TraceFrame on the host cores)."""
+    from lumenrenderer_amd.scenes import sponza_standin
+    W, H, D = 2560, 1440, 6
+    d = sponza_standin()
+    r = product_from(d, W, H, D, blend=True)
+    o = oracle_from(d, W, H, D, blend=True)
+    for _ in range(4):
+        assert r.TraceFrameAsync()
+        assert o.trace_frame() == 0
+    r.Synchronize()
+    got, want = r.GetRadiance(), o.radiance()
+    assert rel_l2(got, want) <= RADIANCE_TOL
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), int(np.sum(got.view(np.uint32) != want.view(np.uint32)))
+    for ch in (0, 1):
+        assert np.array_equal(r.GetChannel(ch).view(np.uint32), o.channel(ch).view(np.uint32)), ch
+    assert np.array_equal(r.GetOutputTexturePixels(), o.output_pixels())
+    c, s = r.GetCounters(), o.stats(24)
+    assert list(c[:4 + D]) == list(s[:4 + D]), (c[:12], s[:12])
+    assert c[0] > W * H and c[2] > 1_000_000
+    r.close(); o.close()
+
+
 def test_c4_4k_depth8_overlapped_schedule_equals_the_serial_one():
     """BASELINE config C4 at its full size (3840x2160, depth 8, blended frames): the overlapped schedule equals the serial one bit
     for bit (4K frames are too large for the oracle; the properties the radiance must have are checked as in the 1440p test)."""
