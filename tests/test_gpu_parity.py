@@ -714,9 +714,49 @@ def test_c2_at_full_size_is_bit_exact_against_the_oracle():
     r.close(); o.close()
 
 
+def test_c3_at_full_size_is_bit_exact_against_the_oracle():
+    """BASELINE config C3 at its full size against the oracle: the atrium with 1 026 emissive triangles (513 quads; the reference's
+    slice quirk keeps one light-list entry per quad, GPUDataBufferKernels.cu:37), 2560x1440, depth 6, two blended TraceFrames,
+    default schedule."""
+    from lumenrenderer_amd.scenes import sponza_standin
+    W, H, D = 2560, 1440, 6
+    d = sponza_standin(extra_lights=512)
+    r = product_from(d, W, H, D, blend=True)
+    o = oracle_from(d, W, H, D, blend=True)
+    for _ in range(2):
+        assert r.TraceFrameAsync()
+        assert o.trace_frame() == 0
+    r.Synchronize()
+    got, want = r.GetRadiance(), o.radiance()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), int(np.sum(got.view(np.uint32) != want.view(np.uint32)))
+    c, s = r.GetCounters(), o.stats(24)
+    assert list(c[:4 + D]) == list(s[:4 + D]), (c[:12], s[:12])
+    assert len(r.GetLights()[0]) == 513
+    r.close(); o.close()
+
+
+def test_c4_at_full_size_is_bit_exact_against_the_oracle():
+    """BASELINE config C4 at its full size against the oracle: 3840x2160, depth 8, two blended TraceFrames, default schedule."""
+    from lumenrenderer_amd.scenes import sponza_standin
+    W, H, D = 3840, 2160, 8
+    d = sponza_standin()
+    r = product_from(d, W, H, D, blend=True)
+    o = oracle_from(d, W, H, D, blend=True)
+    for _ in range(2):
+        assert r.TraceFrameAsync()
+        assert o.trace_frame() == 0
+    r.Synchronize()
+    got, want = r.GetRadiance(), o.radiance()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), int(np.sum(got.view(np.uint32) != want.view(np.uint32)))
+    assert np.array_equal(r.GetOutputTexturePixels(), o.output_pixels())
+    c, s = r.GetCounters(), o.stats(24)
+    assert list(c[:4 + D]) == list(s[:4 + D]), (c[:12], s[:12])
+    r.close(); o.close()
+
+
 def test_c4_4k_depth8_overlapped_schedule_equals_the_serial_one():
     """BASELINE config C4 at its full size (3840x2160, depth 8, blended frames): the overlapped schedule equals the serial one bit
-    for bit (4K frames are too large for the oracle; the properties the radiance must have are checked as in the 1440p test)."""
+    for bit, and the properties the radiance must have hold."""
     from lumenrenderer_amd.scenes import sponza_standin
     W, H, D = 3840, 2160, 8
     out = []
@@ -763,7 +803,11 @@ def test_c5_ten_million_triangles_queries_and_schedules():
             dr = rng.normal(size=(256, 3)).astype(np.float32); dr /= np.linalg.norm(dr, axis=1, keepdims=True)
             ip, uvt = r.QueryClosest(org, dr)
             occ = r.QueryAny(org, dr, np.full(256, 50.0, np.float32))
-            o = oracle_from(d, 16, 16, 2)
+            o = oracle_from(d, W, H, D, blend=True)
+            for _ in range(3):
+                assert o.trace_frame() == 0                       # the C5 frame itself against the oracle (its own median-split BVH)
+            assert np.array_equal(out[0][0].view(np.uint32), o.radiance().view(np.uint32))
+            assert list(out[0][1][:4 + D]) == list(o.stats(24)[:4 + D])
             oip, ouvt = o.trace_closest(org, dr, use_bvh=False)
             oocc = o.trace_any(org, dr, np.full(256, 50.0, np.float32), use_bvh=False)
             assert np.array_equal(uvt.view(np.uint32), ouvt.view(np.uint32)) and np.array_equal(ip, oip) and np.array_equal(occ, oocc)
