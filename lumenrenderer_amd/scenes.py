@@ -590,3 +590,47 @@ def write_scene_file(desc, path):
         for inst in desc.instances:
             f.write(struct.pack("<I16f", inst["mesh"], *np.asarray(inst["transform"], np.float32).ravel()))
             f.write(struct.pack("<i4fi", inst["emission_mode"], *inst["override_radiance"], inst["scale"], inst["override_material"]))
+
+
+def read_scene_file(path):
+    """Inverse of write_scene_file (the C reader is examples/render_scene.c)."""
+    import struct
+    data = open(path, "rb").read()
+    pos = 0
+
+    def take(fmt):
+        nonlocal pos
+        v = struct.unpack_from("<" + fmt, data, pos); pos += struct.calcsize("<" + fmt)
+        return v
+
+    magic, = take("I")
+    if magic != SCENE_FILE_MAGIC:
+        raise ValueError("not a scene file")
+    d = SceneDescription()
+    d.textures, d.materials = [], []
+    cam = take("13f")
+    d.set_camera(cam[0:3], cam[3:6], cam[6:9], cam[9:12], cam[12])
+    for _ in range(take("I")[0]):
+        w, h, srgb = take("3I")
+        px = np.frombuffer(data, np.uint8, w * h * 4, pos).reshape(h, w, 4).copy(); pos += w * h * 4
+        d.textures.append(dict(pixels=px, srgb=bool(srgb)))
+    for _ in range(take("I")[0]):
+        v = take("7f"); t = take("8I"); sc = take("13f"); tt = take("6f")
+        m = dict(diffuse_color=tuple(v[0:4]), emission=tuple(v[4:7]), tint_factor=tuple(tt[0:3]), transmittance=tuple(tt[3:6]))
+        m.update(zip(_MATERIAL_TEXTURES, t)); m.update(zip(_MATERIAL_SCALARS, sc))
+        d.materials.append(m)
+    for _ in range(take("I")[0]):
+        mat, nv, ni = take("3I")
+        v = np.frombuffer(data, np.float32, nv * 12, pos).reshape(nv, 12).copy(); pos += nv * 48
+        i = np.frombuffer(data, np.uint32, ni, pos).copy(); pos += ni * 4
+        d.primitives.append(dict(vertices=v, indices=i, material=mat, index_size=4))
+    for _ in range(take("I")[0]):
+        n, = take("I")
+        d.meshes.append(list(take("%dI" % n)))
+    for _ in range(take("I")[0]):
+        v = take("I16f"); w = take("i4fi")
+        d.instances.append(dict(mesh=v[0], transform=np.float32(v[1:17]).reshape(4, 4), emission_mode=w[0], override_radiance=tuple(w[1:4]),
+                                scale=float(w[4]), override_material=w[5]))
+    if pos != len(data):
+        raise ValueError("trailing bytes in scene file")
+    return d
