@@ -135,7 +135,8 @@ int lumen_mi_get_frame_stat(lumen_mi_renderer*, const char* key, uint64_t* micro
  * [22] child boxes slab-tested by the 4-wide traversal, [24..40) histogram of per-ray traversal steps in log2 buckets,
  * [40] the longest per-ray traversal in steps, [41]/[42] active lanes / lane slots over all node steps, [43]/[44] the same
  * over all triangle tests, [45]/[46] traversal-stack pushes into LDS / into the global spill area
- * ([20]..[46] only in the instrumented build), [48]/[49] ReSTIR visibility rays of pass 1 / pass 2 */
+ * ([20]..[46] only in the instrumented build), [48]/[49] ReSTIR visibility rays of pass 1 / pass 2, [50] GPU refits and
+ * [51] instance-level tree assemblies since the renderer was created */
 int lumen_mi_get_counters(lumen_mi_renderer*, uint64_t* out, uint32_t n);
 /* device time of one kernel class, summed over every frame traced since timing was enabled, measured with HIP events
  * on the renderer's stream; `launches` = number of timed launches (class 4: number of frames).
@@ -148,7 +149,8 @@ int lumen_mi_set_instrumented(lumen_mi_renderer*, int enable);   /* use the node
  * overlap, no frame pipelining), "pick_ahead" (ReSTIR candidate generation of the next frame on its own stream: 1 on, 0 off,
  * -1 automatic), "refill" / "refill_visibility" (lane-refill thresholds of the queue traversal), "shadow_on_wave" (NEE shadow rays on
  * the wave stream), "fuzz" (test aid: a seed != 0 inserts idle launches of random length in front of the kernels of a frame; the image
- * must not change). */
+ * must not change), "assemble" (1, default: after the first build a topology edit — an instance added or removed — assembles cached
+ * per-mesh trees behind a small top tree and refits on the GPU; 0: full host SAH rebuild). */
 int lumen_mi_set_tuning(lumen_mi_renderer*, const char* key, int value);
 
 /* ---- tile sharding (new functionality: the reference is single-GPU) */

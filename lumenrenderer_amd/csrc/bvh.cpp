@@ -11,6 +11,7 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <functional>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -450,4 +451,100 @@ void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out)
     out->levelNodes.resize(depthOf.size());
     std::vector<uint32_t> fill(out->levelStart.begin(), out->levelStart.end() - 1);
     for (uint32_t i = 0; i < depthOf.size(); i++) out->levelNodes[fill[maxD - depthOf[i]]++] = i;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// instance-level assembly (bvh.h)
+// ---------------------------------------------------------------------------------------------------------------------
+void lm_assemble_bvh(const LmInstanceRef* inst, uint32_t nInst, LmBvh* out)
+{
+    *out = LmBvh();
+    struct Top { int child[4]; int n; };                     // child >= 0: top node, < 0: ~instance
+    std::vector<Top> top;
+    std::vector<uint32_t> ids(nInst);
+    for (uint32_t i = 0; i < nInst; i++) ids[i] = i;
+    auto centre = [&](uint32_t i, int k) { return 0.5f * (inst[i].box[k] + inst[i].box[3 + k]); };
+    // splits ids[lo, hi) at the median of the centroids along their longest axis (ties by instance number: deterministic)
+    auto splitHalf = [&](uint32_t lo, uint32_t hi) {
+        float cl[3] = {INFINITY, INFINITY, INFINITY}, ch[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t k = lo; k < hi; k++) for (int a = 0; a < 3; a++) { cl[a] = std::min(cl[a], centre(ids[k], a)); ch[a] = std::max(ch[a], centre(ids[k], a)); }
+        int axis = 0;
+        for (int a = 1; a < 3; a++) if (ch[a] - cl[a] > ch[axis] - cl[axis]) axis = a;
+        const uint32_t mid = lo + (hi - lo) / 2u;
+        std::nth_element(ids.begin() + lo, ids.begin() + mid, ids.begin() + hi, [&](uint32_t a, uint32_t b) {
+            const float ca = centre(a, axis), cb = centre(b, axis);
+            return ca < cb || (ca == cb && a < b);
+        });
+        return mid;
+    };
+    struct Range { uint32_t lo, hi; };
+    // recursion depth is log4(nInst)
+    std::function<int(uint32_t, uint32_t)> build = [&](uint32_t lo, uint32_t hi) -> int {
+        if (hi - lo == 1u) return ~(int)ids[lo];
+        const int me = (int)top.size();
+        top.push_back(Top{{0, 0, 0, 0}, 0});
+        Range g[4]; int ng = 0;
+        const uint32_t mid = splitHalf(lo, hi);
+        for (const Range& h : {Range{lo, mid}, Range{mid, hi}}) {
+            if (h.hi - h.lo >= 2u && hi - lo > 2u) { const uint32_t m = splitHalf(h.lo, h.hi); g[ng++] = Range{h.lo, m}; g[ng++] = Range{m, h.hi}; }
+            else if (h.hi > h.lo) g[ng++] = h;
+        }
+        for (int k = 0; k < ng; k++) { const int c = build(g[k].lo, g[k].hi); top[(size_t)me].child[top[(size_t)me].n++] = c; }
+        return me;
+    };
+    if (nInst == 0) { out->nodes4.assign(1, LmNode4{}); for (auto& c : out->nodes4[0].c) c = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, (uint32_t)LM_REF_NONE); }
+    else if (nInst > 1) build(0, nInst);
+    const uint32_t T = (uint32_t)top.size();
+    std::vector<uint32_t> nodeBase(nInst), slotBase(nInst);
+    uint32_t nNodes = T, nSlots = 0;
+    for (uint32_t i = 0; i < nInst; i++) { nodeBase[i] = nNodes; slotBase[i] = nSlots; nNodes += (uint32_t)inst[i].mesh->nodes4.size(); nSlots += (uint32_t)inst[i].mesh->order.size(); }
+    if (nInst) out->nodes4.resize(nNodes);
+    out->order.resize(nSlots);
+    for (uint32_t t = 0; t < T; t++) {
+        LmNode4 q;
+        for (int k = 0; k < 4; k++) {
+            if (k >= top[t].n) { q.c[k] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, (uint32_t)LM_REF_NONE); continue; }
+            const int c = top[t].child[k];
+            q.c[k] = make_uint4(0u, 0u, 0u, (uint32_t)(c >= 0 ? c : (int)nodeBase[(uint32_t)(~c)]));
+        }
+        out->nodes4[t] = q;
+    }
+    for (uint32_t i = 0; i < nInst; i++) {
+        const LmBvh& m = *inst[i].mesh;
+        for (size_t n = 0; n < m.nodes4.size(); n++) {
+            LmNode4 q = m.nodes4[n];
+            for (auto& c : q.c) {
+                const int ref = (int)c.w;
+                if (ref == LM_REF_NONE) continue;
+                if (ref >= 0) c.w = (uint32_t)(ref + (int)nodeBase[i]);
+                else { const uint32_t leaf = (uint32_t)(~ref); c.w = (uint32_t)(~(int)((((leaf >> 3) + slotBase[i]) << 3) | (leaf & 7u))); }
+            }
+            out->nodes4[nodeBase[i] + n] = q;
+        }
+        for (size_t s = 0; s < m.order.size(); s++) out->order[slotBase[i] + s] = inst[i].triBase + m.order[s];
+    }
+    out->woop.assign((size_t)nSlots + 1, LmWoop{});                   // refit_tris writes the packets; the sentinel stays zero
+    // depth of every node, worst-case stack occupancy (the rule of lm_build_bvh's collapse), refit levels deepest first
+    std::vector<uint32_t> depthOf(out->nodes4.size(), 0);
+    struct Item { uint32_t node, depth, stack; };
+    std::vector<Item> st{{0u, 0u, 0u}};
+    out->maxStack = 1; uint32_t maxDepth = 0;
+    while (!st.empty()) {
+        const Item w = st.back(); st.pop_back();
+        depthOf[w.node] = w.depth; maxDepth = std::max(maxDepth, w.depth);
+        uint32_t present = 0;
+        for (const auto& c : out->nodes4[w.node].c) present += (int)c.w != LM_REF_NONE;
+        const uint32_t below = w.stack + (present ? present - 1u : 0u);
+        out->maxStack = std::max(out->maxStack, below + 1u);
+        for (const auto& c : out->nodes4[w.node].c) if ((int)c.w >= 0 && (int)c.w != LM_REF_NONE) st.push_back({c.w, w.depth + 1u, below});
+    }
+    out->maxDepth = maxDepth + 1u;
+    std::vector<uint32_t> count(maxDepth + 2u, 0);
+    for (uint32_t d : depthOf) count[maxDepth - d + 1u]++;             // level 0 = deepest
+    out->levelStart.assign(maxDepth + 2u, 0);
+    for (uint32_t l = 1; l < maxDepth + 2u; l++) out->levelStart[l] = out->levelStart[l - 1] + count[l];
+    out->levelNodes.resize(out->nodes4.size());
+    std::vector<uint32_t> fill(out->levelStart.begin(), out->levelStart.end() - 1);
+    for (uint32_t n = 0; n < (uint32_t)out->nodes4.size(); n++) out->levelNodes[fill[maxDepth - depthOf[n]]++] = n;
 }

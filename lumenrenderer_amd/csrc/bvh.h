@@ -17,3 +17,14 @@ struct LmBvh {
 };
 // tris: 9 floats per triangle (world space)
 void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out);
+
+// Instance-level assembly for topology edits (an instance added or removed): the scene tree becomes a small 4-wide top tree over the
+// instances plus the cached tree of every instance's mesh (built once, in object space) copied behind it with node / slot offsets.
+// Topology only: child boxes and Woop packets of the result are placeholders, the GPU refit (kernels.hip lm_k_refit_*) computes
+// them from the instance transforms.  Hit records do not depend on the tree, so the image equals that of a full rebuild.
+struct LmInstanceRef {
+    const LmBvh* mesh;          // lm_build_bvh over the mesh's object-space triangles (at least one triangle)
+    float box[6];               // world-space box of the instance, lo.xyz hi.xyz (only to shape the top tree)
+    uint32_t triBase;           // global index of the instance's first triangle (the tie-break order of the hit rule)
+};
+void lm_assemble_bvh(const LmInstanceRef* inst, uint32_t nInst, LmBvh* out);

@@ -506,6 +506,7 @@ int lumen_mi_get_counters(lumen_mi_renderer* r, uint64_t* out, uint32_t n)
     }
     for (int k = 0; k < 4; k++) v[41 + k] = (uint64_t)c[LM_CNT_OCC + 2 * k] | ((uint64_t)c[LM_CNT_OCC + 2 * k + 1] << 32);
     v[48] = c[LM_CNT_RESTIR(0)]; v[49] = c[LM_CNT_RESTIR(1)];
+    v[50] = r->refits; v[51] = r->assemblies;                                          // GPU refits / instance-level assemblies since creation
     for (uint32_t i = 0; i < n && i < 64; i++) out[i] = v[i];
     return 0;
 }
@@ -534,6 +535,7 @@ int lumen_mi_set_tuning(lumen_mi_renderer* r, const char* key, int value)
     else if (k == "refit") r->refitEnabled = value;
     else if (k == "pick_ahead") { if (r->initialised) { int rc = syncAndCollect(r); if (rc) return rc; } r->pickAhead = value; }
     else if (k == "fuzz") r->fuzz = (uint32_t)value;
+    else if (k == "assemble") r->assembleEnabled = value;
     else if (k == "shadow_on_wave") { if (r->initialised) { int rc = syncAndCollect(r); if (rc) return rc; } r->shadowOnWave = value; }
     else if (k == "refill") r->refillBelow = value;
     else if (k == "refill_visibility") r->refillVisibility = value;
@@ -650,7 +652,7 @@ int lumen_mi_get_world_triangles(lumen_mi_renderer* r, float* out, uint32_t cap,
     ApiLock lk(r);
     int rc = prepareScene(r); if (rc) return rc;
     *count = (uint32_t)r->triEntry.size();
-    if (out) { if (cap < *count) return fail(LUMEN_MI_ERR_INVALID, "buffer too small"); memcpy(out, r->worldTris.data(), r->worldTris.size() * 4); }
+    if (out) { if (cap < *count) return fail(LUMEN_MI_ERR_INVALID, "buffer too small"); ensureWorldTris(r); memcpy(out, r->worldTris.data(), r->worldTris.size() * 4); }
     return 0;
 }
 int lumen_mi_get_lights(lumen_mi_renderer* r, float* lights16, float* cdf, uint32_t cap, uint32_t* count)
@@ -672,7 +674,10 @@ int lumen_mi_get_bvh_info(lumen_mi_renderer* r, uint32_t* nodes, uint32_t* tris,
     if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer");
     ApiLock lk(r);
     int rc = prepareScene(r); if (rc) return rc;
-    if (nodes) *nodes = (uint32_t)r->bvh.nodes.size(); if (tris) *tris = (uint32_t)r->bvh.order.size(); if (maxDepth) *maxDepth = r->bvh.maxDepth;
+    // binary nodes of the SAH build; 4-wide nodes of an assembled tree
+    if (nodes) *nodes = (uint32_t)(r->bvh.nodes.empty() ? r->bvh.nodes4.size() : r->bvh.nodes.size());
+    if (tris) *tris = (uint32_t)r->bvh.order.size();
+    if (maxDepth) *maxDepth = r->bvh.maxDepth;
     return 0;
 }
 

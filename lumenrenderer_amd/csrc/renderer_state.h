@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -45,7 +46,11 @@ static_assert(sizeof(Vertex48) == 48, "Vertex layout (ModelStructs.h:21-28)");
 struct Texture { uint32_t w, h; bool srgb; std::vector<uint32_t> px; };
 struct Material { LmDevMaterial dev; float emissiveColor[3]; };
 struct Primitive { std::vector<Vertex48> verts; std::vector<uint32_t> idx; size_t material; std::vector<uint8_t> emissive; uint32_t numLights = 0; bool containEmissive = false; };
-struct Mesh { std::vector<size_t> prims; };
+struct Mesh {
+    std::vector<size_t> prims;
+    // cached for instance-level assembly (scene.cpp flatten): the mesh's own tree over its object-space triangles, its box
+    std::shared_ptr<LmBvh> bvh; float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}; uint32_t tris = 0;
+};
 struct Instance { size_t scene; size_t mesh; float M[16]; int mode; float radiance[3]; float scale; long overrideMaterial; std::vector<uint32_t> entries; };
 struct Scene { std::vector<size_t> instances; };
 
@@ -119,6 +124,9 @@ struct lumen_mi_renderer {
     hipEvent_t evJoin = nullptr, evJoin2 = nullptr, evVis = nullptr, evVisDone = nullptr;
     hipEvent_t evPick = nullptr;
     int pickAhead = 1;                      // 1 on (default), 0 off, -1 only for windows under 1 Mpixel
+    int assembleEnabled = 1;                // topology edits after the first build assemble cached per-mesh trees + GPU refit instead of a host SAH rebuild
+    bool builtOnce = false;
+    uint32_t assemblies = 0;                // scene trees assembled since creation
     uint32_t fuzz = 0;                      // != 0: schedule fuzzing (test aid): random idle launches in front of the kernels of a frame, this is the RNG state
     int shadowOnWave = 0;                   // 1: NEE shadow rays on the wave stream (the path tail then has the third stream to itself); measured: 8 % slower for half-frame windows, equal elsewhere
     hipEvent_t evFront = nullptr, evTemporal[2] = {nullptr, nullptr}, evTop = nullptr, evMerge[2] = {nullptr, nullptr};   // cross-frame pipelining (traceFrameAsync)
@@ -234,6 +242,7 @@ using R = lumen_mi_renderer;
 // scene.cpp
 void findEmissives(const R* r, Primitive& p);
 int flatten(R* r);
+void ensureWorldTris(R* r);
 int syncScene(R* r, hipStream_t su);
 int uploadResources(R* r);
 int buildLights(R* r);

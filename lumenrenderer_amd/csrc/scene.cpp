@@ -70,7 +70,7 @@ int refreshEntries(R* r)
         }
     }
     ++r->entriesVer;
-    if (r->transformsDirty) ++r->geomVer;
+    if (r->transformsDirty) { ++r->geomVer; r->worldTris.clear(); }          // (host copy of the world triangles: ensureWorldTris)
     r->transformsDirty = false;
     r->entriesDirty = false;
     r->lightsDirty = true;
@@ -141,6 +141,11 @@ int flatten(R* r)
     if (r->activeScene < 0) return fail(LUMEN_MI_ERR_STATE, "no scene set (lumen_mi_set_scene)");
     Scene& sc = r->scenes[r->activeScene];
     r->entries.clear(); r->entryPrim.clear(); r->worldTris.clear(); r->triEntry.clear(); r->triPrim.clear();
+    // A topology edit after the first build (instances added / removed) does not need a new SAH tree: every mesh keeps its own tree
+    // (object space, built once), the scene tree is those trees behind a small top tree over the instances (lm_assemble_bvh), and
+    // the GPU refit computes boxes and Woop packets from the instance transforms.  The first build is the full SAH build.
+    const bool assemble = r->assembleEnabled && r->refitEnabled && r->builtOnce;
+    std::vector<LmInstanceRef> refs;
     // vertex / index pools: one slot range per primitive
     std::vector<uint32_t> vertBase(r->prims.size()), idxBase(r->prims.size());
     std::vector<float4> verts; std::vector<uint32_t> indices;
@@ -156,6 +161,28 @@ int flatten(R* r)
     for (size_t ii : sc.instances) {
         Instance& mi = r->instances[ii];
         mi.entries.clear();
+        if (assemble) {
+            Mesh& mesh = r->meshes[mi.mesh];
+            if (!mesh.bvh) {                                   // the mesh's own tree, triangles in the order the loop below numbers them
+                std::vector<float> local;
+                for (size_t p : mesh.prims) { const Primitive& pr = r->prims[p]; for (size_t t = 0; t + 2 < pr.idx.size(); t += 3) for (int k = 0; k < 3; k++) for (int a = 0; a < 3; a++) local.push_back(pr.verts[pr.idx[t + k]].pos[a]); }
+                mesh.tris = (uint32_t)(local.size() / 9);
+                mesh.bvh = std::make_shared<LmBvh>();
+                lm_build_bvh(local.data(), mesh.tris, mesh.bvh.get());
+                for (int a = 0; a < 3; a++) { mesh.lo[a] = INFINITY; mesh.hi[a] = -INFINITY; }
+                for (size_t f = 0; f < local.size(); f++) { mesh.lo[f % 3] = std::min(mesh.lo[f % 3], local[f]); mesh.hi[f % 3] = std::max(mesh.hi[f % 3], local[f]); }
+            }
+            if (mesh.tris) {
+                LmInstanceRef ref; ref.mesh = mesh.bvh.get(); ref.triBase = (uint32_t)r->triEntry.size();
+                for (int a = 0; a < 3; a++) { ref.box[a] = INFINITY; ref.box[3 + a] = -INFINITY; }
+                for (int c = 0; c < 8; c++) {
+                    const float corner[3] = {(c & 1) ? mesh.hi[0] : mesh.lo[0], (c & 2) ? mesh.hi[1] : mesh.lo[1], (c & 4) ? mesh.hi[2] : mesh.lo[2]};
+                    float w[3]; mulPoint(mi.M, corner, 1.f, w);
+                    for (int a = 0; a < 3; a++) { ref.box[a] = std::min(ref.box[a], w[a]); ref.box[3 + a] = std::max(ref.box[3 + a], w[a]); }
+                }
+                refs.push_back(ref);
+            }
+        }
         for (size_t p : r->meshes[mi.mesh].prims) {
             LmEntry e;
             memcpy(e.m, mi.M, sizeof e.m);
@@ -169,7 +196,7 @@ int flatten(R* r)
             r->entryPrim.push_back(p);
             const Primitive& pr = r->prims[p];
             for (size_t t = 0; t + 2 < pr.idx.size(); t += 3) {
-                for (int k = 0; k < 3; k++) {
+                for (int k = 0; k < 3 && !assemble; k++) {        // (the assembled tree needs no host-side world triangles: ensureWorldTris)
                     float w[3];
                     mulPoint(e.m, pr.verts[pr.idx[t + k]].pos, 1.f, w);
                     r->worldTris.push_back(w[0]); r->worldTris.push_back(w[1]); r->worldTris.push_back(w[2]);
@@ -179,7 +206,9 @@ int flatten(R* r)
         }
     }
     const uint32_t nt = (uint32_t)r->triEntry.size();
-    lm_build_bvh(r->worldTris.data(), nt, &r->bvh);
+    const bool assembled = assemble && !refs.empty();
+    if (assembled) { lm_assemble_bvh(refs.data(), (uint32_t)refs.size(), &r->bvh); ++r->assemblies; }
+    else { if (assemble) ensureWorldTris(r); lm_build_bvh(r->worldTris.data(), nt, &r->bvh); }
     if (r->bvh.maxStack > LM_STACK_DEPTH) return fail(LUMEN_MI_ERR_STATE, "BVH needs a deeper traversal stack than LM_STACK_DEPTH");
     std::vector<uint2> triId(nt);
     for (uint32_t s = 0; s < nt; s++) triId[s] = make_uint2(r->triEntry[r->bvh.order[s]], r->triPrim[r->bvh.order[s]]);
@@ -193,7 +222,7 @@ int flatten(R* r)
     for (SceneSet& S : r->sset) {
         if (S.nodes.upload(r->bvh.nodes4, st) || S.woop.upload(r->bvh.woop, st) || S.entries.upload(r->entries, st) || S.quant.upload(quant, st))
             return fail(LUMEN_MI_ERR_DEVICE, "scene upload failed (hipMalloc/hipMemcpy)");
-        S.entriesVer = r->entriesVer; S.geomVer = r->geomVer;
+        S.entriesVer = r->entriesVer; S.geomVer = assembled ? 0 : r->geomVer;      // an assembled tree has no boxes yet: syncScene refits
     }
     if (r->dTriId.upload(triId, st) || r->dTriOrder.upload(r->bvh.order, st) || r->dVerts.upload(verts, st) || r->dIndices.upload(indices, st))
         return fail(LUMEN_MI_ERR_DEVICE, "scene upload failed (hipMalloc/hipMemcpy)");
@@ -217,7 +246,25 @@ int flatten(R* r)
     r->transformsDirty = false;
     r->entriesDirty = false;
     r->lightsDirty = true;
+    r->builtOnce = true;
     return 0;
+}
+
+// world-space triangle soup on the host: input of the SAH build, and what lumen_mi_get_world_triangles returns; an assembled
+// scene tree does not need it, so it is produced on demand
+void ensureWorldTris(R* r)
+{
+    if (r->worldTris.size() == 9 * r->triEntry.size()) return;
+    r->worldTris.clear(); r->worldTris.reserve(9 * r->triEntry.size());
+    for (size_t g = 0; g < r->triEntry.size(); g++) {
+        const LmEntry& e = r->entries[r->triEntry[g]];
+        const Primitive& pr = r->prims[r->entryPrim[r->triEntry[g]]];
+        for (int k = 0; k < 3; k++) {
+            float w[3];
+            mulPoint(e.m, pr.verts[pr.idx[3 * (size_t)r->triPrim[g] + k]].pos, 1.f, w);
+            r->worldTris.push_back(w[0]); r->worldTris.push_back(w[1]); r->worldTris.push_back(w[2]);
+        }
+    }
 }
 
 int uploadResources(R* r)

@@ -331,6 +331,7 @@ class LumenRendererMI:
         self.SetScene(scene)
         self.m_Scene = scene
         self.m_Materials = mats
+        self.m_Meshes = meshes
         cam = desc.camera
         self.SetCamera(cam["position"], cam["right"], cam["up"], cam["forward"], cam["fov"])
         return scene

@@ -5,6 +5,7 @@
 //                  stack occupancy covers the tree and fits the kernels' stack
 //   Woop packets : bit-identical to lm_make_woop (the function the GPU refit runs) of the ordered triangle, zero sentinel
 //   determinism  : 1 thread and N threads produce the same bytes
+//   assembly     : lm_assemble_bvh (instance-level trees for topology edits) passes the same structural checks
 // usage: bvh_check <threads> <nTris>...      prints "ok <n> ..." per size, exits non-zero on the first violation
 #include "bvh.h"
 #include "lm_woop.h"
@@ -38,7 +39,7 @@ std::vector<float> soup(uint32_t n, uint32_t seed)
 int fail(const char* what, long a = 0, long b = 0) { fprintf(stderr, "bvh_check: %s (%ld, %ld)\n", what, a, b); return 1; }
 
 struct Walk {
-    const LmBvh& b; const float* tris;
+    const LmBvh& b; const float* tris; bool boxes = true;
     std::vector<uint8_t> slotSeen, nodeSeen;
     std::vector<int> nodeDepth;
     int err = 0;
@@ -75,7 +76,7 @@ struct Walk {
                 const double bhi = (double)b.qmin[k] + (double)(qq[k] >> 16) * (double)b.qstep[k];
                 // (the kernels evaluate the box in fp32: allow their rounding, which the builder's outward padding covers)
                 const double eps = 4.0 * (double)b.pad;
-                if (clo[k] <= chi[k] && (blo > clo[k] + eps || bhi < chi[k] - eps)) err = fail("child box does not contain its triangles", ref, c);
+                if (boxes && clo[k] <= chi[k] && (blo > clo[k] + eps || bhi < chi[k] - eps)) err = fail("child box does not contain its triangles", ref, c);
                 lo[k] = std::min(lo[k], clo[k]); hi[k] = std::max(hi[k], chi[k]);
             }
         }
@@ -83,19 +84,20 @@ struct Walk {
     }
 };
 
-int check(const LmBvh& b, const float* tris, uint32_t n)
+int check(const LmBvh& b, const float* tris, uint32_t n, bool built = true)
 {
     if (b.order.size() != n) return fail("order size", (long)b.order.size(), n);
     std::vector<uint8_t> seen(n, 0);
     for (uint32_t s = 0; s < n; s++) { if (b.order[s] >= n || seen[b.order[s]]++) return fail("order is not a permutation", s); }
     if (b.nodes4.empty()) return fail("no root node");
     if (b.woop.size() != (size_t)n + 1) return fail("woop packet count", (long)b.woop.size());
-    for (uint32_t s = 0; s < n; s++) {
+    for (uint32_t s = 0; built && s < n; s++) {
         const LmWoop w = lm_make_woop(tris + 9 * (size_t)b.order[s]);
         if (memcmp(&w, &b.woop[s], sizeof w) != 0) return fail("woop packet differs from lm_make_woop", s);
     }
     { LmWoop z; memset(&z, 0, sizeof z); if (memcmp(&z, &b.woop[n], sizeof z) != 0) return fail("sentinel packet is not zero"); }
     Walk w(b, tris);
+    w.boxes = built;
     double lo[3], hi[3];
     const uint32_t worst = w.visit(0, 0, lo, hi);
     if (w.err) return 1;
@@ -144,6 +146,31 @@ int main(int argc, char** argv)
         if (check(one, t.data(), n) || check(many, t.data(), n)) return 1;
         if (!same(one, many)) return fail("the build depends on the thread count", n);
         printf("ok %u triangles: %zu nodes, depth %u, stack %u\n", n, many.nodes4.size(), many.maxDepth, many.maxStack);
+    }
+    // instance-level assembly (lm_assemble_bvh): per-mesh trees + a top tree; topology only (boxes / packets come from the GPU refit)
+    for (uint32_t nInst : {1u, 2u, 3u, 5u, 9u, 40u}) {
+        const uint32_t sizes[3] = {1u, 37u, 2500u};
+        std::vector<float> meshTris[3]; LmBvh meshBvh[3];
+        for (int m = 0; m < 3; m++) { meshTris[m] = soup(sizes[m], 100u + (uint32_t)m); lm_build_bvh(meshTris[m].data(), sizes[m], &meshBvh[m]); }
+        std::vector<LmInstanceRef> inst(nInst);
+        std::vector<float> world;
+        for (uint32_t i = 0; i < nInst; i++) {
+            const int m = (int)(i % 3u);
+            const float off[3] = {50.f * (float)(i % 4u), 7.f * (float)(i / 4u), -30.f * (float)(i % 3u)};
+            inst[i].mesh = &meshBvh[m]; inst[i].triBase = (uint32_t)(world.size() / 9);
+            for (int k = 0; k < 3; k++) { inst[i].box[k] = 1e30f; inst[i].box[3 + k] = -1e30f; }
+            for (size_t f = 0; f < meshTris[m].size(); f++) {
+                const float v = meshTris[m][f] + off[f % 3];
+                world.push_back(v);
+                inst[i].box[f % 3] = std::min(inst[i].box[f % 3], v); inst[i].box[3 + f % 3] = std::max(inst[i].box[3 + f % 3], v);
+            }
+        }
+        LmBvh scene;
+        lm_assemble_bvh(inst.data(), nInst, &scene);
+        const uint32_t n = (uint32_t)(world.size() / 9);
+        if (check(scene, world.data(), n, false)) return 1;
+        if (scene.nodes4.size() > 0 && (int)scene.nodes4[0].c[0].w == LM_REF_NONE) return fail("assembled root has no child");
+        printf("ok assembly of %u instances: %u triangles, %zu nodes, depth %u, stack %u\n", nInst, n, scene.nodes4.size(), scene.maxDepth, scene.maxStack);
     }
     return 0;
 }

@@ -381,7 +381,8 @@ def test_host_bvh_builder_structure_determinism_and_sanitizers(sanitizer, tmp_pa
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1", ASAN_OPTIONS="detect_leaks=1")
     run = subprocess.run([exe, "8"] + sizes, capture_output=True, text=True, env=env, timeout=600)
     assert run.returncode == 0, (run.stdout[-1000:], run.stderr[-3000:])
-    assert run.stdout.count("ok ") == len(sizes) and "WARNING: ThreadSanitizer" not in run.stderr and "runtime error" not in run.stderr
+    assert run.stdout.count("ok ") == len(sizes) + 6 and run.stdout.count("ok assembly") == 6          # + lm_assemble_bvh for 1 .. 40 instances
+    assert "WARNING: ThreadSanitizer" not in run.stderr and "runtime error" not in run.stderr
 
 
 def test_oracle_runs_clean_under_address_and_undefined_behaviour_sanitizers(tmp_path):

@@ -586,6 +586,43 @@ def test_moving_instances_refit_matches_oracle(refit):
     r.close(); o.close()
 
 
+@pytest.mark.parametrize("assemble", [1, 0], ids=["assembled", "host-rebuild"])
+def test_instances_added_and_removed_between_frames(assemble):
+    """Topology edits (the reference rebuilds its instance acceleration structure, PTScene.cpp:74-156): instances are
+    added, moved and the scene is cleared and refilled between blended frames.  After the first (SAH) build the product assembles
+    the scene tree from cached per-mesh trees + a top tree and refits on the GPU (lm_assemble_bvh); the hit rule does not depend on
+    the tree, so every frame still equals the oracle bit for bit, and the ray queries equal the oracle's brute force."""
+    soup = random_soup(600, 21, extent=5.0, size=0.6)
+    d = cornell()
+    p = soup.primitives[0]
+    v = np.array(p["vertices"], np.float32).reshape(-1, 12).copy(); v[:, 0:3] *= np.float32(0.06)
+    mat = d.add_material(diffuse_color=(0.3, 0.6, 0.7, 1.0), roughness_factor=0.6, metallic_factor=0.0)
+    extra_mesh = d.add_mesh([d.add_primitive(v, p["indices"], mat)])
+    W, H, D = 96, 72, 3
+    r = product_from(d, W, H, D, blend=True, tuning={"assemble": assemble}); o = oracle_from(d, W, H, D, blend=True)
+    _compare_frames(r, o, 2, check_gbuffer=False)                                # first build: full SAH
+    meshes = r.m_Meshes
+    added = []
+    for k in range(4):                                                           # add four copies of the extra mesh, one per frame
+        xf = _rigid(0.4 * k, (0.35 * (k - 1.5), 0.6 + 0.25 * k, 0.2 * k))
+        added.append(r.m_Scene.AddMesh(meshes[extra_mesh])); added[-1].SetTransform(xf)
+        o.add_instance(extra_mesh, xf)
+        _compare_frames(r, o, 1, check_gbuffer=False)
+    xf = _rigid(1.3, (0.1, 1.2, -0.3))                                           # move one of them: a refit of the assembled tree
+    added[1].SetTransform(xf); o.set_instance_transform(len(d.instances) + 1, xf)
+    _compare_frames(r, o, 2, check_gbuffer=False)
+    rng = np.random.default_rng(8)
+    org = rng.uniform(-0.8, 0.8, (300, 3)).astype(np.float32) + np.float32([0, 1, 2.5])
+    dr = rng.normal(size=(300, 3)).astype(np.float32); dr /= np.linalg.norm(dr, axis=1, keepdims=True)
+    ip, uvt = r.QueryClosest(org, dr); oip, ouvt = o.trace_closest(org, dr, use_bvh=False)
+    assert np.array_equal(uvt.view(np.uint32), ouvt.view(np.uint32)) and np.array_equal(ip, oip)
+    assert np.array_equal(r.QueryAny(org, dr, np.full(300, 4.0, np.float32)), o.trace_any(org, dr, np.full(300, 4.0, np.float32), use_bvh=False))
+    assert np.array_equal(r.GetWorldTriangles().view(np.uint32), o.world_triangles().view(np.uint32))
+    c = r.GetCounters(52)
+    assert (c[51] >= 4) if assemble else (c[51] == 0)
+    r.close(); o.close()
+
+
 def test_emissiveness_and_override_material_changes_between_frames():
     """MeshInstance::SetEmissiveness / SetOverrideMaterial between frames (MeshInstance.h:57-98, PTMeshInstance.cpp:123-178):
     the product refreshes its scene data table and light list without rebuilding the BVH; the oracle rebuilds everything."""
