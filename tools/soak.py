@@ -25,6 +25,14 @@ def edits(r, k):
         r.SetCamera((0.0, 3.0 + 0.01 * (k % 9), 0.0), (1, 0, 0), (0, 1, 0), (0, 0, -1), 80.0)
     if k % 400 == 399:
         r.SetRenderResolution(W - 64 * ((k // 400) % 3), H)          # buffers are reallocated
+    if k % 97 == 96:                                                  # topology edit: the scene is cleared and refilled (+ a second light quad now and then)
+        sc = r.m_Scene; sc.Clear()
+        for d in desc.instances:
+            mi = sc.AddMesh(r.m_Meshes[d["mesh"]]); mi.SetTransform(d["transform"]); mi.SetEmissiveness(d["emission_mode"], d["override_radiance"], d["scale"])
+        if (k // 97) % 2:
+            d = desc.instances[1]; t = np.array(d["transform"], np.float32).reshape(4, 4).copy(); t[0, 3] += 2.0
+            mi = sc.AddMesh(r.m_Meshes[d["mesh"]]); mi.SetTransform(t); mi.SetEmissiveness(d["emission_mode"], d["override_radiance"], d["scale"])
+        inst = sc.m_MeshInstances
     if k % 250 == 249:
         r.SetWindow(16, 8, 1000, 700) if (k // 250) % 2 else r.SetWindow(0, 0, 0, 0)
 
