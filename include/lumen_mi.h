@@ -91,7 +91,7 @@ int lumen_mi_set_scene(lumen_mi_renderer*, lumen_mi_handle scene);              
 
 /* ---- ILumenScene / MeshInstance (ILumenScene.h:48-67, MeshInstance.h:22-112) */
 int lumen_mi_scene_add_mesh(lumen_mi_renderer*, lumen_mi_handle scene, lumen_mi_handle mesh, lumen_mi_handle* instance_out);               /* AddMesh()->SetMesh() */
-int lumen_mi_scene_clear(lumen_mi_renderer*, lumen_mi_handle scene);                                                                       /* Clear() */
+int lumen_mi_scene_clear(lumen_mi_renderer*, lumen_mi_handle scene);                                                                       /* Clear(): the scene's instance handles are released (later use: LUMEN_MI_ERR_INVALID) */
 int lumen_mi_instance_set_transform(lumen_mi_renderer*, lumen_mi_handle instance, const float world_matrix[16]);                           /* m_Transform */
 int lumen_mi_instance_set_emissiveness(lumen_mi_renderer*, lumen_mi_handle instance, int mode, const float override_radiance[3], float scale); /* SetEmissiveness */
 int lumen_mi_instance_set_override_material(lumen_mi_renderer*, lumen_mi_handle instance, lumen_mi_handle material);                       /* SetOverrideMaterial */

@@ -270,6 +270,19 @@ int lumen_mi_set_scene(lumen_mi_renderer* r, lumen_mi_handle scene)
     return 0;
 }
 
+// instance handles: type tag | 24-bit generation | slot + 1 (MeshInstance objects die with ILumenScene::Clear in the reference; here
+// their slots are recycled and a handle from before the clear no longer resolves)
+static lumen_mi_handle instanceHandle(size_t idx, uint32_t gen) { return ((uint64_t)H_INSTANCE << 56) | ((uint64_t)(gen & 0xffffffu) << 32) | (uint64_t)(idx + 1); }
+static bool instanceOf(const lumen_mi_renderer* r, lumen_mi_handle h, size_t& idx)
+{
+    if ((h >> 56) != (uint64_t)H_INSTANCE) return false;
+    const uint64_t slot = h & 0xffffffffull;
+    if (slot == 0 || slot > r->instances.size()) return false;
+    idx = (size_t)slot - 1;
+    const Instance& i = r->instances[idx];
+    return i.alive && (uint64_t)(i.gen & 0xffffffu) == ((h >> 32) & 0xffffffull);
+}
+
 int lumen_mi_scene_add_mesh(lumen_mi_renderer* r, lumen_mi_handle scene, lumen_mi_handle mesh, lumen_mi_handle* inst)
 {
     size_t s, m;
@@ -280,10 +293,12 @@ int lumen_mi_scene_add_mesh(lumen_mi_renderer* r, lumen_mi_handle scene, lumen_m
     const float id[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     memcpy(i.M, id, sizeof id);
     i.mode = LUMEN_MI_EMISSION_ENABLED; i.radiance[0] = i.radiance[1] = i.radiance[2] = 0.f; i.scale = 1.f; i.overrideMaterial = -1;   // MeshInstance.h:24-35
-    r->instances.push_back(i);
-    r->scenes[s].instances.push_back(r->instances.size() - 1);
+    size_t slot;
+    if (!r->freeInstances.empty()) { slot = r->freeInstances.back(); r->freeInstances.pop_back(); i.gen = r->instances[slot].gen + 1; r->instances[slot] = i; }
+    else { slot = r->instances.size(); r->instances.push_back(i); }
+    r->scenes[s].instances.push_back(slot);
     r->sceneDirty = true;
-    *inst = mkh(H_INSTANCE, r->instances.size() - 1);
+    *inst = instanceHandle(slot, r->instances[slot].gen);
     return 0;
 }
 
@@ -292,6 +307,7 @@ int lumen_mi_scene_clear(lumen_mi_renderer* r, lumen_mi_handle scene)
     size_t s;
     if (!r || !unh(scene, H_SCENE, r->scenes.size(), s)) return fail(LUMEN_MI_ERR_INVALID, "bad scene handle");
     ApiLock lk(r);
+    for (size_t i : r->scenes[s].instances) { r->instances[i].alive = false; r->instances[i].entries.clear(); r->freeInstances.push_back(i); }
     r->scenes[s].instances.clear(); r->sceneDirty = true;
     return 0;
 }
@@ -299,7 +315,7 @@ int lumen_mi_scene_clear(lumen_mi_renderer* r, lumen_mi_handle scene)
 int lumen_mi_instance_set_transform(lumen_mi_renderer* r, lumen_mi_handle inst, const float m[16])
 {
     size_t i;
-    if (!r || !m || !unh(inst, H_INSTANCE, r->instances.size(), i)) return fail(LUMEN_MI_ERR_INVALID, "bad instance handle");
+    if (!r || !m || !instanceOf(r, inst, i)) return fail(LUMEN_MI_ERR_INVALID, "bad instance handle (released by lumen_mi_scene_clear?)");
     ApiLock lk(r);
     if (memcmp(r->instances[i].M, m, 64) != 0) { memcpy(r->instances[i].M, m, 64); r->transformsDirty = true; }   // polled every frame by the adapter
     return 0;
@@ -308,7 +324,7 @@ int lumen_mi_instance_set_transform(lumen_mi_renderer* r, lumen_mi_handle inst, 
 int lumen_mi_instance_set_emissiveness(lumen_mi_renderer* r, lumen_mi_handle inst, int mode, const float rad[3], float scale)
 {
     size_t i;
-    if (!r || !rad || mode < 0 || mode > 2 || !unh(inst, H_INSTANCE, r->instances.size(), i)) return fail(LUMEN_MI_ERR_INVALID, "bad emissiveness arguments");
+    if (!r || !rad || mode < 0 || mode > 2 || !instanceOf(r, inst, i)) return fail(LUMEN_MI_ERR_INVALID, "bad emissiveness arguments");
     ApiLock lk(r);
     Instance& x = r->instances[i];
     if (x.mode != mode || x.radiance[0] != rad[0] || x.radiance[1] != rad[1] || x.radiance[2] != rad[2] || x.scale != scale) r->entriesDirty = true;
@@ -319,7 +335,7 @@ int lumen_mi_instance_set_emissiveness(lumen_mi_renderer* r, lumen_mi_handle ins
 int lumen_mi_instance_set_override_material(lumen_mi_renderer* r, lumen_mi_handle inst, lumen_mi_handle mat)
 {
     size_t i, m;
-    if (!r || !unh(inst, H_INSTANCE, r->instances.size(), i) || !unh(mat, H_MATERIAL, r->materials.size(), m)) return fail(LUMEN_MI_ERR_INVALID, "bad handle");
+    if (!r || !instanceOf(r, inst, i) || !unh(mat, H_MATERIAL, r->materials.size(), m)) return fail(LUMEN_MI_ERR_INVALID, "bad handle");
     ApiLock lk(r);
     if (r->instances[i].overrideMaterial != (long)m) r->entriesDirty = true;
     r->instances[i].overrideMaterial = (long)m;

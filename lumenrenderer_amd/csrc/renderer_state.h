@@ -51,7 +51,10 @@ struct Mesh {
     // cached for instance-level assembly (scene.cpp flatten): the mesh's own tree over its object-space triangles, its box
     std::shared_ptr<LmBvh> bvh; float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}; uint32_t tris = 0;
 };
-struct Instance { size_t scene; size_t mesh; float M[16]; int mode; float radiance[3]; float scale; long overrideMaterial; std::vector<uint32_t> entries; };
+struct Instance {
+    size_t scene; size_t mesh; float M[16]; int mode; float radiance[3]; float scale; long overrideMaterial; std::vector<uint32_t> entries;
+    uint32_t gen = 1; bool alive = true;     // slots of a cleared scene are reused; the handle carries the generation, so a stale handle is refused
+};
 struct Scene { std::vector<size_t> instances; };
 
 template <class T> struct DevBuf {
@@ -183,6 +186,7 @@ struct lumen_mi_renderer {
 
     // flattened scene (host)
     std::vector<LmEntry> entries;
+    std::vector<size_t> freeInstances;      // instance slots released by lumen_mi_scene_clear
     std::vector<size_t> entryPrim;          // table entry -> primitive
     std::vector<float> worldTris;
     std::vector<uint32_t> triEntry, triPrim;

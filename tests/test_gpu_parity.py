@@ -181,11 +181,22 @@ def test_c_abi_reports_bad_arguments_and_call_order():
     r.SetWindow(0, 0, 64, 16); fails(1, r.TraceFrame)                  # a window outside the image is reported by the frame that uses it
     r.SetWindow(0, 0, 0, 0)                                            # (0,0,0,0): the whole image again
     assert r.TraceFrame() is True
+    # instances die with ILumenScene::Clear: their handles stop resolving, the slots are reused under a new generation
+    old = r.m_Scene.m_MeshInstances[0]
+    mesh0 = r.m_Meshes[d.instances[0]["mesh"]]
+    r.m_Scene.Clear()
+    fails(1, old.SetTransform, np.eye(4, dtype=np.float32))
+    again = r.m_Scene.AddMesh(mesh0); again.SetTransform(d.instances[0]["transform"])
+    assert again.handle != old.handle and (again.handle & 0xffffffff) <= len(d.instances) and ((again.handle >> 32) & 0xffffff) == 2   # a released slot, generation 2
+    fails(1, old.SetEmissiveness, 0)
+    for inst in d.instances[1:]:
+        mi = r.m_Scene.AddMesh(r.m_Meshes[inst["mesh"]]); mi.SetTransform(inst["transform"]); mi.SetEmissiveness(inst["emission_mode"], inst["override_radiance"], inst["scale"])
+    assert r.TraceFrame() is True
     small = np.full(8, 7.0, np.float32)
     assert lib.lumen_mi_get_radiance(r.h, small.ctypes.data_as(C.POINTER(C.c_float)), small.nbytes) == 1
     assert (small == 7.0).all() and b"too small" in lib.lumen_mi_last_error()
     o = oracle_from(d, 32, 32, 2)
-    assert o.trace_frame() == 0
+    assert o.trace_frame() == 0 and o.trace_frame() == 0          # the product has completed two frames (the refused ones do not count)
     assert np.array_equal(r.GetRadiance().view(np.uint32), o.radiance().view(np.uint32))
     r.close(); o.close()
 
