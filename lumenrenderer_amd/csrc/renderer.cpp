@@ -91,8 +91,8 @@ int lumen_mi_destroy(lumen_mi_renderer* r)
             for (int i = 0; i < 2; i++) { (void)hipEventDestroy(r->evCnt[i]); (void)hipHostFree(r->pinnedCounters[i]); r->pinnedCounters[i] = nullptr; }
         }
         for (SceneSet& S : r->sset) { if (S.upPending) (void)hipEventSynchronize(S.evUp); S.release(); }
-        r->dSpill.release(); r->dTriId.release(); r->dTriOrder.release(); r->dVerts.release(); r->dIndices.release();
-        r->dTriBox.release(); r->dNodeBox.release(); r->dLevelNodes.release(); r->dRefitBounds.release();
+        r->dSpill.release(); r->dVerts.release(); r->dIndices.release();
+        r->dTriBox.release(); r->dNodeBox.release(); r->dRefitBounds.release();
         r->dMaterials.release(); r->dTexDesc.release(); r->dTexels.release(); r->dLut.release();
         for (auto& b : r->dRay) b.release();
         for (auto& b : r->dTailRay) b.release();

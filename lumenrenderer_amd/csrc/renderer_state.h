@@ -91,12 +91,16 @@ template <class T> struct HostBuf {                 // pinned staging memory for
 // refit kernels) on the wave stream, so frames keep overlapping while the scene changes.
 struct SceneSet {
     DevBuf<LmNode4> nodes; DevBuf<LmWoop> woop; DevBuf<float> quant; DevBuf<LmEntry> entries; DevBuf<LmLight> lights; DevBuf<float> cdf;
+    DevBuf<uint2> triId; DevBuf<uint32_t> triOrder, levelNodes;            // topology of the tree in `nodes` (what an instance add / remove rewrites)
+    std::vector<uint32_t> levelStart; uint32_t nTris = 0;
     HostBuf<LmEntry> hEntries; HostBuf<LmLight> hLights; HostBuf<float> hCdf;
+    HostBuf<LmNode4> hNodes; HostBuf<uint2> hTriId; HostBuf<uint32_t> hOrder, hLevelNodes;
     hipEvent_t evUp = nullptr; bool upPending = false;      // the staging buffers are free again once this event has passed
-    uint64_t entriesVer = 0, geomVer = 0, lightsVer = 0;    // state of the host scene this set holds
+    uint64_t entriesVer = 0, geomVer = 0, lightsVer = 0, topoVer = 0;    // state of the host scene this set holds
     void release() {
         nodes.release(); woop.release(); quant.release(); entries.release(); lights.release(); cdf.release();
-        hEntries.release(); hLights.release(); hCdf.release();
+        triId.release(); triOrder.release(); levelNodes.release();
+        hEntries.release(); hLights.release(); hCdf.release(); hNodes.release(); hTriId.release(); hOrder.release(); hLevelNodes.release();
         if (evUp) { (void)hipEventDestroy(evUp); evUp = nullptr; }
     }
 };
@@ -198,10 +202,11 @@ struct lumen_mi_renderer {
     // device scene
     SceneSet sset[2];                       // sset[sgen] is what the next frame's kernels read
     int sgen = 0;
-    uint64_t entriesVer = 1, geomVer = 1, lightsVer = 1;      // versions of the host-side scene state (instance table, geometry, light list)
-    DevBuf<uint2> dTriId; DevBuf<uint32_t> dTriOrder;
+    uint64_t entriesVer = 1, geomVer = 1, lightsVer = 1, topoVer = 1;      // versions of the host-side scene state (instance table, geometry, light list, tree topology)
+    std::vector<uint2> triId;               // per BVH triangle slot: (table entry, primitive-local triangle)
+    std::vector<uint32_t> vertBase, idxBase; size_t poolPrims = 0, poolVerts = 0, poolIdx = 0;      // vertex / index pools on the device cover prims [0, poolPrims)
     DevBuf<float4> dVerts; DevBuf<uint32_t> dIndices; DevBuf<LmDevMaterial> dMaterials;
-    DevBuf<float4> dTriBox, dNodeBox; DevBuf<uint32_t> dLevelNodes, dRefitBounds;
+    DevBuf<float4> dTriBox, dNodeBox; DevBuf<uint32_t> dRefitBounds;
     DevBuf<int> dSpill; DevBuf<LmTexDesc> dTexDesc; DevBuf<uint32_t> dTexels; DevBuf<float> dLut;
     LmScene dscene{};
 

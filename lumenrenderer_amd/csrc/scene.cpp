@@ -85,11 +85,27 @@ int syncScene(R* r, hipStream_t su)
 {
     if (r->sset[0].nodes.p == nullptr) return 0;                   // nothing built yet
     SceneSet& C = r->sset[r->sgen];
-    if (C.entriesVer != r->entriesVer || C.geomVer != r->geomVer || C.lightsVer != r->lightsVer) {
+    if (C.entriesVer != r->entriesVer || C.geomVer != r->geomVer || C.lightsVer != r->lightsVer || C.topoVer != r->topoVer) {
         SceneSet& T = r->sset[r->sgen ^ 1];
         if (T.upPending) { LM_HIP(hipEventSynchronize(T.evUp)); T.upPending = false; }
         if (!T.evUp) LM_HIP(hipEventCreateWithFlags(&T.evUp, hipEventDisableTiming));
         bool copied = false;
+        if (T.topoVer != r->topoVer) {                              // a new tree (instances added / removed): topology now, boxes by the refit below
+            const LmBvh& b = r->bvh;
+            const size_t nn = b.nodes4.size(), ns = b.order.size(), nl = b.levelNodes.size();
+            if (T.hNodes.ensure(nn) || T.hTriId.ensure(ns) || T.hOrder.ensure(ns) || T.hLevelNodes.ensure(nl) || T.nodes.ensure(nn) || T.triId.ensure(ns) ||
+                T.triOrder.ensure(ns) || T.levelNodes.ensure(nl) || T.woop.ensure(ns + 1) || T.quant.ensure(8))
+                return fail(LUMEN_MI_ERR_DEVICE, "scene tree allocation failed");
+            memcpy(T.hNodes.p, b.nodes4.data(), nn * sizeof(LmNode4)); memcpy(T.hTriId.p, r->triId.data(), ns * sizeof(uint2));
+            memcpy(T.hOrder.p, b.order.data(), ns * sizeof(uint32_t)); memcpy(T.hLevelNodes.p, b.levelNodes.data(), nl * sizeof(uint32_t));
+            LM_HIP(hipMemcpyAsync(T.nodes.p, T.hNodes.p, nn * sizeof(LmNode4), hipMemcpyHostToDevice, su));
+            if (ns) { LM_HIP(hipMemcpyAsync(T.triId.p, T.hTriId.p, ns * sizeof(uint2), hipMemcpyHostToDevice, su)); LM_HIP(hipMemcpyAsync(T.triOrder.p, T.hOrder.p, ns * sizeof(uint32_t), hipMemcpyHostToDevice, su)); }
+            if (nl) LM_HIP(hipMemcpyAsync(T.levelNodes.p, T.hLevelNodes.p, nl * sizeof(uint32_t), hipMemcpyHostToDevice, su));
+            LM_HIP(hipMemsetAsync(T.woop.p + ns, 0, sizeof(LmWoop), su));            // sentinel packet
+            T.levelStart = b.levelStart; T.nTris = (uint32_t)ns;
+            T.topoVer = r->topoVer; T.geomVer = 0;                  // no boxes yet
+            copied = true;
+        }
         if (T.entriesVer != r->entriesVer) {
             const size_t n = r->entries.size();
             if (T.hEntries.ensure(n) || T.entries.ensure(n)) return fail(LUMEN_MI_ERR_DEVICE, "scene table allocation failed");
@@ -111,13 +127,14 @@ int syncScene(R* r, hipStream_t su)
         if (T.geomVer != r->geomVer) {
             const LmKernelTable* K = r->K;
             LmScene sc = r->dscene;
-            sc.nodes = T.nodes.p; sc.woop = T.woop.p; sc.quant = T.quant.p; sc.entries = T.entries.p;
-            const uint32_t nt = (uint32_t)r->bvh.order.size();
+            sc.nodes = T.nodes.p; sc.woop = T.woop.p; sc.quant = T.quant.p; sc.entries = T.entries.p; sc.triId = T.triId.p; sc.triOrder = T.triOrder.p;
+            const uint32_t nt = T.nTris;
+            if (r->dTriBox.ensure(2 * (size_t)nt + 2) || r->dNodeBox.ensure(2 * std::max<size_t>(T.nodes.cap, 1))) return fail(LUMEN_MI_ERR_DEVICE, "refit buffer allocation failed");
             K->refit_tris(su, sc, nt, r->dTriBox.p, r->dRefitBounds.p);
             K->refit_quant(su, r->dRefitBounds.p, T.quant.p);
-            for (size_t l = 0; l + 1 < r->bvh.levelStart.size(); l++) {
-                const uint32_t a = r->bvh.levelStart[l], b = r->bvh.levelStart[l + 1];
-                if (b > a) K->refit_level(su, sc, r->dLevelNodes.p + a, b - a, r->dTriBox.p, r->dNodeBox.p);
+            for (size_t l = 0; l + 1 < T.levelStart.size(); l++) {
+                const uint32_t a = T.levelStart[l], b = T.levelStart[l + 1];
+                if (b > a) K->refit_level(su, sc, T.levelNodes.p + a, b - a, r->dTriBox.p, r->dNodeBox.p);
             }
             LM_HIP(hipGetLastError());
             ++r->refits;
@@ -127,6 +144,7 @@ int syncScene(R* r, hipStream_t su)
     }
     const SceneSet& S = r->sset[r->sgen];
     r->dscene.nodes = S.nodes.p; r->dscene.woop = S.woop.p; r->dscene.quant = S.quant.p; r->dscene.entries = S.entries.p;
+    r->dscene.triId = S.triId.p; r->dscene.triOrder = S.triOrder.p;
     r->dscene.lights = S.lights.p; r->dscene.cdf = S.cdf.p;
     return 0;
 }
@@ -144,20 +162,25 @@ int flatten(R* r)
     // A topology edit after the first build (instances added / removed) does not need a new SAH tree: every mesh keeps its own tree
     // (object space, built once), the scene tree is those trees behind a small top tree over the instances (lm_assemble_bvh), and
     // the GPU refit computes boxes and Woop packets from the instance transforms.  The first build is the full SAH build.
-    const bool assemble = r->assembleEnabled && r->refitEnabled && r->builtOnce;
+    const bool newPrims = r->poolPrims != r->prims.size();          // primitives are only ever appended
+    const bool assemble = r->assembleEnabled && r->refitEnabled && r->builtOnce && !newPrims;
     std::vector<LmInstanceRef> refs;
-    // vertex / index pools: one slot range per primitive
-    std::vector<uint32_t> vertBase(r->prims.size()), idxBase(r->prims.size());
+    // vertex / index pools: one slot range per primitive (primitives are only ever appended: the pools are rebuilt and uploaded
+    // when new ones exist, which takes the synchronous path below)
     std::vector<float4> verts; std::vector<uint32_t> indices;
-    for (size_t p = 0; p < r->prims.size(); p++) {
-        vertBase[p] = (uint32_t)(verts.size() / 3); idxBase[p] = (uint32_t)indices.size();
-        for (const Vertex48& v : r->prims[p].verts) {
-            verts.push_back(make_float4(v.pos[0], v.pos[1], v.pos[2], v.uv[0]));
-            verts.push_back(make_float4(v.uv[1], v.normal[0], v.normal[1], v.normal[2]));
-            verts.push_back(make_float4(v.tangent[0], v.tangent[1], v.tangent[2], v.tangent[3]));
+    if (newPrims) {
+        r->vertBase.assign(r->prims.size(), 0); r->idxBase.assign(r->prims.size(), 0);
+        for (size_t p = 0; p < r->prims.size(); p++) {
+            r->vertBase[p] = (uint32_t)(verts.size() / 3); r->idxBase[p] = (uint32_t)indices.size();
+            for (const Vertex48& v : r->prims[p].verts) {
+                verts.push_back(make_float4(v.pos[0], v.pos[1], v.pos[2], v.uv[0]));
+                verts.push_back(make_float4(v.uv[1], v.normal[0], v.normal[1], v.normal[2]));
+                verts.push_back(make_float4(v.tangent[0], v.tangent[1], v.tangent[2], v.tangent[3]));
+            }
+            indices.insert(indices.end(), r->prims[p].idx.begin(), r->prims[p].idx.end());
         }
-        indices.insert(indices.end(), r->prims[p].idx.begin(), r->prims[p].idx.end());
     }
+    const std::vector<uint32_t>& vertBase = r->vertBase; const std::vector<uint32_t>& idxBase = r->idxBase;
     for (size_t ii : sc.instances) {
         Instance& mi = r->instances[ii];
         mi.entries.clear();
@@ -210,37 +233,46 @@ int flatten(R* r)
     if (assembled) { lm_assemble_bvh(refs.data(), (uint32_t)refs.size(), &r->bvh); ++r->assemblies; }
     else { if (assemble) ensureWorldTris(r); lm_build_bvh(r->worldTris.data(), nt, &r->bvh); }
     if (r->bvh.maxStack > LM_STACK_DEPTH) return fail(LUMEN_MI_ERR_STATE, "BVH needs a deeper traversal stack than LM_STACK_DEPTH");
-    std::vector<uint2> triId(nt);
-    for (uint32_t s = 0; s < nt; s++) triId[s] = make_uint2(r->triEntry[r->bvh.order[s]], r->triPrim[r->bvh.order[s]]);
+    r->triId.resize(nt);
+    for (uint32_t s = 0; s < nt; s++) r->triId[s] = make_uint2(r->triEntry[r->bvh.order[s]], r->triPrim[r->bvh.order[s]]);
+    ++r->entriesVer; ++r->geomVer; ++r->topoVer;
+    if (assembled) {
+        // nothing touches the device here: syncScene() carries the new tree into the idle scene set on the wave stream and refits it
+        // there, like any other scene edit — frames keep overlapping while instances come and go
+        r->sceneDirty = false; r->transformsDirty = false; r->entriesDirty = false; r->lightsDirty = true;
+        return 0;
+    }
     hipStream_t st = r->stream;
     // (stream order puts these copies behind the merge of the last frame, which has joined every other stream; the host then
     // waits for them, so both scene sets are idle and identical afterwards)
     if (hipStreamSynchronize(st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "stream sync failed");
     for (SceneSet& S : r->sset) if (S.upPending) { (void)hipEventSynchronize(S.evUp); S.upPending = false; }
     std::vector<float> quant = {r->bvh.qmin[0], r->bvh.qmin[1], r->bvh.qmin[2], r->bvh.qstep[0], r->bvh.qstep[1], r->bvh.qstep[2], r->bvh.pad, 0.f};
-    ++r->entriesVer; ++r->geomVer;
     for (SceneSet& S : r->sset) {
-        if (S.nodes.upload(r->bvh.nodes4, st) || S.woop.upload(r->bvh.woop, st) || S.entries.upload(r->entries, st) || S.quant.upload(quant, st))
+        if (S.nodes.upload(r->bvh.nodes4, st) || S.woop.upload(r->bvh.woop, st) || S.entries.upload(r->entries, st) || S.quant.upload(quant, st) ||
+            S.triId.upload(r->triId, st) || S.triOrder.upload(r->bvh.order, st) || S.levelNodes.upload(r->bvh.levelNodes, st))
             return fail(LUMEN_MI_ERR_DEVICE, "scene upload failed (hipMalloc/hipMemcpy)");
-        S.entriesVer = r->entriesVer; S.geomVer = assembled ? 0 : r->geomVer;      // an assembled tree has no boxes yet: syncScene refits
+        S.levelStart = r->bvh.levelStart; S.nTris = nt;
+        S.entriesVer = r->entriesVer; S.geomVer = r->geomVer; S.topoVer = r->topoVer;
     }
-    if (r->dTriId.upload(triId, st) || r->dTriOrder.upload(r->bvh.order, st) || r->dVerts.upload(verts, st) || r->dIndices.upload(indices, st))
-        return fail(LUMEN_MI_ERR_DEVICE, "scene upload failed (hipMalloc/hipMemcpy)");
+    if (newPrims) {
+        if (r->dVerts.upload(verts, st) || r->dIndices.upload(indices, st)) return fail(LUMEN_MI_ERR_DEVICE, "scene upload failed (hipMalloc/hipMemcpy)");
+        r->poolPrims = r->prims.size();
+    }
     {
         std::vector<uint32_t> bounds = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
-        if (r->dRefitBounds.upload(bounds, st) || r->dLevelNodes.upload(r->bvh.levelNodes, st) ||
-            r->dTriBox.ensure(2 * (size_t)nt + 2) || r->dNodeBox.ensure(2 * r->bvh.nodes4.size()))
+        if (r->dRefitBounds.upload(bounds, st) || r->dTriBox.ensure(2 * (size_t)nt + 2) || r->dNodeBox.ensure(2 * r->bvh.nodes4.size()))
             return fail(LUMEN_MI_ERR_DEVICE, "refit buffer allocation failed");
     }
     if (hipStreamSynchronize(st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "scene upload sync failed");
     if (r->dSpill.ensure((size_t)4 * r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS)))      // one area per stream
         return fail(LUMEN_MI_ERR_DEVICE, "stack spill allocation failed");
     r->dscene.spill = r->dSpill.p;
-    r->dscene.triId = r->dTriId.p; r->dscene.triOrder = r->dTriOrder.p;
     r->dscene.verts = r->dVerts.p; r->dscene.indices = r->dIndices.p;
     {
         const SceneSet& S = r->sset[r->sgen];
         r->dscene.nodes = S.nodes.p; r->dscene.woop = S.woop.p; r->dscene.quant = S.quant.p; r->dscene.entries = S.entries.p;
+        r->dscene.triId = S.triId.p; r->dscene.triOrder = S.triOrder.p;
     }
     r->sceneDirty = false;
     r->transformsDirty = false;

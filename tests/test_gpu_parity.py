@@ -1025,6 +1025,12 @@ def test_schedule_fuzzing_does_not_change_the_image(fuzz_seed):
                 r.m_Scene.m_MeshInstances[0].SetTransform(m)
             if k == 4:
                 r.m_Scene.m_MeshInstances[1].SetEmissiveness(2, (9.0, 8.0, 7.0), 30.0)
+            if k in (5, 8):                       # topology edit: the scene is cleared and refilled (k = 8: with a second light quad)
+                sc = r.m_Scene; sc.Clear()
+                for n, inst in enumerate(d.instances + ([d.instances[1]] if k == 8 else [])):
+                    mi = sc.AddMesh(r.m_Meshes[inst["mesh"]])
+                    t = np.array(inst["transform"], np.float32).reshape(4, 4).copy(); t[0, 3] += 1.5 * (n >= len(d.instances))
+                    mi.SetTransform(t); mi.SetEmissiveness(inst["emission_mode"], inst["override_radiance"], inst["scale"])
             c = d.camera
             r.SetCamera((c["position"][0] + 0.01 * k, c["position"][1], c["position"][2]), c["right"], c["up"], c["forward"], c["fov"])
             assert r.TraceFrameAsync()

@@ -23,6 +23,13 @@ def run(W, H, depth, tuning, window, tile, sync_each, frames=8):
         if k % 3 != 2:
             m = base.copy(); m[1, 3] += 0.002 * k; inst[0].SetTransform(m)
         if k == 4: inst[1].SetEmissiveness(2, (9.0, 8.0, 7.0), 30.0)
+        if k == 5:                                 # topology edit: cleared and refilled with a second light quad
+            sc = r.m_Scene; sc.Clear()
+            for n, dd in enumerate(desc.instances + [desc.instances[1]]):
+                mi = sc.AddMesh(r.m_Meshes[dd["mesh"]])
+                t = np.array(dd["transform"], np.float32).reshape(4, 4).copy(); t[0, 3] += 1.5 * (n >= len(desc.instances))
+                mi.SetTransform(t); mi.SetEmissiveness(dd["emission_mode"], dd["override_radiance"], dd["scale"])
+            inst = sc.m_MeshInstances
         c = desc.camera
         r.SetCamera((c["position"][0] + 0.01 * k, c["position"][1], c["position"][2]), c["right"], c["up"], c["forward"], c["fov"])
         assert r.TraceFrameAsync()
