@@ -163,10 +163,10 @@ int flatten(R* r)
     // (object space, built once), the scene tree is those trees behind a small top tree over the instances (lm_assemble_bvh), and
     // the GPU refit computes boxes and Woop packets from the instance transforms.  The first build is the full SAH build.
     const bool newPrims = r->poolPrims != r->prims.size();          // primitives are only ever appended
-    const bool assemble = r->assembleEnabled && r->refitEnabled && r->builtOnce && !newPrims;
+    const bool assemble = r->assembleEnabled && r->refitEnabled && r->builtOnce;
     std::vector<LmInstanceRef> refs;
     // vertex / index pools: one slot range per primitive (primitives are only ever appended: the pools are rebuilt and uploaded
-    // when new ones exist, which takes the synchronous path below)
+    // when new ones exist)
     std::vector<float4> verts; std::vector<uint32_t> indices;
     if (newPrims) {
         r->vertBase.assign(r->prims.size(), 0); r->idxBase.assign(r->prims.size(), 0);
@@ -236,6 +236,16 @@ int flatten(R* r)
     r->triId.resize(nt);
     for (uint32_t s = 0; s < nt; s++) r->triId[s] = make_uint2(r->triEntry[r->bvh.order[s]], r->triPrim[r->bvh.order[s]]);
     ++r->entriesVer; ++r->geomVer; ++r->topoVer;
+    if (newPrims) {
+        // new geometry: the vertex / index pools grow (existing ranges keep their bytes).  Behind the merge of the last frame by
+        // stream order, and the host waits, because a grown buffer is a new allocation.
+        hipStream_t st = r->stream;
+        if (hipStreamSynchronize(st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "stream sync failed");
+        if (r->dVerts.upload(verts, st) || r->dIndices.upload(indices, st)) return fail(LUMEN_MI_ERR_DEVICE, "scene upload failed (hipMalloc/hipMemcpy)");
+        if (hipStreamSynchronize(st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "scene upload sync failed");
+        r->poolPrims = r->prims.size();
+        r->dscene.verts = r->dVerts.p; r->dscene.indices = r->dIndices.p;
+    }
     if (assembled) {
         // nothing touches the device here: syncScene() carries the new tree into the idle scene set on the wave stream and refits it
         // there, like any other scene edit — frames keep overlapping while instances come and go
@@ -254,10 +264,6 @@ int flatten(R* r)
             return fail(LUMEN_MI_ERR_DEVICE, "scene upload failed (hipMalloc/hipMemcpy)");
         S.levelStart = r->bvh.levelStart; S.nTris = nt;
         S.entriesVer = r->entriesVer; S.geomVer = r->geomVer; S.topoVer = r->topoVer;
-    }
-    if (newPrims) {
-        if (r->dVerts.upload(verts, st) || r->dIndices.upload(indices, st)) return fail(LUMEN_MI_ERR_DEVICE, "scene upload failed (hipMalloc/hipMemcpy)");
-        r->poolPrims = r->prims.size();
     }
     {
         std::vector<uint32_t> bounds = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};

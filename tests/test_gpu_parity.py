@@ -619,6 +619,15 @@ def test_instances_added_and_removed_between_frames(assemble):
         added.append(r.m_Scene.AddMesh(meshes[extra_mesh])); added[-1].SetTransform(xf)
         o.add_instance(extra_mesh, xf)
         _compare_frames(r, o, 1, check_gbuffer=False)
+    # a brand-new mesh while frames are being rendered: only ITS tree is built (and the vertex / index pools grow)
+    soup2 = random_soup(150, 77, extent=4.0, size=0.9).primitives[0]
+    v2 = np.array(soup2["vertices"], np.float32).reshape(-1, 12).copy(); v2[:, 0:3] *= np.float32(0.05)
+    prim2, _ = r.CreatePrimitive(r.m_Materials[mat], soup2["indices"], vertices=v2)
+    mesh2 = r.CreateMesh([prim2])
+    xf2 = _rigid(-0.7, (-0.3, 1.4, 0.1))
+    r.m_Scene.AddMesh(mesh2).SetTransform(xf2)
+    o.add_instance(o.add_mesh([o.add_primitive(v2, soup2["indices"], mat)]), xf2)
+    _compare_frames(r, o, 2, check_gbuffer=False)
     xf = _rigid(1.3, (0.1, 1.2, -0.3))                                           # move one of them: a refit of the assembled tree
     added[1].SetTransform(xf); o.set_instance_transform(len(d.instances) + 1, xf)
     _compare_frames(r, o, 2, check_gbuffer=False)
@@ -630,7 +639,7 @@ def test_instances_added_and_removed_between_frames(assemble):
     assert np.array_equal(r.QueryAny(org, dr, np.full(300, 4.0, np.float32)), o.trace_any(org, dr, np.full(300, 4.0, np.float32), use_bvh=False))
     assert np.array_equal(r.GetWorldTriangles().view(np.uint32), o.world_triangles().view(np.uint32))
     c = r.GetCounters(52)
-    assert (c[51] >= 4) if assemble else (c[51] == 0)
+    assert (c[51] >= 5) if assemble else (c[51] == 0)
     r.close(); o.close()
 
 
