@@ -192,6 +192,9 @@ int flatten(R* r)
                 mesh.tris = (uint32_t)(local.size() / 9);
                 mesh.bvh = std::make_shared<LmBvh>();
                 lm_build_bvh(local.data(), mesh.tris, mesh.bvh.get());
+                // the assembly only needs the 4-wide topology and the triangle order: drop the binary tree, packets and level lists
+                std::vector<LmNode>().swap(mesh.bvh->nodes); std::vector<LmWoop>().swap(mesh.bvh->woop);
+                std::vector<uint32_t>().swap(mesh.bvh->levelNodes); std::vector<uint32_t>().swap(mesh.bvh->levelStart);
                 for (int a = 0; a < 3; a++) { mesh.lo[a] = INFINITY; mesh.hi[a] = -INFINITY; }
                 for (size_t f = 0; f < local.size(); f++) { mesh.lo[f % 3] = std::min(mesh.lo[f % 3], local[f]); mesh.hi[f % 3] = std::max(mesh.hi[f % 3], local[f]); }
             }
