@@ -140,12 +140,13 @@ namespace MI355X
         {
             Lumen::MeshInstance::SetMesh(mesh);
             Check(lumen_mi_scene_add_mesh(m_R, m_Scene, static_cast<Mesh*>(mesh.get())->m_Handle, &m_Handle), "scene_add_mesh");
+            PushOverride();                    // an override material set before the mesh (the instance had no native handle yet)
         }
         void SetEmissiveness(const Emissiveness& e) override { Lumen::MeshInstance::SetEmissiveness(e); PushEmissiveness(); }
         void SetOverrideMaterial(std::shared_ptr<Lumen::ILumenMaterial> m) override
         {
             Lumen::MeshInstance::SetOverrideMaterial(m);
-            if (m_Handle) Check(lumen_mi_instance_set_override_material(m_R, m_Handle, static_cast<Material*>(m.get())->m_Handle), "set_override_material");
+            PushOverride();
         }
         // called by Renderer before every frame: the app edits m_Transform directly (the reference polls dirty flags, PTMeshInstance.cpp:123-178)
         void Sync()
@@ -154,6 +155,7 @@ namespace MI355X
             const glm::mat4 rowMajor = glm::transpose(m_Transform.GetWorldTransformationMatrix());     // PTMeshInstance.cpp:147-151
             Check(lumen_mi_instance_set_transform(m_R, m_Handle, glm::value_ptr(rowMajor)), "set_transform");
             PushEmissiveness();
+            PushOverride();
         }
         lumen_mi_handle m_Handle = 0;
 
@@ -163,6 +165,13 @@ namespace MI355X
             if (!m_Handle) return;
             const float rad[3] = {m_EmissiveProperties.m_OverrideRadiance.x, m_EmissiveProperties.m_OverrideRadiance.y, m_EmissiveProperties.m_OverrideRadiance.z};
             Check(lumen_mi_instance_set_emissiveness(m_R, m_Handle, static_cast<int>(m_EmissiveProperties.m_EmissionMode), rad, m_EmissiveProperties.m_Scale), "set_emissiveness");
+        }
+        void PushOverride()
+        {
+            // a null override means "use the mesh's own materials" (MeshInstance.h:57-65); the native side keeps an override until it is
+            // replaced, so only a non-null material is pushed
+            if (!m_Handle || !m_OverrideMaterial) return;
+            Check(lumen_mi_instance_set_override_material(m_R, m_Handle, static_cast<Material*>(m_OverrideMaterial.get())->m_Handle), "set_override_material");
         }
         lumen_mi_renderer* m_R;
         lumen_mi_handle m_Scene;
@@ -244,10 +253,13 @@ namespace MI355X
         unsigned int GetOutputTexture() override { return 0; }   // no GL interop: OutputLayer uploads GetOutputTexturePixels() instead
         std::vector<uint8_t> GetOutputTexturePixels(uint32_t& w, uint32_t& h) override
         {
-            uint32_t rw = 0, rh = 0;
-            lumen_mi_get_render_resolution(m_R, &rw, &rh);
-            std::vector<uint8_t> px(static_cast<size_t>(rw) * rh * 4);
-            Check(lumen_mi_get_output_pixels(m_R, px.data(), px.size(), &w, &h), "get_output_pixels");
+            // size of the LAST TRACED frame, not the pending resolution (SetRenderResolution applies at the next frame): a first call
+            // with capacity 0 reports it
+            uint8_t none = 0;
+            w = h = 0;
+            (void)lumen_mi_get_output_pixels(m_R, &none, 0, &w, &h);
+            std::vector<uint8_t> px(static_cast<size_t>(w) * h * 4);
+            if (!px.empty()) Check(lumen_mi_get_output_pixels(m_R, px.data(), px.size(), &w, &h), "get_output_pixels");
             return px;
         }
         void SetRenderResolution(glm::uvec2 r) override { Check(lumen_mi_set_render_resolution(m_R, r.x, r.y), "set_render_resolution"); }

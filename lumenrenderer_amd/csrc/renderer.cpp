@@ -128,6 +128,7 @@ int lumen_mi_create_texture(lumen_mi_renderer* r, const void* rgba8, uint32_t w,
 
 int lumen_mi_create_default_resources(lumen_mi_renderer* r, lumen_mi_handle* white, lumen_mi_handle* normal, lumen_mi_handle* diffuse)
 {
+    if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer");
     ApiLock lk(r);
     // LumenRenderer::CreateDefaultResources (Lumen/src/Lumen/Renderer/LumenRenderer.cpp:50-58): three 1x1 textures, normalize = false
     const uint8_t w[4] = {255, 255, 255, 255}, n[4] = {128, 128, 255, 0}, d[4] = {255, 255, 255, 255};
@@ -190,12 +191,13 @@ int lumen_mi_create_material(lumen_mi_renderer* r, const lumen_mi_material_data*
 
 int lumen_mi_update_material(lumen_mi_renderer* r, lumen_mi_handle material, const lumen_mi_material_data* d)
 {
+    if (!r || !d) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    ApiLock lk(r);                                                // before any read of the resource tables (fillMaterial reads r->textures)
     size_t idx;
-    if (!r || !d || !unh(material, H_MATERIAL, r->materials.size(), idx)) return fail(LUMEN_MI_ERR_INVALID, "bad material handle");
+    if (!unh(material, H_MATERIAL, r->materials.size(), idx)) return fail(LUMEN_MI_ERR_INVALID, "bad material handle");
     Material m;
     const int rc = fillMaterial(r, d, m);
     if (rc) return rc;
-    ApiLock lk(r);
     r->materials[idx] = m;
     r->materialsDirty = true;
     // the emissive classification of primitives is a function of their material (FindEmissives at CreatePrimitive time in the
@@ -263,10 +265,12 @@ int lumen_mi_create_scene(lumen_mi_renderer* r, lumen_mi_handle* out)
 
 int lumen_mi_set_scene(lumen_mi_renderer* r, lumen_mi_handle scene)
 {
-    size_t s;
-    if (!r || !unh(scene, H_SCENE, r->scenes.size(), s)) return fail(LUMEN_MI_ERR_INVALID, "bad scene handle");
+    if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer");
     ApiLock lk(r);
-    r->activeScene = (long)s; r->sceneDirty = true;
+    size_t s;
+    if (!unh(scene, H_SCENE, r->scenes.size(), s)) return fail(LUMEN_MI_ERR_INVALID, "bad scene handle");
+    // the adapter calls this before every TraceFrame (include/lumen_mi_renderer.hpp): only a CHANGE of the active scene is a scene edit
+    if (r->activeScene != (long)s) { r->activeScene = (long)s; r->sceneDirty = true; }
     return 0;
 }
 
@@ -285,9 +289,10 @@ static bool instanceOf(const lumen_mi_renderer* r, lumen_mi_handle h, size_t& id
 
 int lumen_mi_scene_add_mesh(lumen_mi_renderer* r, lumen_mi_handle scene, lumen_mi_handle mesh, lumen_mi_handle* inst)
 {
-    size_t s, m;
-    if (!r || !inst || !unh(scene, H_SCENE, r->scenes.size(), s) || !unh(mesh, H_MESH, r->meshes.size(), m)) return fail(LUMEN_MI_ERR_INVALID, "bad scene/mesh handle");
+    if (!r || !inst) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
     ApiLock lk(r);
+    size_t s, m;
+    if (!unh(scene, H_SCENE, r->scenes.size(), s) || !unh(mesh, H_MESH, r->meshes.size(), m)) return fail(LUMEN_MI_ERR_INVALID, "bad scene/mesh handle");
     Instance i;
     i.scene = s; i.mesh = m;
     const float id[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
@@ -304,9 +309,10 @@ int lumen_mi_scene_add_mesh(lumen_mi_renderer* r, lumen_mi_handle scene, lumen_m
 
 int lumen_mi_scene_clear(lumen_mi_renderer* r, lumen_mi_handle scene)
 {
-    size_t s;
-    if (!r || !unh(scene, H_SCENE, r->scenes.size(), s)) return fail(LUMEN_MI_ERR_INVALID, "bad scene handle");
+    if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer");
     ApiLock lk(r);
+    size_t s;
+    if (!unh(scene, H_SCENE, r->scenes.size(), s)) return fail(LUMEN_MI_ERR_INVALID, "bad scene handle");
     for (size_t i : r->scenes[s].instances) { r->instances[i].alive = false; r->instances[i].entries.clear(); r->freeInstances.push_back(i); }
     r->scenes[s].instances.clear(); r->sceneDirty = true;
     return 0;
@@ -314,18 +320,20 @@ int lumen_mi_scene_clear(lumen_mi_renderer* r, lumen_mi_handle scene)
 
 int lumen_mi_instance_set_transform(lumen_mi_renderer* r, lumen_mi_handle inst, const float m[16])
 {
+    if (!r || !m) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    ApiLock lk(r);                                                // instanceOf indexes r->instances, which add_mesh may reallocate
     size_t i;
-    if (!r || !m || !instanceOf(r, inst, i)) return fail(LUMEN_MI_ERR_INVALID, "bad instance handle (released by lumen_mi_scene_clear?)");
-    ApiLock lk(r);
+    if (!instanceOf(r, inst, i)) return fail(LUMEN_MI_ERR_INVALID, "bad instance handle (released by lumen_mi_scene_clear?)");
     if (memcmp(r->instances[i].M, m, 64) != 0) { memcpy(r->instances[i].M, m, 64); r->transformsDirty = true; }   // polled every frame by the adapter
     return 0;
 }
 
 int lumen_mi_instance_set_emissiveness(lumen_mi_renderer* r, lumen_mi_handle inst, int mode, const float rad[3], float scale)
 {
-    size_t i;
-    if (!r || !rad || mode < 0 || mode > 2 || !instanceOf(r, inst, i)) return fail(LUMEN_MI_ERR_INVALID, "bad emissiveness arguments");
+    if (!r || !rad || mode < 0 || mode > 2) return fail(LUMEN_MI_ERR_INVALID, "bad emissiveness arguments");
     ApiLock lk(r);
+    size_t i;
+    if (!instanceOf(r, inst, i)) return fail(LUMEN_MI_ERR_INVALID, "bad instance handle (released by lumen_mi_scene_clear?)");
     Instance& x = r->instances[i];
     if (x.mode != mode || x.radiance[0] != rad[0] || x.radiance[1] != rad[1] || x.radiance[2] != rad[2] || x.scale != scale) r->entriesDirty = true;
     x.mode = mode; x.radiance[0] = rad[0]; x.radiance[1] = rad[1]; x.radiance[2] = rad[2]; x.scale = scale;
@@ -334,9 +342,10 @@ int lumen_mi_instance_set_emissiveness(lumen_mi_renderer* r, lumen_mi_handle ins
 
 int lumen_mi_instance_set_override_material(lumen_mi_renderer* r, lumen_mi_handle inst, lumen_mi_handle mat)
 {
-    size_t i, m;
-    if (!r || !instanceOf(r, inst, i) || !unh(mat, H_MATERIAL, r->materials.size(), m)) return fail(LUMEN_MI_ERR_INVALID, "bad handle");
+    if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer");
     ApiLock lk(r);
+    size_t i, m;
+    if (!instanceOf(r, inst, i) || !unh(mat, H_MATERIAL, r->materials.size(), m)) return fail(LUMEN_MI_ERR_INVALID, "bad handle");
     if (r->instances[i].overrideMaterial != (long)m) r->entriesDirty = true;
     r->instances[i].overrideMaterial = (long)m;
     return 0;
@@ -366,11 +375,18 @@ int lumen_mi_set_output_resolution(lumen_mi_renderer* r, uint32_t w, uint32_t h)
     r->pending.output_width = w; r->pending.output_height = h;
     return 0;
 }
-int lumen_mi_get_render_resolution(lumen_mi_renderer* r, uint32_t* w, uint32_t* h) { if (!r || !w || !h) return fail(LUMEN_MI_ERR_INVALID, "NULL argument"); *w = r->pending.render_width; *h = r->pending.render_height; return 0; }
-int lumen_mi_get_output_resolution(lumen_mi_renderer* r, uint32_t* w, uint32_t* h) { if (!r || !w || !h) return fail(LUMEN_MI_ERR_INVALID, "NULL argument"); *w = r->pending.output_width; *h = r->pending.output_height; return 0; }
-int lumen_mi_set_blend_mode(lumen_mi_renderer* r, int b) { if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer"); r->pending.blend_output = b ? 1 : 0; if (b) r->blendCounter = 0; return 0; }
-int lumen_mi_get_blend_mode(lumen_mi_renderer* r, int* b) { if (!r || !b) return fail(LUMEN_MI_ERR_INVALID, "NULL argument"); *b = r->pending.blend_output; return 0; }
-int lumen_mi_set_depth(lumen_mi_renderer* r, uint32_t d) { if (!r || d == 0 || d > LM_MAX_DEPTH) return fail(LUMEN_MI_ERR_INVALID, "depth must be in [1, 16]"); r->pending.depth = d; return 0; }
+int lumen_mi_get_render_resolution(lumen_mi_renderer* r, uint32_t* w, uint32_t* h) { if (!r || !w || !h) return fail(LUMEN_MI_ERR_INVALID, "NULL argument"); std::lock_guard<std::mutex> sl(r->settingsMutex); *w = r->pending.render_width; *h = r->pending.render_height; return 0; }
+int lumen_mi_get_output_resolution(lumen_mi_renderer* r, uint32_t* w, uint32_t* h) { if (!r || !w || !h) return fail(LUMEN_MI_ERR_INVALID, "NULL argument"); std::lock_guard<std::mutex> sl(r->settingsMutex); *w = r->pending.output_width; *h = r->pending.output_height; return 0; }
+int lumen_mi_set_blend_mode(lumen_mi_renderer* r, int b)
+{
+    if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer");
+    ApiLock lk(r);                                                // blendCounter belongs to the frame state (the render thread advances it)
+    { std::lock_guard<std::mutex> sl(r->settingsMutex); r->pending.blend_output = b ? 1 : 0; }
+    if (b) r->blendCounter = 0;                                   // WaveFrontRenderer.cpp:377-381
+    return 0;
+}
+int lumen_mi_get_blend_mode(lumen_mi_renderer* r, int* b) { if (!r || !b) return fail(LUMEN_MI_ERR_INVALID, "NULL argument"); std::lock_guard<std::mutex> sl(r->settingsMutex); *b = r->pending.blend_output; return 0; }
+int lumen_mi_set_depth(lumen_mi_renderer* r, uint32_t d) { if (!r || d == 0 || d > LM_MAX_DEPTH) return fail(LUMEN_MI_ERR_INVALID, "depth must be in [1, 16]"); std::lock_guard<std::mutex> sl(r->settingsMutex); r->pending.depth = d; return 0; }
 
 int lumen_mi_trace_frame_async(lumen_mi_renderer* r) { if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer"); ApiLock lk(r); return traceFrameAsync(r); }
 int lumen_mi_synchronize(lumen_mi_renderer* r) { if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer"); ApiLock lk(r); return syncAndCollect(r); }
@@ -403,28 +419,32 @@ int lumen_mi_stop_rendering(lumen_mi_renderer* r)
 }
 int lumen_mi_perform_deferred_operations(lumen_mi_renderer*) { return 0; }
 
-static int copyOut(lumen_mi_renderer* r, const void* dev, size_t bytes, void* host, size_t capacity)
+// read-back of a per-pixel plane of the last traced frame.  Device pointer and size are resolved UNDER the frame lock: a resolution
+// change on the render thread frees and reallocates them (ensureFrameBuffers).
+enum OutPlane { OUT_SRGB8, OUT_RADIANCE, OUT_DIRECT, OUT_INDIRECT, OUT_GBUFFER };
+static int copyOut(lumen_mi_renderer* r, OutPlane which, void* host, size_t capacity, uint32_t* w, uint32_t* h)
 {
-    if (!r || !host) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
-    if (!dev) return fail(LUMEN_MI_ERR_STATE, "no frame has been traced yet");
-    if (capacity < bytes) return fail(LUMEN_MI_ERR_INVALID, "buffer too small");
+    if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer");
     ApiLock lk(r);
+    const LmFrame& f = r->fr;
+    if (w) *w = f.ww; if (h) *h = f.wh;
+    const void* dev = which == OUT_SRGB8 ? (const void*)f.output : which == OUT_RADIANCE ? (const void*)f.combined : which == OUT_DIRECT ? (const void*)f.direct
+                    : which == OUT_INDIRECT ? (const void*)f.indirect : (const void*)f.gbuf[r->lastGbuf];
+    const size_t bytes = (size_t)f.n * (which == OUT_SRGB8 ? 4u : which == OUT_GBUFFER ? 128u : 16u);
+    if (!host) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    if (!dev || !r->allocN) return fail(LUMEN_MI_ERR_STATE, "no frame has been traced yet");
+    if (capacity < bytes) return fail(LUMEN_MI_ERR_INVALID, "buffer too small");
     int rc = syncAndCollect(r);
     if (rc) return rc;
     LM_HIP(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
     return 0;
 }
-int lumen_mi_get_output_pixels(lumen_mi_renderer* r, uint8_t* rgba8, size_t cap, uint32_t* w, uint32_t* h)
-{
-    if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer");
-    if (w) *w = r->fr.ww; if (h) *h = r->fr.wh;
-    return copyOut(r, r->fr.output, (size_t)r->fr.n * 4, rgba8, cap);
-}
-int lumen_mi_get_radiance(lumen_mi_renderer* r, float* out, size_t cap) { if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer"); return copyOut(r, r->fr.combined, (size_t)r->fr.n * 16, out, cap); }
+int lumen_mi_get_output_pixels(lumen_mi_renderer* r, uint8_t* rgba8, size_t cap, uint32_t* w, uint32_t* h) { return copyOut(r, OUT_SRGB8, rgba8, cap, w, h); }
+int lumen_mi_get_radiance(lumen_mi_renderer* r, float* out, size_t cap) { return copyOut(r, OUT_RADIANCE, out, cap, nullptr, nullptr); }
 int lumen_mi_get_channel(lumen_mi_renderer* r, int ch, float* out, size_t cap)
 {
     if (!r || ch < 0 || ch > 1) return fail(LUMEN_MI_ERR_INVALID, "channel must be 0 (DIRECT) or 1 (INDIRECT)");
-    return copyOut(r, ch == 0 ? r->fr.direct : r->fr.indirect, (size_t)r->fr.n * 16, out, cap);
+    return copyOut(r, ch == 0 ? OUT_DIRECT : OUT_INDIRECT, out, cap, nullptr, nullptr);
 }
 int lumen_mi_copy_radiance_device(lumen_mi_renderer* r, void* dst)
 {
@@ -467,10 +487,7 @@ int lumen_mi_import_wave_count(lumen_mi_renderer* r, const void* device_i32) { r
 int lumen_mi_get_gbuffer(lumen_mi_renderer* r, float* out, size_t cap)
 {
     if (!r || !out) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
-    const uint32_t n = r->fr.n;
-    if (cap < (size_t)n * 128) return fail(LUMEN_MI_ERR_INVALID, "buffer too small");
-    const int last = r->lastGbuf;
-    return copyOut(r, r->fr.gbuf[last], (size_t)n * 128, out, cap);
+    return copyOut(r, OUT_GBUFFER, out, cap, nullptr, nullptr);
 }
 
 int lumen_mi_get_denoiser_inputs(lumen_mi_renderer* r, float minD, float maxD, float* depth, uint16_t* normalRoughness, uint16_t* motion)

@@ -643,6 +643,22 @@ def test_instances_added_and_removed_between_frames(assemble):
     r.close(); o.close()
 
 
+def test_set_scene_before_every_frame_is_not_a_scene_edit():
+    """The C++ adapter calls lumen_mi_set_scene before every TraceFrame (include/lumen_mi_renderer.hpp TraceFrame; the reference
+    re-reads m_Scene each frame, WaveFrontRenderer.cpp:443-449).  An unchanged handle must not re-flatten / refit / re-assemble:
+    the refit and assembly counters stay where they were and the frames equal the oracle's."""
+    d = cornell()
+    r = product_from(d, 96, 64, 3, blend=True); o = oracle_from(d, 96, 64, 3, blend=True)
+    _compare_frames(r, o, 1, check_gbuffer=False)
+    before = r.GetCounters(52)
+    for _ in range(4):
+        r.SetScene(r.m_Scene)
+        _compare_frames(r, o, 1, check_gbuffer=False)
+    after = r.GetCounters(52)
+    assert (after[50], after[51]) == (before[50], before[51])
+    r.close(); o.close()
+
+
 def test_emissiveness_and_override_material_changes_between_frames():
     """MeshInstance::SetEmissiveness / SetOverrideMaterial between frames (MeshInstance.h:57-98, PTMeshInstance.cpp:123-178):
     the product refreshes its scene data table and light list without rebuilding the BVH; the oracle rebuilds everything."""

@@ -6,7 +6,7 @@ timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 > gpurun_out/$tag
 if ! grep -q " passed" gpurun_out/$tag/pytest.log || grep -q "failed\|error\|Aborted\|dumped" gpurun_out/$tag/pytest.log; then echo "PARITY TESTS FAILED"; cat gpurun_out/$tag/pytest.log; exit 1; fi
 timeout 600 python bench.py --steps 5 --warmup 1 --no-cpu-baseline $BENCH_ARGS > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err
 R=$PWD
-cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$tag/prof -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline $BENCH_ARGS > $R/gpurun_out/$tag/prof.log 2>&1
+cd /tmp && export TMPDIR=/tmp GPU_MAX_HW_QUEUES=8 && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$tag/prof -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline $BENCH_ARGS > $R/gpurun_out/$tag/prof.log 2>&1
 cd $R
 f=$(find gpurun_out/$tag/prof -name "*kernel_stats.csv" | head -1)
 cp "$f" gpurun_out/$tag/kernel_stats.csv 2>/dev/null

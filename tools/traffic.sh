@@ -3,7 +3,7 @@
 # (they do not fit one pass, MI355X_MICROARCH.md "rocprofv3 PMC slots"); output gpurun_out/<tag>/traffic.json
 tag=${1:-traffic}; R=$PWD; mkdir -p gpurun_out/$tag
 for c in FETCH_SIZE WRITE_SIZE; do
-  cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/$tag/$c -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/$tag/$c.log 2>&1
+  cd /tmp && export TMPDIR=/tmp GPU_MAX_HW_QUEUES=8 && timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/$tag/$c -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/$tag/$c.log 2>&1
   cd $R
 done
 python3 - "$tag" <<'PY'
