@@ -138,6 +138,7 @@ int traceFrameAsync(R* r)
     // sets rotate, so that the next frame's extraction does not wait for this frame's temporal pass
     const int currentIndex = r->gbufIndex, temporalIndex = (r->gbufIndex + 2) % 3;
     const bool blend = r->settings.blend_output != 0;
+    const int fastRs = r->fastResample;
 
     // camera (Camera.cpp:79-93,122-140; aspect = render W/H, WaveFrontRenderer.cpp:577)
     LmCamera cam;
@@ -240,7 +241,7 @@ int traceFrameAsync(R* r)
             rs = wangHash(rs);
             const uint32_t tx0 = fr.x0 / 16u, ty0 = fr.y0 / 16u;
             const uint32_t wtx = (fr.x0 + fr.ww + 15u) / 16u - tx0, wty = (fr.y0 + fr.wh + 15u) / 16u - ty0;
-            Z(sp); K->pick_primary(sp, (int)(wtx * wty), r->dscene, fr, currentIndex, fresh, rs, fr.counters + LM_CNT_RESTIR(0));   // + visibility rays, pass 1
+            Z(sp); K->pick_primary(sp, (int)(wtx * wty), r->dscene, fr, currentIndex, fresh, rs, fr.counters + LM_CNT_RESTIR(0), fastRs);   // + visibility rays, pass 1
             LmScene scp = r->dscene;                                 // the pick-ahead stream traces with its own stack-spill area
             if (sp != st) scp.spill += (size_t)3 * r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS);
             Z(sp); K->trace_shade(sp, gridMain, scp, fr, fresh, fr.counters + LM_CNT_RESTIR(0), r->refillVisibility, 0);
@@ -248,10 +249,10 @@ int traceFrameAsync(R* r)
             if (pickAhead) { LM_HIP(hipEventRecord(r->evPick, sp)); LM_HIP(hipStreamWaitEvent(st, r->evPick, 0)); }
             evBegin(r, 3, ev);
             rs = wangHash(rs);
-            Z(st); K->temporal(st, tiles, fr, currentIndex, temporalIndex, cur, tmp, fresh, rs, fr.counters + LM_CNT_RESTIR(1));         // + visibility rays, pass 2
+            Z(st); K->temporal(st, tiles, fr, currentIndex, temporalIndex, cur, tmp, fresh, rs, fr.counters + LM_CNT_RESTIR(1), fastRs);         // + visibility rays, pass 2
             if (overlap) LM_HIP(hipEventRecord(r->evTemporal[par], st));
             rs = wangHash(rs);
-            Z(st); K->spatial(st, tiles, fr, currentIndex, cur, 2, rs, 30);
+            Z(st); K->spatial(st, tiles, fr, currentIndex, cur, 2, rs, 30, fastRs);
             // second visibility pass (ReSTIR.cpp:211-212) works on the CURRENT buffer, which the second spatial pass does not
             // touch: trace it beside that pass.  (It must follow the first spatial pass, which reads the current buffer.)
             hipStream_t sv = (overlap && !pickAhead) ? r->aux3 : st;
@@ -262,9 +263,9 @@ int traceFrameAsync(R* r)
             }
             Z(sv); K->trace_shade(sv, gridMain, scv, fr, cur, fr.counters + LM_CNT_RESTIR(1), r->refillVisibility, 1);
             if (sv != st) LM_HIP(hipEventRecord(r->evVisDone, sv));
-            Z(st); K->spatial(st, tiles, fr, currentIndex, 2, 3, rs, 0);
+            Z(st); K->spatial(st, tiles, fr, currentIndex, 2, 3, rs, 0, fastRs);
             if (sv != st) LM_HIP(hipStreamWaitEvent(st, r->evVisDone, 0));
-            Z(st); K->combine(st, tiles, fr, currentIndex, cur, 3, wangHash(rs));
+            Z(st); K->combine(st, tiles, fr, currentIndex, cur, 3, wangHash(rs), fastRs);
             evEnd(r, ev);
         } else if ((int)depth >= tailDepth) {
             // path tail: the remaining waves in one launch (kernels.hip lm_k_path_tail) on the shadow stream: its INDIRECT adds

@@ -402,12 +402,10 @@ KN(lm_k_fill_bags)(LmScene sc, LmFrame fr, uint32_t seed, uint32_t total)
 // K21 PickPrimarySamples — ReSTIRKernels.cu:402-522.  One 16x16 pixel tile (aligned to the GLOBAL 16x16 grid) shares a light
 // bag (the reference keys the bag on the hardware SM id, which is not reproducible: DESIGN.md decision D2); the bag's 1000
 // (index, pdf) pairs are staged in LDS once per tile.
-extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
-KN(lm_k_pick_primary)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount)
+template <class A>
+__device__ __forceinline__ void lm_pick_primary_body(const LmScene& sc, const LmFrame& fr, int cur, int rc, uint32_t seed, uint32_t* visCount, uint2* s_bag, uint32_t* s_tmp)
 {
     rc = lm_res_idx(fr, rc);
-    __shared__ uint2 s_bag[1000];
-    __shared__ uint32_t s_tmp[5];
     const uint32_t tilesX = (fr.W + 15u) / 16u;
     const uint32_t tx0 = fr.x0 / 16u, ty0 = fr.y0 / 16u;
     const uint32_t wtx = (fr.x0 + fr.ww + 15u) / 16u - tx0;
@@ -433,6 +431,8 @@ KN(lm_k_pick_primary)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, ui
         else {
             uint32_t s = lm_wang_hash(seed + lm_wang_hash(gi));
             LmReservoir fresh; lm_res_fresh(fresh);
+            LmTarget target;                                       // the pixel's surface, prepared once for its 32 candidates
+            lm_target_setup<A>(pixel, target);
             for (int smp = 0; smp < 32; smp++) {
                 const float r = lm_random_float(s);
                 const int pick = (int)roundf((float)(1000 - 1) * r);
@@ -441,21 +441,20 @@ KN(lm_k_pick_primary)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, ui
                 const float initialPdf = u2f(entry.y);
                 const float u = lm_random_float(s);
                 const float v = lm_random_float(s) * (1.f - u);
-                LmSample ls; lm_sample_zero(ls);
-                ls.radiance = light.radiance; ls.normal = light.normal; ls.area = light.area;
+                LmSample cand;
+                cand.p.radiance = light.radiance; cand.p.normal = light.normal; cand.p.area = light.area;
                 const lf3 arm1 = light.p1 - light.p0, arm2 = light.p2 - light.p0;
-                ls.position = light.p0 + (arm1 * u) + (arm2 * v);
-                LmSample rs;
-                lm_resample(ls, pixel, rs);
-                const float pdf = rs.pdf / initialPdf;
-                lm_res_update(fresh, rs, pdf, s);
+                cand.p.position = light.p0 + (arm1 * u) + (arm2 * v);
+                cand.contribution = v3(0.f);
+                lm_score<A>(cand.p, target, cand.contribution, cand.pdf);
+                lm_res_update<A>(fresh, cand, A::div(cand.pdf, initialPdf), s);
             }
-            lm_res_update_weight(fresh);
+            lm_res_update_weight<A>(fresh);
             lm_res_store(hot, fr.resC[rc], li, fresh);
             // K22 GenerateShadowRay fused (ReSTIRKernels.cu:546-582): the visibility ray of the fresh reservoir
             if (fresh.weight > 0.f) {
                 vpos = pixel.position;
-                vdir = fresh.s.position - vpos;
+                vdir = fresh.s.p.position - vpos;
                 vlen = length3(vdir);
                 vdir = vdir / vlen;
                 shoot = true;
@@ -468,18 +467,31 @@ KN(lm_k_pick_primary)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, ui
         fr.visD[slot] = v4(vdir, u2f(li));
     }
 }
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
+KN(lm_k_pick_primary)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount)
+{
+    __shared__ uint2 s_bag[1000];
+    __shared__ uint32_t s_tmp[5];
+    lm_pick_primary_body<LmExact>(sc, fr, cur, rc, seed, visCount, s_bag, s_tmp);
+}
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
+KN(lm_k_pick_primary_fast)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount)
+{
+    __shared__ uint2 s_bag[1000];
+    __shared__ uint32_t s_tmp[5];
+    lm_pick_primary_body<LmFast>(sc, fr, cur, rc, seed, visCount, s_bag, s_tmp);
+}
 
 // K24 temporal reuse.  `rf` = where this frame's fresh candidates live: the current buffer `rc` itself, or — when candidate
 // generation of the NEXT frame runs ahead on its own stream — a separate buffer, so that it does not have to wait for this
 // frame's spatial passes; the result lands in `rc` either way.
 // K24 temporal reuse — ReSTIRKernels.cu:1015-1121
-extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
-KN(lm_k_restir_temporal)(LmFrame fr, int cur, int prev, int rc, int rp, int rf, uint32_t seed, uint32_t* visCount)
+template <class A>
+__device__ __forceinline__ void lm_restir_temporal_body(const LmFrame& fr, int cur, int prev, int rc, int rp, int rf, uint32_t seed, uint32_t* visCount, uint32_t* s_tmp)
 {
     rc = lm_res_idx(fr, rc);
     rp = lm_res_idx(fr, rp);
     rf = lm_res_idx(fr, rf);
-    __shared__ uint32_t s_tmp[5];
     uint32_t li = 0, gi = 0;
     const bool valid = lm_tile_pixel(fr, li, gi);
     bool shoot = false;
@@ -515,10 +527,12 @@ KN(lm_k_restir_temporal)(LmFrame fr, int cur, int prev, int rc, int rp, int rf, 
                     if (cap < rpv.count) rpv.count = cap;
                     LmSurface s;
                     lm_gbuf_load(fr.gbuf[cur], li, s);
+                    LmTarget target;
+                    lm_target_setup<A>(s, target);
                     LmReservoir out;
-                    lm_combine2(out, rpv, rcv, s, lm_wang_hash(seed + gi));
+                    lm_combine2<A>(out, rpv, rcv, target, lm_wang_hash(seed + gi));
                     lm_res_store(fr.res[rc], fr.resC[rc], li, out);
-                    merged = true; weight = out.weight; vtarget = out.s.position; vpos = s.position;
+                    merged = true; weight = out.weight; vtarget = out.s.p.position; vpos = s.position;
                 }
             }
             if (!merged) {                                         // the fresh reservoir becomes the current one unchanged
@@ -550,6 +564,18 @@ KN(lm_k_restir_temporal)(LmFrame fr, int cur, int prev, int rc, int rp, int rf, 
         fr.vis2D[slot] = v4(vdir, u2f(li));
     }
 }
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
+KN(lm_k_restir_temporal)(LmFrame fr, int cur, int prev, int rc, int rp, int rf, uint32_t seed, uint32_t* visCount)
+{
+    __shared__ uint32_t s_tmp[5];
+    lm_restir_temporal_body<LmExact>(fr, cur, prev, rc, rp, rf, seed, visCount, s_tmp);
+}
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
+KN(lm_k_restir_temporal_fast)(LmFrame fr, int cur, int prev, int rc, int rp, int rf, uint32_t seed, uint32_t* visCount)
+{
+    __shared__ uint32_t s_tmp[5];
+    lm_restir_temporal_body<LmFast>(fr, cur, prev, rc, rp, rf, seed, visCount, s_tmp);
+}
 
 // K25 spatial reuse — ReSTIRKernels.cu:787-980 (biased branch).  The five candidate probes are issued together (one
 // 16-byte gather each from the probe plane) and the accepted candidates' 64-byte reservoir records are fetched one
@@ -557,8 +583,8 @@ KN(lm_k_restir_temporal)(LmFrame fr, int cur, int prev, int rc, int rp, int rf, 
 #ifndef LM_SPATIAL_WAVES
 #define LM_SPATIAL_WAVES 3      // <= 168 VGPRs: three waves per SIMD instead of two (the kernel is gather-latency bound)
 #endif
-extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_SPATIAL_WAVES)
-KN(lm_k_restir_spatial)(LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin)
+template <class A>
+__device__ __forceinline__ void lm_restir_spatial_body(const LmFrame& fr, int cur, int rin, int rout, uint32_t seed, int margin)
 {
     rin = lm_res_idx(fr, rin);
     rout = lm_res_idx(fr, rout);
@@ -603,36 +629,44 @@ KN(lm_k_restir_spatial)(LmFrame fr, int cur, int rin, int rout, uint32_t seed, i
         mask &= mask - 1u;
         const float4* h = hotIn + 4u * nb0;
         float4 a = h[0], p1 = h[1], p2 = h[2], p3 = h[3];
-        LmSurface s0;
-        lm_gbuf_load(fr.gbuf[cur], nb0, s0);                    // every candidate is re-evaluated at the FIRST neighbour's surface (reference :883)
+        LmTarget target;
+        {
+            LmSurface s0;
+            lm_gbuf_load(fr.gbuf[cur], nb0, s0);                // every candidate is re-evaluated at the FIRST neighbour's surface (reference :883)
+            lm_target_setup<A>(s0, target);
+        }
         LmReservoir out; lm_res_fresh(out);
         long long sum = 0;
         for (;;) {
             float4 na = a, np1 = p1, np2 = p2, np3 = p3;
             const bool more = mask != 0u;
             if (more) { const float4* hn = hotIn + 4u * candAt((uint32_t)__ffs((int)mask) - 1u); mask &= mask - 1u; na = hn[0]; np1 = hn[1]; np2 = hn[2]; np3 = hn[3]; }   // prefetch
-            LmSample in; lm_sample_zero(in);
-            in.radiance = v3(p1); in.area = p1.w; in.normal = v3(p2); in.position = v3(p3);
-            const long long cnt = (long long)f2u(a.z);
             LmSample rs;
-            lm_resample(in, s0, rs);
-            lm_res_update(out, rs, (float)cnt * a.y * rs.pdf, seed);   // global seed: same draw for all pixels (reference quirk)
+            rs.p = lm_point_unpack(p1, p2, p3);
+            rs.contribution = v3(0.f);                             // the neighbour's own contribution is not carried over (reference: a fresh LightSample)
+            const long long cnt = (long long)f2u(a.z);
+            lm_score<A>(rs.p, target, rs.contribution, rs.pdf);
+            lm_res_update<A>(out, rs, (float)cnt * a.y * rs.pdf, seed);   // global seed: same draw for all pixels (reference quirk)
             sum += cnt;
             if (!more) break;
             a = na; p1 = np1; p2 = np2; p3 = np3;
         }
         out.count = sum;
-        lm_res_update_weight(out);
+        lm_res_update_weight<A>(out);
         lm_res_store(hotOut, fr.resC[rout], li, out);
     } else {
         const float4 old = hotOut[4u * li];
         hotOut[4u * li] = make_float4(0.f, 0.f, u2f(0u), old.w);   // Reset(): weightSum, sampleCount, weight
     }
 }
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_SPATIAL_WAVES)
+KN(lm_k_restir_spatial)(LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin) { lm_restir_spatial_body<LmExact>(fr, cur, rin, rout, seed, margin); }
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_SPATIAL_WAVES)
+KN(lm_k_restir_spatial_fast)(LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin) { lm_restir_spatial_body<LmFast>(fr, cur, rin, rout, seed, margin); }
 
 // K26 CombineReservoirBuffers — ReSTIRKernels.cu:1407-1436
-extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
-KN(lm_k_restir_combine)(LmFrame fr, int cur, int rc, int rs, uint32_t seed)
+template <class A>
+__device__ __forceinline__ void lm_restir_combine_body(const LmFrame& fr, int cur, int rc, int rs, uint32_t seed)
 {
     rc = lm_res_idx(fr, rc);
     rs = lm_res_idx(fr, rs);
@@ -640,14 +674,22 @@ KN(lm_k_restir_combine)(LmFrame fr, int cur, int rc, int rs, uint32_t seed)
     if (!lm_tile_pixel(fr, li, gi)) return;
     if (!lm_owned(fr, li, 0)) return;
     if (fr.probe[cur][li].w < 0.f) return;
-    LmSurface s;
-    lm_gbuf_load(fr.gbuf[cur], li, s);
+    LmTarget target;
+    {
+        LmSurface s;
+        lm_gbuf_load(fr.gbuf[cur], li, s);
+        lm_target_setup<A>(s, target);
+    }
     LmReservoir a, b, out;
     lm_res_load(fr.res[rc], fr.resC[rc], li, a);
     lm_res_load(fr.res[rs], fr.resC[rs], li, b);
-    lm_combine2(out, a, b, s, lm_wang_hash(seed + gi));
+    lm_combine2<A>(out, a, b, target, lm_wang_hash(seed + gi));
     lm_res_store(fr.res[rc], fr.resC[rc], li, out);
 }
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
+KN(lm_k_restir_combine)(LmFrame fr, int cur, int rc, int rs, uint32_t seed) { lm_restir_combine_body<LmExact>(fr, cur, rc, rs, seed); }
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
+KN(lm_k_restir_combine_fast)(LmFrame fr, int cur, int rc, int rs, uint32_t seed) { lm_restir_combine_body<LmFast>(fr, cur, rc, rs, seed); }
 
 #if LM_INSTRUMENT
 extern "C" __global__ void lm_k_read_pushes(unsigned long long* out) { out[0] = g_lmPushes[0]; out[1] = g_lmPushes[1]; g_lmPushes[0] = 0; g_lmPushes[1] = 0; }
@@ -728,19 +770,6 @@ KN(lm_k_query_closest_raw)(LmScene sc, const float4* __restrict__ rayO, const fl
         idOut[i] = make_uint4(id.x, id.y, found ? 1u : 0u, 0u);
         uvtOut[i] = found ? make_float4(h.u, h.v, h.t, 0.f) : make_float4(0.f, 0.f, -1.f, 0.f);
     }
-}
-// mat: 23 floats per item (color4 tint3 lum transmittance3 ior + 11 parameters through the 8-bit setters)
-__device__ __forceinline__ LmMaterial lm_material_from23(const float* m)
-{
-    LmMaterial sd;
-    sd.color = make_float4(m[0], m[1], m[2], m[3]);
-    sd.tint = make_float4(m[4], m[5], m[6], m[7]);
-    sd.transmittance = make_float4(m[8], m[9], m[10], m[11]);
-    sd.p0 = sd.p1 = sd.p2 = 0u;
-    lm_pack8(sd.p0, 0, m[12]); lm_pack8(sd.p0, 8, m[13]); lm_pack8(sd.p0, 16, m[14]); lm_pack8(sd.p0, 24, m[15]);
-    lm_pack8(sd.p1, 0, m[16]); lm_pack8(sd.p1, 8, m[17]); lm_pack8(sd.p1, 16, m[18]); lm_pack8(sd.p1, 24, m[19]);
-    lm_pack8(sd.p2, 0, m[20]); lm_pack8(sd.p2, 8, m[21]); lm_pack8(sd.p2, 16, m[22]);
-    return sd;
 }
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
 KN(lm_k_test_bsdf)(uint32_t n, int mode, const float* __restrict__ mat, const float* __restrict__ N, const float* __restrict__ T,
@@ -956,11 +985,15 @@ static void l_path_tail(hipStream_t s, int g, LmScene sc, LmFrame fr, int inQ, c
 { hipLaunchKernelGGL(KN(lm_k_path_tail), LM_GRID(g), sc, fr, inQ, inCount, depth0, depthMax, seed0, lanesPerWave); }
 static void l_trace_shadow(hipStream_t s, int g, LmScene sc, LmFrame fr, const uint32_t* cnt, float tmin, int refillBelow) { hipLaunchKernelGGL(KN(lm_k_trace_shadow), LM_GRID(g), sc, fr, cnt, tmin, refillBelow); }
 static void l_fill_bags(hipStream_t s, LmScene sc, LmFrame fr, uint32_t seed, uint32_t total) { hipLaunchKernelGGL(KN(lm_k_fill_bags), LM_GRID((total + LM_BLOCK - 1) / LM_BLOCK), sc, fr, seed, total); }
-static void l_pick_primary(hipStream_t s, int tiles, LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount) { hipLaunchKernelGGL(KN(lm_k_pick_primary), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount); }
+static void l_pick_primary(hipStream_t s, int tiles, LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount, int fast)
+{ if (fast) hipLaunchKernelGGL(KN(lm_k_pick_primary_fast), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount); else hipLaunchKernelGGL(KN(lm_k_pick_primary), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount); }
 static void l_trace_shade(hipStream_t s, int g, LmScene sc, LmFrame fr, int rc, const uint32_t* cnt, int refillBelow, int pass) { hipLaunchKernelGGL(KN(lm_k_restir_trace_shade), LM_GRID(g), sc, fr, rc, cnt, refillBelow, pass); }
-static void l_temporal(hipStream_t s, int g, LmFrame fr, int cur, int prev, int rc, int rp, int rf, uint32_t seed, uint32_t* visCount) { hipLaunchKernelGGL(KN(lm_k_restir_temporal), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); }
-static void l_spatial(hipStream_t s, int g, LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin) { hipLaunchKernelGGL(KN(lm_k_restir_spatial), LM_GRID(g), fr, cur, rin, rout, seed, margin); }
-static void l_combine(hipStream_t s, int g, LmFrame fr, int cur, int rc, int rs, uint32_t seed) { hipLaunchKernelGGL(KN(lm_k_restir_combine), LM_GRID(g), fr, cur, rc, rs, seed); }
+static void l_temporal(hipStream_t s, int g, LmFrame fr, int cur, int prev, int rc, int rp, int rf, uint32_t seed, uint32_t* visCount, int fast)
+{ if (fast) hipLaunchKernelGGL(KN(lm_k_restir_temporal_fast), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); else hipLaunchKernelGGL(KN(lm_k_restir_temporal), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); }
+static void l_spatial(hipStream_t s, int g, LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin, int fast)
+{ if (fast) hipLaunchKernelGGL(KN(lm_k_restir_spatial_fast), LM_GRID(g), fr, cur, rin, rout, seed, margin); else hipLaunchKernelGGL(KN(lm_k_restir_spatial), LM_GRID(g), fr, cur, rin, rout, seed, margin); }
+static void l_combine(hipStream_t s, int g, LmFrame fr, int cur, int rc, int rs, uint32_t seed, int fast)
+{ if (fast) hipLaunchKernelGGL(KN(lm_k_restir_combine_fast), LM_GRID(g), fr, cur, rc, rs, seed); else hipLaunchKernelGGL(KN(lm_k_restir_combine), LM_GRID(g), fr, cur, rc, rs, seed); }
 static void l_clear(hipStream_t s, int g, float4* p, uint32_t n) { hipLaunchKernelGGL(KN(lm_k_clear_f4), LM_GRID(g), p, n); }
 static void l_merge(hipStream_t s, int g, LmFrame fr, int blend, uint32_t blendCount, int depthMax) { hipLaunchKernelGGL(KN(lm_k_merge_output), LM_GRID(g), fr, blend, blendCount, depthMax); }
 static void l_query_any(hipStream_t s, int g, LmScene sc, const float4* o, const float4* d, uint32_t n, float tmin, uint32_t* occ, uint32_t* counters) { hipLaunchKernelGGL(KN(lm_k_query_any), LM_GRID(g), sc, o, d, n, tmin, occ, counters); }

@@ -10,11 +10,11 @@ struct LmKernelTable {
     void (*trace_shadow)(hipStream_t, int grid, LmScene, LmFrame, const uint32_t* count, float tmin, int refillBelow);
     void (*path_tail)(hipStream_t, int grid, LmScene, LmFrame, int inQ, const uint32_t* inCount, int depth0, int depthMax, uint32_t seed0, int lanesPerWave);
     void (*fill_bags)(hipStream_t, LmScene, LmFrame, uint32_t seed, uint32_t total);
-    void (*pick_primary)(hipStream_t, int tiles, LmScene, LmFrame, int cur, int rc, uint32_t seed, uint32_t* visCount);
+    void (*pick_primary)(hipStream_t, int tiles, LmScene, LmFrame, int cur, int rc, uint32_t seed, uint32_t* visCount, int fast);
     void (*trace_shade)(hipStream_t, int grid, LmScene, LmFrame, int rc, const uint32_t* count, int refillBelow, int pass);
-    void (*temporal)(hipStream_t, int tiles, LmFrame, int cur, int prev, int rc, int rp, int rf, uint32_t seed, uint32_t* visCount);
-    void (*spatial)(hipStream_t, int tiles, LmFrame, int cur, int rin, int rout, uint32_t seed, int margin);
-    void (*combine)(hipStream_t, int tiles, LmFrame, int cur, int rc, int rs, uint32_t seed);
+    void (*temporal)(hipStream_t, int tiles, LmFrame, int cur, int prev, int rc, int rp, int rf, uint32_t seed, uint32_t* visCount, int fast);
+    void (*spatial)(hipStream_t, int tiles, LmFrame, int cur, int rin, int rout, uint32_t seed, int margin, int fast);
+    void (*combine)(hipStream_t, int tiles, LmFrame, int cur, int rc, int rs, uint32_t seed, int fast);     // fast: hardware rcp / rsq / sqrt in the resampling target function (LmFast, lm_bsdf.h)
     void (*clear)(hipStream_t, int grid, float4* p, uint32_t n);
     void (*merge)(hipStream_t, int grid, LmFrame, int blend, uint32_t blendCount, int depthMax);
     void (*query_any)(hipStream_t, int grid, LmScene, const float4* o, const float4* d, uint32_t n, float tmin, uint32_t* occluded, uint32_t* counters);

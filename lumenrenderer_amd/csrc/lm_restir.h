@@ -1,21 +1,31 @@
-// lm_restir.h — device code: ReSTIR DI reservoirs (storage, update, resampling, biased combination).  Included by kernels.hip only.
-#pragma once
-
-// ---------------------------------------------------------------------------------------------------------------------
-// ReSTIR DI — reference ReSTIRData.h:115-178, ReSTIRKernels.cu, Framework/ReSTIR.cpp:65-233
+// lm_restir.h — device code: ReSTIR DI reservoirs (storage, streaming update, target function, biased merge).
+// Included by kernels.hip only.
+//
+// Behaviour: reference ReSTIRData.h:115-178 (Reservoir), ReSTIRKernels.cu:1259-1325 (Resample), :1200-1257 (CombineBiased),
+// Framework/ReSTIR.cpp:65-233.  Shape: a resampling loop scores MANY light points against ONE receiving surface, so the receiver is
+// prepared once (LmTarget = position + the BSDF lobes of lm_bsdf.h set up for its view direction) and a candidate only pays for what
+// depends on the light point.  Every function takes the arithmetic policy of lm_bsdf.h (LmExact: the bit-exact contract; LmFast:
+// hardware reciprocal / square root for the target function and the resampling weights).
+//
 // reservoir storage: a 64-byte "hot" record per pixel (what reuse passes gather from other pixels):
 //   0 (weightSum, weight, sampleCount bits, solidAnglePdf)   1 (radiance, area)   2 (normal, 0)   3 (position, 0)
 // plus a separate plane with the unshadowed contribution (only ever read for the pixel being shaded).
-// ---------------------------------------------------------------------------------------------------------------------
-struct LmSample { lf3 radiance, normal, position, contribution; float area, pdf; };
+#pragma once
+
+struct LmLightPoint { lf3 position, normal, radiance; float area; };       // a point on an emissive triangle, as a reservoir remembers it
+struct LmSample { LmLightPoint p; lf3 contribution; float pdf; };            // + what it is worth at the surface it was last scored for
 struct LmReservoir { float weightSum, weight; long long count; LmSample s; };
 
-__device__ __forceinline__ void lm_sample_zero(LmSample& s) { s.radiance = v3(0.f); s.normal = v3(0.f); s.position = v3(0.f); s.contribution = v3(0.f); s.area = 0.f; s.pdf = 0.f; }
+__device__ __forceinline__ void lm_sample_zero(LmSample& s) { s.p.radiance = v3(0.f); s.p.normal = v3(0.f); s.p.position = v3(0.f); s.p.area = 0.f; s.contribution = v3(0.f); s.pdf = 0.f; }
 __device__ __forceinline__ void lm_res_fresh(LmReservoir& r) { r.weightSum = 0.f; r.weight = 0.f; r.count = 0; lm_sample_zero(r.s); }
+__device__ __forceinline__ LmLightPoint lm_point_unpack(const float4& p1, const float4& p2, const float4& p3)
+{
+    LmLightPoint p; p.radiance = v3(p1); p.area = p1.w; p.normal = v3(p2); p.position = v3(p3); return p;
+}
 __device__ __forceinline__ void lm_res_unpack(const float4& a, const float4& p1, const float4& p2, const float4& p3, LmReservoir& r)
 {
     r.weightSum = a.x; r.weight = a.y; r.count = (long long)f2u(a.z); r.s.pdf = a.w;
-    r.s.radiance = v3(p1); r.s.area = p1.w; r.s.normal = v3(p2); r.s.position = v3(p3);
+    r.s.p = lm_point_unpack(p1, p2, p3);
 }
 __device__ __forceinline__ void lm_res_load(const float4* __restrict__ hot, const float4* __restrict__ contrib, uint32_t li, LmReservoir& r)
 {
@@ -27,52 +37,69 @@ __device__ __forceinline__ void lm_res_store(float4* __restrict__ hot, float4* _
 {
     float4* h = hot + 4u * li;
     h[0] = make_float4(r.weightSum, r.weight, u2f((uint32_t)r.count), r.s.pdf);
-    h[1] = v4(r.s.radiance, r.s.area);
-    h[2] = v4(r.s.normal, 0.f);
-    h[3] = v4(r.s.position, 0.f);
+    h[1] = v4(r.s.p.radiance, r.s.p.area);
+    h[2] = v4(r.s.p.normal, 0.f);
+    h[3] = v4(r.s.p.position, 0.f);
     contrib[li] = v4(r.s.contribution, 0.f);
 }
-__device__ __forceinline__ void lm_res_update(LmReservoir& r, const LmSample& s, float w, uint32_t seed /* by value: reference quirk */)
+
+// the receiving surface of a resampling loop
+struct LmTarget { lf3 position; LmLobes lobes; };      // lobes.N is the shading normal, lobes.wo the direction back along the camera path
+template <class A> __device__ __forceinline__ void lm_target_setup(const LmSurface& px, LmTarget& t)
+{
+    t.position = px.position;
+    lm_lobes_setup<A>(px.mat, px.normal, px.tangent, -px.incoming, t.lobes);
+}
+
+// Target function: unshadowed contribution of the light point at the receiver; its mean is the resampling pdf (0 = unusable).
+template <class A> __device__ __forceinline__ void lm_score(const LmLightPoint& p, const LmTarget& t, lf3& contribution, float& pdfOut)
+{
+    lf3 toLight = p.position - t.position;
+    const float dist = A::sqrt(dot3(toLight, toLight));
+    toLight = lm_scale_inv<A>(toLight, dist);
+    const float cosIn = fmaxf(dot3(toLight, t.lobes.N), 0.f);
+    const float cosOut = fmaxf(dot3(p.normal, -toLight), 0.f);
+    pdfOut = 0.f;
+    if (cosIn <= 0 || cosOut <= 0 || dist <= 0.01f) return;            // contribution keeps what the caller put there (reference: out = in)
+    const float solidAngle = A::div(cosOut * p.area, dist * dist);
+    float pdf = 0.f;
+    const lf3 bsdf = lm_lobes_eval<A>(t.lobes, toLight, pdf);
+    const float added = pdf + bsdf.x + bsdf.y + bsdf.z;
+    if (pdf <= LM_EPSILON || added != added || fabsf(added) == u2f(0x7f800000u)) { contribution = v3(0.f); return; }
+    contribution = lm_scale_inv<A>(bsdf, pdf) * solidAngle * cosIn * p.radiance;
+    pdfOut = A::div(contribution.x + contribution.y + contribution.z, 3.f);
+}
+// Resample (ReSTIRKernels.cu:1259-1325): the sample re-scored at another receiver; the stale contribution survives the early-outs
+template <class A> __device__ __forceinline__ void lm_resample(const LmSample& in, const LmTarget& t, LmSample& out)
+{
+    out.p = in.p;
+    out.contribution = in.contribution;
+    lm_score<A>(in.p, t, out.contribution, out.pdf);
+}
+
+// streaming weighted reservoir update (Reservoir::Update: the seed arrives BY VALUE, so every update of one merge draws the same number)
+template <class A> __device__ __forceinline__ void lm_res_update(LmReservoir& r, const LmSample& s, float w, uint32_t seed)
 {
     r.weightSum += w;
     ++r.count;
     const float rnd = lm_random_float(seed);
-    if (rnd <= (w / r.weightSum)) r.s = s;
+    if (rnd <= A::div(w, r.weightSum)) r.s = s;
 }
-__device__ __forceinline__ void lm_res_update_weight(LmReservoir& r)
+template <class A> __device__ __forceinline__ void lm_res_update_weight(LmReservoir& r)
 {
     if (r.count == 0 || r.weightSum <= 0.f) { r.weight = 0; return; }
-    r.weight = (1.f / fmaxf(r.s.pdf, 1.1920928955078125e-7f)) * ((1.f / (float)r.count) * r.weightSum);
+    r.weight = A::rcp(fmaxf(r.s.pdf, 1.1920928955078125e-7f)) * (A::rcp((float)r.count) * r.weightSum);
 }
-// Resample — ReSTIRKernels.cu:1259-1325
-__device__ void lm_resample(const LmSample& in, const LmSurface& px, LmSample& out)
-{
-    out = in;
-    lf3 toLight = in.position - px.position;
-    const float lDistance = length3(toLight);
-    toLight = toLight / lDistance;
-    const float cosIn = fmaxf(dot3(toLight, px.normal), 0.f);
-    const float cosOut = fmaxf(dot3(in.normal, -toLight), 0.f);
-    if (cosIn <= 0 || cosOut <= 0 || lDistance <= 0.01f) { out.pdf = 0; return; }
-    const float solidAngle = (cosOut * in.area) / (lDistance * lDistance);
-    float pdf = 0.f;
-    const lf3 bsdf = lm_evaluate_bsdf(px.mat, px.normal, px.tangent, -px.incoming, toLight, pdf);
-    const float added = pdf + bsdf.x + bsdf.y + bsdf.z;
-    if (pdf <= LM_EPSILON || added != added || fabsf(added) == u2f(0x7f800000u)) { out.contribution = v3(0.f); out.pdf = 0; return; }
-    const lf3 contribution = (bsdf / pdf) * solidAngle * cosIn * out.radiance;
-    out.contribution = contribution;
-    out.pdf = (contribution.x + contribution.y + contribution.z) / 3.f;
-}
-// CombineBiased for two reservoirs — ReSTIRKernels.cu:1200-1257
-__device__ void lm_combine2(LmReservoir& dst, const LmReservoir& a, const LmReservoir& b, const LmSurface& px, uint32_t seed)
+// CombineBiased for two reservoirs (ReSTIRKernels.cu:1200-1257)
+template <class A> __device__ __forceinline__ void lm_combine2(LmReservoir& dst, const LmReservoir& a, const LmReservoir& b, const LmTarget& t, uint32_t seed)
 {
     LmReservoir out; lm_res_fresh(out);
     LmSample rs;
-    lm_resample(a.s, px, rs);
-    lm_res_update(out, rs, (float)a.count * a.weight * rs.pdf, seed);
-    lm_resample(b.s, px, rs);
-    lm_res_update(out, rs, (float)b.count * b.weight * rs.pdf, seed);
+    lm_resample<A>(a.s, t, rs);
+    lm_res_update<A>(out, rs, (float)a.count * a.weight * rs.pdf, seed);
+    lm_resample<A>(b.s, t, rs);
+    lm_res_update<A>(out, rs, (float)b.count * b.weight * rs.pdf, seed);
     out.count = a.count + b.count;
-    lm_res_update_weight(out);
+    lm_res_update_weight<A>(out);
     dst = out;
 }

@@ -25,6 +25,7 @@ int lumen_mi_create(lumen_mi_renderer** out)
     if (const char* e = getenv("LUMEN_MI_TAIL_BELOW")) (*out)->tailBelow = atoi(e);
     if (const char* e = getenv("LUMEN_MI_PICK_AHEAD")) (*out)->pickAhead = atoi(e);
     if (const char* e = getenv("LUMEN_MI_SHADOW_ON_WAVE")) (*out)->shadowOnWave = atoi(e);
+    if (const char* e = getenv("LUMEN_MI_FAST_RESAMPLE")) (*out)->fastResample = atoi(e) != 0;
     if (const char* e = getenv("LUMEN_MI_TAIL_LANES")) (*out)->tailLanes = std::max(1, std::min(64, atoi(e)));
     return 0;
 }
@@ -570,6 +571,7 @@ int lumen_mi_set_tuning(lumen_mi_renderer* r, const char* key, int value)
     else if (k == "fuzz") r->fuzz = (uint32_t)value;
     else if (k == "assemble") r->assembleEnabled = value;
     else if (k == "shadow_on_wave") { if (r->initialised) { int rc = syncAndCollect(r); if (rc) return rc; } r->shadowOnWave = value; }
+    else if (k == "fast_resample") r->fastResample = value != 0;
     else if (k == "refill") r->refillBelow = value;
     else if (k == "refill_visibility") r->refillVisibility = value;
     else if (k == "refill_primary") r->refillPrimary = value;

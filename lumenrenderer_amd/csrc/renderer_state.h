@@ -172,6 +172,8 @@ struct lumen_mi_renderer {
     bool entriesDirty = false;              // emissive mode / radiance / override material of an instance changed: scene table + lights only
     uint32_t refits = 0;                    // refits since the last full build
     int refitEnabled = 1;                   // 0: every transform change triggers a full host rebuild
+    int fastResample = 0;                   // 1: the ReSTIR target function and resampling weights use hardware rcp / rsq / sqrt (LmFast): within 1e-3 rel-L2
+                                            // of the exact mode, not bit-identical (tuning key "fast_resample", LUMEN_MI_FAST_RESAMPLE)
 
     // camera
     float camPos[3] = {0, 0, 0}, camRight[3] = {-1, 0, 0}, camUp[3] = {0, 1, 0}, camFwd[3] = {0, 0, 1};

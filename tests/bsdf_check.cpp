@@ -1,0 +1,44 @@
+// Host-side build of the product's BSDF header (lumenrenderer_amd/csrc/lm_bsdf.h, exact arithmetic policy), compiled for the CPU by
+// tests/test_cpu_host.py and compared bit for bit with the oracle's unsplit restatement of the reference: the setup / per-direction
+// split of the product must not change a single operation.  Test infrastructure only.
+#include "lm_bsdf.h"
+
+extern "C" {
+
+// one-shot evaluation: out = (bsdf.xyz, pdf) per item
+void chk_eval_bsdf(uint32_t n, const float* mat23, const float* N, const float* T, const float* wo, const float* wi, float* out)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        const LmMaterial sd = lm_material_from23(mat23 + 23 * i);
+        float pdf = 0.f;
+        const lf3 b = lm_evaluate_bsdf<LmExact>(sd, v3(N[3*i], N[3*i+1], N[3*i+2]), v3(T[3*i], T[3*i+1], T[3*i+2]), v3(wo[3*i], wo[3*i+1], wo[3*i+2]), v3(wi[3*i], wi[3*i+1], wi[3*i+2]), pdf);
+        out[4*i] = b.x; out[4*i+1] = b.y; out[4*i+2] = b.z; out[4*i+3] = pdf;
+    }
+}
+// the way the light loops use it: ONE setup per surface, then `k` light directions (wi: n * k * 3 floats, out: n * k * 4)
+void chk_eval_many(uint32_t n, uint32_t k, const float* mat23, const float* N, const float* T, const float* wo, const float* wi, float* out)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        const LmMaterial sd = lm_material_from23(mat23 + 23 * i);
+        LmLobes L;
+        lm_lobes_setup<LmExact>(sd, v3(N[3*i], N[3*i+1], N[3*i+2]), v3(T[3*i], T[3*i+1], T[3*i+2]), v3(wo[3*i], wo[3*i+1], wo[3*i+2]), L);
+        for (uint32_t j = 0; j < k; j++) {
+            const size_t q = (size_t)i * k + j;
+            float pdf = 0.f;
+            const lf3 b = lm_lobes_eval<LmExact>(L, v3(wi[3*q], wi[3*q+1], wi[3*q+2]), pdf);
+            out[4*q] = b.x; out[4*q+1] = b.y; out[4*q+2] = b.z; out[4*q+3] = pdf;
+        }
+    }
+}
+void chk_sample_bsdf(uint32_t n, const float* mat23, const float* N, const float* T, const float* wo, const float* r, float* out)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        const LmMaterial sd = lm_material_from23(mat23 + 23 * i);
+        float pdf = 0.f; bool spec = false; lf3 wi = v3(0.f);
+        const lf3 n3 = v3(N[3*i], N[3*i+1], N[3*i+2]);
+        const lf3 b = lm_sample_bsdf(sd, n3, n3, v3(T[3*i], T[3*i+1], T[3*i+2]), v3(wo[3*i], wo[3*i+1], wo[3*i+2]), 1.f, r[3*i], r[3*i+1], r[3*i+2], wi, pdf, spec);
+        out[8*i] = b.x; out[8*i+1] = b.y; out[8*i+2] = b.z; out[8*i+3] = wi.x; out[8*i+4] = wi.y; out[8*i+5] = wi.z; out[8*i+6] = pdf; out[8*i+7] = spec ? 1.f : 0.f;
+    }
+}
+
+}  // extern "C"
