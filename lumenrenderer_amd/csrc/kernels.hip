@@ -186,6 +186,7 @@ KN(lm_k_extract0)(LmScene sc, LmFrame fr, LmCamera cam, int cur, uint32_t seed2,
         LmSurface s;
         lm_extract(sc, fr.hits[i], v3(o4), v3(d4), v3(c4), s);
         lm_gbuf_store(fr.gbuf[cur], fr.probe[cur], li, s);
+        lm_count(fr.counters + LM_CNT_RARE, !s.flags && !lm_quick_contracts(s.mat));      // surfaces the fast ReSTIR mode scores in its second launch (none: no atomic)
         // motion vector
         const uint32_t ly = li / fr.ww, lx = li - ly * fr.ww;
         const uint32_t px = fr.x0 + lx, py = fr.y0 + ly;
@@ -402,9 +403,10 @@ KN(lm_k_fill_bags)(LmScene sc, LmFrame fr, uint32_t seed, uint32_t total)
 // K21 PickPrimarySamples — ReSTIRKernels.cu:402-522.  One 16x16 pixel tile (aligned to the GLOBAL 16x16 grid) shares a light
 // bag (the reference keys the bag on the hardware SM id, which is not reproducible: DESIGN.md decision D2); the bag's 1000
 // (index, pdf) pairs are staged in LDS once per tile.
-template <class A>
+template <class A, int ROLE>
 __device__ __forceinline__ void lm_pick_primary_body(const LmScene& sc, const LmFrame& fr, int cur, int rc, uint32_t seed, uint32_t* visCount, uint2* s_bag, uint32_t* s_tmp)
 {
+    if (ROLE == LM_RARE && fr.counters[LM_CNT_RARE] == 0u) return;      // grid-uniform: no surface of this frame needs the second launch
     rc = lm_res_idx(fr, rc);
     const uint32_t tilesX = (fr.W + 15u) / 16u;
     const uint32_t tx0 = fr.x0 / 16u, ty0 = fr.y0 / 16u;
@@ -413,7 +415,11 @@ __device__ __forceinline__ void lm_pick_primary_body(const LmScene& sc, const Lm
     uint32_t bagSeed = lm_wang_hash(seed + (tileY * tilesX + tileX));
     const float rb = lm_random_float(bagSeed);
     const int bagIndex = (int)roundf((float)(50 - 1) * rb);
-    for (uint32_t k = threadIdx.x; k < 1000u; k += LM_BLOCK) s_bag[k] = fr.bags[(uint32_t)bagIndex * 1000u + k];
+    for (uint32_t k = threadIdx.x; k < 1000u; k += LM_BLOCK) {
+        uint2 e = fr.bags[(uint32_t)bagIndex * 1000u + k];
+        if constexpr (A::contracted) e.y = f2u(A::rcp(u2f(e.y)));      // the loop multiplies by 1 / pdf: 1 000 reciprocals per tile instead of 8 192
+        s_bag[k] = e;
+    }
     __syncthreads();
     const uint32_t px = tileX * 16u + (threadIdx.x & 15u), py = tileY * 16u + (threadIdx.x >> 4);
     const bool inside = !(px < fr.x0 || py < fr.y0 || px >= fr.x0 + fr.ww || py >= fr.y0 + fr.wh);
@@ -427,8 +433,8 @@ __device__ __forceinline__ void lm_pick_primary_body(const LmScene& sc, const Lm
         float4* hot = fr.res[rc];
         LmSurface pixel;
         lm_gbuf_load(fr.gbuf[cur], li, pixel);
-        if (pixel.flags) { float4 a = hot[4u * li]; a.y = 0.f; hot[4u * li] = a; }
-        else {
+        if (pixel.flags) { if (ROLE != LM_RARE) { float4 a = hot[4u * li]; a.y = 0.f; hot[4u * li] = a; } }
+        else if (lm_role_takes<ROLE>(pixel.mat)) {
             uint32_t s = lm_wang_hash(seed + lm_wang_hash(gi));
             LmReservoir fresh; lm_res_fresh(fresh);
             LmTarget target;                                       // the pixel's surface, prepared once for its 32 candidates
@@ -438,7 +444,7 @@ __device__ __forceinline__ void lm_pick_primary_body(const LmScene& sc, const Lm
                 const int pick = (int)roundf((float)(1000 - 1) * r);
                 const uint2 entry = s_bag[pick];
                 const LmTriLight light = lm_load_light(sc.lights, entry.x);
-                const float initialPdf = u2f(entry.y);
+                const float initialPdf = u2f(entry.y);               // contracted policy: its reciprocal (see the staging loop)
                 const float u = lm_random_float(s);
                 const float v = lm_random_float(s) * (1.f - u);
                 LmSample cand;
@@ -447,7 +453,7 @@ __device__ __forceinline__ void lm_pick_primary_body(const LmScene& sc, const Lm
                 cand.p.position = light.p0 + (arm1 * u) + (arm2 * v);
                 cand.contribution = v3(0.f);
                 lm_score<A>(cand.p, target, cand.contribution, cand.pdf);
-                lm_res_update<A>(fresh, cand, A::div(cand.pdf, initialPdf), s);
+                lm_res_update<A>(fresh, cand, A::contracted ? cand.pdf * initialPdf : A::div(cand.pdf, initialPdf), s);
             }
             lm_res_update_weight<A>(fresh);
             lm_res_store(hot, fr.resC[rc], li, fresh);
@@ -472,23 +478,31 @@ KN(lm_k_pick_primary)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, ui
 {
     __shared__ uint2 s_bag[1000];
     __shared__ uint32_t s_tmp[5];
-    lm_pick_primary_body<LmExact>(sc, fr, cur, rc, seed, visCount, s_bag, s_tmp);
+    lm_pick_primary_body<LmExact, LM_ALL>(sc, fr, cur, rc, seed, visCount, s_bag, s_tmp);
 }
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
 KN(lm_k_pick_primary_fast)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount)
 {
     __shared__ uint2 s_bag[1000];
     __shared__ uint32_t s_tmp[5];
-    lm_pick_primary_body<LmFast>(sc, fr, cur, rc, seed, visCount, s_bag, s_tmp);
+    lm_pick_primary_body<LmFast, LM_COMMON>(sc, fr, cur, rc, seed, visCount, s_bag, s_tmp);
+}
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
+KN(lm_k_pick_primary_rare)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount)
+{
+    __shared__ uint2 s_bag[1000];
+    __shared__ uint32_t s_tmp[5];
+    lm_pick_primary_body<LmExact, LM_RARE>(sc, fr, cur, rc, seed, visCount, s_bag, s_tmp);
 }
 
 // K24 temporal reuse.  `rf` = where this frame's fresh candidates live: the current buffer `rc` itself, or — when candidate
 // generation of the NEXT frame runs ahead on its own stream — a separate buffer, so that it does not have to wait for this
 // frame's spatial passes; the result lands in `rc` either way.
 // K24 temporal reuse — ReSTIRKernels.cu:1015-1121
-template <class A>
+template <class A, int ROLE>
 __device__ __forceinline__ void lm_restir_temporal_body(const LmFrame& fr, int cur, int prev, int rc, int rp, int rf, uint32_t seed, uint32_t* visCount, uint32_t* s_tmp)
 {
+    if (ROLE == LM_RARE && fr.counters[LM_CNT_RARE] == 0u) return;
     rc = lm_res_idx(fr, rc);
     rp = lm_res_idx(fr, rp);
     rf = lm_res_idx(fr, rf);
@@ -507,35 +521,40 @@ __device__ __forceinline__ void lm_restir_temporal_body(const LmFrame& fr, int c
             uint32_t tli = li;
             if (ty >= 0 && ty < (int)fr.wh && tx >= 0 && tx < (int)fr.ww) tli = (uint32_t)ty * fr.ww + (uint32_t)tx;
             const float4 pn = fr.probe[prev][tli];
-            bool merged = false;
+            bool merged = false, mine = false;
             float weight = 0.f;
             if (pn.w >= 0.f) {
                 const float d1 = pn.w, d2 = cn.w;
                 const float depthDif = fabsf(d1 - d2) / ((d1 + d2) / 2.f);
                 const float angle = dot3(v3(pn), v3(cn));
                 if (depthDif < 0.10f && angle > 0.72222222223f) {
-                    LmReservoir rpv, rcv;
-                    lm_res_load(fr.res[rp], fr.resC[rp], tli, rpv);
-                    lm_res_load(fr.res[rf], fr.resC[rf], li, rcv);
-                    if (rpv.weight > 0.f) {                        // ShadeReservoirs on the PREVIOUS reservoir
-                        const lf3 add = rpv.s.contribution * (rpv.weight / 3.f);
-                        float4 px = fr.direct[li];
-                        px.x += add.x; px.y += add.y; px.z += add.z;
-                        fr.direct[li] = px;
-                    }
-                    const long long cap = rcv.count * 20;
-                    if (cap < rpv.count) rpv.count = cap;
+                    merged = true;
                     LmSurface s;
                     lm_gbuf_load(fr.gbuf[cur], li, s);
-                    LmTarget target;
-                    lm_target_setup<A>(s, target);
-                    LmReservoir out;
-                    lm_combine2<A>(out, rpv, rcv, target, lm_wang_hash(seed + gi));
-                    lm_res_store(fr.res[rc], fr.resC[rc], li, out);
-                    merged = true; weight = out.weight; vtarget = out.s.p.position; vpos = s.position;
+                    if (lm_role_takes<ROLE>(s.mat)) {              // fast mode: the other launch merges this pixel
+                        mine = true;
+                        LmReservoir rpv, rcv;
+                        lm_res_load(fr.res[rp], fr.resC[rp], tli, rpv);
+                        lm_res_load(fr.res[rf], fr.resC[rf], li, rcv);
+                        if (rpv.weight > 0.f) {                    // ShadeReservoirs on the PREVIOUS reservoir
+                            const lf3 add = rpv.s.contribution * (rpv.weight / 3.f);
+                            float4 px = fr.direct[li];
+                            px.x += add.x; px.y += add.y; px.z += add.z;
+                            fr.direct[li] = px;
+                        }
+                        const long long cap = rcv.count * 20;
+                        if (cap < rpv.count) rpv.count = cap;
+                        LmTarget target;
+                        lm_target_setup<A>(s, target);
+                        LmReservoir out;
+                        lm_combine2<A>(out, rpv, rcv, target, lm_wang_hash(seed + gi));
+                        lm_res_store(fr.res[rc], fr.resC[rc], li, out);
+                        weight = out.weight; vtarget = out.s.p.position; vpos = s.position;
+                    }
                 }
             }
-            if (!merged) {                                         // the fresh reservoir becomes the current one unchanged
+            if (!merged && ROLE != LM_RARE) {                      // the fresh reservoir becomes the current one unchanged (no evaluation: first launch)
+                mine = true;
                 const float4* h = fr.res[rf] + 4u * li;
                 const float4 h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3];
                 if (rf != rc) {
@@ -546,8 +565,8 @@ __device__ __forceinline__ void lm_restir_temporal_body(const LmFrame& fr, int c
                 weight = h0.y;
                 if (weight > 0.f) { vtarget = v3(h3); vpos = v3(fr.gbuf[cur][8u * li]); }
             }
-            shoot = weight > 0.f && lm_owned(fr, li, 0);           // second GenerateShadowRay pass (ReSTIR.cpp:211), fused; only owned pixels are combined
-        } else if (rf != rc) {
+            shoot = mine && weight > 0.f && lm_owned(fr, li, 0);   // second GenerateShadowRay pass (ReSTIR.cpp:211), fused; only owned pixels are combined
+        } else if (rf != rc && ROLE != LM_RARE) {
             // flagged pixel: the candidate pick only zeroes the weight of the CURRENT reservoir and leaves the rest stale
             // (ReSTIRKernels.cu:441-447); when the pick wrote to its own buffer, do that here — a later frame may read this
             // entry as "previous" through a probe plane of a different age
@@ -568,13 +587,19 @@ extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
 KN(lm_k_restir_temporal)(LmFrame fr, int cur, int prev, int rc, int rp, int rf, uint32_t seed, uint32_t* visCount)
 {
     __shared__ uint32_t s_tmp[5];
-    lm_restir_temporal_body<LmExact>(fr, cur, prev, rc, rp, rf, seed, visCount, s_tmp);
+    lm_restir_temporal_body<LmExact, LM_ALL>(fr, cur, prev, rc, rp, rf, seed, visCount, s_tmp);
 }
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
 KN(lm_k_restir_temporal_fast)(LmFrame fr, int cur, int prev, int rc, int rp, int rf, uint32_t seed, uint32_t* visCount)
 {
     __shared__ uint32_t s_tmp[5];
-    lm_restir_temporal_body<LmFast>(fr, cur, prev, rc, rp, rf, seed, visCount, s_tmp);
+    lm_restir_temporal_body<LmFast, LM_COMMON>(fr, cur, prev, rc, rp, rf, seed, visCount, s_tmp);
+}
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
+KN(lm_k_restir_temporal_rare)(LmFrame fr, int cur, int prev, int rc, int rp, int rf, uint32_t seed, uint32_t* visCount)
+{
+    __shared__ uint32_t s_tmp[5];
+    lm_restir_temporal_body<LmExact, LM_RARE>(fr, cur, prev, rc, rp, rf, seed, visCount, s_tmp);
 }
 
 // K25 spatial reuse — ReSTIRKernels.cu:787-980 (biased branch).  The five candidate probes are issued together (one
@@ -583,9 +608,10 @@ KN(lm_k_restir_temporal_fast)(LmFrame fr, int cur, int prev, int rc, int rp, int
 #ifndef LM_SPATIAL_WAVES
 #define LM_SPATIAL_WAVES 3      // <= 168 VGPRs: three waves per SIMD instead of two (the kernel is gather-latency bound)
 #endif
-template <class A>
+template <class A, int ROLE>
 __device__ __forceinline__ void lm_restir_spatial_body(const LmFrame& fr, int cur, int rin, int rout, uint32_t seed, int margin)
 {
+    if (ROLE == LM_RARE && fr.counters[LM_CNT_RARE] == 0u) return;
     rin = lm_res_idx(fr, rin);
     rout = lm_res_idx(fr, rout);
 #ifdef LM_SPATIAL_PRIO
@@ -633,14 +659,19 @@ __device__ __forceinline__ void lm_restir_spatial_body(const LmFrame& fr, int cu
         {
             LmSurface s0;
             lm_gbuf_load(fr.gbuf[cur], nb0, s0);                // every candidate is re-evaluated at the FIRST neighbour's surface (reference :883)
+            if (!lm_role_takes<ROLE>(s0.mat)) return;           // fast mode: the other launch handles this pixel
             lm_target_setup<A>(s0, target);
         }
         LmReservoir out; lm_res_fresh(out);
         long long sum = 0;
         for (;;) {
-            float4 na = a, np1 = p1, np2 = p2, np3 = p3;
+            // prefetch of the next accepted candidate's record.  The load is unconditional (the last round re-reads the first record, a
+            // cache hit): a conditional load makes the compiler select between a global and a stack POINTER, i.e. spill the current
+            // record to scratch and reload everything through flat loads
             const bool more = mask != 0u;
-            if (more) { const float4* hn = hotIn + 4u * candAt((uint32_t)__ffs((int)mask) - 1u); mask &= mask - 1u; na = hn[0]; np1 = hn[1]; np2 = hn[2]; np3 = hn[3]; }   // prefetch
+            const float4* hn = hotIn + 4u * (more ? candAt((uint32_t)__ffs((int)mask) - 1u) : nb0);
+            mask &= mask - 1u;                                      // 0 stays 0
+            const float4 na = hn[0], np1 = hn[1], np2 = hn[2], np3 = hn[3];
             LmSample rs;
             rs.p = lm_point_unpack(p1, p2, p3);
             rs.contribution = v3(0.f);                             // the neighbour's own contribution is not carried over (reference: a fresh LightSample)
@@ -654,20 +685,23 @@ __device__ __forceinline__ void lm_restir_spatial_body(const LmFrame& fr, int cu
         out.count = sum;
         lm_res_update_weight<A>(out);
         lm_res_store(hotOut, fr.resC[rout], li, out);
-    } else {
+    } else if (ROLE != LM_RARE) {
         const float4 old = hotOut[4u * li];
         hotOut[4u * li] = make_float4(0.f, 0.f, u2f(0u), old.w);   // Reset(): weightSum, sampleCount, weight
     }
 }
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_SPATIAL_WAVES)
-KN(lm_k_restir_spatial)(LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin) { lm_restir_spatial_body<LmExact>(fr, cur, rin, rout, seed, margin); }
+KN(lm_k_restir_spatial)(LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin) { lm_restir_spatial_body<LmExact, LM_ALL>(fr, cur, rin, rout, seed, margin); }
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_SPATIAL_WAVES)
-KN(lm_k_restir_spatial_fast)(LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin) { lm_restir_spatial_body<LmFast>(fr, cur, rin, rout, seed, margin); }
+KN(lm_k_restir_spatial_fast)(LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin) { lm_restir_spatial_body<LmFast, LM_COMMON>(fr, cur, rin, rout, seed, margin); }
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_SPATIAL_WAVES)
+KN(lm_k_restir_spatial_rare)(LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin) { lm_restir_spatial_body<LmExact, LM_RARE>(fr, cur, rin, rout, seed, margin); }
 
 // K26 CombineReservoirBuffers — ReSTIRKernels.cu:1407-1436
-template <class A>
+template <class A, int ROLE>
 __device__ __forceinline__ void lm_restir_combine_body(const LmFrame& fr, int cur, int rc, int rs, uint32_t seed)
 {
+    if (ROLE == LM_RARE && fr.counters[LM_CNT_RARE] == 0u) return;
     rc = lm_res_idx(fr, rc);
     rs = lm_res_idx(fr, rs);
     uint32_t li = 0, gi = 0;
@@ -678,6 +712,7 @@ __device__ __forceinline__ void lm_restir_combine_body(const LmFrame& fr, int cu
     {
         LmSurface s;
         lm_gbuf_load(fr.gbuf[cur], li, s);
+        if (!lm_role_takes<ROLE>(s.mat)) return;
         lm_target_setup<A>(s, target);
     }
     LmReservoir a, b, out;
@@ -687,9 +722,11 @@ __device__ __forceinline__ void lm_restir_combine_body(const LmFrame& fr, int cu
     lm_res_store(fr.res[rc], fr.resC[rc], li, out);
 }
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
-KN(lm_k_restir_combine)(LmFrame fr, int cur, int rc, int rs, uint32_t seed) { lm_restir_combine_body<LmExact>(fr, cur, rc, rs, seed); }
+KN(lm_k_restir_combine)(LmFrame fr, int cur, int rc, int rs, uint32_t seed) { lm_restir_combine_body<LmExact, LM_ALL>(fr, cur, rc, rs, seed); }
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
-KN(lm_k_restir_combine_fast)(LmFrame fr, int cur, int rc, int rs, uint32_t seed) { lm_restir_combine_body<LmFast>(fr, cur, rc, rs, seed); }
+KN(lm_k_restir_combine_fast)(LmFrame fr, int cur, int rc, int rs, uint32_t seed) { lm_restir_combine_body<LmFast, LM_COMMON>(fr, cur, rc, rs, seed); }
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
+KN(lm_k_restir_combine_rare)(LmFrame fr, int cur, int rc, int rs, uint32_t seed) { lm_restir_combine_body<LmExact, LM_RARE>(fr, cur, rc, rs, seed); }
 
 #if LM_INSTRUMENT
 extern "C" __global__ void lm_k_read_pushes(unsigned long long* out) { out[0] = g_lmPushes[0]; out[1] = g_lmPushes[1]; g_lmPushes[0] = 0; g_lmPushes[1] = 0; }
@@ -986,14 +1023,14 @@ static void l_path_tail(hipStream_t s, int g, LmScene sc, LmFrame fr, int inQ, c
 static void l_trace_shadow(hipStream_t s, int g, LmScene sc, LmFrame fr, const uint32_t* cnt, float tmin, int refillBelow) { hipLaunchKernelGGL(KN(lm_k_trace_shadow), LM_GRID(g), sc, fr, cnt, tmin, refillBelow); }
 static void l_fill_bags(hipStream_t s, LmScene sc, LmFrame fr, uint32_t seed, uint32_t total) { hipLaunchKernelGGL(KN(lm_k_fill_bags), LM_GRID((total + LM_BLOCK - 1) / LM_BLOCK), sc, fr, seed, total); }
 static void l_pick_primary(hipStream_t s, int tiles, LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount, int fast)
-{ if (fast) hipLaunchKernelGGL(KN(lm_k_pick_primary_fast), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount); else hipLaunchKernelGGL(KN(lm_k_pick_primary), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount); }
+{ if (fast) { hipLaunchKernelGGL(KN(lm_k_pick_primary_fast), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount); hipLaunchKernelGGL(KN(lm_k_pick_primary_rare), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount); } else hipLaunchKernelGGL(KN(lm_k_pick_primary), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount); }
 static void l_trace_shade(hipStream_t s, int g, LmScene sc, LmFrame fr, int rc, const uint32_t* cnt, int refillBelow, int pass) { hipLaunchKernelGGL(KN(lm_k_restir_trace_shade), LM_GRID(g), sc, fr, rc, cnt, refillBelow, pass); }
 static void l_temporal(hipStream_t s, int g, LmFrame fr, int cur, int prev, int rc, int rp, int rf, uint32_t seed, uint32_t* visCount, int fast)
-{ if (fast) hipLaunchKernelGGL(KN(lm_k_restir_temporal_fast), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); else hipLaunchKernelGGL(KN(lm_k_restir_temporal), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); }
+{ if (fast) { hipLaunchKernelGGL(KN(lm_k_restir_temporal_fast), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); hipLaunchKernelGGL(KN(lm_k_restir_temporal_rare), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); } else hipLaunchKernelGGL(KN(lm_k_restir_temporal), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); }
 static void l_spatial(hipStream_t s, int g, LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin, int fast)
-{ if (fast) hipLaunchKernelGGL(KN(lm_k_restir_spatial_fast), LM_GRID(g), fr, cur, rin, rout, seed, margin); else hipLaunchKernelGGL(KN(lm_k_restir_spatial), LM_GRID(g), fr, cur, rin, rout, seed, margin); }
+{ if (fast) { hipLaunchKernelGGL(KN(lm_k_restir_spatial_fast), LM_GRID(g), fr, cur, rin, rout, seed, margin); hipLaunchKernelGGL(KN(lm_k_restir_spatial_rare), LM_GRID(g), fr, cur, rin, rout, seed, margin); } else hipLaunchKernelGGL(KN(lm_k_restir_spatial), LM_GRID(g), fr, cur, rin, rout, seed, margin); }
 static void l_combine(hipStream_t s, int g, LmFrame fr, int cur, int rc, int rs, uint32_t seed, int fast)
-{ if (fast) hipLaunchKernelGGL(KN(lm_k_restir_combine_fast), LM_GRID(g), fr, cur, rc, rs, seed); else hipLaunchKernelGGL(KN(lm_k_restir_combine), LM_GRID(g), fr, cur, rc, rs, seed); }
+{ if (fast) { hipLaunchKernelGGL(KN(lm_k_restir_combine_fast), LM_GRID(g), fr, cur, rc, rs, seed); hipLaunchKernelGGL(KN(lm_k_restir_combine_rare), LM_GRID(g), fr, cur, rc, rs, seed); } else hipLaunchKernelGGL(KN(lm_k_restir_combine), LM_GRID(g), fr, cur, rc, rs, seed); }
 static void l_clear(hipStream_t s, int g, float4* p, uint32_t n) { hipLaunchKernelGGL(KN(lm_k_clear_f4), LM_GRID(g), p, n); }
 static void l_merge(hipStream_t s, int g, LmFrame fr, int blend, uint32_t blendCount, int depthMax) { hipLaunchKernelGGL(KN(lm_k_merge_output), LM_GRID(g), fr, blend, blendCount, depthMax); }
 static void l_query_any(hipStream_t s, int g, LmScene sc, const float4* o, const float4* d, uint32_t n, float tmin, uint32_t* occ, uint32_t* counters) { hipLaunchKernelGGL(KN(lm_k_query_any), LM_GRID(g), sc, o, d, n, tmin, occ, counters); }

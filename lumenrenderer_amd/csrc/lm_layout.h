@@ -118,6 +118,7 @@ struct LmFrame {
 #define LM_CNT_RAYS(d) (d)                       // rays entering wave d            [0, LM_MAX_DEPTH]
 #define LM_CNT_SHADOW(d) (32 + (d))              // NEE shadow rays emitted by wave d
 #define LM_CNT_RESTIR(p) (70 + (p))              // ReSTIR visibility rays of pass p (0, 1)
+#define LM_CNT_RARE 72                           // depth-0 surfaces with a lobe outside the contracted evaluation (lm_bsdf.h lm_quick_contracts)
 #define LM_CNT_STEP_HIST 96                       // instrumented build only: 16 log2 buckets of per-ray traversal steps (queue kernels)
 #define LM_CNT_STEP_MAX 112                       // instrumented build only: longest per-ray traversal (steps)
 #define LM_CNT_NODES 66                          // instrumented build only: child boxes slab-tested (u64 as 2 words); 2 boxes = one binary node of SURVEY 8 d4

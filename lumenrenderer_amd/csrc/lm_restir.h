@@ -44,16 +44,48 @@ __device__ __forceinline__ void lm_res_store(float4* __restrict__ hot, float4* _
 }
 
 // the receiving surface of a resampling loop
-struct LmTarget { lf3 position; LmLobes lobes; };      // lobes.N is the shading normal, lobes.wo the direction back along the camera path
+struct LmTarget {
+    lf3 position; LmLobes lobes;      // lobes.N is the shading normal, lobes.wo the direction back along the camera path
+    LmQuick quick;                    // constants of the contracted evaluation (fast policy only, dead otherwise)
+};
 template <class A> __device__ __forceinline__ void lm_target_setup(const LmSurface& px, LmTarget& t)
 {
     t.position = px.position;
     lm_lobes_setup<A>(px.mat, px.normal, px.tangent, -px.incoming, t.lobes);
+    if constexpr (A::contracted) lm_quick_setup(t.lobes, t.quick);
+}
+// Which kernel instantiation scores a receiving surface (kernels.hip runs the ReSTIR passes in up to two launches):
+//   LM_ALL     every surface, exact policy — the default mode, bit-identical to the oracle
+//   LM_COMMON  fast mode, first launch: surfaces whose lobes the contracted evaluation covers (lm_quick_contracts)
+//   LM_RARE    fast mode, second launch: the others (dielectric, clear coat, mirror-like), with the exact policy; the launch returns
+//              at once when surface extraction counted none in the frame (LM_CNT_RARE)
+enum { LM_ALL = 0, LM_COMMON = 1, LM_RARE = 2 };
+template <int ROLE> __device__ __forceinline__ bool lm_role_takes(const LmMaterial& m)
+{
+    return ROLE == LM_ALL || lm_quick_contracts(m) == (ROLE == LM_COMMON);
+}
+// fast policy: the same target function in contracted form (2 rsq + 5 rcp + 1 sqrt per light point)
+__device__ __forceinline__ void lm_score_quick(const LmLightPoint& p, const LmTarget& t, lf3& contribution, float& pdfOut)
+{
+#pragma clang fp contract(fast)
+    const lf3 d = p.position - t.position;
+    const float d2 = dot3(d, d), rinv = LmFast::rsqrt(d2);
+    const lf3 toLight = d * rinv;
+    const float cosIn = dot3(toLight, t.lobes.N), cosOut = -dot3(p.normal, toLight);
+    pdfOut = 0.f;
+    if (!(cosIn > 0.f && cosOut > 0.f && d2 * rinv > 0.01f)) return;
+    float pdf = 0.f;
+    const lf3 bsdf = lm_quick_eval(t.lobes, t.quick, toLight, cosIn, pdf);
+    const float added = pdf + bsdf.x + bsdf.y + bsdf.z;
+    if (pdf <= LM_EPSILON || added != added || fabsf(added) == u2f(0x7f800000u)) { contribution = v3(0.f); return; }
+    contribution = bsdf * (cosOut * p.area * rinv * rinv * cosIn * LmFast::rcp(pdf)) * p.radiance;
+    pdfOut = (contribution.x + contribution.y + contribution.z) * (1.0f / 3.0f);
 }
 
 // Target function: unshadowed contribution of the light point at the receiver; its mean is the resampling pdf (0 = unusable).
 template <class A> __device__ __forceinline__ void lm_score(const LmLightPoint& p, const LmTarget& t, lf3& contribution, float& pdfOut)
 {
+    if constexpr (A::contracted) { lm_score_quick(p, t, contribution, pdfOut); return; }
     lf3 toLight = p.position - t.position;
     const float dist = A::sqrt(dot3(toLight, toLight));
     toLight = lm_scale_inv<A>(toLight, dist);
@@ -83,12 +115,14 @@ template <class A> __device__ __forceinline__ void lm_res_update(LmReservoir& r,
     r.weightSum += w;
     ++r.count;
     const float rnd = lm_random_float(seed);
-    if (rnd <= A::div(w, r.weightSum)) r.s = s;
+    if constexpr (A::contracted) { if (w > 0.f && rnd * r.weightSum <= w) r.s = s; }      // rnd <= w / weightSum without the division (weightSum >= w > 0)
+    else if (rnd <= A::div(w, r.weightSum)) r.s = s;
 }
 template <class A> __device__ __forceinline__ void lm_res_update_weight(LmReservoir& r)
 {
     if (r.count == 0 || r.weightSum <= 0.f) { r.weight = 0; return; }
-    r.weight = A::rcp(fmaxf(r.s.pdf, 1.1920928955078125e-7f)) * (A::rcp((float)r.count) * r.weightSum);
+    if constexpr (A::contracted) r.weight = r.weightSum * A::rcp(fmaxf(r.s.pdf, 1.1920928955078125e-7f) * (float)r.count);
+    else r.weight = A::rcp(fmaxf(r.s.pdf, 1.1920928955078125e-7f)) * (A::rcp((float)r.count) * r.weightSum);
 }
 // CombineBiased for two reservoirs (ReSTIRKernels.cu:1200-1257)
 template <class A> __device__ __forceinline__ void lm_combine2(LmReservoir& dst, const LmReservoir& a, const LmReservoir& b, const LmTarget& t, uint32_t seed)

@@ -688,6 +688,16 @@ static bool shade_indirect(const Surface& s, uint32_t pixelIndex, uint32_t px, u
     return true;
 }
 
+// make_color — vendor/Include/Cuda/cuda/helpers.h:35-66: clamp, sRGB transfer function, quantise with x * 256 capped at 255
+static inline uint8_t srgb8(float x)
+{
+    const float in = clampf(x, 0.f, 1.f);
+    const float powed = det_powf(in, 1.0f / 2.4f);
+    float s = in < 0.0031308f ? 12.92f * in : 1.055f * powed - 0.055f;
+    s = clampf(s, 0.f, 1.f);
+    return (uint8_t)std::min((unsigned)(s * 256.f), 255u);
+}
+
 // ----------------------------------------------------------------------------------------------------------
 // ReSTIR — Shaders/CppCommon/ReSTIRData.h:115-178, CUDAKernels/ReSTIRKernels.cu
 // ----------------------------------------------------------------------------------------------------------
@@ -1149,14 +1159,8 @@ static int trace_frame(orc_ctx* c)
     c->pfor((uint32_t)pixels.size(), [&](uint32_t pb, uint32_t pe, int) { for (uint32_t pk = pb; pk < pe; pk++) {
         const uint32_t i = pixels[pk];
         const f4 cc = c->combined[i];
-        const float in[3] = {clampf(cc.x, 0.f, 1.f), clampf(cc.y, 0.f, 1.f), clampf(cc.z, 0.f, 1.f)};
-        for (int k = 0; k < 3; k++) {
-            const float powed = det_powf(in[k], 1.0f / 2.4f);
-            float s = in[k] < 0.0031308f ? 12.92f * in[k] : 1.055f * powed - 0.055f;
-            s = clampf(s, 0.f, 1.f);
-            const unsigned q = std::min((unsigned)(s * 256.f), 255u);
-            c->output[(size_t)i * 4 + k] = (uint8_t)q;
-        }
+        const float in[3] = {cc.x, cc.y, cc.z};
+        for (int k = 0; k < 3; k++) c->output[(size_t)i * 4 + k] = srgb8(in[k]);
         c->output[(size_t)i * 4 + 3] = 255;
     } });
     orc_lap("merge+output");
@@ -1318,6 +1322,33 @@ void orc_det_math(uint32_t n, int fn, const float* x, const float* y, float* out
         default: out[i] = det_powf(x[i], y[i]); break;
         }
     }
+}
+// known-answer hooks for tests/golden/ref_kat.npz rows "resv", "cdfq", "color" (oracle/ref_kat/gen_kat2.cpp)
+void orc_reservoir_sequence(uint32_t k, const float* w, const float* pdf, const uint32_t* seeds, float* weightSum, int64_t* count, int32_t* held, int32_t* took,
+                            float* weight, float* afterReset3)
+{
+    Reservoir r = res_fresh();
+    for (uint32_t i = 0; i < k; i++) {
+        LightSample s; memset(&s, 0, sizeof s); s.area = (float)(i + 1); s.solidAnglePdf = pdf[i];
+        took[i] = res_update(r, s, w[i], seeds[i]) ? 1 : 0;
+        weightSum[i] = r.weightSum; count[i] = r.sampleCount; held[i] = (int32_t)r.sample.area;
+    }
+    res_update_weight(r);
+    *weight = r.weight;
+    res_reset(r);
+    afterReset3[0] = r.weightSum; afterReset3[1] = (float)r.sampleCount; afterReset3[2] = r.weight;
+}
+void orc_cdf_get(uint32_t n, const float* data, uint32_t m, const float* values, uint32_t* index, float* pdf)
+{
+    orc_ctx* c = orc_create();
+    c->cdf.assign(data, data + n);
+    c->cdfSum = n ? data[n - 1] : 0.f;
+    for (uint32_t i = 0; i < m; i++) cdf_get(c, values[i], index[i], pdf[i]);
+    orc_destroy(c);
+}
+void orc_make_color(uint32_t n, const float* rgb, uint8_t* rgba)
+{
+    for (uint32_t i = 0; i < n; i++) { for (int k = 0; k < 3; k++) rgba[4 * i + k] = srgb8(rgb[3 * i + k]); rgba[4 * i + 3] = 255; }
 }
 uint16_t orc_f32_to_f16(float f) { return f32_to_f16(f); }
 float orc_f16_to_f32(uint16_t h) { return f16_to_f32(h); }

@@ -5,8 +5,9 @@
  * (lumenrenderer_amd/, include/) never links, imports or executes anything under oracle/.
  *
  * Parity status: the reference as a whole cannot be built or run here (CUDA 10 + OptiX 7.1 + D3D11,
- * SURVEY.md §0 F10).  The header-only parts (RNG, material packing, Disney BSDF) ARE pinned against the
- * reference's own headers through tests/golden/ref_kat.npz (generator: oracle/ref_kat/).  Everything that
+ * SURVEY.md §0 F10).  The header-only parts (RNG, material packing, Disney BSDF, Reservoir update / weight / reset,
+ * CDF::Get / BinarySearch, make_color, binary16 conversion) ARE pinned against the reference's own headers through
+ * tests/golden/ref_kat.npz (generator: oracle/ref_kat/).  Everything that
  * lives in __global__ kernels, OptiX programs or closed libraries (traversal, texture filtering, thrust
  * sort/scan order, %smid bag choice, racy fp16 accumulation) has no reference-side vectors:
  * for those stages this oracle is "parity unpinned" and is the definition the HIP path is held to.
@@ -74,6 +75,13 @@ void  orc_pack_material(const float mat[23], uint32_t params_out[3], float gette
 void  orc_eval_bsdf(uint32_t n, const float* mat23, const float* N, const float* T, const float* wo, const float* wi, float* bsdf_pdf4);
 void  orc_sample_bsdf(uint32_t n, const float* mat23, const float* N, const float* T, const float* wo, const float* r3, float* out8);
 void  orc_det_math(uint32_t n, int fn, const float* x, const float* y, float* out);  /* fn: 0 sin 1 cos 2 log 3 exp 4 pow */
+/* Reservoir::Update x k on a fresh reservoir (sample i carries id i + 1), then UpdateWeight, then Reset (ReSTIRData.h:115-178) */
+void  orc_reservoir_sequence(uint32_t k, const float* w, const float* pdf, const uint32_t* seeds, float* weightSum, int64_t* count, int32_t* held, int32_t* took,
+                             float* weight, float* afterReset3);
+/* CDF::Get / BinarySearch on a given prefix-sum array (ReSTIRData.h:230-306) */
+void  orc_cdf_get(uint32_t n, const float* data, uint32_t m, const float* values, uint32_t* index, float* pdf);
+/* make_color: sRGB8 of a linear colour (vendor/Include/Cuda/cuda/helpers.h:35-66) */
+void  orc_make_color(uint32_t n, const float* rgb, uint8_t* rgba);
 uint16_t orc_f32_to_f16(float);
 float orc_f16_to_f32(uint16_t);
 

@@ -8,14 +8,15 @@ and stores the rows as float64/uint32 arrays.  Only numbers are committed, never
 import os, subprocess, sys, numpy as np
 here = os.path.dirname(os.path.abspath(__file__))
 R = "/root/reference/Lumen_Engine/LumenPT"
-exe = "/tmp/lumen_gen_kat"
-subprocess.check_call(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-D_GNU_SOURCE", "-DNDEBUG", "-w",
-                       f"-I{R}/vendor/Include", f"-I{R}/vendor/Include/Cuda", f"-I{R}/src",
-                       os.path.join(here, "gen_kat.cpp"), "-o", exe])
 rows = {}
-for line in subprocess.check_output([exe], text=True).splitlines():
-    tag, *vals = line.split()
-    rows.setdefault(tag, []).append([float(v) for v in vals])
+for src in ("gen_kat.cpp", "gen_kat2.cpp"):        # two translation units: ReSTIRData.h needs __CUDACC__ undefined, disney.cuh needs it defined
+    exe = "/tmp/lumen_" + src[:-4]
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-D_GNU_SOURCE", "-DNDEBUG", "-w",
+                           f"-I{R}/vendor/Include", f"-I{R}/vendor/Include/Cuda", f"-I{R}/src",
+                           os.path.join(here, src), "-o", exe])
+    for line in subprocess.check_output([exe], text=True).splitlines():
+        tag, *vals = line.split()
+        rows.setdefault(tag, []).append([float(v) for v in vals])
 out = {k: np.asarray(v, dtype=np.float64) for k, v in rows.items()}
 dst = os.path.join(here, "..", "..", "tests", "golden", "ref_kat.npz")
 np.savez_compressed(dst, **out)

@@ -62,6 +62,9 @@ def lib():
             ("orc_sample_bsdf", [C.c_uint32, fp, fp, fp, fp, fp, fp], None),
             ("orc_det_math", [C.c_uint32, C.c_int, fp, fp, fp], None),
             ("orc_f32_to_f16", [C.c_float], C.c_uint16), ("orc_f16_to_f32", [C.c_uint16], C.c_float),
+            ("orc_reservoir_sequence", [C.c_uint32, fp, fp, u32p, fp, C.POINTER(C.c_int64), i32p, i32p, fp, fp], None),
+            ("orc_cdf_get", [C.c_uint32, fp, C.c_uint32, fp, u32p, fp], None),
+            ("orc_make_color", [C.c_uint32, fp, u8p], None),
             ("orc_trace_closest", [C.c_void_p, C.c_uint32, fp, fp, C.c_float, C.c_float, u32p, fp, C.c_int], None),
             ("orc_trace_any", [C.c_void_p, C.c_uint32, fp, fp, C.c_float, fp, u8p, C.c_int], None),
             ("orc_world_triangles", [C.c_void_p, fp], C.c_uint32),

@@ -547,3 +547,62 @@ def test_scene_file_round_trip(tmp_path):
     bad = tmp_path / "bad.slm"; bad.write_bytes(b"nope" + bytes(60))
     with pytest.raises(ValueError):
         read_scene_file(str(bad))
+
+
+def test_product_bsdf_header_equals_the_oracle_bit_for_bit_on_the_host(tmp_path):
+    """lumenrenderer_amd/csrc/lm_bsdf.h splits the Disney model into a per-surface setup and a per-light evaluation (the shape its
+    light loops need).  Compiled for the CPU with the exact arithmetic policy (tests/bsdf_check.cpp) it must reproduce the oracle's
+    unsplit restatement of disney.cuh bit for bit — one-shot evaluation, one setup scored against many directions, and sampling —
+    over random materials that reach every lobe and early-out (dielectric, clear coat, sheen, subsurface, anisotropy, mirror-like
+    roughness, ior == 1, grazing and below-surface directions)."""
+    import ctypes as C
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "libbsdf_check.so")
+    build = subprocess.run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-ffp-contract=off",
+                            "-I" + os.path.join(root, "lumenrenderer_amd", "csrc"), os.path.join(root, "tests", "bsdf_check.cpp"), "-o", so],
+                           capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-3000:]
+    from oracle_lib import lib as orc_lib, fptr
+    L, K = orc_lib(), C.CDLL(so)
+    FP = C.POINTER(C.c_float)
+    K.chk_eval_bsdf.argtypes = [C.c_uint32] + [FP] * 6; K.chk_eval_many.argtypes = [C.c_uint32, C.c_uint32] + [FP] * 6; K.chk_sample_bsdf.argtypes = [C.c_uint32] + [FP] * 6
+
+    def unit(v):
+        return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+
+    def same(a, b):
+        return bool(((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all())
+
+    n, k = 120000, 8
+    for seed in range(3):
+        rng = np.random.default_rng(seed)
+        mat = np.zeros((n, 23), np.float32)
+        mat[:, 0:8] = rng.uniform(0, 1, (n, 8)); mat[:, 8:11] = rng.uniform(0, 2, (n, 3))
+        mat[:, 11] = np.where(rng.uniform(size=n) < 0.05, 1.0, rng.uniform(0.4, 2.5, n))                 # ior, 5 % exactly 1
+        P = rng.uniform(0, 1, (n, 11)).astype(np.float32)       # metallic subsurface specular roughness | spectint aniso sheen sheentint | coat gloss transmission
+        for col, p0 in ((0, 0.3), (1, 0.5), (2, 0.1), (5, 0.5), (6, 0.5), (8, 0.5), (10, 0.6)):
+            P[:, col] = np.where(rng.uniform(size=n) < p0, 0.0, P[:, col])
+        P[:, 0] = np.where(rng.uniform(size=n) < 0.1, 1.0, P[:, 0]); P[:, 1] = np.where(rng.uniform(size=n) < 0.1, 1.0, P[:, 1])
+        P[:, 3] = np.where(rng.uniform(size=n) < 0.05, 0.003, P[:, 3])                                   # packs to roughness 0
+        mat[:, 12:23] = P
+        N, T = unit(rng.normal(size=(n, 3))), unit(rng.normal(size=(n, 3)))
+        wo = unit(rng.normal(size=(n, 3)) + N * rng.uniform(-0.5, 2, (n, 1))); wi = unit(rng.normal(size=(n, 3)) + N * rng.uniform(-0.5, 2, (n, 1)))
+        q = n // 50
+        wo[:q] = N[:q]; wi[q:2 * q] = N[q:2 * q]; wi[2 * q:3 * q] = wo[2 * q:3 * q]; wi[3 * q:4 * q] = -wo[3 * q:4 * q]
+        r3 = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+        want = np.zeros((n, 4), np.float32); L.orc_eval_bsdf(n, fptr(mat), fptr(N), fptr(T), fptr(wo), fptr(wi), fptr(want))
+        got = np.zeros((n, 4), np.float32); K.chk_eval_bsdf(n, fptr(mat), fptr(N), fptr(T), fptr(wo), fptr(wi), fptr(got))
+        assert same(got, want), seed
+        assert (want[:, 3] > 0).sum() > 0.8 * n                  # the comparison is not one of zeros
+        n2 = n // k
+        wim = np.ascontiguousarray(wi[:n2 * k].reshape(n2, k, 3))
+        want = np.zeros((n2, k, 4), np.float32)
+        for j in range(k):
+            tmp = np.zeros((n2, 4), np.float32); wj = np.ascontiguousarray(wim[:, j])
+            L.orc_eval_bsdf(n2, fptr(mat[:n2]), fptr(N[:n2]), fptr(T[:n2]), fptr(wo[:n2]), fptr(wj), fptr(tmp)); want[:, j] = tmp
+        got = np.zeros((n2, k, 4), np.float32); K.chk_eval_many(n2, k, fptr(mat[:n2]), fptr(N[:n2]), fptr(T[:n2]), fptr(wo[:n2]), fptr(wim), fptr(got))
+        assert same(got, want), seed
+        want = np.zeros((n, 8), np.float32); L.orc_sample_bsdf(n, fptr(mat), fptr(N), fptr(T), fptr(wo), fptr(r3), fptr(want))
+        got = np.zeros((n, 8), np.float32); K.chk_sample_bsdf(n, fptr(mat), fptr(N), fptr(T), fptr(wo), fptr(r3), fptr(got))
+        assert same(got, want), seed
+        assert want[:, 7].sum() > 0.1 * n and (want[:, 6] > 0).sum() > 0.8 * n

@@ -93,3 +93,85 @@ def test_half_conversion_round_trip():
     want = xs.astype(np.float16).view(np.uint16)
     got = np.array([L.orc_f32_to_f16(float(x)) for x in xs], dtype=np.uint16)
     assert np.array_equal(got, want)
+
+
+def _bits_to_f32(col):
+    return np.asarray(col, np.float64).astype(np.uint32).view(np.float32)
+
+
+def kat_reservoir_rows():
+    """rows 'resv' -> (w[8], pdf[8], seeds[8]) and the expected (weightSum bits, count, held id, took) per update, weight bits, reset state"""
+    g = GOLD["resv"]
+    ins = g[:, :24].reshape(-1, 8, 3)
+    w, pdf, seeds = _bits_to_f32(ins[:, :, 0]), _bits_to_f32(ins[:, :, 1]), ins[:, :, 2].astype(np.uint32)
+    per = g[:, 24:56].reshape(-1, 8, 4)
+    return w, pdf, seeds, per[:, :, 0].astype(np.uint32), per[:, :, 1].astype(np.int64), per[:, :, 2].astype(np.int32), per[:, :, 3].astype(np.int32), g[:, 56].astype(np.uint32), g[:, 57:61]
+
+
+def test_reservoir_update_weight_reset_match_reference_header_bit_for_bit():
+    """Reservoir::Update / UpdateWeight / Reset of ReSTIRData.h:115-178, compiled from the reference header (gen_kat2.cpp): running
+    weight sum, sample count, WHICH sample the reservoir holds after every update (the `r <= w / weightSum` decision, seed by value),
+    the final weight with the MINFLOAT clamp, and the state after Reset."""
+    L = lib()
+    w, pdf, seeds, ws, cnt, held, took, weight, reset = kat_reservoir_rows()
+    from ctypes import c_int64, POINTER
+    for i in range(w.shape[0]):
+        o_ws = np.zeros(8, np.float32); o_cnt = np.zeros(8, np.int64); o_held = np.zeros(8, np.int32); o_took = np.zeros(8, np.int32)
+        o_w = np.zeros(1, np.float32); o_reset = np.zeros(3, np.float32)
+        wi, pi, si = np.ascontiguousarray(w[i]), np.ascontiguousarray(pdf[i]), np.ascontiguousarray(seeds[i])
+        L.orc_reservoir_sequence(8, fptr(wi), fptr(pi), u32ptr(si), fptr(o_ws), o_cnt.ctypes.data_as(POINTER(c_int64)),
+                                 o_held.ctypes.data_as(POINTER(__import__("ctypes").c_int32)), o_took.ctypes.data_as(POINTER(__import__("ctypes").c_int32)), fptr(o_w), fptr(o_reset))
+        assert np.array_equal(o_ws.view(np.uint32), ws[i]) and np.array_equal(o_cnt, cnt[i]), i
+        assert np.array_equal(o_held, held[i]) and np.array_equal(o_took, took[i]), i
+        assert o_w.view(np.uint32)[0] == weight[i], i
+        assert o_reset.tolist() == [0.0, 0.0, 0.0] and reset[i, :3].tolist() == [0.0, 0.0, 0.0]
+    assert 0 < took.mean() < 1 and len(np.unique(held[:, -1])) > 4          # the vectors exercise both outcomes of the decision
+
+
+def kat_cdf_cases():
+    gw, gq = GOLD["cdfw"], GOLD["cdfq"]
+    for row in gw:
+        cid, n = int(row[0]), int(row[1])
+        data = _bits_to_f32(row[2:2 + n])
+        q = gq[gq[:, 0] == cid]
+        yield cid, data, _bits_to_f32(q[:, 1]), q[:, 2].astype(np.uint32), q[:, 3].astype(np.uint32)
+
+
+def test_cdf_get_matches_reference_header_bit_for_bit():
+    """CDF::Get + BinarySearch of ReSTIRData.h:230-306 on prefix sums accumulated by CDF::Insert: sizes 1..64, uniform / ramp / random
+    weights, queries at 0, 1 and exactly on element boundaries."""
+    L = lib(); cases = 0
+    for cid, data, values, idx, pdfbits in kat_cdf_cases():
+        oi = np.zeros(values.size, np.uint32); op = np.zeros(values.size, np.float32)
+        d, v = np.ascontiguousarray(data), np.ascontiguousarray(values)
+        L.orc_cdf_get(d.size, fptr(d), v.size, fptr(v), u32ptr(oi), fptr(op))
+        assert np.array_equal(oi, idx), (cid, np.flatnonzero(oi != idx)[:5])
+        assert np.array_equal(op.view(np.uint32), pdfbits), cid
+        cases += 1
+    assert cases == 48
+
+
+def test_make_color_matches_reference_header():
+    """make_color (vendor/Include/Cuda/cuda/helpers.h:35-66: clamp, sRGB transfer, x * 256 capped at 255) on 9 000 channel values incl.
+    the neighbourhood of the 0.0031308 switch and out-of-range inputs.  The reference calls libm powf, the oracle its fixed polynomial
+    pow (<= 4e-7 relative): a value within that distance of a quantisation step may land on the other side — at most 1 step, rarely."""
+    L = lib(); g = GOLD["color"]
+    rgb = np.ascontiguousarray(np.stack([_bits_to_f32(g[:, k]) for k in range(3)], axis=1))
+    out = np.zeros((g.shape[0], 4), np.uint8)
+    L.orc_make_color(g.shape[0], fptr(rgb), out.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_uint8)))
+    ref = g[:, 3:7].astype(np.int32)
+    diff = np.abs(out.astype(np.int32) - ref)
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-3, (diff.max(), (diff > 0).mean())
+    assert (out[:, 3] == 255).all() and len(np.unique(ref[:, :3])) > 200
+
+
+def test_binary16_conversion_matches_the_vendored_cuda_header_bit_for_bit():
+    """__float2half / __half2float as the reference's vendored cuda_fp16.hpp defines them on the host (what half4's constructors and
+    AsFloat4 call, Half4.h:9-96; hit barycentrics and motion vectors are stored this way): round to nearest even incl. exact ties,
+    subnormals, underflow, overflow to infinity."""
+    L = lib(); g = GOLD["half"]
+    f = _bits_to_f32(g[:, 0]); hb = g[:, 1].astype(np.uint16); back = g[:, 2].astype(np.uint32)
+    got = np.array([L.orc_f32_to_f16(float(x)) for x in f], np.uint16)
+    assert np.array_equal(got, hb), np.flatnonzero(got != hb)[:5]
+    got_back = np.array([L.orc_f16_to_f32(int(h)) for h in hb], np.float32)
+    assert np.array_equal(got_back.view(np.uint32), back)

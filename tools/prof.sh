@@ -2,8 +2,11 @@
 # usage (on the GPU box, from the repo root): bash tools/prof.sh <tag>  — parity tests, bench line, rocprofv3 kernel stats
 tag=${1:-x}
 mkdir -p gpurun_out/$tag
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 > gpurun_out/$tag/pytest.log
+# SKIP_TESTS=1: profile only (e.g. with LUMEN_MI_FAST_RESAMPLE=1 exported, which the bit-exact suite must not run under)
+if [ -z "$SKIP_TESTS" ]; then
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 > gpurun_out/$tag/pytest.log
 if ! grep -q " passed" gpurun_out/$tag/pytest.log || grep -q "failed\|error\|Aborted\|dumped" gpurun_out/$tag/pytest.log; then echo "PARITY TESTS FAILED"; cat gpurun_out/$tag/pytest.log; exit 1; fi
+else echo "tests skipped" > gpurun_out/$tag/pytest.log; fi
 timeout 600 python bench.py --steps 5 --warmup 1 --no-cpu-baseline $BENCH_ARGS > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err
 R=$PWD
 cd /tmp && export TMPDIR=/tmp GPU_MAX_HW_QUEUES=8 && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$tag/prof -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline $BENCH_ARGS > $R/gpurun_out/$tag/prof.log 2>&1
