@@ -182,6 +182,11 @@ int lumen_mi_query_any(lumen_mi_renderer*, uint32_t n, const float* origins3, co
 /* ---- known-answer hooks: run the device BSDF / math on host arrays */
 int lumen_mi_test_bsdf(lumen_mi_renderer*, uint32_t n, int mode, const float* mat23, const float* N, const float* T, const float* wo, const float* aux3, float* out8);
 int lumen_mi_test_math(lumen_mi_renderer*, uint32_t n, int fn, const float* x, const float* y, float* out);
+/* Known-answer hook for the device-side Reservoir::Update / UpdateWeight (ReSTIRData.h:115-163), CDF::Get (ReSTIRData.h:230-306) and
+ * make_color (vendor/Include/Cuda/cuda/helpers.h:35-66).  mode 0: n sequences of 8 updates, a = weights, b = pdfs, c = seeds (8 n each),
+ * out[33 n] = per update (weightSum, sampleCount, id held, taken), then the weight; mode 1: a = n prefix sums, b = m values, out[2 m] =
+ * (index bits, pdf); mode 2: a = n linear values, out[n] = sRGB8 levels. */
+int lumen_mi_test_restir(lumen_mi_renderer*, int mode, uint32_t n, const float* a, const float* b, const uint32_t* c, uint32_t m, float* out);
 /* host-side scene products, for tests: world-space triangles (9 floats each) and the sorted light list (16 floats each) + CDF */
 int lumen_mi_get_world_triangles(lumen_mi_renderer*, float* out, uint32_t capacity_triangles, uint32_t* count);
 int lumen_mi_get_lights(lumen_mi_renderer*, float* lights16, float* cdf, uint32_t capacity, uint32_t* count);

@@ -739,6 +739,16 @@ KN(lm_k_clear_f4)(float4* __restrict__ p, uint32_t n)
     for (uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x; i < n; i += stride) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// make_color (vendor/Include/Cuda/cuda/helpers.h:35-66): clamp, sRGB transfer function, quantise as x * 256 capped at 255
+__device__ __forceinline__ uint32_t lm_srgb8(float x)
+{
+    const float in = clampf(x, 0.f, 1.f);
+    const float powed = lm_powf(in, 1.0f / 2.4f);
+    float sv = in < 0.0031308f ? 12.92f * in : 1.055f * powed - 0.055f;
+    sv = clampf(sv, 0.f, 1.f);
+    const uint32_t v = (uint32_t)(sv * 256.f);
+    return v < 255u ? v : 255u;
+}
 // K13 + K14: channel merge with optional running-mean blend (GPUMergeOutputChannels.cu:5-88, fp32) and sRGB8 output
 // (GPUShadingKernels.cu:28-56, vendor/Include/Cuda/cuda/helpers.h:35-66)
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
@@ -763,16 +773,7 @@ KN(lm_k_merge_output)(LmFrame fr, int blend, uint32_t blendCount, int depthMax)
             c = make_float4(s.x / k1, s.y / k1, s.z / k1, s.w / k1);
         } else c = m;
         fr.combined[li] = c;
-        const float in[3] = {clampf(c.x, 0.f, 1.f), clampf(c.y, 0.f, 1.f), clampf(c.z, 0.f, 1.f)};
-        uint32_t q[3];
-        for (int k = 0; k < 3; k++) {
-            const float powed = lm_powf(in[k], 1.0f / 2.4f);
-            float sv = in[k] < 0.0031308f ? 12.92f * in[k] : 1.055f * powed - 0.055f;
-            sv = clampf(sv, 0.f, 1.f);
-            const uint32_t v = (uint32_t)(sv * 256.f);
-            q[k] = v < 255u ? v : 255u;
-        }
-        fr.output[li] = make_uchar4((unsigned char)q[0], (unsigned char)q[1], (unsigned char)q[2], 255);
+        fr.output[li] = make_uchar4((unsigned char)lm_srgb8(c.x), (unsigned char)lm_srgb8(c.y), (unsigned char)lm_srgb8(c.z), 255);
     }
 }
 
@@ -824,6 +825,38 @@ KN(lm_k_test_bsdf)(uint32_t n, int mode, const float* __restrict__ mat, const fl
         float pdf = 0.f; bool spec = false; lf3 wi = v3(0.f);
         const lf3 b = lm_sample_bsdf(sd, n3, n3, t3, wo3, 1.f, aux[3*i], aux[3*i+1], aux[3*i+2], wi, pdf, spec);
         out[8*i] = b.x; out[8*i+1] = b.y; out[8*i+2] = b.z; out[8*i+3] = wi.x; out[8*i+4] = wi.y; out[8*i+5] = wi.z; out[8*i+6] = pdf; out[8*i+7] = spec ? 1.f : 0.f;
+    }
+}
+// known-answer hook for the reservoir / CDF / output-quantisation functions (tests/golden/ref_kat.npz rows resv, cdfq, color):
+//   mode 0  n sequences of 8 Reservoir updates: a = weights, b = solid-angle pdfs, c = seeds (n * 8 each);
+//           out[33 * i + 4 * k ..] = (weightSum, sampleCount, id of the held sample, taken) after update k, out[33 * i + 32] = weight
+//   mode 1  a = prefix sums of n weights, b = m query values; out[2 * j] = index bits, out[2 * j + 1] = pdf
+//   mode 2  a = n linear values; out[j] = sRGB8 level
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_test_restir)(int mode, uint32_t n, const float* __restrict__ a, const float* __restrict__ b, const uint32_t* __restrict__ c, uint32_t m, float* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x;
+    if (mode == 0) {
+        if (i >= n) return;
+        LmReservoir r; lm_res_fresh(r);
+        for (uint32_t k = 0; k < 8u; k++) {
+            LmSample s; lm_sample_zero(s); s.p.area = (float)(k + 1u); s.pdf = b[8u * i + k];
+            const bool took = lm_res_update<LmExact>(r, s, a[8u * i + k], c[8u * i + k]);
+            float* o = out + 33u * i + 4u * k;
+            o[0] = r.weightSum; o[1] = (float)r.count; o[2] = r.s.p.area; o[3] = took ? 1.f : 0.f;
+        }
+        lm_res_update_weight<LmExact>(r);
+        out[33u * i + 32u] = r.weight;
+    } else if (mode == 1) {
+        if (i >= m) return;
+        LmScene sc{};
+        sc.cdf = a; sc.numLights = n; sc.cdfSum = a[n - 1u];
+        uint32_t idx; float pdf;
+        lm_cdf_get(sc, b[i], idx, pdf);
+        out[2u * i] = u2f(idx); out[2u * i + 1u] = pdf;
+    } else {
+        if (i >= n) return;
+        out[i] = (float)lm_srgb8(a[i]);
     }
 }
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
@@ -1042,6 +1075,8 @@ static void l_refit_quant(hipStream_t s, uint32_t* bounds, float* quant) { hipLa
 static void l_refit_level(hipStream_t s, LmScene sc, const uint32_t* levelNodes, uint32_t count, const float4* triBox, float4* nodeBox) { hipLaunchKernelGGL(KN(lm_k_refit_level), LM_GRID((count + LM_BLOCK - 1) / LM_BLOCK), sc, levelNodes, count, triBox, nodeBox); }
 static void l_test_bsdf(hipStream_t s, uint32_t n, int mode, const float* mat, const float* N, const float* T, const float* wo, const float* aux, float* out)
 { hipLaunchKernelGGL(KN(lm_k_test_bsdf), LM_GRID((n + LM_BLOCK - 1) / LM_BLOCK), n, mode, mat, N, T, wo, aux, out); }
+static void l_test_restir(hipStream_t s, int mode, uint32_t n, const float* a, const float* b, const uint32_t* c, uint32_t m, float* out)
+{ const uint32_t t = mode == 1 ? m : n; hipLaunchKernelGGL(KN(lm_k_test_restir), LM_GRID((t + LM_BLOCK - 1) / LM_BLOCK), mode, n, a, b, c, m, out); }
 static void l_test_math(hipStream_t s, uint32_t n, int fn, const float* x, const float* y, float* out) { hipLaunchKernelGGL(KN(lm_k_test_math), LM_GRID((n + LM_BLOCK - 1) / LM_BLOCK), n, fn, x, y, out); }
 static void l_history_copy(hipStream_t s, int g, LmFrame fr, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, float4* buf, int import)
 { hipLaunchKernelGGL(KN(lm_k_history_copy), LM_GRID(g), fr, x0, y0, w, h, buf, import); }
@@ -1055,6 +1090,6 @@ extern "C" const LmKernelTable* lm_kernel_table()
 #endif
 {
     static const LmKernelTable t = {l_primary, l_trace_closest, l_extract0, l_shade_wave, l_trace_shadow, l_path_tail, l_fill_bags, l_pick_primary,
-                                    l_trace_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_export_aux, l_refit_tris, l_refit_quant, l_refit_level, l_test_bsdf, l_test_math, l_spin, l_history_copy, l_wave_sync};
+                                    l_trace_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_export_aux, l_refit_tris, l_refit_quant, l_refit_level, l_test_bsdf, l_test_math, l_spin, l_history_copy, l_wave_sync, l_test_restir};
     return &t;
 }

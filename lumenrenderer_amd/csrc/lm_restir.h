@@ -110,13 +110,16 @@ template <class A> __device__ __forceinline__ void lm_resample(const LmSample& i
 }
 
 // streaming weighted reservoir update (Reservoir::Update: the seed arrives BY VALUE, so every update of one merge draws the same number)
-template <class A> __device__ __forceinline__ void lm_res_update(LmReservoir& r, const LmSample& s, float w, uint32_t seed)
+template <class A> __device__ __forceinline__ bool lm_res_update(LmReservoir& r, const LmSample& s, float w, uint32_t seed)
 {
     r.weightSum += w;
     ++r.count;
     const float rnd = lm_random_float(seed);
-    if constexpr (A::contracted) { if (w > 0.f && rnd * r.weightSum <= w) r.s = s; }      // rnd <= w / weightSum without the division (weightSum >= w > 0)
-    else if (rnd <= A::div(w, r.weightSum)) r.s = s;
+    bool take;
+    if constexpr (A::contracted) take = w > 0.f && rnd * r.weightSum <= w;      // rnd <= w / weightSum without the division (weightSum >= w > 0)
+    else take = rnd <= A::div(w, r.weightSum);
+    if (take) r.s = s;
+    return take;
 }
 template <class A> __device__ __forceinline__ void lm_res_update_weight(LmReservoir& r)
 {

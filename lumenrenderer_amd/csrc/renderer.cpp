@@ -665,6 +665,24 @@ int lumen_mi_test_bsdf(lumen_mi_renderer* r, uint32_t n, int mode, const float* 
     dm.release(); dn.release(); dt.release(); dw.release(); da.release(); dout.release();
     return 0;
 }
+int lumen_mi_test_restir(lumen_mi_renderer* r, int mode, uint32_t n, const float* a, const float* b, const uint32_t* c, uint32_t m, float* out)
+{
+    if (!r || !r->initialised) return fail(LUMEN_MI_ERR_STATE, "not initialised");
+    if (mode < 0 || mode > 2 || !a || !out || n == 0 || (mode == 0 && (!b || !c)) || (mode == 1 && (!b || m == 0))) return fail(LUMEN_MI_ERR_INVALID, "bad argument");
+    LM_HIP(hipSetDevice(r->device));
+    const size_t na = mode == 0 ? (size_t)8 * n : n, nb = mode == 0 ? (size_t)8 * n : mode == 1 ? m : 0, nc = mode == 0 ? (size_t)8 * n : 0;
+    const size_t nout = mode == 0 ? (size_t)33 * n : mode == 1 ? (size_t)2 * m : n;
+    DevBuf<float> da, db, dout; DevBuf<uint32_t> dc;
+    std::vector<float> va(a, a + na), vb; std::vector<uint32_t> vc;
+    if (nb) vb.assign(b, b + nb);
+    if (nc) vc.assign(c, c + nc);
+    if (da.upload(va, r->stream) || db.upload(vb, r->stream) || dc.upload(vc, r->stream) || dout.ensure(nout)) return fail(LUMEN_MI_ERR_DEVICE, "allocation failed");
+    r->K->test_restir(r->stream, mode, n, da.p, db.p, dc.p, m, dout.p);
+    LM_HIP(hipStreamSynchronize(r->stream));
+    LM_HIP(hipMemcpy(out, dout.p, nout * 4, hipMemcpyDeviceToHost));
+    da.release(); db.release(); dc.release(); dout.release();
+    return 0;
+}
 int lumen_mi_test_math(lumen_mi_renderer* r, uint32_t n, int fn, const float* x, const float* y, float* out)
 {
     if (!r || !r->initialised) return fail(LUMEN_MI_ERR_STATE, "not initialised");

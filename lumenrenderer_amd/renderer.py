@@ -287,6 +287,16 @@ class LumenRendererMI:
         check(self.lib, self.lib.lumen_mi_test_bsdf(self.h, m.shape[0], mode, _fp(m), _fp(n_), _fp(t), _fp(w), _fp(a), _fp(out)))
         return out
 
+    def TestRestir(self, mode, a, b=None, c=None):
+        """Known-answer hook (lumen_mi_test_restir): 0 reservoir sequences (a, b, c: n x 8), 1 CDF queries (a: prefix sums, b: values), 2 sRGB8."""
+        a = _f32(a); n = a.shape[0] if mode == 0 else a.size
+        b = None if b is None else _f32(b); m = 0 if (b is None or mode != 1) else b.size
+        c = None if c is None else np.ascontiguousarray(c, np.uint32)
+        out = np.zeros(33 * n if mode == 0 else 2 * m if mode == 1 else n, np.float32)
+        check(self.lib, self.lib.lumen_mi_test_restir(self.h, mode, n, _fp(a), None if b is None else _fp(b),
+                                                      None if c is None else c.ctypes.data_as(C.POINTER(C.c_uint32)), m, _fp(out)))
+        return out
+
     def TestMath(self, fn, x, y=None):
         x = _f32(x).ravel(); y = x if y is None else _f32(y).ravel(); out = np.zeros_like(x)
         check(self.lib, self.lib.lumen_mi_test_math(self.h, x.size, fn, _fp(x), _fp(y), _fp(out)))
