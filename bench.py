@@ -19,6 +19,10 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+# fp32 vector issue peak in lane-operations: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-ops/s.  The 157.3 TFLOPS spec line of the
+# guide is this x 2 (FMA) x 2 (packed v_pk_fma_f32); a kernel of unpacked, mostly non-FMA fp32 arithmetic is bounded by the lane-op rate.
+VALU_PEAK_TLANEOPS = 39.3216
+PMC_FILE = os.path.join("profiles", "r02_c2_pmc.json")      # tools/pmc_json.sh on the GPU box; replayed here, never measured by this run
 
 WORKLOADS = {
     # name: (scene factory kwargs, width, height, depth, spp)
@@ -40,7 +44,9 @@ def make_scene(kind, kw):
 
 
 def algorithmic_bytes_closest(rays, nodes, tris):
-    """closest-hit launch = 56 B/ray (read 40 + write 16) + 64 B per BVH2 node visited + 48 B per Woop packet tested."""
+    """Closest-hit launch: 56 B/ray (read 40 + write 16) + 64 B per node record fetched + 48 B per Woop packet tested.
+    `nodes` = 64-byte 4-wide node records the traversal really fetches (16.5 per ray on C2).  SURVEY d4 prices a BINARY node at 64 B;
+    the same visits expressed in binary nodes are twice as many (two child boxes each), which is the figure `*_d4` fields carry."""
     return 56.0 * rays + 64.0 * nodes + 48.0 * tris
 
 
@@ -62,14 +68,14 @@ def algorithmic_bytes_traceframe(c, depth, npix, nodes_all, tris_all, blend=True
     return b
 
 
-def load_traffic():
-    """HBM bytes per launch from PMC counters (separate rocprofv3 --pmc passes, tools/traffic.sh); None when not measured."""
-    path = os.path.join(ROOT, "profiles", "r01_c2_hbm_traffic_pmc.json")
+def load_pmc():
+    """Per-kernel PMC figures (separate rocprofv3 --pmc passes of tools/pmc_json.sh, corrected as MI355X_MICROARCH.md prescribes), taken
+    on the GPU box by the builder and committed under profiles/: a REPLAY of that measurement, not a measurement of this run."""
     try:
-        with open(path) as f:
-            return json.load(f)
-    except OSError:
-        return None
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
+            return json.load(f).get("kernels", {})
+    except (OSError, ValueError):
+        return {}
 
 
 def cpu_baseline(kind, kw, depth, spp, full):
@@ -113,6 +119,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["fast", "exact"], default="fast",
+                    help="arithmetic of the ReSTIR target function for the headline number: 'fast' = hardware rcp / rsq / sqrt + contracted "
+                         "evaluation (tuning key fast_resample; held to 1e-3 rel-L2 against the oracle by tests/test_gpu_parity.py, measured 1e-8), "
+                         "'exact' = correctly rounded, bit-identical to the oracle")
+    ap.add_argument("--no-exact", action="store_true", help="skip the second timed pass in exact mode (reported beside the headline)")
     ap.add_argument("--exact-seams", choices=["auto", "on", "off"], default="auto",
                     help="multi-GPU: exchange the halo rings' reservoir history (and the executed-wave count) after every TraceFrame; "
                          "auto = only for path depths that have temporal history (odd number of waves per frame)")
@@ -171,15 +182,25 @@ def main():
     exact = args.exact_seams == "on" or (args.exact_seams == "auto" and tiles.history_needed(depth))
     hx = tiles.HistoryExchange(r, rank, world, W, H, dev) if (world > 1 and exact) else None
 
-    def frame():
+    ev_log = []                                           # per step: torch events around render / seam exchange / gather (multi-GPU explainers)
+
+    def frame(record=False):
         r.SetBlendMode(True)                              # a fresh 4-spp accumulation per displayed frame
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if record else None
+        if record:
+            evs[0].record()
         for _ in range(spp):
             r.TraceFrameAsync()
             if hx is not None:
                 hx.run(dist)
         r.CopyRadianceToDevice(window_buf.data_ptr())
+        if record:
+            evs[1].record()
         local = window_buf[tile[1] - win[1]: tile[3] - win[1], tile[0] - win[0]: tile[2] - win[0]]
-        return local if emu else tiles.gather_tiles(local, rank, world, W, H, dist)
+        out = local if emu else tiles.gather_tiles(local, rank, world, W, H, dist)
+        if record:
+            evs[2].record(); ev_log.append(evs)
+        return out
 
     def barrier():
         torch.cuda.synchronize()
@@ -191,82 +212,121 @@ def main():
     r.SetInstrumented(True)
     r.SetBlendMode(True)
     r.TraceFrame()
-    ci = r.GetCounters()
-    nodes_per_ray = ci[20] / max(1, ci[0] + ci[1] + ci[2])
-    tris_per_ray = ci[21] / max(1, ci[0] + ci[1] + ci[2])
+    ci = r.GetCounters(50)
+    # 64-byte node records fetched: lane-level node steps of the queue traversal kernels (counter 41); child boxes tested / 4 where the
+    # counting build ran the path tail instead (its steps are not in counter 41)
+    node_records = float(ci[41]) if ci[41] > 0 else ci[22] / 4.0
     r.SetInstrumented(False)
 
-    for _ in range(args.warmup):
-        frame()
-    r.EnableKernelTiming(True)
-    barrier()
-    t0 = time.perf_counter()
-    rays_total = 0
-    closest_ms, closest_launches, closest_rays, shadow_ms, shade_ms, restir_ms = 0.0, 0, 0, 0.0, 0.0, 0.0
-    img = None
-    for _ in range(args.steps):
-        img = frame()
-    barrier()
-    dt = time.perf_counter() - t0
-    r.EnableKernelTiming(False)
-    # counters of the LAST TraceFrame (every TraceFrame of a step traces the same number of rays to within RNG noise);
-    # kernel times are HIP-event sums over the whole timed region, on the stream the kernels were launched on
-    c = r.GetCounters(50)
-    rays_last = c[0] + c[1] + c[2]
-    closest_ms, closest_launches = r.GetKernelTime(0)
-    shadow_ms, _ = r.GetKernelTime(1)
-    shade_ms, _ = r.GetKernelTime(2)
-    restir_ms, _ = r.GetKernelTime(3)
-    total_ms, n_traceframes = r.GetKernelTime(4)
-    n_traceframes = max(1, n_traceframes)
-
-    # a rank's counters include the rays of its halo pixels; those are redundant work (the neighbour owns the pixels), so
-    # only the tile's share is counted: rays scale with pixels to within RNG noise
-    tile_share = ((tile[2] - tile[0]) * (tile[3] - tile[1])) / float(ww * wh)
-    # primary rays and the first ReSTIR visibility pass cover the whole window (scaled to the tile); indirect waves, NEE and
-    # the second visibility pass only run for tile pixels already (lumen_mi_set_tile)
-    rays_tile = (c[4] + c[48]) * tile_share + (c[0] - c[4]) + c[1] + c[49] if (world > 1 or emu) else float(rays_last)
-    stats = torch.tensor([dt, float(rays_tile)], dtype=torch.float64, device=dev)
-    if world > 1:
-        tmax = stats.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = stats.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt = float(tmax[0]); rays_last_all = float(tsum[1])
-    else:
-        rays_last_all = float(rays_tile)
-    if rank == 0:
-        # rays/frame: the spp TraceFrame()s of one step trace (to within RNG noise) the same number of rays each
-        rays_per_frame = rays_last_all * spp
+    def timed_pass(fast):
+        """W warm-up steps, then exactly K steps between barriers; returns the per-rank measurements of the pass."""
+        r.SetTuning("fast_resample", 1 if fast else 0)
+        del ev_log[:]
+        for _ in range(args.warmup):
+            frame()
+        r.EnableKernelTiming(True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            frame(record=world > 1)
+        barrier()
+        dt = time.perf_counter() - t0
+        r.EnableKernelTiming(False)
+        # counters of the LAST TraceFrame (every TraceFrame of a step traces the same number of rays to within RNG noise);
+        # kernel times are HIP-event sums over the whole timed region, on the stream the kernels were launched on
+        c = r.GetCounters(50)
+        k = {name: r.GetKernelTime(i) for i, name in enumerate(("closest", "shadow", "shade", "restir", "total"))}
+        n_tf = max(1, k["total"][1])
+        # a rank's counters include the rays of its halo pixels; those are redundant work (the neighbour owns the pixels), so only the
+        # tile's share is counted: primary rays and the first ReSTIR visibility pass cover the whole window (scaled to the tile);
+        # indirect waves, NEE and the second visibility pass only run for tile pixels already (lumen_mi_set_tile)
+        tile_share = ((tile[2] - tile[0]) * (tile[3] - tile[1])) / float(ww * wh)
+        rays_tile = (c[4] + c[48]) * tile_share + (c[0] - c[4]) + c[1] + c[49] if (world > 1 or emu) else float(c[0] + c[1] + c[2])
+        render_ms = sum(e[0].elapsed_time(e[1]) for e in ev_log) / max(1, len(ev_log)) if ev_log else None
+        gather_ms = sum(e[1].elapsed_time(e[2]) for e in ev_log) / max(1, len(ev_log)) if ev_log else None
+        stats = torch.tensor([dt, float(rays_tile), render_ms or 0.0, gather_ms or 0.0], dtype=torch.float64, device=dev)
+        per_rank = None
+        if world > 1:
+            allst = [torch.zeros_like(stats) for _ in range(world)]
+            dist.all_gather(allst, stats)
+            dt = max(float(t[0]) for t in allst); rays_all = sum(float(t[1]) for t in allst)
+            per_rank = [{"rank": i, "wall_ms_per_step": round(float(t[0]) * 1e3 / args.steps, 3), "render_ms_per_step": round(float(t[2]), 3),
+                         "gather_ms_per_step": round(float(t[3]), 3)} for i, t in enumerate(allst)]
+        else:
+            rays_all = float(rays_tile)
         ms_per_step = dt * 1e3 / args.steps
-        value = rays_per_frame / (ms_per_step * 1e-3) / 1e6
-        # roofline of the dominant kernel (closest-hit traversal) on rank 0: algorithmic bytes / measured device time
-        nodes_c = ci[20] * (c[0] / max(1, ci[0] + ci[1] + ci[2]))       # share of instrumented counts attributed to closest-hit rays
-        tris_c = ci[21] * (c[0] / max(1, ci[0] + ci[1] + ci[2]))
-        alg = algorithmic_bytes_closest(c[0], nodes_c, tris_c)              # per TraceFrame (all `depth` closest-hit launches)
-        launches_per_tf = closest_launches / n_traceframes
+        return {"dt": dt, "ms_per_step": ms_per_step, "rays_per_frame": rays_all * spp, "value": rays_all * spp / (ms_per_step * 1e-3) / 1e6,
+                "counters": c, "kernel_ms": k, "n_traceframes": n_tf, "per_rank": per_rank}
+
+    fast = args.mode == "fast"
+    main_pass = timed_pass(fast)
+    other_pass = None if (args.no_exact or world > 1 or emu) else timed_pass(not fast)
+    if rank == 0:
+        c, k, n_tf = main_pass["counters"], main_pass["kernel_ms"], main_pass["n_traceframes"]
+        ms_per_step, value, rays_per_frame = main_pass["ms_per_step"], main_pass["value"], main_pass["rays_per_frame"]
+        all_rays_inst = max(1, ci[0] + ci[1] + ci[2])
+        # ---- roofline of the dominant kernel by device time (closest-hit traversal: 6 launches per TraceFrame)
+        closest_ms, closest_launches = k["closest"]
+        nodes4_c = node_records * (c[0] / all_rays_inst)                    # 64-byte node records fetched, closest-hit share
+        tris_c = ci[21] * (c[0] / all_rays_inst)
+        alg = algorithmic_bytes_closest(c[0], nodes4_c, tris_c)             # per TraceFrame (all `depth` closest-hit launches)
+        alg_d4 = algorithmic_bytes_closest(c[0], 2.0 * nodes4_c, tris_c)    # the same visits priced as binary nodes (SURVEY d4 wording)
+        launches_per_tf = closest_launches / n_tf
         per_launch_ms = closest_ms / max(1, closest_launches)
-        achieved = (alg / max(1.0, launches_per_tf)) / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
-        traffic = load_traffic() if args.workload == "c2" and world == 1 else None
-        traffic_closest = traffic.get("lm_k_trace_closest", {}).get("hbm_bytes_per_launch_corrected") if traffic else None
-        alg_tf = algorithmic_bytes_traceframe(c, depth, (win[2] - win[0]) * (win[3] - win[1]), ci[20], ci[21])
+        gbs = lambda bytes_per_tf: (bytes_per_tf / max(1.0, launches_per_tf)) / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        achieved = gbs(alg)
+        pmc = load_pmc() if args.workload == "c2" and world == 1 and not emu else {}
+        pk = lambda name, key: pmc.get(name, {}).get(key)
+        traffic_closest = pk("lm_k_trace_closest", "hbm_bytes_per_launch_corrected")
+        npix = (win[2] - win[0]) * (win[3] - win[1])
+        alg_tf = algorithmic_bytes_traceframe(c, depth, npix, ci[20], ci[21])
+        # whole-frame HBM traffic from the PMC replay: sum over kernels of bytes per launch x launches per TraceFrame
+        tf_in_pmc = max(1, pmc.get("lm_k_primary", {}).get("launches", 1))
+        hbm_tf = sum(v.get("hbm_bytes_per_launch_corrected", 0.0) * v.get("launches", 0) / tf_in_pmc for v in pmc.values()) if pmc else None
+        tf_ms = ms_per_step / spp
+        # ---- VALU-bound kernels (candidate pick; spatial reuse): executed lane-operations / alone time against the fp32 issue peak
+        valu = []
+        for name in (("lm_k_pick_primary_fast", "lm_k_restir_spatial_fast") if fast else ("lm_k_pick_primary", "lm_k_restir_spatial")):
+            lane_ops, us = pk(name, "SQ_THREAD_CYCLES_VALU_per_launch"), pk(name, "alone_us")
+            if lane_ops and us:
+                ach = lane_ops / (us * 1e-6) / 1e12
+                valu.append({"kernel": name, "bound": "valu", "achieved": round(ach, 2), "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-ops/s",
+                             "frac": round(ach / VALU_PEAK_TLANEOPS, 4), "alone_us": round(us, 1), "active_lanes_per_inst": round(pk(name, "active_lanes_per_valu_inst") or 0.0, 1),
+                             "valu_insts_per_launch": int(pk(name, "SQ_INSTS_VALU_per_launch") or 0), "source": PMC_FILE + " (replayed)"})
+        dev = lambda kk: {n: round(kk[n][0] / max(1, kk["total"][1]), 3) for n in kk}
         out = {
             "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {'cornell box (the reference asset, tests/golden fixture)' if kind == 'cornell' else kind + ' stand-in'}, {W}x{H}, {spp} spp (blended TraceFrames), depth {depth}, ReSTIR DI on",
+                       "resample_mode": ("fast: hardware rcp/rsq/sqrt + contracted target function in the ReSTIR passes (rel-L2 vs oracle 1e-8 measured, 1e-3 asserted: "
+                                         "test_fast_resampling_mode_stays_within_the_north_star_tolerance)") if fast else "exact: correctly rounded everywhere, bit-identical to the oracle",
+                       "other_mode": None if other_pass is None else {"mode": "exact" if fast else "fast", "value": round(other_pass["value"], 3), "ms_per_step": round(other_pass["ms_per_step"], 4),
+                                                                     "device_ms_per_traceframe": dev(other_pass["kernel_ms"])},
                        "triangles": desc.triangle_count(), "rays_per_frame": int(rays_per_frame), "ms_per_frame": round(ms_per_step, 4),
                        "tiles": f"{tiles.grid_for(world, W, H)[0]}x{tiles.grid_for(world, W, H)[1]} + {tiles.HALO}px halo" if world > 1 else "1x1",
-                       "nodes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2),
+                       "nodes4_per_ray": round(node_records / all_rays_inst, 2), "binary_node_equivalents_per_ray": round(ci[20] / all_rays_inst, 2), "tris_per_ray": round(ci[21] / all_rays_inst, 2),
                        "rays_per_wave": [int(c[4 + d]) for d in range(depth)], "nee_shadow_rays": int(c[1]), "restir_shadow_rays": int(c[2]),
-                       "algorithmic_bytes_per_traceframe": int(alg_tf),
-                       "hbm_fraction_by_algorithmic_bytes": round(alg_tf * spp / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9), 4) if world == 1 else None},
+                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       "d4_accounting_bytes_per_traceframe": int(alg_tf),
+                       "d4_accounting_over_hbm_peak": round(alg_tf * spp / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9), 4) if world == 1 else None,
+                       "d4_note": "SURVEY d4 prices the reference's AoS data flow; above 1.0 means most of those bytes are cache hits or never move here — it is not a roofline",
+                       "hbm_traffic_bytes_per_traceframe": None if hbm_tf is None else int(hbm_tf),
+                       "hbm_traffic_frac": None if hbm_tf is None else round(hbm_tf / (tf_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
+                       "hbm_traffic_source": None if hbm_tf is None else PMC_FILE + " (replayed: PMC passes of the builder's run, 2 x FETCH_SIZE + WRITE_SIZE per kernel)"},
             "roofline": {"bound": "hbm", "kernel": "lm_k_trace_closest", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic_closest,
+                         "traffic_source": None if traffic_closest is None else PMC_FILE + " (replayed, not measured by this run)",
+                         "traffic_over_algorithmic": None if not traffic_closest else round(traffic_closest / (alg / max(1.0, launches_per_tf)), 4),
+                         "limiter": "dependent-load latency x lane divergence: the tree is served by L2 / Infinity Cache, HBM sees a few % of the algorithmic bytes",
                          "launch_ms": round(per_launch_ms, 4), "launches_per_traceframe": launches_per_tf,
-                         "algorithmic_bytes_per_launch": int(alg / max(1.0, launches_per_tf))},
-            "device_ms_per_traceframe": {"closest": round(closest_ms / n_traceframes, 3), "shadow": round(shadow_ms / n_traceframes, 3),
-                                         "shade": round(shade_ms / n_traceframes, 3), "restir": round(restir_ms / n_traceframes, 3),
-                                         "total": round(total_ms / n_traceframes, 3)},
+                         "algorithmic_bytes_per_launch": int(alg / max(1.0, launches_per_tf)),
+                         "achieved_d4_binary_node_pricing": round(gbs(alg_d4), 2)},
+            "roofline_valu": valu,
+            "device_ms_per_traceframe": dev(k),
         }
+        if main_pass["per_rank"]:
+            out["per_rank"] = main_pass["per_rank"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kind, kw, depth, spp, (W, H))
         if emu:

@@ -571,7 +571,7 @@ int lumen_mi_set_tuning(lumen_mi_renderer* r, const char* key, int value)
     else if (k == "fuzz") r->fuzz = (uint32_t)value;
     else if (k == "assemble") r->assembleEnabled = value;
     else if (k == "shadow_on_wave") { if (r->initialised) { int rc = syncAndCollect(r); if (rc) return rc; } r->shadowOnWave = value; }
-    else if (k == "fast_resample") r->fastResample = value != 0;
+    else if (k == "fast_resample") { if (r->initialised) { int rc = syncAndCollect(r); if (rc) return rc; } r->fastResample = value != 0; }
     else if (k == "refill") r->refillBelow = value;
     else if (k == "refill_visibility") r->refillVisibility = value;
     else if (k == "refill_primary") r->refillPrimary = value;

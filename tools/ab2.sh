@@ -7,7 +7,7 @@ for cfg in "" "$@"; do
 import json,sys
 try:
     j=json.loads(open("gpurun_out/$tag/b.json").read().strip().splitlines()[-1])
-    print("[",sys.argv[1],"] Mrays/s", j["value"], "ms/frame", j["ms_per_step"], j["device_ms_per_traceframe"], j["config"]["nodes_per_ray"])
+    print("[",sys.argv[1],"] Mrays/s", j["value"], "ms/frame", j["ms_per_step"], j["device_ms_per_traceframe"], j["config"].get("nodes4_per_ray"))
 except Exception as ex: print(sys.argv[1], "failed", ex, open("gpurun_out/$tag/b.err").read()[-800:])
 PY
 done

@@ -18,7 +18,7 @@ python3 - <<PY
 import json,csv
 try:
     j=json.loads(open("gpurun_out/$tag/bench.json").read().strip().splitlines()[-1])
-    print("Mrays/s",j["value"],"ms/frame",j["ms_per_step"],"dev",j["device_ms_per_traceframe"],"roof",j["roofline"]["frac"], j["config"].get("nodes_per_ray"))
+    print("Mrays/s",j["value"],"ms/frame",j["ms_per_step"],"dev",j["device_ms_per_traceframe"],"roof",j["roofline"]["frac"], j["config"].get("nodes4_per_ray"), "other", j["config"].get("other_mode"))
 except Exception as e: print("bench parse failed",e, open("gpurun_out/$tag/bench.err").read()[-2000:])
 rows=[r for r in csv.DictReader(open("gpurun_out/$tag/kernel_stats.csv")) if not r["Name"].endswith("_inst")]
 for r in rows[:14]: print(f'{r["Name"][:34]:34s} calls {r["Calls"]:>4s} avg_us {float(r["AverageNs"])/1e3:9.1f} pct {r["Percentage"]}')
