@@ -27,6 +27,7 @@ PMC_FILE = os.path.join("profiles", "r02_c2_pmc.json")      # tools/pmc_json.sh 
 WORKLOADS = {
     # name: (scene factory kwargs, width, height, depth, spp)
     "c2": ("sponza", dict(), 2560, 1440, 6, 4),
+    "c2t": ("sponza", dict(textured=True), 2560, 1440, 6, 4),        # C2 with seeded 1024^2 base-colour / normal / metal-roughness maps on 22 materials
     "c3": ("sponza", dict(extra_lights=512), 2560, 1440, 6, 4),
     "c4": ("sponza", dict(), 3840, 2160, 8, 8),
     "c5": ("foliage", dict(), 1920, 1080, 6, 1),

@@ -149,8 +149,9 @@ KN(lm_k_trace_closest)(LmScene sc, const float4* __restrict__ rayO, const float4
                    uint4* __restrict__ hits, float tmin, float tmax, uint32_t* counters, int refillBelow)
 {
     __shared__ int s_stack[LM_STACK_LDS * LM_BLOCK];
+    __shared__ uint4 s_top[4 * LM_TOP_NODES + 1];
     const uint32_t n = *countPtr;
-    lm_trace_queue<false>(sc, n, refillBelow, lm_make_stack(s_stack, sc), counters,
+    lm_trace_queue<false>(sc, n, refillBelow, lm_make_stack(s_stack, sc), lm_stage_top(s_top, sc), counters,
         [&](uint32_t i, lf3& o, lf3& d, float& t0, float& t1) { o = v3(rayO[i]); d = v3(rayD[i]); t0 = tmin; t1 = tmax; },
         [&](uint32_t i, bool found, const LmHit& h) {
             uint4 out = make_uint4(0u, 0u, 0u, f2u(-1.f));
@@ -337,8 +338,9 @@ extern "C" __global__ void __launch_bounds__(LM_BLOCK)
 KN(lm_k_trace_shadow)(LmScene sc, LmFrame fr, const uint32_t* __restrict__ countPtr, float tmin, int refillBelow)
 {
     __shared__ int s_stack[LM_STACK_LDS * LM_BLOCK];
+    __shared__ uint4 s_top[4 * LM_TOP_NODES + 1];
     const uint32_t n = *countPtr;
-    lm_trace_queue<true>(sc, n, refillBelow, lm_make_stack(s_stack, sc), fr.counters,
+    lm_trace_queue<true>(sc, n, refillBelow, lm_make_stack(s_stack, sc), lm_stage_top(s_top, sc), fr.counters,
         [&](uint32_t i, lf3& o, lf3& d, float& t0, float& t1) { const float4 o4 = fr.shO[i]; o = v3(o4); d = v3(fr.shD[i]); t0 = tmin; t1 = o4.w; },
         [&](uint32_t i, bool occluded, const LmHit&) {
             if (!occluded) {
@@ -366,11 +368,12 @@ KN(lm_k_restir_trace_shade)(LmScene sc, LmFrame fr, int rc, const uint32_t* __re
 {
     rc = lm_res_idx(fr, rc);
     __shared__ int s_stack[LM_STACK_LDS * LM_BLOCK];
+    __shared__ uint4 s_top[4 * LM_TOP_NODES + 1];
     const uint32_t n = *countPtr;
     float4* hot = fr.res[rc];
     const float4* __restrict__ qO = pass ? fr.vis2O : fr.visO;
     const float4* __restrict__ qD = pass ? fr.vis2D : fr.visD;
-    lm_trace_queue<true>(sc, n, refillBelow, lm_make_stack(s_stack, sc), fr.counters,
+    lm_trace_queue<true>(sc, n, refillBelow, lm_make_stack(s_stack, sc), lm_stage_top(s_top, sc), fr.counters,
         [&](uint32_t i, lf3& o, lf3& d, float& t0, float& t1) { const float4 o4 = qO[i]; o = v3(o4); d = v3(qD[i]); t0 = 0.1f; t1 = o4.w; },
         [&](uint32_t i, bool occluded, const LmHit&) {
             const uint32_t li = f2u(qD[i].w);
@@ -1034,6 +1037,50 @@ KN(lm_k_refit_level)(LmScene sc, const uint32_t* __restrict__ levelNodes, uint32
     nodeBox[2u * n + 1u] = v4(nhi, 0.f);
 }
 
+// Top-of-tree table for the queue traversal kernels (lm_layout.h LM_TOP_NODES): the first LM_TOP_NODES inner nodes in breadth-first
+// order, with child references rewritten to table slots where the child made it into the table.  One wavefront, level by level
+// (slots are handed out in lane order: deterministic); run whenever the node array changes (build, refit, assembly).
+extern "C" __global__ void KN(lm_k_build_top)(const LmNode4* __restrict__ nodes, LmNode4* __restrict__ top)
+{
+#if LM_TOP_NODES
+    __shared__ int s_src[LM_TOP_NODES];
+    const uint32_t lane = threadIdx.x;
+    if (blockIdx.x != 0 || lane >= 64u) return;
+    if (lane == 0u) s_src[0] = 0;
+    __syncthreads();
+    uint32_t begin = 0, count = 1;
+    while (begin < count) {
+        const uint32_t end = count;
+        for (uint32_t base = begin; base < end; base += 64u) {
+            const uint32_t s = base + lane;
+            const bool valid = s < end;
+            LmNode4 nd;
+            uint32_t inner = 0;
+            if (valid) {
+                nd = nodes[s_src[s]];
+                for (int j = 0; j < 4; j++) inner += ((int)nd.c[j].w >= 0 && (int)nd.c[j].w != LM_REF_NONE) ? 1u : 0u;
+            }
+            uint32_t prefix = inner;                                      // inclusive scan over the wavefront
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(prefix, o); if ((int)lane >= o) prefix += v; }
+            const uint32_t total = __shfl(prefix, 63);
+            uint32_t slot = count + prefix - inner;
+            if (valid) {
+                for (int j = 0; j < 4; j++) {
+                    const int ref = (int)nd.c[j].w;
+                    if (ref < 0 || ref == LM_REF_NONE) continue;
+                    if (slot < (uint32_t)LM_TOP_NODES) { s_src[slot] = ref; nd.c[j].w = (uint32_t)(LM_TOP_BASE + (int)slot); }
+                    slot++;
+                }
+                top[s] = nd;
+            }
+            count = min((uint32_t)LM_TOP_NODES, count + total);
+            __syncthreads();
+        }
+        begin = end;
+    }
+#endif
+}
+
 // Schedule fuzzing (tuning key "fuzz"): a single wavefront that holds its stream busy for a while.  Inserted at random in front of
 // the launches of a frame, it shifts what overlaps with what; a missing dependency between streams then shows as a changed image.
 extern "C" __global__ void KN(lm_k_spin)(uint32_t ticks)
@@ -1081,6 +1128,7 @@ static void l_test_math(hipStream_t s, uint32_t n, int fn, const float* x, const
 static void l_history_copy(hipStream_t s, int g, LmFrame fr, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, float4* buf, int import)
 { hipLaunchKernelGGL(KN(lm_k_history_copy), LM_GRID(g), fr, x0, y0, w, h, buf, import); }
 static void l_wave_sync(hipStream_t s, int* swap, int* io, int import) { hipLaunchKernelGGL(KN(lm_k_wave_sync), dim3(1), dim3(64), 0, s, swap, io, import); }
+static void l_build_top(hipStream_t s, const LmNode4* nodes, LmNode4* top) { hipLaunchKernelGGL(KN(lm_k_build_top), dim3(1), dim3(64), 0, s, nodes, top); }
 static void l_spin(hipStream_t s, uint32_t ticks) { hipLaunchKernelGGL(KN(lm_k_spin), dim3(1), dim3(64), 0, s, ticks); }
 
 #if LM_INSTRUMENT
@@ -1090,6 +1138,6 @@ extern "C" const LmKernelTable* lm_kernel_table()
 #endif
 {
     static const LmKernelTable t = {l_primary, l_trace_closest, l_extract0, l_shade_wave, l_trace_shadow, l_path_tail, l_fill_bags, l_pick_primary,
-                                    l_trace_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_export_aux, l_refit_tris, l_refit_quant, l_refit_level, l_test_bsdf, l_test_math, l_spin, l_history_copy, l_wave_sync, l_test_restir};
+                                    l_trace_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_export_aux, l_refit_tris, l_refit_quant, l_refit_level, l_test_bsdf, l_test_math, l_spin, l_history_copy, l_wave_sync, l_test_restir, l_build_top};
     return &t;
 }

@@ -29,6 +29,7 @@ struct LmKernelTable {
     void (*history_copy)(hipStream_t, int grid, LmFrame, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, float4* buf, int import);
     void (*wave_sync)(hipStream_t, int* swap, int* io, int import);
     void (*test_restir)(hipStream_t, int mode, uint32_t n, const float* a, const float* b, const uint32_t* c, uint32_t m, float* out);
+    void (*build_top)(hipStream_t, const LmNode4* nodes, LmNode4* top);       // top-of-tree table of the queue traversal kernels (after every change of `nodes`)
 };
 extern "C" const LmKernelTable* lm_kernel_table();
 extern "C" const LmKernelTable* lm_kernel_table_instrumented();

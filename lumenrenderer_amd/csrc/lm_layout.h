@@ -9,10 +9,16 @@
 #include <stdint.h>
 
 #define LM_STACK_DEPTH 64        // traversal stack entries per lane; the BVH builder bounds the tree so that this suffices
+#ifndef LM_STACK_LDS
 #define LM_STACK_LDS 16          // of which in LDS; deeper entries spill to a per-thread global array
+#endif
 #define LM_BVH2_MAX_DEPTH 40     // depth bound of the binary tree the 4-wide tree is collapsed from: a 4-wide node spans >= 2 binary
                                  // levels per 3 pushes, so the stack need is <= 1.5 * 40 + 1 <= LM_STACK_DEPTH
 #define LM_REF_NONE 0x7fffffff   // absent child of a 4-wide node (also the traversal's "finished" marker; never followed)
+#ifndef LM_TOP_NODES
+#define LM_TOP_NODES 21          // top-of-tree node records (breadth-first from the root) the queue traversal kernels stage in LDS; 0 = none.
+#endif                           // 21 = three full levels = 1.3 KB per block beside the 16 KB stack: still eight blocks per CU
+#define LM_TOP_BASE 0x40000000   // a node reference >= LM_TOP_BASE (and != LM_REF_NONE) names slot (ref - LM_TOP_BASE) of the staged table
 #define LM_MAX_LEAF 8            // triangles per leaf representable in a leaf reference
 #define LM_MAX_DEPTH 16          // path depth the counter block is sized for
 
@@ -59,6 +65,8 @@ struct LmLight { float4 a, b, c, d; };   // a = p0.xyz p1.x | b = p1.yz p2.xy | 
 
 struct LmScene {
     LmNode4* nodes;             // written only by the refit kernels
+    const LmNode4* top;         // LM_TOP_NODES records: the top of the tree in breadth-first order, child references relinked to table slots
+                                // where the child is in the table too (lm_k_build_top, rebuilt whenever `nodes` changes)
     const float* quant;         // dequantisation of node boxes, in device memory so that a refit can move it without a host
                                 // round trip: [0..2] qmin, [3..5] qstep (world = qmin + q * qstep), [6] box padding
     LmWoop* woop;               // written only by the refit kernels

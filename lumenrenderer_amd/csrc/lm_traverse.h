@@ -12,7 +12,22 @@ struct LmHit { float t, u, v; uint32_t slot; };
 // Per-lane traversal stack: the first LM_STACK_LDS entries live in LDS ([level][lane]: one bank per lane), deeper entries
 // (rare) spill to a per-thread global array, so that the LDS footprint (16 KB per 256-thread block) does not cap occupancy.
 typedef __attribute__((address_space(3))) int lm_lds_int;      // explicit LDS pointer: ds_read / ds_write, never flat accesses
+typedef uint32_t lm_u4v __attribute__((ext_vector_type(4)));   // (HIP's uint4 is a class and cannot be read through an address-space pointer)
+typedef __attribute__((address_space(3))) lm_u4v lm_lds_u4;
+__device__ __forceinline__ uint4 lm_lds_read4(const lm_lds_u4* p) { const lm_u4v v = *p; return make_uint4(v.x, v.y, v.z, v.w); }
 struct LmStack { lm_lds_int* lds; int* spill; };
+// Top of the tree staged in LDS (queue kernels): every ray starts at the root and spends its first steps in the same few nodes, so
+// those records are copied once per block and read with ds_read_b128 instead of a global load per lane and step.
+__device__ __forceinline__ lm_lds_u4* lm_stage_top(uint4* s_top, const LmScene& sc)
+{
+#if LM_TOP_NODES
+    for (uint32_t i = threadIdx.x; i < 4u * LM_TOP_NODES; i += LM_BLOCK) s_top[i] = ((const uint4*)sc.top)[i];
+    __syncthreads();
+    return (lm_lds_u4*)s_top;
+#else
+    return nullptr;
+#endif
+}
 #if LM_INSTRUMENT
 __device__ unsigned long long g_lmPushes[2];       // counting build: [0] stack pushes, [1] of which went to the global spill area
 #endif
@@ -93,10 +108,21 @@ __device__ __forceinline__ void lm_cex(uint32_t& ka, int& ra, uint32_t& kb, int&
     ka = k0; kb = k1; ra = r0; rb = r1;
 }
 template <bool ANY>
-__device__ __forceinline__ int lm_node_step(const LmScene& sc, int cur, const LmRayQ& rq, float tmin, float hitT, const LmStack& stack, int& sp)
+__device__ __forceinline__ int lm_node_step(const LmScene& sc, int cur, const LmRayQ& rq, float tmin, float hitT, const LmStack& stack, int& sp,
+                                            const lm_lds_u4* top, uint32_t* boxes = nullptr)
 {
-    const uint4* nd = sc.nodes[cur].c;
-    const uint4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+    uint4 q0, q1, q2, q3;
+#if LM_TOP_NODES
+    if (cur >= LM_TOP_BASE) {                                    // (only kernels that staged the table ever hold such a reference)
+        const lm_lds_u4* nd = top + 4u * (uint32_t)(cur - LM_TOP_BASE);
+        q0 = lm_lds_read4(nd); q1 = lm_lds_read4(nd + 1); q2 = lm_lds_read4(nd + 2); q3 = lm_lds_read4(nd + 3);
+    } else
+#endif
+    {
+        const uint4* nd = sc.nodes[cur].c;
+        q0 = nd[0]; q1 = nd[1]; q2 = nd[2]; q3 = nd[3];
+    }
+    if (boxes) *boxes += ((int)q0.w != LM_REF_NONE) + ((int)q1.w != LM_REF_NONE) + ((int)q2.w != LM_REF_NONE) + ((int)q3.w != LM_REF_NONE);   // counting build
     uint32_t k0, k1, k2, k3;
     lm_slab(q0, rq, tmin, hitT, k0); lm_slab(q1, rq, tmin, hitT, k1); lm_slab(q2, rq, tmin, hitT, k2); lm_slab(q3, rq, tmin, hitT, k3);
     int r0 = (int)q0.w, r1 = (int)q1.w, r2 = (int)q2.w, r3 = (int)q3.w;
@@ -137,9 +163,10 @@ __device__ __forceinline__ bool lm_traverse(const LmScene& sc, const lf3& o, con
     for (;;) {
         while (cur >= 0 && cur != LM_REF_NONE) {
 #if LM_INSTRUMENT
-            for (int k = 0; k < 4; k++) nNodes += (int)sc.nodes[cur].c[k].w != LM_REF_NONE;      // child boxes tested
+            cur = lm_node_step<ANY>(sc, cur, rq, tmin, hitT, stack, sp, nullptr, &nNodes);      // + child boxes tested
+#else
+            cur = lm_node_step<ANY>(sc, cur, rq, tmin, hitT, stack, sp, nullptr);
 #endif
-            cur = lm_node_step<ANY>(sc, cur, rq, tmin, hitT, stack, sp);
         }
         if (cur == 0x7fffffff) break;
         // leaf
@@ -188,9 +215,10 @@ __device__ __forceinline__ bool lm_traverse(const LmScene& sc, const lf3& o, con
 #define LM_NODE_EXIT 14
 #endif
 template <bool ANY, class Fetch, class Done>
-__device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, int refillBelow, const LmStack& stack,
+__device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, int refillBelow, const LmStack& stack, const lm_lds_u4* top,
                                                uint32_t* cnt, Fetch fetch, Done done)
 {
+    const int root = (LM_TOP_NODES && top) ? LM_TOP_BASE : 0;
     // A small queue cannot fill the machine: its launch time is one wave's dependent chain, which stretches when the wave
     // shares its SIMD with VALU-bound kernels of the other streams.  Such waves ask the SIMD arbiter for priority.
     if (n < LM_PRIO_RAYS) __builtin_amdgcn_s_setprio(3);
@@ -226,7 +254,7 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
                 const float idx = lm_safe_rcp(d.x), idy = lm_safe_rcp(d.y), idz = lm_safe_rcp(d.z);
                 rq.ax = sc.quant[3] * idx; rq.ay = sc.quant[4] * idy; rq.az = sc.quant[5] * idz;
                 rq.bx = (sc.quant[0] - o.x) * idx; rq.by = (sc.quant[1] - o.y) * idy; rq.bz = (sc.quant[2] - o.z) * idz;
-                hitT = tmax; hitOrder = 0xffffffffu; found = false; sp = 0; cur = 0;
+                hitT = tmax; hitOrder = 0xffffffffu; found = false; sp = 0; cur = root;
                 active = true;
 #if LM_INSTRUMENT
                 raySteps = 0;
@@ -253,12 +281,13 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
 #endif
 #endif
 #if LM_INSTRUMENT
-                for (int k = 0; k < 4; k++) nNodes += (int)sc.nodes[cur].c[k].w != LM_REF_NONE;  // child boxes tested
                 raySteps++;
                 { const unsigned long long m = __ballot(true);           // lane occupancy of this node-step issue
                   if ((int)lane == __ffsll((long long)m) - 1) { atomicAdd((unsigned long long*)(cnt + LM_CNT_OCC), (unsigned long long)__popcll(m)); atomicAdd((unsigned long long*)(cnt + LM_CNT_OCC + 2), 64ull); } }
+                cur = lm_node_step<ANY>(sc, cur, rq, tmin, hitT, stack, sp, top, &nNodes);      // + child boxes tested
+#else
+                cur = lm_node_step<ANY>(sc, cur, rq, tmin, hitT, stack, sp, top);
 #endif
-                cur = lm_node_step<ANY>(sc, cur, rq, tmin, hitT, stack, sp);
             }
             if (cur < 0) {
                 const uint32_t leaf = (uint32_t)(~cur);

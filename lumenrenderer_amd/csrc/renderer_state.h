@@ -90,6 +90,7 @@ template <class T> struct HostBuf {                 // pinned staging memory for
 // the other one (instance table and light list by asynchronous copies from pinned memory, BVH boxes and Woop packets by the
 // refit kernels) on the wave stream, so frames keep overlapping while the scene changes.
 struct SceneSet {
+    DevBuf<LmNode4> top;                                                     // top-of-tree table of `nodes` (lm_k_build_top)
     DevBuf<LmNode4> nodes; DevBuf<LmWoop> woop; DevBuf<float> quant; DevBuf<LmEntry> entries; DevBuf<LmLight> lights; DevBuf<float> cdf;
     DevBuf<uint2> triId; DevBuf<uint32_t> triOrder, levelNodes;            // topology of the tree in `nodes` (what an instance add / remove rewrites)
     std::vector<uint32_t> levelStart; uint32_t nTris = 0;
@@ -98,7 +99,7 @@ struct SceneSet {
     hipEvent_t evUp = nullptr; bool upPending = false;      // the staging buffers are free again once this event has passed
     uint64_t entriesVer = 0, geomVer = 0, lightsVer = 0, topoVer = 0;    // state of the host scene this set holds
     void release() {
-        nodes.release(); woop.release(); quant.release(); entries.release(); lights.release(); cdf.release();
+        top.release(); nodes.release(); woop.release(); quant.release(); entries.release(); lights.release(); cdf.release();
         triId.release(); triOrder.release(); levelNodes.release();
         hEntries.release(); hLights.release(); hCdf.release(); hNodes.release(); hTriId.release(); hOrder.release(); hLevelNodes.release();
         if (evUp) { (void)hipEventDestroy(evUp); evUp = nullptr; }

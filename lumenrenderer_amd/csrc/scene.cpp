@@ -136,6 +136,8 @@ int syncScene(R* r, hipStream_t su)
                 const uint32_t a = T.levelStart[l], b = T.levelStart[l + 1];
                 if (b > a) K->refit_level(su, sc, T.levelNodes.p + a, b - a, r->dTriBox.p, r->dNodeBox.p);
             }
+            if (T.top.ensure(LM_TOP_NODES + 1)) return fail(LUMEN_MI_ERR_DEVICE, "top table allocation failed");
+            K->build_top(su, T.nodes.p, T.top.p);                   // the boxes changed: so does their copy in the top-of-tree table
             LM_HIP(hipGetLastError());
             ++r->refits;
             T.geomVer = r->geomVer;
@@ -144,7 +146,7 @@ int syncScene(R* r, hipStream_t su)
     }
     const SceneSet& S = r->sset[r->sgen];
     r->dscene.nodes = S.nodes.p; r->dscene.woop = S.woop.p; r->dscene.quant = S.quant.p; r->dscene.entries = S.entries.p;
-    r->dscene.triId = S.triId.p; r->dscene.triOrder = S.triOrder.p;
+    r->dscene.triId = S.triId.p; r->dscene.triOrder = S.triOrder.p; r->dscene.top = S.top.p;
     r->dscene.lights = S.lights.p; r->dscene.cdf = S.cdf.p;
     return 0;
 }
@@ -267,6 +269,8 @@ int flatten(R* r)
             return fail(LUMEN_MI_ERR_DEVICE, "scene upload failed (hipMalloc/hipMemcpy)");
         S.levelStart = r->bvh.levelStart; S.nTris = nt;
         S.entriesVer = r->entriesVer; S.geomVer = r->geomVer; S.topoVer = r->topoVer;
+        if (S.top.ensure(LM_TOP_NODES + 1)) return fail(LUMEN_MI_ERR_DEVICE, "top table allocation failed");
+        r->K->build_top(st, S.nodes.p, S.top.p);
     }
     {
         std::vector<uint32_t> bounds = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
@@ -281,7 +285,7 @@ int flatten(R* r)
     {
         const SceneSet& S = r->sset[r->sgen];
         r->dscene.nodes = S.nodes.p; r->dscene.woop = S.woop.p; r->dscene.quant = S.quant.p; r->dscene.entries = S.entries.p;
-        r->dscene.triId = S.triId.p; r->dscene.triOrder = S.triOrder.p;
+        r->dscene.triId = S.triId.p; r->dscene.triOrder = S.triOrder.p; r->dscene.top = S.top.p;
     }
     r->sceneDirty = false;
     r->transformsDirty = false;

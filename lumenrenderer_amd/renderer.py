@@ -212,6 +212,9 @@ class LumenRendererMI:
         w, h = C.c_uint32(), C.c_uint32()
         buf = (C.c_uint8 * 4)()
         self.lib.lumen_mi_get_output_pixels(self.h, buf, 0, C.byref(w), C.byref(h))
+        if w.value == 0 or h.value == 0:            # (with a render thread running, the first frame may land between this query and the read-back)
+            from .capi import LumenMIError
+            raise LumenMIError(3, "no frame has been traced yet")
         return h.value, w.value
 
     def GetOutputTexturePixels(self):

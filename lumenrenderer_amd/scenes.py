@@ -360,8 +360,51 @@ SPONZA_AABB_MAX = np.array([1799.9, 1429.4, 1105.4])
 SPONZA_NODE_SCALE = 0.008
 
 
-def sponza_standin(extra_lights=0, light_radiance=(17.0, 12.0, 4.0), light_scale=50.0):
-    """C2 (and C3 with ``extra_lights=512`` quads = 1024 emissive triangles).  Deterministic: xorshift32 seeded 'SPON'."""
+def procedural_maps(seed, size=1024, tiles=6):
+    """Seeded base-colour / normal / metal-roughness maps (RGBA8, size x size) for the textured variant of the stand-in: multi-octave value
+    noise over a tile pattern with grout lines; the normal map is the gradient of the same height field; roughness follows a second noise
+    field in the G channel (>= 1/255, as the reference's loader clamps it, LumenPTModelConverter.cpp:121-128), metallic in B.  Deterministic
+    (PCG64 of ``seed``); tests/test_cpu_host.py pins a checksum."""
+    g = np.random.Generator(np.random.PCG64(int(seed)))
+    x = (np.arange(size, dtype=np.float64) + 0.5) / size
+
+    def octave(n):                                                # n x n lattice, bilinear, wrapping
+        lat = g.random((n, n))
+        f = x * n - 0.5
+        i0 = np.floor(f).astype(np.int64); t = f - i0
+        i0 %= n; i1 = (i0 + 1) % n
+        rows = lat[i0][:, i0] * (1 - t)[None, :] + lat[i0][:, i1] * t[None, :]
+        rows1 = lat[i1][:, i0] * (1 - t)[None, :] + lat[i1][:, i1] * t[None, :]
+        return rows * (1 - t)[:, None] + rows1 * t[:, None]
+
+    def field():
+        h = sum(octave(8 << k) * 0.5 ** k for k in range(5))
+        return h / sum(0.5 ** k for k in range(5))
+    h, h2 = field(), field()
+    fu = (x * tiles) % 1.0
+    grout = (fu < 0.04)[None, :] | (fu < 0.04)[:, None]
+    height = np.where(grout, 0.15 * h, 0.35 + 0.65 * h)
+    tint = 0.85 + 0.15 * g.random(3)
+    albedo = np.where(grout, 0.45, 0.6 + 0.4 * h)[..., None] * tint[None, None, :]
+    diffuse = np.empty((size, size, 4), np.uint8)
+    diffuse[..., :3] = np.clip(np.rint(albedo * 255.0), 0, 255).astype(np.uint8); diffuse[..., 3] = 255
+    du = (np.roll(height, -1, axis=1) - np.roll(height, 1, axis=1)) * 0.5 * size
+    dv = (np.roll(height, -1, axis=0) - np.roll(height, 1, axis=0)) * 0.5 * size
+    n = np.stack([-du * 0.012, -dv * 0.012, np.ones_like(du)], -1)
+    n /= np.linalg.norm(n, axis=-1, keepdims=True)
+    normal = np.empty((size, size, 4), np.uint8)
+    normal[..., :3] = np.clip(np.rint((n * 0.5 + 0.5) * 255.0), 0, 255).astype(np.uint8); normal[..., 3] = 0
+    mr = np.full((size, size, 4), 255, np.uint8)
+    mr[..., 1] = np.clip(np.rint((0.45 + 0.55 * h2) * 255.0), 1, 255).astype(np.uint8)
+    mr[..., 2] = np.where(grout, 160, 255).astype(np.uint8)
+    return diffuse, normal, mr
+
+
+def sponza_standin(extra_lights=0, light_radiance=(17.0, 12.0, 4.0), light_scale=50.0, textured=False, tex_size=1024):
+    """C2 (and C3 with ``extra_lights=512`` quads = 1024 emissive triangles).  Deterministic: xorshift32 seeded 'SPON'.
+    ``textured``: the 22 opaque / metal materials get seeded ``tex_size``^2 base-colour (sRGB), normal and metal-roughness maps
+    (procedural_maps), so that surface extraction really performs its bilinear texture fetches (GPUExtractSurfaceData.cu:59-60,169-181);
+    geometry, UVs, lights and camera are those of the untextured scene."""
     rng = _Xorshift(0x53504F4E)
     d = SceneDescription()
     lo, hi = SPONZA_AABB_MIN, SPONZA_AABB_MAX
@@ -383,6 +426,13 @@ def sponza_standin(extra_lights=0, light_radiance=(17.0, 12.0, 4.0), light_scale
     light_mat = d.add_material(diffuse_color=(1, 1, 1, 1), emission=(1, 1, 1), metallic_factor=0.0, roughness_factor=1.0)
     mats.append(light_mat)
     assert len(mats) == SPONZA_MATERIALS
+    if textured:
+        for k in range(22):
+            dm, nm, mr = procedural_maps(0x54455800 + k, tex_size, tiles=4 + k % 5)          # 'TEX' + material number
+            m = d.materials[mats[k]]
+            m["diffuse_texture"] = d.add_texture(dm, srgb=True)           # the .ollad path decodes base colour as sRGB (LumenPTModelConverter.cpp:130-133)
+            m["normal_map"] = d.add_texture(nm, srgb=False)
+            m["metallic_roughness_texture"] = d.add_texture(mr, srgb=False)
     prims, tri = [], 0
     opaque = mats[:20]
     fy = lo[1]                                                    # floor height

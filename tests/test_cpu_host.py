@@ -606,3 +606,20 @@ def test_product_bsdf_header_equals_the_oracle_bit_for_bit_on_the_host(tmp_path)
         got = np.zeros((n, 8), np.float32); K.chk_sample_bsdf(n, fptr(mat), fptr(N), fptr(T), fptr(wo), fptr(r3), fptr(got))
         assert same(got, want), seed
         assert want[:, 7].sum() > 0.1 * n and (want[:, 6] > 0).sum() > 0.8 * n
+
+
+def test_textured_standin_maps_are_deterministic():
+    """The textured variant of the benchmark scene (bench workload c2t) is generated, not stored: the seeded map generator must produce
+    the same bytes everywhere (checksums), roughness never reaches 0 (G >= 1/255, LumenPTModelConverter.cpp:121-128), and the scene
+    carries 3 maps for each of its 22 opaque / metal materials on top of the untextured scene's 6 textures."""
+    import zlib
+    from lumenrenderer_amd import scenes
+    d, n, m = scenes.procedural_maps(0x54455800, 1024, 4)
+    assert (hex(zlib.crc32(d.tobytes())), hex(zlib.crc32(n.tobytes())), hex(zlib.crc32(m.tobytes()))) == ("0x29fa890e", "0xe4a6ba3b", "0xb9bb74d4")
+    assert d.shape == (1024, 1024, 4) and m[..., 1].min() >= 1 and (d[..., 3] == 255).all() and (n[..., 2] > 128).all() and n[..., 2].mean() > 240
+    small = scenes.sponza_standin(textured=True, tex_size=64)
+    plain = scenes.sponza_standin()
+    assert len(small.textures) == len(plain.textures) + 66 and small.triangle_count() == plain.triangle_count() == scenes.SPONZA_TRIANGLES + 2
+    for a, b in zip(small.primitives, plain.primitives):                                          # same geometry, UVs included
+        assert np.array_equal(a["vertices"], b["vertices"]) and np.array_equal(a["indices"], b["indices"])
+    assert sum(1 for mt in small.materials if small.textures[mt["normal_map"]]["pixels"].shape[0] == 64) == 22

@@ -890,6 +890,33 @@ def test_c2_at_full_size_is_bit_exact_against_the_oracle():
     r.close(); o.close()
 
 
+def test_c2_textured_at_full_size_is_bit_exact_against_the_oracle():
+    """Bench workload c2t: the C2 scene with seeded 1024 x 1024 base-colour (sRGB-decoded), normal and metal-roughness maps on its 22
+    opaque / metal materials, so that every hit performs the bilinear fetches of GPUExtractSurfaceData.cu:59-60,169-181 and the shading
+    normal / roughness / albedo vary per pixel.  2560x1440, depth 6, two blended TraceFrames, default schedule, exact mode: radiance,
+    G-buffer and counters equal the oracle bit for bit."""
+    from lumenrenderer_amd.scenes import sponza_standin
+    W, H, D = 2560, 1440, 6
+    d = sponza_standin(textured=True)
+    r = product_from(d, W, H, D, blend=True)
+    o = oracle_from(d, W, H, D, blend=True)
+    for _ in range(2):
+        assert r.TraceFrameAsync()
+        assert o.trace_frame() == 0
+    r.Synchronize()
+    got, want = r.GetRadiance(), o.radiance()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), int(np.sum(got.view(np.uint32) != want.view(np.uint32)))
+    g = r.GetGBuffer()
+    assert np.array_equal(g.view(np.uint32), o.gbuffer().view(np.uint32))
+    c, s = r.GetCounters(), o.stats(24)
+    assert list(c[:4 + D]) == list(s[:4 + D]), (c[:12], s[:12])
+    # the maps are really sampled: tens of thousands of distinct albedo values and shading normals that leave the geometric ones
+    hit = g[..., 0, 3] > 0
+    assert len(np.unique(g[..., 4, :3][hit].view(np.uint32).reshape(-1, 3), axis=0)) > 50000
+    assert len(np.unique(g[..., 7, 0][hit].view(np.uint32) >> 24)) > 50                    # roughness bytes from the G channel
+    r.close(); o.close()
+
+
 def test_c3_at_full_size_is_bit_exact_against_the_oracle():
     """BASELINE config C3 at its full size against the oracle: the atrium with 1 026 emissive triangles (513 quads; the reference's
     slice quirk keeps one light-list entry per quad, GPUDataBufferKernels.cu:37), 2560x1440, depth 6, two blended TraceFrames,
@@ -939,6 +966,8 @@ FAST_CASES = {                                                    # BASELINE con
     # dielectric + clear-coat + textured materials and an odd depth (temporal history is live): the surfaces the contracted evaluation
     # does not cover go through the second, exact launch of each ReSTIR pass (LM_RARE), the others through the first
     "mixed": ("textured", {}, 288, 224, 5, 4),
+    # C2 with 1024^2 procedural base-colour / normal / metal-roughness maps on 22 of its 25 materials (bench workload c2t)
+    "c2t": ("sponza", {"textured": True}, 2560, 1440, 6, 2),
 }
 
 
