@@ -52,25 +52,46 @@ def max_tile_shape(n, width, height):
     return max(r[3] - r[1] for r in rects), max(r[2] - r[0] for r in rects)
 
 
+class TileGather:
+    """The one collective of the tiled path: every rank's finished radiance tile to ``dst`` (RCCL gather over xGMI with the nccl backend).
+    All buffers are allocated once: a send tile of the common (maximal) tile shape, the receive tiles and the assembled image on ``dst``;
+    a frame costs one device copy into the send tile, one gather and ``world`` device copies into the image — no per-frame allocation."""
+
+    def __init__(self, rank, world, width, height, dtype, device, dst=0):
+        import torch
+        self.rank, self.world, self.width, self.height, self.dst = rank, world, width, height, dst
+        mh, mw = max_tile_shape(world, width, height)
+        self.tile = tile_rect(rank, world, width, height)
+        self.send = torch.zeros((mh, mw, 4), dtype=dtype, device=device)          # the padding is never read back
+        self.parts = [torch.empty_like(self.send) for _ in range(world)] if (rank == dst and world > 1) else None
+        self.image = torch.empty((height, width, 4), dtype=dtype, device=device) if rank == dst else None
+        self.rects = [tile_rect(r, world, width, height) for r in range(world)]
+
+    def run(self, local_tile, dist):
+        """local_tile: tensor [th, tw, 4] (this rank's tile, halo removed).  Returns the assembled image on ``dst``, None elsewhere."""
+        x0, y0, x1, y1 = self.tile
+        if self.world == 1:
+            self.image[y0:y1, x0:x1] = local_tile
+            return self.image
+        self.send[: y1 - y0, : x1 - x0] = local_tile
+        dist.gather(self.send, self.parts, dst=self.dst)
+        if self.rank != self.dst:
+            return None
+        for r, (rx0, ry0, rx1, ry1) in enumerate(self.rects):
+            self.image[ry0:ry1, rx0:rx1] = self.parts[r][: ry1 - ry0, : rx1 - rx0]
+        return self.image
+
+
+_GATHERS = {}
+
+
 def gather_tiles(local_tile, rank, world, width, height, dist, dst=0):
-    """local_tile: torch tensor [th, tw, 4] (this rank's tile, halo removed).  Returns the assembled [H, W, 4] image on
-    ``dst`` (None elsewhere).  Tiles are padded to a common shape so that one gather moves them."""
-    import torch
-    mh, mw = max_tile_shape(world, width, height)
-    pad = torch.zeros((mh, mw, 4), dtype=local_tile.dtype, device=local_tile.device)
-    pad[: local_tile.shape[0], : local_tile.shape[1]] = local_tile
-    if world == 1:
-        parts = [pad]
-    else:
-        parts = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-        dist.gather(pad, parts, dst=dst)
-    if rank != dst:
-        return None
-    img = torch.empty((height, width, 4), dtype=local_tile.dtype, device=local_tile.device)
-    for r in range(world):
-        x0, y0, x1, y1 = tile_rect(r, world, width, height)
-        img[y0:y1, x0:x1] = parts[r][: y1 - y0, : x1 - x0]
-    return img
+    """Convenience form of TileGather.run with the buffers cached per (shape, dtype, device)."""
+    key = (rank, world, width, height, local_tile.dtype, str(local_tile.device), dst)
+    g = _GATHERS.get(key)
+    if g is None:
+        g = _GATHERS[key] = TileGather(rank, world, width, height, local_tile.dtype, local_tile.device, dst)
+    return g.run(local_tile, dist)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

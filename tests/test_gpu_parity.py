@@ -1179,6 +1179,35 @@ def test_seam_history_exchange_makes_odd_depth_tiles_exact(n_ranks, size, scene,
     assert tiles.history_needed(5) and not tiles.history_needed(6)
 
 
+@pytest.mark.parametrize("n_ranks", [2, 4, 8])
+def test_tiled_path_on_real_gpus_over_rccl(n_ranks):
+    """The multi-GPU path as it runs in production: one process per GPU (torch.distributed.run, backend nccl = RCCL over xGMI),
+    tiles + 60-px halo, seam exchange of reservoir history after every TraceFrame (odd depth), one RCCL gather per displayed frame;
+    rank 0 compares the stitched blended frames bit for bit with a single-GPU render (tests/multigpu_worker.py).  Needs n_ranks GPUs
+    on the box: skipped on the single-GPU boxes of the development pool, runs wherever the driver has a multi-GPU node."""
+    import subprocess, sys, torch
+    if torch.cuda.device_count() < n_ranks:
+        pytest.skip(f"{torch.cuda.device_count()} GPU(s) on this box, {n_ranks} needed")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29540 + n_ranks), os.path.join(root, "tests", "multigpu_worker.py")]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)      # children start fresh: nothing GPU-side is inherited
+    assert res.returncode == 0 and "MULTIGPU OK" in res.stdout, res.stdout[-3000:] + res.stderr[-5000:]
+
+
+def test_tiled_worker_single_rank_communicator():
+    """The same worker with one rank: the nccl communicator, the preallocated gather buffers and the frame loop on the GPU that is there
+    (the 2 / 4 / 8-rank forms above need a multi-GPU box)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", "29539",
+           os.path.join(root, "tests", "multigpu_worker.py")]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "MULTIGPU OK" in res.stdout, res.stdout[-3000:] + res.stderr[-5000:]
+
+
 def test_full_size_moving_scene_async_equals_serial():
     """Refit, scene-table refresh and light rebuild between asynchronously enqueued full-size frames.  The scene exists twice on
     the device: an edit is written into the set no frame in flight reads (scene.cpp syncScene), on the wave stream.  The edit
