@@ -1,0 +1,138 @@
+// sandbox_driver.cpp — the reference's own call sequence (Sandbox/src/Application.cpp:83-152, OutputLayer.cpp:119-168,882-896) driven through
+// the reference-shaped adapter include/lumen_mi_renderer.hpp: construct the renderer where Sandbox constructs `LumenPT`, Init, default
+// resources, textures / materials / primitives / meshes through the LumenRenderer virtuals, a scene with mesh instances, the scene's
+// camera, StartRendering, the per-frame PerformDeferredOperations of the main loop, GetOutputTexturePixels -> a PPM.
+//
+//     sandbox_driver <scene file> <width> <height> <depth> <frames> <out.ppm>
+//
+// Two builds (tests/): against the reference tree's real headers + the handful of Lumen sources the interface needs (build container;
+// without a GPU the run stops where lumen_mi_init reports that there is no device), and against the minimal interface headers of
+// examples/sandbox_min/ on the GPU box, where the picture must equal the one examples/render_scene.c produces through the bare C ABI.
+// Only the public interface of LumenRenderer / ILumenScene / MeshInstance / Camera is used — no adapter internals.
+#include "lumen_mi_renderer.hpp"
+
+#include <glm/gtc/quaternion.hpp>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <vector>
+
+namespace
+{
+    struct Reader
+    {
+        std::ifstream f;
+        explicit Reader(const char* path) : f(path, std::ios::binary) {}
+        void Bytes(void* dst, size_t n) { f.read(static_cast<char*>(dst), static_cast<std::streamsize>(n)); if (!f) { std::fprintf(stderr, "scene file truncated\n"); std::exit(64); } }
+        uint32_t U32() { uint32_t v; Bytes(&v, 4); return v; }
+        float F32() { float v; Bytes(&v, 4); return v; }
+    };
+}
+
+int main(int argc, char** argv)
+{
+    if (argc != 7) { std::fprintf(stderr, "usage: %s <scene file> <width> <height> <depth> <frames> <out.ppm>\n", argv[0]); return 64; }
+    const unsigned width = static_cast<unsigned>(std::atoi(argv[2])), height = static_cast<unsigned>(std::atoi(argv[3])), depth = static_cast<unsigned>(std::atoi(argv[4]));
+    const int frames = std::atoi(argv[5]);
+    Reader in(argv[1]);
+    if (!in.f || in.U32() != 0x314D4C53u) { std::fprintf(stderr, "not a scene file\n"); return 64; }
+    float cam[13];
+    in.Bytes(cam, sizeof cam);
+
+    // Application.cpp:83-98
+    auto renderer = std::make_shared<MI355X::Renderer>();
+    MI355X::Renderer::Settings settings;
+    settings.depth = depth;
+    settings.renderResolution = {width, height};
+    settings.outputResolution = {width, height};
+    settings.blendOutput = true;
+    renderer->Init(settings);
+    renderer->CreateDefaultResources();
+
+    // what SceneManager does per glTF texture / material / primitive / mesh (SceneManager.cpp:277-541,704-822)
+    std::vector<std::shared_ptr<Lumen::ILumenTexture>> textures(in.U32());
+    for (auto& t : textures) {
+        const uint32_t w = in.U32(), h = in.U32(), srgb = in.U32();
+        std::vector<uint8_t> px(static_cast<size_t>(w) * h * 4);
+        in.Bytes(px.data(), px.size());
+        t = renderer->CreateTexture(px.data(), w, h, srgb != 0);
+    }
+    std::vector<std::shared_ptr<Lumen::ILumenMaterial>> materials(in.U32());
+    for (auto& m : materials) {
+        LumenRenderer::MaterialData d;
+        uint32_t t[8]; float sc[13]; float v4[4], v3[3];
+        in.Bytes(v4, 16); d.m_DiffuseColor = glm::vec4(v4[0], v4[1], v4[2], v4[3]);
+        in.Bytes(v3, 12); d.m_EmissionVal = glm::vec3(v3[0], v3[1], v3[2]);
+        in.Bytes(t, sizeof t); in.Bytes(sc, sizeof sc);
+        for (uint32_t k : t) if (k >= textures.size()) { std::fprintf(stderr, "texture index out of range\n"); return 64; }
+        d.m_DiffuseTexture = textures[t[0]]; d.m_NormalMap = textures[t[1]]; d.m_MetallicRoughnessTexture = textures[t[2]]; d.m_EmissiveTexture = textures[t[3]];
+        d.m_TransmissionTexture = textures[t[4]]; d.m_ClearCoatTexture = textures[t[5]]; d.m_ClearCoatRoughnessTexture = textures[t[6]]; d.m_TintTexture = textures[t[7]];
+        d.m_TransmissionFactor = sc[0]; d.m_ClearCoatFactor = sc[1]; d.m_ClearCoatRoughnessFactor = sc[2]; d.m_IndexOfRefraction = sc[3];
+        d.m_SpecularFactor = sc[4]; d.m_SpecularTintFactor = sc[5]; d.m_SubSurfaceFactor = sc[6]; d.m_Luminance = sc[7]; d.m_Anisotropic = sc[8];
+        d.m_SheenFactor = sc[9]; d.m_SheenTintFactor = sc[10]; d.m_MetallicFactor = sc[11]; d.m_RoughnessFactor = sc[12];
+        in.Bytes(v3, 12); d.m_TintFactor = glm::vec3(v3[0], v3[1], v3[2]);
+        in.Bytes(v3, 12); d.m_Transmittance = glm::vec3(v3[0], v3[1], v3[2]);
+        m = renderer->CreateMaterial(d);
+    }
+    std::vector<std::shared_ptr<Lumen::ILumenPrimitive>> primitives(in.U32());
+    unsigned emissiveTriangles = 0;
+    for (auto& p : primitives) {
+        const uint32_t m = in.U32(), nv = in.U32(), ni = in.U32();
+        if (m >= materials.size()) { std::fprintf(stderr, "material index out of range\n"); return 64; }
+        LumenRenderer::PrimitiveData d;
+        d.m_Interleaved = true;                                   // the 48-byte Vertex layout of ModelStructs.h:21-28
+        d.m_VertexBinary.resize(static_cast<size_t>(nv) * 48); in.Bytes(d.m_VertexBinary.data(), d.m_VertexBinary.size());
+        d.m_IndexBinary.resize(static_cast<size_t>(ni) * 4); in.Bytes(d.m_IndexBinary.data(), d.m_IndexBinary.size());
+        d.m_IndexSize = 4;
+        d.m_Material = materials[m];
+        p = renderer->CreatePrimitive(d);                         // unique_ptr -> shared_ptr, as SceneManager stores them
+        emissiveTriangles += p->m_NumLights;
+    }
+    std::vector<std::shared_ptr<Lumen::ILumenMesh>> meshes(in.U32());
+    for (auto& mesh : meshes) {
+        std::vector<std::shared_ptr<Lumen::ILumenPrimitive>> ps(in.U32());
+        for (auto& p : ps) { const uint32_t pi = in.U32(); if (pi >= primitives.size()) { std::fprintf(stderr, "primitive index out of range\n"); return 64; } p = primitives[pi]; }
+        mesh = renderer->CreateMesh(ps);
+    }
+    // Application.cpp:134-146: the scene, its instances, the camera
+    std::shared_ptr<Lumen::ILumenScene> scene = renderer->CreateScene();
+    const uint32_t nInst = in.U32();
+    for (uint32_t i = 0; i < nInst; i++) {
+        const uint32_t m = in.U32();
+        float xf[16], rad[4]; int32_t mode, overrideMaterial;
+        in.Bytes(xf, sizeof xf); in.Bytes(&mode, 4); in.Bytes(rad, sizeof rad); in.Bytes(&overrideMaterial, 4);
+        if (m >= meshes.size()) { std::fprintf(stderr, "mesh index out of range\n"); return 64; }
+        Lumen::MeshInstance* inst = scene->AddMesh();
+        inst->SetMesh(meshes[m]);
+        glm::mat4 world;                                          // the file holds row-major matrices, glm is column-major
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) world[c][r] = xf[4 * r + c];
+        inst->m_Transform = world;
+        if (overrideMaterial >= 0) inst->SetOverrideMaterial(materials[static_cast<size_t>(overrideMaterial)]);
+        inst->SetEmissiveness(Lumen::MeshInstance::Emissiveness(static_cast<Lumen::EmissionMode>(mode), glm::vec3(rad[0], rad[1], rad[2]), rad[3]));
+    }
+    renderer->m_Scene = scene;
+    const glm::mat3 basis(glm::vec3(cam[3], cam[4], cam[5]), glm::vec3(cam[6], cam[7], cam[8]), glm::vec3(cam[9], cam[10], cam[11]));   // columns right / up / forward (Camera.cpp:128-140)
+    scene->m_Camera->SetRotation(glm::quat_cast(basis));
+    scene->m_Camera->SetPosition(glm::vec3(cam[0], cam[1], cam[2]));
+
+    // OutputLayer.cpp:492-495 pushes the blend mode every update; Application.cpp:152 starts the renderer; LumenApp::Run's loop
+    // calls PerformDeferredOperations once per displayed frame (LumenApp.cpp:50-78 -> OutputLayer.cpp:119-168)
+    renderer->SetBlendMode(true);
+    renderer->StartRendering();
+    for (int k = 0; k < frames; k++) renderer->PerformDeferredOperations();
+
+    uint32_t w = 0, h = 0;
+    const std::vector<uint8_t> rgba = renderer->GetOutputTexturePixels(w, h);       // OutputLayer.cpp:882-896 (the screenshot path)
+    std::FILE* o = std::fopen(argv[6], "wb");
+    if (!o) { std::perror(argv[6]); return 64; }
+    std::fprintf(o, "P6\n%u %u\n255\n", w, h);
+    for (size_t i = 0; i < static_cast<size_t>(w) * h; i++) std::fwrite(rgba.data() + 4 * i, 1, 3, o);
+    std::fclose(o);
+    const FrameStats stats = renderer->GetLastFrameStats();
+    std::printf("%ux%u, depth %u, %d frames, %u emissive triangles, frame id %llu\n", w, h, depth, frames, emissiveTriangles, static_cast<unsigned long long>(stats.m_Id));
+    return 0;
+}

@@ -1,0 +1,1 @@
+#include "../glm_min.h"

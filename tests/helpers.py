@@ -88,3 +88,16 @@ def build_c_example(tmp_path):
     build = subprocess.run(cmd, capture_output=True, text=True)
     assert build.returncode == 0, build.stderr[-3000:]
     return exe
+
+
+def build_sandbox_driver(tmp_path):
+    """examples/sandbox_driver.cpp (the Sandbox call sequence through include/lumen_mi_renderer.hpp) built against the minimal interface
+    headers of examples/sandbox_min/ — no reference tree, no glm needed — and linked with the product library."""
+    import subprocess
+    exe = str(tmp_path / "sandbox_driver")
+    libdir = os.path.join(ROOT, "lumenrenderer_amd")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "examples", "sandbox_min"),
+           os.path.join(ROOT, "examples", "sandbox_driver.cpp"), "-o", exe, "-L" + libdir, "-llumen_mi", "-Wl,-rpath," + libdir]
+    build = subprocess.run(cmd, capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-3000:]
+    return exe

@@ -360,6 +360,36 @@ def test_plain_c_caller_of_the_abi_renders_the_oracle_pixels(tmp_path):
     o.close()
 
 
+def test_reference_shaped_adapter_renders_the_c_example_picture(tmp_path):
+    """The reference-side binding executed on the GPU: examples/sandbox_driver.cpp drives include/lumen_mi_renderer.hpp (class
+    MI355X::Renderer : public LumenRenderer) through Sandbox's call sequence — Init, CreateDefaultResources, CreateTexture / Material /
+    Primitive / Mesh, CreateScene + AddMesh + SetMesh, the scene's camera, StartRendering, PerformDeferredOperations per frame,
+    GetOutputTexturePixels — built against the minimal interface headers of examples/sandbox_min/ (the reference tree does not exist on
+    this box; the build container links the same two files against the real headers and sources).  The picture must equal, byte for
+    byte, the one the plain-C caller of the C ABI renders from the same scene file — and both equal the oracle's pixels."""
+    import subprocess
+    from helpers import build_c_example, build_sandbox_driver
+    from lumenrenderer_amd.scenes import write_scene_file
+    d = cornell()
+    scene = str(tmp_path / "cornell.slm"); write_scene_file(d, scene)
+    cexe, xexe = build_c_example(tmp_path), build_sandbox_driver(tmp_path)
+    W, H, D, F = 112, 80, 5, 3
+    outs = []
+    for exe, name in ((cexe, "c.ppm"), (xexe, "cpp.ppm")):
+        out = str(tmp_path / name)
+        run = subprocess.run([exe, scene, str(W), str(H), str(D), str(F), out], capture_output=True, text=True, timeout=300)
+        assert run.returncode == 0, (run.stdout[-1000:], run.stderr[-2000:])
+        outs.append(open(out, "rb").read())
+        assert f"{W}x{H}" in run.stdout
+    assert outs[0] == outs[1] and len(outs[0]) > W * H * 3
+    o = oracle_from(d, W, H, D, blend=True)
+    for _ in range(F):
+        assert o.trace_frame() == 0
+    want = o.output_pixels()[..., :3].tobytes()
+    assert outs[1].endswith(want)
+    o.close()
+
+
 def test_screenshot_of_the_output_matches_the_oracle_pixels(tmp_path):
     """OutputLayer::MakeScreenshot (Sandbox OutputLayer.cpp:882-896) over GetOutputTexturePixels: the PNG holds the oracle's
     sRGB8 output with the display gamma applied."""
