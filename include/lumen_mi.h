@@ -119,6 +119,9 @@ int lumen_mi_perform_deferred_operations(lumen_mi_renderer*);   /* PerformDeferr
 /* ---- readback */
 int lumen_mi_get_output_pixels(lumen_mi_renderer*, uint8_t* rgba8, size_t capacity_bytes, uint32_t* w, uint32_t* h);   /* GetOutputTexturePixels LumenRenderer.h:176 */
 int lumen_mi_get_radiance(lumen_mi_renderer*, float* rgba32f, size_t capacity_bytes);     /* merged fp32 radiance of the render window (no reference equivalent; parity checks) */
+/* The same radiance as the reference STORES it: binary16 RGBA, round to nearest even (its pixel buffers are half4 surfaces,
+ * GPUMergeOutputChannels.cu:5-88, Half4.h:9-96).  8 bytes per pixel of the render window. */
+int lumen_mi_get_radiance_half4(lumen_mi_renderer*, uint16_t* rgba16f, size_t capacity_bytes);
 int lumen_mi_copy_radiance_device(lumen_mi_renderer*, void* device_rgba32f);              /* same, device-to-device on the renderer's stream (RCCL gather source) */
 int lumen_mi_get_channel(lumen_mi_renderer*, int channel, float* rgba32f, size_t capacity_bytes);   /* 0 DIRECT, 1 INDIRECT */
 int lumen_mi_get_gbuffer(lumen_mi_renderer*, float* planes8x4, size_t capacity_bytes);   /* depth-0 surface data of the last frame, pixel-major [n][8][4] */

@@ -61,6 +61,7 @@ SYMBOLS = {
     "lumen_mi_trace_frame": [_R], "lumen_mi_trace_frame_async": [_R], "lumen_mi_synchronize": [_R],
     "lumen_mi_start_rendering": [_R], "lumen_mi_stop_rendering": [_R], "lumen_mi_perform_deferred_operations": [_R],
     "lumen_mi_get_output_pixels": [_R, _U8P, C.c_size_t, _U32P, _U32P], "lumen_mi_get_radiance": [_R, _FP, C.c_size_t],
+    "lumen_mi_get_radiance_half4": [_R, C.POINTER(C.c_uint16), C.c_size_t],
     "lumen_mi_copy_radiance_device": [_R, C.c_void_p], "lumen_mi_get_channel": [_R, C.c_int, _FP, C.c_size_t],
     "lumen_mi_get_gbuffer": [_R, _FP, C.c_size_t],
     "lumen_mi_get_frame_stat": [_R, C.c_char_p, _U64P], "lumen_mi_get_counters": [_R, _U64P, C.c_uint32],

@@ -906,6 +906,19 @@ KN(lm_k_export_aux)(LmFrame fr, int cur, float minD, float maxD, float* __restri
     }
 }
 
+// The merged radiance as the reference stores it: its pixel buffers are half4 surfaces (GPUMergeOutputChannels.cu:5-88 works on
+// half4Ushort4; Half4.h:9-96 converts with __float2half = round to nearest even).  One rounding of the fp32 result — the report
+// SURVEY.md §8 c6 asks for beside the fp32 contract (the reference's own chain of fp16 adds is order-dependent and racy, F9).
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_export_half4)(const float4* __restrict__ src, uint2* __restrict__ dst, uint32_t n)
+{
+    const uint32_t stride = gridDim.x * LM_BLOCK;
+    for (uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x; i < n; i += stride) {
+        const float4 c = src[i];
+        dst[i] = make_uint2(lm_f32_to_f16(c.x) | (lm_f32_to_f16(c.y) << 16), lm_f32_to_f16(c.z) | (lm_f32_to_f16(c.w) << 16));
+    }
+}
+
 // Multi-GPU seams: a single GPU advances the reservoir swap chain once per wave that holds a ray ANYWHERE in the image.  A rank
 // only sees its window, so the ranks exchange the number of waves they executed (export), take the maximum (all-reduce) and
 // advance by the difference (import).
@@ -1128,6 +1141,7 @@ static void l_test_math(hipStream_t s, uint32_t n, int fn, const float* x, const
 static void l_history_copy(hipStream_t s, int g, LmFrame fr, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, float4* buf, int import)
 { hipLaunchKernelGGL(KN(lm_k_history_copy), LM_GRID(g), fr, x0, y0, w, h, buf, import); }
 static void l_wave_sync(hipStream_t s, int* swap, int* io, int import) { hipLaunchKernelGGL(KN(lm_k_wave_sync), dim3(1), dim3(64), 0, s, swap, io, import); }
+static void l_export_half4(hipStream_t s, int g, const float4* src, uint2* dst, uint32_t n) { hipLaunchKernelGGL(KN(lm_k_export_half4), LM_GRID(g), src, dst, n); }
 static void l_build_top(hipStream_t s, const LmNode4* nodes, LmNode4* top) { hipLaunchKernelGGL(KN(lm_k_build_top), dim3(1), dim3(64), 0, s, nodes, top); }
 static void l_spin(hipStream_t s, uint32_t ticks) { hipLaunchKernelGGL(KN(lm_k_spin), dim3(1), dim3(64), 0, s, ticks); }
 
@@ -1138,6 +1152,6 @@ extern "C" const LmKernelTable* lm_kernel_table()
 #endif
 {
     static const LmKernelTable t = {l_primary, l_trace_closest, l_extract0, l_shade_wave, l_trace_shadow, l_path_tail, l_fill_bags, l_pick_primary,
-                                    l_trace_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_export_aux, l_refit_tris, l_refit_quant, l_refit_level, l_test_bsdf, l_test_math, l_spin, l_history_copy, l_wave_sync, l_test_restir, l_build_top};
+                                    l_trace_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_export_aux, l_refit_tris, l_refit_quant, l_refit_level, l_test_bsdf, l_test_math, l_spin, l_history_copy, l_wave_sync, l_test_restir, l_build_top, l_export_half4};
     return &t;
 }

@@ -30,6 +30,7 @@ struct LmKernelTable {
     void (*wave_sync)(hipStream_t, int* swap, int* io, int import);
     void (*test_restir)(hipStream_t, int mode, uint32_t n, const float* a, const float* b, const uint32_t* c, uint32_t m, float* out);
     void (*build_top)(hipStream_t, const LmNode4* nodes, LmNode4* top);       // top-of-tree table of the queue traversal kernels (after every change of `nodes`)
+    void (*export_half4)(hipStream_t, int grid, const float4* src, uint2* dst, uint32_t n);      // merged radiance rounded to the reference's half4 storage
 };
 extern "C" const LmKernelTable* lm_kernel_table();
 extern "C" const LmKernelTable* lm_kernel_table_instrumented();

@@ -442,6 +442,23 @@ static int copyOut(lumen_mi_renderer* r, OutPlane which, void* host, size_t capa
 }
 int lumen_mi_get_output_pixels(lumen_mi_renderer* r, uint8_t* rgba8, size_t cap, uint32_t* w, uint32_t* h) { return copyOut(r, OUT_SRGB8, rgba8, cap, w, h); }
 int lumen_mi_get_radiance(lumen_mi_renderer* r, float* out, size_t cap) { return copyOut(r, OUT_RADIANCE, out, cap, nullptr, nullptr); }
+int lumen_mi_get_radiance_half4(lumen_mi_renderer* r, uint16_t* out, size_t cap)
+{
+    if (!r || !out) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    ApiLock lk(r);
+    const uint32_t n = r->fr.n;
+    if (!r->fr.combined || !r->allocN) return fail(LUMEN_MI_ERR_STATE, "no frame has been traced yet");
+    if (cap < (size_t)n * 8) return fail(LUMEN_MI_ERR_INVALID, "buffer too small");
+    int rc = syncAndCollect(r); if (rc) return rc;
+    DevBuf<uint2> d;
+    if (d.ensure(n)) return fail(LUMEN_MI_ERR_DEVICE, "export allocation failed");
+    r->K->export_half4(r->stream, r->gridFor(n, 8), r->fr.combined, d.p, n);
+    LM_HIP(hipGetLastError());
+    LM_HIP(hipStreamSynchronize(r->stream));
+    LM_HIP(hipMemcpy(out, d.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    d.release();
+    return 0;
+}
 int lumen_mi_get_channel(lumen_mi_renderer* r, int ch, float* out, size_t cap)
 {
     if (!r || ch < 0 || ch > 1) return fail(LUMEN_MI_ERR_INVALID, "channel must be 0 (DIRECT) or 1 (INDIRECT)");

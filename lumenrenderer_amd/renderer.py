@@ -235,6 +235,13 @@ class LumenRendererMI:
         check(self.lib, self.lib.lumen_mi_get_radiance(self.h, _fp(out), out.nbytes))
         return out
 
+    def GetRadianceHalf4(self):
+        """The merged radiance rounded once to binary16 — what the reference's half4 pixel buffers would hold (as float16 array)."""
+        hh, ww = self._window_shape()
+        out = np.zeros((hh, ww, 4), np.uint16)
+        check(self.lib, self.lib.lumen_mi_get_radiance_half4(self.h, out.ctypes.data_as(C.POINTER(C.c_uint16)), out.nbytes))
+        return out.view(np.float16)
+
     def GetChannel(self, ch):
         hh, ww = self._window_shape()
         out = np.zeros((hh, ww, 4), np.float32)
