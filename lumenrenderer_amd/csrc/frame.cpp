@@ -138,7 +138,8 @@ int traceFrameAsync(R* r)
     // sets rotate, so that the next frame's extraction does not wait for this frame's temporal pass
     const int currentIndex = r->gbufIndex, temporalIndex = (r->gbufIndex + 2) % 3;
     const bool blend = r->settings.blend_output != 0;
-    const int fastRs = r->fastResample;
+    // 0 exact; 1 fast, common launch only (no material can produce a surface outside the contracted evaluation); 2 fast, common + rare launch
+    const int fastRs = r->fastResample ? (r->anyRareMaterial ? 2 : 1) : 0;
 
     // camera (Camera.cpp:79-93,122-140; aspect = render W/H, WaveFrontRenderer.cpp:577)
     LmCamera cam;
@@ -286,6 +287,14 @@ int traceFrameAsync(R* r)
             break;
         } else {
             uint32_t* shCount = fr.counters + LM_CNT_SHADOW(depth);
+            if (r->sortRays > 0 && (int)depth <= r->sortRays) {
+                // reorder this wave's rays into the other queue (free: its rays were consumed by the previous shading launch on this stream)
+                if (!r->dSortBins.p) { if (r->dSortBins.ensure(2 * 4096)) return fail(LUMEN_MI_ERR_DEVICE, "sort bins allocation failed"); LM_HIP(hipMemsetAsync(r->dSortBins.p, 0, 2 * 4096 * sizeof(uint32_t), sx)); }
+                evBegin2(r, 2, ev, sx);
+                Z(sx); K->sort_rays(sx, r->gridFor(fr.n / 4u, 8), r->dscene, fr.rayO[q], fr.rayD[q], fr.rayC[q], fr.rayO[q ^ 1], fr.rayD[q ^ 1], fr.rayC[q ^ 1], inCount, r->dSortBins.p);
+                evEnd2(r, ev, sx);
+                q ^= 1;
+            }
             evBegin2(r, 0, ev, sx);
             Z(sx); K->trace_closest(sx, gridAux, scx, fr.rayO[q], fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters, r->refillBelow);
             evEnd2(r, ev, sx);

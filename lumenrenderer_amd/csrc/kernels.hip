@@ -1050,6 +1050,60 @@ KN(lm_k_refit_level)(LmScene sc, const uint32_t* __restrict__ levelNodes, uint32
     nodeBox[2u * n + 1u] = v4(nhi, 0.f);
 }
 
+// Ray reorder between waves (tuning key "sort_rays"): a counting sort of a continuation-ray queue by (origin cell, direction octant), so that
+// the 64 rays a wavefront traces together start in the same part of the scene and head the same way.  Three launches: count per bin
+// (4 096 bins = 8 x 8 x 8 cells of the scene box x 8 octants, non-returning atomics), exclusive scan, scatter (one returning atomic per
+// ray on its bin's cursor).  The order inside a bin is whatever the atomics give — every consumer finds its pixel in rayD.w, so results
+// do not depend on it (test_schedules_do_not_change_results).
+#define LM_SORT_BINS 4096u
+__device__ __forceinline__ uint32_t lm_sort_key(const LmScene& sc, const float4& o, const float4& d)
+{
+    uint32_t key = (d.x < 0.f ? 1u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 4u : 0u);
+    const float c[3] = {o.x, o.y, o.z};
+    for (int k = 0; k < 3; k++) {
+        const float rel = (c[k] - sc.quant[k]) / (sc.quant[3 + k] * 65535.0f);
+        const int cell = min(7, max(0, (int)(rel * 8.0f)));
+        key |= (uint32_t)cell << (3 + 3 * k);
+    }
+    return key;
+}
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_sort_count)(LmScene sc, const float4* __restrict__ rayO, const float4* __restrict__ rayD, const uint32_t* __restrict__ countPtr, uint32_t* bins)
+{
+    const uint32_t n = *countPtr, stride = gridDim.x * LM_BLOCK;
+    for (uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x; i < n; i += stride) atomicAdd(bins + lm_sort_key(sc, rayO[i], rayD[i]), 1u);
+}
+// bins -> exclusive prefix in cursors; bins are zeroed for the next use.  One block of 1024 threads, 4 bins each.
+extern "C" __global__ void __launch_bounds__(1024)
+KN(lm_k_sort_scan)(uint32_t* bins, uint32_t* cursors)
+{
+    __shared__ uint32_t s_part[1024];
+    const uint32_t t = threadIdx.x;
+    uint32_t v[4], sum = 0;
+    for (int k = 0; k < 4; k++) { v[k] = bins[4u * t + k]; bins[4u * t + k] = 0u; sum += v[k]; }
+    s_part[t] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1) {
+        const uint32_t add = t >= off ? s_part[t - off] : 0u;
+        __syncthreads();
+        s_part[t] += add;
+        __syncthreads();
+    }
+    uint32_t base = s_part[t] - sum;
+    for (int k = 0; k < 4; k++) { cursors[4u * t + k] = base; base += v[k]; }
+}
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_sort_scatter)(LmScene sc, const float4* __restrict__ srcO, const float4* __restrict__ srcD, const float4* __restrict__ srcC,
+                      float4* __restrict__ dstO, float4* __restrict__ dstD, float4* __restrict__ dstC, const uint32_t* __restrict__ countPtr, uint32_t* cursors)
+{
+    const uint32_t n = *countPtr, stride = gridDim.x * LM_BLOCK;
+    for (uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x; i < n; i += stride) {
+        const float4 o = srcO[i], d = srcD[i], c = srcC[i];
+        const uint32_t pos = atomicAdd(cursors + lm_sort_key(sc, o, d), 1u);
+        dstO[pos] = o; dstD[pos] = d; dstC[pos] = c;
+    }
+}
+
 // Top-of-tree table for the queue traversal kernels (lm_layout.h LM_TOP_NODES): the first LM_TOP_NODES inner nodes in breadth-first
 // order, with child references rewritten to table slots where the child made it into the table.  One wavefront, level by level
 // (slots are handed out in lane order: deterministic); run whenever the node array changes (build, refit, assembly).
@@ -1116,14 +1170,14 @@ static void l_path_tail(hipStream_t s, int g, LmScene sc, LmFrame fr, int inQ, c
 static void l_trace_shadow(hipStream_t s, int g, LmScene sc, LmFrame fr, const uint32_t* cnt, float tmin, int refillBelow) { hipLaunchKernelGGL(KN(lm_k_trace_shadow), LM_GRID(g), sc, fr, cnt, tmin, refillBelow); }
 static void l_fill_bags(hipStream_t s, LmScene sc, LmFrame fr, uint32_t seed, uint32_t total) { hipLaunchKernelGGL(KN(lm_k_fill_bags), LM_GRID((total + LM_BLOCK - 1) / LM_BLOCK), sc, fr, seed, total); }
 static void l_pick_primary(hipStream_t s, int tiles, LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount, int fast)
-{ if (fast) { hipLaunchKernelGGL(KN(lm_k_pick_primary_fast), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount); hipLaunchKernelGGL(KN(lm_k_pick_primary_rare), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount); } else hipLaunchKernelGGL(KN(lm_k_pick_primary), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount); }
+{ if (fast) { hipLaunchKernelGGL(KN(lm_k_pick_primary_fast), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount); if (fast > 1) hipLaunchKernelGGL(KN(lm_k_pick_primary_rare), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount); } else hipLaunchKernelGGL(KN(lm_k_pick_primary), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount); }
 static void l_trace_shade(hipStream_t s, int g, LmScene sc, LmFrame fr, int rc, const uint32_t* cnt, int refillBelow, int pass) { hipLaunchKernelGGL(KN(lm_k_restir_trace_shade), LM_GRID(g), sc, fr, rc, cnt, refillBelow, pass); }
 static void l_temporal(hipStream_t s, int g, LmFrame fr, int cur, int prev, int rc, int rp, int rf, uint32_t seed, uint32_t* visCount, int fast)
-{ if (fast) { hipLaunchKernelGGL(KN(lm_k_restir_temporal_fast), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); hipLaunchKernelGGL(KN(lm_k_restir_temporal_rare), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); } else hipLaunchKernelGGL(KN(lm_k_restir_temporal), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); }
+{ if (fast) { hipLaunchKernelGGL(KN(lm_k_restir_temporal_fast), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); if (fast > 1) hipLaunchKernelGGL(KN(lm_k_restir_temporal_rare), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); } else hipLaunchKernelGGL(KN(lm_k_restir_temporal), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); }
 static void l_spatial(hipStream_t s, int g, LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin, int fast)
-{ if (fast) { hipLaunchKernelGGL(KN(lm_k_restir_spatial_fast), LM_GRID(g), fr, cur, rin, rout, seed, margin); hipLaunchKernelGGL(KN(lm_k_restir_spatial_rare), LM_GRID(g), fr, cur, rin, rout, seed, margin); } else hipLaunchKernelGGL(KN(lm_k_restir_spatial), LM_GRID(g), fr, cur, rin, rout, seed, margin); }
+{ if (fast) { hipLaunchKernelGGL(KN(lm_k_restir_spatial_fast), LM_GRID(g), fr, cur, rin, rout, seed, margin); if (fast > 1) hipLaunchKernelGGL(KN(lm_k_restir_spatial_rare), LM_GRID(g), fr, cur, rin, rout, seed, margin); } else hipLaunchKernelGGL(KN(lm_k_restir_spatial), LM_GRID(g), fr, cur, rin, rout, seed, margin); }
 static void l_combine(hipStream_t s, int g, LmFrame fr, int cur, int rc, int rs, uint32_t seed, int fast)
-{ if (fast) { hipLaunchKernelGGL(KN(lm_k_restir_combine_fast), LM_GRID(g), fr, cur, rc, rs, seed); hipLaunchKernelGGL(KN(lm_k_restir_combine_rare), LM_GRID(g), fr, cur, rc, rs, seed); } else hipLaunchKernelGGL(KN(lm_k_restir_combine), LM_GRID(g), fr, cur, rc, rs, seed); }
+{ if (fast) { hipLaunchKernelGGL(KN(lm_k_restir_combine_fast), LM_GRID(g), fr, cur, rc, rs, seed); if (fast > 1) hipLaunchKernelGGL(KN(lm_k_restir_combine_rare), LM_GRID(g), fr, cur, rc, rs, seed); } else hipLaunchKernelGGL(KN(lm_k_restir_combine), LM_GRID(g), fr, cur, rc, rs, seed); }
 static void l_clear(hipStream_t s, int g, float4* p, uint32_t n) { hipLaunchKernelGGL(KN(lm_k_clear_f4), LM_GRID(g), p, n); }
 static void l_merge(hipStream_t s, int g, LmFrame fr, int blend, uint32_t blendCount, int depthMax) { hipLaunchKernelGGL(KN(lm_k_merge_output), LM_GRID(g), fr, blend, blendCount, depthMax); }
 static void l_query_any(hipStream_t s, int g, LmScene sc, const float4* o, const float4* d, uint32_t n, float tmin, uint32_t* occ, uint32_t* counters) { hipLaunchKernelGGL(KN(lm_k_query_any), LM_GRID(g), sc, o, d, n, tmin, occ, counters); }
@@ -1141,6 +1195,13 @@ static void l_test_math(hipStream_t s, uint32_t n, int fn, const float* x, const
 static void l_history_copy(hipStream_t s, int g, LmFrame fr, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, float4* buf, int import)
 { hipLaunchKernelGGL(KN(lm_k_history_copy), LM_GRID(g), fr, x0, y0, w, h, buf, import); }
 static void l_wave_sync(hipStream_t s, int* swap, int* io, int import) { hipLaunchKernelGGL(KN(lm_k_wave_sync), dim3(1), dim3(64), 0, s, swap, io, import); }
+static void l_sort_rays(hipStream_t s, int g, LmScene sc, const float4* srcO, const float4* srcD, const float4* srcC, float4* dstO, float4* dstD, float4* dstC,
+                        const uint32_t* cnt, uint32_t* bins)
+{
+    hipLaunchKernelGGL(KN(lm_k_sort_count), LM_GRID(g), sc, srcO, srcD, cnt, bins);
+    hipLaunchKernelGGL(KN(lm_k_sort_scan), dim3(1), dim3(1024), 0, s, bins, bins + LM_SORT_BINS);
+    hipLaunchKernelGGL(KN(lm_k_sort_scatter), LM_GRID(g), sc, srcO, srcD, srcC, dstO, dstD, dstC, cnt, bins + LM_SORT_BINS);
+}
 static void l_export_half4(hipStream_t s, int g, const float4* src, uint2* dst, uint32_t n) { hipLaunchKernelGGL(KN(lm_k_export_half4), LM_GRID(g), src, dst, n); }
 static void l_build_top(hipStream_t s, const LmNode4* nodes, LmNode4* top) { hipLaunchKernelGGL(KN(lm_k_build_top), dim3(1), dim3(64), 0, s, nodes, top); }
 static void l_spin(hipStream_t s, uint32_t ticks) { hipLaunchKernelGGL(KN(lm_k_spin), dim3(1), dim3(64), 0, s, ticks); }
@@ -1152,6 +1213,6 @@ extern "C" const LmKernelTable* lm_kernel_table()
 #endif
 {
     static const LmKernelTable t = {l_primary, l_trace_closest, l_extract0, l_shade_wave, l_trace_shadow, l_path_tail, l_fill_bags, l_pick_primary,
-                                    l_trace_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_export_aux, l_refit_tris, l_refit_quant, l_refit_level, l_test_bsdf, l_test_math, l_spin, l_history_copy, l_wave_sync, l_test_restir, l_build_top, l_export_half4};
+                                    l_trace_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_export_aux, l_refit_tris, l_refit_quant, l_refit_level, l_test_bsdf, l_test_math, l_spin, l_history_copy, l_wave_sync, l_test_restir, l_build_top, l_export_half4, l_sort_rays};
     return &t;
 }

@@ -14,7 +14,8 @@ struct LmKernelTable {
     void (*trace_shade)(hipStream_t, int grid, LmScene, LmFrame, int rc, const uint32_t* count, int refillBelow, int pass);
     void (*temporal)(hipStream_t, int tiles, LmFrame, int cur, int prev, int rc, int rp, int rf, uint32_t seed, uint32_t* visCount, int fast);
     void (*spatial)(hipStream_t, int tiles, LmFrame, int cur, int rin, int rout, uint32_t seed, int margin, int fast);
-    void (*combine)(hipStream_t, int tiles, LmFrame, int cur, int rc, int rs, uint32_t seed, int fast);     // fast: hardware rcp / rsq / sqrt in the resampling target function (LmFast, lm_bsdf.h)
+    void (*combine)(hipStream_t, int tiles, LmFrame, int cur, int rc, int rs, uint32_t seed, int fast);     // fast: 0 exact; 1 contracted evaluation with hardware rcp / rsq / sqrt (LmFast / LmQuick, lm_bsdf.h);
+                                                                                                 // 2 the same + the second, exact launch for surfaces the contracted evaluation does not cover
     void (*clear)(hipStream_t, int grid, float4* p, uint32_t n);
     void (*merge)(hipStream_t, int grid, LmFrame, int blend, uint32_t blendCount, int depthMax);
     void (*query_any)(hipStream_t, int grid, LmScene, const float4* o, const float4* d, uint32_t n, float tmin, uint32_t* occluded, uint32_t* counters);
@@ -31,6 +32,9 @@ struct LmKernelTable {
     void (*test_restir)(hipStream_t, int mode, uint32_t n, const float* a, const float* b, const uint32_t* c, uint32_t m, float* out);
     void (*build_top)(hipStream_t, const LmNode4* nodes, LmNode4* top);       // top-of-tree table of the queue traversal kernels (after every change of `nodes`)
     void (*export_half4)(hipStream_t, int grid, const float4* src, uint2* dst, uint32_t n);      // merged radiance rounded to the reference's half4 storage
+    // counting sort of a ray queue by (origin cell, direction octant) into another queue; bins: 2 x 4096 words, zero on entry and on return
+    void (*sort_rays)(hipStream_t, int grid, LmScene, const float4* srcO, const float4* srcD, const float4* srcC, float4* dstO, float4* dstD, float4* dstC,
+                      const uint32_t* count, uint32_t* bins);
 };
 extern "C" const LmKernelTable* lm_kernel_table();
 extern "C" const LmKernelTable* lm_kernel_table_instrumented();

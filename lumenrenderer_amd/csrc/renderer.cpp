@@ -25,6 +25,7 @@ int lumen_mi_create(lumen_mi_renderer** out)
     if (const char* e = getenv("LUMEN_MI_TAIL_BELOW")) (*out)->tailBelow = atoi(e);
     if (const char* e = getenv("LUMEN_MI_PICK_AHEAD")) (*out)->pickAhead = atoi(e);
     if (const char* e = getenv("LUMEN_MI_SHADOW_ON_WAVE")) (*out)->shadowOnWave = atoi(e);
+    if (const char* e = getenv("LUMEN_MI_SORT_RAYS")) (*out)->sortRays = std::max(0, atoi(e));
     if (const char* e = getenv("LUMEN_MI_FAST_RESAMPLE")) (*out)->fastResample = atoi(e) != 0;
     if (const char* e = getenv("LUMEN_MI_TAIL_LANES")) (*out)->tailLanes = std::max(1, std::min(64, atoi(e)));
     return 0;
@@ -105,7 +106,7 @@ int lumen_mi_destroy(lumen_mi_renderer* r)
         for (auto& b : r->dResC) b.release();
         for (auto& b : r->dMotion) b.release();
         for (int i = 0; i < 2; i++) { r->dDirect[i].release(); r->dIndirect[i].release(); }
-        r->dCombined.release(); r->dHits.release(); r->dCounters.release(); r->dSwap.release(); r->dOutput.release(); r->dBags.release();
+        r->dSortBins.release(); r->dCombined.release(); r->dHits.release(); r->dCounters.release(); r->dSwap.release(); r->dOutput.release(); r->dBags.release();
         for (auto& e : r->evPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     }
     delete r;
@@ -121,6 +122,7 @@ int lumen_mi_create_texture(lumen_mi_renderer* r, const void* rgba8, uint32_t w,
     Texture t; t.w = w; t.h = h; t.srgb = normalize != 0;          // a_Normalize selects sRGB decode (PTTexture.cpp:57-73)
     t.px.resize((size_t)w * h);
     memcpy(t.px.data(), rgba8, (size_t)w * h * 4);
+    for (uint32_t p : t.px) t.minG = std::min<uint8_t>(t.minG, (uint8_t)((p >> 8) & 255u));
     r->textures.push_back(std::move(t));
     r->texturesDirty = true;
     *out = mkh(H_TEXTURE, r->textures.size() - 1);
@@ -174,6 +176,11 @@ static int fillMaterial(lumen_mi_renderer* r, const lumen_mi_material_data* d, M
     // PTMaterial::CreateDeviceMaterial (PTMaterial.cpp:97-148): the clear-coat-roughness texture overwrites the clear-coat
     // slot and the roughness slot stays a null handle; kept for parity
     v.tex[0] = tCCR; v.tex[1] = -1; v.tex[2] = tTr; v.tex[3] = tDiff; v.tex[4] = tEm; v.tex[5] = tMR; v.tex[6] = tNorm; v.tex[7] = tTint;
+    // Can surface extraction produce a material outside the contracted ReSTIR evaluation?  Transmission / clear coat are factor x texel
+    // (GPUExtractSurfaceData.cu:183-196): 0 when the factor byte is 0.  Roughness is texel.g x factor re-packed by truncation: the byte is
+    // 0 (mirror-like: the opaque stack is absent) iff the product is below 1/255; bilinear filtering never goes below the smallest texel.
+    const float baseRough = (float)(v.p[0] >> 24) * (1.0f / 255.0f), minG = (float)r->textures[(size_t)tMR].minG / 255.0f;
+    m.mayBeRare = (v.p[2] & 0x00ff00ffu) != 0u || (uint32_t)(minG * baseRough * 255.f) == 0u;
     return 0;
 }
 
@@ -185,6 +192,7 @@ int lumen_mi_create_material(lumen_mi_renderer* r, const lumen_mi_material_data*
     const int rc = fillMaterial(r, d, m);
     if (rc) return rc;
     r->materials.push_back(m);
+    r->anyRareMaterial |= m.mayBeRare;
     r->materialsDirty = true;
     *out = mkh(H_MATERIAL, r->materials.size() - 1);
     return 0;
@@ -200,6 +208,7 @@ int lumen_mi_update_material(lumen_mi_renderer* r, lumen_mi_handle material, con
     const int rc = fillMaterial(r, d, m);
     if (rc) return rc;
     r->materials[idx] = m;
+    r->anyRareMaterial |= m.mayBeRare;
     r->materialsDirty = true;
     // the emissive classification of primitives is a function of their material (FindEmissives at CreatePrimitive time in the
     // reference; re-evaluated here so that the light list follows the edit)
@@ -558,6 +567,7 @@ int lumen_mi_get_counters(lumen_mi_renderer* r, uint64_t* out, uint32_t n)
     for (int k = 0; k < 4; k++) v[41 + k] = (uint64_t)c[LM_CNT_OCC + 2 * k] | ((uint64_t)c[LM_CNT_OCC + 2 * k + 1] << 32);
     v[48] = c[LM_CNT_RESTIR(0)]; v[49] = c[LM_CNT_RESTIR(1)];
     v[50] = r->refits; v[51] = r->assemblies;                                          // GPU refits / instance-level assemblies since creation
+    v[52] = c[LM_CNT_RARE]; v[53] = r->anyRareMaterial ? 1u : 0u;                      // depth-0 surfaces outside the contracted ReSTIR evaluation / can any material produce one
     for (uint32_t i = 0; i < n && i < 64; i++) out[i] = v[i];
     return 0;
 }
@@ -589,6 +599,7 @@ int lumen_mi_set_tuning(lumen_mi_renderer* r, const char* key, int value)
     else if (k == "assemble") r->assembleEnabled = value;
     else if (k == "shadow_on_wave") { if (r->initialised) { int rc = syncAndCollect(r); if (rc) return rc; } r->shadowOnWave = value; }
     else if (k == "fast_resample") { if (r->initialised) { int rc = syncAndCollect(r); if (rc) return rc; } r->fastResample = value != 0; }
+    else if (k == "sort_rays") { if (r->initialised) { int rc = syncAndCollect(r); if (rc) return rc; } r->sortRays = std::max(0, value); }
     else if (k == "refill") r->refillBelow = value;
     else if (k == "refill_visibility") r->refillVisibility = value;
     else if (k == "refill_primary") r->refillPrimary = value;

@@ -43,8 +43,12 @@ inline bool unh(lumen_mi_handle h, HType t, size_t n, size_t& idx) { if ((h >> 5
 struct Vertex48 { float pos[3]; float uv[2]; float normal[3]; float tangent[4]; };
 static_assert(sizeof(Vertex48) == 48, "Vertex layout (ModelStructs.h:21-28)");
 
-struct Texture { uint32_t w, h; bool srgb; std::vector<uint32_t> px; };
-struct Material { LmDevMaterial dev; float emissiveColor[3]; };
+struct Texture { uint32_t w, h; bool srgb; std::vector<uint32_t> px; uint8_t minG = 255; };      // minG: smallest green texel (roughness channel of a metal-roughness map)
+struct Material {
+    LmDevMaterial dev; float emissiveColor[3];
+    bool mayBeRare = false;     // can a surface of this material fall outside the contracted ReSTIR evaluation (lm_bsdf.h lm_quick_contracts)?  dielectric
+                                // or clear-coat factor > 0, or a roughness byte that can truncate to 0 given the smallest roughness texel
+};
 struct Primitive { std::vector<Vertex48> verts; std::vector<uint32_t> idx; size_t material; std::vector<uint8_t> emissive; uint32_t numLights = 0; bool containEmissive = false; };
 struct Mesh {
     std::vector<size_t> prims;
@@ -173,6 +177,9 @@ struct lumen_mi_renderer {
     bool entriesDirty = false;              // emissive mode / radiance / override material of an instance changed: scene table + lights only
     uint32_t refits = 0;                    // refits since the last full build
     int refitEnabled = 1;                   // 0: every transform change triggers a full host rebuild
+    bool anyRareMaterial = false;           // some material ever created may need the second (exact) launch of the fast ReSTIR passes
+    int sortRays = 0;                       // > 0: continuation-ray queues of waves 1 .. sortRays are reordered by (origin cell, octant) before their closest-hit launch
+    DevBuf<uint32_t> dSortBins;             // 2 x 4096 words (histogram + cursors)
     int fastResample = 0;                   // 1: the ReSTIR target function and resampling weights use hardware rcp / rsq / sqrt (LmFast): within 1e-3 rel-L2
                                             // of the exact mode, not bit-identical (tuning key "fast_resample", LUMEN_MI_FAST_RESAMPLE)
 

@@ -645,8 +645,9 @@ def test_sponza_with_1024_emissive_triangles_matches_oracle():
 
 TUNINGS = [{"tail_below": 0}, {"tail_below": 1 << 30}, {"tail_below": 6000}, {"tail_below": 6000, "tail_lanes": 64},
            {"single_stream": 1, "tail_below": 0}, {"single_stream": 1}, {"refill": 0, "tail_below": 0},
-           {"pick_ahead": 0}, {"pick_ahead": 1, "tail_below": 0}, {"shadow_on_wave": 1}, {"shadow_on_wave": 1, "tail_below": 0}]
-DEEP = [{}, {"pick_ahead": 0, "tail_below": 0}, {"pick_ahead": 1, "tail_below": 1 << 30}, {"single_stream": 1}, {"shadow_on_wave": 1}]
+           {"pick_ahead": 0}, {"pick_ahead": 1, "tail_below": 0}, {"shadow_on_wave": 1}, {"shadow_on_wave": 1, "tail_below": 0},
+           {"sort_rays": 1}, {"sort_rays": 16, "tail_below": 0}, {"sort_rays": 2, "single_stream": 1, "tail_below": 6000}]
+DEEP = [{}, {"pick_ahead": 0, "tail_below": 0}, {"pick_ahead": 1, "tail_below": 1 << 30}, {"single_stream": 1}, {"shadow_on_wave": 1}, {"sort_rays": 16, "tail_below": 0}]
 
 
 @pytest.mark.parametrize("tuning", DEEP, ids=lambda t: ",".join(f"{k}={v}" for k, v in t.items()) or "default")
@@ -1054,6 +1055,9 @@ def test_fast_resampling_mode_stays_within_the_north_star_tolerance(case):
     for k in range(3):                                                # closest-hit rays, NEE shadow rays, ReSTIR visibility rays
         assert abs(int(c[k]) - int(s[k])) <= 1e-3 * max(1, int(s[k])), (case, k, c[:4], s[:4])
     assert list(c[4:4 + D]) == list(s[4:4 + D])                       # the path waves do not depend on the resampling arithmetic
+    c2 = r.GetCounters(56)
+    assert c2[52] == 0 or c2[53] == 1                                 # the second (exact) launch is only skipped when no material can need it
+    assert (c2[53] == 1) == (case == "mixed") and (c2[52] > 0) == (case == "mixed")
     if case == "mixed":
         g = r.GetGBuffer()
         p = g[..., 7, :3].copy().view(np.uint32)
