@@ -18,6 +18,9 @@
 #ifndef LM_INSTRUMENT
 #define LM_INSTRUMENT 0
 #endif
+#ifndef LM_SHADE_PRIO
+#define LM_SHADE_PRIO 3          // s_setprio of the surface-extraction / shading kernels of the wave chain: with the fast ReSTIR mode that chain is the
+#endif                           // critical path, and its VALU-heavy kernels otherwise queue behind the candidate pick on every SIMD (+1.5 % on C2)
 // the file is compiled twice into one library: kernel symbols of the counting build get a suffix
 #if LM_INSTRUMENT
 #define KN(x) x##_inst
@@ -174,6 +177,9 @@ extern "C" __global__ void __launch_bounds__(LM_BLOCK)
 KN(lm_k_extract0)(LmScene sc, LmFrame fr, LmCamera cam, int cur, uint32_t seed2, int doIndirect, int outQ, uint32_t* outCount)
 {
     __shared__ uint32_t s_tmp[5];
+#if LM_SHADE_PRIO
+    __builtin_amdgcn_s_setprio(LM_SHADE_PRIO);
+#endif
     const uint32_t stride = gridDim.x * LM_BLOCK;
     const uint32_t nIter = (fr.n + stride - 1u) / stride;
     for (uint32_t it = 0; it < nIter; it++) {
@@ -232,6 +238,9 @@ KN(lm_k_shade_wave)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict_
                 uint32_t* outCount, uint32_t* shadowCount)
 {
     __shared__ uint32_t s_tmp[5];
+#if LM_SHADE_PRIO
+    __builtin_amdgcn_s_setprio(LM_SHADE_PRIO);
+#endif
     const uint32_t n = *inCount;
     const uint32_t stride = gridDim.x * LM_BLOCK;
     const uint32_t nIter = (n + stride - 1u) / stride;
@@ -486,6 +495,10 @@ KN(lm_k_pick_primary)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, ui
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
 KN(lm_k_pick_primary_fast)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount)
 {
+#ifdef LM_PICK_LDS_PAD
+    __shared__ uint32_t s_pad[LM_PICK_LDS_PAD / 4];      // occupancy cap (A/B knob): fewer resident blocks of this VALU-saturating kernel
+    if (seed == 0xffffffffu && visCount == nullptr) s_pad[threadIdx.x] = 1u;
+#endif
     __shared__ uint2 s_bag[1000];
     __shared__ uint32_t s_tmp[5];
     lm_pick_primary_body<LmFast, LM_COMMON>(sc, fr, cur, rc, seed, visCount, s_bag, s_tmp);
