@@ -708,7 +708,10 @@ __device__ __forceinline__ void lm_restir_spatial_body(const LmFrame& fr, int cu
 }
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_SPATIAL_WAVES)
 KN(lm_k_restir_spatial)(LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin) { lm_restir_spatial_body<LmExact, LM_ALL>(fr, cur, rin, rout, seed, margin); }
-extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_SPATIAL_WAVES)
+#ifndef LM_SPATIAL_FAST_WAVES
+#define LM_SPATIAL_FAST_WAVES 4
+#endif
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_SPATIAL_FAST_WAVES)
 KN(lm_k_restir_spatial_fast)(LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin) { lm_restir_spatial_body<LmFast, LM_COMMON>(fr, cur, rin, rout, seed, margin); }
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_SPATIAL_WAVES)
 KN(lm_k_restir_spatial_rare)(LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin) { lm_restir_spatial_body<LmExact, LM_RARE>(fr, cur, rin, rout, seed, margin); }

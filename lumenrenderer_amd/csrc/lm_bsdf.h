@@ -20,9 +20,9 @@
 //            checks against the oracle (default everywhere);
 //   LmFast   v_rcp_f32 / v_rsq_f32 / v_sqrt_f32 (1 ulp, no refinement sequences) — selectable for the ReSTIR target function
 //            (tuning key "fast_resample"), where only a 1e-3 relative-L2 agreement is required (BASELINE north_star).  For the
-//            lobes the benchmark materials use (diffuse + sheen + GGX specular) the fast policy goes further: LmQuick / lm_quick_eval
-//            evaluate the same model in contracted form (one half vector, |wo.h| cancelled out of the pdf, G and 1 / cos merged
-//            into one reciprocal, FMA contraction): 2 rsq + 4 rcp + 1 sqrt per light direction.
+//            isotropic opaque stack (diffuse + sheen + GGX specular, no clear coat) the fast policy goes further: LmQuick / lm_quick_eval
+//            evaluate the same model in contracted form (no tangent frame: three cosines from N.wo, N.wi, wo.wi; |wo.h| cancelled out of the
+//            pdf, G and 1 / cos merged into one reciprocal, FMA contraction): 2 rsq + 4 rcp + 1 sqrt per light direction.
 // With LmExact the hoisting changes no operation and no operand: results equal the unsplit evaluation bit for bit.
 #pragma once
 #include "lm_math.h"
@@ -398,25 +398,26 @@ template <class A = LmExact> LM_HD lf3 lm_evaluate_bsdf(const LmMaterial& sd, co
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Contracted evaluation (fast policy only) of the opaque stack without clear coat.  Same model, different algebra:
-//   * one half vector, in the frame: wi.h = wo.h exactly, so the diffuse / sheen lobes use it too
-//   * D  = 1 / (pi ax ay (hx^2/ax^2 + hy^2/ay^2 + hz^2)^2)                              one reciprocal, no tan / sin
-//   * lambda(wi) = (sqrt(1 + (ax^2 wx^2 + ay^2 wy^2) / wz^2) - 1) / 2                   one reciprocal, one square root
-//   * G / cos_i  = 1 / ((1 + lambda(wo) + lambda(wi)) cos_i)                            one reciprocal
-//   * specular pdf = G1(wo) |wo.h| D / |cos_o| / (4 |wo.h|) = D * [G1(wo) / (4 |cos_o|)]   no reciprocal: the bracket is per surface
-// Agreement with the exact policy: a few ulp (tests/test_gpu_parity.py holds whole frames to 1e-3 relative L2).
+// Contracted evaluation (fast policy only) of the ISOTROPIC opaque stack without clear coat.  Same model, different algebra — no tangent
+// frame at all, because with alpha_x = alpha_y every term depends on three cosines only (N.wi, N.h, wi.h):
+//   * h = (wo + wi) / |wo + wi| in world space;   wi.h = wo.h;   N.h = (N.wo + N.wi) / |wo + wi|
+//   * D  = 1 / (pi a^2 ((1 - (N.h)^2) / a^2 + (N.h)^2)^2)                                one reciprocal, no tan / sin
+//   * lambda(wi) = (sqrt(1 + a^2 (1 - (N.wi)^2) / (N.wi)^2) - 1) / 2                     one reciprocal, one square root
+//   * G / cos_i  = 1 / ((1 + lambda(wo) + lambda(wi)) cos_i)                             one reciprocal
+//   * specular pdf = G1(wo) |wo.h| D / |cos_o| / (4 |wo.h|) = D * [G1(wo) / (4 |cos_o|)]    no reciprocal: the bracket is per surface
+// Agreement with the exact policy: a few ulp (tests/test_gpu_parity.py holds whole frames to 1e-3 relative L2; measured 1e-8).
 // ---------------------------------------------------------------------------------------------------------------------
 struct LmQuick {
     lf3 kd;                          // albedo (1 - metallic) / pi
     float pdfDiffuse, pdfSheen;      // w0 / pi,  w1 / (2 pi)
     float sheenK;                    // sheen (1 - metallic)
-    float ax2, ay2, iax2, iay2, kD;  // alpha^2, 1 / alpha^2, 1 / (pi ax ay)
+    float a2, ia2, kD;               // alpha^2, 1 / alpha^2, 1 / (pi alpha^2)
     float kG;                        // 1 + lambda(wo)
     float inv4cosO, pdfSpecular;     // 1 / (4 |cos_o|),  w2 G1(wo) / (4 |cos_o|); both 0 for an exactly grazing view (no specular term, as in the exact path)
 };
-// Does the contracted evaluation cover this material?  Not with a dielectric lobe, a clear coat, or a roughness byte of 0 (the opaque
-// stack is then absent, disney.cuh:374): such surfaces are scored by the exact path (lm_restir.h LM_RARE).
-LM_HD bool lm_quick_contracts(const LmMaterial& m) { return (m.p2 & 0x00ff00ffu) == 0u && (m.p0 >> 24) != 0u; }
+// Does the contracted evaluation cover this material?  Not with a dielectric lobe, a clear coat, anisotropy, or a roughness byte of 0
+// (the opaque stack is then absent, disney.cuh:374): such surfaces are scored by the exact path (lm_restir.h LM_RARE).
+LM_HD bool lm_quick_contracts(const LmMaterial& m) { return (m.p2 & 0x00ff00ffu) == 0u && (m.p0 >> 24) != 0u && (m.p1 & 0x0000ff00u) == 0u; }
 __device__ __forceinline__ void lm_quick_setup(const LmLobes& L, LmQuick& Q)
 {
 #pragma clang fp contract(fast)
@@ -424,21 +425,21 @@ __device__ __forceinline__ void lm_quick_setup(const LmLobes& L, LmQuick& Q)
     Q.pdfDiffuse = L.w0 * LM_INVPI;
     Q.pdfSheen = L.w1 * (0.5f * LM_INVPI);
     Q.sheenK = L.sheen * L.dielectric;
-    Q.ax2 = L.ax * L.ax; Q.ay2 = L.ay * L.ay;
-    Q.iax2 = LmFast::rcp(Q.ax2); Q.iay2 = LmFast::rcp(Q.ay2);
-    Q.kD = LmFast::rcp(LM_PI * L.ax * L.ay);
+    Q.a2 = L.ax * L.ax;                                  // (ax == ay: lm_quick_contracts)
+    Q.ia2 = LmFast::rcp(Q.a2);
+    Q.kD = Q.ia2 * LM_INVPI;
     Q.kG = 1.0f + L.lamO;
-    Q.inv4cosO = L.wol.z != 0.f ? LmFast::rcp(4.0f * fabsf(L.wol.z)) : 0.f;
+    Q.inv4cosO = L.cosO != 0.f ? LmFast::rcp(4.0f * fabsf(L.cosO)) : 0.f;
     Q.pdfSpecular = L.w2 * L.g1O * Q.inv4cosO;
 }
 // `cin` = N.wi > 0 (the caller has culled lights below the horizon)
 __device__ __forceinline__ lf3 lm_quick_eval(const LmLobes& L, const LmQuick& Q, const lf3& wiw, float cin, float& pdf)
 {
 #pragma clang fp contract(fast)
-    const lf3 wil = v3(dot3(wiw, L.T), dot3(wiw, L.B), cin);
-    const lf3 h = L.wol + wil;
-    const lf3 hl = h * LmFast::rsqrt(dot3(h, h));
-    const float ch = dot3(wil, hl);
+    const lf3 h = L.wo + wiw;                            // (from the components, not from 2 + 2 wo.wi: that loses every digit when wo ~ -wi)
+    const float hinv = LmFast::rsqrt(dot3(h, h));
+    const float ch = dot3(wiw, h) * hinv;                // wi.h = wo.h
+    const float hz = (L.cosO + cin) * hinv;              // N.h
     lf3 value = v3(0.f);
     pdf = 0.f;
     if (L.w0 + L.w1 > 0.f) {
@@ -457,10 +458,10 @@ __device__ __forceinline__ lf3 lm_quick_eval(const LmLobes& L, const LmQuick& Q,
         if (L.w1 > 0.f) { value = L.sheenTint * (lm_schlick(ch) * Q.sheenK); pdf += Q.pdfSheen; }      // replaces the diffuse value, as the exact path does
     }
     if (L.w2 > 0.f && ch != 0.f) {
-        const float e = hl.x * hl.x * Q.iax2 + hl.y * hl.y * Q.iay2 + hl.z * hl.z;
+        const float hz2 = hz * hz, e = (1.0f - hz2) * Q.ia2 + hz2;
         const float D = Q.kD * LmFast::rcp(e * e);
-        const float a2 = (Q.ax2 * wil.x * wil.x + Q.ay2 * wil.y * wil.y) * LmFast::rcp(cin * cin);
-        const float lamI = 0.5f * (LmFast::sqrt(1.0f + a2) - 1.0f);
+        const float c2 = cin * cin;
+        const float lamI = 0.5f * (LmFast::sqrt(1.0f + Q.a2 * (1.0f - c2) * LmFast::rcp(c2)) - 1.0f);
         const float gOverCos = LmFast::rcp((Q.kG + lamI) * cin);
         const float fh = lm_schlick(fabsf(ch));
         const float p = Q.pdfSpecular * D;

@@ -180,7 +180,7 @@ static int fillMaterial(lumen_mi_renderer* r, const lumen_mi_material_data* d, M
     // (GPUExtractSurfaceData.cu:183-196): 0 when the factor byte is 0.  Roughness is texel.g x factor re-packed by truncation: the byte is
     // 0 (mirror-like: the opaque stack is absent) iff the product is below 1/255; bilinear filtering never goes below the smallest texel.
     const float baseRough = (float)(v.p[0] >> 24) * (1.0f / 255.0f), minG = (float)r->textures[(size_t)tMR].minG / 255.0f;
-    m.mayBeRare = (v.p[2] & 0x00ff00ffu) != 0u || (uint32_t)(minG * baseRough * 255.f) == 0u;
+    m.mayBeRare = (v.p[2] & 0x00ff00ffu) != 0u || (v.p[1] & 0x0000ff00u) != 0u || (uint32_t)(minG * baseRough * 255.f) == 0u;      // + anisotropy (a per-material constant)
     return 0;
 }
 
