@@ -218,7 +218,7 @@ int traceFrameAsync(R* r)
         const int doIndirect = depth < depthMax - 1 ? 1 : 0;
         if (depth == 0) {
             evBegin2(r, 0, ev, sx);
-            Z(sx); K->trace_closest(sx, gridMain, scx, fr.rayO[q], fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters, r->refillPrimary);    // :678,:703
+            Z(sx); K->trace_closest(sx, gridMain, scx, nullptr, fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters, r->refillPrimary, cam.eye);    // :678,:703; primary rays start at the eye
             evEnd2(r, ev, sx);
             if (overlap) LM_HIP(hipStreamWaitEvent(sx, r->evTemporal[par], 0));          // the temporal pass two frames back has read what extraction overwrites
             evBegin2(r, 2, ev, sx);
@@ -296,7 +296,7 @@ int traceFrameAsync(R* r)
                 q ^= 1;
             }
             evBegin2(r, 0, ev, sx);
-            Z(sx); K->trace_closest(sx, gridAux, scx, fr.rayO[q], fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters, r->refillBelow);
+            Z(sx); K->trace_closest(sx, gridAux, scx, fr.rayO[q], fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters, r->refillBelow, nullptr);
             evEnd2(r, ev, sx);
             if (overlap) LM_HIP(hipStreamWaitEvent(sx, r->evJoin2, 0));                   // previous wave's (or frame's) shadow rays consumed
             evBegin2(r, 2, ev, sx);

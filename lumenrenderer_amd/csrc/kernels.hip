@@ -134,9 +134,10 @@ KN(lm_k_primary)(LmFrame fr, LmCamera cam, uint32_t frameCount)
         dy = -(dy * 2.0f - 1.0f);
         const lf3 U = v3(cam.U[0], cam.U[1], cam.U[2]), V = v3(cam.V[0], cam.V[1], cam.V[2]), Wv = v3(cam.Wv[0], cam.Wv[1], cam.Wv[2]);
         const lf3 dir = normalize3(dx * U + dy * V + Wv);
-        fr.rayO[0][i] = make_float4(cam.eye[0], cam.eye[1], cam.eye[2], 0.f);
+        // only the direction plane is written: every primary ray starts at the eye with contribution (1, 1, 1), which the first closest-hit
+        // launch and the depth-0 extraction take from their arguments instead of reading 32 bytes per pixel back (IntersectionRayData's
+        // origin and contribution, GPUGeneratePrimRay.cu:69-72)
         fr.rayD[0][i] = make_float4(dir.x, dir.y, dir.z, u2f(li));
-        fr.rayC[0][i] = make_float4(1.f, 1.f, 1.f, 0.f);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) fr.counters[LM_CNT_RAYS(0)] = fr.n;
 }
@@ -148,14 +149,14 @@ KN(lm_k_primary)(LmFrame fr, LmCamera cam, uint32_t frameCount)
 #define LM_TRACE_WAVES 8      // <= 64 VGPRs: eight waves per SIMD
 #endif
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_TRACE_WAVES)
-KN(lm_k_trace_closest)(LmScene sc, const float4* __restrict__ rayO, const float4* __restrict__ rayD, const uint32_t* __restrict__ countPtr,
-                   uint4* __restrict__ hits, float tmin, float tmax, uint32_t* counters, int refillBelow)
+KN(lm_k_trace_closest)(LmScene sc, const float4* __restrict__ rayO /* NULL: every ray starts at `eye` (primary rays) */, const float4* __restrict__ rayD,
+                   const uint32_t* __restrict__ countPtr, uint4* __restrict__ hits, float tmin, float tmax, uint32_t* counters, int refillBelow, float4 eye)
 {
     __shared__ int s_stack[LM_STACK_LDS * LM_BLOCK];
     __shared__ uint4 s_top[4 * LM_TOP_NODES + 1];
     const uint32_t n = *countPtr;
     lm_trace_queue<false>(sc, n, refillBelow, lm_make_stack(s_stack, sc), lm_stage_top(s_top, sc), counters,
-        [&](uint32_t i, lf3& o, lf3& d, float& t0, float& t1) { o = v3(rayO[i]); d = v3(rayD[i]); t0 = tmin; t1 = tmax; },
+        [&](uint32_t i, lf3& o, lf3& d, float& t0, float& t1) { o = rayO ? v3(rayO[i]) : v3(eye); d = v3(rayD[i]); t0 = tmin; t1 = tmax; },
         [&](uint32_t i, bool found, const LmHit& h) {
             uint4 out = make_uint4(0u, 0u, 0u, f2u(-1.f));
             if (found) {
@@ -188,10 +189,10 @@ KN(lm_k_extract0)(LmScene sc, LmFrame fr, LmCamera cam, int cur, uint32_t seed2,
         lf3 bo = v3(0.f), bd = v3(0.f), bc = v3(0.f);
         uint32_t liOut = 0u;
         if (i < fr.n) {
-        const float4 o4 = fr.rayO[0][i], d4 = fr.rayD[0][i], c4 = fr.rayC[0][i];
+        const float4 d4 = fr.rayD[0][i];                          // origin = eye, contribution = 1 (lm_k_primary)
         const uint32_t li = f2u(d4.w);
         LmSurface s;
-        lm_extract(sc, fr.hits[i], v3(o4), v3(d4), v3(c4), s);
+        lm_extract(sc, fr.hits[i], v3(cam.eye[0], cam.eye[1], cam.eye[2]), v3(d4), v3(1.f, 1.f, 1.f), s);
         lm_gbuf_store(fr.gbuf[cur], fr.probe[cur], li, s);
         lm_count(fr.counters + LM_CNT_RARE, !s.flags && !lm_quick_contracts(s.mat));      // surfaces the fast ReSTIR mode scores in its second launch (none: no atomic)
         // motion vector
@@ -1175,8 +1176,8 @@ extern "C" __global__ void KN(lm_k_spin)(uint32_t ticks)
 #define LM_GRID(g) dim3((unsigned)(g)), dim3(LM_BLOCK), 0, s
 
 static void l_primary(hipStream_t s, int g, LmFrame fr, LmCamera cam, uint32_t frameCount) { hipLaunchKernelGGL(KN(lm_k_primary), LM_GRID(g), fr, cam, frameCount); }
-static void l_trace_closest(hipStream_t s, int g, LmScene sc, const float4* o, const float4* d, const uint32_t* cnt, uint4* hits, float tmin, float tmax, uint32_t* counters, int refillBelow)
-{ hipLaunchKernelGGL(KN(lm_k_trace_closest), LM_GRID(g), sc, o, d, cnt, hits, tmin, tmax, counters, refillBelow); }
+static void l_trace_closest(hipStream_t s, int g, LmScene sc, const float4* o, const float4* d, const uint32_t* cnt, uint4* hits, float tmin, float tmax, uint32_t* counters, int refillBelow, const float* eye)
+{ hipLaunchKernelGGL(KN(lm_k_trace_closest), LM_GRID(g), sc, o, d, cnt, hits, tmin, tmax, counters, refillBelow, eye ? make_float4(eye[0], eye[1], eye[2], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f)); }
 static void l_extract0(hipStream_t s, int g, LmScene sc, LmFrame fr, LmCamera cam, int cur, uint32_t seed2, int doIndirect, int outQ, uint32_t* outCount)
 { hipLaunchKernelGGL(KN(lm_k_extract0), LM_GRID(g), sc, fr, cam, cur, seed2, doIndirect, outQ, outCount); }
 static void l_shade_wave(hipStream_t s, int g, LmScene sc, LmFrame fr, int inQ, const uint32_t* inCount, uint32_t seed, uint32_t seed2, int doIndirect, uint32_t* outCount, uint32_t* shadowCount)

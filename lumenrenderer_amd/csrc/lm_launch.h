@@ -4,7 +4,8 @@
 
 struct LmKernelTable {
     void (*primary)(hipStream_t, int grid, LmFrame, LmCamera, uint32_t frameCount);
-    void (*trace_closest)(hipStream_t, int grid, LmScene, const float4* o, const float4* d, const uint32_t* count, uint4* hits, float tmin, float tmax, uint32_t* counters, int refillBelow);
+    void (*trace_closest)(hipStream_t, int grid, LmScene, const float4* o, const float4* d, const uint32_t* count, uint4* hits, float tmin, float tmax, uint32_t* counters, int refillBelow,
+                          const float* eye /* with o == NULL: the common origin of the rays */);
     void (*extract0)(hipStream_t, int grid, LmScene, LmFrame, LmCamera, int cur, uint32_t seed2, int doIndirect, int outQ, uint32_t* outCount);
     void (*shade_wave)(hipStream_t, int grid, LmScene, LmFrame, int inQ, const uint32_t* inCount, uint32_t seed, uint32_t seed2, int doIndirect, uint32_t* outCount, uint32_t* shadowCount);
     void (*trace_shadow)(hipStream_t, int grid, LmScene, LmFrame, const uint32_t* count, float tmin, int refillBelow);
