@@ -408,7 +408,12 @@ template <class A = LmExact> LM_HD lf3 lm_evaluate_bsdf(const LmMaterial& sd, co
 // Agreement with the exact policy: a few ulp (tests/test_gpu_parity.py holds whole frames to 1e-3 relative L2; measured 1e-8).
 // ---------------------------------------------------------------------------------------------------------------------
 struct LmQuick {
+    lf3 N, wo;                       // shading normal, view direction (world)
+    float cosO, fresO;               // N.wo and its Schlick weight
+    float w0, w1, w2;                // lobe weights: diffuse, sheen, specular (normalised; no clear coat on this path)
+    float rough, subsurface;
     lf3 kd;                          // albedo (1 - metallic) / pi
+    lf3 sheenTint, f0;
     float pdfDiffuse, pdfSheen;      // w0 / pi,  w1 / (2 pi)
     float sheenK;                    // sheen (1 - metallic)
     float a2, ia2, kD;               // alpha^2, 1 / alpha^2, 1 / (pi alpha^2)
@@ -418,46 +423,62 @@ struct LmQuick {
 // Does the contracted evaluation cover this material?  Not with a dielectric lobe, a clear coat, anisotropy, or a roughness byte of 0
 // (the opaque stack is then absent, disney.cuh:374): such surfaces are scored by the exact path (lm_restir.h LM_RARE).
 LM_HD bool lm_quick_contracts(const LmMaterial& m) { return (m.p2 & 0x00ff00ffu) == 0u && (m.p0 >> 24) != 0u && (m.p1 & 0x0000ff00u) == 0u; }
-__device__ __forceinline__ void lm_quick_setup(const LmLobes& L, LmQuick& Q)
+// Once per surface, from the material, the shading normal and the view direction only: neither the tangent nor the dielectric constants
+// of the surface record are touched (a reuse pass does not even load them).
+__device__ __forceinline__ void lm_quick_setup(const LmMaterial& sd, const lf3& N, const lf3& wow, LmQuick& Q)
 {
 #pragma clang fp contract(fast)
-    Q.kd = L.base * (LM_INVPI * L.dielectric);
-    Q.pdfDiffuse = L.w0 * LM_INVPI;
-    Q.pdfSheen = L.w1 * (0.5f * LM_INVPI);
-    Q.sheenK = L.sheen * L.dielectric;
-    Q.a2 = L.ax * L.ax;                                  // (ax == ay: lm_quick_contracts)
+    Q.N = N; Q.wo = wow;
+    Q.cosO = dot3(N, wow);
+    Q.fresO = lm_schlick(Q.cosO);
+    Q.rough = LM_P_ROUGHNESS(sd);
+    Q.subsurface = LM_P_SUBSURFACE(sd);
+    const float metallic = LM_P_METALLIC(sd), dielectric = 1.0f - metallic, sheen = LM_P_SHEEN(sd), specular = LM_P_SPECULAR(sd);
+    Q.w0 = sd.tint.w * dielectric; Q.w1 = sheen * dielectric; Q.w2 = specular + metallic * (1.0f - specular);
+    const float inv = LmFast::rcp(Q.w0 + Q.w1 + Q.w2);
+    Q.w0 *= inv; Q.w1 *= inv; Q.w2 *= inv;
+    Q.kd = v3(sd.color) * (LM_INVPI * dielectric);
+    const float sheenTint = LM_P_SHEENTINT(sd), specTint = LM_P_SPECTINT(sd);
+    Q.sheenTint = (1.0f - sheenTint) + sheenTint * v3(sd.tint);
+    Q.f0 = dielectric * (((1.0f - specTint) + specTint * v3(sd.tint)) * (specular * 0.08f)) + metallic * v3(sd.color);
+    Q.pdfDiffuse = Q.w0 * LM_INVPI;
+    Q.pdfSheen = Q.w1 * (0.5f * LM_INVPI);
+    Q.sheenK = sheen * dielectric;
+    Q.a2 = sqrf(fmaxf(0.001f, Q.rough * Q.rough));      // alpha_x = alpha_y = max(0.001, roughness^2) without anisotropy
     Q.ia2 = LmFast::rcp(Q.a2);
     Q.kD = Q.ia2 * LM_INVPI;
-    Q.kG = 1.0f + L.lamO;
-    Q.inv4cosO = L.cosO != 0.f ? LmFast::rcp(4.0f * fabsf(L.cosO)) : 0.f;
-    Q.pdfSpecular = L.w2 * L.g1O * Q.inv4cosO;
+    const float c2 = Q.cosO * Q.cosO;
+    const float lamO = Q.cosO != 0.f ? 0.5f * (LmFast::sqrt(1.0f + Q.a2 * fmaxf(0.0f, 1.0f - c2) * LmFast::rcp(c2)) - 1.0f) : 0.f;
+    Q.kG = 1.0f + lamO;
+    Q.inv4cosO = Q.cosO != 0.f ? LmFast::rcp(4.0f * fabsf(Q.cosO)) : 0.f;
+    Q.pdfSpecular = Q.w2 * LmFast::rcp(Q.kG) * Q.inv4cosO;
 }
 // `cin` = N.wi > 0 (the caller has culled lights below the horizon)
-__device__ __forceinline__ lf3 lm_quick_eval(const LmLobes& L, const LmQuick& Q, const lf3& wiw, float cin, float& pdf)
+__device__ __forceinline__ lf3 lm_quick_eval(const LmQuick& Q, const lf3& wiw, float cin, float& pdf)
 {
 #pragma clang fp contract(fast)
-    const lf3 h = L.wo + wiw;                            // (from the components, not from 2 + 2 wo.wi: that loses every digit when wo ~ -wi)
+    const lf3 h = Q.wo + wiw;                            // (from the components, not from 2 + 2 wo.wi: that loses every digit when wo ~ -wi)
     const float hinv = LmFast::rsqrt(dot3(h, h));
     const float ch = dot3(wiw, h) * hinv;                // wi.h = wo.h
-    const float hz = (L.cosO + cin) * hinv;              // N.h
+    const float hz = (Q.cosO + cin) * hinv;              // N.h
     lf3 value = v3(0.f);
     pdf = 0.f;
-    if (L.w0 + L.w1 > 0.f) {
-        if (L.w0 > 0.f) {
-            const float fl = lm_schlick(cin), ch2r = ch * ch * L.rough;
+    if (Q.w0 + Q.w1 > 0.f) {
+        if (Q.w0 > 0.f) {
+            const float fl = lm_schlick(cin), ch2r = ch * ch * Q.rough;
             float fd = 0.f;
-            if (L.subsurface != 1.0f) { const float k = 2.0f * ch2r - 0.5f; fd = (1.0f + k * fl) * (1.0f + k * L.fresO); }
-            if (L.subsurface > 0.f) {
-                const float k = ch2r - 1.0f, fss = (1.0f + k * fl) * (1.0f + k * L.fresO);
-                const float ss = 1.25f * (fss * (LmFast::rcp(fabsf(L.cosO) + cin) - 0.5f) + 0.5f);
-                fd = fd + L.subsurface * (ss - fd);
+            if (Q.subsurface != 1.0f) { const float k = 2.0f * ch2r - 0.5f; fd = (1.0f + k * fl) * (1.0f + k * Q.fresO); }
+            if (Q.subsurface > 0.f) {
+                const float k = ch2r - 1.0f, fss = (1.0f + k * fl) * (1.0f + k * Q.fresO);
+                const float ss = 1.25f * (fss * (LmFast::rcp(fabsf(Q.cosO) + cin) - 0.5f) + 0.5f);
+                fd = fd + Q.subsurface * (ss - fd);
             }
             value = Q.kd * fd;
             pdf = Q.pdfDiffuse * cin;
         }
-        if (L.w1 > 0.f) { value = L.sheenTint * (lm_schlick(ch) * Q.sheenK); pdf += Q.pdfSheen; }      // replaces the diffuse value, as the exact path does
+        if (Q.w1 > 0.f) { value = Q.sheenTint * (lm_schlick(ch) * Q.sheenK); pdf += Q.pdfSheen; }      // replaces the diffuse value, as the exact path does
     }
-    if (L.w2 > 0.f && ch != 0.f) {
+    if (Q.w2 > 0.f && ch != 0.f) {
         const float hz2 = hz * hz, e = (1.0f - hz2) * Q.ia2 + hz2;
         const float D = Q.kD * LmFast::rcp(e * e);
         const float c2 = cin * cin;
@@ -465,7 +486,7 @@ __device__ __forceinline__ lf3 lm_quick_eval(const LmLobes& L, const LmQuick& Q,
         const float gOverCos = LmFast::rcp((Q.kG + lamI) * cin);
         const float fh = lm_schlick(fabsf(ch));
         const float p = Q.pdfSpecular * D;
-        if (p > 0.f) { pdf += p; value = value + ((1.0f - fh) * L.f0 + fh) * (D * gOverCos * Q.inv4cosO); }
+        if (p > 0.f) { pdf += p; value = value + ((1.0f - fh) * Q.f0 + fh) * (D * gOverCos * Q.inv4cosO); }
     }
     return value;
 }

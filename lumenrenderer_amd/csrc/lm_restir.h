@@ -45,14 +45,15 @@ __device__ __forceinline__ void lm_res_store(float4* __restrict__ hot, float4* _
 
 // the receiving surface of a resampling loop
 struct LmTarget {
-    lf3 position; LmLobes lobes;      // lobes.N is the shading normal, lobes.wo the direction back along the camera path
-    LmQuick quick;                    // constants of the contracted evaluation (fast policy only, dead otherwise)
+    lf3 position;
+    LmLobes lobes;                    // exact policy: lobes.N is the shading normal, lobes.wo the direction back along the camera path
+    LmQuick quick;                    // fast policy: the contracted evaluation's own (smaller) setup; whichever part a kernel does not use is never computed
 };
 template <class A> __device__ __forceinline__ void lm_target_setup(const LmSurface& px, LmTarget& t)
 {
     t.position = px.position;
-    lm_lobes_setup<A>(px.mat, px.normal, px.tangent, -px.incoming, t.lobes);
-    if constexpr (A::contracted) lm_quick_setup(t.lobes, t.quick);
+    if constexpr (A::contracted) lm_quick_setup(px.mat, px.normal, -px.incoming, t.quick);
+    else lm_lobes_setup<A>(px.mat, px.normal, px.tangent, -px.incoming, t.lobes);
 }
 // Which kernel instantiation scores a receiving surface (kernels.hip runs the ReSTIR passes in up to two launches):
 //   LM_ALL     every surface, exact policy — the default mode, bit-identical to the oracle
@@ -71,11 +72,11 @@ __device__ __forceinline__ void lm_score_quick(const LmLightPoint& p, const LmTa
     const lf3 d = p.position - t.position;
     const float d2 = dot3(d, d), rinv = LmFast::rsqrt(d2);
     const lf3 toLight = d * rinv;
-    const float cosIn = dot3(toLight, t.lobes.N), cosOut = -dot3(p.normal, toLight);
+    const float cosIn = dot3(toLight, t.quick.N), cosOut = -dot3(p.normal, toLight);
     pdfOut = 0.f;
     if (!(cosIn > 0.f && cosOut > 0.f && d2 * rinv > 0.01f)) return;
     float pdf = 0.f;
-    const lf3 bsdf = lm_quick_eval(t.lobes, t.quick, toLight, cosIn, pdf);
+    const lf3 bsdf = lm_quick_eval(t.quick, toLight, cosIn, pdf);
     const float added = pdf + bsdf.x + bsdf.y + bsdf.z;
     if (pdf <= LM_EPSILON || added != added || fabsf(added) == u2f(0x7f800000u)) { contribution = v3(0.f); return; }
     contribution = bsdf * (cosOut * p.area * rinv * rinv * cosIn * LmFast::rcp(pdf)) * p.radiance;
