@@ -240,6 +240,9 @@ __device__ __forceinline__ bool lm_traverse(const LmScene& sc, const lf3& o, con
 #ifndef LM_NODE_EXIT
 #define LM_NODE_EXIT 14
 #endif
+#ifndef LM_SPECULATE
+#define LM_SPECULATE 0       // 1: a lane that reaches its first leaf postpones it and keeps stepping through nodes (Aila & Laine's speculative
+#endif                       //    while-while traversal) instead of idling until the wave leaves the node loop; hit records cannot change
 template <bool ANY, class Fetch, class Done>
 __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, int refillBelow, const LmStack& stack, const lm_lds_u4* top,
                                                uint32_t* cnt, Fetch fetch, Done done)
@@ -260,10 +263,34 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
     uint32_t hitOrder = 0xffffffffu;
     bool found = false;
     int sp = 0, cur = 0;
+#if LM_SPECULATE
+    int pending = LM_REF_NONE;          // postponed leaf
+#endif
     LmHit hit; hit.t = -1.f; hit.u = 0.f; hit.v = 0.f; hit.slot = 0;
 #if LM_INSTRUMENT
     uint32_t nNodes = 0, nTris = 0, raySteps = 0;
 #endif
+    // triangles of one leaf against the lane's ray
+    auto testLeaf = [&](int ref) {
+        const uint32_t leaf = (uint32_t)(~ref);
+        const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
+        for (uint32_t k = 0; k < count; k++) {
+            float t, u, v;
+#if LM_INSTRUMENT
+            nTris++; raySteps++;
+            { const unsigned long long m = __ballot(true);       // lane occupancy of this triangle-test issue
+              if ((int)lane == __ffsll((long long)m) - 1) { atomicAdd((unsigned long long*)(cnt + LM_CNT_OCC + 4), (unsigned long long)__popcll(m)); atomicAdd((unsigned long long*)(cnt + LM_CNT_OCC + 6), 64ull); } }
+#endif
+            if (lm_woop(sc.woop, first + k, o, d, tmin, tmax, t, u, v)) {
+                if (ANY) { found = true; break; }
+                const uint32_t order = sc.triOrder[first + k];
+                if (t < hitT || (t == hitT && found && order < hitOrder)) {
+                    hitT = t; hitOrder = order; found = true;
+                    hit.t = t; hit.u = u; hit.v = v; hit.slot = first + k;
+                }
+            }
+        }
+    };
     for (;;) {
         // ---- refill idle lanes from the wave's groups
         unsigned long long need = __ballot(!active);
@@ -281,6 +308,9 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
                 rq.ax = sc.quant[3] * idx; rq.ay = sc.quant[4] * idy; rq.az = sc.quant[5] * idz;
                 rq.bx = (sc.quant[0] - o.x) * idx; rq.by = (sc.quant[1] - o.y) * idy; rq.bz = (sc.quant[2] - o.z) * idz;
                 hitT = tmax; hitOrder = 0xffffffffu; found = false; sp = 0; cur = root;
+#if LM_SPECULATE
+                pending = LM_REF_NONE;
+#endif
                 active = true;
 #if LM_INSTRUMENT
                 raySteps = 0;
@@ -314,26 +344,19 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
 #else
                 cur = lm_node_step<ANY>(sc, cur, rq, tmin, hitT, stack, sp, top);
 #endif
-            }
-            if (cur < 0) {
-                const uint32_t leaf = (uint32_t)(~cur);
-                const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
-                for (uint32_t k = 0; k < count; k++) {
-                    float t, u, v;
-#if LM_INSTRUMENT
-                    nTris++; raySteps++;
-                    { const unsigned long long m = __ballot(true);       // lane occupancy of this triangle-test issue
-                      if ((int)lane == __ffsll((long long)m) - 1) { atomicAdd((unsigned long long*)(cnt + LM_CNT_OCC + 4), (unsigned long long)__popcll(m)); atomicAdd((unsigned long long*)(cnt + LM_CNT_OCC + 6), 64ull); } }
+#if LM_SPECULATE
+                if (cur < 0 && pending == LM_REF_NONE) { pending = cur; cur = sp == 0 ? LM_REF_NONE : lm_pop(stack, sp); }
 #endif
-                    if (lm_woop(sc.woop, first + k, o, d, tmin, tmax, t, u, v)) {
-                        if (ANY) { found = true; break; }
-                        const uint32_t order = sc.triOrder[first + k];
-                        if (t < hitT || (t == hitT && found && order < hitOrder)) {
-                            hitT = t; hitOrder = order; found = true;
-                            hit.t = t; hit.u = u; hit.v = v; hit.slot = first + k;
-                        }
-                    }
-                }
+            }
+#if LM_SPECULATE
+            if (pending != LM_REF_NONE) {
+                testLeaf(pending);
+                pending = LM_REF_NONE;
+                if (ANY && found) cur = LM_REF_NONE;
+            }
+#endif
+            if (cur < 0) {
+                testLeaf(cur);
                 cur = ((ANY && found) || sp == 0) ? 0x7fffffff : lm_pop(stack, sp);
             }
             const bool fin = cur == 0x7fffffff;
