@@ -140,6 +140,7 @@ int traceFrameAsync(R* r)
     const bool blend = r->settings.blend_output != 0;
     // 0 exact; 1 fast, common launch only (no material can produce a surface outside the contracted evaluation); 2 fast, common + rare launch
     const int fastRs = r->fastResample ? (r->anyRareMaterial ? 2 : 1) : 0;
+    const bool usePackets = r->packetPrimary > 0 || (r->packetPrimary < 0 && (uint64_t)r->triEntry.size() * 4u < (uint64_t)r->fr.n && r->fr.n > 0);
 
     // camera (Camera.cpp:79-93,122-140; aspect = render W/H, WaveFrontRenderer.cpp:577)
     LmCamera cam;
@@ -218,7 +219,7 @@ int traceFrameAsync(R* r)
         const int doIndirect = depth < depthMax - 1 ? 1 : 0;
         if (depth == 0) {
             evBegin2(r, 0, ev, sx);
-            Z(sx); K->trace_closest(sx, gridMain, scx, nullptr, fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters, r->refillPrimary, cam.eye);    // :678,:703; primary rays start at the eye
+            Z(sx); K->trace_closest(sx, gridMain, scx, nullptr, fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters, usePackets ? -1 : r->refillPrimary, cam.eye);    // :678,:703; primary rays start at the eye
             evEnd2(r, ev, sx);
             if (overlap) LM_HIP(hipStreamWaitEvent(sx, r->evTemporal[par], 0));          // the temporal pass two frames back has read what extraction overwrites
             evBegin2(r, 2, ev, sx);

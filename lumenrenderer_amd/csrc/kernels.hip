@@ -169,6 +169,28 @@ KN(lm_k_trace_closest)(LmScene sc, const float4* __restrict__ rayO /* NULL: ever
         });
 }
 
+// the same query for a queue of COHERENT rays (the primary wave): packet traversal, one shared stack per wavefront (lm_traverse.h)
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_TRACE_WAVES)
+KN(lm_k_trace_closest_packet)(LmScene sc, const float4* __restrict__ rayO, const float4* __restrict__ rayD, const uint32_t* __restrict__ countPtr,
+                          uint4* __restrict__ hits, float tmin, float tmax, float4 eye)
+{
+    __shared__ int s_wstack[LM_PACKET_STACK * (LM_BLOCK / 64)];
+    __shared__ uint4 s_top[4 * LM_TOP_NODES + 1];
+    const uint32_t n = *countPtr;
+    lm_trace_packets<false>(sc, n, (lm_lds_int*)(s_wstack + LM_PACKET_STACK * (threadIdx.x >> 6)), lm_stage_top(s_top, sc),
+        [&](uint32_t i, lf3& o, lf3& d, float& t0, float& t1) { o = rayO ? v3(rayO[i]) : v3(eye); d = v3(rayD[i]); t0 = tmin; t1 = tmax; },
+        [&](uint32_t i, bool found, const LmHit& h) {
+            uint4 out = make_uint4(0u, 0u, 0u, f2u(-1.f));
+            if (found) {
+                const uint2 id = sc.triId[h.slot];
+                out.x = id.x; out.y = id.y;
+                out.z = lm_f32_to_f16(h.u) | (lm_f32_to_f16(h.v) << 16);
+                out.w = f2u(h.t);
+            }
+            hits[i] = out;
+        });
+}
+
 #include "lm_shade.h"
 
 // K7 (depth 0) + K9 motion vectors (MotionVectors.cu:8-55) + K10 ResolveDirectLightHits (GPUShadeDirect.cu:11-40) + channel clear
@@ -1177,7 +1199,15 @@ extern "C" __global__ void KN(lm_k_spin)(uint32_t ticks)
 
 static void l_primary(hipStream_t s, int g, LmFrame fr, LmCamera cam, uint32_t frameCount) { hipLaunchKernelGGL(KN(lm_k_primary), LM_GRID(g), fr, cam, frameCount); }
 static void l_trace_closest(hipStream_t s, int g, LmScene sc, const float4* o, const float4* d, const uint32_t* cnt, uint4* hits, float tmin, float tmax, uint32_t* counters, int refillBelow, const float* eye)
-{ hipLaunchKernelGGL(KN(lm_k_trace_closest), LM_GRID(g), sc, o, d, cnt, hits, tmin, tmax, counters, refillBelow, eye ? make_float4(eye[0], eye[1], eye[2], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f)); }
+{
+    const float4 e = eye ? make_float4(eye[0], eye[1], eye[2], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+#if !LM_INSTRUMENT
+    // refillBelow < 0: the queue holds coherent bundles (primary rays): packet traversal.  (The counting build always takes the per-lane
+    // kernel: its node / triangle counts are per ray.)
+    if (refillBelow < 0) { hipLaunchKernelGGL(KN(lm_k_trace_closest_packet), LM_GRID(g), sc, o, d, cnt, hits, tmin, tmax, e); return; }
+#endif
+    hipLaunchKernelGGL(KN(lm_k_trace_closest), LM_GRID(g), sc, o, d, cnt, hits, tmin, tmax, counters, refillBelow < 0 ? 0 : refillBelow, e);
+}
 static void l_extract0(hipStream_t s, int g, LmScene sc, LmFrame fr, LmCamera cam, int cur, uint32_t seed2, int doIndirect, int outQ, uint32_t* outCount)
 { hipLaunchKernelGGL(KN(lm_k_extract0), LM_GRID(g), sc, fr, cam, cur, seed2, doIndirect, outQ, outCount); }
 static void l_shade_wave(hipStream_t s, int g, LmScene sc, LmFrame fr, int inQ, const uint32_t* inCount, uint32_t seed, uint32_t seed2, int doIndirect, uint32_t* outCount, uint32_t* shadowCount)

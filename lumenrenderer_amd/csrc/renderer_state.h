@@ -178,6 +178,9 @@ struct lumen_mi_renderer {
     uint32_t refits = 0;                    // refits since the last full build
     int refitEnabled = 1;                   // 0: every transform change triggers a full host rebuild
     bool anyRareMaterial = false;           // some material ever created may need the second (exact) launch of the fast ReSTIR passes
+    int packetPrimary = -1;                 // the primary wave is traced as packets (one shared stack per wavefront, lm_trace_packets): 1 on, 0 off,
+                                            // -1 auto = when the window has more than 4 pixels per scene triangle (a wavefront's 8 x 8 pixel tile then meets
+                                            // few distinct leaves: C2 / C3 +1.2 %; with sub-pixel geometry the union of 64 rays' nodes costs more: C5 -11 %)
     int sortRays = 0;                       // > 0: continuation-ray queues of waves 1 .. sortRays are reordered by (origin cell, octant) before their closest-hit launch
     DevBuf<uint32_t> dSortBins;             // 2 x 4096 words (histogram + cursors)
     int fastResample = 0;                   // 1: the ReSTIR target function and resampling weights use hardware rcp / rsq / sqrt (LmFast): within 1e-3 rel-L2

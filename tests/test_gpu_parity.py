@@ -646,7 +646,8 @@ def test_sponza_with_1024_emissive_triangles_matches_oracle():
 TUNINGS = [{"tail_below": 0}, {"tail_below": 1 << 30}, {"tail_below": 6000}, {"tail_below": 6000, "tail_lanes": 64},
            {"single_stream": 1, "tail_below": 0}, {"single_stream": 1}, {"refill": 0, "tail_below": 0},
            {"pick_ahead": 0}, {"pick_ahead": 1, "tail_below": 0}, {"shadow_on_wave": 1}, {"shadow_on_wave": 1, "tail_below": 0},
-           {"sort_rays": 1}, {"sort_rays": 16, "tail_below": 0}, {"sort_rays": 2, "single_stream": 1, "tail_below": 6000}]
+           {"sort_rays": 1}, {"sort_rays": 16, "tail_below": 0}, {"sort_rays": 2, "single_stream": 1, "tail_below": 6000},
+           {"packet_primary": 1}, {"packet_primary": 1, "single_stream": 1, "tail_below": 0}]
 DEEP = [{}, {"pick_ahead": 0, "tail_below": 0}, {"pick_ahead": 1, "tail_below": 1 << 30}, {"single_stream": 1}, {"shadow_on_wave": 1}, {"sort_rays": 16, "tail_below": 0}]
 
 
