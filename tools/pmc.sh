@@ -2,7 +2,7 @@
 # usage: bash tools/pmc.sh <tag> "<counter list>"   (GPU box; separate pass per counter group)
 tag=${1:-pmc}; ctrs=${2:-"SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES"}
 R=$PWD; mkdir -p gpurun_out/$tag
-cd /tmp && export TMPDIR=/tmp GPU_MAX_HW_QUEUES=8 && timeout 900 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $R/gpurun_out/$tag/prof -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/$tag/pmc.log 2>&1
+cd /tmp && export TMPDIR=/tmp GPU_MAX_HW_QUEUES=8 && timeout 900 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $R/gpurun_out/$tag/prof -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-exact > $R/gpurun_out/$tag/pmc.log 2>&1
 cd $R
 f=$(find gpurun_out/$tag/prof -name "*counter_collection.csv" | head -1)
 python3 - "$f" <<'PY'
