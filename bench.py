@@ -5,6 +5,11 @@ A "step" is one displayed frame = 4 blended TraceFrame() calls (the reference ha
 synthetic geometry already resident in HBM.  N GPUs shard the frame by tile (lumenrenderer_amd/tiles.py) and gather the
 radiance on rank 0 with one RCCL collective; the total work is fixed, so scaling is "strong".
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` and `cpu_baseline`.
+
+Arithmetic mode: `value` is measured with the fast ReSTIR mode (tuning key fast_resample: hardware rcp / rsq / sqrt and the contracted target
+function in the candidate pick and the reuse passes; radiance within 1e-8 relative L2 of the oracle on every BASELINE configuration, 1e-3
+asserted by tests/test_gpu_parity.py, every ray counter identical).  The same run then times the exact mode (bit-identical to the oracle) the
+same way and reports it as config.other_mode; --mode exact swaps the two, --no-exact skips the second pass.
 """
 import argparse
 import json
