@@ -148,7 +148,7 @@ int lumen_mi_get_kernel_time(lumen_mi_renderer*, int which, float* milliseconds,
 int lumen_mi_enable_kernel_timing(lumen_mi_renderer*, int enable);
 int lumen_mi_set_instrumented(lumen_mi_renderer*, int enable);   /* use the node/triangle counting traversal kernels */
 /* Scheduling knobs (no reference equivalent; none of them changes a result).  Keys: "tail_below" (waves expected to hold fewer rays run
- * as one path-tail launch; 0 = off, -1 = automatic), "tail_lanes" (paths per wavefront in that launch, 1..64), "single_stream" (1 = no stream
+ * as one path-tail launch; 0 = off, -1 = automatic), "tail_lanes" (paths per wavefront in that launch, 1..64; 0 or less = automatic), "single_stream" (1 = no stream
  * overlap, no frame pipelining), "pick_ahead" (ReSTIR candidate generation of the next frame on its own stream: 1 on, 0 off,
  * -1 automatic), "refill" / "refill_visibility" (lane-refill thresholds of the queue traversal), "shadow_on_wave" (NEE shadow rays on
  * the wave stream), "fuzz" (test aid: a seed != 0 inserts idle launches of random length in front of the kernels of a frame; the image

@@ -311,7 +311,7 @@ void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out)
     memset(&out->woop[nSlots], 0, sizeof(LmWoop));               // sentinel packet: t = -0/0 = NaN, never a hit
 
     lap("woop packets");
-    // ---- 16-bit quantisation relative to the (padded) scene box, rounded outward by one extra step
+    // ---- 16-bit quantisation relative to the (padded) scene box, rounded outward by LM_QUANT_MARGIN extra steps
     float smin[3] = {INFINITY, INFINITY, INFINITY}, smax[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (uint32_t t = 0; t < nTris; t++) for (int k = 0; k < 3; k++) { smin[k] = std::min(smin[k], tbox[t].lo[k]); smax[k] = std::max(smax[k], tbox[t].hi[k]); }
     for (int k = 0; k < 3; k++) {
@@ -323,8 +323,8 @@ void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out)
     }
     auto quant = [&](float lo, float hi, int k, uint32_t& packed) {
         const double inv = 1.0 / (double)out->qstep[k];
-        long long ql = (long long)std::floor(((double)lo - (double)out->qmin[k]) * inv) - 1;
-        long long qh = (long long)std::ceil(((double)hi - (double)out->qmin[k]) * inv) + 1;
+        long long ql = (long long)std::floor(((double)lo - (double)out->qmin[k]) * inv) - LM_QUANT_MARGIN;
+        long long qh = (long long)std::ceil(((double)hi - (double)out->qmin[k]) * inv) + LM_QUANT_MARGIN;
         ql = std::max(0LL, std::min(65535LL, ql)); qh = std::max(0LL, std::min(65535LL, qh));
         packed = (uint32_t)ql | ((uint32_t)qh << 16);
     };
@@ -369,7 +369,7 @@ void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out)
         maxStack = std::max(maxStack, stackBelow + 1u);
         LmNode4 q;
         for (int i = 0; i < 4; i++) {
-            if (i >= n) { q.c[i] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, (uint32_t)LM_REF_NONE); continue; }
+            if (i >= n) { q.c[i] = make_uint4(LM_BOX_NONE, LM_BOX_NONE, LM_BOX_NONE, (uint32_t)LM_REF_NONE); continue; }
             int ref = c[i].ref;
             if (ref >= 0) {
                 const int id4 = nextId++;
@@ -493,7 +493,7 @@ void lm_assemble_bvh(const LmInstanceRef* inst, uint32_t nInst, LmBvh* out)
         for (int k = 0; k < ng; k++) { const int c = build(g[k].lo, g[k].hi); top[(size_t)me].child[top[(size_t)me].n++] = c; }
         return me;
     };
-    if (nInst == 0) { out->nodes4.assign(1, LmNode4{}); for (auto& c : out->nodes4[0].c) c = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, (uint32_t)LM_REF_NONE); }
+    if (nInst == 0) { out->nodes4.assign(1, LmNode4{}); for (auto& c : out->nodes4[0].c) c = make_uint4(LM_BOX_NONE, LM_BOX_NONE, LM_BOX_NONE, (uint32_t)LM_REF_NONE); }
     else if (nInst > 1) build(0, nInst);
     const uint32_t T = (uint32_t)top.size();
     std::vector<uint32_t> nodeBase(nInst), slotBase(nInst);
@@ -504,7 +504,7 @@ void lm_assemble_bvh(const LmInstanceRef* inst, uint32_t nInst, LmBvh* out)
     for (uint32_t t = 0; t < T; t++) {
         LmNode4 q;
         for (int k = 0; k < 4; k++) {
-            if (k >= top[t].n) { q.c[k] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, (uint32_t)LM_REF_NONE); continue; }
+            if (k >= top[t].n) { q.c[k] = make_uint4(LM_BOX_NONE, LM_BOX_NONE, LM_BOX_NONE, (uint32_t)LM_REF_NONE); continue; }
             const int c = top[t].child[k];
             q.c[k] = make_uint4(0u, 0u, 0u, (uint32_t)(c >= 0 ? c : (int)nodeBase[(uint32_t)(~c)]));
         }

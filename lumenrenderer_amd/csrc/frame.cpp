@@ -281,7 +281,7 @@ int traceFrameAsync(R* r)
                 LM_HIP(hipEventRecord(r->evShade[depth], sx)); LM_HIP(hipStreamWaitEvent(stl, r->evShade[depth], 0));     // the queue's producer is done
             }
             evBegin2(r, 0, ev, stl);
-            Z(stl); K->path_tail(stl, r->numCU * 8, sct, withTailQueue(fr, q), q, inCount, (int)depth, (int)depthMax, seed, r->tailLanes);
+            Z(stl); K->path_tail(stl, r->numCU * 8, sct, withTailQueue(fr, q), q, inCount, (int)depth, (int)depthMax, seed, r->tailLanes > 0 ? r->tailLanes : (fr.n >= 786432u ? 64 : 16));
             evEnd2(r, ev, stl);
             if (overlap) LM_HIP(hipEventRecord(r->evTail, stl));
             tailLaunched = true;

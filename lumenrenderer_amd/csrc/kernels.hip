@@ -1050,8 +1050,8 @@ extern "C" __global__ void KN(lm_k_refit_quant)(uint32_t* bounds, float* quant)
 __device__ __forceinline__ uint32_t lm_quant_axis(float lo, float hi, float qmin, float qstep)
 {
     const double inv = 1.0 / (double)qstep;
-    long long ql = (long long)floor(((double)lo - (double)qmin) * inv) - 1;
-    long long qh = (long long)ceil(((double)hi - (double)qmin) * inv) + 1;
+    long long ql = (long long)floor(((double)lo - (double)qmin) * inv) - LM_QUANT_MARGIN;
+    long long qh = (long long)ceil(((double)hi - (double)qmin) * inv) + LM_QUANT_MARGIN;
     ql = ql < 0 ? 0 : (ql > 65535 ? 65535 : ql); qh = qh < 0 ? 0 : (qh > 65535 ? 65535 : qh);
     return (uint32_t)ql | ((uint32_t)qh << 16);
 }

@@ -14,6 +14,9 @@
 #endif
 #define LM_BVH2_MAX_DEPTH 40     // depth bound of the binary tree the 4-wide tree is collapsed from: a 4-wide node spans >= 2 binary
                                  // levels per 3 pushes, so the stack need is <= 1.5 * 40 + 1 <= LM_STACK_DEPTH
+#define LM_QUANT_MARGIN 2        // grid cells a quantised child box is widened by on each side beyond outward rounding: one for the fp32 evaluation of the slab
+                                 // distances, one for the folded 2^23 offset of the packed slab test (lm_traverse.h LM_SLAB_PERM 3: up to half a cell)
+#define LM_BOX_NONE 0x0000ffffu  // per-axis word of an absent child: lo = 0xffff, hi = 0 — inverted, so the slab test misses without looking at the reference
 #define LM_REF_NONE 0x7fffffff   // absent child of a 4-wide node (also the traversal's "finished" marker; never followed)
 #ifndef LM_TOP_NODES
 #define LM_TOP_NODES 21          // top-of-tree node records (breadth-first from the root) the queue traversal kernels stage in LDS; 0 = none.

@@ -90,41 +90,73 @@ __device__ __forceinline__ float lm_safe_rcp(float d)
 #ifndef LM_ANY_ORDERED
 #define LM_ANY_ORDERED 0      // 1: any-hit queries also visit children near to far (finds close occluders sooner, costs the sort)
 #endif
-struct LmRayQ { float ax, ay, az, bx, by, bz; };      // t = q * a + b per axis (dequantisation folded into the slab test)
+typedef float lm_f2 __attribute__((ext_vector_type(2)));
 #ifndef LM_SLAB_PERM
-#define LM_SLAB_PERM 1       // 1: pick the near / far plane per axis by the sign of the direction (one v_perm_b32 on the packed lo|hi word) instead of min / max
-                             //    (measured alone: closest hit 270 -> 257 us, visibility 244 -> 230, NEE shadow 98 -> 95; identical results);
-                             // 2: additionally both planes of an axis in one v_pk_fma_f32 — the register pairs push the kernels over 64 VGPRs (spills / 7 waves): not used
+#define LM_SLAB_PERM 3       // 0: min / max of the two plane distances per axis;
+                             // 1: the near / far plane per axis picked by the sign of the direction (one v_perm_b32 on the packed lo|hi word), then 2 conversions
+                             //    + 2 FMAs (measured alone against 0: closest hit 270 -> 257 us, visibility 244 -> 230, NEE shadow 98 -> 95; identical results);
+                             // 3: the permute builds the FLOAT 2^23 + q directly (exponent byte of 2^23 over the 16-bit plane index: exact, no conversion), near
+                             //    and far plane of an axis sit in a register pair and take ONE packed FMA: 3 instructions per axis instead of 5.  The offset
+                             //    is folded into the ray's b (one rounding of b - 2^23 a: up to half a grid cell), which the builders' rounding margin
+                             //    covers (LM_QUANT_MARGIN: bvh.cpp `quant`, kernels.hip lm_quant_axis)
 #endif
+// t = q * a + b per axis (dequantisation folded into the slab test); variant 3 keeps (a, b - 2^23 a) as a pair and the two byte selectors per axis
+struct LmRayQ { lm_f2 x, y, z; uint32_t nx, fx, ny, fy, nz, fz; };
+__device__ __forceinline__ void lm_ray_setup(const LmScene& sc, const lf3& o, const lf3& d, LmRayQ& r)
+{
+    const float idx = lm_safe_rcp(d.x), idy = lm_safe_rcp(d.y), idz = lm_safe_rcp(d.z);
+    // node boxes are 16-bit fixed point: world = qmin + q * qstep, so t = q * (qstep * idir) + (qmin - o) * idir
+    const float ax = sc.quant[3] * idx, ay = sc.quant[4] * idy, az = sc.quant[5] * idz;
+    const float bx = (sc.quant[0] - o.x) * idx, by = (sc.quant[1] - o.y) * idy, bz = (sc.quant[2] - o.z) * idz;
+#if LM_SLAB_PERM == 3
+    r.x = (lm_f2){ax, fmaf(-8388608.f, ax, bx)}; r.y = (lm_f2){ay, fmaf(-8388608.f, ay, by)}; r.z = (lm_f2){az, fmaf(-8388608.f, az, bz)};
+    // v_perm_b32 selectors, result bytes 3..0: exponent byte of 2^23 (byte 7 of the source pair), 0x00, then the lo (a >= 0: near) or hi half of the word
+    r.nx = ax < 0.f ? 0x070c0302u : 0x070c0100u; r.fx = r.nx ^ 0x00000202u;
+    r.ny = ay < 0.f ? 0x070c0302u : 0x070c0100u; r.fy = r.ny ^ 0x00000202u;
+    r.nz = az < 0.f ? 0x070c0302u : 0x070c0100u; r.fz = r.nz ^ 0x00000202u;
+#else
+    r.x = (lm_f2){ax, bx}; r.y = (lm_f2){ay, by}; r.z = (lm_f2){az, bz};
+    // swapping the halves of the packed word by the sign gives (near, far) in (lo, hi)
+    r.nx = ax < 0.f ? 0x01000302u : 0x03020100u; r.ny = ay < 0.f ? 0x01000302u : 0x03020100u; r.nz = az < 0.f ? 0x01000302u : 0x03020100u;
+    r.fx = r.fy = r.fz = 0u;
+#endif
+}
+// Slab test of one quantised child box against [tmin, hitT]: key = entry distance (its bit pattern orders like the value: tn >= tmin >= 0), or
+// 0xffffffff for a miss.  An absent child carries an inverted box (lo = 0xffff, hi = 0: near > far on every axis), so it misses without a test.
 __device__ __forceinline__ void lm_slab(const uint4& q, const LmRayQ& r, float tmin, float hitT, uint32_t& key)
 {
-#if LM_SLAB_PERM
-    // t is monotonic in q (fma rounds monotonically), rising for a >= 0 and falling for a < 0, so the smaller of the two plane distances
-    // is the lo plane's for a >= 0 and the hi plane's otherwise: swapping the halves of the packed word by the sign gives the same two
-    // numbers min / max would, with 3 permutes instead of 6 min / max per child
-    const uint32_t sx = r.ax < 0.f ? 0x01000302u : 0x03020100u, sy = r.ay < 0.f ? 0x01000302u : 0x03020100u, sz = r.az < 0.f ? 0x01000302u : 0x03020100u;
-    const uint32_t px = __builtin_amdgcn_perm(q.x, q.x, sx), py = __builtin_amdgcn_perm(q.y, q.y, sy), pz = __builtin_amdgcn_perm(q.z, q.z, sz);
-#if LM_SLAB_PERM > 1          // 2: near and far plane of an axis in one packed v_pk_fma_f32 (two binary32 FMAs, each rounded once: the same numbers)
-    typedef float lm_f2 __attribute__((ext_vector_type(2)));
-    const lm_f2 tx = __builtin_elementwise_fma((lm_f2){(float)(px & 0xffffu), (float)(px >> 16)}, (lm_f2){r.ax, r.ax}, (lm_f2){r.bx, r.bx});
-    const lm_f2 ty = __builtin_elementwise_fma((lm_f2){(float)(py & 0xffffu), (float)(py >> 16)}, (lm_f2){r.ay, r.ay}, (lm_f2){r.by, r.by});
-    const lm_f2 tz = __builtin_elementwise_fma((lm_f2){(float)(pz & 0xffffu), (float)(pz >> 16)}, (lm_f2){r.az, r.az}, (lm_f2){r.bz, r.bz});
-    const float nx = tx.x, fx = tx.y, ny = ty.x, fy = ty.y, nz = tz.x, fz = tz.y;
-#else
-    const float nx = fmaf((float)(px & 0xffffu), r.ax, r.bx), fx = fmaf((float)(px >> 16), r.ax, r.bx);
-    const float ny = fmaf((float)(py & 0xffffu), r.ay, r.by), fy = fmaf((float)(py >> 16), r.ay, r.by);
-    const float nz = fmaf((float)(pz & 0xffffu), r.az, r.bz), fz = fmaf((float)(pz >> 16), r.az, r.bz);
-#endif
+#if LM_SLAB_PERM == 3
+    // t is monotonic in q (fma rounds monotonically), rising for a >= 0 and falling for a < 0, so the smaller of the two plane distances is the
+    // lo plane's for a >= 0 and the hi plane's otherwise
+    lm_f2 px, py, pz, tx, ty, tz;
+    px.x = u2f(__builtin_amdgcn_perm(0x4b000000u, q.x, r.nx)); px.y = u2f(__builtin_amdgcn_perm(0x4b000000u, q.x, r.fx));
+    py.x = u2f(__builtin_amdgcn_perm(0x4b000000u, q.y, r.ny)); py.y = u2f(__builtin_amdgcn_perm(0x4b000000u, q.y, r.fy));
+    pz.x = u2f(__builtin_amdgcn_perm(0x4b000000u, q.z, r.nz)); pz.y = u2f(__builtin_amdgcn_perm(0x4b000000u, q.z, r.fz));
+    // (near, far) * a + b': source 0 by halves, source 1 = the pair's low word for both results, source 2 = its high word for both
+    asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(tx) : "v"(px), "v"(r.x));
+    asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(ty) : "v"(py), "v"(r.y));
+    asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(tz) : "v"(pz), "v"(r.z));
+    // (written as instructions: behind an asm result, fmaxf / fminf would first quiet a possible signalling NaN — 2 more instructions per child)
+    float tn, tf;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tn) : "v"(tx.x), "v"(ty.x), "v"(tz.x));
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tf) : "v"(tx.y), "v"(ty.y), "v"(tz.y));
+    asm("v_max_f32 %0, %1, %2" : "=v"(tn) : "v"(tn), "v"(tmin));
+    asm("v_min_f32 %0, %1, %2" : "=v"(tf) : "v"(tf), "v"(hitT));
+#elif LM_SLAB_PERM == 1
+    const uint32_t px = __builtin_amdgcn_perm(q.x, q.x, r.nx), py = __builtin_amdgcn_perm(q.y, q.y, r.ny), pz = __builtin_amdgcn_perm(q.z, q.z, r.nz);
+    const float nx = fmaf((float)(px & 0xffffu), r.x.x, r.x.y), fx = fmaf((float)(px >> 16), r.x.x, r.x.y);
+    const float ny = fmaf((float)(py & 0xffffu), r.y.x, r.y.y), fy = fmaf((float)(py >> 16), r.y.x, r.y.y);
+    const float nz = fmaf((float)(pz & 0xffffu), r.z.x, r.z.y), fz = fmaf((float)(pz >> 16), r.z.x, r.z.y);
     const float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
     const float tf = fminf(fminf(fx, fy), fminf(fz, hitT));
 #else
-    const float lox = fmaf((float)(q.x & 0xffffu), r.ax, r.bx), hix = fmaf((float)(q.x >> 16), r.ax, r.bx);
-    const float loy = fmaf((float)(q.y & 0xffffu), r.ay, r.by), hiy = fmaf((float)(q.y >> 16), r.ay, r.by);
-    const float loz = fmaf((float)(q.z & 0xffffu), r.az, r.bz), hiz = fmaf((float)(q.z >> 16), r.az, r.bz);
+    const float lox = fmaf((float)(q.x & 0xffffu), r.x.x, r.x.y), hix = fmaf((float)(q.x >> 16), r.x.x, r.x.y);
+    const float loy = fmaf((float)(q.y & 0xffffu), r.y.x, r.y.y), hiy = fmaf((float)(q.y >> 16), r.y.x, r.y.y);
+    const float loz = fmaf((float)(q.z & 0xffffu), r.z.x, r.z.y), hiz = fmaf((float)(q.z >> 16), r.z.x, r.z.y);
     const float tn = fmaxf(fmaxf(fminf(lox, hix), fminf(loy, hiy)), fmaxf(fminf(loz, hiz), tmin));
     const float tf = fminf(fminf(fmaxf(lox, hix), fmaxf(loy, hiy)), fminf(fmaxf(loz, hiz), hitT));
 #endif
-    key = (tn <= tf && (int)q.w != LM_REF_NONE) ? f2u(tn) : 0xffffffffu;       // tn >= tmin >= 0: the bit pattern orders like the value
+    key = tn <= tf ? f2u(tn) : 0xffffffffu;
 }
 __device__ __forceinline__ void lm_cex(uint32_t& ka, int& ra, uint32_t& kb, int& rb)
 {
@@ -173,11 +205,8 @@ template <bool ANY>
 __device__ __forceinline__ bool lm_traverse(const LmScene& sc, const lf3& o, const lf3& d, float tmin, float tmax,
                                             const LmStack& stack, LmHit& hit, uint32_t* cnt)
 {
-    const float idx = lm_safe_rcp(d.x), idy = lm_safe_rcp(d.y), idz = lm_safe_rcp(d.z);
-    // node boxes are 16-bit fixed point: world = qmin + q * qstep, so t = q * (qstep * idir) + (qmin - o) * idir
     LmRayQ rq;
-    rq.ax = sc.quant[3] * idx; rq.ay = sc.quant[4] * idy; rq.az = sc.quant[5] * idz;
-    rq.bx = (sc.quant[0] - o.x) * idx; rq.by = (sc.quant[1] - o.y) * idy; rq.bz = (sc.quant[2] - o.z) * idz;
+    lm_ray_setup(sc, o, d, rq);
     float hitT = tmax;
     uint32_t hitOrder = 0xffffffffu;
     bool found = false;
@@ -259,7 +288,7 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
     uint32_t rayIdx = 0;
     lf3 o = v3(0.f), d = v3(0.f);
     float tmin = 0.f, tmax = 0.f, hitT = 0.f;
-    LmRayQ rq = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    LmRayQ rq = {(lm_f2){0.f, 0.f}, (lm_f2){0.f, 0.f}, (lm_f2){0.f, 0.f}, 0u, 0u, 0u, 0u, 0u, 0u};
     uint32_t hitOrder = 0xffffffffu;
     bool found = false;
     int sp = 0, cur = 0;
@@ -304,9 +333,7 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
             if (!active && rank < give) {
                 rayIdx = base + used + rank;
                 fetch(rayIdx, o, d, tmin, tmax);
-                const float idx = lm_safe_rcp(d.x), idy = lm_safe_rcp(d.y), idz = lm_safe_rcp(d.z);
-                rq.ax = sc.quant[3] * idx; rq.ay = sc.quant[4] * idy; rq.az = sc.quant[5] * idz;
-                rq.bx = (sc.quant[0] - o.x) * idx; rq.by = (sc.quant[1] - o.y) * idy; rq.bz = (sc.quant[2] - o.z) * idz;
+                lm_ray_setup(sc, o, d, rq);
                 hitT = tmax; hitOrder = 0xffffffffu; found = false; sp = 0; cur = root;
 #if LM_SPECULATE
                 pending = LM_REF_NONE;
@@ -405,10 +432,8 @@ __device__ __forceinline__ void lm_trace_packets(const LmScene& sc, uint32_t n, 
         lf3 o = v3(0.f), d = v3(0.f, 0.f, 1.f);
         float tmin = 0.f, tmax = 0.f;
         if (valid) fetch(i, o, d, tmin, tmax);
-        const float idx = lm_safe_rcp(d.x), idy = lm_safe_rcp(d.y), idz = lm_safe_rcp(d.z);
         LmRayQ rq;
-        rq.ax = sc.quant[3] * idx; rq.ay = sc.quant[4] * idy; rq.az = sc.quant[5] * idz;
-        rq.bx = (sc.quant[0] - o.x) * idx; rq.by = (sc.quant[1] - o.y) * idy; rq.bz = (sc.quant[2] - o.z) * idz;
+        lm_ray_setup(sc, o, d, rq);
         float hitT = valid ? tmax : -1.f;                          // a lane without a ray (or, any-hit, with its answer) fails every box test: tf < tmin
         uint32_t hitOrder = 0xffffffffu;
         bool found = false;

@@ -154,7 +154,8 @@ struct lumen_mi_renderer {
     bool instrumented = false;
     int tailBelow = -1;                     // waves expected to hold fewer rays than this run as one path-tail launch (0 = off,
                                             // -1 = auto: 65536 for windows under 1 Mpixel, where the wave chain is the critical path, else 16384) ...
-    int tailLanes = 16;                     // ... with this many paths per wavefront
+    int tailLanes = -1;                     // ... with this many paths per wavefront (-1 = auto: 64 for windows from 0.75 Mpixel, where the tail hides behind
+                                            // the other streams and fuller wavefronts save VALU issue slots; 16 for smaller windows, where the tail IS the critical path)
     uint32_t* pinnedCounters[2] = {nullptr, nullptr}; hipEvent_t evCnt[2] = {nullptr, nullptr}; bool cntPending[2] = {false, false};
     uint32_t estRays[LM_MAX_DEPTH + 1] = {0}; bool haveEst = false;     // rays per wave of the most recent frame that has been read back
     int refillBelow = 40, refillVisibility = 32, refillPrimary = 0;      // lane-refill thresholds of the queue traversal kernels (tunable via LUMEN_MI_REFILL*)
