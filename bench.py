@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--exact-seams", choices=["auto", "on", "off"], default="auto",
                     help="multi-GPU: exchange the halo rings' reservoir history (and the executed-wave count) after every TraceFrame; "
                          "auto = only for path depths that have temporal history (odd number of waves per frame)")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: no HIP events around the kernels in the timed region (the roofline "
+                    "entry then has no live launch time)")
     ap.add_argument("--emulate-rank", default="", help="R/N: on ONE GPU render only rank R's window of an N-GPU tile grid (no gather); "
                     "design aid for the per-rank time of the tiled path, never the reported benchmark line")
     args = ap.parse_args()
@@ -230,18 +232,28 @@ def main():
         del ev_log[:]
         for _ in range(args.warmup):
             frame()
-        r.EnableKernelTiming(True)
+        # HIP events around the roofline kernel's launches (and one pair per TraceFrame) only; the per-class breakdown comes from the pass below
+        r.EnableKernelTiming(0 if args.no_kernel_timing else 2)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             frame(record=world > 1)
+        host_dt = time.perf_counter() - t0                # the host has queued every launch of the K steps; the device is still working
         barrier()
         dt = time.perf_counter() - t0
         r.EnableKernelTiming(False)
-        # counters of the LAST TraceFrame (every TraceFrame of a step traces the same number of rays to within RNG noise);
-        # kernel times are HIP-event sums over the whole timed region, on the stream the kernels were launched on
+        # counters of the LAST TraceFrame (every TraceFrame of a step traces the same number of rays to within RNG noise); reading them also
+        # collects the HIP-event times of the timed region, on the stream the kernels were launched on
         c = r.GetCounters(50)
-        k = {name: r.GetKernelTime(i) for i, name in enumerate(("closest", "shadow", "shade", "restir", "total"))}
+        k = {name: r.GetKernelTime(i) for i, name in enumerate(("closest", "shadow", "shade", "restir", "total", "tail"))}
+        # device time by kernel class (explainer, outside the timed region): two more steps with events around every launch
+        r.EnableKernelTiming(1)
+        for _ in range(2):
+            frame()
+        barrier()
+        r.EnableKernelTiming(False)
+        r.GetCounters(50)
+        kb = {name: r.GetKernelTime(i) for i, name in enumerate(("closest", "shadow", "shade", "restir", "total", "tail"))}
         n_tf = max(1, k["total"][1])
         # a rank's counters include the rays of its halo pixels; those are redundant work (the neighbour owns the pixels), so only the
         # tile's share is counted: primary rays and the first ReSTIR visibility pass cover the whole window (scaled to the tile);
@@ -261,8 +273,8 @@ def main():
         else:
             rays_all = float(rays_tile)
         ms_per_step = dt * 1e3 / args.steps
-        return {"dt": dt, "ms_per_step": ms_per_step, "rays_per_frame": rays_all * spp, "value": rays_all * spp / (ms_per_step * 1e-3) / 1e6,
-                "counters": c, "kernel_ms": k, "n_traceframes": n_tf, "per_rank": per_rank}
+        return {"dt": dt, "ms_per_step": ms_per_step, "host_submit_ms_per_step": host_dt * 1e3 / args.steps, "rays_per_frame": rays_all * spp, "value": rays_all * spp / (ms_per_step * 1e-3) / 1e6,
+                "counters": c, "kernel_ms": k, "class_ms": kb, "n_traceframes": n_tf, "per_rank": per_rank}
 
     fast = args.mode == "fast"
     main_pass = timed_pass(fast)
@@ -271,19 +283,24 @@ def main():
         c, k, n_tf = main_pass["counters"], main_pass["kernel_ms"], main_pass["n_traceframes"]
         ms_per_step, value, rays_per_frame = main_pass["ms_per_step"], main_pass["value"], main_pass["rays_per_frame"]
         all_rays_inst = max(1, ci[0] + ci[1] + ci[2])
-        # ---- roofline of the dominant kernel by device time (closest-hit traversal: 6 launches per TraceFrame)
+        # ---- roofline of the dominant kernel by device time (closest-hit traversal: one launch per wave in front of the path tail)
         closest_ms, closest_launches = k["closest"]
-        nodes4_c = node_records * (c[0] / all_rays_inst)                    # 64-byte node records fetched, closest-hit share
-        tris_c = ci[21] * (c[0] / all_rays_inst)
-        alg = algorithmic_bytes_closest(c[0], nodes4_c, tris_c)             # per TraceFrame (all `depth` closest-hit launches)
-        alg_d4 = algorithmic_bytes_closest(c[0], 2.0 * nodes4_c, tris_c)    # the same visits priced as binary nodes (SURVEY d4 wording)
+        # rays the closest-hit KERNELS traced: the waves before the path tail takes over (the tail is its own launch and timing class)
+        rays_ck = float(sum(c[4 + d] for d in range(min(depth, int(round(closest_launches / n_tf))))))
+        nodes4_c = node_records * (rays_ck / all_rays_inst)                 # 64-byte node records fetched, closest-hit kernels' share
+        tris_c = ci[21] * (rays_ck / all_rays_inst)
+        alg = algorithmic_bytes_closest(rays_ck, nodes4_c, tris_c)          # per TraceFrame (all closest-hit launches)
+        alg_d4 = algorithmic_bytes_closest(rays_ck, 2.0 * nodes4_c, tris_c) # the same visits priced as binary nodes (SURVEY d4 wording)
         launches_per_tf = closest_launches / n_tf
         per_launch_ms = closest_ms / max(1, closest_launches)
         gbs = lambda bytes_per_tf: (bytes_per_tf / max(1.0, launches_per_tf)) / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
         achieved = gbs(alg)
         pmc = load_pmc() if args.workload == "c2" and world == 1 and not emu else {}
         pk = lambda name, key: pmc.get(name, {}).get(key)
-        traffic_closest = pk("lm_k_trace_closest", "hbm_bytes_per_launch_corrected")
+        # per launch, averaged over both closest-hit kernels (per-lane queue kernel + the packet kernel of the primary wave)
+        tc = [(pk(n, "hbm_bytes_per_launch_corrected"), pk(n, "launches")) for n in ("lm_k_trace_closest", "lm_k_trace_closest_packet")]
+        tc = [(b, l) for b, l in tc if b is not None and l]
+        traffic_closest = sum(b * l for b, l in tc) / sum(l for _, l in tc) if tc else None
         npix = (win[2] - win[0]) * (win[3] - win[1])
         alg_tf = algorithmic_bytes_traceframe(c, depth, npix, ci[20], ci[21])
         # whole-frame HBM traffic from the PMC replay: sum over kernels of bytes per launch x launches per TraceFrame
@@ -308,19 +325,19 @@ def main():
                        "resample_mode": ("fast: hardware rcp/rsq/sqrt + contracted target function in the ReSTIR passes (rel-L2 vs oracle 1e-8 measured, 1e-3 asserted: "
                                          "test_fast_resampling_mode_stays_within_the_north_star_tolerance)") if fast else "exact: correctly rounded everywhere, bit-identical to the oracle",
                        "other_mode": None if other_pass is None else {"mode": "exact" if fast else "fast", "value": round(other_pass["value"], 3), "ms_per_step": round(other_pass["ms_per_step"], 4),
-                                                                     "device_ms_per_traceframe": dev(other_pass["kernel_ms"])},
+                                                                     "device_ms_per_traceframe": dev(other_pass["class_ms"])},
                        "triangles": desc.triangle_count(), "rays_per_frame": int(rays_per_frame), "ms_per_frame": round(ms_per_step, 4),
                        "tiles": f"{tiles.grid_for(world, W, H)[0]}x{tiles.grid_for(world, W, H)[1]} + {tiles.HALO}px halo" if world > 1 else "1x1",
                        "nodes4_per_ray": round(node_records / all_rays_inst, 2), "binary_node_equivalents_per_ray": round(ci[20] / all_rays_inst, 2), "tris_per_ray": round(ci[21] / all_rays_inst, 2),
                        "rays_per_wave": [int(c[4 + d]) for d in range(depth)], "nee_shadow_rays": int(c[1]), "restir_shadow_rays": int(c[2]),
-                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "host_submit_ms_per_step": round(main_pass["host_submit_ms_per_step"], 3),
                        "d4_accounting_bytes_per_traceframe": int(alg_tf),
                        "d4_accounting_over_hbm_peak": round(alg_tf * spp / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9), 4) if world == 1 else None,
                        "d4_note": "SURVEY d4 prices the reference's AoS data flow; above 1.0 means most of those bytes are cache hits or never move here — it is not a roofline",
                        "hbm_traffic_bytes_per_traceframe": None if hbm_tf is None else int(hbm_tf),
                        "hbm_traffic_frac": None if hbm_tf is None else round(hbm_tf / (tf_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
                        "hbm_traffic_source": None if hbm_tf is None else PMC_FILE + " (replayed: PMC passes of the builder's run, 2 x FETCH_SIZE + WRITE_SIZE per kernel)"},
-            "roofline": {"bound": "hbm", "kernel": "lm_k_trace_closest", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "lm_k_trace_closest (+ lm_k_trace_closest_packet: the primary wave)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic_closest,
                          "traffic_source": None if traffic_closest is None else PMC_FILE + " (replayed, not measured by this run)",
                          "traffic_over_algorithmic": None if not traffic_closest else round(traffic_closest / (alg / max(1.0, launches_per_tf)), 4),
@@ -329,7 +346,7 @@ def main():
                          "algorithmic_bytes_per_launch": int(alg / max(1.0, launches_per_tf)),
                          "achieved_d4_binary_node_pricing": round(gbs(alg_d4), 2)},
             "roofline_valu": valu,
-            "device_ms_per_traceframe": dev(k),
+            "device_ms_per_traceframe": dev(main_pass["class_ms"]),
         }
         if main_pass["per_rank"]:
             out["per_rank"] = main_pass["per_rank"]

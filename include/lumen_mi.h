@@ -143,7 +143,8 @@ int lumen_mi_get_frame_stat(lumen_mi_renderer*, const char* key, uint64_t* micro
 int lumen_mi_get_counters(lumen_mi_renderer*, uint64_t* out, uint32_t n);
 /* device time of one kernel class, summed over every frame traced since timing was enabled, measured with HIP events
  * on the renderer's stream; `launches` = number of timed launches (class 4: number of frames).
- * which: 0 closest-hit traversal, 1 shadow traversal, 2 extract+shade, 3 ReSTIR (all passes), 4 whole frame */
+ * which: 0 closest-hit traversal, 1 shadow traversal, 2 extract+shade, 3 ReSTIR (all passes), 4 whole frame, 5 path tail (the deep waves in one launch).
+ * enable: 0 off, 1 every class, 2 classes 0 and 4 only (fewer events in the streams: what a throughput measurement wants) */
 int lumen_mi_get_kernel_time(lumen_mi_renderer*, int which, float* milliseconds, uint32_t* launches);
 int lumen_mi_enable_kernel_timing(lumen_mi_renderer*, int enable);
 int lumen_mi_set_instrumented(lumen_mi_renderer*, int enable);   /* use the node/triangle counting traversal kernels */

@@ -84,7 +84,7 @@ void invert4(const float* m, float* out)
 void evBegin(R* r, int cls, size_t& slot)
 {
     slot = (size_t)-1;
-    if (!r->timing) return;
+    if (!r->timing || (r->timing == 2 && cls != 0 && cls != 4)) return;
     if (r->evUsed == r->evPool.size()) { R::EvPair p; if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return; p.cls = 0; r->evPool.push_back(p); }
     slot = r->evUsed++;
     r->evPool[slot].cls = cls;
@@ -94,7 +94,7 @@ void evEnd(R* r, size_t slot) { if (slot != (size_t)-1) (void)hipEventRecord(r->
 void evBegin2(R* r, int cls, size_t& slot, hipStream_t s)
 {
     slot = (size_t)-1;
-    if (!r->timing) return;
+    if (!r->timing || (r->timing == 2 && cls != 0 && cls != 4)) return;
     if (r->evUsed == r->evPool.size()) { R::EvPair p; if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return; p.cls = 0; r->evPool.push_back(p); }
     slot = r->evUsed++;
     r->evPool[slot].cls = cls;
@@ -280,7 +280,7 @@ int traceFrameAsync(R* r)
                 sct.spill += (size_t)r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS);
                 LM_HIP(hipEventRecord(r->evShade[depth], sx)); LM_HIP(hipStreamWaitEvent(stl, r->evShade[depth], 0));     // the queue's producer is done
             }
-            evBegin2(r, 0, ev, stl);
+            evBegin2(r, 5, ev, stl);
             Z(stl); K->path_tail(stl, r->numCU * 8, sct, withTailQueue(fr, q), q, inCount, (int)depth, (int)depthMax, seed, r->tailLanes > 0 ? r->tailLanes : (fr.n >= 786432u ? 64 : 16));
             evEnd2(r, ev, stl);
             if (overlap) LM_HIP(hipEventRecord(r->evTail, stl));
@@ -359,7 +359,7 @@ int syncAndCollect(R* r)
         }
         r->evUsed = 0;
         const float frames = (float)std::max<uint32_t>(1u, r->classLaunches[4]);
-        r->frameStats["Wavefront Iteration"] = (uint64_t)((r->classMs[0] + r->classMs[2] + r->classMs[3]) * 1000.f / frames);
+        r->frameStats["Wavefront Iteration"] = (uint64_t)((r->classMs[0] + r->classMs[2] + r->classMs[3] + r->classMs[5]) * 1000.f / frames);
         r->frameStats["Shadow Rays"] = (uint64_t)(r->classMs[1] * 1000.f / frames);
         r->frameStats["ReSTIR"] = (uint64_t)(r->classMs[3] * 1000.f / frames);
         r->frameStats["Total Frame Time"] = (uint64_t)(r->classMs[4] * 1000.f / frames);

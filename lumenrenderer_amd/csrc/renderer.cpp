@@ -574,7 +574,7 @@ int lumen_mi_get_counters(lumen_mi_renderer* r, uint64_t* out, uint32_t n)
 }
 int lumen_mi_get_kernel_time(lumen_mi_renderer* r, int which, float* ms, uint32_t* launches)
 {
-    if (!r || which < 0 || which > 4) return fail(LUMEN_MI_ERR_INVALID, "bad kernel class");
+    if (!r || which < 0 || which > 5) return fail(LUMEN_MI_ERR_INVALID, "bad kernel class");
     if (ms) *ms = r->classMs[which]; if (launches) *launches = r->classLaunches[which];
     return 0;
 }
@@ -582,8 +582,8 @@ int lumen_mi_enable_kernel_timing(lumen_mi_renderer* r, int e)
 {
     if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer");
     ApiLock lk(r);
-    if (e) { for (int c = 0; c < 5; c++) { r->classMs[c] = 0.f; r->classLaunches[c] = 0; } }      // enabling starts a new accumulation window
-    r->timing = e != 0;
+    if (e) { for (int c = 0; c < 6; c++) { r->classMs[c] = 0.f; r->classLaunches[c] = 0; } }      // enabling starts a new accumulation window
+    r->timing = e < 0 ? 0 : (e > 2 ? 1 : e);
     return 0;
 }
 int lumen_mi_set_tuning(lumen_mi_renderer* r, const char* key, int value)

@@ -237,10 +237,10 @@ struct lumen_mi_renderer {
     size_t lastLightCount = 0;
 
     // timing
-    bool timing = false;
+    int timing = 0;                         // 0 off, 1 every kernel class, 2 closest-hit launches and the frame only (a quarter of the events)
     struct EvPair { hipEvent_t a, b; int cls; };
     std::vector<EvPair> evPool; size_t evUsed = 0;
-    float classMs[5] = {0}; uint32_t classLaunches[5] = {0};
+    float classMs[6] = {0}; uint32_t classLaunches[6] = {0};
     std::map<std::string, uint64_t> frameStats;
 
     // render thread
