@@ -438,10 +438,27 @@ KN(lm_k_fill_bags)(LmScene sc, LmFrame fr, uint32_t seed, uint32_t total)
 // K21 PickPrimarySamples — ReSTIRKernels.cu:402-522.  One 16x16 pixel tile (aligned to the GLOBAL 16x16 grid) shares a light
 // bag (the reference keys the bag on the hardware SM id, which is not reproducible: DESIGN.md decision D2); the bag's 1000
 // (index, pdf) pairs are staged in LDS once per tile.
-template <class A, int ROLE>
-__device__ __forceinline__ void lm_pick_primary_body(const LmScene& sc, const LmFrame& fr, int cur, int rc, uint32_t seed, uint32_t* visCount, uint2* s_bag, uint32_t* s_tmp)
+// LDSL: the scene's light table fits LM_PICK_LDS_LIGHTS records and is staged in LDS as (p0, arm1, arm2, normal, radiance, area) — the 32
+// candidates of a pixel then read their light with four ds_read_b128 instead of four global gathers (the texture path is what this
+// kernel and the traversal kernels beside it compete for), and the arms are subtracted once per tile instead of once per candidate.
+#ifndef LM_PICK_LDS_LIGHTS
+#define LM_PICK_LDS_LIGHTS 256u
+#endif
+template <class A, int ROLE, bool LDSL = false>
+__device__ __forceinline__ void lm_pick_primary_body(const LmScene& sc, const LmFrame& fr, int cur, int rc, uint32_t seed, uint32_t* visCount, uint2* s_bag, uint32_t* s_tmp,
+                                                     float4* s_lights = nullptr)
 {
     if (ROLE == LM_RARE && fr.counters[LM_CNT_RARE] == 0u) return;      // grid-uniform: no surface of this frame needs the second launch
+    if constexpr (LDSL) {
+        for (uint32_t k = threadIdx.x; k < sc.numLights; k += LM_BLOCK) {
+            const LmTriLight l = lm_load_light(sc.lights, k);
+            const lf3 arm1 = l.p1 - l.p0, arm2 = l.p2 - l.p0;
+            s_lights[4u * k] = make_float4(l.p0.x, l.p0.y, l.p0.z, arm1.x);
+            s_lights[4u * k + 1u] = make_float4(arm1.y, arm1.z, arm2.x, arm2.y);
+            s_lights[4u * k + 2u] = make_float4(arm2.z, l.normal.x, l.normal.y, l.normal.z);
+            s_lights[4u * k + 3u] = make_float4(l.radiance.x, l.radiance.y, l.radiance.z, l.area);
+        }
+    }
     rc = lm_res_idx(fr, rc);
     const uint32_t tilesX = (fr.W + 15u) / 16u;
     const uint32_t tx0 = fr.x0 / 16u, ty0 = fr.y0 / 16u;
@@ -478,14 +495,22 @@ __device__ __forceinline__ void lm_pick_primary_body(const LmScene& sc, const Lm
                 const float r = lm_random_float(s);
                 const int pick = (int)roundf((float)(1000 - 1) * r);
                 const uint2 entry = s_bag[pick];
-                const LmTriLight light = lm_load_light(sc.lights, entry.x);
                 const float initialPdf = u2f(entry.y);               // contracted policy: its reciprocal (see the staging loop)
                 const float u = lm_random_float(s);
                 const float v = lm_random_float(s) * (1.f - u);
                 LmSample cand;
-                cand.p.radiance = light.radiance; cand.p.normal = light.normal; cand.p.area = light.area;
-                const lf3 arm1 = light.p1 - light.p0, arm2 = light.p2 - light.p0;
-                cand.p.position = light.p0 + (arm1 * u) + (arm2 * v);
+                lf3 p0, arm1, arm2;
+                if constexpr (LDSL) {
+                    const lm_lds_u4* lp = (const lm_lds_u4*)s_lights + 4u * entry.x;
+                    const uint4 a = lm_lds_read4(lp), b = lm_lds_read4(lp + 1), c = lm_lds_read4(lp + 2), d = lm_lds_read4(lp + 3);
+                    p0 = v3(u2f(a.x), u2f(a.y), u2f(a.z)); arm1 = v3(u2f(a.w), u2f(b.x), u2f(b.y)); arm2 = v3(u2f(b.z), u2f(b.w), u2f(c.x));
+                    cand.p.normal = v3(u2f(c.y), u2f(c.z), u2f(c.w)); cand.p.radiance = v3(u2f(d.x), u2f(d.y), u2f(d.z)); cand.p.area = u2f(d.w);
+                } else {
+                    const LmTriLight light = lm_load_light(sc.lights, entry.x);
+                    cand.p.radiance = light.radiance; cand.p.normal = light.normal; cand.p.area = light.area;
+                    p0 = light.p0; arm1 = light.p1 - light.p0; arm2 = light.p2 - light.p0;
+                }
+                cand.p.position = p0 + (arm1 * u) + (arm2 * v);
                 cand.contribution = v3(0.f);
                 lm_score<A>(cand.p, target, cand.contribution, cand.pdf);
                 lm_res_update<A>(fresh, cand, A::contracted ? cand.pdf * initialPdf : A::div(cand.pdf, initialPdf), s);
@@ -525,6 +550,23 @@ KN(lm_k_pick_primary_fast)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t see
     __shared__ uint2 s_bag[1000];
     __shared__ uint32_t s_tmp[5];
     lm_pick_primary_body<LmFast, LM_COMMON>(sc, fr, cur, rc, seed, visCount, s_bag, s_tmp);
+}
+// the same two kernels for scenes whose light table fits in LDS
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
+KN(lm_k_pick_primary_lds)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount)
+{
+    __shared__ uint2 s_bag[1000];
+    __shared__ uint32_t s_tmp[5];
+    __shared__ float4 s_lights[4 * LM_PICK_LDS_LIGHTS + 1];
+    lm_pick_primary_body<LmExact, LM_ALL, true>(sc, fr, cur, rc, seed, visCount, s_bag, s_tmp, s_lights);
+}
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
+KN(lm_k_pick_primary_fast_lds)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount)
+{
+    __shared__ uint2 s_bag[1000];
+    __shared__ uint32_t s_tmp[5];
+    __shared__ float4 s_lights[4 * LM_PICK_LDS_LIGHTS + 1];
+    lm_pick_primary_body<LmFast, LM_COMMON, true>(sc, fr, cur, rc, seed, visCount, s_bag, s_tmp, s_lights);
 }
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
 KN(lm_k_pick_primary_rare)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount)
@@ -1217,7 +1259,15 @@ static void l_path_tail(hipStream_t s, int g, LmScene sc, LmFrame fr, int inQ, c
 static void l_trace_shadow(hipStream_t s, int g, LmScene sc, LmFrame fr, const uint32_t* cnt, float tmin, int refillBelow) { hipLaunchKernelGGL(KN(lm_k_trace_shadow), LM_GRID(g), sc, fr, cnt, tmin, refillBelow); }
 static void l_fill_bags(hipStream_t s, LmScene sc, LmFrame fr, uint32_t seed, uint32_t total) { hipLaunchKernelGGL(KN(lm_k_fill_bags), LM_GRID((total + LM_BLOCK - 1) / LM_BLOCK), sc, fr, seed, total); }
 static void l_pick_primary(hipStream_t s, int tiles, LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount, int fast)
-{ if (fast) { hipLaunchKernelGGL(KN(lm_k_pick_primary_fast), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount); if (fast > 1) hipLaunchKernelGGL(KN(lm_k_pick_primary_rare), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount); } else hipLaunchKernelGGL(KN(lm_k_pick_primary), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount); }
+{
+    const bool ldsLights = sc.numLights <= LM_PICK_LDS_LIGHTS && LM_PICK_LDS_LIGHTS > 0u;
+    if (fast) {
+        if (ldsLights) hipLaunchKernelGGL(KN(lm_k_pick_primary_fast_lds), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount);
+        else hipLaunchKernelGGL(KN(lm_k_pick_primary_fast), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount);
+        if (fast > 1) hipLaunchKernelGGL(KN(lm_k_pick_primary_rare), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount);
+    } else if (ldsLights) hipLaunchKernelGGL(KN(lm_k_pick_primary_lds), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount);
+    else hipLaunchKernelGGL(KN(lm_k_pick_primary), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount);
+}
 static void l_trace_shade(hipStream_t s, int g, LmScene sc, LmFrame fr, int rc, const uint32_t* cnt, int refillBelow, int pass) { hipLaunchKernelGGL(KN(lm_k_restir_trace_shade), LM_GRID(g), sc, fr, rc, cnt, refillBelow, pass); }
 static void l_temporal(hipStream_t s, int g, LmFrame fr, int cur, int prev, int rc, int rp, int rf, uint32_t seed, uint32_t* visCount, int fast)
 { if (fast) { hipLaunchKernelGGL(KN(lm_k_restir_temporal_fast), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); if (fast > 1) hipLaunchKernelGGL(KN(lm_k_restir_temporal_rare), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); } else hipLaunchKernelGGL(KN(lm_k_restir_temporal), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); }
