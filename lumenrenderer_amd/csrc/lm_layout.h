@@ -61,6 +61,11 @@ struct LmDevMaterial {
     float4 color, emissive, transmittance, tint;
     uint32_t p[4];
     int32_t tex[8];         // 0 clearcoat 1 clearcoatRoughness 2 transmission 3 diffuse 4 emissive 5 metalRoughness 6 normal 7 tint; -1 = null
+    // Slots whose texture is a single texel (the default textures of a material without that map) or null are folded at material upload:
+    // bit k of constMask set = texConst[k] IS what the fetch of slot k returns for every uv (same arithmetic, done once on the host), so
+    // surface extraction skips descriptor + texel + sRGB-table loads for them.  Textures are immutable after lumen_mi_create_texture.
+    uint32_t constMask, pad[3];
+    float4 texConst[8];
 };
 struct LmTexDesc { uint32_t offset, w, h, srgb; };
 // emissive triangle, 64 bytes, memory order of TriangleLight (LightData.h:21-27)

@@ -32,6 +32,13 @@ __device__ float4 lm_tex2D(const LmScene& sc, int id, float u, float v)
     return r;
 }
 
+// texture slot k of a material: the folded constant when the slot's texture is a single texel or null (LmDevMaterial::constMask)
+__device__ __forceinline__ float4 lm_mat_tex(const LmScene& sc, const LmDevMaterial* mat, uint32_t constMask, int k, float u, float v)
+{
+    if ((constMask >> k) & 1u) return mat->texConst[k];
+    return lm_tex2D(sc, mat->tex[k], u, v);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // surface extraction — reference GPUExtractSurfaceData.cu:8-228
 // ---------------------------------------------------------------------------------------------------------------------
@@ -66,10 +73,11 @@ __device__ void lm_extract(const LmScene& sc, const uint4 hit, const lf3& ro, co
     const float uvx = A.uv.x * Wt + B.uv.x * U + C.uv.x * V;
     const float uvy = A.uv.y * Wt + B.uv.y * U + C.uv.y * V;
     const float flip = A.tangent.w;
-    const float4 normalMap = lm_tex2D(sc, mat->tex[6], uvx, uvy);
-    const float4 texColor = lm_tex2D(sc, mat->tex[3], uvx, uvy);
+    const uint32_t cm = mat->constMask;
+    const float4 normalMap = lm_mat_tex(sc, mat, cm, 6, uvx, uvy);
+    const float4 texColor = lm_mat_tex(sc, mat, cm, 3, uvx, uvy);
     float4 emissive = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (e.mode == 0u) { emissive = mat->emissive * e.emissive.w; emissive = emissive * lm_tex2D(sc, mat->tex[4], uvx, uvy); }
+    if (e.mode == 0u) { emissive = mat->emissive * e.emissive.w; emissive = emissive * lm_mat_tex(sc, mat, cm, 4, uvx, uvy); }
     else if (e.mode == 2u) emissive = e.emissive * e.emissive.w;
 
     const lf3 localNormal = normalize3(A.normal * Wt + B.normal * U + C.normal * V);
@@ -106,15 +114,15 @@ __device__ void lm_extract(const LmScene& sc, const uint4 hit, const lf3& ro, co
     s.tangent = tangentWorld;
     s.mat.color = mat->color; s.mat.transmittance = mat->transmittance; s.mat.tint = mat->tint;
     s.mat.p0 = mat->p[0]; s.mat.p1 = mat->p[1]; s.mat.p2 = mat->p[2];
-    const float4 mr = lm_tex2D(sc, mat->tex[5], uvx, uvy);
+    const float4 mr = lm_mat_tex(sc, mat, cm, 5, uvx, uvy);
     const float baseMetal = lm_unpack8(mat->p[0], 0), baseRough = lm_unpack8(mat->p[0], 24);
     lm_pack8(s.mat.p0, 0, mr.z * baseMetal);
     lm_pack8(s.mat.p0, 24, mr.y * baseRough);
     s.mat.color = texColor * mat->color;
-    const float4 cc = lm_tex2D(sc, mat->tex[0], uvx, uvy);
-    const float4 ccr = lm_tex2D(sc, mat->tex[1], uvx, uvy);
-    const float4 tr = lm_tex2D(sc, mat->tex[2], uvx, uvy);
-    const float4 tint = lm_tex2D(sc, mat->tex[7], uvx, uvy);
+    const float4 cc = lm_mat_tex(sc, mat, cm, 0, uvx, uvy);
+    const float4 ccr = lm_mat_tex(sc, mat, cm, 1, uvx, uvy);
+    const float4 tr = lm_mat_tex(sc, mat, cm, 2, uvx, uvy);
+    const float4 tint = lm_mat_tex(sc, mat, cm, 7, uvx, uvy);
     const lf3 finalTint = v3(tint.x, tint.y, tint.z) * v3(mat->tint);
     const float finalClearCoat = lm_unpack8(mat->p[2], 0) * cc.x;
     const float gloss = lm_unpack8(mat->p[2], 8) * (1.f - ccr.x);

@@ -177,6 +177,12 @@ static int fillMaterial(lumen_mi_renderer* r, const lumen_mi_material_data* d, M
     // PTMaterial::CreateDeviceMaterial (PTMaterial.cpp:97-148): the clear-coat-roughness texture overwrites the clear-coat
     // slot and the roughness slot stays a null handle; kept for parity
     v.tex[0] = tCCR; v.tex[1] = -1; v.tex[2] = tTr; v.tex[3] = tDiff; v.tex[4] = tEm; v.tex[5] = tMR; v.tex[6] = tNorm; v.tex[7] = tTint;
+    for (int k = 0; k < 8; k++) {                                 // constant slots (lm_layout.h LmDevMaterial::constMask)
+        float c[4] = {0.f, 0.f, 0.f, 0.f};
+        if (v.tex[k] >= 0) { const Texture& t = r->textures[(size_t)v.tex[k]]; if (t.w != 1u || t.h != 1u) continue; texel(t, 0, 0, c); }
+        v.constMask |= 1u << k;
+        v.texConst[k] = make_float4(c[0], c[1], c[2], c[3]);
+    }
     // Can surface extraction produce a material outside the contracted ReSTIR evaluation?  Transmission / clear coat are factor x texel
     // (GPUExtractSurfaceData.cu:183-196): 0 when the factor byte is 0.  Roughness is texel.g x factor re-packed by truncation: the byte is
     // 0 (mirror-like: the opaque stack is absent) iff the product is below 1/255; bilinear filtering never goes below the smallest texel.

@@ -110,6 +110,7 @@ struct SceneSet {
     }
 };
 
+void texel(const Texture& t, int x, int y, float out[4]);      // scene.cpp: host texture fetch, same definition as the device fetch
 inline float g_srgbLut[256];
 inline void initLut() { static bool d = false; if (d) return; for (int i = 0; i < 256; i++) { const double c = i / 255.0; g_srgbLut[i] = (float)(c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4)); } d = true; }
 
