@@ -201,6 +201,61 @@ __device__ __forceinline__ int lm_node_step(const LmScene& sc, int cur, const Lm
     return next;
 }
 
+// The same step in two halves for the queue kernels (LM_NODE_PIPELINE): the record fetch, and the evaluation, which issues the fetch of the
+// child it continues with as soon as that child is known — after three of the five comparators (closest hit) or the first-hit select
+// (any hit) — so that the rest of the ordering and the stack pushes run under the load instead of in front of it.  `pre` tells the
+// caller that q0..q3 already hold the records of the returned node.  Visiting order, stack contents and results are those of lm_node_step.
+// Measured and NOT used: the records in flight stay live across the pushes, which costs 12 more VGPRs — closest hit spills at eight
+// waves per SIMD (200 -> 400 us) or runs with six (230 us), visibility 228 -> 300 us, NEE shadow 91 -> 106 us, frame -5 %
+// (profiles/r02_node_pipeline_ab.txt): occupancy hides the load better than the overlap does.
+#ifndef LM_NODE_PIPELINE
+#define LM_NODE_PIPELINE 0
+#endif
+__device__ __forceinline__ void lm_node_fetch(const LmScene& sc, int cur, const lm_lds_u4* top, uint4& q0, uint4& q1, uint4& q2, uint4& q3)
+{
+#if LM_TOP_NODES
+    if (cur >= LM_TOP_BASE) {                                    // (only kernels that staged the table ever hold such a reference)
+        const lm_lds_u4* nd = top + 4u * (uint32_t)(cur - LM_TOP_BASE);
+        q0 = lm_lds_read4(nd); q1 = lm_lds_read4(nd + 1); q2 = lm_lds_read4(nd + 2); q3 = lm_lds_read4(nd + 3);
+    } else
+#endif
+    {
+        const uint4* nd = sc.nodes[cur].c;
+        q0 = nd[0]; q1 = nd[1]; q2 = nd[2]; q3 = nd[3];
+    }
+}
+template <bool ANY>
+__device__ __forceinline__ int lm_node_eval(const LmScene& sc, uint4& q0, uint4& q1, uint4& q2, uint4& q3, bool& pre, const LmRayQ& rq, float tmin, float hitT,
+                                            const LmStack& stack, int& sp, const lm_lds_u4* top, uint32_t* boxes = nullptr)
+{
+    if (boxes) *boxes += ((int)q0.w != LM_REF_NONE) + ((int)q1.w != LM_REF_NONE) + ((int)q2.w != LM_REF_NONE) + ((int)q3.w != LM_REF_NONE);   // counting build
+    uint32_t k0, k1, k2, k3;
+    lm_slab(q0, rq, tmin, hitT, k0); lm_slab(q1, rq, tmin, hitT, k1); lm_slab(q2, rq, tmin, hitT, k2); lm_slab(q3, rq, tmin, hitT, k3);
+    int r0 = (int)q0.w, r1 = (int)q1.w, r2 = (int)q2.w, r3 = (int)q3.w;
+    pre = false;
+    if (!ANY || LM_ANY_ORDERED) {
+        lm_cex(k0, r0, k1, r1); lm_cex(k2, r2, k3, r3); lm_cex(k0, r0, k2, r2);          // (k0, r0) is the nearest hit child now
+        if (k0 == 0xffffffffu) return sp == 0 ? LM_REF_NONE : lm_pop(stack, sp);
+        pre = r0 >= 0;
+        if (pre) lm_node_fetch(sc, r0, top, q0, q1, q2, q3);
+        lm_cex(k1, r1, k3, r3); lm_cex(k1, r1, k2, r2);
+        if (k3 != 0xffffffffu) lm_push(stack, sp, r3);
+        if (k2 != 0xffffffffu) lm_push(stack, sp, r2);
+        if (k1 != 0xffffffffu) lm_push(stack, sp, r1);
+        return r0;
+    }
+    // any hit: continue with the first hit child in node order, push the others (highest index first: the same stack as lm_node_step)
+    const bool h0 = k0 != 0xffffffffu, h1 = k1 != 0xffffffffu, h2 = k2 != 0xffffffffu, h3 = k3 != 0xffffffffu;
+    const int next = h0 ? r0 : h1 ? r1 : h2 ? r2 : h3 ? r3 : LM_REF_NONE;
+    if (next == LM_REF_NONE) return sp == 0 ? LM_REF_NONE : lm_pop(stack, sp);
+    pre = next >= 0;
+    if (pre) lm_node_fetch(sc, next, top, q0, q1, q2, q3);
+    if (h3 && (h0 || h1 || h2)) lm_push(stack, sp, r3);
+    if (h2 && (h0 || h1)) lm_push(stack, sp, r2);
+    if (h1 && h0) lm_push(stack, sp, r1);
+    return next;
+}
+
 template <bool ANY>
 __device__ __forceinline__ bool lm_traverse(const LmScene& sc, const lf3& o, const lf3& d, float tmin, float tmax,
                                             const LmStack& stack, LmHit& hit, uint32_t* cnt)
@@ -353,6 +408,10 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
 #if LM_NODE_EXIT
             const int roundLanes = (int)__popcll(__ballot(true));
 #endif
+#if LM_NODE_PIPELINE && !LM_INSTRUMENT
+            bool pre = false;                                        // nq0..nq3 hold the records of `cur` (only inside this loop: a lane that
+            uint4 nq0, nq1, nq2, nq3;                                // leaves it with a prefetched node fetches it again on re-entry)
+#endif
             while (cur >= 0 && cur != 0x7fffffff) {
 #if LM_NODE_EXIT
                 // leave the node loop once few lanes are still descending while others wait with a leaf (or a finished ray):
@@ -368,6 +427,9 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
                 { const unsigned long long m = __ballot(true);           // lane occupancy of this node-step issue
                   if ((int)lane == __ffsll((long long)m) - 1) { atomicAdd((unsigned long long*)(cnt + LM_CNT_OCC), (unsigned long long)__popcll(m)); atomicAdd((unsigned long long*)(cnt + LM_CNT_OCC + 2), 64ull); } }
                 cur = lm_node_step<ANY>(sc, cur, rq, tmin, hitT, stack, sp, top, &nNodes);      // + child boxes tested
+#elif LM_NODE_PIPELINE
+                if (!pre) lm_node_fetch(sc, cur, top, nq0, nq1, nq2, nq3);
+                cur = lm_node_eval<ANY>(sc, nq0, nq1, nq2, nq3, pre, rq, tmin, hitT, stack, sp, top);
 #else
                 cur = lm_node_step<ANY>(sc, cur, rq, tmin, hitT, stack, sp, top);
 #endif
