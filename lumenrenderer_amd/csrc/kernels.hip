@@ -15,6 +15,9 @@
 #ifndef LM_RESTIR_WAVES
 #define LM_RESTIR_WAVES 1        // __launch_bounds__ minimum waves per SIMD for the ALU-heavy ReSTIR kernels (tuning knob)
 #endif
+#ifndef LM_FAST_WAVES
+#define LM_FAST_WAVES 5          // the fast-mode instantiations of those kernels fit 96 VGPRs: five waves per SIMD
+#endif
 #ifndef LM_INSTRUMENT
 #define LM_INSTRUMENT 0
 #endif
@@ -540,7 +543,7 @@ KN(lm_k_pick_primary)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, ui
     __shared__ uint32_t s_tmp[5];
     lm_pick_primary_body<LmExact, LM_ALL>(sc, fr, cur, rc, seed, visCount, s_bag, s_tmp);
 }
-extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_FAST_WAVES)
 KN(lm_k_pick_primary_fast)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount)
 {
 #ifdef LM_PICK_LDS_PAD
@@ -560,7 +563,7 @@ KN(lm_k_pick_primary_lds)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed
     __shared__ float4 s_lights[4 * LM_PICK_LDS_LIGHTS + 1];
     lm_pick_primary_body<LmExact, LM_ALL, true>(sc, fr, cur, rc, seed, visCount, s_bag, s_tmp, s_lights);
 }
-extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_FAST_WAVES)
 KN(lm_k_pick_primary_fast_lds)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount)
 {
     __shared__ uint2 s_bag[1000];
@@ -670,7 +673,7 @@ KN(lm_k_restir_temporal)(LmFrame fr, int cur, int prev, int rc, int rp, int rf, 
     __shared__ uint32_t s_tmp[5];
     lm_restir_temporal_body<LmExact, LM_ALL>(fr, cur, prev, rc, rp, rf, seed, visCount, s_tmp);
 }
-extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_FAST_WAVES)
 KN(lm_k_restir_temporal_fast)(LmFrame fr, int cur, int prev, int rc, int rp, int rf, uint32_t seed, uint32_t* visCount)
 {
     __shared__ uint32_t s_tmp[5];
@@ -745,14 +748,9 @@ __device__ __forceinline__ void lm_restir_spatial_body(const LmFrame& fr, int cu
         }
         LmReservoir out; lm_res_fresh(out);
         long long sum = 0;
+        // (no prefetch of the next record: holding it costs 16 registers = one wave per SIMD, and five waves hide the gather as well: 500 us alone
+        // either way, frame equal within noise — profiles/r02_spatial_prefetch_ab.txt)
         for (;;) {
-            // prefetch of the next accepted candidate's record.  The load is unconditional (the last round re-reads the first record, a
-            // cache hit): a conditional load makes the compiler select between a global and a stack POINTER, i.e. spill the current
-            // record to scratch and reload everything through flat loads
-            const bool more = mask != 0u;
-            const float4* hn = hotIn + 4u * (more ? candAt((uint32_t)__ffs((int)mask) - 1u) : nb0);
-            mask &= mask - 1u;                                      // 0 stays 0
-            const float4 na = hn[0], np1 = hn[1], np2 = hn[2], np3 = hn[3];
             LmSample rs;
             rs.p = lm_point_unpack(p1, p2, p3);
             rs.contribution = v3(0.f);                             // the neighbour's own contribution is not carried over (reference: a fresh LightSample)
@@ -760,8 +758,10 @@ __device__ __forceinline__ void lm_restir_spatial_body(const LmFrame& fr, int cu
             lm_score<A>(rs.p, target, rs.contribution, rs.pdf);
             lm_res_update<A>(out, rs, (float)cnt * a.y * rs.pdf, seed);   // global seed: same draw for all pixels (reference quirk)
             sum += cnt;
-            if (!more) break;
-            a = na; p1 = np1; p2 = np2; p3 = np3;
+            if (mask == 0u) break;
+            const float4* hn = hotIn + 4u * candAt((uint32_t)__ffs((int)mask) - 1u);
+            mask &= mask - 1u;
+            a = hn[0]; p1 = hn[1]; p2 = hn[2]; p3 = hn[3];
         }
         out.count = sum;
         lm_res_update_weight<A>(out);
@@ -774,7 +774,7 @@ __device__ __forceinline__ void lm_restir_spatial_body(const LmFrame& fr, int cu
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_SPATIAL_WAVES)
 KN(lm_k_restir_spatial)(LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin) { lm_restir_spatial_body<LmExact, LM_ALL>(fr, cur, rin, rout, seed, margin); }
 #ifndef LM_SPATIAL_FAST_WAVES
-#define LM_SPATIAL_FAST_WAVES 4
+#define LM_SPATIAL_FAST_WAVES 5
 #endif
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_SPATIAL_FAST_WAVES)
 KN(lm_k_restir_spatial_fast)(LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin) { lm_restir_spatial_body<LmFast, LM_COMMON>(fr, cur, rin, rout, seed, margin); }
@@ -807,7 +807,7 @@ __device__ __forceinline__ void lm_restir_combine_body(const LmFrame& fr, int cu
 }
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
 KN(lm_k_restir_combine)(LmFrame fr, int cur, int rc, int rs, uint32_t seed) { lm_restir_combine_body<LmExact, LM_ALL>(fr, cur, rc, rs, seed); }
-extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_FAST_WAVES)
 KN(lm_k_restir_combine_fast)(LmFrame fr, int cur, int rc, int rs, uint32_t seed) { lm_restir_combine_body<LmFast, LM_COMMON>(fr, cur, rc, rs, seed); }
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
 KN(lm_k_restir_combine_rare)(LmFrame fr, int cur, int rc, int rs, uint32_t seed) { lm_restir_combine_body<LmExact, LM_RARE>(fr, cur, rc, rs, seed); }
