@@ -309,7 +309,9 @@ def main():
         tf_ms = ms_per_step / spp
         # ---- VALU-bound kernels (candidate pick; spatial reuse): executed lane-operations / alone time against the fp32 issue peak
         valu = []
-        for name in (("lm_k_pick_primary_fast", "lm_k_restir_spatial_fast") if fast else ("lm_k_pick_primary", "lm_k_restir_spatial")):
+        pick = "lm_k_pick_primary_fast" if fast else "lm_k_pick_primary"
+        pick = pick + "_lds" if pick + "_lds" in pmc else pick           # scenes whose light table fits in LDS run that instantiation
+        for name in (pick, "lm_k_restir_spatial_fast" if fast else "lm_k_restir_spatial"):
             lane_ops, us = pk(name, "SQ_THREAD_CYCLES_VALU_per_launch"), pk(name, "alone_us")
             if lane_ops and us:
                 ach = lane_ops / (us * 1e-6) / 1e12
