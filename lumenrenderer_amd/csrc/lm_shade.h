@@ -5,25 +5,34 @@
 // ---------------------------------------------------------------------------------------------------------------------
 // texture fetch: RGBA8, bilinear, wrap, normalised coordinates, optional sRGB decode (reference PTTexture.cpp:35-74)
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float4 lm_texel(const LmScene& sc, const LmTexDesc& t, int x, int y)
+// `lut` = the 256-entry sRGB decode table staged in LDS by the calling kernel (lm_stage_lut): three table reads per texel of an sRGB
+// texture are ds_read_b32 instead of dependent global gathers
+typedef __attribute__((address_space(3))) float lm_lds_float;
+__device__ __forceinline__ const lm_lds_float* lm_stage_lut(float* s_lut, const LmScene& sc)
+{
+    s_lut[threadIdx.x] = sc.srgbLut ? sc.srgbLut[threadIdx.x] : 0.f;          // LM_BLOCK = 256 threads = 256 entries (no table: a scene without textures)
+    __syncthreads();
+    return (const lm_lds_float*)s_lut;
+}
+__device__ __forceinline__ float4 lm_texel(const LmScene& sc, const lm_lds_float* lut, const LmTexDesc& t, int x, int y)
 {
     const uint32_t p = sc.texels[t.offset + (uint32_t)y * t.w + (uint32_t)x];
     const uint32_t r = p & 255u, g = (p >> 8) & 255u, b = (p >> 16) & 255u, a = p >> 24;
-    if (t.srgb) return make_float4(sc.srgbLut[r], sc.srgbLut[g], sc.srgbLut[b], (float)a / 255.0f);
+    if (t.srgb) return make_float4(lut[r], lut[g], lut[b], (float)a / 255.0f);
     return make_float4((float)r / 255.0f, (float)g / 255.0f, (float)b / 255.0f, (float)a / 255.0f);
 }
 __device__ __forceinline__ int lm_wrapi(int i, int n) { const int m = i % n; return m < 0 ? m + n : m; }
-__device__ float4 lm_tex2D(const LmScene& sc, int id, float u, float v)
+__device__ float4 lm_tex2D(const LmScene& sc, const lm_lds_float* lut, int id, float u, float v)
 {
     if (id < 0) return make_float4(0.f, 0.f, 0.f, 0.f);
     const LmTexDesc t = sc.texDesc[id];
-    if (t.w == 1u && t.h == 1u) return lm_texel(sc, t, 0, 0);           // lerp(a, a, w) == a exactly
+    if (t.w == 1u && t.h == 1u) return lm_texel(sc, lut, t, 0, 0);           // lerp(a, a, w) == a exactly
     const float x = u * (float)t.w - 0.5f, y = v * (float)t.h - 0.5f;
     const float fx0 = floorf(x), fy0 = floorf(y);
     const float ax = x - fx0, ay = y - fy0;
     const int x0 = lm_wrapi((int)fx0, (int)t.w), y0 = lm_wrapi((int)fy0, (int)t.h);
     const int x1 = lm_wrapi(x0 + 1, (int)t.w), y1 = lm_wrapi(y0 + 1, (int)t.h);
-    const float4 t00 = lm_texel(sc, t, x0, y0), t10 = lm_texel(sc, t, x1, y0), t01 = lm_texel(sc, t, x0, y1), t11 = lm_texel(sc, t, x1, y1);
+    const float4 t00 = lm_texel(sc, lut, t, x0, y0), t10 = lm_texel(sc, lut, t, x1, y0), t01 = lm_texel(sc, lut, t, x0, y1), t11 = lm_texel(sc, lut, t, x1, y1);
     float4 r;
     r.x = lerpf(lerpf(t00.x, t10.x, ax), lerpf(t01.x, t11.x, ax), ay);
     r.y = lerpf(lerpf(t00.y, t10.y, ax), lerpf(t01.y, t11.y, ax), ay);
@@ -33,10 +42,10 @@ __device__ float4 lm_tex2D(const LmScene& sc, int id, float u, float v)
 }
 
 // texture slot k of a material: the folded constant when the slot's texture is a single texel or null (LmDevMaterial::constMask)
-__device__ __forceinline__ float4 lm_mat_tex(const LmScene& sc, const LmDevMaterial* mat, uint32_t constMask, int k, float u, float v)
+__device__ __forceinline__ float4 lm_mat_tex(const LmScene& sc, const lm_lds_float* lut, const LmDevMaterial* mat, uint32_t constMask, int k, float u, float v)
 {
     if ((constMask >> k) & 1u) return mat->texConst[k];
-    return lm_tex2D(sc, mat->tex[k], u, v);
+    return lm_tex2D(sc, lut, mat->tex[k], u, v);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -57,7 +66,7 @@ __device__ __forceinline__ LmVertex lm_load_vertex(const float4* __restrict__ ve
     return r;
 }
 
-__device__ void lm_extract(const LmScene& sc, const uint4 hit, const lf3& ro, const lf3& rd, const lf3& rc, LmSurface& s)
+__device__ void lm_extract(const LmScene& sc, const lm_lds_float* lut, const uint4 hit, const lf3& ro, const lf3& rd, const lf3& rc, LmSurface& s)
 {
     s.position = v3(0.f); s.normal = v3(0.f); s.tangent = v3(0.f); s.incoming = v3(0.f); s.transport = v3(0.f);
     s.t = 0.f; s.flags = 0u;
@@ -74,10 +83,10 @@ __device__ void lm_extract(const LmScene& sc, const uint4 hit, const lf3& ro, co
     const float uvy = A.uv.y * Wt + B.uv.y * U + C.uv.y * V;
     const float flip = A.tangent.w;
     const uint32_t cm = mat->constMask;
-    const float4 normalMap = lm_mat_tex(sc, mat, cm, 6, uvx, uvy);
-    const float4 texColor = lm_mat_tex(sc, mat, cm, 3, uvx, uvy);
+    const float4 normalMap = lm_mat_tex(sc, lut, mat, cm, 6, uvx, uvy);
+    const float4 texColor = lm_mat_tex(sc, lut, mat, cm, 3, uvx, uvy);
     float4 emissive = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (e.mode == 0u) { emissive = mat->emissive * e.emissive.w; emissive = emissive * lm_mat_tex(sc, mat, cm, 4, uvx, uvy); }
+    if (e.mode == 0u) { emissive = mat->emissive * e.emissive.w; emissive = emissive * lm_mat_tex(sc, lut, mat, cm, 4, uvx, uvy); }
     else if (e.mode == 2u) emissive = e.emissive * e.emissive.w;
 
     const lf3 localNormal = normalize3(A.normal * Wt + B.normal * U + C.normal * V);
@@ -114,15 +123,15 @@ __device__ void lm_extract(const LmScene& sc, const uint4 hit, const lf3& ro, co
     s.tangent = tangentWorld;
     s.mat.color = mat->color; s.mat.transmittance = mat->transmittance; s.mat.tint = mat->tint;
     s.mat.p0 = mat->p[0]; s.mat.p1 = mat->p[1]; s.mat.p2 = mat->p[2];
-    const float4 mr = lm_mat_tex(sc, mat, cm, 5, uvx, uvy);
+    const float4 mr = lm_mat_tex(sc, lut, mat, cm, 5, uvx, uvy);
     const float baseMetal = lm_unpack8(mat->p[0], 0), baseRough = lm_unpack8(mat->p[0], 24);
     lm_pack8(s.mat.p0, 0, mr.z * baseMetal);
     lm_pack8(s.mat.p0, 24, mr.y * baseRough);
     s.mat.color = texColor * mat->color;
-    const float4 cc = lm_mat_tex(sc, mat, cm, 0, uvx, uvy);
-    const float4 ccr = lm_mat_tex(sc, mat, cm, 1, uvx, uvy);
-    const float4 tr = lm_mat_tex(sc, mat, cm, 2, uvx, uvy);
-    const float4 tint = lm_mat_tex(sc, mat, cm, 7, uvx, uvy);
+    const float4 cc = lm_mat_tex(sc, lut, mat, cm, 0, uvx, uvy);
+    const float4 ccr = lm_mat_tex(sc, lut, mat, cm, 1, uvx, uvy);
+    const float4 tr = lm_mat_tex(sc, lut, mat, cm, 2, uvx, uvy);
+    const float4 tint = lm_mat_tex(sc, lut, mat, cm, 7, uvx, uvy);
     const lf3 finalTint = v3(tint.x, tint.y, tint.z) * v3(mat->tint);
     const float finalClearCoat = lm_unpack8(mat->p[2], 0) * cc.x;
     const float gloss = lm_unpack8(mat->p[2], 8) * (1.f - ccr.x);
