@@ -520,6 +520,65 @@ def test_textured_materials_match_oracle():
     r.close(); o.close()
 
 
+def test_single_texel_slots_folded_at_upload_equal_the_real_fetch():
+    """A material slot with a 1x1 texture is folded into the material record when the material is created (LmDevMaterial::constMask); the
+    same texel repeated over a 3x2 image is not, and goes through descriptor + bilinear fetch + sRGB table.  Both must give the same frame
+    bit for bit (lerp(a, a, w) == a), in both arithmetic modes, and both equal the oracle."""
+    import copy
+    rng = np.random.default_rng(21)
+    d = cornell()
+    one = lambda srgb, lo=1, hi=256: d.add_texture(rng.integers(lo, hi, (1, 1, 4), dtype=np.uint8), srgb)
+    nm = np.array([[[140, 120, 255, 255]]], np.uint8)
+    mats = [d.add_material(diffuse_color=(0.9, 0.8, 0.7, 1.0), roughness_factor=0.6, metallic_factor=0.7, diffuse_texture=one(True, 160), normal_map=d.add_texture(nm, False),
+                           metallic_roughness_texture=one(False, 40), emissive_texture=one(True), tint_texture=one(False), sheen_factor=0.3, specular_factor=0.4),
+            d.add_material(diffuse_color=(0.8, 0.9, 1.0, 1.0), roughness_factor=0.3, metallic_factor=0.0, transmission_factor=0.7, index_of_refraction=1.4,
+                           clearcoat_factor=0.6, clearcoat_roughness_factor=0.2, transmission_texture=one(False, 128), clearcoat_texture=one(False, 128),
+                           clearcoat_roughness_texture=one(False), diffuse_texture=one(True, 200)),
+            d.add_material(diffuse_color=(1, 1, 1, 1), emission=(2.0, 1.5, 1.0), emissive_texture=one(True, 64))]
+    for k, (m, n, scale, off) in enumerate(((mats[0], 200, 0.11, (0.0, 1.0, 0.0)), (mats[1], 100, 0.08, (0.4, 0.6, 0.3)), (mats[2], 16, 0.04, (-0.4, 1.5, -0.2)))):
+        p = random_soup(n, 40 + k, extent=6.0, size=1.0).primitives[0]
+        v = np.array(p["vertices"], np.float32).reshape(-1, 12).copy()
+        v[:, 0:3] *= np.float32(scale)
+        v[:, 3:5] = rng.uniform(-1.5, 2.5, (len(v), 2)).astype(np.float32)
+        d.add_instance(d.add_mesh([d.add_primitive(v, p["indices"], m)]), _rigid(0.2 * k, off))
+    wide = copy.deepcopy(d)
+    for t in wide.textures:
+        if t["pixels"].shape[:2] == (1, 1):
+            t["pixels"] = np.ascontiguousarray(np.broadcast_to(t["pixels"], (2, 3, 4)))
+    for fast in (0, 1):
+        ra = product_from(d, 120, 96, 5, blend=True); rb = product_from(wide, 120, 96, 5, blend=True)
+        ra.SetTuning("fast_resample", fast); rb.SetTuning("fast_resample", fast)
+        for _ in range(3):
+            ra.TraceFrame(); rb.TraceFrame()
+            assert np.array_equal(ra.GetRadiance().view(np.uint32), rb.GetRadiance().view(np.uint32))
+            assert np.array_equal(ra.GetGBuffer().view(np.uint32), rb.GetGBuffer().view(np.uint32))
+        ra.close(); rb.close()
+    r = product_from(d, 120, 96, 5, blend=True); o = oracle_from(d, 120, 96, 5, blend=True)
+    _compare_frames(r, o, 2)
+    r.close(); o.close()
+
+
+def test_kernel_timing_classes_and_modes():
+    """lumen_mi_enable_kernel_timing: mode 1 times every class, mode 2 only the closest-hit launches and the frame; the path tail is class 5."""
+    from lumenrenderer_amd.scenes import sponza_standin
+    d = sponza_standin()
+    r = product_from(d, 640, 360, 6, blend=True)
+    for _ in range(3):
+        r.TraceFrame()                                   # the tail needs the ray counts of earlier frames
+    for mode, expect_all in ((1, True), (2, False)):
+        r.EnableKernelTiming(mode)
+        for _ in range(4):
+            r.TraceFrameAsync()
+        r.EnableKernelTiming(0)
+        r.GetCounters(8)
+        t = [r.GetKernelTime(i) for i in range(6)]
+        assert t[4][1] == 4 and t[0][1] >= 4 and t[0][0] > 0.0           # four frames, at least one closest-hit launch each
+        assert (t[2][1] > 0) == expect_all and (t[3][1] > 0) == expect_all  # extraction / shading and the ReSTIR passes: only in mode 1
+        if mode == 1:
+            assert t[5][1] == 4 and t[5][0] > 0.0                        # small window: the deep waves run as the path tail, one launch per frame
+    r.close()
+
+
 @pytest.mark.parametrize("fixture", ["ref_cube_textured.npz", "ref_milk_truck.npz"])
 def test_reference_sample_assets_match_oracle(fixture):
     """Two of the reference's own textured sample models (ingested in the build container by tests/golden/
