@@ -204,7 +204,9 @@ KN(lm_k_extract0)(LmScene sc, LmFrame fr, LmCamera cam, int cur, uint32_t seed2,
 {
     __shared__ uint32_t s_tmp[5];
     __shared__ float s_lut[256];
+    __shared__ uint4 s_tab[LM_TABLE_QUADS];
     const lm_lds_float* lut = lm_stage_lut(s_lut, sc);
+    const LmTables tab = lm_stage_tables(s_tab, sc);
 #if LM_SHADE_PRIO
     __builtin_amdgcn_s_setprio(LM_SHADE_PRIO);
 #endif
@@ -219,7 +221,7 @@ KN(lm_k_extract0)(LmScene sc, LmFrame fr, LmCamera cam, int cur, uint32_t seed2,
         const float4 d4 = fr.rayD[0][i];                          // origin = eye, contribution = 1 (lm_k_primary)
         const uint32_t li = f2u(d4.w);
         LmSurface s;
-        lm_extract(sc, lut, fr.hits[i], v3(cam.eye[0], cam.eye[1], cam.eye[2]), v3(d4), v3(1.f, 1.f, 1.f), s);
+        lm_extract(sc, lut, tab, fr.hits[i], v3(cam.eye[0], cam.eye[1], cam.eye[2]), v3(d4), v3(1.f, 1.f, 1.f), s);
         lm_gbuf_store(fr.gbuf[cur], fr.probe[cur], li, s);
         lm_count(fr.counters + LM_CNT_RARE, !s.flags && !lm_quick_contracts(s.mat));      // surfaces the fast ReSTIR mode scores in its second launch (none: no atomic)
         // motion vector
@@ -267,7 +269,9 @@ KN(lm_k_shade_wave)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict_
 {
     __shared__ uint32_t s_tmp[5];
     __shared__ float s_lut[256];
+    __shared__ uint4 s_tab[LM_TABLE_QUADS];
     const lm_lds_float* lut = lm_stage_lut(s_lut, sc);
+    const LmTables tab = lm_stage_tables(s_tab, sc);
 #if LM_SHADE_PRIO
     __builtin_amdgcn_s_setprio(LM_SHADE_PRIO);
 #endif
@@ -285,7 +289,7 @@ KN(lm_k_shade_wave)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict_
             const float4 o4 = fr.rayO[inQ][i], d4 = fr.rayD[inQ][i], c4 = fr.rayC[inQ][i];
             li = f2u(d4.w);
             LmSurface s;
-            lm_extract(sc, lut, fr.hits[i], v3(o4), v3(d4), v3(c4), s);
+            lm_extract(sc, lut, tab, fr.hits[i], v3(o4), v3(d4), v3(c4), s);
             const uint32_t ly = li / fr.ww, lx = li - ly * fr.ww;
             const uint32_t gi = (fr.y0 + ly) * fr.W + (fr.x0 + lx);
             emitShadow = lm_shade_direct(sc, s, gi, seed, sdir, stmax, srad);
@@ -318,7 +322,9 @@ KN(lm_k_path_tail)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict__
 {
     __shared__ int s_stack[LM_STACK_LDS * LM_BLOCK];
     __shared__ float s_lut[256];
+    __shared__ uint4 s_tab[LM_TABLE_QUADS];
     const lm_lds_float* lut = lm_stage_lut(s_lut, sc);
+    const LmTables tab = lm_stage_tables(s_tab, sc);
     const LmStack stack = lm_make_stack(s_stack, sc);
     const uint32_t n = *inCount;
     __builtin_amdgcn_s_setprio(3);
@@ -350,7 +356,7 @@ KN(lm_k_path_tail)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict__
                     rec = make_uint4(id.x, id.y, lm_f32_to_f16(h.u) | (lm_f32_to_f16(h.v) << 16), f2u(h.t));
                 }
                 LmSurface s;
-                lm_extract(sc, lut, rec, o, d, c, s);
+                lm_extract(sc, lut, tab, rec, o, d, c, s);
                 const uint32_t ly = li / fr.ww, lx = li - ly * fr.ww;
                 const uint32_t gi = (fr.y0 + ly) * fr.W + (fr.x0 + lx);
                 emitShadow = lm_shade_direct(sc, s, gi, seed, sdir, stmax, srad);

@@ -92,6 +92,7 @@ struct LmScene {
     int* spill;                 // per-thread stack overflow area: (LM_STACK_DEPTH - LM_STACK_LDS) ints per thread of the largest trace grid
     uint32_t numLights;
     float cdfSum;
+    uint32_t numEntries, numMaterials;   // sizes of `entries` / `materials` (small tables are staged in LDS by the extraction kernels)
 };
 
 // per-frame working set; all per-pixel arrays are indexed by the window-local pixel index

@@ -41,12 +41,30 @@ __device__ float4 lm_tex2D(const LmScene& sc, const lm_lds_float* lut, int id, f
     return r;
 }
 
-// texture slot k of a material: the folded constant when the slot's texture is a single texel or null (LmDevMaterial::constMask)
-__device__ __forceinline__ float4 lm_mat_tex(const LmScene& sc, const lm_lds_float* lut, const LmDevMaterial* mat, uint32_t constMask, int k, float u, float v)
+// The scene's entry table (80 B per primitive instance) and material table (256 B) are read by every hit; scenes of up to LM_LDS_ENTRIES /
+// LM_LDS_MATERIALS of them (the benchmark scene: 104 / 26) get both staged in LDS per block, so that extraction reads them with
+// ds_read_b128 instead of ~ 20 global gathers per hit.  `on` false: larger scenes read global memory as before.
+#ifndef LM_LDS_TABLES
+#define LM_LDS_TABLES 1            // 0: A/B switch, every scene reads the tables from global memory
+#endif
+#define LM_LDS_ENTRIES 128u
+#define LM_LDS_MATERIALS 32u
+#define LM_TABLE_QUADS (5u * LM_LDS_ENTRIES + 16u * LM_LDS_MATERIALS)
+static_assert(sizeof(LmEntry) == 80 && sizeof(LmDevMaterial) == 256, "table staging copies 5 / 16 quads per record");
+struct LmTables { const lm_lds_u4* ent; const lm_lds_u4* mat; bool on; };
+__device__ __forceinline__ LmTables lm_stage_tables(uint4* s_tab, const LmScene& sc)
 {
-    if ((constMask >> k) & 1u) return mat->texConst[k];
-    return lm_tex2D(sc, lut, mat->tex[k], u, v);
+    LmTables t; t.ent = (const lm_lds_u4*)s_tab; t.mat = (const lm_lds_u4*)s_tab + 5u * LM_LDS_ENTRIES;
+    t.on = LM_LDS_TABLES && sc.numEntries <= LM_LDS_ENTRIES && sc.numMaterials <= LM_LDS_MATERIALS;      // block-uniform
+    if (t.on) {
+        const uint4* ge = (const uint4*)sc.entries; const uint4* gm = (const uint4*)sc.materials;
+        for (uint32_t i = threadIdx.x; i < 5u * sc.numEntries; i += LM_BLOCK) s_tab[i] = ge[i];
+        for (uint32_t i = threadIdx.x; i < 16u * sc.numMaterials; i += LM_BLOCK) s_tab[5u * LM_LDS_ENTRIES + i] = gm[i];
+    }
+    __syncthreads();
+    return t;
 }
+__device__ __forceinline__ float4 lm_as_float4(const uint4& v) { return make_float4(u2f(v.x), u2f(v.y), u2f(v.z), u2f(v.w)); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // surface extraction — reference GPUExtractSurfaceData.cu:8-228
@@ -66,7 +84,7 @@ __device__ __forceinline__ LmVertex lm_load_vertex(const float4* __restrict__ ve
     return r;
 }
 
-__device__ void lm_extract(const LmScene& sc, const lm_lds_float* lut, const uint4 hit, const lf3& ro, const lf3& rd, const lf3& rc, LmSurface& s)
+__device__ void lm_extract(const LmScene& sc, const lm_lds_float* lut, const LmTables& tab, const uint4 hit, const lf3& ro, const lf3& rd, const lf3& rc, LmSurface& s)
 {
     s.position = v3(0.f); s.normal = v3(0.f); s.tangent = v3(0.f); s.incoming = v3(0.f); s.transport = v3(0.f);
     s.t = 0.f; s.flags = 0u;
@@ -74,19 +92,32 @@ __device__ void lm_extract(const LmScene& sc, const lm_lds_float* lut, const uin
     s.mat.p0 = s.mat.p1 = s.mat.p2 = 0u;
     const float t = u2f(hit.w);
     if (!(t > 0.f)) { s.flags = LM_SF_NON_INTERSECT; return; }
-    const LmEntry e = sc.entries[hit.x];
-    const LmDevMaterial* mat = sc.materials + e.material;
+    // quad q of the hit's entry: 0..2 world matrix rows, 3 (vertBase, idxBase, material, mode), 4 override radiance + scale
+    auto EQ = [&](uint32_t q) -> float4 { if (tab.on) return lm_as_float4(lm_lds_read4(tab.ent + 5u * hit.x + q)); return ((const float4*)(sc.entries + hit.x))[q]; };
+    LmEntry e;
+    { const float4 r0 = EQ(0), r1 = EQ(1), r2 = EQ(2), ids = EQ(3);
+      e.m[0] = r0.x; e.m[1] = r0.y; e.m[2] = r0.z; e.m[3] = r0.w; e.m[4] = r1.x; e.m[5] = r1.y; e.m[6] = r1.z; e.m[7] = r1.w; e.m[8] = r2.x; e.m[9] = r2.y; e.m[10] = r2.z; e.m[11] = r2.w;
+      e.vertBase = f2u(ids.x); e.idxBase = f2u(ids.y); e.material = f2u(ids.z); e.mode = f2u(ids.w); e.emissive = EQ(4); }
+    // quad q of its material: 0 color, 1 emissive, 2 transmittance, 3 tint, 4 packed parameters, 5..6 texture ids, 7 constMask, 8..15 folded slots
+    auto MQ = [&](uint32_t q) -> float4 { if (tab.on) return lm_as_float4(lm_lds_read4(tab.mat + 16u * e.material + q)); return ((const float4*)(sc.materials + e.material))[q]; };
+    const uint32_t cm = f2u(MQ(7).x);
     const uint32_t i0 = sc.indices[e.idxBase + 3u * hit.y], i1 = sc.indices[e.idxBase + 3u * hit.y + 1u], i2 = sc.indices[e.idxBase + 3u * hit.y + 2u];
     const LmVertex A = lm_load_vertex(sc.verts, e.vertBase + i0), B = lm_load_vertex(sc.verts, e.vertBase + i1), C = lm_load_vertex(sc.verts, e.vertBase + i2);
     const float U = lm_f16_to_f32(hit.z & 0xffffu), V = lm_f16_to_f32(hit.z >> 16), Wt = 1.f - (U + V);
     const float uvx = A.uv.x * Wt + B.uv.x * U + C.uv.x * V;
     const float uvy = A.uv.y * Wt + B.uv.y * U + C.uv.y * V;
     const float flip = A.tangent.w;
-    const uint32_t cm = mat->constMask;
-    const float4 normalMap = lm_mat_tex(sc, lut, mat, cm, 6, uvx, uvy);
-    const float4 texColor = lm_mat_tex(sc, lut, mat, cm, 3, uvx, uvy);
+    // texture slot k: the folded constant when the slot's texture is a single texel or null (LmDevMaterial::constMask), else the fetch
+    auto TEX = [&](int k) -> float4 {
+        if ((cm >> k) & 1u) return MQ(8u + (uint32_t)k);
+        const float4 ids = MQ(5u + ((uint32_t)k >> 2));
+        const int id = (int)f2u((k & 3) == 0 ? ids.x : (k & 3) == 1 ? ids.y : (k & 3) == 2 ? ids.z : ids.w);
+        return lm_tex2D(sc, lut, id, uvx, uvy);
+    };
+    const float4 normalMap = TEX(6);
+    const float4 texColor = TEX(3);
     float4 emissive = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (e.mode == 0u) { emissive = mat->emissive * e.emissive.w; emissive = emissive * lm_mat_tex(sc, lut, mat, cm, 4, uvx, uvy); }
+    if (e.mode == 0u) { emissive = MQ(1) * e.emissive.w; emissive = emissive * TEX(4); }
     else if (e.mode == 2u) emissive = e.emissive * e.emissive.w;
 
     const lf3 localNormal = normalize3(A.normal * Wt + B.normal * U + C.normal * V);
@@ -116,26 +147,28 @@ __device__ void lm_extract(const LmScene& sc, const lm_lds_float* lut, const uin
         s.transport = rc;
         return;
     }
-    const float eta = 1.f / mat->transmittance.w;
+    const float4 matColor = MQ(0), matTransmittance = MQ(2), matTint = MQ(3), matP = MQ(4);
+    const float eta = 1.f / matTransmittance.w;
     s.position = ro + rd * t;
     s.incoming = rd;
     s.transport = rc;
     s.tangent = tangentWorld;
-    s.mat.color = mat->color; s.mat.transmittance = mat->transmittance; s.mat.tint = mat->tint;
-    s.mat.p0 = mat->p[0]; s.mat.p1 = mat->p[1]; s.mat.p2 = mat->p[2];
-    const float4 mr = lm_mat_tex(sc, lut, mat, cm, 5, uvx, uvy);
-    const float baseMetal = lm_unpack8(mat->p[0], 0), baseRough = lm_unpack8(mat->p[0], 24);
+    s.mat.color = matColor; s.mat.transmittance = matTransmittance; s.mat.tint = matTint;
+    const uint32_t mp0 = f2u(matP.x), mp1 = f2u(matP.y), mp2 = f2u(matP.z);
+    s.mat.p0 = mp0; s.mat.p1 = mp1; s.mat.p2 = mp2;
+    const float4 mr = TEX(5);
+    const float baseMetal = lm_unpack8(mp0, 0), baseRough = lm_unpack8(mp0, 24);
     lm_pack8(s.mat.p0, 0, mr.z * baseMetal);
     lm_pack8(s.mat.p0, 24, mr.y * baseRough);
-    s.mat.color = texColor * mat->color;
-    const float4 cc = lm_mat_tex(sc, lut, mat, cm, 0, uvx, uvy);
-    const float4 ccr = lm_mat_tex(sc, lut, mat, cm, 1, uvx, uvy);
-    const float4 tr = lm_mat_tex(sc, lut, mat, cm, 2, uvx, uvy);
-    const float4 tint = lm_mat_tex(sc, lut, mat, cm, 7, uvx, uvy);
-    const lf3 finalTint = v3(tint.x, tint.y, tint.z) * v3(mat->tint);
-    const float finalClearCoat = lm_unpack8(mat->p[2], 0) * cc.x;
-    const float gloss = lm_unpack8(mat->p[2], 8) * (1.f - ccr.x);
-    const float finalTransmission = lm_unpack8(mat->p[2], 16) * tr.x;
+    s.mat.color = texColor * matColor;
+    const float4 cc = TEX(0);
+    const float4 ccr = TEX(1);
+    const float4 tr = TEX(2);
+    const float4 tint = TEX(7);
+    const lf3 finalTint = v3(tint.x, tint.y, tint.z) * v3(matTint);
+    const float finalClearCoat = lm_unpack8(mp2, 0) * cc.x;
+    const float gloss = lm_unpack8(mp2, 8) * (1.f - ccr.x);
+    const float finalTransmission = lm_unpack8(mp2, 16) * tr.x;
     lm_pack8(s.mat.p2, 0, finalClearCoat);
     lm_pack8(s.mat.p2, 8, gloss);
     s.mat.tint = make_float4(finalTint.x, finalTint.y, finalTint.z, s.mat.tint.w);

@@ -127,7 +127,7 @@ int syncScene(R* r, hipStream_t su)
         if (T.geomVer != r->geomVer) {
             const LmKernelTable* K = r->K;
             LmScene sc = r->dscene;
-            sc.nodes = T.nodes.p; sc.woop = T.woop.p; sc.quant = T.quant.p; sc.entries = T.entries.p; sc.triId = T.triId.p; sc.triOrder = T.triOrder.p;
+            sc.nodes = T.nodes.p; sc.woop = T.woop.p; sc.quant = T.quant.p; sc.entries = T.entries.p; sc.numEntries = (uint32_t)r->entries.size(); sc.triId = T.triId.p; sc.triOrder = T.triOrder.p;
             const uint32_t nt = T.nTris;
             if (r->dTriBox.ensure(2 * (size_t)nt + 2) || r->dNodeBox.ensure(2 * std::max<size_t>(T.nodes.cap, 1))) return fail(LUMEN_MI_ERR_DEVICE, "refit buffer allocation failed");
             K->refit_tris(su, sc, nt, r->dTriBox.p, r->dRefitBounds.p);
@@ -145,7 +145,7 @@ int syncScene(R* r, hipStream_t su)
         r->sgen ^= 1;
     }
     const SceneSet& S = r->sset[r->sgen];
-    r->dscene.nodes = S.nodes.p; r->dscene.woop = S.woop.p; r->dscene.quant = S.quant.p; r->dscene.entries = S.entries.p;
+    r->dscene.nodes = S.nodes.p; r->dscene.woop = S.woop.p; r->dscene.quant = S.quant.p; r->dscene.entries = S.entries.p; r->dscene.numEntries = (uint32_t)r->entries.size();
     r->dscene.triId = S.triId.p; r->dscene.triOrder = S.triOrder.p; r->dscene.top = S.top.p;
     r->dscene.lights = S.lights.p; r->dscene.cdf = S.cdf.p;
     return 0;
@@ -284,7 +284,7 @@ int flatten(R* r)
     r->dscene.verts = r->dVerts.p; r->dscene.indices = r->dIndices.p;
     {
         const SceneSet& S = r->sset[r->sgen];
-        r->dscene.nodes = S.nodes.p; r->dscene.woop = S.woop.p; r->dscene.quant = S.quant.p; r->dscene.entries = S.entries.p;
+        r->dscene.nodes = S.nodes.p; r->dscene.woop = S.woop.p; r->dscene.quant = S.quant.p; r->dscene.entries = S.entries.p; r->dscene.numEntries = (uint32_t)r->entries.size();
         r->dscene.triId = S.triId.p; r->dscene.triOrder = S.triOrder.p; r->dscene.top = S.top.p;
     }
     r->sceneDirty = false;
@@ -329,7 +329,7 @@ int uploadResources(R* r)
         for (const Material& x : r->materials) m.push_back(x.dev);
         if (r->dMaterials.upload(m, st)) return fail(LUMEN_MI_ERR_DEVICE, "material upload failed");
         if (hipStreamSynchronize(st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "material upload sync failed");
-        r->dscene.materials = r->dMaterials.p;
+        r->dscene.materials = r->dMaterials.p; r->dscene.numMaterials = (uint32_t)r->materials.size();
         r->materialsDirty = false;
     }
     return 0;
