@@ -558,6 +558,30 @@ def test_single_texel_slots_folded_at_upload_equal_the_real_fetch():
     r.close(); o.close()
 
 
+def test_scene_with_more_entries_and_materials_than_the_lds_tables_hold():
+    """The extraction kernels stage the entry / material tables in LDS up to 128 entries / 32 materials (lm_shade.h lm_stage_tables); a scene
+    beyond either limit reads them from global memory.  150 instances x 40 materials (some emissive, some textured) against the oracle, in
+    every schedule that extracts surfaces (per-wave kernels, path tail)."""
+    rng = np.random.default_rng(77)
+    d = cornell()
+    mats = []
+    for k in range(40):
+        tex = d.add_texture(rng.integers(32, 256, (5, 7, 4), dtype=np.uint8), True) if k % 5 == 0 else d.tex_white
+        mats.append(d.add_material(diffuse_color=tuple(rng.uniform(0.2, 1.0, 3)) + (1.0,), roughness_factor=float(rng.uniform(0.2, 1.0)),
+                                   metallic_factor=float(rng.uniform(0.0, 1.0)), emission=(1.5, 1.2, 0.9) if k % 13 == 0 else (0.0, 0.0, 0.0), diffuse_texture=tex))
+    meshes = []
+    for k in range(40):
+        p = random_soup(6, 300 + k, extent=0.15, size=0.12).primitives[0]
+        meshes.append(d.add_mesh([d.add_primitive(np.array(p["vertices"], np.float32), p["indices"], mats[k])]))
+    for i in range(150):
+        d.add_instance(meshes[i % 40], _rigid(0.37 * i, tuple(rng.uniform(-0.8, 0.8, 3) + np.array([0.0, 1.0, 0.0]))))
+    for tuning in ({}, {"tail_below": 1 << 30}, {"tail_below": 0}):
+        r = product_from(d, 112, 88, 6, blend=True, tuning=tuning); o = oracle_from(d, 112, 88, 6, blend=True)
+        _compare_frames(r, o, 3)
+        assert r.GetCounters(8)[0] > 0
+        r.close(); o.close()
+
+
 def test_kernel_timing_classes_and_modes():
     """lumen_mi_enable_kernel_timing: mode 1 times every class, mode 2 only the closest-hit launches and the frame; the path tail is class 5."""
     from lumenrenderer_amd.scenes import sponza_standin
