@@ -508,7 +508,7 @@ __device__ __forceinline__ void lm_pick_primary_body(const LmScene& sc, const Lm
             lm_target_setup<A>(pixel, target);
             for (int smp = 0; smp < 32; smp++) {
                 const float r = lm_random_float(s);
-                const int pick = (int)roundf((float)(1000 - 1) * r);
+                const int pick = lm_round_nonneg((float)(1000 - 1) * r);
                 const uint2 entry = s_bag[pick];
                 const float initialPdf = u2f(entry.y);               // contracted policy: its reciprocal (see the staging loop)
                 const float u = lm_random_float(s);

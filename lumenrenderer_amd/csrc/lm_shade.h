@@ -51,6 +51,9 @@ __device__ float4 lm_tex2D(const LmScene& sc, const lm_lds_float* lut, int id, f
 #define LM_LDS_MATERIALS 32u
 #define LM_TABLE_QUADS (5u * LM_LDS_ENTRIES + 16u * LM_LDS_MATERIALS)
 static_assert(sizeof(LmEntry) == 80 && sizeof(LmDevMaterial) == 256, "table staging copies 5 / 16 quads per record");
+static_assert(offsetof(LmEntry, vertBase) == 48 && offsetof(LmEntry, emissive) == 64, "lm_extract reads LmEntry by 16-byte quads");
+static_assert(offsetof(LmDevMaterial, p) == 64 && offsetof(LmDevMaterial, tex) == 80 && offsetof(LmDevMaterial, constMask) == 112 && offsetof(LmDevMaterial, texConst) == 128,
+              "lm_extract reads LmDevMaterial by 16-byte quads");
 struct LmTables { const lm_lds_u4* ent; const lm_lds_u4* mat; bool on; };
 __device__ __forceinline__ LmTables lm_stage_tables(uint4* s_tab, const LmScene& sc)
 {
