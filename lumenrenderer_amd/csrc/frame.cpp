@@ -179,7 +179,9 @@ int traceFrameAsync(R* r)
     }
     r->fenceNeeded = false;
     size_t evAll; evBegin2(r, 4, evAll, sx);
+#if !LM_PRIMARY_CLEARS
     LM_HIP(hipMemsetAsync(fr.counters, 0, LM_CNT_WORDS * sizeof(uint32_t), sx));
+#endif
     if (!blend) { Z(st); K->clear(st, r->gridFor(fr.n, 8), fr.combined, fr.n); }                        // :559
     ++r->frameCount;                                                                          // :593
     Z(sx); K->primary(sx, r->gridFor(fr.n, 8), fr, cam, r->frameCount);

@@ -123,6 +123,12 @@ __device__ __forceinline__ void lm_slot_to_pixel(const LmFrame& fr, uint32_t i, 
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
 KN(lm_k_primary)(LmFrame fr, LmCamera cam, uint32_t frameCount)
 {
+#if LM_PRIMARY_CLEARS
+    if (blockIdx.x == 0) {              // the frame's counter block (this frame parity's; every other kernel of the frame runs behind this one)
+        for (uint32_t w = threadIdx.x; w < LM_CNT_WORDS; w += LM_BLOCK) fr.counters[w] = 0u;
+        __syncthreads();
+    }
+#endif
     const uint32_t stride = gridDim.x * LM_BLOCK;
     for (uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x; i < fr.n; i += stride) {
         uint32_t lx, ly;

@@ -142,5 +142,8 @@ struct LmFrame {
 #define LM_CNT_TRIS 68                           // instrumented build only: triangles tested (u64 as 2 words)
 #define LM_CNT_OCC 120                            // instrumented build only, u64 each: active lanes / lane slots of node steps, of triangle tests
 #define LM_CNT_WORDS 136
+#ifndef LM_PRIMARY_CLEARS
+#define LM_PRIMARY_CLEARS 1     // the frame's first kernel (lm_k_primary, block 0) zeroes the counter block: no fill launch in front of every frame on the wave stream
+#endif
 
 struct LmCamera { float eye[3], U[3], V[3], Wv[3]; float prevViewProj[16]; };
