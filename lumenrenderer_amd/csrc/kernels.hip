@@ -430,10 +430,10 @@ KN(lm_k_restir_trace_shade)(LmScene sc, LmFrame fr, int rc, const uint32_t* __re
         [&](uint32_t i, lf3& o, lf3& d, float& t0, float& t1) { const float4 o4 = qO[i]; o = v3(o4); d = v3(qD[i]); t0 = 0.1f; t1 = o4.w; },
         [&](uint32_t i, bool occluded, const LmHit&) {
             const uint32_t li = f2u(qD[i].w);
-            float4 r0 = hot[4u * li];
-            if (occluded) { r0.y = 0.f; hot[4u * li] = r0; }
+            float* weight = (float*)(hot + 4u * li + 1u);           // quad 1 = (weight, count, normal.xy): lm_restir.h (included below)
+            if (occluded) *weight = 0.f;
             else {
-                const lf3 add = v3(fr.resC[rc][li]) * (r0.y / 3.f);
+                const lf3 add = v3(fr.resC[rc][li]) * (*weight / 3.f);
                 float4 px = fr.direct[li];
                 px.x += add.x; px.y += add.y; px.z += add.z;
                 fr.direct[li] = px;
@@ -506,7 +506,7 @@ __device__ __forceinline__ void lm_pick_primary_body(const LmScene& sc, const Lm
         float4* hot = fr.res[rc];
         LmSurface pixel;
         lm_gbuf_load(fr.gbuf[cur], li, pixel);
-        if (pixel.flags) { if (ROLE != LM_RARE) { float4 a = hot[4u * li]; a.y = 0.f; hot[4u * li] = a; } }
+        if (pixel.flags) { if (ROLE != LM_RARE) lm_hot_zero_weight(hot, li); }
         else if (lm_role_takes<ROLE>(pixel.mat)) {
             uint32_t s = lm_wang_hash(seed + lm_wang_hash(gi));
             LmReservoir fresh; lm_res_fresh(fresh);
@@ -664,7 +664,8 @@ __device__ __forceinline__ void lm_restir_temporal_body(const LmFrame& fr, int c
                     o[0] = h0; o[1] = h1; o[2] = h2; o[3] = h3;
                     fr.resC[rc][li] = fr.resC[rf][li];
                 }
-                weight = h0.y;
+                weight = ((const float*)h)[4];                      // quad 1 = (weight, count, normal.xy): lm_restir.h (its own load: taking h1 apart
+                                                                   // makes the compiler park the other three words in LDS)
                 if (weight > 0.f) { vtarget = v3(h3); vpos = v3(fr.gbuf[cur][8u * li]); }
             }
             shoot = mine && weight > 0.f && lm_owned(fr, li, 0);   // second GenerateShadowRay pass (ReSTIR.cpp:211), fused; only owned pixels are combined
@@ -672,8 +673,7 @@ __device__ __forceinline__ void lm_restir_temporal_body(const LmFrame& fr, int c
             // flagged pixel: the candidate pick only zeroes the weight of the CURRENT reservoir and leaves the rest stale
             // (ReSTIRKernels.cu:441-447); when the pick wrote to its own buffer, do that here — a later frame may read this
             // entry as "previous" through a probe plane of a different age
-            float4* h = fr.res[rc] + 4u * li;
-            float4 a = h[0]; a.y = 0.f; h[0] = a;
+            lm_hot_zero_weight(fr.res[rc], li);
         }
     }
     lf3 vdir = vtarget - vpos;
@@ -756,7 +756,7 @@ __device__ __forceinline__ void lm_restir_spatial_body(const LmFrame& fr, int cu
         const uint32_t nb0 = candAt((uint32_t)__ffs((int)mask) - 1u);
         mask &= mask - 1u;
         const float4* h = hotIn + 4u * nb0;
-        float4 a = h[0], p1 = h[1], p2 = h[2], p3 = h[3];
+        float4 p1 = h[1], p2 = h[2], p3 = h[3];                    // the three quads a neighbour's reservoir is gathered by (lm_restir.h)
         LmTarget target;
         {
             LmSurface s0;
@@ -772,21 +772,22 @@ __device__ __forceinline__ void lm_restir_spatial_body(const LmFrame& fr, int cu
             LmSample rs;
             rs.p = lm_point_unpack(p1, p2, p3);
             rs.contribution = v3(0.f);                             // the neighbour's own contribution is not carried over (reference: a fresh LightSample)
-            const long long cnt = (long long)f2u(a.z);
+            const long long cnt = lm_hot_count(p1);
             lm_score<A>(rs.p, target, rs.contribution, rs.pdf);
-            lm_res_update<A>(out, rs, (float)cnt * a.y * rs.pdf, seed);   // global seed: same draw for all pixels (reference quirk)
+            lm_res_update<A>(out, rs, (float)cnt * lm_hot_weight(p1) * rs.pdf, seed);   // global seed: same draw for all pixels (reference quirk)
             sum += cnt;
             if (mask == 0u) break;
             const float4* hn = hotIn + 4u * candAt((uint32_t)__ffs((int)mask) - 1u);
             mask &= mask - 1u;
-            a = hn[0]; p1 = hn[1]; p2 = hn[2]; p3 = hn[3];
+            p1 = hn[1]; p2 = hn[2]; p3 = hn[3];
         }
         out.count = sum;
         lm_res_update_weight<A>(out);
         lm_res_store(hotOut, fr.resC[rout], li, out);
     } else if (ROLE != LM_RARE) {
-        const float4 old = hotOut[4u * li];
-        hotOut[4u * li] = make_float4(0.f, 0.f, u2f(0u), old.w);   // Reset(): weightSum, sampleCount, weight
+        const float4 q0 = hotOut[4u * li], q1 = hotOut[4u * li + 1u];      // Reset(): weightSum, sampleCount, weight; the sample stays
+        hotOut[4u * li] = make_float4(0.f, q0.y, 0.f, 0.f);
+        hotOut[4u * li + 1u] = make_float4(0.f, u2f(0u), q1.z, q1.w);
     }
 }
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_SPATIAL_WAVES)

@@ -7,8 +7,9 @@
 // depends on the light point.  Every function takes the arithmetic policy of lm_bsdf.h (LmExact: the bit-exact contract; LmFast:
 // hardware reciprocal / square root for the target function and the resampling weights).
 //
-// reservoir storage: a 64-byte "hot" record per pixel (what reuse passes gather from other pixels):
-//   0 (weightSum, weight, sampleCount bits, solidAnglePdf)   1 (radiance, area)   2 (normal, 0)   3 (position, 0)
+// reservoir storage: a 64-byte "hot" record per pixel, ordered by who reads it — a reuse pass gathers only quads 1..3 from OTHER pixels
+// (three loads per neighbour instead of four), quad 0 is only ever read for the pixel itself:
+//   0 (weightSum, solidAnglePdf, 0, 0)   1 (weight, sampleCount bits, normal.x, normal.y)   2 (radiance, area)   3 (position, normal.z)
 // plus a separate plane with the unshadowed contribution (only ever read for the pixel being shaded).
 #pragma once
 
@@ -18,15 +19,20 @@ struct LmReservoir { float weightSum, weight; long long count; LmSample s; };
 
 __device__ __forceinline__ void lm_sample_zero(LmSample& s) { s.p.radiance = v3(0.f); s.p.normal = v3(0.f); s.p.position = v3(0.f); s.p.area = 0.f; s.contribution = v3(0.f); s.pdf = 0.f; }
 __device__ __forceinline__ void lm_res_fresh(LmReservoir& r) { r.weightSum = 0.f; r.weight = 0.f; r.count = 0; lm_sample_zero(r.s); }
-__device__ __forceinline__ LmLightPoint lm_point_unpack(const float4& p1, const float4& p2, const float4& p3)
+__device__ __forceinline__ LmLightPoint lm_point_unpack(const float4& q1, const float4& q2, const float4& q3)
 {
-    LmLightPoint p; p.radiance = v3(p1); p.area = p1.w; p.normal = v3(p2); p.position = v3(p3); return p;
+    LmLightPoint p; p.radiance = v3(q2); p.area = q2.w; p.normal = v3(q1.z, q1.w, q3.w); p.position = v3(q3); return p;
 }
-__device__ __forceinline__ void lm_res_unpack(const float4& a, const float4& p1, const float4& p2, const float4& p3, LmReservoir& r)
+__device__ __forceinline__ float lm_hot_weight(const float4& q1) { return q1.x; }
+__device__ __forceinline__ long long lm_hot_count(const float4& q1) { return (long long)f2u(q1.y); }
+__device__ __forceinline__ void lm_res_unpack(const float4& q0, const float4& q1, const float4& q2, const float4& q3, LmReservoir& r)
 {
-    r.weightSum = a.x; r.weight = a.y; r.count = (long long)f2u(a.z); r.s.pdf = a.w;
-    r.s.p = lm_point_unpack(p1, p2, p3);
+    r.weightSum = q0.x; r.s.pdf = q0.y; r.weight = lm_hot_weight(q1); r.count = lm_hot_count(q1);
+    r.s.p = lm_point_unpack(q1, q2, q3);
 }
+// weight = 0 in place (an occluded or flagged pixel's reservoir keeps everything else)
+__device__ __forceinline__ float* lm_hot_weight_at(float4* hot, uint32_t li) { return (float*)(hot + 4u * li + 1u); }       // the weight word of pixel li
+__device__ __forceinline__ void lm_hot_zero_weight(float4* hot, uint32_t li) { *lm_hot_weight_at(hot, li) = 0.f; }
 __device__ __forceinline__ void lm_res_load(const float4* __restrict__ hot, const float4* __restrict__ contrib, uint32_t li, LmReservoir& r)
 {
     const float4* h = hot + 4u * li;
@@ -36,10 +42,10 @@ __device__ __forceinline__ void lm_res_load(const float4* __restrict__ hot, cons
 __device__ __forceinline__ void lm_res_store(float4* __restrict__ hot, float4* __restrict__ contrib, uint32_t li, const LmReservoir& r)
 {
     float4* h = hot + 4u * li;
-    h[0] = make_float4(r.weightSum, r.weight, u2f((uint32_t)r.count), r.s.pdf);
-    h[1] = v4(r.s.p.radiance, r.s.p.area);
-    h[2] = v4(r.s.p.normal, 0.f);
-    h[3] = v4(r.s.p.position, 0.f);
+    h[0] = make_float4(r.weightSum, r.s.pdf, 0.f, 0.f);
+    h[1] = make_float4(r.weight, u2f((uint32_t)r.count), r.s.p.normal.x, r.s.p.normal.y);
+    h[2] = v4(r.s.p.radiance, r.s.p.area);
+    h[3] = v4(r.s.p.position, r.s.p.normal.z);
     contrib[li] = v4(r.s.contribution, 0.f);
 }
 
