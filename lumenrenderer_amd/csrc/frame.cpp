@@ -26,6 +26,7 @@ int ensureFrameBuffers(R* r)
     for (int i = 0; i < 4; i++) bad |= r->dSh2[i].ensure(n);
     for (int i = 0; i < 3; i++) bad |= r->dGbuf[i].ensure((size_t)8 * n) | r->dProbe[i].ensure(n);
     for (int i = 0; i < 2; i++) bad |= r->dMotion[i].ensure(n);
+    bad |= r->dReuseMask.ensure(n);
     for (int i = 0; i < 5; i++) bad |= r->dRes[i].ensure((size_t)4 * n) | r->dResC[i].ensure(n);
     for (int i = 0; i < 2; i++) bad |= r->dDirect[i].ensure(n) | r->dIndirect[i].ensure(n);
     bad |= r->dCombined.ensure(n) | r->dHits.ensure(n) | r->dOutput.ensure(n);
@@ -39,6 +40,7 @@ int ensureFrameBuffers(R* r)
     f.hits = r->dHits.p;
     for (int i = 0; i < 3; i++) { f.gbuf[i] = r->dGbuf[i].p; f.probe[i] = r->dProbe[i].p; }
     for (int i = 0; i < 5; i++) { f.res[i] = r->dRes[i].p; f.resC[i] = r->dResC[i].p; }
+    f.reuseMask = r->dReuseMask.p;
     f.motion = r->dMotion[0].p; f.direct = r->dDirect[0].p; f.indirect = r->dIndirect[0].p; f.combined = r->dCombined.p; f.output = r->dOutput.p;
     f.counters = r->dCounters.p; f.bags = r->dBags.p;
     // ResizeBuffers (WaveFrontRenderer.cpp:1424-1540): history is dropped; reservoirs reset (ReSTIRKernels.cu:36-47)
@@ -258,7 +260,7 @@ int traceFrameAsync(R* r)
             Z(st); K->temporal(st, tiles, fr, currentIndex, temporalIndex, cur, tmp, fresh, rs, fr.counters + LM_CNT_RESTIR(1), fastRs);         // + visibility rays, pass 2
             if (overlap) LM_HIP(hipEventRecord(r->evTemporal[par], st));
             rs = wangHash(rs);
-            Z(st); K->spatial(st, tiles, fr, currentIndex, cur, 2, rs, 30, fastRs);
+            Z(st); K->spatial(st, tiles, fr, currentIndex, cur, 2, rs, 30, 0, fastRs);
             // second visibility pass (ReSTIR.cpp:211-212) works on the CURRENT buffer, which the second spatial pass does not
             // touch: trace it beside that pass.  (It must follow the first spatial pass, which reads the current buffer.)
             hipStream_t sv = (overlap && !pickAhead) ? r->aux3 : st;
@@ -269,7 +271,7 @@ int traceFrameAsync(R* r)
             }
             Z(sv); K->trace_shade(sv, gridMain, scv, fr, cur, fr.counters + LM_CNT_RESTIR(1), r->refillVisibility, 1);
             if (sv != st) LM_HIP(hipEventRecord(r->evVisDone, sv));
-            Z(st); K->spatial(st, tiles, fr, currentIndex, 2, 3, rs, 0, fastRs);
+            Z(st); K->spatial(st, tiles, fr, currentIndex, 2, 3, rs, 0, 1, fastRs);      // the same seed as the first pass (ReSTIR.cpp: one seed for both): same candidates, same verdicts
             if (sv != st) LM_HIP(hipStreamWaitEvent(st, r->evVisDone, 0));
             Z(st); K->combine(st, tiles, fr, currentIndex, cur, 3, wangHash(rs), fastRs);
             evEnd(r, ev);

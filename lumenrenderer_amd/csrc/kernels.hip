@@ -711,7 +711,7 @@ KN(lm_k_restir_temporal_rare)(LmFrame fr, int cur, int prev, int rc, int rp, int
 #define LM_SPATIAL_WAVES 3      // <= 168 VGPRs: three waves per SIMD instead of two (the kernel is gather-latency bound)
 #endif
 template <class A, int ROLE>
-__device__ __forceinline__ void lm_restir_spatial_body(const LmFrame& fr, int cur, int rin, int rout, uint32_t seed, int margin)
+__device__ __forceinline__ void lm_restir_spatial_body(const LmFrame& fr, int cur, int rin, int rout, uint32_t seed, int margin, int pass)
 {
     if (ROLE == LM_RARE && fr.counters[LM_CNT_RARE] == 0u) return;
     rin = lm_res_idx(fr, rin);
@@ -722,15 +722,14 @@ __device__ __forceinline__ void lm_restir_spatial_body(const LmFrame& fr, int cu
     uint32_t li = 0, gi = 0;
     if (!lm_tile_pixel(fr, li, gi)) return;
     if (!lm_owned(fr, li, margin)) return;                       // pass 1 feeds pass 2 within 30 pixels of the owned tile, pass 2 only the tile
-    const float4* probe = fr.probe[cur];
     const float4* hotIn = fr.res[rin];
-    const float4 cn = probe[li];
-    if (cn.w < 0.f) return;
+    // The second pass draws the candidates of the first (same seed) against the same probe plane: the first pass leaves its verdicts
+    // (5 bits, or "flagged pixel") in a 4-byte plane and the second reads that instead of gathering five probes again.
+    uint32_t mask = 0u;
+    if (pass) { mask = fr.reuseMask[li]; if (mask == LM_REUSE_FLAGGED) return; }
     const int y = (int)(li / fr.ww), x = (int)(li - (uint32_t)y * fr.ww);
     uint32_t s = lm_wang_hash(seed + gi);
-    const float ct = cn.w;
     uint32_t cand[5];
-    float4 pr[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) {
         const int ny = (int)roundf((lm_random_float(s) * 2.f - 1.f) * 30.f) + y;
@@ -738,17 +737,24 @@ __device__ __forceinline__ void lm_restir_spatial_body(const LmFrame& fr, int cu
         const bool in = !(nx < 0 || nx >= (int)fr.ww || ny < 0 || ny >= (int)fr.wh);
         cand[k] = in ? (uint32_t)ny * fr.ww + (uint32_t)nx : 0xffffffffu;
     }
+    if (!pass) {
+        const float4* probe = fr.probe[cur];
+        const float4 cn = probe[li];
+        if (cn.w < 0.f) { if (ROLE != LM_RARE) fr.reuseMask[li] = LM_REUSE_FLAGGED; return; }
+        const float ct = cn.w;
+        float4 pr[5];
 #pragma unroll
-    for (int k = 0; k < 5; k++) pr[k] = probe[cand[k] != 0xffffffffu ? cand[k] : li];
-    // accepted candidates as a bit mask; they are visited in candidate order (no dynamically indexed array: registers only)
-    uint32_t mask = 0u;
+        for (int k = 0; k < 5; k++) pr[k] = probe[cand[k] != 0xffffffffu ? cand[k] : li];
+        // accepted candidates as a bit mask; they are visited in candidate order (no dynamically indexed array: registers only)
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
-        if (cand[k] == 0xffffffffu || pr[k].w < 0.f) continue;
-        const float d1 = pr[k].w;
-        const float depthDif = fabsf(d1 - ct) / ((d1 + ct) / 2.f);
-        const float angle = dot3(v3(pr[k]), v3(cn));
-        if (depthDif < 0.10f && angle > 0.72222222223f) mask |= 1u << k;
+        for (int k = 0; k < 5; k++) {
+            if (cand[k] == 0xffffffffu || pr[k].w < 0.f) continue;
+            const float d1 = pr[k].w;
+            const float depthDif = fabsf(d1 - ct) / ((d1 + ct) / 2.f);
+            const float angle = dot3(v3(pr[k]), v3(cn));
+            if (depthDif < 0.10f && angle > 0.72222222223f) mask |= 1u << k;
+        }
+        if (ROLE != LM_RARE) fr.reuseMask[li] = mask;
     }
     auto candAt = [&](uint32_t k) { return k == 0u ? cand[0] : k == 1u ? cand[1] : k == 2u ? cand[2] : k == 3u ? cand[3] : cand[4]; };
     float4* hotOut = fr.res[rout];
@@ -791,14 +797,14 @@ __device__ __forceinline__ void lm_restir_spatial_body(const LmFrame& fr, int cu
     }
 }
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_SPATIAL_WAVES)
-KN(lm_k_restir_spatial)(LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin) { lm_restir_spatial_body<LmExact, LM_ALL>(fr, cur, rin, rout, seed, margin); }
+KN(lm_k_restir_spatial)(LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin, int pass) { lm_restir_spatial_body<LmExact, LM_ALL>(fr, cur, rin, rout, seed, margin, pass); }
 #ifndef LM_SPATIAL_FAST_WAVES
 #define LM_SPATIAL_FAST_WAVES 5
 #endif
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_SPATIAL_FAST_WAVES)
-KN(lm_k_restir_spatial_fast)(LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin) { lm_restir_spatial_body<LmFast, LM_COMMON>(fr, cur, rin, rout, seed, margin); }
+KN(lm_k_restir_spatial_fast)(LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin, int pass) { lm_restir_spatial_body<LmFast, LM_COMMON>(fr, cur, rin, rout, seed, margin, pass); }
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_SPATIAL_WAVES)
-KN(lm_k_restir_spatial_rare)(LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin) { lm_restir_spatial_body<LmExact, LM_RARE>(fr, cur, rin, rout, seed, margin); }
+KN(lm_k_restir_spatial_rare)(LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin, int pass) { lm_restir_spatial_body<LmExact, LM_RARE>(fr, cur, rin, rout, seed, margin, pass); }
 
 // K26 CombineReservoirBuffers — ReSTIRKernels.cu:1407-1436
 template <class A, int ROLE>
@@ -1290,8 +1296,8 @@ static void l_pick_primary(hipStream_t s, int tiles, LmScene sc, LmFrame fr, int
 static void l_trace_shade(hipStream_t s, int g, LmScene sc, LmFrame fr, int rc, const uint32_t* cnt, int refillBelow, int pass) { hipLaunchKernelGGL(KN(lm_k_restir_trace_shade), LM_GRID(g), sc, fr, rc, cnt, refillBelow, pass); }
 static void l_temporal(hipStream_t s, int g, LmFrame fr, int cur, int prev, int rc, int rp, int rf, uint32_t seed, uint32_t* visCount, int fast)
 { if (fast) { hipLaunchKernelGGL(KN(lm_k_restir_temporal_fast), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); if (fast > 1) hipLaunchKernelGGL(KN(lm_k_restir_temporal_rare), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); } else hipLaunchKernelGGL(KN(lm_k_restir_temporal), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); }
-static void l_spatial(hipStream_t s, int g, LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin, int fast)
-{ if (fast) { hipLaunchKernelGGL(KN(lm_k_restir_spatial_fast), LM_GRID(g), fr, cur, rin, rout, seed, margin); if (fast > 1) hipLaunchKernelGGL(KN(lm_k_restir_spatial_rare), LM_GRID(g), fr, cur, rin, rout, seed, margin); } else hipLaunchKernelGGL(KN(lm_k_restir_spatial), LM_GRID(g), fr, cur, rin, rout, seed, margin); }
+static void l_spatial(hipStream_t s, int g, LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin, int pass, int fast)
+{ if (fast) { hipLaunchKernelGGL(KN(lm_k_restir_spatial_fast), LM_GRID(g), fr, cur, rin, rout, seed, margin, pass); if (fast > 1) hipLaunchKernelGGL(KN(lm_k_restir_spatial_rare), LM_GRID(g), fr, cur, rin, rout, seed, margin, pass); } else hipLaunchKernelGGL(KN(lm_k_restir_spatial), LM_GRID(g), fr, cur, rin, rout, seed, margin, pass); }
 static void l_combine(hipStream_t s, int g, LmFrame fr, int cur, int rc, int rs, uint32_t seed, int fast)
 { if (fast) { hipLaunchKernelGGL(KN(lm_k_restir_combine_fast), LM_GRID(g), fr, cur, rc, rs, seed); if (fast > 1) hipLaunchKernelGGL(KN(lm_k_restir_combine_rare), LM_GRID(g), fr, cur, rc, rs, seed); } else hipLaunchKernelGGL(KN(lm_k_restir_combine), LM_GRID(g), fr, cur, rc, rs, seed); }
 static void l_clear(hipStream_t s, int g, float4* p, uint32_t n) { hipLaunchKernelGGL(KN(lm_k_clear_f4), LM_GRID(g), p, n); }

@@ -14,7 +14,7 @@ struct LmKernelTable {
     void (*pick_primary)(hipStream_t, int tiles, LmScene, LmFrame, int cur, int rc, uint32_t seed, uint32_t* visCount, int fast);
     void (*trace_shade)(hipStream_t, int grid, LmScene, LmFrame, int rc, const uint32_t* count, int refillBelow, int pass);
     void (*temporal)(hipStream_t, int tiles, LmFrame, int cur, int prev, int rc, int rp, int rf, uint32_t seed, uint32_t* visCount, int fast);
-    void (*spatial)(hipStream_t, int tiles, LmFrame, int cur, int rin, int rout, uint32_t seed, int margin, int fast);
+    void (*spatial)(hipStream_t, int tiles, LmFrame, int cur, int rin, int rout, uint32_t seed, int margin, int pass /* 0 first, 1 second */, int fast);
     void (*combine)(hipStream_t, int tiles, LmFrame, int cur, int rc, int rs, uint32_t seed, int fast);     // fast: 0 exact; 1 contracted evaluation with hardware rcp / rsq / sqrt (LmFast / LmQuick, lm_bsdf.h);
                                                                                                  // 2 the same + the second, exact launch for surfaces the contracted evaluation does not cover
     void (*clear)(hipStream_t, int grid, float4* p, uint32_t n);

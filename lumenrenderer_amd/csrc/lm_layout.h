@@ -17,6 +17,7 @@
 #define LM_QUANT_MARGIN 2        // grid cells a quantised child box is widened by on each side beyond outward rounding: one for the fp32 evaluation of the slab
                                  // distances, one for the folded 2^23 offset of the packed slab test (lm_traverse.h LM_SLAB_PERM 3: up to half a cell)
 #define LM_BOX_NONE 0x0000ffffu  // per-axis word of an absent child: lo = 0xffff, hi = 0 — inverted, so the slab test misses without looking at the reference
+#define LM_REUSE_FLAGGED 0x80000000u
 #define LM_REF_NONE 0x7fffffff   // absent child of a 4-wide node (also the traversal's "finished" marker; never followed)
 #ifndef LM_TOP_NODES
 #define LM_TOP_NODES 21          // top-of-tree node records (breadth-first from the root) the queue traversal kernels stage in LDS; 0 = none.
@@ -113,6 +114,8 @@ struct LmFrame {
     // (current, previous, and the one the NEXT frame's extraction already fills while this frame's temporal pass still reads)
     float4* gbuf[3];
     float4* probe[3];
+    uint32_t* reuseMask;        // per pixel: which of its five spatial-reuse candidates passed the similarity test (bits 0..4), or LM_REUSE_FLAGGED; written
+                                // by the first spatial pass, read by the second (both draw the same candidates: the reference passes one seed to both)
     // reservoirs, 5 buffers (the reference's two swap-chain and two spatial buffers + [4], fresh candidates when candidate
     // generation runs ahead on its own stream): one 64-byte hot record (4 float4) per pixel + a contribution plane
     float4* res[5];

@@ -104,7 +104,9 @@ __device__ void lm_extract(const LmScene& sc, const lm_lds_float* lut, const LmT
     // quad q of its material: 0 color, 1 emissive, 2 transmittance, 3 tint, 4 packed parameters, 5..6 texture ids, 7 constMask, 8..15 folded slots
     auto MQ = [&](uint32_t q) -> float4 { if (tab.on) return lm_as_float4(lm_lds_read4(tab.mat + 16u * e.material + q)); return ((const float4*)(sc.materials + e.material))[q]; };
     const uint32_t cm = f2u(MQ(7).x);
-    const uint32_t i0 = sc.indices[e.idxBase + 3u * hit.y], i1 = sc.indices[e.idxBase + 3u * hit.y + 1u], i2 = sc.indices[e.idxBase + 3u * hit.y + 2u];
+    struct __attribute__((packed, aligned(4))) Tri3 { uint32_t a, b, c; };                  // one 12-byte load instead of three gathers
+    const Tri3 tri = *(const Tri3*)(sc.indices + e.idxBase + 3u * hit.y);
+    const uint32_t i0 = tri.a, i1 = tri.b, i2 = tri.c;
     const LmVertex A = lm_load_vertex(sc.verts, e.vertBase + i0), B = lm_load_vertex(sc.verts, e.vertBase + i1), C = lm_load_vertex(sc.verts, e.vertBase + i2);
     const float U = lm_f16_to_f32(hit.z & 0xffffu), V = lm_f16_to_f32(hit.z >> 16), Wt = 1.f - (U + V);
     const float uvx = A.uv.x * Wt + B.uv.x * U + C.uv.x * V;

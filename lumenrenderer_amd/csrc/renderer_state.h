@@ -231,7 +231,7 @@ struct lumen_mi_renderer {
     DevBuf<float4> dTailRay[6];             // ray queue of the path tail, double-buffered by frame parity (3 planes each)
     hipEvent_t evTail = nullptr;
     DevBuf<float4> dRay[6], dSh[3], dSh2[4], dGbuf[3], dProbe[3], dRes[5], dResC[5], dDirect[2], dIndirect[2], dCombined;
-    DevBuf<uint4> dHits; DevBuf<uint32_t> dMotion[2], dCounters; DevBuf<uchar4> dOutput; DevBuf<uint2> dBags;
+    DevBuf<uint4> dHits; DevBuf<uint32_t> dMotion[2], dCounters, dReuseMask; DevBuf<uchar4> dOutput; DevBuf<uint2> dBags;
     uint32_t hostCounters[LM_CNT_WORDS] = {0};
     bool countersValid = false;
     uint32_t lastDepth = 0;
