@@ -21,15 +21,15 @@ int ensureFrameBuffers(R* r)
     }
     r->allocN = 0;                                        // a failure below leaves "nothing allocated": the next call starts over
     int bad = 0;
-    for (int i = 0; i < 6; i++) bad |= r->dRay[i].ensure(n) | r->dTailRay[i].ensure(n);
-    for (int i = 0; i < 3; i++) bad |= r->dSh[i].ensure(n);
+    for (int i = 0; i < 6; i++) bad |= r->dRay[i].ensure(n) | r->dRay[6 + i].ensure(n) | r->dTailRay[i].ensure(n);
+    for (int i = 0; i < 6; i++) bad |= r->dSh[i].ensure(n);
     for (int i = 0; i < 4; i++) bad |= r->dSh2[i].ensure(n);
     for (int i = 0; i < 3; i++) bad |= r->dGbuf[i].ensure((size_t)8 * n) | r->dProbe[i].ensure(n);
     for (int i = 0; i < 2; i++) bad |= r->dMotion[i].ensure(n);
     bad |= r->dReuseMask.ensure(n);
     for (int i = 0; i < 5; i++) bad |= r->dRes[i].ensure((size_t)4 * n) | r->dResC[i].ensure(n);
     for (int i = 0; i < 2; i++) bad |= r->dDirect[i].ensure(n) | r->dIndirect[i].ensure(n);
-    bad |= r->dCombined.ensure(n) | r->dHits.ensure(n) | r->dOutput.ensure(n);
+    bad |= r->dCombined.ensure(n) | r->dHits[0].ensure(n) | r->dHits[1].ensure(n) | r->dOutput.ensure(n);
     bad |= r->dCounters.ensure(2 * LM_CNT_WORDS) | r->dBags.ensure(50 * 1000);
     if (bad) return fail(LUMEN_MI_ERR_DEVICE, "frame buffer allocation failed");
     f.W = W; f.H = H; f.x0 = r->wx0; f.y0 = r->wy0; f.ww = ww; f.wh = wh; f.n = n;
@@ -37,7 +37,7 @@ int ensureFrameBuffers(R* r)
     for (int q = 0; q < 2; q++) { f.rayO[q] = r->dRay[3 * q].p; f.rayD[q] = r->dRay[3 * q + 1].p; f.rayC[q] = r->dRay[3 * q + 2].p; }
     f.shO = r->dSh[0].p; f.shD = r->dSh[1].p; f.shR = r->dSh[2].p;
     f.visO = r->dSh2[0].p; f.visD = r->dSh2[1].p; f.vis2O = r->dSh2[2].p; f.vis2D = r->dSh2[3].p;
-    f.hits = r->dHits.p;
+    f.hits = r->dHits[0].p;
     for (int i = 0; i < 3; i++) { f.gbuf[i] = r->dGbuf[i].p; f.probe[i] = r->dProbe[i].p; }
     for (int i = 0; i < 5; i++) { f.res[i] = r->dRes[i].p; f.resC[i] = r->dResC[i].p; }
     f.reuseMask = r->dReuseMask.p;
@@ -49,7 +49,7 @@ int ensureFrameBuffers(R* r)
     for (int i = 0; i < 5; i++) if (hipMemsetAsync(f.res[i], 0, (size_t)4 * n * sizeof(float4), st) != hipSuccess || hipMemsetAsync(f.resC[i], 0, (size_t)n * sizeof(float4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
     if (hipMemsetAsync(f.combined, 0, (size_t)n * sizeof(float4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
     if (hipMemsetAsync(f.output, 0, (size_t)n * sizeof(uchar4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
-    r->fenceNeeded = true;
+    r->fenceNeeded = 2;
     r->haveEst = false; r->cntPending[0] = r->cntPending[1] = false;
     if (r->dSwap.ensure(2) || hipMemsetAsync(r->dSwap.p, 0, 2 * sizeof(int), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "swap index allocation failed");
     f.swap = r->dSwap.p;
@@ -115,11 +115,13 @@ int traceFrameAsync(R* r)
     if ((rc = buildLights(r))) return rc;                                                     // :456
     r->countersValid = false;
     if (r->totalEmissive == 0 || r->lights.empty()) return LUMEN_MI_NO_LIGHTS;                // :459-464
-    {   // scene edits since the last frame go to the device on the stream of the frame front, behind the merge of the frame two
-        // back (the last reader of the scene set that is rewritten); see SceneSet
+    {   // scene edits since the last frame go to the device on the first wave stream, behind the merge of the frame two back (the last
+        // reader of the scene set that is rewritten); see SceneSet.  With two wave streams the refit kernels of consecutive frames still
+        // share one stream (and their scratch buffers); an odd frame's own stream waits for them below (evScene).
         hipStream_t su = (r->overlap && r->aux != nullptr) ? r->aux : r->stream;
         if (su != r->stream) LM_HIP(hipStreamWaitEvent(su, r->evMerge[r->framePar], 0));
         if ((rc = syncScene(r, su))) return rc;
+        if (su != r->stream && r->waveStreams == 2 && r->framePar) { LM_HIP(hipEventRecord(r->evScene, su)); LM_HIP(hipStreamWaitEvent(r->aux2, r->evScene, 0)); }
     }
     if ((rc = ensureFrameBuffers(r))) return rc;
     const LmKernelTable* K = r->K;
@@ -171,15 +173,26 @@ int traceFrameAsync(R* r)
     // probe plane / motion vectors it overwrites); a frame's front waits for the merge of the frame two back (owner of
     // the same parity buffers).  Accumulation order per pixel is unchanged, so results equal the serial order bit for bit.
     const bool overlap = r->overlap && r->aux != nullptr;
-    hipStream_t sx = overlap ? r->aux : st;
     const int par = r->framePar; r->framePar ^= 1;
+    // Two wave streams (`wave_streams` 2, default): the path-tracing launches of a frame — closest hit, extraction / shading, NEE shadow rays,
+    // path tail — run in series on ONE stream, and even / odd frames use different ones, so the wave chains of consecutive frames (which do
+    // not depend on each other) overlap instead of queueing behind each other; ray queues, shadow queue and hit records exist once per
+    // parity for that.  (One wave stream: every frame's waves on `aux`, shadows and tail beside them on `aux2`.)
+    const bool twoWave = overlap && r->waveStreams == 2 && r->sortRays == 0;
+    hipStream_t sx = overlap ? ((twoWave && par) ? r->aux2 : r->aux) : st;
+    {
+        const int b = twoWave ? par : 0;
+        for (int q2 = 0; q2 < 2; q2++) { fr.rayO[q2] = r->dRay[6 * b + 3 * q2].p; fr.rayD[q2] = r->dRay[6 * b + 3 * q2 + 1].p; fr.rayC[q2] = r->dRay[6 * b + 3 * q2 + 2].p; }
+        fr.shO = r->dSh[3 * b].p; fr.shD = r->dSh[3 * b + 1].p; fr.shR = r->dSh[3 * b + 2].p;
+        fr.hits = r->dHits[b].p;
+    }
     fr.motion = r->dMotion[par].p;
     fr.direct = r->dDirect[par].p; fr.indirect = r->dIndirect[par].p; fr.counters = r->dCounters.p + (size_t)par * LM_CNT_WORDS;
     if (overlap) {
         if (r->fenceNeeded) { LM_HIP(hipEventRecord(r->evTop, st)); LM_HIP(hipStreamWaitEvent(sx, r->evTop, 0)); }
         LM_HIP(hipStreamWaitEvent(sx, r->evMerge[par], 0));
     }
-    r->fenceNeeded = false;
+    if (r->fenceNeeded > 0) --r->fenceNeeded;
     size_t evAll; evBegin2(r, 4, evAll, sx);
 #if !LM_PRIMARY_CLEARS
     LM_HIP(hipMemsetAsync(fr.counters, 0, LM_CNT_WORDS * sizeof(uint32_t), sx));
@@ -189,7 +202,7 @@ int traceFrameAsync(R* r)
     Z(sx); K->primary(sx, r->gridFor(fr.n, 8), fr, cam, r->frameCount);
     uint32_t seed = wangHash(r->frameCount);                                                  // :685
     LmScene scx = r->dscene;                                                                  // same scene, its own stack-spill area
-    if (overlap) scx.spill += (size_t)r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS);
+    if (overlap) scx.spill += (size_t)((twoWave && par) ? 2 : 1) * r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS);
     const int gridMain = r->numCU * r->traceBlocksMain, gridAux = r->numCU * (overlap ? r->traceBlocksAux : r->traceBlocksMain);
     const int tiles = (int)(((fr.ww + 15u) / 16u) * ((fr.wh + 15u) / 16u));
     // Deep waves hold too few rays to fill the machine; from the first wave expected to be shorter than `tailBelow` rays the
@@ -278,10 +291,10 @@ int traceFrameAsync(R* r)
         } else if ((int)depth >= tailDepth) {
             // path tail: the remaining waves in one launch (kernels.hip lm_k_path_tail) on the shadow stream: its INDIRECT adds
             // follow the previous wave's NEE adds by stream order, and the wave stream is free for the next frame's front
-            hipStream_t stl = overlap ? r->aux2 : sx;
+            hipStream_t stl = (overlap && !twoWave) ? r->aux2 : sx;
             LmScene sct = scx;
             if (overlap) {
-                sct.spill += (size_t)r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS);
+                if (stl != sx) sct.spill += (size_t)r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS);
                 LM_HIP(hipEventRecord(r->evShade[depth], sx)); LM_HIP(hipStreamWaitEvent(stl, r->evShade[depth], 0));     // the queue's producer is done
             }
             evBegin2(r, 5, ev, stl);
@@ -303,14 +316,15 @@ int traceFrameAsync(R* r)
             evBegin2(r, 0, ev, sx);
             Z(sx); K->trace_closest(sx, gridAux, scx, fr.rayO[q], fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters, r->refillBelow, nullptr);
             evEnd2(r, ev, sx);
-            if (overlap) LM_HIP(hipStreamWaitEvent(sx, r->evJoin2, 0));                   // previous wave's (or frame's) shadow rays consumed
+            if (overlap && !twoWave) LM_HIP(hipStreamWaitEvent(sx, r->evJoin2, 0));       // previous wave's (or frame's) shadow rays consumed (two wave streams: the
+                                                                                         // shadow launches are on this stream, and the event is not per frame)
             evBegin2(r, 2, ev, sx);
             Z(sx); K->shade_wave(sx, r->numCU * 8, scx, (int)depth + 1 == tailDepth ? withTailQueue(fr, q ^ 1) : fr, q, inCount, seed, seed2, doIndirect, outCount, shCount);
             evEnd2(r, ev, sx);
             // NEE shadow rays of this wave: third stream, beside the next wave's closest-hit launch.  The shadow queue is
             // rewritten by the NEXT shade_wave, which therefore waits for this launch (evJoin2).  (`shadow_on_wave` 1 keeps them on
             // the wave stream: equal at full size and for the windows of 4 / 8 ranks, 8 % slower for those of 2 ranks.)
-            const bool shadowOnWave = r->shadowOnWave != 0;
+            const bool shadowOnWave = r->shadowOnWave != 0 || twoWave;
             hipStream_t ss = (overlap && !shadowOnWave) ? r->aux2 : sx;
             LmScene scs = scx;
             if (ss != sx) { scs.spill += (size_t)r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS); LM_HIP(hipEventRecord(r->evShade[depth], sx)); LM_HIP(hipStreamWaitEvent(ss, r->evShade[depth], 0)); }

@@ -28,6 +28,7 @@ int lumen_mi_create(lumen_mi_renderer** out)
     if (const char* e = getenv("LUMEN_MI_PACKET_PRIMARY")) (*out)->packetPrimary = atoi(e);
     if (const char* e = getenv("LUMEN_MI_SORT_RAYS")) (*out)->sortRays = std::max(0, atoi(e));
     if (const char* e = getenv("LUMEN_MI_FAST_RESAMPLE")) (*out)->fastResample = atoi(e) != 0;
+    if (const char* e = getenv("LUMEN_MI_WAVE_STREAMS")) (*out)->waveStreams = atoi(e) == 2 ? 2 : 1;
     if (const char* e = getenv("LUMEN_MI_TAIL_LANES")) { const int v = atoi(e); (*out)->tailLanes = v <= 0 ? -1 : std::min(64, v); }
     return 0;
 }
@@ -69,6 +70,7 @@ int lumen_mi_init(lumen_mi_renderer* r, const lumen_mi_settings* s)
         LM_HIP(hipEventCreateWithFlags(&r->evFront, hipEventDisableTiming));
         for (auto& e : r->evTemporal) LM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         LM_HIP(hipEventCreateWithFlags(&r->evTail, hipEventDisableTiming));
+        LM_HIP(hipEventCreateWithFlags(&r->evScene, hipEventDisableTiming));
         LM_HIP(hipEventCreateWithFlags(&r->evTop, hipEventDisableTiming));
         for (auto& e : r->evMerge) LM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (int i = 0; i < 2; i++) { LM_HIP(hipEventCreateWithFlags(&r->evCnt[i], hipEventDisableTiming)); LM_HIP(hipHostMalloc((void**)&r->pinnedCounters[i], LM_CNT_WORDS * sizeof(uint32_t), hipHostMallocDefault)); }
@@ -87,7 +89,7 @@ int lumen_mi_destroy(lumen_mi_renderer* r)
         (void)hipStreamSynchronize(r->stream);
         if (r->aux) {
             for (hipStream_t s : {r->aux, r->aux2, r->aux3}) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
-            for (hipEvent_t e : {r->evPick, r->evVis, r->evVisDone, r->evJoin, r->evJoin2, r->evFront, r->evTail, r->evTop}) (void)hipEventDestroy(e);
+            for (hipEvent_t e : {r->evPick, r->evVis, r->evVisDone, r->evJoin, r->evJoin2, r->evFront, r->evTail, r->evTop, r->evScene}) (void)hipEventDestroy(e);
             for (auto& e : r->evShade) (void)hipEventDestroy(e);
             for (auto& e : r->evTemporal) (void)hipEventDestroy(e);
             for (auto& e : r->evMerge) (void)hipEventDestroy(e);
@@ -107,7 +109,7 @@ int lumen_mi_destroy(lumen_mi_renderer* r)
         for (auto& b : r->dResC) b.release();
         for (auto& b : r->dMotion) b.release();
         for (int i = 0; i < 2; i++) { r->dDirect[i].release(); r->dIndirect[i].release(); }
-        r->dSortBins.release(); r->dCombined.release(); r->dHits.release(); r->dCounters.release(); r->dSwap.release(); r->dOutput.release(); r->dBags.release();
+        r->dSortBins.release(); r->dCombined.release(); for (auto& b : r->dHits) b.release(); r->dCounters.release(); r->dSwap.release(); r->dOutput.release(); r->dBags.release();
         for (auto& e : r->evPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     }
     delete r;
@@ -598,6 +600,7 @@ int lumen_mi_set_tuning(lumen_mi_renderer* r, const char* key, int value)
     ApiLock lk(r);
     const std::string k = key;
     if (k == "tail_below") r->tailBelow = value;
+    else if (k == "wave_streams") { if (r->initialised) { int rc = syncAndCollect(r); if (rc) return rc; } r->waveStreams = value == 2 ? 2 : 1; }
     else if (k == "tail_lanes") r->tailLanes = value <= 0 ? -1 : std::min(64, value);
     else if (k == "single_stream") { if (r->initialised) { int rc = syncAndCollect(r); if (rc) return rc; } r->overlap = value == 0; }
     else if (k == "refit") r->refitEnabled = value;

@@ -144,7 +144,8 @@ struct lumen_mi_renderer {
     int shadowOnWave = 0;                   // 1: NEE shadow rays on the wave stream (the path tail then has the third stream to itself); measured: 8 % slower for half-frame windows, equal elsewhere
     hipEvent_t evFront = nullptr, evTemporal[2] = {nullptr, nullptr}, evTop = nullptr, evMerge[2] = {nullptr, nullptr};   // cross-frame pipelining (traceFrameAsync)
     int framePar = 0;                       // parity of the frame being enqueued: selects the channel buffers and the counter block
-    bool fenceNeeded = true;                // main-stream work (uploads, memsets) the frame front on the aux stream must wait for
+    int fenceNeeded = 2;                    // main-stream work (uploads, memsets) the frame front must wait for: counts the frames that still have to
+                                            // fence (two: with two wave streams each stream's first frame)
     std::vector<hipEvent_t> evShade;        // per wave: shade_wave(d) done
     int auxPriority = 1;                    // 1: highest priority for the aux streams, 0: default
     int aux3Priority = 0;                   // the visibility / pick-ahead stream runs at default priority (pick-ahead must not starve the main chain)
@@ -155,6 +156,9 @@ struct lumen_mi_renderer {
     bool instrumented = false;
     int tailBelow = -1;                     // waves expected to hold fewer rays than this run as one path-tail launch (0 = off,
                                             // -1 = auto: 65536 for windows under 1 Mpixel, where the wave chain is the critical path, else 16384) ...
+    int waveStreams = 2;                    // 1: every frame's waves on one stream, NEE shadows + path tail on another; 2: the path-tracing work of even / odd
+                                            // frames alternates between those two streams (each frame's closest-hit, shading, shadow and tail launches in
+                                            // series on its own), so that consecutive frames' wave chains overlap
     int tailLanes = -1;                     // ... with this many paths per wavefront (-1 = auto: 64 for windows from 0.75 Mpixel, where the tail hides behind
                                             // the other streams and fuller wavefronts save VALU issue slots; 16 for smaller windows, where the tail IS the critical path)
     uint32_t* pinnedCounters[2] = {nullptr, nullptr}; hipEvent_t evCnt[2] = {nullptr, nullptr}; bool cntPending[2] = {false, false};
@@ -229,9 +233,10 @@ struct lumen_mi_renderer {
     LmFrame fr{};
     uint32_t allocN = 0, allocDepth = 0;
     DevBuf<float4> dTailRay[6];             // ray queue of the path tail, double-buffered by frame parity (3 planes each)
-    hipEvent_t evTail = nullptr;
-    DevBuf<float4> dRay[6], dSh[3], dSh2[4], dGbuf[3], dProbe[3], dRes[5], dResC[5], dDirect[2], dIndirect[2], dCombined;
-    DevBuf<uint4> dHits; DevBuf<uint32_t> dMotion[2], dCounters, dReuseMask; DevBuf<uchar4> dOutput; DevBuf<uint2> dBags;
+    hipEvent_t evTail = nullptr, evScene = nullptr;
+    DevBuf<float4> dRay[12], dSh[6], dSh2[4];      // ray queues and the NEE shadow queue once per frame parity (two wave streams: consecutive frames trace concurrently)
+    DevBuf<float4> dGbuf[3], dProbe[3], dRes[5], dResC[5], dDirect[2], dIndirect[2], dCombined;
+    DevBuf<uint4> dHits[2]; DevBuf<uint32_t> dMotion[2], dCounters, dReuseMask; DevBuf<uchar4> dOutput; DevBuf<uint2> dBags;
     uint32_t hostCounters[LM_CNT_WORDS] = {0};
     bool countersValid = false;
     uint32_t lastDepth = 0;
