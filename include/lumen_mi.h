@@ -152,8 +152,8 @@ int lumen_mi_set_instrumented(lumen_mi_renderer*, int enable);   /* use the node
  * as one path-tail launch; 0 = off, -1 = automatic), "tail_lanes" (paths per wavefront in that launch, 1..64; 0 or less = automatic), "single_stream" (1 = no stream
  * overlap, no frame pipelining), "pick_ahead" (ReSTIR candidate generation of the next frame on its own stream: 1 on, 0 off,
  * -1 automatic), "refill" / "refill_visibility" (lane-refill thresholds of the queue traversal), "shadow_on_wave" (NEE shadow rays on
- * the wave stream), "wave_streams" (2, default: the path-tracing launches of even / odd frames alternate between two streams, so that
- * the wave chains of consecutive frames overlap; 1: one wave stream, NEE shadows and the path tail on a stream beside it), "fuzz" (test aid: a seed != 0 inserts idle launches of random length in front of the kernels of a frame; the image
+ * the wave stream), "wave_streams" (1, default: one wave stream, NEE shadows and the path tail on a stream beside it; 2: the path-tracing launches of
+ * even / odd frames alternate between those two streams, so that the wave chains of consecutive frames overlap), "fuzz" (test aid: a seed != 0 inserts idle launches of random length in front of the kernels of a frame; the image
  * must not change), "assemble" (1, default: after the first build a topology edit — an instance added or removed — assembles cached
  * per-mesh trees behind a small top tree and refits on the GPU; 0: full host SAH rebuild). */
 int lumen_mi_set_tuning(lumen_mi_renderer*, const char* key, int value);

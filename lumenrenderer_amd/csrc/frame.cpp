@@ -174,7 +174,7 @@ int traceFrameAsync(R* r)
     // the same parity buffers).  Accumulation order per pixel is unchanged, so results equal the serial order bit for bit.
     const bool overlap = r->overlap && r->aux != nullptr;
     const int par = r->framePar; r->framePar ^= 1;
-    // Two wave streams (`wave_streams` 2, default): the path-tracing launches of a frame — closest hit, extraction / shading, NEE shadow rays,
+    // Two wave streams (`wave_streams` 2; default 1): the path-tracing launches of a frame — closest hit, extraction / shading, NEE shadow rays,
     // path tail — run in series on ONE stream, and even / odd frames use different ones, so the wave chains of consecutive frames (which do
     // not depend on each other) overlap instead of queueing behind each other; ray queues, shadow queue and hit records exist once per
     // parity for that.  (One wave stream: every frame's waves on `aux`, shadows and tail beside them on `aux2`.)

@@ -156,9 +156,10 @@ struct lumen_mi_renderer {
     bool instrumented = false;
     int tailBelow = -1;                     // waves expected to hold fewer rays than this run as one path-tail launch (0 = off,
                                             // -1 = auto: 65536 for windows under 1 Mpixel, where the wave chain is the critical path, else 16384) ...
-    int waveStreams = 2;                    // 1: every frame's waves on one stream, NEE shadows + path tail on another; 2: the path-tracing work of even / odd
-                                            // frames alternates between those two streams (each frame's closest-hit, shading, shadow and tail launches in
-                                            // series on its own), so that consecutive frames' wave chains overlap
+    int waveStreams = 1;                    // 1 (default): every frame's waves on one stream, NEE shadows + path tail on another; 2: the path-tracing work of
+                                            // even / odd frames alternates between those two streams (each frame's closest-hit, shading, shadow and tail
+                                            // launches in series on its own), so that consecutive frames' wave chains overlap.  Measured box-dependent:
+                                            // + 1.5 % on one box, - 3 % on two others (tiles - 6 ... - 8 %), toy frames + 24 %: off by default
     int tailLanes = -1;                     // ... with this many paths per wavefront (-1 = auto: 64 for windows from 0.75 Mpixel, where the tail hides behind
                                             // the other streams and fuller wavefronts save VALU issue slots; 16 for smaller windows, where the tail IS the critical path)
     uint32_t* pinnedCounters[2] = {nullptr, nullptr}; hipEvent_t evCnt[2] = {nullptr, nullptr}; bool cntPending[2] = {false, false};
