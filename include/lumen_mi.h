@@ -192,6 +192,11 @@ int lumen_mi_test_math(lumen_mi_renderer*, uint32_t n, int fn, const float* x, c
  * out[33 n] = per update (weightSum, sampleCount, id held, taken), then the weight; mode 1: a = n prefix sums, b = m values, out[2 m] =
  * (index bits, pdf); mode 2: a = n linear values, out[n] = sRGB8 levels. */
 int lumen_mi_test_restir(lumen_mi_renderer*, int mode, uint32_t n, const float* a, const float* b, const uint32_t* c, uint32_t m, float* out);
+/* Known-answer hook for the host-side camera arithmetic of a frame (no renderer, no GPU): the image-plane vectors U, V, W of
+ * Camera::GetVectorData (Lumen/src/Lumen/Renderer/Camera.cpp:79-93,122-128) for the rotation columns right / up / forward, and the matrix
+ * projection * inverse(previous camera world matrix) the motion-vector pass receives (WaveFrontRenderer.cpp:763-776,
+ * CPUShadingKernels.cu:39), both row major.  out25 = U(3) V(3) W(3) M(16). */
+int lumen_mi_test_camera(const float right[3], const float up[3], const float forward[3], const float prev_world16[16], float fov_y_degrees, float aspect, float out25[25]);
 /* host-side scene products, for tests: world-space triangles (9 floats each) and the sorted light list (16 floats each) + CDF */
 int lumen_mi_get_world_triangles(lumen_mi_renderer*, float* out, uint32_t capacity_triangles, uint32_t* count);
 int lumen_mi_get_lights(lumen_mi_renderer*, float* lights16, float* cdf, uint32_t capacity, uint32_t* count);

@@ -104,6 +104,25 @@ void evBegin2(R* r, int cls, size_t& slot, hipStream_t s)
 }
 void evEnd2(R* r, size_t slot, hipStream_t s) { if (slot != (size_t)-1) (void)hipEventRecord(r->evPool[slot].b, s); }
 
+// Camera::GetVectorData (Camera.cpp:79-93,122-128): image-plane half sizes from the vertical field of view, focal length 1
+void cameraVectors(const float* right, const float* up, const float* fwd, float fovY, float aspect, float* U, float* V, float* Wv)
+{
+    const float halfY = 1.0f * (float)tan((double)(fovY * 0.01745329251994329576923690768489f) * 0.5);
+    const float halfX = halfY * aspect;
+    for (int k = 0; k < 3; k++) { U[k] = right[k] * halfX; V[k] = up[k] * halfY; Wv[k] = fwd[k] * 1.0f; }
+}
+// M = projection(fovY, aspect, 0.5, 10000) * inverse(previous camera world matrix), row major   (WaveFrontRenderer.cpp:763-776, CPUShadingKernels.cu:39)
+void motionMatrix(const float* prevCamWorld, float fovY, float aspect, float* M)
+{
+    float proj[16] = {0}, invPrev[16];
+    const float tanHalf = (float)tan((double)(fovY * 0.01745329251994329576923690768489f) / 2.0);
+    const float zn = 0.5f, zf = 10000.f;
+    proj[0] = 1.0f / (aspect * tanHalf); proj[5] = 1.0f / tanHalf;
+    proj[10] = -(zf + zn) / (zf - zn); proj[11] = -(2.0f * zf * zn) / (zf - zn); proj[14] = -1.0f;
+    invert4(prevCamWorld, invPrev);
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { float s = 0.f; for (int k = 0; k < 4; k++) s += proj[i * 4 + k] * invPrev[k * 4 + j]; M[i * 4 + j] = s; }
+}
+
 int traceFrameAsync(R* r)
 {
     if (!r->initialised) return fail(LUMEN_MI_ERR_STATE, "lumen_mi_init has not been called");
@@ -149,21 +168,12 @@ int traceFrameAsync(R* r)
     // camera (Camera.cpp:79-93,122-140; aspect = render W/H, WaveFrontRenderer.cpp:577)
     LmCamera cam;
     const float aspect = (float)fr.W / (float)fr.H;
-    const float halfY = 1.0f * (float)tan((double)(r->fovY * 0.01745329251994329576923690768489f) * 0.5);
-    const float halfX = halfY * aspect;
-    for (int k = 0; k < 3; k++) { cam.eye[k] = r->camPos[k]; cam.U[k] = r->camRight[k] * halfX; cam.V[k] = r->camUp[k] * halfY; cam.Wv[k] = r->camFwd[k] * 1.0f; }
+    for (int k = 0; k < 3; k++) cam.eye[k] = r->camPos[k];
+    cameraVectors(r->camRight, r->camUp, r->camFwd, r->fovY, aspect, cam.U, cam.V, cam.Wv);
     float camWorld[16] = {r->camRight[0], r->camUp[0], r->camFwd[0], r->camPos[0], r->camRight[1], r->camUp[1], r->camFwd[1], r->camPos[1],
                           r->camRight[2], r->camUp[2], r->camFwd[2], r->camPos[2], 0, 0, 0, 1};
     if (!r->havePrev) { memcpy(r->prevCamWorld, camWorld, sizeof camWorld); r->havePrev = true; }
-    {   // M = projection(fovY, aspect, 0.5, 10000) * inverse(previous camera world matrix)   (WaveFrontRenderer.cpp:763-776)
-        float proj[16] = {0}, invPrev[16];
-        const float tanHalf = (float)tan((double)(r->fovY * 0.01745329251994329576923690768489f) / 2.0);
-        const float zn = 0.5f, zf = 10000.f;
-        proj[0] = 1.0f / (aspect * tanHalf); proj[5] = 1.0f / tanHalf;
-        proj[10] = -(zf + zn) / (zf - zn); proj[11] = -(2.0f * zf * zn) / (zf - zn); proj[14] = -1.0f;
-        invert4(r->prevCamWorld, invPrev);
-        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { float s = 0.f; for (int k = 0; k < 4; k++) s += proj[i * 4 + k] * invPrev[k * 4 + j]; cam.prevViewProj[i * 4 + j] = s; }
-    }
+    motionMatrix(r->prevCamWorld, r->fovY, aspect, cam.prevViewProj);
 
     // ---- frame graph.  Streams: main `st` (ReSTIR chain, merge), `sx` (frame front + indirect waves), aux2 (NEE shadow
     // rays), aux3 (second ReSTIR visibility pass).  Frames are software-pipelined: the front of frame i+1 (primary rays,

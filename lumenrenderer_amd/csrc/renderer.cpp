@@ -704,6 +704,13 @@ int lumen_mi_test_bsdf(lumen_mi_renderer* r, uint32_t n, int mode, const float* 
     dm.release(); dn.release(); dt.release(); dw.release(); da.release(); dout.release();
     return 0;
 }
+int lumen_mi_test_camera(const float right[3], const float up[3], const float forward[3], const float prev_world16[16], float fov, float aspect, float out25[25])
+{
+    if (!right || !up || !forward || !prev_world16 || !out25) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    cameraVectors(right, up, forward, fov, aspect, out25, out25 + 3, out25 + 6);
+    motionMatrix(prev_world16, fov, aspect, out25 + 9);
+    return 0;
+}
 int lumen_mi_test_restir(lumen_mi_renderer* r, int mode, uint32_t n, const float* a, const float* b, const uint32_t* c, uint32_t m, float* out)
 {
     if (!r || !r->initialised) return fail(LUMEN_MI_ERR_STATE, "not initialised");

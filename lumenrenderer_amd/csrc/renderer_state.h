@@ -279,6 +279,8 @@ int buildLights(R* r);
 // frame.cpp
 int ensureFrameBuffers(R* r);
 int traceFrameAsync(R* r);
+void cameraVectors(const float* right, const float* up, const float* fwd, float fovY, float aspect, float* U, float* V, float* Wv);
+void motionMatrix(const float* prevCamWorld, float fovY, float aspect, float* M);
 int syncAndCollect(R* r);
 
 }  // namespace lmr

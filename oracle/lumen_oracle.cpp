@@ -985,6 +985,25 @@ static void rigid_inverse(const float* m, float* out)
     for (int i = 0; i < 16; i++) out[i] = (float)(inv[i] / det);
 }
 
+// Camera::GetVectorData (Camera.cpp:79-93,122-128): image-plane half sizes from the vertical field of view, focal length 1
+static void camera_vectors(const f3& right, const f3& up, const f3& forward, float fovY, float aspect, f3& U, f3& V, f3& Wv)
+{
+    const float halfY = 1.0f * (float)tan((double)(fovY * 0.01745329251994329576923690768489f) * 0.5);
+    const float halfX = halfY * aspect;
+    U = right * halfX; V = up * halfY; Wv = forward * 1.0f;
+}
+// the matrix GenerateMotionVectors receives (WaveFrontRenderer.cpp:763-776, CPUShadingKernels.cu:39): projection * inverse(previous camera world matrix)
+static void motion_matrix(const float* prevCamWorld, float fovY, float aspect, float* M)
+{
+    float proj[16] = {0}, invPrev[16];
+    const float tanHalf = (float)tan((double)(fovY * 0.01745329251994329576923690768489f) / 2.0);
+    const float zn = 0.5f, zf = 10000.f;                           // glm::perspective RH, -1..1 depth (Camera.cpp:106-109)
+    proj[0] = 1.0f / (aspect * tanHalf); proj[5] = 1.0f / tanHalf;
+    proj[10] = -(zf + zn) / (zf - zn); proj[11] = -(2.0f * zf * zn) / (zf - zn); proj[14] = -1.0f;
+    rigid_inverse(prevCamWorld, invPrev);
+    mat4_mul44(proj, invPrev, M);
+}
+
 // ----------------------------------------------------------------------------------------------------------
 // TraceFrame — Framework/WaveFrontRenderer.cpp:435-1089 (loop order + seed evolution), Shade: CPUShadingKernels.cu:89-193
 // ----------------------------------------------------------------------------------------------------------
@@ -1015,9 +1034,9 @@ static int trace_frame(orc_ctx* c)
 
     // camera — Camera.cpp:79-93,122-128 (aspect = render W/H, WaveFrontRenderer.cpp:577)
     const float aspect = (float)W / (float)H;
-    const float halfY = 1.0f * (float)tan((double)(c->fovY * 0.01745329251994329576923690768489f) * 0.5);
-    const float halfX = halfY * aspect;
-    const f3 U = c->camRight * halfX, V = c->camUp * halfY, Wv = c->camForward * 1.0f, eye = c->camPos;
+    f3 U, V, Wv;
+    camera_vectors(c->camRight, c->camUp, c->camForward, c->fovY, aspect, U, V, Wv);
+    const f3 eye = c->camPos;
     float camWorld[16] = {c->camRight.x, c->camUp.x, c->camForward.x, c->camPos.x,
                           c->camRight.y, c->camUp.y, c->camForward.y, c->camPos.y,
                           c->camRight.z, c->camUp.z, c->camForward.z, c->camPos.z, 0, 0, 0, 1};
@@ -1054,13 +1073,8 @@ static int trace_frame(orc_ctx* c)
         orc_lap("extract");
         if (depth == 0) {
             // GenerateMotionVectors: M = projection * inverse(previous camera world matrix)
-            float proj[16] = {0}, invPrev[16], M[16];
-            const float tanHalf = (float)tan((double)(c->fovY * 0.01745329251994329576923690768489f) / 2.0);
-            const float zn = 0.5f, zf = 10000.f;                           // glm::perspective RH, -1..1 depth (Camera.cpp:106-109)
-            proj[0] = 1.0f / (aspect * tanHalf); proj[5] = 1.0f / tanHalf;
-            proj[10] = -(zf + zn) / (zf - zn); proj[11] = -(2.0f * zf * zn) / (zf - zn); proj[14] = -1.0f;
-            rigid_inverse(c->prevCamWorld, invPrev);
-            mat4_mul44(proj, invPrev, M);
+            float M[16];
+            motion_matrix(c->prevCamWorld, c->fovY, aspect, M);
             c->pfor((uint32_t)pixels.size(), [&](uint32_t b, uint32_t e, int) {
                 for (uint32_t k = b; k < e; k++) {
                     const uint32_t i = pixels[k];
@@ -1266,6 +1280,14 @@ void orc_set_instance_emissiveness(orc_ctx* c, int inst, int mode, const float r
     mi.mode = mode; mi.overrideRadiance = f3{rad[0], rad[1], rad[2]}; mi.scale = scale; c->sceneDirty = true;
 }
 void orc_set_instance_override_material(orc_ctx* c, int inst, int material) { c->instances[inst].overrideMaterial = material; c->sceneDirty = true; }
+// known-answer hooks for the camera (tests/golden/ref_kat.npz rows "cam" / "mvm": the reference's Camera.cpp compiled from source)
+void orc_camera_vectors(const float right[3], const float up[3], const float fwd[3], float fov, float aspect, float out[9])
+{
+    f3 U, V, W;
+    camera_vectors(f3{right[0], right[1], right[2]}, f3{up[0], up[1], up[2]}, f3{fwd[0], fwd[1], fwd[2]}, fov, aspect, U, V, W);
+    out[0] = U.x; out[1] = U.y; out[2] = U.z; out[3] = V.x; out[4] = V.y; out[5] = V.z; out[6] = W.x; out[7] = W.y; out[8] = W.z;
+}
+void orc_motion_matrix(const float prevCamWorld[16], float fov, float aspect, float out[16]) { motion_matrix(prevCamWorld, fov, aspect, out); }
 void orc_set_camera(orc_ctx* c, const float pos[3], const float right[3], const float up[3], const float fwd[3], float fov)
 {
     c->camPos = f3{pos[0], pos[1], pos[2]}; c->camRight = f3{right[0], right[1], right[2]};

@@ -50,6 +50,8 @@ void orc_set_instance_override_material(orc_ctx*, int instance, int material);
 void orc_get_denoiser_inputs(orc_ctx*, float min_distance, float max_distance, float* depth, uint16_t* normal_roughness_half4, uint16_t* motion_half2);
 
 /* camera: position + rotation matrix columns right/up/forward (Camera.cpp:122-140), vertical fov in degrees */
+void orc_camera_vectors(const float right[3], const float up[3], const float forward[3], float fov_y_deg, float aspect, float out_uvw[9]);
+void orc_motion_matrix(const float prev_cam_world_row_major[16], float fov_y_deg, float aspect, float out_row_major[16]);
 void orc_set_camera(orc_ctx*, const float pos[3], const float right[3], const float up[3], const float forward[3], float fov_y_deg);
 void orc_set_resolution(orc_ctx*, uint32_t w, uint32_t h);
 void orc_set_depth(orc_ctx*, uint32_t depth);

@@ -2,7 +2,8 @@
 """Build tests/golden/ref_kat.npz from the reference's own headers (container-only).
 
 Usage (in the build container, where /root/reference exists):  python oracle/ref_kat/make_kat.py
-Compiles gen_kat.cpp against /root/reference/Lumen_Engine/LumenPT (headers only, via shim.h), runs it,
+Compiles gen_kat.cpp / gen_kat2.cpp against /root/reference/Lumen_Engine/LumenPT (headers only, via shim.h) and gen_kat3.cpp together
+with the reference's Camera.cpp (its own source file, on the vendored glm), runs them,
 and stores the rows as float64/uint32 arrays.  Only numbers are committed, never reference text.
 """
 import os, subprocess, sys, numpy as np
@@ -17,6 +18,15 @@ for src in ("gen_kat.cpp", "gen_kat2.cpp"):        # two translation units: ReST
     for line in subprocess.check_output([exe], text=True).splitlines():
         tag, *vals = line.split()
         rows.setdefault(tag, []).append([float(v) for v in vals])
+# third unit: the reference's camera, compiled from its own source file (plain C++ on the vendored glm) + the vendored sutil matrix
+L = "/root/reference/Lumen_Engine/Lumen"
+exe = "/tmp/lumen_gen_kat3"
+subprocess.check_call(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-DNDEBUG", "-w", "-DGLM_ENABLE_EXPERIMENTAL",
+                       f"-I{L}/vendor/glm", f"-I{L}/src", f"-I{R}/vendor/Include", f"-I{R}/vendor/Include/Cuda",
+                       os.path.join(here, "gen_kat3.cpp"), f"{L}/src/Lumen/Renderer/Camera.cpp", "-o", exe])
+for line in subprocess.check_output([exe], text=True).splitlines():
+    tag, *vals = line.split()
+    rows.setdefault(tag, []).append([float(v) for v in vals])
 out = {k: np.asarray(v, dtype=np.float64) for k, v in rows.items()}
 dst = os.path.join(here, "..", "..", "tests", "golden", "ref_kat.npz")
 np.savez_compressed(dst, **out)

@@ -62,6 +62,8 @@ def lib():
             ("orc_sample_bsdf", [C.c_uint32, fp, fp, fp, fp, fp, fp], None),
             ("orc_det_math", [C.c_uint32, C.c_int, fp, fp, fp], None),
             ("orc_f32_to_f16", [C.c_float], C.c_uint16), ("orc_f16_to_f32", [C.c_uint16], C.c_float),
+            ("orc_camera_vectors", [fp, fp, fp, C.c_float, C.c_float, fp], None),
+            ("orc_motion_matrix", [fp, C.c_float, C.c_float, fp], None),
             ("orc_reservoir_sequence", [C.c_uint32, fp, fp, u32p, fp, C.POINTER(C.c_int64), i32p, i32p, fp, fp], None),
             ("orc_cdf_get", [C.c_uint32, fp, C.c_uint32, fp, u32p, fp], None),
             ("orc_make_color", [C.c_uint32, fp, u8p], None),

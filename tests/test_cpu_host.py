@@ -26,6 +26,36 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, name), name
 
 
+def test_product_camera_arithmetic_matches_the_reference_camera_source():
+    """The host-side camera arithmetic of the PRODUCT library (frame.cpp cameraVectors / motionMatrix through lumen_mi_test_camera: no
+    renderer, no GPU) against the vectors made from the reference's Camera.cpp + glm + sutil (tests/golden/ref_kat.npz rows cam / mvm),
+    and bit for bit against the oracle's."""
+    import ctypes as C
+    import lumenrenderer_amd
+    from test_oracle_kat import _check_camera, _camera_rows
+    from oracle_lib import lib as orc, fptr, f32
+    plib = lumenrenderer_amd.load_library()
+    FP = C.POINTER(C.c_float)
+    def call(r, u, f, prev, fov, a):
+        out = np.zeros(25, np.float32)
+        rc = plib.lumen_mi_test_camera(f32(r).ctypes.data_as(FP), f32(u).ctypes.data_as(FP), f32(f).ctypes.data_as(FP), f32(prev).ctypes.data_as(FP), C.c_float(fov), C.c_float(a), out.ctypes.data_as(FP))
+        assert rc == 0
+        return out
+    ident = np.eye(4, dtype=np.float32).ravel()
+    worst_uvw, worst_ndc = _check_camera(lambda r, u, f, fov, a: call(r, u, f, ident, fov, a)[:9], lambda prev, fov, a: call([1, 0, 0], [0, 1, 0], [0, 0, 1], prev, fov, a)[9:])
+    assert worst_uvw <= 2.5e-7 and worst_ndc <= 4e-5, (worst_uvw, worst_ndc)
+    L = orc()
+    aspect, right, up, fwd, eye, uvw, prev, aspect2, M = _camera_rows()
+    for i in range(0, len(aspect), 7):
+        o9 = np.zeros(9, np.float32); o16 = np.zeros(16, np.float32)
+        L.orc_camera_vectors(fptr(f32(right[i])), fptr(f32(up[i])), fptr(f32(fwd[i])), 73.5, float(aspect[i]), fptr(o9))
+        L.orc_motion_matrix(fptr(f32(prev[i])), 73.5, float(aspect2[i]), fptr(o16))
+        got = call(right[i], up[i], fwd[i], prev[i], 73.5, float(aspect[i]))
+        assert np.array_equal(got[:9].view(np.uint32), o9.view(np.uint32))
+        got = call(right[i], up[i], fwd[i], prev[i], 73.5, float(aspect2[i]))
+        assert np.array_equal(got[9:].view(np.uint32), o16.view(np.uint32))
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     """Without a HIP device lumen_mi_init must fail with ERR_DEVICE; nothing silently renders on the CPU."""
     import torch
