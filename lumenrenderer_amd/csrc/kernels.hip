@@ -512,14 +512,14 @@ __device__ __forceinline__ void lm_pick_primary_body(const LmScene& sc, const Lm
             LmReservoir fresh; lm_res_fresh(fresh);
             LmTarget target;                                       // the pixel's surface, prepared once for its 32 candidates
             lm_target_setup<A>(pixel, target);
-            for (int smp = 0; smp < 32; smp++) {
-                const float r = lm_random_float(s);
+            // one candidate from RNG state `st`: a light from the tile's bag, a point on it, its score at this surface; returns the resampling weight
+            auto candidate = [&](uint32_t& st, LmSample& cand) -> float {
+                const float r = lm_random_float(st);
                 const int pick = lm_round_nonneg((float)(1000 - 1) * r);
                 const uint2 entry = s_bag[pick];
                 const float initialPdf = u2f(entry.y);               // contracted policy: its reciprocal (see the staging loop)
-                const float u = lm_random_float(s);
-                const float v = lm_random_float(s) * (1.f - u);
-                LmSample cand;
+                const float u = lm_random_float(st);
+                const float v = lm_random_float(st) * (1.f - u);
                 lf3 p0, arm1, arm2;
                 if constexpr (LDSL) {
                     const lm_lds_u4* lp = (const lm_lds_u4*)s_lights + 4u * entry.x;
@@ -534,8 +534,19 @@ __device__ __forceinline__ void lm_pick_primary_body(const LmScene& sc, const Lm
                 cand.p.position = p0 + (arm1 * u) + (arm2 * v);
                 cand.contribution = v3(0.f);
                 lm_score<A>(cand.p, target, cand.contribution, cand.pdf);
-                lm_res_update<A>(fresh, cand, A::contracted ? cand.pdf * initialPdf : A::div(cand.pdf, initialPdf), s);
+                return A::contracted ? cand.pdf * initialPdf : A::div(cand.pdf, initialPdf);
+            };
+            // The loop only remembers WHERE in the RNG stream the candidate the reservoir holds began (one register instead of the 14 of a
+            // sample, which a take by any lane of the wavefront would copy); that candidate is generated once more behind the loop.
+            uint32_t heldAt = 0u;
+            bool holds = false;
+            for (int smp = 0; smp < 32; smp++) {
+                const uint32_t begin = s;
+                LmSample cand;
+                const float w = candidate(s, cand);
+                if (lm_res_update_decide<A>(fresh, w, s)) { heldAt = begin; holds = true; }
             }
+            if (holds) (void)candidate(heldAt, fresh.s);
             lm_res_update_weight<A>(fresh);
             lm_res_store(hot, fr.resC[rc], li, fresh);
             // K22 GenerateShadowRay fused (ReSTIRKernels.cu:546-582): the visibility ray of the fresh reservoir

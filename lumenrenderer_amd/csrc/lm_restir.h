@@ -117,14 +117,17 @@ template <class A> __device__ __forceinline__ void lm_resample(const LmSample& i
 }
 
 // streaming weighted reservoir update (Reservoir::Update: the seed arrives BY VALUE, so every update of one merge draws the same number)
-template <class A> __device__ __forceinline__ bool lm_res_update(LmReservoir& r, const LmSample& s, float w, uint32_t seed)
+template <class A> __device__ __forceinline__ bool lm_res_update_decide(LmReservoir& r, float w, uint32_t seed)
 {
     r.weightSum += w;
     ++r.count;
     const float rnd = lm_random_float(seed);
-    bool take;
-    if constexpr (A::contracted) take = w > 0.f && rnd * r.weightSum <= w;      // rnd <= w / weightSum without the division (weightSum >= w > 0)
-    else take = rnd <= A::div(w, r.weightSum);
+    if constexpr (A::contracted) return w > 0.f && rnd * r.weightSum <= w;        // rnd <= w / weightSum without the division (weightSum >= w > 0)
+    else return rnd <= A::div(w, r.weightSum);
+}
+template <class A> __device__ __forceinline__ bool lm_res_update(LmReservoir& r, const LmSample& s, float w, uint32_t seed)
+{
+    const bool take = lm_res_update_decide<A>(r, w, seed);
     if (take) r.s = s;
     return take;
 }
