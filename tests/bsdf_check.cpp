@@ -41,4 +41,20 @@ void chk_sample_bsdf(uint32_t n, const float* mat23, const float* N, const float
     }
 }
 
+// lm_round_nonneg (lm_math.h) against roundf: the bag index of every possible 32-bit random number (x = 999 * r, r = k * 2^-32 rounded to
+// binary32: `stride` samples the k) plus every binary32 value near a half-integer up to 1000.  Returns the number of disagreements.
+uint32_t chk_round_nonneg(uint32_t stride)
+{
+    uint32_t bad = 0;
+    for (uint64_t k = 0; k < (1ull << 32); k += stride) {
+        const float r = (float)(uint32_t)k * 2.3283064365387e-10f, x = (float)(1000 - 1) * r;
+        bad += lm_round_nonneg(x) != (int)roundf(x);
+    }
+    for (int h = 0; h < 1000; h++) {
+        float x = (float)h + 0.5f;
+        for (int step = 0; step < 64; step++) x = nextafterf(x, 0.f);
+        for (int step = 0; step < 128; step++) { bad += lm_round_nonneg(x) != (int)roundf(x); x = nextafterf(x, 2000.f); }
+    }
+    return bad;
+}
 }  // extern "C"

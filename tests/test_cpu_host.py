@@ -636,6 +636,8 @@ def test_product_bsdf_header_equals_the_oracle_bit_for_bit_on_the_host(tmp_path)
         got = np.zeros((n, 8), np.float32); K.chk_sample_bsdf(n, fptr(mat), fptr(N), fptr(T), fptr(wo), fptr(r3), fptr(got))
         assert same(got, want), seed
         assert want[:, 7].sum() > 0.1 * n and (want[:, 6] > 0).sum() > 0.8 * n
+    K.chk_round_nonneg.argtypes = [C.c_uint32]; K.chk_round_nonneg.restype = C.c_uint32
+    assert K.chk_round_nonneg(61) == 0            # lm_round_nonneg == (int)roundf on the candidate loop's domain (70 M of the 2^32 random numbers + every half-integer neighbourhood)
 
 
 def test_textured_standin_maps_are_deterministic():
