@@ -190,7 +190,15 @@ int lumen_mi_test_math(lumen_mi_renderer*, uint32_t n, int fn, const float* x, c
 /* Known-answer hook for the device-side Reservoir::Update / UpdateWeight (ReSTIRData.h:115-163), CDF::Get (ReSTIRData.h:230-306) and
  * make_color (vendor/Include/Cuda/cuda/helpers.h:35-66).  mode 0: n sequences of 8 updates, a = weights, b = pdfs, c = seeds (8 n each),
  * out[33 n] = per update (weightSum, sampleCount, id held, taken), then the weight; mode 1: a = n prefix sums, b = m values, out[2 m] =
- * (index bits, pdf); mode 2: a = n linear values, out[n] = sRGB8 levels. */
+ * (index bits, pdf); mode 2: a = n linear values, out[n] = sRGB8 levels.
+ * modes 3 / 5: Resample (LumenPT/src/CUDAKernels/ReSTIRKernels.cu:1259-1325) in the exact / fast arithmetic policy: a = n surfaces (35 floats:
+ * position normal tangent incoming + the 23 material floats of lumen_mi_test_bsdf), b = n light samples (14: radiance normal position area
+ * contribution solidAnglePdf), out[5 n] = (contribution, solidAnglePdf, applies).  modes 4 / 6: CombineBiased of two reservoirs
+ * (ReSTIRKernels.cu:1200-1257), exact / fast: a = n surfaces, b = 2 n reservoirs (17: weightSum sampleCount weight sample(14)), c = n seeds,
+ * out[18 n] = (reservoir(17), applies).  applies = 0 only in the fast modes, for surfaces the contracted evaluation does not cover (the
+ * renderer scores those with the exact policy in a second launch).
+ * lumen_mi_test_bsdf mode 2 = the contracted EvaluateBSDF of the fast policy (disney.cuh:320-405 for the isotropic opaque stack):
+ * out8 = (bsdf, pdf, applies, 0, 0, 0). */
 int lumen_mi_test_restir(lumen_mi_renderer*, int mode, uint32_t n, const float* a, const float* b, const uint32_t* c, uint32_t m, float* out);
 /* Known-answer hook for the host-side camera arithmetic of a frame (no renderer, no GPU): the image-plane vectors U, V, W of
  * Camera::GetVectorData (Lumen/src/Lumen/Renderer/Camera.cpp:79-93,122-128) for the rotation columns right / up / forward, and the matrix

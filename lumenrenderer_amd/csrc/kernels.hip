@@ -941,6 +941,19 @@ KN(lm_k_test_bsdf)(uint32_t n, int mode, const float* __restrict__ mat, const fl
         float pdf = 0.f;
         const lf3 b = lm_evaluate_bsdf(sd, n3, t3, wo3, v3(aux[3*i], aux[3*i+1], aux[3*i+2]), pdf);
         out[8*i] = b.x; out[8*i+1] = b.y; out[8*i+2] = b.z; out[8*i+3] = pdf; out[8*i+4] = 0; out[8*i+5] = 0; out[8*i+6] = 0; out[8*i+7] = 0;
+    } else if (mode == 2) {
+        // the contracted evaluation the fast ReSTIR mode runs (lm_quick_setup + lm_quick_eval): out[4] = 1 where it applies
+        // (lm_quick_contracts and a light above the horizon, what lm_score_quick hands it), else the row is left zero
+        const lf3 wi3 = v3(aux[3*i], aux[3*i+1], aux[3*i+2]);
+        const float cin = dot3(wi3, n3);
+        float* o = out + 8u * i;
+        for (int k = 0; k < 8; k++) o[k] = 0.f;
+        if (lm_quick_contracts(sd) && cin > 0.f) {
+            LmQuick Q; lm_quick_setup(sd, n3, wo3, Q);
+            float pdf = 0.f;
+            const lf3 b = lm_quick_eval(Q, wi3, cin, pdf);
+            o[0] = b.x; o[1] = b.y; o[2] = b.z; o[3] = pdf; o[4] = 1.f;
+        }
     } else {
         float pdf = 0.f; bool spec = false; lf3 wi = v3(0.f);
         const lf3 b = lm_sample_bsdf(sd, n3, n3, t3, wo3, 1.f, aux[3*i], aux[3*i+1], aux[3*i+2], wi, pdf, spec);
@@ -952,10 +965,47 @@ KN(lm_k_test_bsdf)(uint32_t n, int mode, const float* __restrict__ mat, const fl
 //           out[33 * i + 4 * k ..] = (weightSum, sampleCount, id of the held sample, taken) after update k, out[33 * i + 32] = weight
 //   mode 1  a = prefix sums of n weights, b = m query values; out[2 * j] = index bits, out[2 * j + 1] = pdf
 //   mode 2  a = n linear values; out[j] = sRGB8 level
+//   mode 3 / 5  Resample (ReSTIRKernels.cu:1259-1325), exact / fast policy: a = n surfaces (35 floats: position normal tangent incoming mat23),
+//           b = n light samples (14: radiance normal position area contribution solidAnglePdf); out[5 * i ..] = contribution, pdf, applies
+//   mode 4 / 6  CombineBiased of two reservoirs (:1200-1257), exact / fast: a = n surfaces, b = 2n reservoirs (17: weightSum sampleCount
+//           weight sample(14)), c = n seeds; out[18 * i ..] = reservoir(17), applies
+//   "applies" = 1, except in the fast modes for surfaces the contracted evaluation does not cover (those take the exact launch: LM_RARE)
+template <class A> __device__ void lm_test_resample_combine(bool combine, uint32_t i, const float* __restrict__ a, const float* __restrict__ b, const uint32_t* __restrict__ c, float* __restrict__ out)
+{
+    const float* sv = a + 35u * i;
+    LmSurface px;
+    px.position = v3(sv[0], sv[1], sv[2]); px.normal = v3(sv[3], sv[4], sv[5]); px.tangent = v3(sv[6], sv[7], sv[8]); px.incoming = v3(sv[9], sv[10], sv[11]);
+    px.transport = v3(1.f); px.t = 1.f; px.flags = 0u;
+    px.mat = lm_material_from23(sv + 12);
+    const bool applies = !A::contracted || lm_quick_contracts(px.mat);
+    auto sample = [](const float* v) { LmSample s; s.p.radiance = v3(v[0], v[1], v[2]); s.p.normal = v3(v[3], v[4], v[5]); s.p.position = v3(v[6], v[7], v[8]); s.p.area = v[9];
+                                        s.contribution = v3(v[10], v[11], v[12]); s.pdf = v[13]; return s; };
+    LmTarget t; lm_target_setup<A>(px, t);
+    if (!combine) {
+        float* o = out + 5u * i;
+        LmSample rs; lm_resample<A>(sample(b + 14u * i), t, rs);
+        o[0] = rs.contribution.x; o[1] = rs.contribution.y; o[2] = rs.contribution.z; o[3] = rs.pdf; o[4] = applies ? 1.f : 0.f;
+    } else {
+        LmReservoir r[2], dst;
+        for (uint32_t k = 0; k < 2u; k++) { const float* v = b + 17u * (2u * i + k); r[k].weightSum = v[0]; r[k].count = (long long)v[1]; r[k].weight = v[2]; r[k].s = sample(v + 3); }
+        lm_combine2<A>(dst, r[0], r[1], t, c[i]);
+        float* o = out + 18u * i;
+        o[0] = dst.weightSum; o[1] = (float)dst.count; o[2] = dst.weight;
+        o[3] = dst.s.p.radiance.x; o[4] = dst.s.p.radiance.y; o[5] = dst.s.p.radiance.z; o[6] = dst.s.p.normal.x; o[7] = dst.s.p.normal.y; o[8] = dst.s.p.normal.z;
+        o[9] = dst.s.p.position.x; o[10] = dst.s.p.position.y; o[11] = dst.s.p.position.z; o[12] = dst.s.p.area;
+        o[13] = dst.s.contribution.x; o[14] = dst.s.contribution.y; o[15] = dst.s.contribution.z; o[16] = dst.s.pdf; o[17] = applies ? 1.f : 0.f;
+    }
+}
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
 KN(lm_k_test_restir)(int mode, uint32_t n, const float* __restrict__ a, const float* __restrict__ b, const uint32_t* __restrict__ c, uint32_t m, float* __restrict__ out)
 {
     const uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x;
+    if (mode >= 3) {
+        if (i >= n) return;
+        if (mode == 3 || mode == 4) lm_test_resample_combine<LmExact>(mode == 4, i, a, b, c, out);
+        else lm_test_resample_combine<LmFast>(mode == 6, i, a, b, c, out);
+        return;
+    }
     if (mode == 0) {
         if (i >= n) return;
         LmReservoir r; lm_res_fresh(r);

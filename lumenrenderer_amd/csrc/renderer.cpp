@@ -714,11 +714,17 @@ int lumen_mi_test_camera(const float right[3], const float up[3], const float fo
 int lumen_mi_test_restir(lumen_mi_renderer* r, int mode, uint32_t n, const float* a, const float* b, const uint32_t* c, uint32_t m, float* out)
 {
     if (!r || !r->initialised) return fail(LUMEN_MI_ERR_STATE, "not initialised");
-    if (mode < 0 || mode > 2 || !a || !out || n == 0 || (mode == 0 && (!b || !c)) || (mode == 1 && (!b || m == 0))) return fail(LUMEN_MI_ERR_INVALID, "bad argument");
+    const bool resample = mode == 3 || mode == 5, combine = mode == 4 || mode == 6;
+    if (mode < 0 || mode > 6 || !a || !out || n == 0 || (mode == 0 && (!b || !c)) || (mode == 1 && (!b || m == 0)) || (resample && !b) || (combine && (!b || !c)))
+        return fail(LUMEN_MI_ERR_INVALID, "bad argument");
+    ApiLock lk(r);                                  // r->stream is the render thread's stream too
     LM_HIP(hipSetDevice(r->device));
-    const size_t na = mode == 0 ? (size_t)8 * n : n, nb = mode == 0 ? (size_t)8 * n : mode == 1 ? m : 0, nc = mode == 0 ? (size_t)8 * n : 0;
-    const size_t nout = mode == 0 ? (size_t)33 * n : mode == 1 ? (size_t)2 * m : n;
+    const size_t na = mode == 0 ? (size_t)8 * n : (resample || combine) ? (size_t)35 * n : n;
+    const size_t nb = mode == 0 ? (size_t)8 * n : mode == 1 ? m : resample ? (size_t)14 * n : combine ? (size_t)34 * n : 0;
+    const size_t nc = mode == 0 ? (size_t)8 * n : combine ? n : 0;
+    const size_t nout = mode == 0 ? (size_t)33 * n : mode == 1 ? (size_t)2 * m : resample ? (size_t)5 * n : combine ? (size_t)18 * n : n;
     DevBuf<float> da, db, dout; DevBuf<uint32_t> dc;
+    struct Release { DevBuf<float>&a, &b, &o; DevBuf<uint32_t>& c; ~Release() { a.release(); b.release(); o.release(); c.release(); } } guard{da, db, dout, dc};   // on every exit path
     std::vector<float> va(a, a + na), vb; std::vector<uint32_t> vc;
     if (nb) vb.assign(b, b + nb);
     if (nc) vc.assign(c, c + nc);
@@ -726,7 +732,6 @@ int lumen_mi_test_restir(lumen_mi_renderer* r, int mode, uint32_t n, const float
     r->K->test_restir(r->stream, mode, n, da.p, db.p, dc.p, m, dout.p);
     LM_HIP(hipStreamSynchronize(r->stream));
     LM_HIP(hipMemcpy(out, dout.p, nout * 4, hipMemcpyDeviceToHost));
-    da.release(); db.release(); dc.release(); dout.release();
     return 0;
 }
 int lumen_mi_test_math(lumen_mi_renderer* r, uint32_t n, int fn, const float* x, const float* y, float* out)

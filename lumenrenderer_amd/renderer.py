@@ -298,14 +298,17 @@ class LumenRendererMI:
         return out
 
     def TestRestir(self, mode, a, b=None, c=None):
-        """Known-answer hook (lumen_mi_test_restir): 0 reservoir sequences (a, b, c: n x 8), 1 CDF queries (a: prefix sums, b: values), 2 sRGB8."""
-        a = _f32(a); n = a.shape[0] if mode == 0 else a.size
+        """Known-answer hook (lumen_mi_test_restir): 0 reservoir sequences (a, b, c: n x 8), 1 CDF queries (a: prefix sums, b: values), 2 sRGB8,
+        3 / 5 Resample exact / fast (a: n x 35 surfaces, b: n x 14 samples -> n x 5), 4 / 6 CombineBiased of two reservoirs exact / fast
+        (a: n x 35, b: n x 2 x 17, c: n seeds -> n x 18)."""
+        a = _f32(a); n = a.shape[0] if mode in (0, 3, 4, 5, 6) else a.size
         b = None if b is None else _f32(b); m = 0 if (b is None or mode != 1) else b.size
         c = None if c is None else np.ascontiguousarray(c, np.uint32)
-        out = np.zeros(33 * n if mode == 0 else 2 * m if mode == 1 else n, np.float32)
+        nout = {0: 33 * n, 1: 2 * m, 2: n, 3: 5 * n, 5: 5 * n, 4: 18 * n, 6: 18 * n}[mode]
+        out = np.zeros(nout, np.float32)
         check(self.lib, self.lib.lumen_mi_test_restir(self.h, mode, n, _fp(a), None if b is None else _fp(b),
                                                       None if c is None else c.ctypes.data_as(C.POINTER(C.c_uint32)), m, _fp(out)))
-        return out
+        return out.reshape(n, -1) if mode >= 3 else out
 
     def TestMath(self, fn, x, y=None):
         x = _f32(x).ravel(); y = x if y is None else _f32(y).ravel(); out = np.zeros_like(x)

@@ -751,6 +751,31 @@ static void combine_biased(Reservoir& dst, int count, const Reservoir* rs, const
     res_update_weight(out);
     dst = out;
 }
+// CombineUnbiased — ReSTIRKernels.cu:1123-1198.  Dead on the path (ReSTIRSettings::enableBiased is constexpr true, ReSTIRData.h:59; the only
+// call sites are the else-branches at :865-871, :1110-1117); restated and pinned with the others so that the whole merge family is.
+// Quirks kept: the running count is an `int` (:1135), and the correction counts a neighbour when the held sample re-scores > 0 THERE.
+static void combine_unbiased(Reservoir& dst, const Surface& outPx, int count, const Reservoir* rs, const Surface* pxs, uint32_t seed)
+{
+    Reservoir out = res_fresh();
+    int sum = 0;
+    for (int i = 0; i < count; i++) {
+        LightSample rsd;
+        resample(rs[i].sample, outPx, rsd);
+        const float w = (float)rs[i].sampleCount * rs[i].weight * rsd.solidAnglePdf;
+        res_update(out, rsd, w, seed);
+        sum += (int)rs[i].sampleCount;
+    }
+    out.sampleCount = sum;
+    int correction = 0;
+    for (int i = 0; i < count; i++) {
+        LightSample rsd;
+        resample(out.sample, pxs[i], rsd);
+        if (rsd.solidAnglePdf > 0) correction += (int)rs[i].sampleCount;
+    }
+    const float m = 1.f / fmaxf((float)correction, 1.1920928955078125e-7f);
+    out.weight = (1.f / fmaxf(out.sample.solidAnglePdf, 1.1920928955078125e-7f)) * (m * out.weightSum);
+    dst = out;
+}
 // ShadeReservoirs — ReSTIRKernels.cu:618-665 (fp32 accumulate, D1)
 static inline void shade_reservoir(orc_ctx* c, const Reservoir& r, uint32_t outIdx)
 {
@@ -1306,6 +1331,67 @@ void orc_get_stats(orc_ctx* c, uint64_t* out, uint32_t n) { for (uint32_t i = 0;
 uint32_t orc_wang_hash(uint32_t s) { return wang_hash(s); }
 void orc_random_floats(uint32_t seed, uint32_t n, float* out, uint32_t* states) { uint32_t s = seed; for (uint32_t i = 0; i < n; i++) { out[i] = random_float(s); if (states) states[i] = s; } }
 float orc_halton(uint32_t index, uint32_t base) { return halton(index, base); }
+// rows of tests/golden/ref_kat.npz (generator oracle/ref_kat/gen_kat4.cpp): surface(35) = position normal tangent incoming mat23;
+// sample(14) = radiance normal position area contribution solidAnglePdf; reservoir(17) = weightSum sampleCount weight sample(14)
+static Surface surface_from35(const float* v)
+{
+    Surface s; memset(&s, 0, sizeof s);
+    s.position = f3{v[0], v[1], v[2]}; s.normal = f3{v[3], v[4], v[5]}; s.tangent = f3{v[6], v[7], v[8]}; s.incoming = f3{v[9], v[10], v[11]};
+    s.geomNormal = s.normal; s.transport = mk3(1.f);
+    s.mat = material_from23(v + 12);
+    return s;
+}
+static LightSample sample_from14(const float* v)
+{
+    LightSample l;
+    l.radiance = f3{v[0], v[1], v[2]}; l.normal = f3{v[3], v[4], v[5]}; l.position = f3{v[6], v[7], v[8]}; l.area = v[9];
+    l.contribution = f3{v[10], v[11], v[12]}; l.solidAnglePdf = v[13];
+    return l;
+}
+static Reservoir reservoir_from17(const float* v)
+{
+    Reservoir r; r.weightSum = v[0]; r.sampleCount = (long long)v[1]; r.weight = v[2]; r.sample = sample_from14(v + 3);
+    return r;
+}
+static void reservoir_to17(const Reservoir& r, float* o)
+{
+    o[0] = r.weightSum; o[1] = (float)r.sampleCount; o[2] = r.weight;
+    const LightSample& l = r.sample;
+    o[3] = l.radiance.x; o[4] = l.radiance.y; o[5] = l.radiance.z; o[6] = l.normal.x; o[7] = l.normal.y; o[8] = l.normal.z;
+    o[9] = l.position.x; o[10] = l.position.y; o[11] = l.position.z; o[12] = l.area;
+    o[13] = l.contribution.x; o[14] = l.contribution.y; o[15] = l.contribution.z; o[16] = l.solidAnglePdf;
+}
+void orc_resample(uint32_t n, const float* surf35, const float* sample14, float* out4)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        const Surface s = surface_from35(surf35 + 35 * i);
+        LightSample out;
+        resample(sample_from14(sample14 + 14 * i), s, out);
+        out4[4*i] = out.contribution.x; out4[4*i+1] = out.contribution.y; out4[4*i+2] = out.contribution.z; out4[4*i+3] = out.solidAnglePdf;
+    }
+}
+void orc_combine_biased(uint32_t n, uint32_t count, const float* surf35, const uint32_t* seeds, const float* res17, float* out17)
+{
+    std::vector<Reservoir> rs(count);
+    for (uint32_t i = 0; i < n; i++) {
+        const Surface s = surface_from35(surf35 + 35 * i);
+        for (uint32_t k = 0; k < count; k++) rs[k] = reservoir_from17(res17 + 17 * ((size_t)i * count + k));
+        Reservoir out;
+        combine_biased(out, (int)count, rs.data(), s, seeds[i]);
+        reservoir_to17(out, out17 + 17 * i);
+    }
+}
+void orc_combine_unbiased(uint32_t n, uint32_t count, const float* outsurf35, const uint32_t* seeds, const float* res17, const float* surfs35, float* out17)
+{
+    std::vector<Reservoir> rs(count); std::vector<Surface> ss(count);
+    for (uint32_t i = 0; i < n; i++) {
+        const Surface s = surface_from35(outsurf35 + 35 * i);
+        for (uint32_t k = 0; k < count; k++) { rs[k] = reservoir_from17(res17 + 17 * ((size_t)i * count + k)); ss[k] = surface_from35(surfs35 + 35 * ((size_t)i * count + k)); }
+        Reservoir out;
+        combine_unbiased(out, s, (int)count, rs.data(), ss.data(), seeds[i]);
+        reservoir_to17(out, out17 + 17 * i);
+    }
+}
 void orc_pack_material(const float mat[23], uint32_t params_out[3], float g[11])
 {
     const Material sd = material_from23(mat);

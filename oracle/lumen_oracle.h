@@ -80,6 +80,12 @@ void  orc_det_math(uint32_t n, int fn, const float* x, const float* y, float* ou
 /* Reservoir::Update x k on a fresh reservoir (sample i carries id i + 1), then UpdateWeight, then Reset (ReSTIRData.h:115-178) */
 void  orc_reservoir_sequence(uint32_t k, const float* w, const float* pdf, const uint32_t* seeds, float* weightSum, int64_t* count, int32_t* held, int32_t* took,
                              float* weight, float* afterReset3);
+/* Resample / CombineBiased / CombineUnbiased (ReSTIRKernels.cu:1259-1325, :1200-1257, :1123-1198) on the row layout of
+ * oracle/ref_kat/gen_kat4.cpp: surface(35) = position normal tangent incoming mat23; sample(14) = radiance normal position area
+ * contribution solidAnglePdf; reservoir(17) = weightSum sampleCount weight sample(14) */
+void  orc_resample(uint32_t n, const float* surf35, const float* sample14, float* out4);
+void  orc_combine_biased(uint32_t n, uint32_t count, const float* surf35, const uint32_t* seeds, const float* res17, float* out17);
+void  orc_combine_unbiased(uint32_t n, uint32_t count, const float* outsurf35, const uint32_t* seeds, const float* res17, const float* surfs35, float* out17);
 /* CDF::Get / BinarySearch on a given prefix-sum array (ReSTIRData.h:230-306) */
 void  orc_cdf_get(uint32_t n, const float* data, uint32_t m, const float* values, uint32_t* index, float* pdf);
 /* make_color: sRGB8 of a linear colour (vendor/Include/Cuda/cuda/helpers.h:35-66) */

@@ -1,0 +1,184 @@
+// gen_kat4.cpp — known-answer generator, fourth translation unit: the plain __device__ functions of the reference's ReSTIR / primary-ray
+// kernels that contain no __global__, surf2D, tex2D or atomics, compiled from the reference's OWN TEXT:
+//   Resample          CUDAKernels/ReSTIRKernels.cu:1259-1325     the target function of every ReSTIR pass
+//   CombineBiased     CUDAKernels/ReSTIRKernels.cu:1200-1257     temporal / spatial / final merge
+//   CombineUnbiased   CUDAKernels/ReSTIRKernels.cu:1123-1198     (dead under ReSTIRSettings::enableBiased = true, ReSTIRData.h:59; pinned all the same)
+//   HaltonSequence    CUDAKernels/WaveFrontKernels/GPUGeneratePrimRay.cu:8-26
+// make_kat.py slices exactly those line ranges out of /root/reference into /tmp/lumen_slice_restir.inc and /tmp/lumen_slice_halton.inc
+// (never into the repository) and this file #includes them behind the same include order the reference's .cu uses:
+// RenderingUtility.h BEFORE disney.cuh, so `EPSILON` inside the kernel bodies is bsdf_math.cuh's macro 1e-4, and
+// ReSTIRData.h / SurfaceData.h while __CUDACC__ is still undefined (they pull optix.h).
+// Container-only; contains no reference source text.  Rows (floats as %.9g, integers as decimal; u = bits of a float):
+//   rsmp  surface(35) sample(14)                                   | contribution(3) solidAnglePdf
+//   cmbb2 / cmbb6  surface(35) count seed  count x reservoir(17)            | weightSum sampleCount weight sample(14)
+//   cmbu2 / cmbu6  out-surface(35) count seed  count x (reservoir(17) surface(35)) | weightSum sampleCount weight sample(14)
+//   halt  index base | value bits
+// surface(35) = position(3) normal(3) tangent(3) incoming(3) mat23(23);  sample(14) = radiance(3) normal(3) position(3) area contribution(3) solidAnglePdf;
+// reservoir(17) = weightSum sampleCount weight sample(14)
+#include <cmath>
+#include <algorithm>
+#include <cstdio>
+#include <cstdint>
+#include <cstring>
+#include <random>
+using std::min; using std::max; using std::abs; using std::isnan; using std::isinf;
+#include <cuda_runtime.h>
+#include <sutil/vec_math.h>
+#include "Shaders/CppCommon/MaterialStructs.h"
+#include "Shaders/CppCommon/ReSTIRData.h"
+#include "Shaders/CppCommon/WaveFrontDataStructs/SurfaceData.h"
+#include "Shaders/CppCommon/RenderingUtility.h"
+static inline float saturate(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
+#define lerp lerp_ref
+#define __CUDACC__ 1
+#include "CUDAKernels/disney.cuh"
+
+// signatures as ReSTIRKernels.cuh:266-296 declares them (the .cu defines CombineUnbiased before Resample)
+__device__ __inline__ void CombineUnbiased(Reservoir*, const WaveFront::SurfaceData*, int, Reservoir*, const WaveFront::SurfaceData*, const std::uint32_t);
+__device__ __inline__ void CombineBiased(Reservoir*, int, Reservoir*, const WaveFront::SurfaceData*, const std::uint32_t);
+__device__ __inline__ void Resample(LightSample*, const WaveFront::SurfaceData*, LightSample*);
+#include "/tmp/lumen_slice_restir.inc"
+#include "/tmp/lumen_slice_halton.inc"
+
+static std::mt19937 rng(20261004u);
+static float U() { return std::uniform_real_distribution<float>(0.f, 1.f)(rng); }
+static uint32_t bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static float3 unitvec() {
+    for (;;) { float3 v = make_float3(U()*2-1, U()*2-1, U()*2-1); float l = length(v); if (l > 0.1f && l <= 1.f) return v / l; }
+}
+struct MatIn { float c[4], tint[3], lum, trn[3], ior, p[11]; };
+// p: metallic subsurface specular roughness spectint anisotropic sheen sheentint clearcoat clearcoatgloss transmission
+static MaterialData build(const MatIn& in) {
+    MaterialData m(0.f);
+    m.SetColor(make_float4(in.c[0], in.c[1], in.c[2], in.c[3]));
+    m.SetTint(make_float3(in.tint[0], in.tint[1], in.tint[2]));
+    m.SetLuminance(in.lum);
+    m.SetTransmittance(make_float3(in.trn[0], in.trn[1], in.trn[2]));
+    m.SetRefractiveIndex(in.ior);
+    m.SetMetallic(in.p[0]); m.SetSubSurface(in.p[1]); m.SetSpecular(in.p[2]); m.SetRoughness(in.p[3]);
+    m.SetSpecTint(in.p[4]); m.SetAnisotropic(in.p[5]); m.SetSheen(in.p[6]); m.SetSheenTint(in.p[7]);
+    m.SetClearCoat(in.p[8]); m.SetClearCoatGloss(in.p[9]); m.SetTransmission(in.p[10]);
+    return m;
+}
+static MatIn randmat(int kind) {
+    MatIn in{};
+    for (int i = 0; i < 3; i++) { in.c[i] = U(); in.tint[i] = U(); in.trn[i] = U() * 2.f; }
+    in.c[3] = 1.f; in.lum = 0.25f + U();
+    in.ior = (kind & 1) ? 1.f / (1.1f + U()) : 1.f;
+    for (int i = 0; i < 11; i++) in.p[i] = 0.f;
+    in.p[3] = 0.02f + 0.98f * U();
+    switch (kind % 6) {
+    case 0: break;                                                                          // plain diffuse
+    case 1: in.p[0] = U(); in.p[2] = U(); in.p[4] = U(); break;                             // metal / specular mix
+    case 2: in.p[0] = U(); in.p[2] = U(); in.p[6] = U(); in.p[7] = U(); in.p[1] = U(); break; // + sheen + subsurface
+    case 3: in.p[0] = U(); in.p[2] = U(); in.p[8] = U(); in.p[9] = U(); break;              // + clear coat
+    case 4: in.p[0] = U()*0.5f; in.p[2] = U(); in.p[5] = U(); in.p[10] = 0.2f + 0.8f*U(); in.ior = 1.f/(1.1f+U()); break; // transmission + anisotropy
+    case 5: for (int i = 0; i < 11; i++) if (i != 3) in.p[i] = U(); in.ior = 1.f/(1.1f+U()); break;
+    }
+    return in;
+}
+struct Surf { WaveFront::SurfaceData sd; MatIn in; };
+// a depth-0 surface as ExtractSurfaceData leaves it: unit shading normal, a tangent, the incoming direction pointing INTO the surface
+static Surf randsurf(int kind)
+{
+    Surf s; memset(&s.sd, 0, sizeof s.sd);
+    s.in = randmat(kind);
+    s.sd.m_MaterialData = build(s.in);
+    s.sd.m_Position = make_float3(U()*8-4, U()*8-4, U()*8-4);
+    s.sd.m_Normal = unitvec();
+    float3 t = unitvec(); t = t - s.sd.m_Normal * dot(t, s.sd.m_Normal);
+    s.sd.m_Tangent = (kind % 4 == 3) ? unitvec() : normalize(t);                              // also tangents that are not orthogonal (normal-mapped)
+    float3 in = unitvec(); if (dot(in, s.sd.m_Normal) > 0.f && (kind % 9)) in = in * -1.f;     // mostly arriving from the front side
+    if (kind % 13 == 12) in = normalize(in - s.sd.m_Normal * (dot(in, s.sd.m_Normal) * 0.999f)); // grazing view
+    s.sd.m_IncomingRayDirection = in;
+    s.sd.m_IntersectionT = 1.f + U();
+    s.sd.m_TransportFactor = make_float3(1.f, 1.f, 1.f);
+    return s;
+}
+static void printsurf(const Surf& s)
+{
+    const auto& d = s.sd;
+    printf(" %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g", d.m_Position.x, d.m_Position.y, d.m_Position.z, d.m_Normal.x, d.m_Normal.y, d.m_Normal.z,
+           d.m_Tangent.x, d.m_Tangent.y, d.m_Tangent.z, d.m_IncomingRayDirection.x, d.m_IncomingRayDirection.y, d.m_IncomingRayDirection.z);
+    for (float v : s.in.c) printf(" %.9g", v); for (float v : s.in.tint) printf(" %.9g", v); printf(" %.9g", s.in.lum);
+    for (float v : s.in.trn) printf(" %.9g", v); printf(" %.9g", s.in.ior); for (float v : s.in.p) printf(" %.9g", v);
+}
+// a light sample near a surface: kinds reach every early-out of Resample
+static LightSample randsample(const WaveFront::SurfaceData& at, int kind)
+{
+    LightSample l;
+    const float3 n = at.m_Normal;
+    float3 dir = unitvec();
+    if (dot(dir, n) < 0.f && kind % 8 != 1) dir = dir * -1.f;               // kind 1: may be below the horizon (cosIn <= 0)
+    float dist = 0.05f + U() * 6.f;
+    if (kind % 8 == 2) dist = 0.002f + U() * 0.016f;                        // around lDistance <= 0.01
+    l.position = at.m_Position + dir * dist;
+    l.normal = unitvec();
+    if (dot(l.normal, dir) > 0.f && kind % 8 != 3) l.normal = l.normal * -1.f; // kind 3: may face away (cosOut <= 0)
+    if (kind % 8 == 4) l.normal = normalize(l.normal - dir * (dot(l.normal, dir) * 0.9999f));   // grazing emitter
+    l.radiance = make_float3(U() * 50.f, U() * 50.f, U() * 50.f);
+    if (kind % 8 == 5) l.radiance = make_float3(0.f, 0.f, 0.f);             // black light: pdf 0 through the product
+    l.area = 0.001f + U() * 4.f;
+    l.unshadowedPathContribution = make_float3(U(), U(), U());              // stale values: survive the first early-out (out = in)
+    l.solidAnglePdf = U();
+    return l;
+}
+static void printsample(const LightSample& l)
+{
+    printf(" %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g", l.radiance.x, l.radiance.y, l.radiance.z, l.normal.x, l.normal.y, l.normal.z,
+           l.position.x, l.position.y, l.position.z, l.area, l.unshadowedPathContribution.x, l.unshadowedPathContribution.y, l.unshadowedPathContribution.z, l.solidAnglePdf);
+}
+static Reservoir randres(const WaveFront::SurfaceData& at, int kind)
+{
+    Reservoir r;
+    r.sample = randsample(at, kind);
+    r.sampleCount = kind % 5 == 0 ? 0 : 1 + (long long)(rng() % (kind % 3 ? 640u : 32u));       // the 20x history clamp gives counts up to 640
+    r.weight = kind % 7 == 0 ? 0.f : U() * (kind % 2 ? 10.f : 0.1f);                              // occluded reservoirs carry weight 0
+    r.weightSum = U() * 100.f;
+    return r;
+}
+static void printres(const Reservoir& r) { printf(" %.9g %lld %.9g", r.weightSum, r.sampleCount, r.weight); printsample(r.sample); }
+
+int main()
+{
+    for (int i = 0; i < 3000; i++) {
+        const Surf s = randsurf(i);
+        LightSample in = randsample(s.sd, i / 3), out;
+        if (i % 97 == 96) in.position = s.sd.m_Position;                    // zero distance: 0 / 0 in the normalisation, NaN cosines fail every comparison
+        Resample(&in, &s.sd, &out);
+        printf("rsmp"); printsurf(s); printsample(in);
+        printf(" %.9g %.9g %.9g %.9g\n", out.unshadowedPathContribution.x, out.unshadowedPathContribution.y, out.unshadowedPathContribution.z, out.solidAnglePdf);
+    }
+    for (int i = 0; i < 1200; i++) {
+        const Surf s = randsurf(i);
+        const int count = i % 3 == 2 ? 6 : 2;
+        Reservoir rs[6], out;
+        for (int k = 0; k < count; k++) rs[k] = randres(s.sd, i + 3 * k);
+        const uint32_t seed = rng();
+        CombineBiased(&out, count, rs, &s.sd, seed);
+        printf("cmbb%d", count); printsurf(s); printf(" %d %u", count, seed);
+        for (int k = 0; k < count; k++) printres(rs[k]);
+        printres(out); printf("\n");
+    }
+    for (int i = 0; i < 600; i++) {
+        const Surf s = randsurf(i);
+        const int count = i % 3 == 2 ? 6 : 2;
+        Reservoir rs[6], out; Surf ss[6]; WaveFront::SurfaceData sds[6];
+        for (int k = 0; k < count; k++) {
+            ss[k] = randsurf(i + k);
+            if (k == 0 || i % 2) { ss[k].sd.m_Position = s.sd.m_Position + unitvec() * (0.3f * U()); }      // neighbours: nearby points
+            sds[k] = ss[k].sd;
+            rs[k] = randres(s.sd, i + 3 * k);
+        }
+        const uint32_t seed = rng();
+        CombineUnbiased(&out, &s.sd, count, rs, sds, seed);
+        printf("cmbu%d", count); printsurf(s); printf(" %d %u", count, seed);
+        for (int k = 0; k < count; k++) { printres(rs[k]); printsurf(ss[k]); }
+        printres(out); printf("\n");
+    }
+    for (unsigned i = 0; i < 10000; i++) {
+        const unsigned idx = i < 9000 ? i : (i < 9990 ? rng() : 0xffffffffu - (i - 9990));    // 0xffffffff wraps to 0 after the ++index
+        for (unsigned base : {2u, 3u}) { float r; HaltonSequence(idx, base, &r); printf("halt %u %u %u\n", idx, base, bits(r)); }
+    }
+    return 0;
+}

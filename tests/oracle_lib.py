@@ -66,6 +66,9 @@ def lib():
             ("orc_motion_matrix", [fp, C.c_float, C.c_float, fp], None),
             ("orc_reservoir_sequence", [C.c_uint32, fp, fp, u32p, fp, C.POINTER(C.c_int64), i32p, i32p, fp, fp], None),
             ("orc_cdf_get", [C.c_uint32, fp, C.c_uint32, fp, u32p, fp], None),
+            ("orc_resample", [C.c_uint32, fp, fp, fp], None),
+            ("orc_combine_biased", [C.c_uint32, C.c_uint32, fp, u32p, fp, fp], None),
+            ("orc_combine_unbiased", [C.c_uint32, C.c_uint32, fp, u32p, fp, fp, fp], None),
             ("orc_make_color", [C.c_uint32, fp, u8p], None),
             ("orc_trace_closest", [C.c_void_p, C.c_uint32, fp, fp, C.c_float, C.c_float, u32p, fp, C.c_int], None),
             ("orc_trace_any", [C.c_void_p, C.c_uint32, fp, fp, C.c_float, fp, u8p, C.c_int], None),

@@ -103,6 +103,88 @@ def test_device_reservoir_cdf_and_output_quantisation_match_reference_header_vec
     assert np.array_equal(q, oq[:, :3].astype(np.int32))
 
 
+def _rel_floor(got, ref, floor=1e-3):
+    got = got.astype(np.float64)
+    both_nan = np.isnan(got) & np.isnan(ref)
+    return np.nan_to_num(np.where(both_nan, 0.0, np.abs(got - ref) / np.maximum(np.abs(ref), floor)), nan=1.0)
+
+
+def test_device_resample_and_combine_match_the_reference_functions(bare):
+    """Round 3: the DEVICE functions lm_resample / lm_combine2 (lm_restir.h) against rows produced by the reference's own text of Resample
+    and CombineBiased (ReSTIRKernels.cu:1259-1325, :1200-1257; oracle/ref_kat/gen_kat4.cpp), in both arithmetic policies.
+    Exact policy: bit-identical to the oracle, and to the reference up to the libm-vs-polynomial difference inside EvaluateBSDF.
+    Fast policy (what bench.py's headline runs), on the surfaces the contracted evaluation covers: same early-outs, same held sample."""
+    from test_oracle_kat import resample_rows
+    L = orc_lib()
+    surf, smp, ref = resample_rows(); n = surf.shape[0]
+    want = np.zeros((n, 4), np.float32); L.orc_resample(n, fptr(surf), fptr(smp), fptr(want))
+    got = bare.TestRestir(3, surf, smp)
+    assert np.all(got[:, 4] == 1)
+    same = (got[:, :4].copy().view(np.uint32) == want.view(np.uint32)) | (np.isnan(got[:, :4]) & np.isnan(want))
+    assert same.all(), np.argwhere(~same)[:5]
+    assert np.array_equal(got[:, 3] == 0, ref[:, 3] == 0)
+    err = _rel_floor(got[:, :4], ref).max()
+    assert err < 2e-5, err
+    fast = bare.TestRestir(5, surf, smp)
+    ok = fast[:, 4] == 1
+    assert 0.3 < ok.mean() < 0.9                                  # the contracted evaluation covers the opaque isotropic stack only
+    # an early-out decided by a comparison within rounding of its threshold may differ: bound how many and how large
+    flip = ok & ((fast[:, 3] == 0) != (ref[:, 3] == 0))
+    assert flip.sum() <= 3 and np.all(np.maximum(fast[flip, 3], ref[flip, 3]) < 1e-3), (flip.sum(), ref[flip, 3])
+    live = ok & ~flip & (ref[:, 3] != 0)
+    ferr = _rel_floor(fast[live, :4], ref[live], floor=1e-4)
+    print(f"fast Resample vs reference: max rel {ferr.max():.3e} over {live.sum()} rows; exact vs reference {err:.3e}")
+    assert ferr.max() < 1e-4, ferr.max()
+    stale = ok & ~flip & (ref[:, 3] == 0) & np.all(ref[:, :3].astype(np.float32) == smp[:, 10:13], axis=1)
+    assert np.array_equal(fast[stale, :3], smp[stale, 10:13])     # the geometric early-out keeps the stale contribution
+
+    g = KAT["cmbb2"]; n = g.shape[0]
+    surf = f32(g[:, :35]); seeds = np.ascontiguousarray(g[:, 36], dtype=np.uint32); res = f32(g[:, 37:71]); ref = g[:, 71:]
+    want = np.zeros((n, 17), np.float32); L.orc_combine_biased(n, 2, fptr(surf), seeds.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_uint32)), fptr(res), fptr(want))
+    got = bare.TestRestir(4, surf, res, seeds)
+    same = (got[:, :17].copy().view(np.uint32) == want.view(np.uint32)) | (np.isnan(got[:, :17]) & np.isnan(want))
+    assert same.all(), np.argwhere(~same)[:5]
+    assert np.array_equal(got[:, 9:13], ref[:, 9:13].astype(np.float32))          # the held sample: same choice as the reference
+    assert _rel_floor(got[:, :17], ref).max() < 5e-5
+    fast = bare.TestRestir(6, surf, res, seeds)
+    ok = fast[:, 17] == 1
+    held_same = np.all(fast[:, 9:13] == ref[:, 9:13].astype(np.float32), axis=1)
+    assert (ok & ~held_same).sum() <= 2, np.flatnonzero(ok & ~held_same)        # rnd <= w / weightSum decided within an ulp
+    live = ok & held_same
+    ferr = _rel_floor(fast[live, :17], ref[live], floor=1e-4)
+    print(f"fast CombineBiased vs reference: max rel {ferr.max():.3e} over {live.sum()} rows")
+    assert ferr.max() < 1e-4, ferr.max()
+
+
+def test_device_contracted_bsdf_matches_the_reference_evaluate_bsdf(bare):
+    """The contracted evaluation of the fast policy (lm_quick_setup + lm_quick_eval, lm_bsdf.h) against the reference's EvaluateBSDF
+    (disney.cuh:320-405) on the reference-header rows of ref_kat.npz it covers, plus the depth-0 surfaces of the Resample rows
+    (sheen, subsurface, grazing views) with the light direction of each row."""
+    e = KAT["eval"]
+    mat, N, T, wo, wi = f32(e[:, :23]), f32(e[:, 26:29]), f32(e[:, 29:32]), f32(e[:, 32:35]), f32(e[:, 35:38])
+    ref = e[:, 38:42]
+    g = KAT["rsmp"]                                                # surface(35) sample(14): wo = -incoming, wi = towards the light point
+    d = g[:, 35 + 6:35 + 9] - g[:, 0:3]; dist = np.linalg.norm(d, axis=1); keep = dist > 0.05
+    mat2, N2, T2, wo2 = f32(g[keep, 12:35]), f32(g[keep, 3:6]), f32(g[keep, 6:9]), f32(-g[keep, 9:12])
+    wi2 = f32(d[keep] / dist[keep, None]); wi2 /= np.linalg.norm(wi2, axis=1, keepdims=True).astype(np.float32)
+    exact2 = bare.TestBsdf(0, mat2, N2, T2, wo2, wi2)[:, :4]      # = the oracle = the reference to 2e-7 (test above)
+    total = 0
+    for name, (m_, n_, t_, wo_, wi_, ref_) in {"eval rows": (mat, N, T, wo, wi, ref), "resample surfaces": (mat2, N2, T2, wo2, wi2, exact2.astype(np.float64))}.items():
+        q = bare.TestBsdf(2, m_, n_, t_, wo_, wi_)
+        ok = q[:, 4] == 1
+        # the contracted form is specified for a view direction on the lit side (a depth-0 surface seen by the camera)
+        front = ok & (np.einsum("ij,ij->i", n_, wo_) > 1e-3) & np.isfinite(ref_).all(axis=1)
+        err = _rel_floor(q[front, :4], ref_[front], floor=1e-4)
+        print(f"contracted EvaluateBSDF vs reference, {name}: {front.sum()} rows, max rel {err.max():.3e}, p99 {np.quantile(err.max(axis=1), 0.99):.3e}")
+        assert front.sum() > 150 and err.max() < 1e-4, (name, err.max(), int(err.max(axis=1).argmax()))
+        total += front.sum()
+        sheen = front & (m_[:, 18] > 0); sub = front & (m_[:, 13] > 0)
+        if name == "resample surfaces":
+            graz = front & (np.einsum("ij,ij->i", n_, wo_) < 0.05)
+            assert sheen.sum() > 50 and sub.sum() > 50 and graz.sum() > 5, (sheen.sum(), sub.sum(), graz.sum())
+    assert total > 800
+
+
 def _moller_trumbore_f64(tris, org, dr, tmin, tmax, chunk=512):
     """Brute-force closest hit in float64 with the textbook Moeller-Trumbore test — shares no code and no formulation with the
     product (Woop unit-triangle packets, fp32) or the oracle.  Returns per ray (nearest t, triangle, second-nearest t)."""

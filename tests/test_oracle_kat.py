@@ -215,3 +215,74 @@ def test_camera_vectors_and_motion_matrix_match_the_reference_camera_source():
         out = np.zeros(16, np.float32); L.orc_motion_matrix(fptr(f32(prev)), fov, a, fptr(out)); return out
     worst_uvw, worst_ndc = _check_camera(vectors, matrix)
     assert worst_uvw <= 2.5e-7 and worst_ndc <= 4e-5, (worst_uvw, worst_ndc)          # measured: 0 (bit-identical) and 1.8e-5
+
+
+# ---- round 3: the plain __device__ functions of the ReSTIR / primary-ray kernels, compiled from the reference's own text (gen_kat4.cpp) ----
+def _close(got, ref, tol):
+    """relative agreement with a floor: libm (reference host build) vs the fixed polynomial routines inside EvaluateBSDF"""
+    got = got.astype(np.float64)
+    both_nan = np.isnan(got) & np.isnan(ref)
+    err = np.where(both_nan, 0.0, np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3))
+    return np.nan_to_num(err, nan=1.0)
+
+
+def resample_rows():
+    g = GOLD["rsmp"]
+    return f32(g[:, :35]), f32(g[:, 35:49]), g[:, 49:53]
+
+
+def test_halton_matches_the_reference_function_bit_for_bit():
+    L = lib(); g = GOLD["halt"]
+    got = np.array([np.float32(L.orc_halton(int(i), int(b))) for i, b in g[:, :2]], np.float32)
+    assert np.array_equal(got.view(np.uint32), g[:, 2].astype(np.uint32))
+    assert set(g[:, 1].astype(int)) == {2, 3} and g[:, 0].max() == 0xffffffff          # incl. the index that wraps in `++index`
+
+
+def test_resample_matches_the_reference_function():
+    L = lib(); surf, smp, ref = resample_rows(); n = surf.shape[0]
+    out = np.zeros((n, 4), np.float32)
+    L.orc_resample(n, fptr(surf), fptr(smp), fptr(out))
+    # every early-out decides the same way: the rows whose pdf is exactly 0 are the same rows ...
+    assert np.array_equal(out[:, 3] == 0, ref[:, 3] == 0)
+    zero = ref[:, 3] == 0
+    assert 0.2 < zero.mean() < 0.5
+    # ... on the geometric early-out the stale contribution survives (reference: *a_Output = *a_Input), on the BSDF one it is zeroed
+    stale = zero & np.all(ref[:, :3].astype(np.float32) == smp[:, 10:13], axis=1)
+    assert stale.sum() > 100 and np.array_equal(out[stale, :3], smp[stale, 10:13])
+    zeroed = zero & ~stale
+    assert np.all(out[zeroed, :3] == 0) and np.all(ref[zeroed, :3] == 0)
+    err = _close(out, ref, 0).max(axis=1)
+    assert err.max() < 2e-5, (err.max(), int(err.argmax()))
+
+
+@pytest.mark.parametrize("count", [2, 6])
+def test_combine_biased_matches_the_reference_function(count):
+    L = lib(); g = GOLD[f"cmbb{count}"]; n = g.shape[0]
+    surf = f32(g[:, :35]); assert np.all(g[:, 35] == count)
+    seeds = np.ascontiguousarray(g[:, 36], dtype=np.uint32)
+    res = f32(g[:, 37:37 + 17 * count]); ref = g[:, 37 + 17 * count:]
+    out = np.zeros((n, 17), np.float32)
+    L.orc_combine_biased(n, count, fptr(surf), u32ptr(seeds), fptr(res), fptr(out))
+    assert np.array_equal(out[:, 1], ref[:, 1].astype(np.float32))                        # sample counts: exact
+    # which input sample is held (identified by its light position, copied verbatim by Resample): same choice in every row
+    assert np.array_equal(out[:, 9:13], ref[:, 9:13].astype(np.float32))
+    err = _close(out, ref, 0).max(axis=1)
+    assert err.max() < 5e-5, (err.max(), int(err.argmax()))
+    assert (ref[:, 2] == 0).sum() > (10 if count == 2 else 0) and (ref[:, 2] > 0).sum() > n // 3               # both the empty and the weighted outcome occur
+
+
+@pytest.mark.parametrize("count", [2, 6])
+def test_combine_unbiased_matches_the_reference_function(count):
+    L = lib(); g = GOLD[f"cmbu{count}"]; n = g.shape[0]
+    surf = f32(g[:, :35]); assert np.all(g[:, 35] == count)
+    seeds = np.ascontiguousarray(g[:, 36], dtype=np.uint32)
+    body = g[:, 37:37 + 52 * count].reshape(n, count, 52)
+    res = f32(body[:, :, :17]); surfs = f32(body[:, :, 17:]); ref = g[:, 37 + 52 * count:]
+    out = np.zeros((n, 17), np.float32)
+    L.orc_combine_unbiased(n, count, fptr(surf), u32ptr(seeds), fptr(res), fptr(surfs), fptr(out))
+    assert np.array_equal(out[:, 1], ref[:, 1].astype(np.float32))
+    assert np.array_equal(out[:, 9:13], ref[:, 9:13].astype(np.float32))
+    fin = np.isfinite(ref).all(axis=1)                                                   # correction 0 => weight = weightSum / epsilon^2 may overflow: same on both sides
+    assert np.array_equal(np.isfinite(out).all(axis=1), fin)
+    err = _close(out[fin], ref[fin], 0).max(axis=1)
+    assert err.max() < 5e-5, (err.max(), int(err.argmax()))

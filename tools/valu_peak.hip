@@ -1,0 +1,100 @@
+// valu_peak.hip — measures the fp32 VALU issue ceiling of the box every "VALU-bound" statement in DESIGN.md is divided by.
+// Independent v_fma_f32 chains (8 accumulators per lane, so a wave never waits on its own result), all CUs, 1 / 2 / 4 / 8 waves per SIMD;
+// variants: plain v_fma_f32, one v_rcp_f32 in eight instructions (quarter-rate transcendental), packed v_pk_fma_f32, and a dependent
+// chain (1 accumulator) for the issue latency of a single wave.
+// Build + run on the GPU box:  hipcc --offload-arch=gfx950 -O3 tools/valu_peak.hip -o /tmp/valu_peak && /tmp/valu_peak > profiles/r03_valu_peak.txt
+// Output: wave-instructions/s and lane-operations/s (64 lanes per wave instruction; an FMA counts as ONE lane-operation here, as
+// SQ_THREAD_CYCLES_VALU-derived figures in bench.py do), and the implied cycles per wave instruction per SIMD at the measured clock.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+constexpr int UNROLL = 64;          // instructions per loop body per accumulator group
+
+template <int MODE> __global__ void __launch_bounds__(256) k_valu(float* out, int iters, float seed)
+{
+    float a0 = seed + threadIdx.x, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+    const float m = 0.999f, c = 0.001f;
+    for (int it = 0; it < iters; it++) {
+        if constexpr (MODE == 0) {               // 8 independent fp32 FMA chains
+#pragma unroll
+            for (int u = 0; u < UNROLL / 8; u++)
+                asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                             "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+        } else if constexpr (MODE == 1) {        // one v_rcp_f32 in eight
+#pragma unroll
+            for (int u = 0; u < UNROLL / 8; u++)
+                asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                             "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_rcp_f32 %7, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+        } else if constexpr (MODE == 2) {        // packed: 4 independent v_pk_fma_f32 chains on register pairs
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}; const f2 mm = {m, m}, cc = {c, c};
+#pragma unroll
+            for (int u = 0; u < UNROLL / 4; u++)
+                asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n"
+                             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(mm), "v"(cc));
+            a0 = p0.x; a1 = p0.y; a2 = p1.x; a3 = p1.y; a4 = p2.x; a5 = p2.y; a6 = p3.x; a7 = p3.y;
+        } else if constexpr (MODE == 3) {        // ONE dependent chain: what a single wave can issue by itself
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a0) : "v"(m), "v"(c));
+        } else {                                 // all quarter-rate: independent v_rcp_f32
+#pragma unroll
+            for (int u = 0; u < UNROLL / 8; u++)
+                asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+
+template <int MODE> static double run(float* out, int blocks, int iters, int reps)
+{
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_valu<MODE>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.f);      // warm-up
+    CHECK(hipDeviceSynchronize());
+    std::vector<double> ms;
+    for (int r = 0; r < reps; r++) {
+        CHECK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k_valu<MODE>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.f);
+        CHECK(hipEventRecord(e1, 0));
+        CHECK(hipEventSynchronize(e1));
+        float t; CHECK(hipEventElapsedTime(&t, e0, e1)); ms.push_back(t);
+    }
+    std::sort(ms.begin(), ms.end());
+    return ms[ms.size() / 2];
+}
+
+int main()
+{
+    hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, 0));
+    const int cus = p.multiProcessorCount;
+    const double clockGHz = p.clockRate * 1e-6;
+    printf("# device %s, %d CUs, clockRate %.3f GHz (hipDeviceProp; the sustained clock under load may be lower)\n", p.gcnArchName, cus, clockGHz);
+    printf("# a block = 256 threads = 4 wavefronts = one per SIMD; grid = CUs x (waves per SIMD) blocks; median of 7 launches\n");
+    printf("# %-34s %5s %10s %14s %14s %12s\n", "variant", "w/SIMD", "ms", "Gwave-inst/s", "Tlane-ops/s", "cyc/inst/SIMD");
+    float* out; CHECK(hipMalloc(&out, (size_t)cus * 16 * 256 * 4));
+    const int iters = 4096;
+    const char* names[5] = {"v_fma_f32 x8 independent", "7 v_fma_f32 + 1 v_rcp_f32", "v_pk_fma_f32 x4 independent", "v_fma_f32 dependent chain", "v_rcp_f32 x8 independent"};
+    for (int mode = 0; mode < 5; mode++) {
+        for (int w : {1, 2, 4, 8}) {
+            const int blocks = cus * w;
+            double ms = 0;
+            switch (mode) { case 0: ms = run<0>(out, blocks, iters, 7); break; case 1: ms = run<1>(out, blocks, iters, 7); break;
+                            case 2: ms = run<2>(out, blocks, iters, 7); break; case 3: ms = run<3>(out, blocks, iters, 7); break; default: ms = run<4>(out, blocks, iters, 7); }
+            const double instPerWave = (double)iters * UNROLL;                  // wave instructions of the measured kind per wavefront (loop overhead: 3 scalar per 64)
+            const double waves = (double)blocks * 4;
+            const double winst = instPerWave * waves / (ms * 1e-3);
+            const double simds = cus * 4.0;
+            printf("  %-34s %5d %10.3f %14.1f %14.2f %12.2f\n", names[mode], w, ms, winst * 1e-9, winst * 64 * 1e-12 * (mode == 2 ? 2 : 1), clockGHz * 1e9 * simds / winst);
+        }
+    }
+    printf("# lane-ops: one per lane per instruction (an FMA = 1; packed = 2).  fp32 FLOP/s = 2 x that for FMA.\n");
+    CHECK(hipFree(out));
+    return 0;
+}
