@@ -24,10 +24,22 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
-# fp32 vector issue peak in lane-operations: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-ops/s.  The 157.3 TFLOPS spec line of the
-# guide is this x 2 (FMA) x 2 (packed v_pk_fma_f32); a kernel of unpacked, mostly non-FMA fp32 arithmetic is bounded by the lane-op rate.
-VALU_PEAK_TLANEOPS = 39.3216
-PMC_FILE = os.path.join("profiles", "r02_c2_pmc.json")      # tools/pmc_json.sh on the GPU box; replayed here, never measured by this run
+# fp32 vector issue peak in lane-operations (one per lane per VALU instruction, an FMA = 1): 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz =
+# 78.6 T lane-ops/s = 1 229 G wave instructions/s (a wave64 v_fma_f32 takes 2 cycles on a CDNA4 SIMD, MI355X_MICROARCH.md; 157.3 TFLOPS =
+# this x 2 for FMA).  Measured on the box with tools/valu_peak.hip -> profiles/r03_valu_peak.txt.  (Round 2 divided by 39.3: wrong by 2x.)
+VALU_PEAK_TLANEOPS = 78.6432
+PMC_FILE = os.path.join("profiles", "r03_c2_pmc.json")      # tools/pmc_json.sh on the GPU box; replayed here, never measured by this run
+
+
+def kernel_source_id():
+    """sha256 over the device sources: the PMC replay is only valid for the build it was measured on (tools/pmc_json.sh stores this id)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "lumenrenderer_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 WORKLOADS = {
     # name: (scene factory kwargs, width, height, depth, spp)
@@ -76,12 +88,44 @@ def algorithmic_bytes_traceframe(c, depth, npix, nodes_all, tris_all, blend=True
 
 def load_pmc():
     """Per-kernel PMC figures (separate rocprofv3 --pmc passes of tools/pmc_json.sh, corrected as MI355X_MICROARCH.md prescribes), taken
-    on the GPU box by the builder and committed under profiles/: a REPLAY of that measurement, not a measurement of this run."""
+    on the GPU box by the builder and committed under profiles/: a REPLAY of that measurement, not a measurement of this run — and only
+    of the SAME device sources (the file carries kernel_source_id()); a stale file is refused and the PMC-derived fields are null."""
     try:
         with open(os.path.join(ROOT, PMC_FILE)) as f:
-            return json.load(f).get("kernels", {})
+            j = json.load(f)
+        if j.get("kernel_source_id") != kernel_source_id():
+            return {}
+        return j.get("kernels", {})
     except (OSError, ValueError):
         return {}
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run` over this script as a CHILD process (never an
+    exec: nothing here may replace a process, and nothing in this branch touches the GPU), pass its output through with rank 0's JSON
+    line last, and exit with its code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + [a for a in argv if a != "--dry-launch"]
+    if args.dry_launch:
+        print(json.dumps({"launch": cmd}))
+        return 0
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line_json = None
+    for line in p.stdout:
+        s = line.strip()
+        if s.startswith("{") and '"metric"' in s:
+            line_json = s                                   # held back: printed last
+        else:
+            sys.stdout.write(line); sys.stdout.flush()
+    rc = p.wait()
+    if line_json is not None:
+        print(line_json, flush=True)
+    return rc
 
 
 def cpu_baseline(kind, kw, depth, spp, full):
@@ -135,9 +179,14 @@ def main():
                          "auto = only for path depths that have temporal history (odd number of waves per frame)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: no HIP events around the kernels in the timed region (the roofline "
                     "entry then has no live launch time)")
+    ap.add_argument("--dry-launch", action="store_true", help="with --gpus N > 1 and no launcher environment: print the child command as JSON and exit")
     ap.add_argument("--emulate-rank", default="", help="R/N: on ONE GPU render only rank R's window of an N-GPU tile grid (no gather); "
                     "design aid for the per-rank time of the tiled path, never the reported benchmark line")
     args = ap.parse_args()
+
+    # --gpus N > 1 started bare (no RANK / WORLD_SIZE from a launcher): become the launcher.  Before torch or any GPU call.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -148,6 +197,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    present = torch.cuda.device_count()                   # counting devices does not initialise the GPU
+    if present < world:
+        raise SystemExit(f"bench.py: {world} GPUs requested, {present} present")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -235,6 +287,7 @@ def main():
         # HIP events around the roofline kernel's launches (and one pair per TraceFrame) only; the per-class breakdown comes from the pass below
         r.EnableKernelTiming(0 if args.no_kernel_timing else 2)
         barrier()
+        r.GetCounterTotals(4, reset=True)                 # device-side running sums of the ray counters: from here on, the timed TraceFrames only
         t0 = time.perf_counter()
         for _ in range(args.steps):
             frame(record=world > 1)
@@ -245,6 +298,8 @@ def main():
         # counters of the LAST TraceFrame (every TraceFrame of a step traces the same number of rays to within RNG noise); reading them also
         # collects the HIP-event times of the timed region, on the stream the kernels were launched on
         c = r.GetCounters(50)
+        ct = r.GetCounterTotals(50)                       # summed over all K x spp timed TraceFrames
+        assert ct[3] == args.steps * spp, (ct[3], args.steps, spp)
         k = {name: r.GetKernelTime(i) for i, name in enumerate(("closest", "shadow", "shade", "restir", "total", "tail"))}
         # device time by kernel class (explainer, outside the timed region): two more steps with events around every launch
         r.EnableKernelTiming(1)
@@ -259,7 +314,7 @@ def main():
         # tile's share is counted: primary rays and the first ReSTIR visibility pass cover the whole window (scaled to the tile);
         # indirect waves, NEE and the second visibility pass only run for tile pixels already (lumen_mi_set_tile)
         tile_share = ((tile[2] - tile[0]) * (tile[3] - tile[1])) / float(ww * wh)
-        rays_tile = (c[4] + c[48]) * tile_share + (c[0] - c[4]) + c[1] + c[49] if (world > 1 or emu) else float(c[0] + c[1] + c[2])
+        rays_tile = (ct[4] + ct[48]) * tile_share + (ct[0] - ct[4]) + ct[1] + ct[49] if (world > 1 or emu) else float(ct[0] + ct[1] + ct[2])      # all timed steps
         render_ms = sum(e[0].elapsed_time(e[1]) for e in ev_log) / max(1, len(ev_log)) if ev_log else None
         gather_ms = sum(e[1].elapsed_time(e[2]) for e in ev_log) / max(1, len(ev_log)) if ev_log else None
         stats = torch.tensor([dt, float(rays_tile), render_ms or 0.0, gather_ms or 0.0], dtype=torch.float64, device=dev)
@@ -273,7 +328,7 @@ def main():
         else:
             rays_all = float(rays_tile)
         ms_per_step = dt * 1e3 / args.steps
-        return {"dt": dt, "ms_per_step": ms_per_step, "host_submit_ms_per_step": host_dt * 1e3 / args.steps, "rays_per_frame": rays_all * spp, "value": rays_all * spp / (ms_per_step * 1e-3) / 1e6,
+        return {"dt": dt, "ms_per_step": ms_per_step, "host_submit_ms_per_step": host_dt * 1e3 / args.steps, "rays_per_frame": rays_all / args.steps, "value": rays_all / dt / 1e6,
                 "counters": c, "kernel_ms": k, "class_ms": kb, "n_traceframes": n_tf, "per_rank": per_rank}
 
     fast = args.mode == "fast"
@@ -323,6 +378,11 @@ def main():
             "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            # both arithmetic modes at the top level, so that `value` cannot be read without its mode: "fast" = hardware rcp / rsq / sqrt +
+            # contracted target function in the ReSTIR passes (the reference's Release build is -use_fast_math); "exact" = bit-identical to the oracle
+            "mode": args.mode, "value_fast": round((main_pass if fast else other_pass)["value"], 3) if (fast or other_pass) else None,
+            "value_exact": round((other_pass if fast else main_pass)["value"], 3) if (not fast or other_pass) else None,
+            "ms_per_step_exact": round((other_pass if fast else main_pass)["ms_per_step"], 4) if (not fast or other_pass) else None,
             "config": {"workload": f"{args.workload}: {'cornell box (the reference asset, tests/golden fixture)' if kind == 'cornell' else kind + ' stand-in'}, {W}x{H}, {spp} spp (blended TraceFrames), depth {depth}, ReSTIR DI on",
                        "resample_mode": ("fast: hardware rcp/rsq/sqrt + contracted target function in the ReSTIR passes (rel-L2 vs oracle 1e-8 measured, 1e-3 asserted: "
                                          "test_fast_resampling_mode_stays_within_the_north_star_tolerance)") if fast else "exact: correctly rounded everywhere, bit-identical to the oracle",
@@ -341,6 +401,8 @@ def main():
                        "hbm_traffic_source": None if hbm_tf is None else PMC_FILE + " (replayed: PMC passes of the builder's run, 2 x FETCH_SIZE + WRITE_SIZE per kernel)"},
             "roofline": {"bound": "hbm", "kernel": "lm_k_trace_closest (+ lm_k_trace_closest_packet: the primary wave)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic_closest,
+                         # the PHYSICAL fraction beside the algorithmic one: PMC bytes per launch / live launch time / peak
+                         "frac_hbm_physical": None if (not traffic_closest or per_launch_ms <= 0) else round(traffic_closest / (per_launch_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 5),
                          "traffic_source": None if traffic_closest is None else PMC_FILE + " (replayed, not measured by this run)",
                          "traffic_over_algorithmic": None if not traffic_closest else round(traffic_closest / (alg / max(1.0, launches_per_tf)), 4),
                          "limiter": "dependent-load latency x lane divergence: the tree is served by L2 / Infinity Cache, HBM sees a few % of the algorithmic bytes",

@@ -141,6 +141,11 @@ int lumen_mi_get_frame_stat(lumen_mi_renderer*, const char* key, uint64_t* micro
  * ([20]..[46] only in the instrumented build), [48]/[49] ReSTIR visibility rays of pass 1 / pass 2, [50] GPU refits and
  * [51] instance-level tree assemblies since the renderer was created */
 int lumen_mi_get_counters(lumen_mi_renderer*, uint64_t* out, uint32_t n);
+/* the same counters SUMMED over every TraceFrame since the renderer was created or since the last call with reset != 0 (accumulated on the
+ * device by the frame's last kernel, no read-back between frames): [0] closest-hit rays, [1] NEE shadow rays, [2] ReSTIR shadow rays,
+ * [3] number of TraceFrames summed, [4..4+depth) rays per wave, [48]/[49] ReSTIR visibility rays of pass 1 / 2.  What bench.py divides by
+ * the wall time of the frames it timed (the reference's counters: WaveFrontRenderer.cpp:700-703,815,837; ReSTIRKernels.cu:543). */
+int lumen_mi_get_counter_totals(lumen_mi_renderer*, uint64_t* out, uint32_t n, int reset);
 /* device time of one kernel class, summed over every frame traced since timing was enabled, measured with HIP events
  * on the renderer's stream; `launches` = number of timed launches (class 4: number of frames).
  * which: 0 closest-hit traversal, 1 shadow traversal, 2 extract+shade, 3 ReSTIR (all passes), 4 whole frame, 5 path tail (the deep waves in one launch).

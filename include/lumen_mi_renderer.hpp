@@ -168,10 +168,10 @@ namespace MI355X
         }
         void PushOverride()
         {
-            // a null override means "use the mesh's own materials" (MeshInstance.h:57-65); the native side keeps an override until it is
-            // replaced, so only a non-null material is pushed
-            if (!m_Handle || !m_OverrideMaterial) return;
-            Check(lumen_mi_instance_set_override_material(m_R, m_Handle, static_cast<Material*>(m_OverrideMaterial.get())->m_Handle), "set_override_material");
+            // a null override means "use the mesh's own materials" (MeshInstance.h:57-65, PTMeshInstance.cpp:163-165): pushed as handle 0,
+            // which clears an override set earlier
+            if (!m_Handle) return;
+            Check(lumen_mi_instance_set_override_material(m_R, m_Handle, m_OverrideMaterial ? static_cast<Material*>(m_OverrideMaterial.get())->m_Handle : 0), "set_override_material");
         }
         lumen_mi_renderer* m_R;
         lumen_mi_handle m_Scene;

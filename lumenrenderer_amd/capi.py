@@ -65,6 +65,7 @@ SYMBOLS = {
     "lumen_mi_copy_radiance_device": [_R, C.c_void_p], "lumen_mi_get_channel": [_R, C.c_int, _FP, C.c_size_t],
     "lumen_mi_get_gbuffer": [_R, _FP, C.c_size_t],
     "lumen_mi_get_frame_stat": [_R, C.c_char_p, _U64P], "lumen_mi_get_counters": [_R, _U64P, C.c_uint32],
+    "lumen_mi_get_counter_totals": [_R, _U64P, C.c_uint32, C.c_int],
     "lumen_mi_get_kernel_time": [_R, C.c_int, _FP, _U32P], "lumen_mi_enable_kernel_timing": [_R, C.c_int], "lumen_mi_set_instrumented": [_R, C.c_int],
     "lumen_mi_set_tuning": [_R, C.c_char_p, C.c_int],
     "lumen_mi_get_denoiser_inputs": [_R, C.c_float, C.c_float, _FP, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16)],

@@ -1,4 +1,5 @@
-// bvh.cpp — host-side BVH builder: binned-SAH binary tree collapsed to the 4-wide tree the kernels read, Woop triangle packets.
+// bvh.cpp — host-side BVH builder: binned-SAH binary tree collapsed to the LM_WIDTH-wide tree the kernels read (8-wide: children in octant
+// slots), Woop triangle packets.
 //
 // Replaces the reference's two opaque calls OptixWrapper::BuildGeometryAccelerationStructure /
 // BuildInstanceAccelerationStructure (LumenPT/src/Framework/OptixWrapper.cpp:46-131): instance transforms are
@@ -216,6 +217,36 @@ static unsigned usableCpus()
     return std::max(1u, n);
 }
 
+// Octant slots of an 8-wide node (lm_layout.h LM_WIDTH): child i goes to the slot whose sign pattern best matches the offset of its centre
+// from the centre of the node (slot bit k set = towards + along axis k), assigned greedily by the largest score sum_k +-(c_k - n_k); a ray
+// then visits slot p ^ octant(direction), p = 0 .. 7, which is near to far for well-separated children (Ylitie, Karras, Laine 2017 use an
+// auction for the same assignment; with at most 8 x 8 scores greedy is within noise of it).  Only the ORDER of visits depends on this.
+// boxes: n x (lo.x hi.x lo.y hi.y lo.z hi.z).  4-wide: slot = child number.
+static void lm_assign_slots(int n, const float (*b)[6], int* slotOf)
+{
+#if LM_WIDTH == 8
+    float nlo[3] = {INFINITY, INFINITY, INFINITY}, nhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) { nlo[k] = std::min(nlo[k], b[i][2 * k]); nhi[k] = std::max(nhi[k], b[i][2 * k + 1]); }
+    float d[8][3];
+    for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) {
+        const float ext = nhi[k] - nlo[k];
+        d[i][k] = ext > 0.f ? (0.5f * (b[i][2 * k] + b[i][2 * k + 1]) - 0.5f * (nlo[k] + nhi[k])) / ext : 0.f;      // per-axis relative offset
+    }
+    bool usedC[8] = {false}, usedS[8] = {false};
+    for (int it = 0; it < n; it++) {
+        float best = -INFINITY; int bc = -1, bs = -1;
+        for (int c = 0; c < n; c++) if (!usedC[c]) for (int s = 0; s < 8; s++) if (!usedS[s]) {
+            const float score = ((s & 1) ? d[c][0] : -d[c][0]) + ((s & 2) ? d[c][1] : -d[c][1]) + ((s & 4) ? d[c][2] : -d[c][2]);
+            if (score > best) { best = score; bc = c; bs = s; }
+        }
+        usedC[bc] = true; usedS[bs] = true; slotOf[bc] = bs;
+    }
+#else
+    (void)b;
+    for (int i = 0; i < n; i++) slotOf[i] = i;
+#endif
+}
+
 void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out)
 {
     out->nodes.clear(); out->order.clear(); out->woop.clear();
@@ -328,8 +359,8 @@ void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out)
         ql = std::max(0LL, std::min(65535LL, ql)); qh = std::max(0LL, std::min(65535LL, qh));
         packed = (uint32_t)ql | ((uint32_t)qh << 16);
     };
-    // ---- collapse to 4-wide nodes: starting from a binary node's two children, repeatedly replace the inner child of
-    // largest surface area by its own two children until there are four (or only leaves are left)
+    // ---- collapse to LM_WIDTH-wide nodes: starting from a binary node's two children, repeatedly replace the inner child of
+    // largest surface area by its own two children until there are LM_WIDTH (or only leaves are left)
     struct Child { int ref; float b[6]; uint32_t src; };      // padded box: lo.x hi.x lo.y hi.y lo.z hi.z; src = (binary node << 1) | side
     auto childrenOf = [&](int node, Child* c) {
         const LmNode& n = out->nodes[node];
@@ -349,13 +380,13 @@ void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out)
     // expands one work item: children + the number of 4-wide children it creates
     auto expand = [&](const Work& w, Child* c) {
         int n = childrenOf(w.node2, c);
-        while (n < 4) {
+        while (n < LM_WIDTH) {
             int best = -1; float bestArea = -1.f;
             for (int i = 0; i < n; i++) if (c[i].ref >= 0) { const float a = areaOf(c[i]); if (a > bestArea) { bestArea = a; best = i; } }
             if (best < 0) break;
             Child g[2];
             const int m = childrenOf(c[best].ref, g);
-            if (n - 1 + m > 4) break;
+            if (n - 1 + m > LM_WIDTH) break;
             c[best] = g[0];
             if (m > 1) c[n++] = g[1];
         }
@@ -363,13 +394,17 @@ void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out)
     };
     // writes node w.node4 and pushes its inner children (indices taken from `nextId`) on `stack`
     auto emit = [&](const Work& w, std::vector<Work>& stack, int& nextId, uint32_t& maxStack) {
-        Child c[4];
+        Child c[LM_WIDTH];
         const int n = expand(w, c);
         const uint32_t stackBelow = w.stack + (uint32_t)(n > 0 ? n - 1 : 0);
         maxStack = std::max(maxStack, stackBelow + 1u);
-        LmNode4 q;
-        for (int i = 0; i < 4; i++) {
-            if (i >= n) { q.c[i] = make_uint4(LM_BOX_NONE, LM_BOX_NONE, LM_BOX_NONE, (uint32_t)LM_REF_NONE); continue; }
+        LmNodeW q;
+        int slotOf[LM_WIDTH];
+        float boxes[LM_WIDTH][6];
+        for (int i = 0; i < n; i++) memcpy(boxes[i], c[i].b, sizeof boxes[i]);
+        lm_assign_slots(n, boxes, slotOf);
+        for (int s = 0; s < LM_WIDTH; s++) q.c[s] = make_uint4(LM_BOX_NONE, LM_BOX_NONE, LM_BOX_NONE, (uint32_t)LM_REF_NONE);
+        for (int i = 0; i < n; i++) {
             int ref = c[i].ref;
             if (ref >= 0) {
                 const int id4 = nextId++;
@@ -377,18 +412,18 @@ void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out)
                 depthOf[id4] = w.depth + 1;
                 ref = id4;
             }
-            q.c[i] = make_uint4(c[i].src, 0u, 0u, (uint32_t)ref);        // .x = where the box comes from; quantised below
+            q.c[slotOf[i]] = make_uint4(c[i].src, 0u, 0u, (uint32_t)ref);        // .x = where the box comes from; quantised below
         }
-        out->nodes4[w.node4] = q;
+        out->nodesW[w.node4] = q;
     };
-    out->nodes4.assign(1, LmNode4{});
+    out->nodesW.assign(1, LmNodeW{});
     depthOf.assign(1, 0);
     std::vector<Work> work;
     work.push_back({0, 0, 0, 0});
     int nextId = 1;
     while (!work.empty() && (threads <= 1 || work.size() < 8u * threads)) {   // sequential part (the whole tree when single-threaded)
         const Work w = work.back(); work.pop_back();
-        if (out->nodes4.size() < (size_t)nextId + 4) { out->nodes4.resize(2 * (size_t)nextId + 4); depthOf.resize(2 * (size_t)nextId + 4); }
+        if (out->nodesW.size() < (size_t)nextId + LM_WIDTH) { out->nodesW.resize(2 * (size_t)nextId + LM_WIDTH); depthOf.resize(2 * (size_t)nextId + LM_WIDTH); }
         emit(w, work, nextId, out->maxStack);
     }
     if (!work.empty()) {
@@ -398,7 +433,7 @@ void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out)
             std::vector<int> st{root.node2};
             while (!st.empty()) {
                 Work w{st.back(), 0, 0, 0}; st.pop_back();
-                Child c[4];
+                Child c[LM_WIDTH];
                 const int n = expand(w, c);
                 for (int i = 0; i < n; i++) if (c[i].ref >= 0) { total++; st.push_back(c[i].ref); }
             }
@@ -410,7 +445,7 @@ void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out)
         for (auto& th : pool) th.join();
         std::vector<int> base(work.size());
         for (size_t i = 0; i < work.size(); i++) { base[i] = nextId; nextId += (int)cnt[i]; }
-        out->nodes4.resize((size_t)nextId); depthOf.resize((size_t)nextId);
+        out->nodesW.resize((size_t)nextId); depthOf.resize((size_t)nextId);
         std::vector<uint32_t> tmax(threads, 1u);
         next = 0; pool.clear();
         for (unsigned t = 0; t < threads; t++) pool.emplace_back([&, t] {
@@ -426,12 +461,12 @@ void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out)
         for (auto& th : pool) th.join();
         for (uint32_t m : tmax) out->maxStack = std::max(out->maxStack, m);
     }
-    out->nodes4.resize((size_t)nextId);
+    out->nodesW.resize((size_t)nextId);
     depthOf.resize((size_t)nextId);
     lap("collapse");
-    parallelChunks(out->nodes4.size(), threads, [&](unsigned, size_t lo, size_t hi) {
-        for (size_t i = lo; i < hi; i++) for (int k = 0; k < 4; k++) {
-            uint4& ch = out->nodes4[i].c[k];
+    parallelChunks(out->nodesW.size(), threads, [&](unsigned, size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) for (int k = 0; k < LM_WIDTH; k++) {
+            uint4& ch = out->nodesW[i].c[k];
             if ((int)ch.w == LM_REF_NONE) continue;
             const LmNode& n = out->nodes[ch.x >> 1];
             const float c0[6] = {n.n0.x, n.n0.y, n.n0.z, n.n0.w, n.n2.x, n.n2.y}, c1[6] = {n.n1.x, n.n1.y, n.n1.z, n.n1.w, n.n2.z, n.n2.w};
@@ -493,40 +528,40 @@ void lm_assemble_bvh(const LmInstanceRef* inst, uint32_t nInst, LmBvh* out)
         for (int k = 0; k < ng; k++) { const int c = build(g[k].lo, g[k].hi); top[(size_t)me].child[top[(size_t)me].n++] = c; }
         return me;
     };
-    if (nInst == 0) { out->nodes4.assign(1, LmNode4{}); for (auto& c : out->nodes4[0].c) c = make_uint4(LM_BOX_NONE, LM_BOX_NONE, LM_BOX_NONE, (uint32_t)LM_REF_NONE); }
+    if (nInst == 0) { out->nodesW.assign(1, LmNodeW{}); for (auto& c : out->nodesW[0].c) c = make_uint4(LM_BOX_NONE, LM_BOX_NONE, LM_BOX_NONE, (uint32_t)LM_REF_NONE); }
     else if (nInst > 1) build(0, nInst);
     const uint32_t T = (uint32_t)top.size();
     std::vector<uint32_t> nodeBase(nInst), slotBase(nInst);
     uint32_t nNodes = T, nSlots = 0;
-    for (uint32_t i = 0; i < nInst; i++) { nodeBase[i] = nNodes; slotBase[i] = nSlots; nNodes += (uint32_t)inst[i].mesh->nodes4.size(); nSlots += (uint32_t)inst[i].mesh->order.size(); }
-    if (nInst) out->nodes4.resize(nNodes);
+    for (uint32_t i = 0; i < nInst; i++) { nodeBase[i] = nNodes; slotBase[i] = nSlots; nNodes += (uint32_t)inst[i].mesh->nodesW.size(); nSlots += (uint32_t)inst[i].mesh->order.size(); }
+    if (nInst) out->nodesW.resize(nNodes);
     out->order.resize(nSlots);
     for (uint32_t t = 0; t < T; t++) {
-        LmNode4 q;
+        LmNodeW q;
         for (int k = 0; k < 4; k++) {
             if (k >= top[t].n) { q.c[k] = make_uint4(LM_BOX_NONE, LM_BOX_NONE, LM_BOX_NONE, (uint32_t)LM_REF_NONE); continue; }
             const int c = top[t].child[k];
             q.c[k] = make_uint4(0u, 0u, 0u, (uint32_t)(c >= 0 ? c : (int)nodeBase[(uint32_t)(~c)]));
         }
-        out->nodes4[t] = q;
+        out->nodesW[t] = q;
     }
     for (uint32_t i = 0; i < nInst; i++) {
         const LmBvh& m = *inst[i].mesh;
-        for (size_t n = 0; n < m.nodes4.size(); n++) {
-            LmNode4 q = m.nodes4[n];
+        for (size_t n = 0; n < m.nodesW.size(); n++) {
+            LmNodeW q = m.nodesW[n];
             for (auto& c : q.c) {
                 const int ref = (int)c.w;
                 if (ref == LM_REF_NONE) continue;
                 if (ref >= 0) c.w = (uint32_t)(ref + (int)nodeBase[i]);
                 else { const uint32_t leaf = (uint32_t)(~ref); c.w = (uint32_t)(~(int)((((leaf >> 3) + slotBase[i]) << 3) | (leaf & 7u))); }
             }
-            out->nodes4[nodeBase[i] + n] = q;
+            out->nodesW[nodeBase[i] + n] = q;
         }
         for (size_t s = 0; s < m.order.size(); s++) out->order[slotBase[i] + s] = inst[i].triBase + m.order[s];
     }
     out->woop.assign((size_t)nSlots + 1, LmWoop{});                   // refit_tris writes the packets; the sentinel stays zero
     // depth of every node, worst-case stack occupancy (the rule of lm_build_bvh's collapse), refit levels deepest first
-    std::vector<uint32_t> depthOf(out->nodes4.size(), 0);
+    std::vector<uint32_t> depthOf(out->nodesW.size(), 0);
     struct Item { uint32_t node, depth, stack; };
     std::vector<Item> st{{0u, 0u, 0u}};
     out->maxStack = 1; uint32_t maxDepth = 0;
@@ -534,17 +569,17 @@ void lm_assemble_bvh(const LmInstanceRef* inst, uint32_t nInst, LmBvh* out)
         const Item w = st.back(); st.pop_back();
         depthOf[w.node] = w.depth; maxDepth = std::max(maxDepth, w.depth);
         uint32_t present = 0;
-        for (const auto& c : out->nodes4[w.node].c) present += (int)c.w != LM_REF_NONE;
+        for (const auto& c : out->nodesW[w.node].c) present += (int)c.w != LM_REF_NONE;
         const uint32_t below = w.stack + (present ? present - 1u : 0u);
         out->maxStack = std::max(out->maxStack, below + 1u);
-        for (const auto& c : out->nodes4[w.node].c) if ((int)c.w >= 0 && (int)c.w != LM_REF_NONE) st.push_back({c.w, w.depth + 1u, below});
+        for (const auto& c : out->nodesW[w.node].c) if ((int)c.w >= 0 && (int)c.w != LM_REF_NONE) st.push_back({c.w, w.depth + 1u, below});
     }
     out->maxDepth = maxDepth + 1u;
     std::vector<uint32_t> count(maxDepth + 2u, 0);
     for (uint32_t d : depthOf) count[maxDepth - d + 1u]++;             // level 0 = deepest
     out->levelStart.assign(maxDepth + 2u, 0);
     for (uint32_t l = 1; l < maxDepth + 2u; l++) out->levelStart[l] = out->levelStart[l - 1] + count[l];
-    out->levelNodes.resize(out->nodes4.size());
+    out->levelNodes.resize(out->nodesW.size());
     std::vector<uint32_t> fill(out->levelStart.begin(), out->levelStart.end() - 1);
-    for (uint32_t n = 0; n < (uint32_t)out->nodes4.size(); n++) out->levelNodes[fill[maxDepth - depthOf[n]]++] = n;
+    for (uint32_t n = 0; n < (uint32_t)out->nodesW.size(); n++) out->levelNodes[fill[maxDepth - depthOf[n]]++] = n;
 }

@@ -5,7 +5,7 @@
 
 struct LmBvh {
     std::vector<LmNode> nodes;          // node 0 is the root and always an inner node
-    std::vector<LmNode4> nodes4;        // the tree collapsed to 4-wide nodes with 16-bit boxes (what the kernels read); node 0 = root
+    std::vector<LmNodeW> nodesW;        // the tree collapsed to 4-wide nodes with 16-bit boxes (what the kernels read); node 0 = root
     float qmin[3] = {0, 0, 0}, qstep[3] = {1, 1, 1};
     std::vector<uint32_t> order;        // BVH triangle slot -> input triangle index
     std::vector<LmWoop> woop;           // per slot, plus one all-zero sentinel packet at index order.size()

@@ -13,6 +13,10 @@ int ensureFrameBuffers(R* r)
     const uint32_t ww = r->wx1 - r->wx0, wh = r->wy1 - r->wy0, n = ww * wh;
     if (r->tileSet && (r->ox0 < r->wx0 || r->oy0 < r->wy0 || r->ox1 > r->wx1 || r->oy1 > r->wy1)) return fail(LUMEN_MI_ERR_INVALID, "owned tile outside the render window");
     LmFrame& f = r->fr;
+    if (!r->dTotals.p) {
+        if (r->dTotals.ensure(LM_CNT_WORDS + 1) || hipMemsetAsync(r->dTotals.p, 0, (LM_CNT_WORDS + 1) * sizeof(unsigned long long), r->stream) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "counter totals allocation failed");
+    }
+    f.totals = r->dTotals.p;
     // compared against the COMMITTED state: allocN is only set once every allocation and reset below has succeeded
     const bool realloc = n != r->allocN || f.W != W || f.H != H || f.x0 != r->wx0 || f.y0 != r->wy0 || f.ww != ww;
     if (!realloc) {

@@ -229,7 +229,10 @@ KN(lm_k_extract0)(LmScene sc, LmFrame fr, LmCamera cam, int cur, uint32_t seed2,
         LmSurface s;
         lm_extract(sc, lut, tab, fr.hits[i], v3(cam.eye[0], cam.eye[1], cam.eye[2]), v3(d4), v3(1.f, 1.f, 1.f), s);
         lm_gbuf_store(fr.gbuf[cur], fr.probe[cur], li, s);
-        lm_count(fr.counters + LM_CNT_RARE, !s.flags && !lm_quick_contracts(s.mat));      // surfaces the fast ReSTIR mode scores in its second launch (none: no atomic)
+        // does any surface of the frame need the second (exact) launch of the fast ReSTIR passes?  A FLAG, not a count: one plain store per
+        // wavefront that sees such a surface (an atomic per wavefront on one address is ~ 88 per microsecond: 0.65 ms at 1440p in a scene of
+        // glass or clear coat, on the critical wave chain, in every mode)
+        if (__ballot(!s.flags && !lm_quick_contracts(s.mat)) != 0ull && lm_lane() == 0u) fr.counters[LM_CNT_RARE] = 1u;
         // motion vector
         const uint32_t ly = li / fr.ww, lx = li - ly * fr.ww;
         const uint32_t px = fr.x0 + lx, py = fr.y0 + ly;
@@ -880,6 +883,9 @@ KN(lm_k_merge_output)(LmFrame fr, int blend, uint32_t blendCount, int depthMax)
         *fr.swap = (*fr.swap + executed) & 1;
         fr.swap[1] = executed;
     }
+    // running sums of the counter block (merges of consecutive frames are ordered on one stream, and every producer of this frame's
+    // counters has been joined before the merge)
+    if (blockIdx.x == 0 && threadIdx.x <= LM_CNT_WORDS) fr.totals[threadIdx.x] += threadIdx.x < LM_CNT_WORDS ? (unsigned long long)fr.counters[threadIdx.x] : 1ull;
     const uint32_t stride = gridDim.x * LM_BLOCK;
     for (uint32_t li = blockIdx.x * LM_BLOCK + threadIdx.x; li < fr.n; li += stride) {
         float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1274,7 +1280,7 @@ KN(lm_k_sort_scatter)(LmScene sc, const float4* __restrict__ srcO, const float4*
 // Top-of-tree table for the queue traversal kernels (lm_layout.h LM_TOP_NODES): the first LM_TOP_NODES inner nodes in breadth-first
 // order, with child references rewritten to table slots where the child made it into the table.  One wavefront, level by level
 // (slots are handed out in lane order: deterministic); run whenever the node array changes (build, refit, assembly).
-extern "C" __global__ void KN(lm_k_build_top)(const LmNode4* __restrict__ nodes, LmNode4* __restrict__ top)
+extern "C" __global__ void KN(lm_k_build_top)(const LmNodeW* __restrict__ nodes, LmNodeW* __restrict__ top)
 {
 #if LM_TOP_NODES
     __shared__ int s_src[LM_TOP_NODES];
@@ -1288,7 +1294,7 @@ extern "C" __global__ void KN(lm_k_build_top)(const LmNode4* __restrict__ nodes,
         for (uint32_t base = begin; base < end; base += 64u) {
             const uint32_t s = base + lane;
             const bool valid = s < end;
-            LmNode4 nd;
+            LmNodeW nd;
             uint32_t inner = 0;
             if (valid) {
                 nd = nodes[s_src[s]];
@@ -1386,7 +1392,7 @@ static void l_sort_rays(hipStream_t s, int g, LmScene sc, const float4* srcO, co
     hipLaunchKernelGGL(KN(lm_k_sort_scatter), LM_GRID(g), sc, srcO, srcD, srcC, dstO, dstD, dstC, cnt, bins + LM_SORT_BINS);
 }
 static void l_export_half4(hipStream_t s, int g, const float4* src, uint2* dst, uint32_t n) { hipLaunchKernelGGL(KN(lm_k_export_half4), LM_GRID(g), src, dst, n); }
-static void l_build_top(hipStream_t s, const LmNode4* nodes, LmNode4* top) { hipLaunchKernelGGL(KN(lm_k_build_top), dim3(1), dim3(64), 0, s, nodes, top); }
+static void l_build_top(hipStream_t s, const LmNodeW* nodes, LmNodeW* top) { hipLaunchKernelGGL(KN(lm_k_build_top), dim3(1), dim3(64), 0, s, nodes, top); }
 static void l_spin(hipStream_t s, uint32_t ticks) { hipLaunchKernelGGL(KN(lm_k_spin), dim3(1), dim3(64), 0, s, ticks); }
 
 #if LM_INSTRUMENT

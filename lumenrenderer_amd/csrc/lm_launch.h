@@ -31,7 +31,7 @@ struct LmKernelTable {
     void (*history_copy)(hipStream_t, int grid, LmFrame, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, float4* buf, int import);
     void (*wave_sync)(hipStream_t, int* swap, int* io, int import);
     void (*test_restir)(hipStream_t, int mode, uint32_t n, const float* a, const float* b, const uint32_t* c, uint32_t m, float* out);
-    void (*build_top)(hipStream_t, const LmNode4* nodes, LmNode4* top);       // top-of-tree table of the queue traversal kernels (after every change of `nodes`)
+    void (*build_top)(hipStream_t, const LmNodeW* nodes, LmNodeW* top);       // top-of-tree table of the queue traversal kernels (after every change of `nodes`)
     void (*export_half4)(hipStream_t, int grid, const float4* src, uint2* dst, uint32_t n);      // merged radiance rounded to the reference's half4 storage
     // counting sort of a ray queue by (origin cell, direction octant) into another queue; bins: 2 x 4096 words, zero on entry and on return
     void (*sort_rays)(hipStream_t, int grid, LmScene, const float4* srcO, const float4* srcD, const float4* srcC, float4* dstO, float4* dstD, float4* dstC,

@@ -8,20 +8,30 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define LM_STACK_DEPTH 64        // traversal stack entries per lane; the BVH builder bounds the tree so that this suffices
+#ifndef LM_WIDTH
+#define LM_WIDTH 4               // children per node of the tree the kernels traverse (4 or 8; the binary SAH tree is collapsed to this width, bvh.cpp).
+#endif                           // 8: children sit in OCTANT slots (slot bit k set = the child lies on the + side of the node's centre along axis k) and a ray
+                                 // visits slot (p ^ octant of its direction), p = 0 .. 7: near-to-far order without sorting, and half the dependent node
+                                 // fetches of the 4-wide tree (which orders its children by entry distance with a comparator network)
+#if LM_WIDTH != 4 && LM_WIDTH != 8
+#error "LM_WIDTH must be 4 or 8"
+#endif
+#define LM_STACK_DEPTH (LM_WIDTH == 8 ? 96 : 64)   // traversal stack entries per lane; the BVH builder bounds the tree so that this suffices
 #ifndef LM_STACK_LDS
 #define LM_STACK_LDS 16          // of which in LDS; deeper entries spill to a per-thread global array
 #endif
-#define LM_BVH2_MAX_DEPTH 40     // depth bound of the binary tree the 4-wide tree is collapsed from: a 4-wide node spans >= 2 binary
-                                 // levels per 3 pushes, so the stack need is <= 1.5 * 40 + 1 <= LM_STACK_DEPTH
+#define LM_BVH2_MAX_DEPTH 40     // depth bound of the binary tree the wide tree is collapsed from.  A wide node with n children pushes n - 1 entries and
+                                 // spans at least ceil(log2 n) binary levels: (n - 1) / ceil(log2 n) <= 1.5 for n <= 4 and <= 7 / 3 for n <= 8, so the
+                                 // stack need is <= 1.5 * 40 + 1 = 61 (4-wide) or 2.34 * 40 + 1 = 95 (8-wide) <= LM_STACK_DEPTH
 #define LM_QUANT_MARGIN 2        // grid cells a quantised child box is widened by on each side beyond outward rounding: one for the fp32 evaluation of the slab
                                  // distances, one for the folded 2^23 offset of the packed slab test (lm_traverse.h LM_SLAB_PERM 3: up to half a cell)
 #define LM_BOX_NONE 0x0000ffffu  // per-axis word of an absent child: lo = 0xffff, hi = 0 — inverted, so the slab test misses without looking at the reference
 #define LM_REUSE_FLAGGED 0x80000000u
 #define LM_REF_NONE 0x7fffffff   // absent child of a 4-wide node (also the traversal's "finished" marker; never followed)
 #ifndef LM_TOP_NODES
-#define LM_TOP_NODES 21          // top-of-tree node records (breadth-first from the root) the queue traversal kernels stage in LDS; 0 = none.
-#endif                           // 21 = three full levels = 1.3 KB per block beside the 16 KB stack: still eight blocks per CU
+#define LM_TOP_NODES (LM_WIDTH == 8 ? 9 : 21)   // top-of-tree node records (breadth-first from the root) the queue traversal kernels stage in LDS; 0 = none.
+#endif                           // 21 four-wide records = three full levels = 1.3 KB per block beside the 16 KB stack (9 eight-wide records = two levels, 1.1 KB):
+                                 // still eight blocks per CU
 #define LM_TOP_BASE 0x40000000   // a node reference >= LM_TOP_BASE (and != LM_REF_NONE) names slot (ref - LM_TOP_BASE) of the staged table
 #define LM_MAX_LEAF 8            // triangles per leaf representable in a leaf reference
 #define LM_MAX_DEPTH 16          // path depth the counter block is sized for
@@ -39,11 +49,12 @@ struct LmNode {
     float4 n2;      // c0.lo.z c0.hi.z c1.lo.z c1.hi.z
     int4 ref;       // c0, c1, unused, unused
 };
-// 4-wide node as the GPU traverses it: 64 bytes, the binary tree collapsed by surface area (bvh.cpp).  Child boxes are
-// 16-bit fixed point relative to the scene box, rounded outward (lo | hi << 16 per axis); boxes only cull, so the hit
-// record does not depend on them.  An absent child has reference LM_REF_NONE.
-struct LmNode4 {
-    uint4 c[4];     // per child  x: lo.x | hi.x << 16   y: lo.y | hi.y << 16   z: lo.z | hi.z << 16   w: reference
+// Wide node as the GPU traverses it: LM_WIDTH children of 16 bytes (64 / 128 bytes: one cache line), the binary tree collapsed by surface
+// area (bvh.cpp).  Child boxes are 16-bit fixed point relative to the scene box, rounded outward (lo | hi << 16 per axis); boxes only
+// cull, so the hit record does not depend on them, nor on the width or the slot order.  An absent child has reference LM_REF_NONE and an
+// inverted box.  8-wide: c[s] is octant slot s (see LM_WIDTH).
+struct LmNodeW {
+    uint4 c[LM_WIDTH];     // per child  x: lo.x | hi.x << 16   y: lo.y | hi.y << 16   z: lo.z | hi.z << 16   w: reference
 };
 // Woop unit-triangle packet, 48 bytes: rows of the affine map world -> (u, v, w)
 struct LmWoop { float4 r0, r1, r2; };
@@ -73,8 +84,8 @@ struct LmTexDesc { uint32_t offset, w, h, srgb; };
 struct LmLight { float4 a, b, c, d; };   // a = p0.xyz p1.x | b = p1.yz p2.xy | c = p2.z n.xyz | d = radiance.xyz area
 
 struct LmScene {
-    LmNode4* nodes;             // written only by the refit kernels
-    const LmNode4* top;         // LM_TOP_NODES records: the top of the tree in breadth-first order, child references relinked to table slots
+    LmNodeW* nodes;             // written only by the refit kernels
+    const LmNodeW* top;         // LM_TOP_NODES records: the top of the tree in breadth-first order, child references relinked to table slots
                                 // where the child is in the table too (lm_k_build_top, rebuilt whenever `nodes` changes)
     const float* quant;         // dequantisation of node boxes, in device memory so that a refit can move it without a host
                                 // round trip: [0..2] qmin, [3..5] qstep (world = qmin + q * qstep), [6] box padding
@@ -125,6 +136,8 @@ struct LmFrame {
     float4* combined;           // merged / blended radiance
     uchar4* output;             // sRGB8
     uint32_t* counters;         // see LM_CNT_*
+    unsigned long long* totals; // LM_CNT_WORDS + 1 running sums: the merge kernel adds every frame's counter block (and 1 to the last word), so that a
+                                // throughput measurement counts the rays of ALL the frames it timed without reading counters back between frames
     int* swap;                  // ReSTIR swap-chain index (ReSTIR::m_SwapChainIndex), on the device: it advances once per EXECUTED
                                 // wave, and the wave loop ends when a wave's queue is empty (WaveFrontRenderer.cpp:697,827) — a count only
                                 // the device knows without a host round trip.  Kernels take buffer indices as LM_RES_* codes.
@@ -138,7 +151,7 @@ struct LmFrame {
 #define LM_CNT_RAYS(d) (d)                       // rays entering wave d            [0, LM_MAX_DEPTH]
 #define LM_CNT_SHADOW(d) (32 + (d))              // NEE shadow rays emitted by wave d
 #define LM_CNT_RESTIR(p) (70 + (p))              // ReSTIR visibility rays of pass p (0, 1)
-#define LM_CNT_RARE 72                           // depth-0 surfaces with a lobe outside the contracted evaluation (lm_bsdf.h lm_quick_contracts)
+#define LM_CNT_RARE 72                           // flag: 1 when a depth-0 surface of the frame has a lobe outside the contracted evaluation (lm_bsdf.h lm_quick_contracts)
 #define LM_CNT_STEP_HIST 96                       // instrumented build only: 16 log2 buckets of per-ray traversal steps (queue kernels)
 #define LM_CNT_STEP_MAX 112                       // instrumented build only: longest per-ray traversal (steps)
 #define LM_CNT_NODES 66                          // instrumented build only: child boxes slab-tested (u64 as 2 words); 2 boxes = one binary node of SURVEY 8 d4

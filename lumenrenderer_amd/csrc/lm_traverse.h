@@ -331,7 +331,7 @@ template <bool ANY, class Fetch, class Done>
 __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, int refillBelow, const LmStack& stack, const lm_lds_u4* top,
                                                uint32_t* cnt, Fetch fetch, Done done)
 {
-    const int root = (LM_TOP_NODES && top) ? LM_TOP_BASE : 0;
+    const int root = (LM_TOP_NODES != 0 && top) ? LM_TOP_BASE : 0;
     // A small queue cannot fill the machine: its launch time is one wave's dependent chain, which stretches when the wave
     // shares its SIMD with VALU-bound kernels of the other streams.  Such waves ask the SIMD arbiter for priority.
     if (n < LM_PRIO_RAYS) __builtin_amdgcn_s_setprio(3);
@@ -487,7 +487,7 @@ __device__ __forceinline__ void lm_trace_packets(const LmScene& sc, uint32_t n, 
 {
     const uint32_t lane = lm_lane();
     const uint32_t W = gridDim.x * (LM_BLOCK / 64u);
-    const int root = (LM_TOP_NODES && top) ? LM_TOP_BASE : 0;
+    const int root = (LM_TOP_NODES != 0 && top) ? LM_TOP_BASE : 0;
     for (uint32_t group = blockIdx.x * (LM_BLOCK / 64u) + (threadIdx.x >> 6); (unsigned long long)group * 64ull < (unsigned long long)n; group += W) {
         const uint32_t i = group * 64u + lane;
         const bool valid = i < n;

@@ -109,7 +109,7 @@ int lumen_mi_destroy(lumen_mi_renderer* r)
         for (auto& b : r->dResC) b.release();
         for (auto& b : r->dMotion) b.release();
         for (int i = 0; i < 2; i++) { r->dDirect[i].release(); r->dIndirect[i].release(); }
-        r->dSortBins.release(); r->dCombined.release(); for (auto& b : r->dHits) b.release(); r->dCounters.release(); r->dSwap.release(); r->dOutput.release(); r->dBags.release();
+        r->dSortBins.release(); r->dExportHalf.release(); r->dTotals.release(); r->dCombined.release(); for (auto& b : r->dHits) b.release(); r->dCounters.release(); r->dSwap.release(); r->dOutput.release(); r->dBags.release();
         for (auto& e : r->evPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     }
     delete r;
@@ -187,9 +187,14 @@ static int fillMaterial(lumen_mi_renderer* r, const lumen_mi_material_data* d, M
     }
     // Can surface extraction produce a material outside the contracted ReSTIR evaluation?  Transmission / clear coat are factor x texel
     // (GPUExtractSurfaceData.cu:183-196): 0 when the factor byte is 0.  Roughness is texel.g x factor re-packed by truncation: the byte is
-    // 0 (mirror-like: the opaque stack is absent) iff the product is below 1/255; bilinear filtering never goes below the smallest texel.
-    const float baseRough = (float)(v.p[0] >> 24) * (1.0f / 255.0f), minG = (float)r->textures[(size_t)tMR].minG / 255.0f;
-    m.mayBeRare = (v.p[2] & 0x00ff00ffu) != 0u || (v.p[1] & 0x0000ff00u) != 0u || (uint32_t)(minG * baseRough * 255.f) == 0u;      // + anisotropy (a per-material constant)
+    // 0 (mirror-like: the opaque stack is absent) iff the product is below 1/255.  The prediction must be CONSERVATIVE (a surface wrongly
+    // predicted "common" would be skipped by both launches): the smallest green texel goes through the SAME decode the device fetch applies
+    // (sRGB table for a texture created with normalize = 1: byte 10 decodes to 0.003, not 10/255), and the bilinear filter's
+    // a + t (b - a) may land an ulp below the smallest texel, hence the margin of one part in 1e3 on the threshold.
+    const Texture& tmr = r->textures[(size_t)tMR];
+    const float baseRough = (float)(v.p[0] >> 24) * (1.0f / 255.0f);
+    const float minG = tmr.srgb ? g_srgbLut[tmr.minG] : (float)tmr.minG / 255.0f;
+    m.mayBeRare = (v.p[2] & 0x00ff00ffu) != 0u || (v.p[1] & 0x0000ff00u) != 0u || minG * baseRough * 255.f < 1.001f;      // + anisotropy (a per-material constant)
     return 0;
 }
 
@@ -363,10 +368,13 @@ int lumen_mi_instance_set_override_material(lumen_mi_renderer* r, lumen_mi_handl
 {
     if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer");
     ApiLock lk(r);
-    size_t i, m;
-    if (!instanceOf(r, inst, i) || !unh(mat, H_MATERIAL, r->materials.size(), m)) return fail(LUMEN_MI_ERR_INVALID, "bad handle");
-    if (r->instances[i].overrideMaterial != (long)m) r->entriesDirty = true;
-    r->instances[i].overrideMaterial = (long)m;
+    size_t i, m = 0;
+    // handle 0 clears the override: the instance falls back to the mesh's own materials, as the reference does whenever
+    // m_OverrideMaterial == nullptr (PTMeshInstance.cpp:163-165)
+    if (!instanceOf(r, inst, i) || (mat != 0 && !unh(mat, H_MATERIAL, r->materials.size(), m))) return fail(LUMEN_MI_ERR_INVALID, "bad handle");
+    const long want = mat == 0 ? -1L : (long)m;
+    if (r->instances[i].overrideMaterial != want) r->entriesDirty = true;
+    r->instances[i].overrideMaterial = want;
     return 0;
 }
 
@@ -468,13 +476,12 @@ int lumen_mi_get_radiance_half4(lumen_mi_renderer* r, uint16_t* out, size_t cap)
     if (!r->fr.combined || !r->allocN) return fail(LUMEN_MI_ERR_STATE, "no frame has been traced yet");
     if (cap < (size_t)n * 8) return fail(LUMEN_MI_ERR_INVALID, "buffer too small");
     int rc = syncAndCollect(r); if (rc) return rc;
-    DevBuf<uint2> d;
+    DevBuf<uint2>& d = r->dExportHalf;               // kept with the renderer (released with the frame buffers): no allocation per call, nothing to leak on an error return
     if (d.ensure(n)) return fail(LUMEN_MI_ERR_DEVICE, "export allocation failed");
     r->K->export_half4(r->stream, r->gridFor(n, 8), r->fr.combined, d.p, n);
     LM_HIP(hipGetLastError());
     LM_HIP(hipStreamSynchronize(r->stream));
     LM_HIP(hipMemcpy(out, d.p, (size_t)n * 8, hipMemcpyDeviceToHost));
-    d.release();
     return 0;
 }
 int lumen_mi_get_channel(lumen_mi_renderer* r, int ch, float* out, size_t cap)
@@ -577,6 +584,24 @@ int lumen_mi_get_counters(lumen_mi_renderer* r, uint64_t* out, uint32_t n)
     v[48] = c[LM_CNT_RESTIR(0)]; v[49] = c[LM_CNT_RESTIR(1)];
     v[50] = r->refits; v[51] = r->assemblies;                                          // GPU refits / instance-level assemblies since creation
     v[52] = c[LM_CNT_RARE]; v[53] = r->anyRareMaterial ? 1u : 0u;                      // depth-0 surfaces outside the contracted ReSTIR evaluation / can any material produce one
+    for (uint32_t i = 0; i < n && i < 64; i++) out[i] = v[i];
+    return 0;
+}
+int lumen_mi_get_counter_totals(lumen_mi_renderer* r, uint64_t* out, uint32_t n, int reset)
+{
+    if (!r || !out) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    ApiLock lk(r);
+    int rc = syncAndCollect(r); if (rc) return rc;
+    uint64_t v[64] = {0};
+    if (r->dTotals.p) {
+        unsigned long long t[LM_CNT_WORDS + 1];
+        LM_HIP(hipMemcpy(t, r->dTotals.p, sizeof t, hipMemcpyDeviceToHost));
+        for (uint32_t d = 0; d < r->lastDepth && d < 16; d++) { v[0] += t[LM_CNT_RAYS(d)]; v[4 + d] = t[LM_CNT_RAYS(d)]; v[1] += t[LM_CNT_SHADOW(d)]; }
+        v[2] = t[LM_CNT_RESTIR(0)] + t[LM_CNT_RESTIR(1)];
+        v[3] = t[LM_CNT_WORDS];
+        v[48] = t[LM_CNT_RESTIR(0)]; v[49] = t[LM_CNT_RESTIR(1)];
+        if (reset) LM_HIP(hipMemsetAsync(r->dTotals.p, 0, sizeof t, r->stream));
+    }
     for (uint32_t i = 0; i < n && i < 64; i++) out[i] = v[i];
     return 0;
 }
@@ -779,7 +804,7 @@ int lumen_mi_get_bvh_info(lumen_mi_renderer* r, uint32_t* nodes, uint32_t* tris,
     ApiLock lk(r);
     int rc = prepareScene(r); if (rc) return rc;
     // binary nodes of the SAH build; 4-wide nodes of an assembled tree
-    if (nodes) *nodes = (uint32_t)(r->bvh.nodes.empty() ? r->bvh.nodes4.size() : r->bvh.nodes.size());
+    if (nodes) *nodes = (uint32_t)(r->bvh.nodes.empty() ? r->bvh.nodesW.size() : r->bvh.nodes.size());
     if (tris) *tris = (uint32_t)r->bvh.order.size();
     if (maxDepth) *maxDepth = r->bvh.maxDepth;
     return 0;

@@ -94,12 +94,12 @@ template <class T> struct HostBuf {                 // pinned staging memory for
 // the other one (instance table and light list by asynchronous copies from pinned memory, BVH boxes and Woop packets by the
 // refit kernels) on the wave stream, so frames keep overlapping while the scene changes.
 struct SceneSet {
-    DevBuf<LmNode4> top;                                                     // top-of-tree table of `nodes` (lm_k_build_top)
-    DevBuf<LmNode4> nodes; DevBuf<LmWoop> woop; DevBuf<float> quant; DevBuf<LmEntry> entries; DevBuf<LmLight> lights; DevBuf<float> cdf;
+    DevBuf<LmNodeW> top;                                                     // top-of-tree table of `nodes` (lm_k_build_top)
+    DevBuf<LmNodeW> nodes; DevBuf<LmWoop> woop; DevBuf<float> quant; DevBuf<LmEntry> entries; DevBuf<LmLight> lights; DevBuf<float> cdf;
     DevBuf<uint2> triId; DevBuf<uint32_t> triOrder, levelNodes;            // topology of the tree in `nodes` (what an instance add / remove rewrites)
     std::vector<uint32_t> levelStart; uint32_t nTris = 0;
     HostBuf<LmEntry> hEntries; HostBuf<LmLight> hLights; HostBuf<float> hCdf;
-    HostBuf<LmNode4> hNodes; HostBuf<uint2> hTriId; HostBuf<uint32_t> hOrder, hLevelNodes;
+    HostBuf<LmNodeW> hNodes; HostBuf<uint2> hTriId; HostBuf<uint32_t> hOrder, hLevelNodes;
     hipEvent_t evUp = nullptr; bool upPending = false;      // the staging buffers are free again once this event has passed
     uint64_t entriesVer = 0, geomVer = 0, lightsVer = 0, topoVer = 0;    // state of the host scene this set holds
     void release() {
@@ -238,6 +238,8 @@ struct lumen_mi_renderer {
     DevBuf<float4> dRay[12], dSh[6], dSh2[4];      // ray queues and the NEE shadow queue once per frame parity (two wave streams: consecutive frames trace concurrently)
     DevBuf<float4> dGbuf[3], dProbe[3], dRes[5], dResC[5], dDirect[2], dIndirect[2], dCombined;
     DevBuf<uint4> dHits[2]; DevBuf<uint32_t> dMotion[2], dCounters, dReuseMask; DevBuf<uchar4> dOutput; DevBuf<uint2> dBags;
+    DevBuf<uint2> dExportHalf;                          // lumen_mi_get_radiance_half4
+    DevBuf<unsigned long long> dTotals;                 // LmFrame::totals
     uint32_t hostCounters[LM_CNT_WORDS] = {0};
     bool countersValid = false;
     uint32_t lastDepth = 0;

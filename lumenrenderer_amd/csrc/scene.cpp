@@ -92,13 +92,13 @@ int syncScene(R* r, hipStream_t su)
         bool copied = false;
         if (T.topoVer != r->topoVer) {                              // a new tree (instances added / removed): topology now, boxes by the refit below
             const LmBvh& b = r->bvh;
-            const size_t nn = b.nodes4.size(), ns = b.order.size(), nl = b.levelNodes.size();
+            const size_t nn = b.nodesW.size(), ns = b.order.size(), nl = b.levelNodes.size();
             if (T.hNodes.ensure(nn) || T.hTriId.ensure(ns) || T.hOrder.ensure(ns) || T.hLevelNodes.ensure(nl) || T.nodes.ensure(nn) || T.triId.ensure(ns) ||
                 T.triOrder.ensure(ns) || T.levelNodes.ensure(nl) || T.woop.ensure(ns + 1) || T.quant.ensure(8))
                 return fail(LUMEN_MI_ERR_DEVICE, "scene tree allocation failed");
-            memcpy(T.hNodes.p, b.nodes4.data(), nn * sizeof(LmNode4)); memcpy(T.hTriId.p, r->triId.data(), ns * sizeof(uint2));
+            memcpy(T.hNodes.p, b.nodesW.data(), nn * sizeof(LmNodeW)); memcpy(T.hTriId.p, r->triId.data(), ns * sizeof(uint2));
             memcpy(T.hOrder.p, b.order.data(), ns * sizeof(uint32_t)); memcpy(T.hLevelNodes.p, b.levelNodes.data(), nl * sizeof(uint32_t));
-            LM_HIP(hipMemcpyAsync(T.nodes.p, T.hNodes.p, nn * sizeof(LmNode4), hipMemcpyHostToDevice, su));
+            LM_HIP(hipMemcpyAsync(T.nodes.p, T.hNodes.p, nn * sizeof(LmNodeW), hipMemcpyHostToDevice, su));
             if (ns) { LM_HIP(hipMemcpyAsync(T.triId.p, T.hTriId.p, ns * sizeof(uint2), hipMemcpyHostToDevice, su)); LM_HIP(hipMemcpyAsync(T.triOrder.p, T.hOrder.p, ns * sizeof(uint32_t), hipMemcpyHostToDevice, su)); }
             if (nl) LM_HIP(hipMemcpyAsync(T.levelNodes.p, T.hLevelNodes.p, nl * sizeof(uint32_t), hipMemcpyHostToDevice, su));
             LM_HIP(hipMemsetAsync(T.woop.p + ns, 0, sizeof(LmWoop), su));            // sentinel packet
@@ -264,7 +264,7 @@ int flatten(R* r)
     for (SceneSet& S : r->sset) if (S.upPending) { (void)hipEventSynchronize(S.evUp); S.upPending = false; }
     std::vector<float> quant = {r->bvh.qmin[0], r->bvh.qmin[1], r->bvh.qmin[2], r->bvh.qstep[0], r->bvh.qstep[1], r->bvh.qstep[2], r->bvh.pad, 0.f};
     for (SceneSet& S : r->sset) {
-        if (S.nodes.upload(r->bvh.nodes4, st) || S.woop.upload(r->bvh.woop, st) || S.entries.upload(r->entries, st) || S.quant.upload(quant, st) ||
+        if (S.nodes.upload(r->bvh.nodesW, st) || S.woop.upload(r->bvh.woop, st) || S.entries.upload(r->entries, st) || S.quant.upload(quant, st) ||
             S.triId.upload(r->triId, st) || S.triOrder.upload(r->bvh.order, st) || S.levelNodes.upload(r->bvh.levelNodes, st))
             return fail(LUMEN_MI_ERR_DEVICE, "scene upload failed (hipMalloc/hipMemcpy)");
         S.levelStart = r->bvh.levelStart; S.nTris = nt;
@@ -274,7 +274,7 @@ int flatten(R* r)
     }
     {
         std::vector<uint32_t> bounds = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
-        if (r->dRefitBounds.upload(bounds, st) || r->dTriBox.ensure(2 * (size_t)nt + 2) || r->dNodeBox.ensure(2 * r->bvh.nodes4.size()))
+        if (r->dRefitBounds.upload(bounds, st) || r->dTriBox.ensure(2 * (size_t)nt + 2) || r->dNodeBox.ensure(2 * r->bvh.nodesW.size()))
             return fail(LUMEN_MI_ERR_DEVICE, "refit buffer allocation failed");
     }
     if (hipStreamSynchronize(st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "scene upload sync failed");

@@ -260,6 +260,10 @@ class LumenRendererMI:
     def GetCounters(self, n=24):
         out = (C.c_uint64 * n)(); check(self.lib, self.lib.lumen_mi_get_counters(self.h, out, n)); return list(out)
 
+    def GetCounterTotals(self, n=50, reset=False):
+        """Counters summed over every TraceFrame since creation / the last reset (layout of GetCounters; [3] = TraceFrames summed)."""
+        out = (C.c_uint64 * n)(); check(self.lib, self.lib.lumen_mi_get_counter_totals(self.h, out, n, int(reset))); return list(out)
+
     def GetDenoiserInputs(self, min_distance=0.1, max_distance=1000.0):
         """(depth [h,w] f32, normal_roughness [h,w,4] f16 bits, motion [h,w,2] f16 bits) of the last frame's window."""
         h, w = self._window_shape(); n = h * w

@@ -43,7 +43,7 @@ struct Walk {
     std::vector<uint8_t> slotSeen, nodeSeen;
     std::vector<int> nodeDepth;
     int err = 0;
-    Walk(const LmBvh& bb, const float* t) : b(bb), tris(t), slotSeen(bb.order.size(), 0), nodeSeen(bb.nodes4.size(), 0), nodeDepth(bb.nodes4.size(), -1) {}
+    Walk(const LmBvh& bb, const float* t) : b(bb), tris(t), slotSeen(bb.order.size(), 0), nodeSeen(bb.nodesW.size(), 0), nodeDepth(bb.nodesW.size(), -1) {}
     // returns the exact box of the subtree in lo/hi and the worst-case stack occupancy below this reference
     uint32_t visit(int ref, int depth, double lo[3], double hi[3])
     {
@@ -58,14 +58,14 @@ struct Walk {
             }
             return 0;
         }
-        if ((size_t)ref >= b.nodes4.size()) { err = fail("node reference out of range", ref); return 0; }
+        if ((size_t)ref >= b.nodesW.size()) { err = fail("node reference out of range", ref); return 0; }
         if (nodeSeen[ref]++) { err = fail("node reachable twice", ref); return 0; }
         nodeDepth[ref] = depth;
         uint32_t present = 0, worst = 0;
-        for (int c = 0; c < 4; c++) present += (int)b.nodes4[ref].c[c].w != LM_REF_NONE;
+        for (int c = 0; c < 4; c++) present += (int)b.nodesW[ref].c[c].w != LM_REF_NONE;
         if (present == 0 && !(ref == 0 && b.order.empty())) { err = fail("inner node without children", ref); return 0; }
         for (int c = 0; c < 4 && !err; c++) {
-            const uint4 q = b.nodes4[ref].c[c];
+            const uint4 q = b.nodesW[ref].c[c];
             if ((int)q.w == LM_REF_NONE) continue;
             double clo[3], chi[3];
             const uint32_t below = visit((int)q.w, depth + 1, clo, chi);
@@ -89,7 +89,7 @@ int check(const LmBvh& b, const float* tris, uint32_t n, bool built = true)
     if (b.order.size() != n) return fail("order size", (long)b.order.size(), n);
     std::vector<uint8_t> seen(n, 0);
     for (uint32_t s = 0; s < n; s++) { if (b.order[s] >= n || seen[b.order[s]]++) return fail("order is not a permutation", s); }
-    if (b.nodes4.empty()) return fail("no root node");
+    if (b.nodesW.empty()) return fail("no root node");
     if (b.woop.size() != (size_t)n + 1) return fail("woop packet count", (long)b.woop.size());
     for (uint32_t s = 0; built && s < n; s++) {
         const LmWoop w = lm_make_woop(tris + 9 * (size_t)b.order[s]);
@@ -102,21 +102,21 @@ int check(const LmBvh& b, const float* tris, uint32_t n, bool built = true)
     const uint32_t worst = w.visit(0, 0, lo, hi);
     if (w.err) return 1;
     for (uint32_t s = 0; s < n; s++) if (!w.slotSeen[s]) return fail("slot in no leaf", s);
-    for (size_t i = 0; i < b.nodes4.size(); i++) if (!w.nodeSeen[i]) return fail("unreachable node", (long)i);
+    for (size_t i = 0; i < b.nodesW.size(); i++) if (!w.nodeSeen[i]) return fail("unreachable node", (long)i);
     if (b.maxStack < worst) return fail("maxStack below the worst case of the tree", b.maxStack, worst);
     if (b.maxStack > LM_STACK_DEPTH) return fail("tree needs more than LM_STACK_DEPTH", b.maxStack);
     // refit order: every node exactly once, the children of a node in an earlier (deeper) level
-    if (b.levelNodes.size() != b.nodes4.size() || b.levelStart.empty() || b.levelStart.back() != b.levelNodes.size()) return fail("level lists incomplete");
-    std::vector<int> levelOf(b.nodes4.size(), -1);
+    if (b.levelNodes.size() != b.nodesW.size() || b.levelStart.empty() || b.levelStart.back() != b.levelNodes.size()) return fail("level lists incomplete");
+    std::vector<int> levelOf(b.nodesW.size(), -1);
     for (size_t l = 0; l + 1 < b.levelStart.size(); l++)
         for (uint32_t i = b.levelStart[l]; i < b.levelStart[l + 1]; i++) {
             const uint32_t nd = b.levelNodes[i];
-            if (nd >= b.nodes4.size() || levelOf[nd] != -1) return fail("level list entry", nd);
+            if (nd >= b.nodesW.size() || levelOf[nd] != -1) return fail("level list entry", nd);
             levelOf[nd] = (int)l;
         }
-    for (size_t nd = 0; nd < b.nodes4.size(); nd++)
+    for (size_t nd = 0; nd < b.nodesW.size(); nd++)
         for (int c = 0; c < 4; c++) {
-            const int ref = (int)b.nodes4[nd].c[c].w;
+            const int ref = (int)b.nodesW[nd].c[c].w;
             if (ref >= 0 && ref != LM_REF_NONE && !(levelOf[ref] < levelOf[nd])) return fail("child not refitted before its parent", (long)nd, ref);
         }
     return 0;
@@ -125,7 +125,7 @@ int check(const LmBvh& b, const float* tris, uint32_t n, bool built = true)
 bool same(const LmBvh& a, const LmBvh& b)
 {
     auto eq = [](const auto& x, const auto& y) { return x.size() == y.size() && (x.empty() || memcmp(x.data(), y.data(), x.size() * sizeof(x[0])) == 0); };
-    return eq(a.nodes4, b.nodes4) && eq(a.order, b.order) && eq(a.woop, b.woop) && eq(a.levelNodes, b.levelNodes) && eq(a.levelStart, b.levelStart) &&
+    return eq(a.nodesW, b.nodesW) && eq(a.order, b.order) && eq(a.woop, b.woop) && eq(a.levelNodes, b.levelNodes) && eq(a.levelStart, b.levelStart) &&
            memcmp(a.qmin, b.qmin, sizeof a.qmin) == 0 && memcmp(a.qstep, b.qstep, sizeof a.qstep) == 0 && a.pad == b.pad && a.maxStack == b.maxStack && a.maxDepth == b.maxDepth;
 }
 
@@ -145,7 +145,7 @@ int main(int argc, char** argv)
         lm_build_bvh(t.data(), n, &many);
         if (check(one, t.data(), n) || check(many, t.data(), n)) return 1;
         if (!same(one, many)) return fail("the build depends on the thread count", n);
-        printf("ok %u triangles: %zu nodes, depth %u, stack %u\n", n, many.nodes4.size(), many.maxDepth, many.maxStack);
+        printf("ok %u triangles: %zu nodes, depth %u, stack %u\n", n, many.nodesW.size(), many.maxDepth, many.maxStack);
     }
     // instance-level assembly (lm_assemble_bvh): per-mesh trees + a top tree; topology only (boxes / packets come from the GPU refit)
     for (uint32_t nInst : {1u, 2u, 3u, 5u, 9u, 40u}) {
@@ -169,8 +169,8 @@ int main(int argc, char** argv)
         lm_assemble_bvh(inst.data(), nInst, &scene);
         const uint32_t n = (uint32_t)(world.size() / 9);
         if (check(scene, world.data(), n, false)) return 1;
-        if (scene.nodes4.size() > 0 && (int)scene.nodes4[0].c[0].w == LM_REF_NONE) return fail("assembled root has no child");
-        printf("ok assembly of %u instances: %u triangles, %zu nodes, depth %u, stack %u\n", nInst, n, scene.nodes4.size(), scene.maxDepth, scene.maxStack);
+        if (scene.nodesW.size() > 0 && (int)scene.nodesW[0].c[0].w == LM_REF_NONE) return fail("assembled root has no child");
+        printf("ok assembly of %u instances: %u triangles, %zu nodes, depth %u, stack %u\n", nInst, n, scene.nodesW.size(), scene.maxDepth, scene.maxStack);
     }
     return 0;
 }

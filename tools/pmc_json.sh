@@ -45,7 +45,13 @@ for k, v in out.items():
     if v.get("SQ_BUSY_CYCLES_per_launch"):
         # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs of the chip; SQ_BUSY_CYCLES is summed over the shader engines' SQs
         v["valu_quadcycles_per_launch"] = v.get("SQ_ACTIVE_INST_VALU_per_launch", 0.0)
-json.dump({"note": "per launch; counter passes serialise the dispatches (alone times); hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction, upper bound for gathers)",
+import hashlib, os
+def ksid():
+    h = hashlib.sha256(); d = "lumenrenderer_amd/csrc"
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")): h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+json.dump({"kernel_source_id": ksid(), "note": "per launch; counter passes serialise the dispatches (alone times); hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction, upper bound for gathers)",
            "kernels": out}, open(f"gpurun_out/{tag}/pmc.json", "w"), indent=1, sort_keys=True)
 tot = 0.0
 for k in sorted(out, key=lambda k: -out[k].get("alone_us", 0) * out[k]["launches"]):

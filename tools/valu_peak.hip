@@ -53,6 +53,57 @@ template <int MODE> __global__ void __launch_bounds__(256) k_valu(float* out, in
     out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
 }
 
+// Explicit-register variants (register numbers fixed in the asm, so that the VGPR bank of every operand is known: bank = index mod 4):
+//   10  v_fma_f32 vK, vK, v40, v41   K = 8..15   accumulators cycle through the banks, multiplier / addend in banks 0 and 1
+//   11  v_fma_f32 vK, vK, v40, v44               multiplier and addend in the SAME bank
+//   12  v_fma_f32 vK, vK, vK, vK                 one register per instruction
+//   13  v_mul_f32 vK, vK, v40                    two-source VOP2
+//   14  v_fma_f32 vK, vK, s4, v41                multiplier in an SGPR
+//   15  v_fma_f32 vK, vK, 0.5, 0.5               inline constants
+//   16  v_fma_f32 with K = 8, 12, 16, .. (all accumulators in bank 0), v41 (bank 1), v42 (bank 2): no instruction reads one bank twice
+//   17  as 10 but dependent pairs: each accumulator is used twice in a row
+template <int MODE> __global__ void __launch_bounds__(256) k_regs(float* out, int iters, float seed)
+{
+    float r = 0.f;
+    for (int it = 0; it < iters; it++) {
+#define REP8(X) X X X X X X X X
+        if constexpr (MODE == 10) asm volatile(REP8("v_fma_f32 v8, v8, v40, v41\n v_fma_f32 v9, v9, v40, v41\n v_fma_f32 v10, v10, v40, v41\n v_fma_f32 v11, v11, v40, v41\n"
+                                                    "v_fma_f32 v12, v12, v40, v41\n v_fma_f32 v13, v13, v40, v41\n v_fma_f32 v14, v14, v40, v41\n v_fma_f32 v15, v15, v40, v41\n") ::: "v8","v9","v10","v11","v12","v13","v14","v15","v40","v41");
+        else if constexpr (MODE == 11) asm volatile(REP8("v_fma_f32 v8, v8, v40, v44\n v_fma_f32 v9, v9, v40, v44\n v_fma_f32 v10, v10, v40, v44\n v_fma_f32 v11, v11, v40, v44\n"
+                                                    "v_fma_f32 v12, v12, v40, v44\n v_fma_f32 v13, v13, v40, v44\n v_fma_f32 v14, v14, v40, v44\n v_fma_f32 v15, v15, v40, v44\n") ::: "v8","v9","v10","v11","v12","v13","v14","v15","v40","v44");
+        else if constexpr (MODE == 12) asm volatile(REP8("v_fma_f32 v8, v8, v8, v8\n v_fma_f32 v9, v9, v9, v9\n v_fma_f32 v10, v10, v10, v10\n v_fma_f32 v11, v11, v11, v11\n"
+                                                    "v_fma_f32 v12, v12, v12, v12\n v_fma_f32 v13, v13, v13, v13\n v_fma_f32 v14, v14, v14, v14\n v_fma_f32 v15, v15, v15, v15\n") ::: "v8","v9","v10","v11","v12","v13","v14","v15");
+        else if constexpr (MODE == 13) asm volatile(REP8("v_mul_f32 v8, v8, v40\n v_mul_f32 v9, v9, v40\n v_mul_f32 v10, v10, v40\n v_mul_f32 v11, v11, v40\n"
+                                                    "v_mul_f32 v12, v12, v40\n v_mul_f32 v13, v13, v40\n v_mul_f32 v14, v14, v40\n v_mul_f32 v15, v15, v40\n") ::: "v8","v9","v10","v11","v12","v13","v14","v15","v40");
+        else if constexpr (MODE == 14) asm volatile(REP8("v_fma_f32 v8, v8, s4, v41\n v_fma_f32 v9, v9, s4, v41\n v_fma_f32 v10, v10, s4, v41\n v_fma_f32 v11, v11, s4, v41\n"
+                                                    "v_fma_f32 v12, v12, s4, v41\n v_fma_f32 v13, v13, s4, v41\n v_fma_f32 v14, v14, s4, v41\n v_fma_f32 v15, v15, s4, v41\n") ::: "v8","v9","v10","v11","v12","v13","v14","v15","v41","s4");
+        else if constexpr (MODE == 15) asm volatile(REP8("v_fma_f32 v8, v8, 0.5, 0.5\n v_fma_f32 v9, v9, 0.5, 0.5\n v_fma_f32 v10, v10, 0.5, 0.5\n v_fma_f32 v11, v11, 0.5, 0.5\n"
+                                                    "v_fma_f32 v12, v12, 0.5, 0.5\n v_fma_f32 v13, v13, 0.5, 0.5\n v_fma_f32 v14, v14, 0.5, 0.5\n v_fma_f32 v15, v15, 0.5, 0.5\n") ::: "v8","v9","v10","v11","v12","v13","v14","v15");
+        else if constexpr (MODE == 16) asm volatile(REP8("v_fma_f32 v8, v8, v41, v42\n v_fma_f32 v12, v12, v41, v42\n v_fma_f32 v16, v16, v41, v42\n v_fma_f32 v20, v20, v41, v42\n"
+                                                    "v_fma_f32 v24, v24, v41, v42\n v_fma_f32 v28, v28, v41, v42\n v_fma_f32 v32, v32, v41, v42\n v_fma_f32 v36, v36, v41, v42\n") ::: "v8","v12","v16","v20","v24","v28","v32","v36","v41","v42");
+        else asm volatile(REP8("v_fma_f32 v8, v8, v40, v41\n v_fma_f32 v8, v8, v40, v41\n v_fma_f32 v10, v10, v40, v41\n v_fma_f32 v10, v10, v40, v41\n"
+                               "v_fma_f32 v12, v12, v40, v41\n v_fma_f32 v12, v12, v40, v41\n v_fma_f32 v14, v14, v40, v41\n v_fma_f32 v14, v14, v40, v41\n") ::: "v8","v10","v12","v14","v40","v41");
+        asm volatile("v_mov_b32 %0, v8" : "=v"(r));
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = r + seed;
+}
+template <int MODE> static double run_regs(float* out, int blocks, int iters, int reps)
+{
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_regs<MODE>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.f);
+    CHECK(hipDeviceSynchronize());
+    std::vector<double> ms;
+    for (int r = 0; r < reps; r++) {
+        CHECK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k_regs<MODE>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.f);
+        CHECK(hipEventRecord(e1, 0));
+        CHECK(hipEventSynchronize(e1));
+        float t; CHECK(hipEventElapsedTime(&t, e0, e1)); ms.push_back(t);
+    }
+    std::sort(ms.begin(), ms.end());
+    return ms[ms.size() / 2];
+}
+
 template <int MODE> static double run(float* out, int blocks, int iters, int reps)
 {
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -92,6 +143,19 @@ int main()
             const double winst = instPerWave * waves / (ms * 1e-3);
             const double simds = cus * 4.0;
             printf("  %-34s %5d %10.3f %14.1f %14.2f %12.2f\n", names[mode], w, ms, winst * 1e-9, winst * 64 * 1e-12 * (mode == 2 ? 2 : 1), clockGHz * 1e9 * simds / winst);
+        }
+    }
+    const char* rnames[8] = {"fma vK,vK,v40,v41 (banks k,0,1)", "fma vK,vK,v40,v44 (banks k,0,0)", "fma vK,vK,vK,vK", "v_mul_f32 vK,vK,v40 (VOP2)",
+                             "fma vK,vK,s4,v41 (SGPR)", "fma vK,vK,0.5,0.5 (inline)", "fma v(4k),..,v41,v42 (banks 0,1,2)", "fma pairs (dependent in twos)"};
+    for (int mode = 10; mode < 18; mode++) {
+        for (int w : {1, 2, 4, 8}) {
+            const int blocks = cus * w;
+            double ms = 0;
+            switch (mode) { case 10: ms = run_regs<10>(out, blocks, iters, 7); break; case 11: ms = run_regs<11>(out, blocks, iters, 7); break; case 12: ms = run_regs<12>(out, blocks, iters, 7); break;
+                            case 13: ms = run_regs<13>(out, blocks, iters, 7); break; case 14: ms = run_regs<14>(out, blocks, iters, 7); break; case 15: ms = run_regs<15>(out, blocks, iters, 7); break;
+                            case 16: ms = run_regs<16>(out, blocks, iters, 7); break; default: ms = run_regs<17>(out, blocks, iters, 7); }
+            const double winst = (double)iters * 64 * blocks * 4 / (ms * 1e-3);
+            printf("  %-34s %5d %10.3f %14.1f %14.2f %12.2f\n", rnames[mode - 10], w, ms, winst * 1e-9, winst * 64 * 1e-12, clockGHz * 1e9 * cus * 4.0 / winst);
         }
     }
     printf("# lane-ops: one per lane per instruction (an FMA = 1; packed = 2).  fp32 FLOP/s = 2 x that for FMA.\n");
