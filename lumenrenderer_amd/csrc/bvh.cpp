@@ -495,7 +495,7 @@ void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out)
 void lm_assemble_bvh(const LmInstanceRef* inst, uint32_t nInst, LmBvh* out)
 {
     *out = LmBvh();
-    struct Top { int child[4]; int n; };                     // child >= 0: top node, < 0: ~instance
+    struct Top { int child[LM_WIDTH]; };                     // per slot: >= 0 top node, < 0 ~instance, LM_REF_NONE absent
     std::vector<Top> top;
     std::vector<uint32_t> ids(nInst);
     for (uint32_t i = 0; i < nInst; i++) ids[i] = i;
@@ -514,18 +514,30 @@ void lm_assemble_bvh(const LmInstanceRef* inst, uint32_t nInst, LmBvh* out)
         return mid;
     };
     struct Range { uint32_t lo, hi; };
-    // recursion depth is log4(nInst)
+    // a top node = its range halved at medians until there are LM_WIDTH groups (or only single instances); recursion depth log_W(nInst)
     std::function<int(uint32_t, uint32_t)> build = [&](uint32_t lo, uint32_t hi) -> int {
         if (hi - lo == 1u) return ~(int)ids[lo];
         const int me = (int)top.size();
-        top.push_back(Top{{0, 0, 0, 0}, 0});
-        Range g[4]; int ng = 0;
-        const uint32_t mid = splitHalf(lo, hi);
-        for (const Range& h : {Range{lo, mid}, Range{mid, hi}}) {
-            if (h.hi - h.lo >= 2u && hi - lo > 2u) { const uint32_t m = splitHalf(h.lo, h.hi); g[ng++] = Range{h.lo, m}; g[ng++] = Range{m, h.hi}; }
-            else if (h.hi > h.lo) g[ng++] = h;
+        top.push_back(Top{});
+        std::vector<Range> g{Range{lo, hi}};
+        while ((int)g.size() < LM_WIDTH) {
+            size_t pick = g.size(); uint32_t best = 1u;
+            for (size_t k = 0; k < g.size(); k++) if (g[k].hi - g[k].lo > best) { best = g[k].hi - g[k].lo; pick = k; }
+            if (pick == g.size()) break;
+            const uint32_t m = splitHalf(g[pick].lo, g[pick].hi);
+            const Range a{g[pick].lo, m}, b{m, g[pick].hi};
+            g[pick] = a; g.insert(g.begin() + (long)pick + 1, b);
         }
-        for (int k = 0; k < ng; k++) { const int c = build(g[k].lo, g[k].hi); top[(size_t)me].child[top[(size_t)me].n++] = c; }
+        float boxes[LM_WIDTH][6]; int slotOf[LM_WIDTH];
+        for (size_t k = 0; k < g.size(); k++) {
+            float lo3[3] = {INFINITY, INFINITY, INFINITY}, hi3[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (uint32_t i = g[k].lo; i < g[k].hi; i++) for (int a = 0; a < 3; a++) { lo3[a] = std::min(lo3[a], inst[ids[i]].box[a]); hi3[a] = std::max(hi3[a], inst[ids[i]].box[3 + a]); }
+            for (int a = 0; a < 3; a++) { boxes[k][2 * a] = lo3[a]; boxes[k][2 * a + 1] = hi3[a]; }
+        }
+        lm_assign_slots((int)g.size(), boxes, slotOf);
+        Top t; for (int s = 0; s < LM_WIDTH; s++) t.child[s] = LM_REF_NONE;
+        for (size_t k = 0; k < g.size(); k++) { const int c = build(g[k].lo, g[k].hi); t.child[slotOf[k]] = c; }
+        top[(size_t)me] = t;
         return me;
     };
     if (nInst == 0) { out->nodesW.assign(1, LmNodeW{}); for (auto& c : out->nodesW[0].c) c = make_uint4(LM_BOX_NONE, LM_BOX_NONE, LM_BOX_NONE, (uint32_t)LM_REF_NONE); }
@@ -538,9 +550,9 @@ void lm_assemble_bvh(const LmInstanceRef* inst, uint32_t nInst, LmBvh* out)
     out->order.resize(nSlots);
     for (uint32_t t = 0; t < T; t++) {
         LmNodeW q;
-        for (int k = 0; k < 4; k++) {
-            if (k >= top[t].n) { q.c[k] = make_uint4(LM_BOX_NONE, LM_BOX_NONE, LM_BOX_NONE, (uint32_t)LM_REF_NONE); continue; }
+        for (int k = 0; k < LM_WIDTH; k++) {
             const int c = top[t].child[k];
+            if (c == LM_REF_NONE) { q.c[k] = make_uint4(LM_BOX_NONE, LM_BOX_NONE, LM_BOX_NONE, (uint32_t)LM_REF_NONE); continue; }
             q.c[k] = make_uint4(0u, 0u, 0u, (uint32_t)(c >= 0 ? c : (int)nodeBase[(uint32_t)(~c)]));
         }
         out->nodesW[t] = q;

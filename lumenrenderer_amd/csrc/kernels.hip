@@ -162,7 +162,7 @@ KN(lm_k_trace_closest)(LmScene sc, const float4* __restrict__ rayO /* NULL: ever
                    const uint32_t* __restrict__ countPtr, uint4* __restrict__ hits, float tmin, float tmax, uint32_t* counters, int refillBelow, float4 eye)
 {
     __shared__ int s_stack[LM_STACK_LDS * LM_BLOCK];
-    __shared__ uint4 s_top[4 * LM_TOP_NODES + 1];
+    __shared__ uint4 s_top[LM_WIDTH * LM_TOP_NODES + 1];
     const uint32_t n = *countPtr;
     lm_trace_queue<false>(sc, n, refillBelow, lm_make_stack(s_stack, sc), lm_stage_top(s_top, sc), counters,
         [&](uint32_t i, lf3& o, lf3& d, float& t0, float& t1) { o = rayO ? v3(rayO[i]) : v3(eye); d = v3(rayD[i]); t0 = tmin; t1 = tmax; },
@@ -184,7 +184,7 @@ KN(lm_k_trace_closest_packet)(LmScene sc, const float4* __restrict__ rayO, const
                           uint4* __restrict__ hits, float tmin, float tmax, float4 eye)
 {
     __shared__ int s_wstack[LM_PACKET_STACK * (LM_BLOCK / 64)];
-    __shared__ uint4 s_top[4 * LM_TOP_NODES + 1];
+    __shared__ uint4 s_top[LM_WIDTH * LM_TOP_NODES + 1];
     const uint32_t n = *countPtr;
     lm_trace_packets<false>(sc, n, (lm_lds_int*)(s_wstack + LM_PACKET_STACK * (threadIdx.x >> 6)), lm_stage_top(s_top, sc),
         [&](uint32_t i, lf3& o, lf3& d, float& t0, float& t1) { o = rayO ? v3(rayO[i]) : v3(eye); d = v3(rayD[i]); t0 = tmin; t1 = tmax; },
@@ -394,7 +394,7 @@ extern "C" __global__ void __launch_bounds__(LM_BLOCK)
 KN(lm_k_trace_shadow)(LmScene sc, LmFrame fr, const uint32_t* __restrict__ countPtr, float tmin, int refillBelow)
 {
     __shared__ int s_stack[LM_STACK_LDS * LM_BLOCK];
-    __shared__ uint4 s_top[4 * LM_TOP_NODES + 1];
+    __shared__ uint4 s_top[LM_WIDTH * LM_TOP_NODES + 1];
     const uint32_t n = *countPtr;
     lm_trace_queue<true>(sc, n, refillBelow, lm_make_stack(s_stack, sc), lm_stage_top(s_top, sc), fr.counters,
         [&](uint32_t i, lf3& o, lf3& d, float& t0, float& t1) { const float4 o4 = fr.shO[i]; o = v3(o4); d = v3(fr.shD[i]); t0 = tmin; t1 = o4.w; },
@@ -424,7 +424,7 @@ KN(lm_k_restir_trace_shade)(LmScene sc, LmFrame fr, int rc, const uint32_t* __re
 {
     rc = lm_res_idx(fr, rc);
     __shared__ int s_stack[LM_STACK_LDS * LM_BLOCK];
-    __shared__ uint4 s_top[4 * LM_TOP_NODES + 1];
+    __shared__ uint4 s_top[LM_WIDTH * LM_TOP_NODES + 1];
     const uint32_t n = *countPtr;
     float4* hot = fr.res[rc];
     const float4* __restrict__ qO = pass ? fr.vis2O : fr.visO;
@@ -1198,7 +1198,7 @@ KN(lm_k_refit_level)(LmScene sc, const uint32_t* __restrict__ levelNodes, uint32
     const uint32_t n = levelNodes[i];
     const float pad = sc.quant[6];
     lf3 nlo = v3(INFINITY), nhi = v3(-INFINITY);
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < LM_WIDTH; k++) {
         uint4 c = sc.nodes[n].c[k];
         const int ref = (int)c.w;
         if (ref == LM_REF_NONE) continue;
@@ -1298,14 +1298,14 @@ extern "C" __global__ void KN(lm_k_build_top)(const LmNodeW* __restrict__ nodes,
             uint32_t inner = 0;
             if (valid) {
                 nd = nodes[s_src[s]];
-                for (int j = 0; j < 4; j++) inner += ((int)nd.c[j].w >= 0 && (int)nd.c[j].w != LM_REF_NONE) ? 1u : 0u;
+                for (int j = 0; j < LM_WIDTH; j++) inner += ((int)nd.c[j].w >= 0 && (int)nd.c[j].w != LM_REF_NONE) ? 1u : 0u;
             }
             uint32_t prefix = inner;                                      // inclusive scan over the wavefront
             for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(prefix, o); if ((int)lane >= o) prefix += v; }
             const uint32_t total = __shfl(prefix, 63);
             uint32_t slot = count + prefix - inner;
             if (valid) {
-                for (int j = 0; j < 4; j++) {
+                for (int j = 0; j < LM_WIDTH; j++) {
                     const int ref = (int)nd.c[j].w;
                     if (ref < 0 || ref == LM_REF_NONE) continue;
                     if (slot < (uint32_t)LM_TOP_NODES) { s_src[slot] = ref; nd.c[j].w = (uint32_t)(LM_TOP_BASE + (int)slot); }

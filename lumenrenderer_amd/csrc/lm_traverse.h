@@ -21,7 +21,7 @@ struct LmStack { lm_lds_int* lds; int* spill; };
 __device__ __forceinline__ lm_lds_u4* lm_stage_top(uint4* s_top, const LmScene& sc)
 {
 #if LM_TOP_NODES
-    for (uint32_t i = threadIdx.x; i < 4u * LM_TOP_NODES; i += LM_BLOCK) s_top[i] = ((const uint4*)sc.top)[i];
+    for (uint32_t i = threadIdx.x; i < (uint32_t)(LM_WIDTH * LM_TOP_NODES); i += LM_BLOCK) s_top[i] = ((const uint4*)sc.top)[i];
     __syncthreads();
     return (lm_lds_u4*)s_top;
 #else
@@ -101,7 +101,14 @@ typedef float lm_f2 __attribute__((ext_vector_type(2)));
                              //    covers (LM_QUANT_MARGIN: bvh.cpp `quant`, kernels.hip lm_quant_axis)
 #endif
 // t = q * a + b per axis (dequantisation folded into the slab test); variant 3 keeps (a, b - 2^23 a) as a pair and the two byte selectors per axis
-struct LmRayQ { lm_f2 x, y, z; uint32_t nx, fx, ny, fy, nz, fz; };
+#ifndef LM_PERM_VGPR
+#define LM_PERM_VGPR 0       // 1: the exponent word 0x4b000000 of the slab test's permutes sits in a VGPR instead of an SGPR.  profiles/r03_valu_peak.txt: a VOP3
+#endif                       // instruction with an SGPR source issues at 4.2 cycles per SIMD, with VGPR / inline-constant sources at 2.4; six permutes per child box
+struct LmRayQ { lm_f2 x, y, z; uint32_t nx, fx, ny, fy, nz, fz;
+#if LM_PERM_VGPR
+                uint32_t k23;
+#endif
+                uint32_t oct; };     // 8-wide tree: (direction octant) << 4 = byte offset of the slot a ray visits first; slot of visit p = p ^ octant
 __device__ __forceinline__ void lm_ray_setup(const LmScene& sc, const lf3& o, const lf3& d, LmRayQ& r)
 {
     const float idx = lm_safe_rcp(d.x), idy = lm_safe_rcp(d.y), idz = lm_safe_rcp(d.z);
@@ -120,6 +127,10 @@ __device__ __forceinline__ void lm_ray_setup(const LmScene& sc, const lf3& o, co
     r.nx = ax < 0.f ? 0x01000302u : 0x03020100u; r.ny = ay < 0.f ? 0x01000302u : 0x03020100u; r.nz = az < 0.f ? 0x01000302u : 0x03020100u;
     r.fx = r.fy = r.fz = 0u;
 #endif
+#if LM_PERM_VGPR
+    r.k23 = 0x4b000000u; asm volatile("" : "+v"(r.k23));           // opaque to the compiler: stays a VGPR
+#endif
+    r.oct = ((d.x < 0.f ? 1u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 4u : 0u)) << 4;
 }
 // Slab test of one quantised child box against [tmin, hitT]: key = entry distance (its bit pattern orders like the value: tn >= tmin >= 0), or
 // 0xffffffff for a miss.  An absent child carries an inverted box (lo = 0xffff, hi = 0: near > far on every axis), so it misses without a test.
@@ -129,9 +140,14 @@ __device__ __forceinline__ void lm_slab(const uint4& q, const LmRayQ& r, float t
     // t is monotonic in q (fma rounds monotonically), rising for a >= 0 and falling for a < 0, so the smaller of the two plane distances is the
     // lo plane's for a >= 0 and the hi plane's otherwise
     lm_f2 px, py, pz, tx, ty, tz;
-    px.x = u2f(__builtin_amdgcn_perm(0x4b000000u, q.x, r.nx)); px.y = u2f(__builtin_amdgcn_perm(0x4b000000u, q.x, r.fx));
-    py.x = u2f(__builtin_amdgcn_perm(0x4b000000u, q.y, r.ny)); py.y = u2f(__builtin_amdgcn_perm(0x4b000000u, q.y, r.fy));
-    pz.x = u2f(__builtin_amdgcn_perm(0x4b000000u, q.z, r.nz)); pz.y = u2f(__builtin_amdgcn_perm(0x4b000000u, q.z, r.fz));
+#if LM_PERM_VGPR
+    const uint32_t e = r.k23;
+#else
+    const uint32_t e = 0x4b000000u;
+#endif
+    px.x = u2f(__builtin_amdgcn_perm(e, q.x, r.nx)); px.y = u2f(__builtin_amdgcn_perm(e, q.x, r.fx));
+    py.x = u2f(__builtin_amdgcn_perm(e, q.y, r.ny)); py.y = u2f(__builtin_amdgcn_perm(e, q.y, r.fy));
+    pz.x = u2f(__builtin_amdgcn_perm(e, q.z, r.nz)); pz.y = u2f(__builtin_amdgcn_perm(e, q.z, r.fz));
     // (near, far) * a + b': source 0 by halves, source 1 = the pair's low word for both results, source 2 = its high word for both
     asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(tx) : "v"(px), "v"(r.x));
     asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(ty) : "v"(py), "v"(r.y));
@@ -165,6 +181,55 @@ __device__ __forceinline__ void lm_cex(uint32_t& ka, int& ra, uint32_t& kb, int&
     const int r0 = sw ? rb : ra, r1 = sw ? ra : rb;
     ka = k0; kb = k1; ra = r0; rb = r1;
 }
+#if LM_WIDTH == 8
+// 8-wide node step.  The eight child records are fetched in the ray's VISITING order — record p from octant slot p ^ octant(direction): a
+// per-lane address inside the node's one 128-byte line — so everything behind the loads is compile-time ordered: p = 0 is the child
+// nearest along the ray, p = 7 the farthest.  No sorting network: every hit child is pushed far to near, and the nearest, which ends on top,
+// is taken back at once.  The pushes of the common case are unconditional LDS stores whose stack pointer only advances for a hit (no
+// branches); a lane whose LDS share of the stack could overflow within this step takes the branching lm_push path.
+template <bool ANY>
+__device__ __forceinline__ int lm_node_step(const LmScene& sc, int cur, const LmRayQ& rq, float tmin, float hitT, const LmStack& stack, int& sp,
+                                            const lm_lds_u4* top, uint32_t* boxes = nullptr)
+{
+    uint4 q[8];
+#if LM_TOP_NODES
+    if (cur >= LM_TOP_BASE) {                                    // (only kernels that staged the table ever hold such a reference)
+        const uint32_t off = ((uint32_t)(cur - LM_TOP_BASE) << 7) | rq.oct;
+        typedef __attribute__((address_space(3))) char lm_lds_char;
+        const lm_lds_char* tb = (const lm_lds_char*)top;
+#pragma unroll
+        for (int p = 0; p < 8; p++) q[p] = lm_lds_read4((const lm_lds_u4*)(tb + (off ^ ((uint32_t)p << 4))));
+    } else
+#endif
+    {
+        const uint32_t off = ((uint32_t)cur << 7) | rq.oct;
+        const char* nb = (const char*)sc.nodes;
+#pragma unroll
+        for (int p = 0; p < 8; p++) q[p] = *(const uint4*)(nb + (off ^ ((uint32_t)p << 4)));
+    }
+    if (boxes) { for (int p = 0; p < 8; p++) *boxes += (int)q[p].w != LM_REF_NONE; }      // counting build
+    uint32_t k[8];
+#pragma unroll
+    for (int p = 0; p < 8; p++) lm_slab(q[p], rq, tmin, hitT, k[p]);
+    int next = LM_REF_NONE;
+    if (sp + 8 <= LM_STACK_LDS) {
+        lm_lds_int* sl = stack.lds + sp * LM_BLOCK;
+#pragma unroll
+        for (int p = 7; p >= 0; p--) {
+            const bool h = k[p] != 0xffffffffu;
+            *sl = (int)q[p].w;                                   // overwritten by the next store unless this child is hit
+            sl += h ? LM_BLOCK : 0; sp += h ? 1 : 0;
+            next = h ? (int)q[p].w : next;
+        }
+    } else {
+#pragma unroll
+        for (int p = 7; p >= 0; p--) if (k[p] != 0xffffffffu) { lm_push(stack, sp, (int)q[p].w); next = (int)q[p].w; }
+    }
+    if (next == LM_REF_NONE) return sp == 0 ? LM_REF_NONE : lm_pop(stack, sp);
+    --sp;                                                        // the nearest hit child is on top: continue with it
+    return next;
+}
+#else
 template <bool ANY>
 __device__ __forceinline__ int lm_node_step(const LmScene& sc, int cur, const LmRayQ& rq, float tmin, float hitT, const LmStack& stack, int& sp,
                                             const lm_lds_u4* top, uint32_t* boxes = nullptr)
@@ -255,6 +320,7 @@ __device__ __forceinline__ int lm_node_eval(const LmScene& sc, uint4& q0, uint4&
     if (h1 && h0) lm_push(stack, sp, r1);
     return next;
 }
+#endif   // LM_WIDTH
 
 template <bool ANY>
 __device__ __forceinline__ bool lm_traverse(const LmScene& sc, const lf3& o, const lf3& d, float tmin, float tmax,
@@ -408,7 +474,7 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
 #if LM_NODE_EXIT
             const int roundLanes = (int)__popcll(__ballot(true));
 #endif
-#if LM_NODE_PIPELINE && !LM_INSTRUMENT
+#if LM_NODE_PIPELINE && !LM_INSTRUMENT && LM_WIDTH == 4
             bool pre = false;                                        // nq0..nq3 hold the records of `cur` (only inside this loop: a lane that
             uint4 nq0, nq1, nq2, nq3;                                // leaves it with a prefetched node fetches it again on re-entry)
 #endif
@@ -427,7 +493,7 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
                 { const unsigned long long m = __ballot(true);           // lane occupancy of this node-step issue
                   if ((int)lane == __ffsll((long long)m) - 1) { atomicAdd((unsigned long long*)(cnt + LM_CNT_OCC), (unsigned long long)__popcll(m)); atomicAdd((unsigned long long*)(cnt + LM_CNT_OCC + 2), 64ull); } }
                 cur = lm_node_step<ANY>(sc, cur, rq, tmin, hitT, stack, sp, top, &nNodes);      // + child boxes tested
-#elif LM_NODE_PIPELINE
+#elif LM_NODE_PIPELINE && LM_WIDTH == 4
                 if (!pre) lm_node_fetch(sc, cur, top, nq0, nq1, nq2, nq3);
                 cur = lm_node_eval<ANY>(sc, nq0, nq1, nq2, nq3, pre, rq, tmin, hitT, stack, sp, top);
 #else
@@ -480,7 +546,7 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
 // visiting the union of the lanes' nodes.  The hit rule is order independent (minimum t, then lowest global triangle index), so the
 // hit records are those of lm_trace_queue bit for bit.
 // ---------------------------------------------------------------------------------------------------------------------
-#define LM_PACKET_STACK 64       // shared stack entries per wavefront (= LM_STACK_DEPTH: the builder bounds the tree by it)
+#define LM_PACKET_STACK LM_STACK_DEPTH       // shared stack entries per wavefront (the builder bounds the tree by it)
 __device__ __forceinline__ void lm_sort2u(uint32_t& ka, int& ra, uint32_t& kb, int& rb) { if (kb < ka) { const uint32_t k = ka; ka = kb; kb = k; const int r = ra; ra = rb; rb = r; } }
 template <bool ANY, class Fetch, class Done>
 __device__ __forceinline__ void lm_trace_packets(const LmScene& sc, uint32_t n, lm_lds_int* wstack, const lm_lds_u4* top, Fetch fetch, Done done)
@@ -503,6 +569,52 @@ __device__ __forceinline__ void lm_trace_packets(const LmScene& sc, uint32_t n, 
         int sp = 0, cur = root;                                    // wave-uniform
         for (;;) {
             cur = __builtin_amdgcn_readfirstlane(cur);
+#if LM_WIDTH == 8
+            if (cur >= 0) {
+                // the wave visits the children in the octant order of its first ray (the rays of an 8 x 8 pixel tile almost always share
+                // their octant; where they do not the order is merely less near-to-far for some lanes): no distances, no sorting
+                const uint32_t uoct = (uint32_t)__builtin_amdgcn_readfirstlane((int)rq.oct) >> 4;
+                uint4 q[8];
+#if LM_TOP_NODES
+                if (cur >= LM_TOP_BASE) {
+                    const lm_lds_u4* nd = top + 8u * (uint32_t)(cur - LM_TOP_BASE);
+#pragma unroll
+                    for (uint32_t p = 0; p < 8u; p++) q[p] = lm_lds_read4(nd + (p ^ uoct));
+                } else
+#endif
+                {
+                    const uint4* nd = sc.nodes[cur].c;
+#pragma unroll
+                    for (uint32_t p = 0; p < 8u; p++) q[p] = nd[p ^ uoct];
+                }
+                uint32_t hits = 0u;                                   // bit p: some lane enters visit p's child (wave-uniform)
+                int refs[8];
+#pragma unroll
+                for (int p = 0; p < 8; p++) {
+                    uint32_t k;
+                    lm_slab(q[p], rq, tmin, hitT, k);
+                    hits |= __ballot(k != 0xffffffffu) != 0ull ? 1u << p : 0u;
+                    refs[p] = __builtin_amdgcn_readfirstlane((int)q[p].w);
+                }
+                if (hits == 0u) {
+                    if (sp == 0) break;
+                    cur = wstack[--sp];
+                    continue;
+                }
+                const int first = __ffs((int)hits) - 1;
+                if (lane == 0u) {                                  // far children first: the nearest is followed, the next nearest popped first
+                    int s = sp;
+#pragma unroll
+                    for (int p = 7; p >= 1; p--) if (((hits >> p) & 1u) && p > first) wstack[s++] = refs[p];
+                }
+                sp += (int)__popc(hits) - 1;
+                int nx = refs[7];
+#pragma unroll
+                for (int p = 6; p >= 0; p--) nx = ((hits >> p) & 1u) ? refs[p] : nx;
+                cur = nx;
+                continue;
+            }
+#else
             if (cur >= 0) {
                 uint4 q0, q1, q2, q3;
 #if LM_TOP_NODES
@@ -540,6 +652,7 @@ __device__ __forceinline__ void lm_trace_packets(const LmScene& sc, uint32_t n, 
                 cur = r0;
                 continue;
             }
+#endif   // LM_WIDTH
             // leaf: every lane tests its ray against the leaf's triangles (a lane that cannot hit any more has hitT < tmin and fails the interval test)
             const uint32_t leaf = (uint32_t)(~cur);
             const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;

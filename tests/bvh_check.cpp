@@ -62,9 +62,9 @@ struct Walk {
         if (nodeSeen[ref]++) { err = fail("node reachable twice", ref); return 0; }
         nodeDepth[ref] = depth;
         uint32_t present = 0, worst = 0;
-        for (int c = 0; c < 4; c++) present += (int)b.nodesW[ref].c[c].w != LM_REF_NONE;
+        for (int c = 0; c < LM_WIDTH; c++) present += (int)b.nodesW[ref].c[c].w != LM_REF_NONE;
         if (present == 0 && !(ref == 0 && b.order.empty())) { err = fail("inner node without children", ref); return 0; }
-        for (int c = 0; c < 4 && !err; c++) {
+        for (int c = 0; c < LM_WIDTH && !err; c++) {
             const uint4 q = b.nodesW[ref].c[c];
             if ((int)q.w == LM_REF_NONE) continue;
             double clo[3], chi[3];
@@ -115,7 +115,7 @@ int check(const LmBvh& b, const float* tris, uint32_t n, bool built = true)
             levelOf[nd] = (int)l;
         }
     for (size_t nd = 0; nd < b.nodesW.size(); nd++)
-        for (int c = 0; c < 4; c++) {
+        for (int c = 0; c < LM_WIDTH; c++) {
             const int ref = (int)b.nodesW[nd].c[c].w;
             if (ref >= 0 && ref != LM_REF_NONE && !(levelOf[ref] < levelOf[nd])) return fail("child not refitted before its parent", (long)nd, ref);
         }
@@ -169,7 +169,8 @@ int main(int argc, char** argv)
         lm_assemble_bvh(inst.data(), nInst, &scene);
         const uint32_t n = (uint32_t)(world.size() / 9);
         if (check(scene, world.data(), n, false)) return 1;
-        if (scene.nodesW.size() > 0 && (int)scene.nodesW[0].c[0].w == LM_REF_NONE) return fail("assembled root has no child");
+        { bool any = false; for (int c = 0; c < LM_WIDTH; c++) any |= (int)scene.nodesW[0].c[c].w != LM_REF_NONE;     // (8-wide: children sit in octant slots, slot 0 may be empty)
+          if (scene.nodesW.size() > 0 && !any) return fail("assembled root has no child"); }
         printf("ok assembly of %u instances: %u triangles, %zu nodes, depth %u, stack %u\n", nInst, n, scene.nodesW.size(), scene.maxDepth, scene.maxStack);
     }
     return 0;

@@ -81,7 +81,23 @@ template <int MODE> __global__ void __launch_bounds__(256) k_regs(float* out, in
                                                     "v_fma_f32 v12, v12, 0.5, 0.5\n v_fma_f32 v13, v13, 0.5, 0.5\n v_fma_f32 v14, v14, 0.5, 0.5\n v_fma_f32 v15, v15, 0.5, 0.5\n") ::: "v8","v9","v10","v11","v12","v13","v14","v15");
         else if constexpr (MODE == 16) asm volatile(REP8("v_fma_f32 v8, v8, v41, v42\n v_fma_f32 v12, v12, v41, v42\n v_fma_f32 v16, v16, v41, v42\n v_fma_f32 v20, v20, v41, v42\n"
                                                     "v_fma_f32 v24, v24, v41, v42\n v_fma_f32 v28, v28, v41, v42\n v_fma_f32 v32, v32, v41, v42\n v_fma_f32 v36, v36, v41, v42\n") ::: "v8","v12","v16","v20","v24","v28","v32","v36","v41","v42");
-        else asm volatile(REP8("v_fma_f32 v8, v8, v40, v41\n v_fma_f32 v8, v8, v40, v41\n v_fma_f32 v10, v10, v40, v41\n v_fma_f32 v10, v10, v40, v41\n"
+        else if constexpr (MODE == 18) asm volatile(REP8("v_fmaak_f32 v8, v8, v40, 0x3f7fbe77\n v_fmaak_f32 v9, v9, v40, 0x3f7fbe77\n v_fmaak_f32 v10, v10, v40, 0x3f7fbe77\n v_fmaak_f32 v11, v11, v40, 0x3f7fbe77\n"
+                                                    "v_fmaak_f32 v12, v12, v40, 0x3f7fbe77\n v_fmaak_f32 v13, v13, v40, 0x3f7fbe77\n v_fmaak_f32 v14, v14, v40, 0x3f7fbe77\n v_fmaak_f32 v15, v15, v40, 0x3f7fbe77\n") ::: "v8","v9","v10","v11","v12","v13","v14","v15","v40");
+        else if constexpr (MODE == 19) asm volatile(REP8("v_mul_f32_e32 v8, s4, v8\n v_mul_f32_e32 v9, s4, v9\n v_mul_f32_e32 v10, s4, v10\n v_mul_f32_e32 v11, s4, v11\n"
+                                                    "v_mul_f32_e32 v12, s4, v12\n v_mul_f32_e32 v13, s4, v13\n v_mul_f32_e32 v14, s4, v14\n v_mul_f32_e32 v15, s4, v15\n") ::: "v8","v9","v10","v11","v12","v13","v14","v15","s4");
+        else if constexpr (MODE == 20) asm volatile(REP8("v_mul_f32_e32 v8, 0x3f7fbe77, v8\n v_mul_f32_e32 v9, 0x3f7fbe77, v9\n v_mul_f32_e32 v10, 0x3f7fbe77, v10\n v_mul_f32_e32 v11, 0x3f7fbe77, v11\n"
+                                                    "v_mul_f32_e32 v12, 0x3f7fbe77, v12\n v_mul_f32_e32 v13, 0x3f7fbe77, v13\n v_mul_f32_e32 v14, 0x3f7fbe77, v14\n v_mul_f32_e32 v15, 0x3f7fbe77, v15\n") ::: "v8","v9","v10","v11","v12","v13","v14","v15");
+        else if constexpr (MODE == 21) asm volatile(REP8("v_perm_b32 v8, s4, v8, v40\n v_perm_b32 v9, s4, v9, v40\n v_perm_b32 v10, s4, v10, v40\n v_perm_b32 v11, s4, v11, v40\n"
+                                                    "v_perm_b32 v12, s4, v12, v40\n v_perm_b32 v13, s4, v13, v40\n v_perm_b32 v14, s4, v14, v40\n v_perm_b32 v15, s4, v15, v40\n") ::: "v8","v9","v10","v11","v12","v13","v14","v15","v40","s4");
+        else if constexpr (MODE == 22) asm volatile(REP8("v_perm_b32 v8, v41, v8, v40\n v_perm_b32 v9, v41, v9, v40\n v_perm_b32 v10, v41, v10, v40\n v_perm_b32 v11, v41, v11, v40\n"
+                                                    "v_perm_b32 v12, v41, v12, v40\n v_perm_b32 v13, v41, v13, v40\n v_perm_b32 v14, v41, v14, v40\n v_perm_b32 v15, v41, v15, v40\n") ::: "v8","v9","v10","v11","v12","v13","v14","v15","v40","v41");
+        else if constexpr (MODE == 23) asm volatile(REP8("v_cndmask_b32_e64 v8, v8, v40, s[4:5]\n v_cndmask_b32_e64 v9, v9, v40, s[4:5]\n v_cndmask_b32_e64 v10, v10, v40, s[4:5]\n v_cndmask_b32_e64 v11, v11, v40, s[4:5]\n"
+                                                    "v_cndmask_b32_e64 v12, v12, v40, s[4:5]\n v_cndmask_b32_e64 v13, v13, v40, s[4:5]\n v_cndmask_b32_e64 v14, v14, v40, s[4:5]\n v_cndmask_b32_e64 v15, v15, v40, s[4:5]\n") ::: "v8","v9","v10","v11","v12","v13","v14","v15","v40","s4","s5");
+        else if constexpr (MODE == 24) asm volatile(REP8("v_cmp_lt_f32_e64 s[4:5], v8, v40\n v_cmp_lt_f32_e64 s[6:7], v9, v40\n v_cmp_lt_f32_e64 s[4:5], v10, v40\n v_cmp_lt_f32_e64 s[6:7], v11, v40\n"
+                                                    "v_cmp_lt_f32_e64 s[4:5], v12, v40\n v_cmp_lt_f32_e64 s[6:7], v13, v40\n v_cmp_lt_f32_e64 s[4:5], v14, v40\n v_cmp_lt_f32_e64 s[6:7], v15, v40\n") ::: "v8","v9","v10","v11","v12","v13","v14","v15","v40","s4","s5","s6","s7");
+        else if constexpr (MODE == 25) asm volatile(REP8("v_max3_f32 v8, v8, v40, v41\n v_max3_f32 v9, v9, v40, v41\n v_max3_f32 v10, v10, v40, v41\n v_max3_f32 v11, v11, v40, v41\n"
+                                                    "v_max3_f32 v12, v12, v40, v41\n v_max3_f32 v13, v13, v40, v41\n v_max3_f32 v14, v14, v40, v41\n v_max3_f32 v15, v15, v40, v41\n") ::: "v8","v9","v10","v11","v12","v13","v14","v15","v40","v41");
+        else if constexpr (MODE == 17) asm volatile(REP8("v_fma_f32 v8, v8, v40, v41\n v_fma_f32 v8, v8, v40, v41\n v_fma_f32 v10, v10, v40, v41\n v_fma_f32 v10, v10, v40, v41\n"
                                "v_fma_f32 v12, v12, v40, v41\n v_fma_f32 v12, v12, v40, v41\n v_fma_f32 v14, v14, v40, v41\n v_fma_f32 v14, v14, v40, v41\n") ::: "v8","v10","v12","v14","v40","v41");
         asm volatile("v_mov_b32 %0, v8" : "=v"(r));
     }
@@ -145,15 +161,20 @@ int main()
             printf("  %-34s %5d %10.3f %14.1f %14.2f %12.2f\n", names[mode], w, ms, winst * 1e-9, winst * 64 * 1e-12 * (mode == 2 ? 2 : 1), clockGHz * 1e9 * simds / winst);
         }
     }
-    const char* rnames[8] = {"fma vK,vK,v40,v41 (banks k,0,1)", "fma vK,vK,v40,v44 (banks k,0,0)", "fma vK,vK,vK,vK", "v_mul_f32 vK,vK,v40 (VOP2)",
-                             "fma vK,vK,s4,v41 (SGPR)", "fma vK,vK,0.5,0.5 (inline)", "fma v(4k),..,v41,v42 (banks 0,1,2)", "fma pairs (dependent in twos)"};
-    for (int mode = 10; mode < 18; mode++) {
+    const char* rnames[16] = {"fma vK,vK,v40,v41 (banks k,0,1)", "fma vK,vK,v40,v44 (banks k,0,0)", "fma vK,vK,vK,vK", "v_mul_f32 vK,vK,v40 (VOP2)",
+                             "fma vK,vK,s4,v41 (SGPR)", "fma vK,vK,0.5,0.5 (inline)", "fma v(4k),..,v41,v42 (banks 0,1,2)", "fma pairs (dependent in twos)",
+                             "v_fmaak_f32 vK,vK,v40,literal", "v_mul_f32_e32 vK,s4,vK (VOP2 SGPR)", "v_mul_f32_e32 vK,literal,vK", "v_perm_b32 vK,s4,vK,v40", "v_perm_b32 vK,v41,vK,v40",
+                             "v_cndmask_b32 vK,vK,v40,s[4:5]", "v_cmp_lt_f32 s[..],vK,v40", "v_max3_f32 vK,vK,v40,v41"};
+    for (int mode = 10; mode < 26; mode++) {
         for (int w : {1, 2, 4, 8}) {
             const int blocks = cus * w;
             double ms = 0;
             switch (mode) { case 10: ms = run_regs<10>(out, blocks, iters, 7); break; case 11: ms = run_regs<11>(out, blocks, iters, 7); break; case 12: ms = run_regs<12>(out, blocks, iters, 7); break;
                             case 13: ms = run_regs<13>(out, blocks, iters, 7); break; case 14: ms = run_regs<14>(out, blocks, iters, 7); break; case 15: ms = run_regs<15>(out, blocks, iters, 7); break;
-                            case 16: ms = run_regs<16>(out, blocks, iters, 7); break; default: ms = run_regs<17>(out, blocks, iters, 7); }
+                            case 16: ms = run_regs<16>(out, blocks, iters, 7); break; case 17: ms = run_regs<17>(out, blocks, iters, 7); break;
+                            case 18: ms = run_regs<18>(out, blocks, iters, 7); break; case 19: ms = run_regs<19>(out, blocks, iters, 7); break; case 20: ms = run_regs<20>(out, blocks, iters, 7); break;
+                            case 21: ms = run_regs<21>(out, blocks, iters, 7); break; case 22: ms = run_regs<22>(out, blocks, iters, 7); break; case 23: ms = run_regs<23>(out, blocks, iters, 7); break;
+                            case 24: ms = run_regs<24>(out, blocks, iters, 7); break; default: ms = run_regs<25>(out, blocks, iters, 7); }
             const double winst = (double)iters * 64 * blocks * 4 / (ms * 1e-3);
             printf("  %-34s %5d %10.3f %14.1f %14.2f %12.2f\n", rnames[mode - 10], w, ms, winst * 1e-9, winst * 64 * 1e-12, clockGHz * 1e9 * cus * 4.0 / winst);
         }
