@@ -160,7 +160,10 @@ int lumen_mi_set_instrumented(lumen_mi_renderer*, int enable);   /* use the node
  * the wave stream), "wave_streams" (1, default: one wave stream, NEE shadows and the path tail on a stream beside it; 2: the path-tracing launches of
  * even / odd frames alternate between those two streams, so that the wave chains of consecutive frames overlap), "fuzz" (test aid: a seed != 0 inserts idle launches of random length in front of the kernels of a frame; the image
  * must not change), "assemble" (1, default: after the first build a topology edit — an instance added or removed — assembles cached
- * per-mesh trees behind a small top tree and refits on the GPU; 0: full host SAH rebuild). */
+ * per-mesh trees behind a small top tree and refits on the GPU; 0: full host SAH rebuild), "packet_primary" / "packet_visibility" (the primary
+ * wave / the ReSTIR visibility rays are traced as wavefront packets — one shared traversal stack per 64 coherent rays: 1 on, 0 off, -1
+ * automatic: on when the window has more than 4 pixels per scene triangle; default -1 for the primary wave, 0 for the visibility rays, where packets measured slower), "fast_resample" (arithmetic mode of the ReSTIR passes, see
+ * the only key that changes results, within the stated tolerance). */
 int lumen_mi_set_tuning(lumen_mi_renderer*, const char* key, int value);
 
 /* ---- tile sharding (new functionality: the reference is single-GPU) */

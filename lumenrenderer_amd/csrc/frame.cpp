@@ -167,6 +167,8 @@ int traceFrameAsync(R* r)
     const bool blend = r->settings.blend_output != 0;
     // 0 exact; 1 fast, common launch only (no material can produce a surface outside the contracted evaluation); 2 fast, common + rare launch
     const int fastRs = r->fastResample ? (r->anyRareMaterial ? 2 : 1) : 0;
+    // visibility rays of the ReSTIR passes: packets under the same rule (tuning key packet_visibility: 1 on, 0 off, -1 automatic)
+    const bool visPackets = r->packetVisibility > 0 || (r->packetVisibility < 0 && (uint64_t)r->triEntry.size() * 4u < (uint64_t)r->fr.n && r->fr.n > 0);
     const bool usePackets = r->packetPrimary > 0 || (r->packetPrimary < 0 && (uint64_t)r->triEntry.size() * 4u < (uint64_t)r->fr.n && r->fr.n > 0);
 
     // camera (Camera.cpp:79-93,122-140; aspect = render W/H, WaveFrontRenderer.cpp:577)
@@ -279,7 +281,7 @@ int traceFrameAsync(R* r)
             Z(sp); K->pick_primary(sp, (int)(wtx * wty), r->dscene, fr, currentIndex, fresh, rs, fr.counters + LM_CNT_RESTIR(0), fastRs);   // + visibility rays, pass 1
             LmScene scp = r->dscene;                                 // the pick-ahead stream traces with its own stack-spill area
             if (sp != st) scp.spill += (size_t)3 * r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS);
-            Z(sp); K->trace_shade(sp, gridMain, scp, fr, fresh, fr.counters + LM_CNT_RESTIR(0), r->refillVisibility, 0);
+            Z(sp); K->trace_shade(sp, gridMain, scp, fr, fresh, fr.counters + LM_CNT_RESTIR(0), visPackets ? -1 : r->refillVisibility, 0);
             evEnd2(r, ev, sp);
             if (pickAhead) { LM_HIP(hipEventRecord(r->evPick, sp)); LM_HIP(hipStreamWaitEvent(st, r->evPick, 0)); }
             evBegin(r, 3, ev);
@@ -296,7 +298,7 @@ int traceFrameAsync(R* r)
                 scv.spill += (size_t)3 * r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS);
                 LM_HIP(hipEventRecord(r->evVis, st)); LM_HIP(hipStreamWaitEvent(sv, r->evVis, 0));
             }
-            Z(sv); K->trace_shade(sv, gridMain, scv, fr, cur, fr.counters + LM_CNT_RESTIR(1), r->refillVisibility, 1);
+            Z(sv); K->trace_shade(sv, gridMain, scv, fr, cur, fr.counters + LM_CNT_RESTIR(1), visPackets ? -1 : r->refillVisibility, 1);
             if (sv != st) LM_HIP(hipEventRecord(r->evVisDone, sv));
             Z(st); K->spatial(st, tiles, fr, currentIndex, 2, 3, rs, 0, 1, fastRs);      // the same seed as the first pass (ReSTIR.cpp: one seed for both): same candidates, same verdicts
             if (sv != st) LM_HIP(hipStreamWaitEvent(st, r->evVisDone, 0));

@@ -444,6 +444,34 @@ KN(lm_k_restir_trace_shade)(LmScene sc, LmFrame fr, int rc, const uint32_t* __re
         });
 }
 
+// the same pass for queues of COHERENT visibility rays: the candidate pick / temporal pass append a 16 x 16 pixel tile's rays together, a
+// wavefront's 64 rays start on neighbouring surface points and (with few lights) head for the same emitter, so the wavefront walks the
+// tree as one (lm_trace_packets: shared stack, no per-lane ordering or stack traffic).  Occlusion is a yes / no answer: identical results.
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_TRACE_WAVES)
+KN(lm_k_restir_trace_shade_packet)(LmScene sc, LmFrame fr, int rc, const uint32_t* __restrict__ countPtr, int pass)
+{
+    rc = lm_res_idx(fr, rc);
+    __shared__ int s_wstack[LM_PACKET_STACK * (LM_BLOCK / 64)];
+    __shared__ uint4 s_top[LM_WIDTH * LM_TOP_NODES + 1];
+    const uint32_t n = *countPtr;
+    float4* hot = fr.res[rc];
+    const float4* __restrict__ qO = pass ? fr.vis2O : fr.visO;
+    const float4* __restrict__ qD = pass ? fr.vis2D : fr.visD;
+    lm_trace_packets<true>(sc, n, (lm_lds_int*)(s_wstack + LM_PACKET_STACK * (threadIdx.x >> 6)), lm_stage_top(s_top, sc),
+        [&](uint32_t i, lf3& o, lf3& d, float& t0, float& t1) { const float4 o4 = qO[i]; o = v3(o4); d = v3(qD[i]); t0 = 0.1f; t1 = o4.w; },
+        [&](uint32_t i, bool occluded, const LmHit&) {
+            const uint32_t li = f2u(qD[i].w);
+            float* weight = (float*)(hot + 4u * li + 1u);
+            if (occluded) *weight = 0.f;
+            else {
+                const lf3 add = v3(fr.resC[rc][li]) * (*weight / 3.f);
+                float4 px = fr.direct[li];
+                px.x += add.x; px.y += add.y; px.z += add.z;
+                fr.direct[li] = px;
+            }
+        });
+}
+
 #include "lm_restir.h"
 
 // K20 FillLightBags — ReSTIRKernels.cu:343-370
@@ -1360,7 +1388,13 @@ static void l_pick_primary(hipStream_t s, int tiles, LmScene sc, LmFrame fr, int
     } else if (ldsLights) hipLaunchKernelGGL(KN(lm_k_pick_primary_lds), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount);
     else hipLaunchKernelGGL(KN(lm_k_pick_primary), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount);
 }
-static void l_trace_shade(hipStream_t s, int g, LmScene sc, LmFrame fr, int rc, const uint32_t* cnt, int refillBelow, int pass) { hipLaunchKernelGGL(KN(lm_k_restir_trace_shade), LM_GRID(g), sc, fr, rc, cnt, refillBelow, pass); }
+static void l_trace_shade(hipStream_t s, int g, LmScene sc, LmFrame fr, int rc, const uint32_t* cnt, int refillBelow, int pass)
+{
+#if !LM_INSTRUMENT
+    if (refillBelow < 0) { hipLaunchKernelGGL(KN(lm_k_restir_trace_shade_packet), LM_GRID(g), sc, fr, rc, cnt, pass); return; }      // coherent queue: packet traversal
+#endif
+    hipLaunchKernelGGL(KN(lm_k_restir_trace_shade), LM_GRID(g), sc, fr, rc, cnt, refillBelow < 0 ? 0 : refillBelow, pass);
+}
 static void l_temporal(hipStream_t s, int g, LmFrame fr, int cur, int prev, int rc, int rp, int rf, uint32_t seed, uint32_t* visCount, int fast)
 { if (fast) { hipLaunchKernelGGL(KN(lm_k_restir_temporal_fast), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); if (fast > 1) hipLaunchKernelGGL(KN(lm_k_restir_temporal_rare), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); } else hipLaunchKernelGGL(KN(lm_k_restir_temporal), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); }
 static void l_spatial(hipStream_t s, int g, LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin, int pass, int fast)

@@ -26,6 +26,7 @@ int lumen_mi_create(lumen_mi_renderer** out)
     if (const char* e = getenv("LUMEN_MI_PICK_AHEAD")) (*out)->pickAhead = atoi(e);
     if (const char* e = getenv("LUMEN_MI_SHADOW_ON_WAVE")) (*out)->shadowOnWave = atoi(e);
     if (const char* e = getenv("LUMEN_MI_PACKET_PRIMARY")) (*out)->packetPrimary = atoi(e);
+    if (const char* e = getenv("LUMEN_MI_PACKET_VISIBILITY")) (*out)->packetVisibility = atoi(e);
     if (const char* e = getenv("LUMEN_MI_SORT_RAYS")) (*out)->sortRays = std::max(0, atoi(e));
     if (const char* e = getenv("LUMEN_MI_FAST_RESAMPLE")) (*out)->fastResample = atoi(e) != 0;
     if (const char* e = getenv("LUMEN_MI_WAVE_STREAMS")) (*out)->waveStreams = atoi(e) == 2 ? 2 : 1;
@@ -635,6 +636,7 @@ int lumen_mi_set_tuning(lumen_mi_renderer* r, const char* key, int value)
     else if (k == "shadow_on_wave") { if (r->initialised) { int rc = syncAndCollect(r); if (rc) return rc; } r->shadowOnWave = value; }
     else if (k == "fast_resample") { if (r->initialised) { int rc = syncAndCollect(r); if (rc) return rc; } r->fastResample = value != 0; }
     else if (k == "packet_primary") r->packetPrimary = value;
+    else if (k == "packet_visibility") r->packetVisibility = value;
     else if (k == "sort_rays") { if (r->initialised) { int rc = syncAndCollect(r); if (rc) return rc; } r->sortRays = std::max(0, value); }
     else if (k == "refill") r->refillBelow = value;
     else if (k == "refill_visibility") r->refillVisibility = value;

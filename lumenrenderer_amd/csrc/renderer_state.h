@@ -185,6 +185,9 @@ struct lumen_mi_renderer {
     uint32_t refits = 0;                    // refits since the last full build
     int refitEnabled = 1;                   // 0: every transform change triggers a full host rebuild
     bool anyRareMaterial = false;           // some material ever created may need the second (exact) launch of the fast ReSTIR passes
+    int packetVisibility = 0;               // the ReSTIR visibility rays likewise (lm_k_restir_trace_shade_packet): 1 on, 0 off (default), -1 the primary wave's rule.
+                                            // Measured 3x SLOWER on C2 (profiles/r03_packet_visibility_ab.txt): a tile's visibility rays start on surfaces at very
+                                            // different depths, the union of their paths is large, and an any-hit packet runs until its last unoccluded ray is through
     int packetPrimary = -1;                 // the primary wave is traced as packets (one shared stack per wavefront, lm_trace_packets): 1 on, 0 off,
                                             // -1 auto = when the window has more than 4 pixels per scene triangle (a wavefront's 8 x 8 pixel tile then meets
                                             // few distinct leaves: C2 / C3 +1.2 %; with sub-pixel geometry the union of 64 rays' nodes costs more: C5 -11 %)
