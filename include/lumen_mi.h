@@ -154,7 +154,8 @@ int lumen_mi_get_kernel_time(lumen_mi_renderer*, int which, float* milliseconds,
 int lumen_mi_enable_kernel_timing(lumen_mi_renderer*, int enable);
 int lumen_mi_set_instrumented(lumen_mi_renderer*, int enable);   /* use the node/triangle counting traversal kernels */
 /* Scheduling knobs (no reference equivalent; none of them changes a result).  Keys: "tail_below" (waves expected to hold fewer rays run
- * as one path-tail launch; 0 = off, -1 = automatic), "tail_lanes" (paths per wavefront in that launch, 1..64; 0 or less = automatic), "single_stream" (1 = no stream
+ * as one path-tail launch; 0 = off, -1 = automatic), "tail_lanes" (paths per wavefront in that launch, 1..64; 0 or less = automatic), "tail_pair" (the NEE
+ * shadow ray a path emits at one depth is traced by a partner lane beside the path's closest-hit query of the next depth: 1 on, 0 off, -1 automatic), "single_stream" (1 = no stream
  * overlap, no frame pipelining), "pick_ahead" (ReSTIR candidate generation of the next frame on its own stream: 1 on, 0 off,
  * -1 automatic), "refill" / "refill_visibility" (lane-refill thresholds of the queue traversal), "shadow_on_wave" (NEE shadow rays on
  * the wave stream), "wave_streams" (1, default: one wave stream, NEE shadows and the path tail on a stream beside it; 2: the path-tracing launches of

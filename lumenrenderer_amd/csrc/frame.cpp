@@ -313,8 +313,15 @@ int traceFrameAsync(R* r)
                 if (stl != sx) sct.spill += (size_t)r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS);
                 LM_HIP(hipEventRecord(r->evShade[depth], sx)); LM_HIP(hipStreamWaitEvent(stl, r->evShade[depth], 0));     // the queue's producer is done
             }
+            // paths per wavefront; negative = pair mode (kernels.hip): the NEE shadow ray of depth d is traced by a partner lane beside the
+            // path's closest-hit query of depth d + 1 (at most 32 paths per wavefront then)
+            const int tailL = r->tailLanes > 0 ? r->tailLanes : (fr.n >= 786432u ? 64 : 16);
+            // (automatic: on small windows, where the tail is the longest launch of the frame — 1/4 tile of 1440p +4.8 %, 1/8 tile +1.6 %; off from
+            // 1.5 Mpixel, where it hides behind the other streams and 64 paths per wavefront cost fewer issue slots: profiles/r03_tail_pair_ab.txt)
+            const bool pair = r->tailPair > 0 || (r->tailPair < 0 && fr.n < 1500000u);
+            const int tailShape = pair ? -std::min(32, tailL) : tailL;
             evBegin2(r, 5, ev, stl);
-            Z(stl); K->path_tail(stl, r->numCU * 8, sct, withTailQueue(fr, q), q, inCount, (int)depth, (int)depthMax, seed, r->tailLanes > 0 ? r->tailLanes : (fr.n >= 786432u ? 64 : 16));
+            Z(stl); K->path_tail(stl, r->numCU * 8, sct, withTailQueue(fr, q), q, inCount, (int)depth, (int)depthMax, seed, tailShape);
             evEnd2(r, ev, stl);
             if (overlap) LM_HIP(hipEventRecord(r->evTail, stl));
             tailLaunched = true;

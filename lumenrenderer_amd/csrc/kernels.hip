@@ -326,8 +326,8 @@ KN(lm_k_shade_wave)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict_
 // K12 three launches per depth).  Here a wavefront only waits for its own `lanesPerWave` paths.  Arithmetic, RNG streams
 // and the order of the INDIRECT adds per pixel are those of the per-wave kernels (same device functions), so the result
 // is identical; ray counters are accumulated per depth like the queue appends do.
-extern "C" __global__ void __launch_bounds__(LM_BLOCK)
-KN(lm_k_path_tail)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict__ inCount, int depth0, int depthMax, uint32_t seed0, int lanesPerWave)
+template <bool PAIR>
+__device__ __forceinline__ void lm_path_tail_body(const LmScene& sc, const LmFrame& fr, int inQ, const uint32_t* __restrict__ inCount, int depth0, int depthMax, uint32_t seed0, int lanesPerWave)
 {
     __shared__ int s_stack[LM_STACK_LDS * LM_BLOCK];
     __shared__ float s_lut[256];
@@ -337,8 +337,78 @@ KN(lm_k_path_tail)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict__
     const LmStack stack = lm_make_stack(s_stack, sc);
     const uint32_t n = *inCount;
     __builtin_amdgcn_s_setprio(3);
-    const uint32_t lane = lm_lane(), L = (uint32_t)lanesPerWave;
+    const uint32_t lane = lm_lane(), L = (uint32_t)(lanesPerWave < 0 ? -lanesPerWave : lanesPerWave);
     const uint32_t W = gridDim.x * (LM_BLOCK / 64u);
+    if constexpr (PAIR) {
+        // PAIR MODE (L <= 32): lanes [0, L) carry the paths, lanes [L, 2L) their partners.  The NEE shadow ray a path emits at depth d is handed
+        // to its partner lane and traced in the NEXT round, beside the path's own closest-hit query of depth d + 1: a depth costs
+        // max(closest hit, shadow ray) + shading instead of their sum.  Per pixel the INDIRECT adds still happen in depth order (the add of
+        // depth d is made in round d + 1, before that round's shading can emit the next shadow ray), with the same operands: identical image.
+        const bool isPath = lane < L, isShadow = lane >= L && lane < 2u * L;
+        const int partner = (int)lane - (int)L;                      // the path lane a shadow lane serves
+        for (uint32_t base = (blockIdx.x * (LM_BLOCK / 64u) + (threadIdx.x >> 6)) * L; base < n; base += W * L) {     // wave-uniform
+            const uint32_t i = base + lane;
+            bool alive = isPath && i < n;
+            lf3 o = v3(0.f), d = v3(0.f), c = v3(0.f);
+            uint32_t li = 0u;
+            if (alive) {
+                const float4 o4 = fr.rayO[inQ][i], d4 = fr.rayD[inQ][i], c4 = fr.rayC[inQ][i];
+                o = v3(o4); d = v3(d4); c = v3(c4); li = f2u(d4.w);
+            }
+            bool shValid = false;                                     // shadow lanes: a ray is waiting
+            lf3 shO = v3(0.f), shD = v3(0.f), shR = v3(0.f);
+            float shT = 0.f;
+            uint32_t shLi = 0u;
+            uint32_t seed = seed0;
+            for (int depth = depth0; depth <= depthMax; depth++) {     // one extra round resolves the last depth's shadow rays
+                const bool tracePath = alive && depth < depthMax;
+                if (depth > depth0 && depth < depthMax) lm_count(fr.counters + LM_CNT_RAYS(depth), alive);
+                if (__ballot(tracePath || shValid) == 0ull) break;
+                const uint32_t seed2 = lm_wang_hash(seed);
+                LmHit h; h.t = -1.f; h.u = 0.f; h.v = 0.f; h.slot = 0;
+                const bool found = lm_traverse_mixed(sc, isShadow ? shO : o, isShadow ? shD : d, 0.01f, isShadow ? shT : 5000.f, isShadow, tracePath || shValid, stack, h, fr.counters);
+                if (shValid && !found) {
+                    float4 px = fr.indirect[shLi];
+                    px.x += shR.x; px.y += shR.y; px.z += shR.z;
+                    fr.indirect[shLi] = px;
+                }
+                shValid = false;
+                bool emitShadow = false, emitRay = false;
+                lf3 sdir = v3(0.f), srad = v3(0.f), spos = v3(0.f), o2 = v3(0.f), d2 = v3(0.f), c2 = v3(0.f);
+                float stmax = 0.f;
+                if (tracePath) {
+                    uint4 rec = make_uint4(0u, 0u, 0u, f2u(-1.f));
+                    if (found) {
+                        const uint2 id = sc.triId[h.slot];
+                        rec = make_uint4(id.x, id.y, lm_f32_to_f16(h.u) | (lm_f32_to_f16(h.v) << 16), f2u(h.t));
+                    }
+                    LmSurface s;
+                    lm_extract(sc, lut, tab, rec, o, d, c, s);
+                    const uint32_t ly = li / fr.ww, lx = li - ly * fr.ww;
+                    const uint32_t gi = (fr.y0 + ly) * fr.W + (fr.x0 + lx);
+                    emitShadow = lm_shade_direct(sc, s, gi, seed, sdir, stmax, srad);
+                    spos = s.position;
+                    if (depth < depthMax - 1) emitRay = lm_shade_indirect(s, gi, seed2, o2, d2, c2);
+                }
+                if (depth < depthMax) lm_count(fr.counters + LM_CNT_SHADOW(depth), emitShadow);
+                // hand the shadow ray to the partner lane (every lane takes part in the shuffles)
+                {
+                    const int src = isShadow ? partner : (int)lane;
+                    const int ev = __shfl((int)emitShadow, src, 64);
+                    const float ax = __shfl(spos.x, src, 64), ay = __shfl(spos.y, src, 64), az = __shfl(spos.z, src, 64);
+                    const float bx = __shfl(sdir.x, src, 64), by = __shfl(sdir.y, src, 64), bz = __shfl(sdir.z, src, 64);
+                    const float cx = __shfl(srad.x, src, 64), cy = __shfl(srad.y, src, 64), cz = __shfl(srad.z, src, 64);
+                    const float tm = __shfl(stmax, src, 64);
+                    const uint32_t pl = (uint32_t)__shfl((int)li, src, 64);
+                    if (isShadow) { shValid = ev != 0; shO = v3(ax, ay, az); shD = v3(bx, by, bz); shR = v3(cx, cy, cz); shT = tm; shLi = pl; }
+                }
+                alive = emitRay;
+                o = o2; d = d2; c = c2;
+                seed = lm_wang_hash(seed);
+            }
+        }
+        return;
+    } else {
     for (uint32_t base = (blockIdx.x * (LM_BLOCK / 64u) + (threadIdx.x >> 6)) * L; base < n; base += W * L) {     // wave-uniform
         const uint32_t i = base + lane;
         bool alive = lane < L && i < n;
@@ -386,7 +456,14 @@ KN(lm_k_path_tail)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict__
             seed = lm_wang_hash(seed);
         }
     }
+    }
 }
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_path_tail)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict__ inCount, int depth0, int depthMax, uint32_t seed0, int lanesPerWave)
+{ lm_path_tail_body<false>(sc, fr, inQ, inCount, depth0, depthMax, seed0, lanesPerWave); }
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_path_tail_pair)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict__ inCount, int depth0, int depthMax, uint32_t seed0, int lanesPerWave)
+{ lm_path_tail_body<true>(sc, fr, inQ, inCount, depth0, depthMax, seed0, lanesPerWave); }
 
 // K5: NEE shadow rays — reference WaveFrontShaders.cu:114-179 (tmin 0.01; unoccluded => channel += radiance).
 // At most one shadow ray per pixel per wave, so the add is a plain fp32 read-modify-write.
@@ -1375,7 +1452,10 @@ static void l_extract0(hipStream_t s, int g, LmScene sc, LmFrame fr, LmCamera ca
 static void l_shade_wave(hipStream_t s, int g, LmScene sc, LmFrame fr, int inQ, const uint32_t* inCount, uint32_t seed, uint32_t seed2, int doIndirect, uint32_t* outCount, uint32_t* shadowCount)
 { hipLaunchKernelGGL(KN(lm_k_shade_wave), LM_GRID(g), sc, fr, inQ, inCount, seed, seed2, doIndirect, outCount, shadowCount); }
 static void l_path_tail(hipStream_t s, int g, LmScene sc, LmFrame fr, int inQ, const uint32_t* inCount, int depth0, int depthMax, uint32_t seed0, int lanesPerWave)
-{ hipLaunchKernelGGL(KN(lm_k_path_tail), LM_GRID(g), sc, fr, inQ, inCount, depth0, depthMax, seed0, lanesPerWave); }
+{
+    if (lanesPerWave < 0) hipLaunchKernelGGL(KN(lm_k_path_tail_pair), LM_GRID(g), sc, fr, inQ, inCount, depth0, depthMax, seed0, lanesPerWave);
+    else hipLaunchKernelGGL(KN(lm_k_path_tail), LM_GRID(g), sc, fr, inQ, inCount, depth0, depthMax, seed0, lanesPerWave);
+}
 static void l_trace_shadow(hipStream_t s, int g, LmScene sc, LmFrame fr, const uint32_t* cnt, float tmin, int refillBelow) { hipLaunchKernelGGL(KN(lm_k_trace_shadow), LM_GRID(g), sc, fr, cnt, tmin, refillBelow); }
 static void l_fill_bags(hipStream_t s, LmScene sc, LmFrame fr, uint32_t seed, uint32_t total) { hipLaunchKernelGGL(KN(lm_k_fill_bags), LM_GRID((total + LM_BLOCK - 1) / LM_BLOCK), sc, fr, seed, total); }
 static void l_pick_primary(hipStream_t s, int tiles, LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount, int fast)

@@ -373,6 +373,60 @@ __device__ __forceinline__ bool lm_traverse(const LmScene& sc, const lf3& o, con
     return found;
 }
 
+// The same traversal with the query kind chosen PER LANE at run time (path tail in pair mode: half of a wavefront's lanes trace
+// closest-hit continuation rays while the other half trace the any-hit shadow rays of the previous depth).  Any-hit lanes take the
+// ordered node step too — an occlusion answer does not depend on the visiting order — and stop at their first hit.  A lane without a
+// ray returns at once.  Results are those of lm_traverse<false> / lm_traverse<true>.
+__device__ __forceinline__ bool lm_traverse_mixed(const LmScene& sc, const lf3& o, const lf3& d, float tmin, float tmax, bool any, bool valid,
+                                                  const LmStack& stack, LmHit& hit, uint32_t* cnt)
+{
+    if (!valid) return false;
+    LmRayQ rq;
+    lm_ray_setup(sc, o, d, rq);
+    float hitT = tmax;
+    uint32_t hitOrder = 0xffffffffu;
+    bool found = false;
+    int sp = 0;
+    int cur = 0;
+#if LM_INSTRUMENT
+    uint32_t nNodes = 0, nTris = 0;
+#endif
+    for (;;) {
+        while (cur >= 0 && cur != LM_REF_NONE) {
+#if LM_INSTRUMENT
+            cur = lm_node_step<false>(sc, cur, rq, tmin, hitT, stack, sp, nullptr, &nNodes);
+#else
+            cur = lm_node_step<false>(sc, cur, rq, tmin, hitT, stack, sp, nullptr);
+#endif
+        }
+        if (cur == 0x7fffffff) break;
+        const uint32_t leaf = (uint32_t)(~cur);
+        const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
+        for (uint32_t k = 0; k < count; k++) {
+            float t, u, v;
+#if LM_INSTRUMENT
+            nTris++;
+#endif
+            if (lm_woop(sc.woop, first + k, o, d, tmin, tmax, t, u, v)) {
+                if (any) { found = true; break; }
+                const uint32_t order = sc.triOrder[first + k];
+                if (t < hitT || (t == hitT && found && order < hitOrder)) {
+                    hitT = t; hitOrder = order; found = true;
+                    hit.t = t; hit.u = u; hit.v = v; hit.slot = first + k;
+                }
+            }
+        }
+        if (any && found) break;
+        if (sp == 0) break;
+        cur = lm_pop(stack, sp);
+    }
+#if LM_INSTRUMENT
+    atomicAdd((unsigned long long*)(cnt + LM_CNT_NODES), (unsigned long long)nNodes);
+    atomicAdd((unsigned long long*)(cnt + LM_CNT_TRIS), (unsigned long long)nTris);
+#endif
+    return found;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Queue traversal with per-lane ray replacement ("persistent threads").  Wavefront w of the launch owns the 64-ray groups
 // w, w + W, w + 2W, ... of the queue (W = wavefronts in the grid; no atomics: one address retires only ~88 returning atomics

@@ -30,6 +30,7 @@ int lumen_mi_create(lumen_mi_renderer** out)
     if (const char* e = getenv("LUMEN_MI_SORT_RAYS")) (*out)->sortRays = std::max(0, atoi(e));
     if (const char* e = getenv("LUMEN_MI_FAST_RESAMPLE")) (*out)->fastResample = atoi(e) != 0;
     if (const char* e = getenv("LUMEN_MI_WAVE_STREAMS")) (*out)->waveStreams = atoi(e) == 2 ? 2 : 1;
+    if (const char* e = getenv("LUMEN_MI_TAIL_PAIR")) (*out)->tailPair = atoi(e);
     if (const char* e = getenv("LUMEN_MI_TAIL_LANES")) { const int v = atoi(e); (*out)->tailLanes = v <= 0 ? -1 : std::min(64, v); }
     return 0;
 }
@@ -628,6 +629,7 @@ int lumen_mi_set_tuning(lumen_mi_renderer* r, const char* key, int value)
     if (k == "tail_below") r->tailBelow = value;
     else if (k == "wave_streams") { if (r->initialised) { int rc = syncAndCollect(r); if (rc) return rc; } r->waveStreams = value == 2 ? 2 : 1; }
     else if (k == "tail_lanes") r->tailLanes = value <= 0 ? -1 : std::min(64, value);
+    else if (k == "tail_pair") r->tailPair = value;
     else if (k == "single_stream") { if (r->initialised) { int rc = syncAndCollect(r); if (rc) return rc; } r->overlap = value == 0; }
     else if (k == "refit") r->refitEnabled = value;
     else if (k == "pick_ahead") { if (r->initialised) { int rc = syncAndCollect(r); if (rc) return rc; } r->pickAhead = value; }

@@ -160,6 +160,8 @@ struct lumen_mi_renderer {
                                             // even / odd frames alternates between those two streams (each frame's closest-hit, shading, shadow and tail
                                             // launches in series on its own), so that consecutive frames' wave chains overlap.  Measured box-dependent:
                                             // + 1.5 % on one box, - 3 % on two others (tiles - 6 ... - 8 %), toy frames + 24 %: off by default
+    int tailPair = -1;                      // path tail in pair mode (shadow ray of depth d traced by a partner lane beside the closest-hit query of depth d + 1):
+                                            // 1 on (at most 32 paths per wavefront), 0 off, -1 automatic: on for windows under 1.5 Mpixel
     int tailLanes = -1;                     // ... with this many paths per wavefront (-1 = auto: 64 for windows from 0.75 Mpixel, where the tail hides behind
                                             // the other streams and fuller wavefronts save VALU issue slots; 16 for smaller windows, where the tail IS the critical path)
     uint32_t* pinnedCounters[2] = {nullptr, nullptr}; hipEvent_t evCnt[2] = {nullptr, nullptr}; bool cntPending[2] = {false, false};

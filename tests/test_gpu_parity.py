@@ -830,9 +830,11 @@ TUNINGS = [{"tail_below": 0}, {"tail_below": 1 << 30}, {"tail_below": 6000}, {"t
            {"pick_ahead": 0}, {"pick_ahead": 1, "tail_below": 0}, {"shadow_on_wave": 1}, {"shadow_on_wave": 1, "tail_below": 0},
            {"sort_rays": 1}, {"sort_rays": 16, "tail_below": 0}, {"sort_rays": 2, "single_stream": 1, "tail_below": 6000},
            {"packet_primary": 1}, {"packet_primary": 1, "single_stream": 1, "tail_below": 0},
+           {"tail_pair": 1, "tail_below": 1 << 30}, {"tail_pair": 1, "tail_below": 6000, "tail_lanes": 16}, {"tail_pair": 1, "tail_lanes": 64, "single_stream": 1, "tail_below": 1 << 30},
+           {"tail_pair": 1, "tail_lanes": 5, "tail_below": 1 << 30, "wave_streams": 2},
            {"packet_visibility": 1}, {"packet_visibility": 1, "packet_primary": 1, "pick_ahead": 0}, {"packet_visibility": 0, "packet_primary": 0},
            {"wave_streams": 2}, {"wave_streams": 2, "tail_below": 0}, {"wave_streams": 2, "pick_ahead": 0}, {"wave_streams": 2, "tail_below": 6000, "pick_ahead": 0}]
-DEEP = [{}, {"packet_visibility": 1}, {"pick_ahead": 0, "tail_below": 0}, {"pick_ahead": 1, "tail_below": 1 << 30}, {"single_stream": 1}, {"shadow_on_wave": 1}, {"sort_rays": 16, "tail_below": 0}, {"wave_streams": 2}]
+DEEP = [{}, {"packet_visibility": 1}, {"tail_pair": 1, "tail_below": 1 << 30}, {"tail_pair": 1}, {"pick_ahead": 0, "tail_below": 0}, {"pick_ahead": 1, "tail_below": 1 << 30}, {"single_stream": 1}, {"shadow_on_wave": 1}, {"sort_rays": 16, "tail_below": 0}, {"wave_streams": 2}]
 
 
 @pytest.mark.parametrize("tuning", DEEP, ids=lambda t: ",".join(f"{k}={v}" for k, v in t.items()) or "default")
