@@ -164,8 +164,14 @@ LM_HD float lm_random_float(uint32_t& s) { return (float)lm_random_int(s) * 2.32
 // (int)roundf(x) for x >= 0 (round half away from zero): x - trunc(x) is exact, so this IS roundf there, without the sign handling
 // of the general function (5 instead of 8 instructions in the 32-candidate loop of the pick)
 LM_HD int lm_round_nonneg(float x) { const float t = truncf(x); return (int)t + ((x - t) >= 0.5f ? 1 : 0); }
-// Halton radical inverse, index pre-incremented (reference: GPUGeneratePrimRay.cu:8-26)
-LM_HD float lm_halton(uint32_t index, uint32_t base)
+// Halton radical inverse, index pre-incremented (reference: GPUGeneratePrimRay.cu:8-26): f = f / base; r = r + f * (index % base); index /= base.
+// The primary-ray kernel spent 31 M wave instructions per frame in these two loops (an IEEE division sequence per digit), so bases 2 and 3
+// take shortcuts that reproduce the loop's roundings exactly (pinned: tests/golden/ref_kat.npz rows `halt`, and the loop itself below):
+//   base 2: f = 2^-k is exact and every partial sum has at most k significant bits, so below 2^24 the result is the bit-reversed index
+//           scaled by 2^-32, exactly; larger indices (never reached by a 4K frame) take the loop;
+//   base 3: the loop's f values do not depend on the index — f_k = fl(f_(k-1) / 3) — so they are compile-time constants, the digits come
+//           from a multiply-high, and a zero digit above the top one adds +0 (r + 0 = r) where the loop has already stopped.
+LM_HD float lm_halton_loop(uint32_t index, uint32_t base)
 {
     ++index;
     float f = 1.f, r = 0.f;
@@ -176,4 +182,38 @@ LM_HD float lm_halton(uint32_t index, uint32_t base)
         index = index / base;
     }
     return r;
+}
+struct LmThirds { float f[21]; };
+constexpr LmThirds lm_thirds() { LmThirds t{}; float f = 1.f; for (int k = 0; k < 21; k++) { f = f / 3.f; t.f[k] = f; } return t; }      // 3^21 > 2^32
+LM_HD uint32_t lm_brev32(uint32_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brev(v);
+#else
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1); v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0f0f0f0fu) | ((v & 0x0f0f0f0fu) << 4); v = ((v >> 8) & 0x00ff00ffu) | ((v & 0x00ff00ffu) << 8);
+    return (v >> 16) | (v << 16);
+#endif
+}
+LM_HD float lm_halton(uint32_t index, uint32_t base)
+{
+    if (base == 2u) {
+        const uint32_t i1 = index + 1u;
+        if (i1 < (1u << 24)) return (float)lm_brev32(i1) * 2.3283064365386963e-10f;      // 2^-32; at most 24 significant bits: both steps exact
+        return lm_halton_loop(index, 2u);
+    }
+    if (base == 3u) {
+        constexpr LmThirds T = lm_thirds();
+        uint32_t i1 = index + 1u;
+        float r = 0.f;
+#pragma unroll
+        for (int k = 0; k < 21; k++) {
+            if (i1 == 0u) break;
+            const uint32_t q = i1 / 3u;
+            r = r + T.f[k] * (float)(i1 - 3u * q);
+            i1 = q;
+        }
+        return r;
+    }
+    return lm_halton_loop(index, base);
 }

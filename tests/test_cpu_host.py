@@ -745,3 +745,14 @@ def test_bench_self_launch_fails_clearly_when_the_gpus_are_not_there():
                          capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode != 0
     assert "2 GPUs requested, 0 present" in out.stderr + out.stdout
+
+
+def test_shortcut_halton_equals_the_digit_loop_bit_for_bit(tmp_path):
+    """lm_math.h: bases 2 and 3 of the Halton radical inverse are computed without the per-digit division sequence (bit reversal / constant
+    powers of 1/3); the result must be the loop's (GPUGeneratePrimRay.cu:8-26) to the bit, for every index — host build, no GPU."""
+    exe = str(tmp_path / "halton_check")
+    build = subprocess.run(["g++", "-std=c++17", "-O2", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-ffp-contract=off", "-w",
+                            "-I" + os.path.join(ROOT, "lumenrenderer_amd", "csrc"), os.path.join(ROOT, "tests", "halton_check.cpp"), "-o", exe], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([exe, "3000000"], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and " 0 mismatches" in run.stdout, run.stdout[-500:]

@@ -47,6 +47,17 @@ def test_device_pow_halton_hash_half_bit_exact(bare):
         got = bare.TestMath(5, idx.view(np.float32), np.full(idx.size, base, np.uint32).view(np.float32))
         want = np.array([L.orc_halton(int(i), base) for i in idx[:4000]], np.float32)
         assert np.array_equal(got[:4000].view(np.uint32), want.view(np.uint32))
+    # ... and against the REFERENCE's HaltonSequence compiled from its own text (ref_kat.npz rows `halt`, incl. the index that wraps in `++index`)
+    hr = KAT["halt"]
+    for base in (2, 3):
+        rows = hr[hr[:, 1] == base]
+        got = bare.TestMath(5, rows[:, 0].astype(np.uint32).view(np.float32), np.full(len(rows), base, np.uint32).view(np.float32))
+        assert np.array_equal(got.view(np.uint32), rows[:, 2].astype(np.uint32)), base
+    big = np.concatenate([rng.integers(2 ** 24 - 64, 2 ** 24 + 64, 500, dtype=np.uint32), rng.integers(0, 2 ** 32, 4000, dtype=np.uint64).astype(np.uint32)])
+    for base in (2, 3):
+        got = bare.TestMath(5, big.view(np.float32), np.full(big.size, base, np.uint32).view(np.float32))
+        want = np.array([L.orc_halton(int(i), base) for i in big], np.float32)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), base
     got = bare.TestMath(6, idx.view(np.float32)).view(np.uint32)
     assert got[:2000].tolist() == [L.orc_wang_hash(int(i)) for i in idx[:2000]]
     xs = np.concatenate([rng.uniform(-2, 2, 20000), rng.uniform(-7e4, 7e4, 2000), rng.uniform(-1e-5, 1e-5, 2000)]).astype(np.float32)
