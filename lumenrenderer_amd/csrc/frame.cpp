@@ -289,7 +289,7 @@ int traceFrameAsync(R* r)
             Z(st); K->temporal(st, tiles, fr, currentIndex, temporalIndex, cur, tmp, fresh, rs, fr.counters + LM_CNT_RESTIR(1), fastRs);         // + visibility rays, pass 2
             if (overlap) LM_HIP(hipEventRecord(r->evTemporal[par], st));
             rs = wangHash(rs);
-            Z(st); K->spatial(st, tiles, fr, currentIndex, cur, 2, rs, 30, 0, fastRs);
+            Z(st); K->spatial(st, tiles, fr, currentIndex, cur, 2, rs, 30, 0, fastRs | ((fastRs && r->spatialLds) ? 16 : 0));
             // second visibility pass (ReSTIR.cpp:211-212) works on the CURRENT buffer, which the second spatial pass does not
             // touch: trace it beside that pass.  (It must follow the first spatial pass, which reads the current buffer.)
             hipStream_t sv = (overlap && !pickAhead) ? r->aux3 : st;
@@ -321,7 +321,7 @@ int traceFrameAsync(R* r)
             const bool pair = r->tailPair > 0 || (r->tailPair < 0 && fr.n < 1500000u);
             const int tailShape = pair ? -std::min(32, tailL) : tailL;
             evBegin2(r, 5, ev, stl);
-            Z(stl); K->path_tail(stl, r->numCU * 8, sct, withTailQueue(fr, q), q, inCount, (int)depth, (int)depthMax, seed, tailShape);
+            Z(stl); K->path_tail(stl, r->numCU * 8, sct, withTailQueue(fr, q), q | (r->fastShade ? 2 : 0), inCount, (int)depth, (int)depthMax, seed, tailShape);
             evEnd2(r, ev, stl);
             if (overlap) LM_HIP(hipEventRecord(r->evTail, stl));
             tailLaunched = true;
@@ -342,7 +342,7 @@ int traceFrameAsync(R* r)
             if (overlap && !twoWave) LM_HIP(hipStreamWaitEvent(sx, r->evJoin2, 0));       // previous wave's (or frame's) shadow rays consumed (two wave streams: the
                                                                                          // shadow launches are on this stream, and the event is not per frame)
             evBegin2(r, 2, ev, sx);
-            Z(sx); K->shade_wave(sx, r->numCU * 8, scx, (int)depth + 1 == tailDepth ? withTailQueue(fr, q ^ 1) : fr, q, inCount, seed, seed2, doIndirect, outCount, shCount);
+            Z(sx); K->shade_wave(sx, r->numCU * 8, scx, (int)depth + 1 == tailDepth ? withTailQueue(fr, q ^ 1) : fr, q, inCount, seed, seed2, doIndirect | (r->fastShade ? 2 : 0), outCount, shCount);
             evEnd2(r, ev, sx);
             // NEE shadow rays of this wave: third stream, beside the next wave's closest-hit launch.  The shadow queue is
             // rewritten by the NEXT shade_wave, which therefore waits for this launch (evJoin2).  (`shadow_on_wave` 1 keeps them on

@@ -272,8 +272,8 @@ KN(lm_k_extract0)(LmScene sc, LmFrame fr, LmCamera cam, int cur, uint32_t seed2,
 
 
 // depth >= 1: extraction + NEE + continuation fused (no SurfaceData round trip through HBM)
-extern "C" __global__ void __launch_bounds__(LM_BLOCK)
-KN(lm_k_shade_wave)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict__ inCount, uint32_t seed, uint32_t seed2, int doIndirect,
+template <class NEE>
+__device__ __forceinline__ void lm_shade_wave_body(const LmScene& sc, const LmFrame& fr, int inQ, const uint32_t* __restrict__ inCount, uint32_t seed, uint32_t seed2, int doIndirect,
                 uint32_t* outCount, uint32_t* shadowCount)
 {
     __shared__ uint32_t s_tmp[5];
@@ -301,7 +301,7 @@ KN(lm_k_shade_wave)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict_
             lm_extract(sc, lut, tab, fr.hits[i], v3(o4), v3(d4), v3(c4), s);
             const uint32_t ly = li / fr.ww, lx = li - ly * fr.ww;
             const uint32_t gi = (fr.y0 + ly) * fr.W + (fr.x0 + lx);
-            emitShadow = lm_shade_direct(sc, s, gi, seed, sdir, stmax, srad);
+            emitShadow = lm_shade_direct<NEE>(sc, s, gi, seed, sdir, stmax, srad);
             spos = s.position;
             if (doIndirect) emitRay = lm_shade_indirect(s, gi, seed2, o, d, c);
         }
@@ -319,6 +319,13 @@ KN(lm_k_shade_wave)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict_
         }
     }
 }
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_shade_wave)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict__ inCount, uint32_t seed, uint32_t seed2, int doIndirect, uint32_t* outCount, uint32_t* shadowCount)
+{ lm_shade_wave_body<LmExact>(sc, fr, inQ, inCount, seed, seed2, doIndirect, outCount, shadowCount); }
+// tuning key fast_shade: the NEE contribution with hardware reciprocal / square root (lm_shade.h lm_shade_direct)
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_shade_wave_fs)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict__ inCount, uint32_t seed, uint32_t seed2, int doIndirect, uint32_t* outCount, uint32_t* shadowCount)
+{ lm_shade_wave_body<LmFast>(sc, fr, inQ, inCount, seed, seed2, doIndirect, outCount, shadowCount); }
 
 // Path tail: waves `depth0 .. depthMax-1` of the rays left in the queue, one path per lane, in ONE launch (closest hit ->
 // extraction + NEE + continuation -> shadow ray -> next depth).  Deep waves hold too few rays to fill the machine, so a
@@ -326,7 +333,7 @@ KN(lm_k_shade_wave)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict_
 // K12 three launches per depth).  Here a wavefront only waits for its own `lanesPerWave` paths.  Arithmetic, RNG streams
 // and the order of the INDIRECT adds per pixel are those of the per-wave kernels (same device functions), so the result
 // is identical; ray counters are accumulated per depth like the queue appends do.
-template <bool PAIR>
+template <bool PAIR, class NEE>
 __device__ __forceinline__ void lm_path_tail_body(const LmScene& sc, const LmFrame& fr, int inQ, const uint32_t* __restrict__ inCount, int depth0, int depthMax, uint32_t seed0, int lanesPerWave)
 {
     __shared__ int s_stack[LM_STACK_LDS * LM_BLOCK];
@@ -386,7 +393,7 @@ __device__ __forceinline__ void lm_path_tail_body(const LmScene& sc, const LmFra
                     lm_extract(sc, lut, tab, rec, o, d, c, s);
                     const uint32_t ly = li / fr.ww, lx = li - ly * fr.ww;
                     const uint32_t gi = (fr.y0 + ly) * fr.W + (fr.x0 + lx);
-                    emitShadow = lm_shade_direct(sc, s, gi, seed, sdir, stmax, srad);
+                    emitShadow = lm_shade_direct<NEE>(sc, s, gi, seed, sdir, stmax, srad);
                     spos = s.position;
                     if (depth < depthMax - 1) emitRay = lm_shade_indirect(s, gi, seed2, o2, d2, c2);
                 }
@@ -438,7 +445,7 @@ __device__ __forceinline__ void lm_path_tail_body(const LmScene& sc, const LmFra
                 lm_extract(sc, lut, tab, rec, o, d, c, s);
                 const uint32_t ly = li / fr.ww, lx = li - ly * fr.ww;
                 const uint32_t gi = (fr.y0 + ly) * fr.W + (fr.x0 + lx);
-                emitShadow = lm_shade_direct(sc, s, gi, seed, sdir, stmax, srad);
+                emitShadow = lm_shade_direct<NEE>(sc, s, gi, seed, sdir, stmax, srad);
                 spos = s.position;
                 if (depth < depthMax - 1) emitRay = lm_shade_indirect(s, gi, seed2, o2, d2, c2);
             }
@@ -460,10 +467,16 @@ __device__ __forceinline__ void lm_path_tail_body(const LmScene& sc, const LmFra
 }
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
 KN(lm_k_path_tail)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict__ inCount, int depth0, int depthMax, uint32_t seed0, int lanesPerWave)
-{ lm_path_tail_body<false>(sc, fr, inQ, inCount, depth0, depthMax, seed0, lanesPerWave); }
+{ lm_path_tail_body<false, LmExact>(sc, fr, inQ, inCount, depth0, depthMax, seed0, lanesPerWave); }
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
 KN(lm_k_path_tail_pair)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict__ inCount, int depth0, int depthMax, uint32_t seed0, int lanesPerWave)
-{ lm_path_tail_body<true>(sc, fr, inQ, inCount, depth0, depthMax, seed0, lanesPerWave); }
+{ lm_path_tail_body<true, LmExact>(sc, fr, inQ, inCount, depth0, depthMax, seed0, lanesPerWave); }
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_path_tail_fs)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict__ inCount, int depth0, int depthMax, uint32_t seed0, int lanesPerWave)
+{ lm_path_tail_body<false, LmFast>(sc, fr, inQ, inCount, depth0, depthMax, seed0, lanesPerWave); }
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_path_tail_pair_fs)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict__ inCount, int depth0, int depthMax, uint32_t seed0, int lanesPerWave)
+{ lm_path_tail_body<true, LmFast>(sc, fr, inQ, inCount, depth0, depthMax, seed0, lanesPerWave); }
 
 // K5: NEE shadow rays — reference WaveFrontShaders.cu:114-179 (tmin 0.01; unoccluded => channel += radiance).
 // At most one shadow ray per pixel per wave, so the add is a plain fp32 read-modify-write.
@@ -829,8 +842,12 @@ KN(lm_k_restir_temporal_rare)(LmFrame fr, int cur, int prev, int rc, int rp, int
 #ifndef LM_SPATIAL_WAVES
 #define LM_SPATIAL_WAVES 3      // <= 168 VGPRs: three waves per SIMD instead of two (the kernel is gather-latency bound)
 #endif
-template <class A, int ROLE>
-__device__ __forceinline__ void lm_restir_spatial_body(const LmFrame& fr, int cur, int rin, int rout, uint32_t seed, int margin, int pass)
+// LDS_PROBES (first pass only, 1024-thread blocks = 32 x 32 pixel tiles): the block stages the probes of its tile grown by the 30-pixel reach of
+// the neighbour draw — 92 x 92 x 16 B = 132 KB of the CU's 160 KB LDS — with coalesced loads, and the five similarity tests of a pixel read LDS
+// instead of gathering five 16-byte probes through the L1.  The probes are the same bits, so the verdicts and the image are unchanged.
+#define LM_SPATIAL_WIN 92u
+template <class A, int ROLE, uint32_t LOG_TS = 4, bool LDS_PROBES = false>
+__device__ __forceinline__ void lm_restir_spatial_body(const LmFrame& fr, int cur, int rin, int rout, uint32_t seed, int margin, int pass, float4* s_probe = nullptr)
 {
     if (ROLE == LM_RARE && fr.counters[LM_CNT_RARE] == 0u) return;
     rin = lm_res_idx(fr, rin);
@@ -838,8 +855,20 @@ __device__ __forceinline__ void lm_restir_spatial_body(const LmFrame& fr, int cu
 #ifdef LM_SPATIAL_PRIO
     __builtin_amdgcn_s_setprio(LM_SPATIAL_PRIO);
 #endif
+    int wx0 = 0, wy0 = 0;                                           // window origin of the staged probes (window-local pixels, may be negative)
+    if constexpr (LDS_PROBES) {
+        uint32_t tx, ty;
+        lm_tile_origin<LOG_TS>(fr, tx, ty);
+        wx0 = (int)(tx << LOG_TS) - 30; wy0 = (int)(ty << LOG_TS) - 30;
+        const float4* probe = fr.probe[cur];
+        for (uint32_t k = threadIdx.x; k < LM_SPATIAL_WIN * LM_SPATIAL_WIN; k += blockDim.x) {
+            const int py = wy0 + (int)(k / LM_SPATIAL_WIN), px = wx0 + (int)(k % LM_SPATIAL_WIN);
+            if (px >= 0 && px < (int)fr.ww && py >= 0 && py < (int)fr.wh) s_probe[k] = probe[(uint32_t)py * fr.ww + (uint32_t)px];
+        }
+        __syncthreads();
+    }
     uint32_t li = 0, gi = 0;
-    if (!lm_tile_pixel(fr, li, gi)) return;
+    if (!lm_tile_pixel<LOG_TS>(fr, li, gi)) return;
     if (!lm_owned(fr, li, margin)) return;                       // pass 1 feeds pass 2 within 30 pixels of the owned tile, pass 2 only the tile
     const float4* hotIn = fr.res[rin];
     // The second pass draws the candidates of the first (same seed) against the same probe plane: the first pass leaves its verdicts
@@ -858,12 +887,21 @@ __device__ __forceinline__ void lm_restir_spatial_body(const LmFrame& fr, int cu
     }
     if (!pass) {
         const float4* probe = fr.probe[cur];
-        const float4 cn = probe[li];
-        if (cn.w < 0.f) { if (ROLE != LM_RARE) fr.reuseMask[li] = LM_REUSE_FLAGGED; return; }
-        const float ct = cn.w;
+        float4 cn;
         float4 pr[5];
+        if constexpr (LDS_PROBES) {
+            auto at = [&](uint32_t pix) { const int py = (int)(pix / fr.ww), px = (int)(pix - (uint32_t)py * fr.ww); return s_probe[(uint32_t)(py - wy0) * LM_SPATIAL_WIN + (uint32_t)(px - wx0)]; };
+            cn = at(li);
+            if (cn.w < 0.f) { if (ROLE != LM_RARE) fr.reuseMask[li] = LM_REUSE_FLAGGED; return; }
 #pragma unroll
-        for (int k = 0; k < 5; k++) pr[k] = probe[cand[k] != 0xffffffffu ? cand[k] : li];
+            for (int k = 0; k < 5; k++) pr[k] = at(cand[k] != 0xffffffffu ? cand[k] : li);
+        } else {
+            cn = probe[li];
+            if (cn.w < 0.f) { if (ROLE != LM_RARE) fr.reuseMask[li] = LM_REUSE_FLAGGED; return; }
+#pragma unroll
+            for (int k = 0; k < 5; k++) pr[k] = probe[cand[k] != 0xffffffffu ? cand[k] : li];
+        }
+        const float ct = cn.w;
         // accepted candidates as a bit mask; they are visited in candidate order (no dynamically indexed array: registers only)
 #pragma unroll
         for (int k = 0; k < 5; k++) {
@@ -922,6 +960,13 @@ KN(lm_k_restir_spatial)(LmFrame fr, int cur, int rin, int rout, uint32_t seed, i
 #endif
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_SPATIAL_FAST_WAVES)
 KN(lm_k_restir_spatial_fast)(LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin, int pass) { lm_restir_spatial_body<LmFast, LM_COMMON>(fr, cur, rin, rout, seed, margin, pass); }
+// first pass with the probe window in LDS: one 1024-thread block per CU (132 KB), four waves per SIMD
+extern "C" __global__ void __launch_bounds__(1024, 1)
+KN(lm_k_restir_spatial_fast_lds)(LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin)
+{
+    __shared__ float4 s_probe[LM_SPATIAL_WIN * LM_SPATIAL_WIN];
+    lm_restir_spatial_body<LmFast, LM_COMMON, 5, true>(fr, cur, rin, rout, seed, margin, 0, s_probe);
+}
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_SPATIAL_WAVES)
 KN(lm_k_restir_spatial_rare)(LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin, int pass) { lm_restir_spatial_body<LmExact, LM_RARE>(fr, cur, rin, rout, seed, margin, pass); }
 
@@ -1450,10 +1495,17 @@ static void l_trace_closest(hipStream_t s, int g, LmScene sc, const float4* o, c
 static void l_extract0(hipStream_t s, int g, LmScene sc, LmFrame fr, LmCamera cam, int cur, uint32_t seed2, int doIndirect, int outQ, uint32_t* outCount)
 { hipLaunchKernelGGL(KN(lm_k_extract0), LM_GRID(g), sc, fr, cam, cur, seed2, doIndirect, outQ, outCount); }
 static void l_shade_wave(hipStream_t s, int g, LmScene sc, LmFrame fr, int inQ, const uint32_t* inCount, uint32_t seed, uint32_t seed2, int doIndirect, uint32_t* outCount, uint32_t* shadowCount)
-{ hipLaunchKernelGGL(KN(lm_k_shade_wave), LM_GRID(g), sc, fr, inQ, inCount, seed, seed2, doIndirect, outCount, shadowCount); }
+{
+    // bit 1 of doIndirect / of inQ (path tail): tuning key fast_shade, the NEE contribution in the fast arithmetic policy
+    if (doIndirect & 2) hipLaunchKernelGGL(KN(lm_k_shade_wave_fs), LM_GRID(g), sc, fr, inQ, inCount, seed, seed2, doIndirect & 1, outCount, shadowCount);
+    else hipLaunchKernelGGL(KN(lm_k_shade_wave), LM_GRID(g), sc, fr, inQ, inCount, seed, seed2, doIndirect, outCount, shadowCount);
+}
 static void l_path_tail(hipStream_t s, int g, LmScene sc, LmFrame fr, int inQ, const uint32_t* inCount, int depth0, int depthMax, uint32_t seed0, int lanesPerWave)
 {
-    if (lanesPerWave < 0) hipLaunchKernelGGL(KN(lm_k_path_tail_pair), LM_GRID(g), sc, fr, inQ, inCount, depth0, depthMax, seed0, lanesPerWave);
+    const bool fs = (inQ & 2) != 0; inQ &= 1;
+    if (lanesPerWave < 0) { if (fs) hipLaunchKernelGGL(KN(lm_k_path_tail_pair_fs), LM_GRID(g), sc, fr, inQ, inCount, depth0, depthMax, seed0, lanesPerWave);
+                            else hipLaunchKernelGGL(KN(lm_k_path_tail_pair), LM_GRID(g), sc, fr, inQ, inCount, depth0, depthMax, seed0, lanesPerWave); }
+    else if (fs) hipLaunchKernelGGL(KN(lm_k_path_tail_fs), LM_GRID(g), sc, fr, inQ, inCount, depth0, depthMax, seed0, lanesPerWave);
     else hipLaunchKernelGGL(KN(lm_k_path_tail), LM_GRID(g), sc, fr, inQ, inCount, depth0, depthMax, seed0, lanesPerWave);
 }
 static void l_trace_shadow(hipStream_t s, int g, LmScene sc, LmFrame fr, const uint32_t* cnt, float tmin, int refillBelow) { hipLaunchKernelGGL(KN(lm_k_trace_shadow), LM_GRID(g), sc, fr, cnt, tmin, refillBelow); }
@@ -1478,7 +1530,17 @@ static void l_trace_shade(hipStream_t s, int g, LmScene sc, LmFrame fr, int rc, 
 static void l_temporal(hipStream_t s, int g, LmFrame fr, int cur, int prev, int rc, int rp, int rf, uint32_t seed, uint32_t* visCount, int fast)
 { if (fast) { hipLaunchKernelGGL(KN(lm_k_restir_temporal_fast), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); if (fast > 1) hipLaunchKernelGGL(KN(lm_k_restir_temporal_rare), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); } else hipLaunchKernelGGL(KN(lm_k_restir_temporal), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); }
 static void l_spatial(hipStream_t s, int g, LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin, int pass, int fast)
-{ if (fast) { hipLaunchKernelGGL(KN(lm_k_restir_spatial_fast), LM_GRID(g), fr, cur, rin, rout, seed, margin, pass); if (fast > 1) hipLaunchKernelGGL(KN(lm_k_restir_spatial_rare), LM_GRID(g), fr, cur, rin, rout, seed, margin, pass); } else hipLaunchKernelGGL(KN(lm_k_restir_spatial), LM_GRID(g), fr, cur, rin, rout, seed, margin, pass); }
+{
+    // fast | 16: the first pass stages its probe window in LDS (32 x 32 pixel tiles, 1024-thread blocks; tuning key spatial_lds)
+    if ((fast & 16) && pass == 0) {
+        const int g32 = (int)(((fr.ww + 31u) / 32u) * ((fr.wh + 31u) / 32u));
+        hipLaunchKernelGGL(KN(lm_k_restir_spatial_fast_lds), dim3((unsigned)g32), dim3(1024), 0, s, fr, cur, rin, rout, seed, margin);
+        if ((fast & 15) > 1) hipLaunchKernelGGL(KN(lm_k_restir_spatial_rare), LM_GRID(g), fr, cur, rin, rout, seed, margin, pass);
+        return;
+    }
+    fast &= 15;
+    if (fast) { hipLaunchKernelGGL(KN(lm_k_restir_spatial_fast), LM_GRID(g), fr, cur, rin, rout, seed, margin, pass); if (fast > 1) hipLaunchKernelGGL(KN(lm_k_restir_spatial_rare), LM_GRID(g), fr, cur, rin, rout, seed, margin, pass); } else hipLaunchKernelGGL(KN(lm_k_restir_spatial), LM_GRID(g), fr, cur, rin, rout, seed, margin, pass);
+}
 static void l_combine(hipStream_t s, int g, LmFrame fr, int cur, int rc, int rs, uint32_t seed, int fast)
 { if (fast) { hipLaunchKernelGGL(KN(lm_k_restir_combine_fast), LM_GRID(g), fr, cur, rc, rs, seed); if (fast > 1) hipLaunchKernelGGL(KN(lm_k_restir_combine_rare), LM_GRID(g), fr, cur, rc, rs, seed); } else hipLaunchKernelGGL(KN(lm_k_restir_combine), LM_GRID(g), fr, cur, rc, rs, seed); }
 static void l_clear(hipStream_t s, int g, float4* p, uint32_t n) { hipLaunchKernelGGL(KN(lm_k_clear_f4), LM_GRID(g), p, n); }

@@ -206,7 +206,6 @@ LM_HD float lm_halton(uint32_t index, uint32_t base)
         constexpr LmThirds T = lm_thirds();
         uint32_t i1 = index + 1u;
         float r = 0.f;
-#pragma unroll
         for (int k = 0; k < 21; k++) {
             if (i1 == 0u) break;
             const uint32_t q = i1 / 3u;

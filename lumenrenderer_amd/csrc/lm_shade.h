@@ -214,7 +214,7 @@ __device__ __forceinline__ void lm_gbuf_load(const float4* __restrict__ g, uint3
 // rows, column-major inside a band, and each XCD (blocks b, b+8, ... share one) gets a contiguous run of that order, so the
 // tiles resident on one XCD form a compact patch and neighbour gathers (+-30 px) hit that XCD's L2.  Speed only.
 template <uint32_t LOG_TS = 4>   // tile edge = 1 << LOG_TS: 16 for 256-thread blocks, 32 for 1024-thread blocks
-__device__ __forceinline__ bool lm_tile_pixel(const LmFrame& fr, uint32_t& li, uint32_t& gi)
+__device__ __forceinline__ void lm_tile_origin(const LmFrame& fr, uint32_t& tx, uint32_t& ty)      // the block's tile (block-uniform)
 {
     constexpr uint32_t TS = 1u << LOG_TS;
     const uint32_t tilesX = (fr.ww + TS - 1u) >> LOG_TS, tilesY = (fr.wh + TS - 1u) >> LOG_TS, T = tilesX * tilesY;
@@ -222,7 +222,14 @@ __device__ __forceinline__ bool lm_tile_pixel(const LmFrame& fr, uint32_t& li, u
     const uint32_t t = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (b >> 3);
     const uint32_t band = t / (8u * tilesX), within = t - band * 8u * tilesX;
     const uint32_t bh = min(8u, tilesY - band * 8u);
-    const uint32_t tx = within / bh, ty = band * 8u + within % bh;
+    tx = within / bh; ty = band * 8u + within % bh;
+}
+template <uint32_t LOG_TS = 4>
+__device__ __forceinline__ bool lm_tile_pixel(const LmFrame& fr, uint32_t& li, uint32_t& gi)
+{
+    constexpr uint32_t TS = 1u << LOG_TS;
+    uint32_t tx, ty;
+    lm_tile_origin<LOG_TS>(fr, tx, ty);
     const uint32_t lx = tx * TS + (threadIdx.x & (TS - 1u)), ly = ty * TS + (threadIdx.x >> LOG_TS);
     if (lx >= fr.ww || ly >= fr.wh) return false;
     li = ly * fr.ww + lx;
@@ -233,6 +240,7 @@ __device__ __forceinline__ bool lm_tile_pixel(const LmFrame& fr, uint32_t& li, u
 // ---------------------------------------------------------------------------------------------------------------------
 // lights / CDF — reference ReSTIRData.h:230-306 (CDF::Get, BinarySearch)
 // ---------------------------------------------------------------------------------------------------------------------
+template <class A = LmExact>
 __device__ __forceinline__ void lm_cdf_get(const LmScene& sc, float value, uint32_t& index, float& pdf)
 {
     const float required = sc.cdfSum * value;
@@ -244,7 +252,7 @@ __device__ __forceinline__ void lm_cdf_get(const LmScene& sc, float value, uint3
         if (required < lower && center - 1 >= first) { last = center - 1; continue; }
         if (required > higher && center + 1 <= last) { first = center + 1; continue; }
         index = (uint32_t)center;
-        pdf = (higher - lower) / sc.cdfSum;
+        pdf = A::div(higher - lower, sc.cdfSum);
         return;
     }
 }
@@ -261,29 +269,33 @@ __device__ __forceinline__ LmTriLight lm_load_light(const LmLight* __restrict__ 
 // ---------------------------------------------------------------------------------------------------------------------
 // NEE (reference GPUShadeDirect.cu:42-153) and continuation (GPUShadeIndirect.cu:7-146) on one surface
 // ---------------------------------------------------------------------------------------------------------------------
+// Arithmetic policy A (lm_bsdf.h): LmExact is the bit-exact contract.  LmFast (tuning key fast_shade) evaluates the light's CONTRIBUTION with hardware
+// reciprocal / square root; what it can change beyond the last bits of a radiance value is a shadow ray within rounding of the two thresholds
+// below (cosIn <= 0, bsdfPdf <= epsilon) — never which path continues: sampling and Russian roulette (lm_shade_indirect) stay exact in every mode.
+template <class A = LmExact>
 __device__ bool lm_shade_direct(const LmScene& sc, const LmSurface& s, uint32_t gi, uint32_t seedIn, lf3& dir, float& tmaxOut, lf3& radiance)
 {
     uint32_t seed = lm_wang_hash(seedIn + gi);
     if (s.flags) return false;
     uint32_t index; float pdf;
-    lm_cdf_get(sc, lm_random_float(seed), index, pdf);
+    lm_cdf_get<A>(sc, lm_random_float(seed), index, pdf);
     const LmTriLight light = lm_load_light(sc.lights, index);
     const float u = lm_random_float(seed);
     const float v = lm_random_float(seed) * (1.f - u);
     const lf3 arm1 = light.p1 - light.p0, arm2 = light.p2 - light.p0;
     const lf3 lightCenter = light.p0 + (arm1 * u) + (arm2 * v);
     lf3 toLight = lightCenter - s.position;
-    const float lDistance = length3(toLight);
-    toLight = toLight / lDistance;
+    const float lDistance = A::sqrt(dot3(toLight, toLight));
+    toLight = lm_scale_inv<A>(toLight, lDistance);
     const float cosIn = fmaxf(dot3(toLight, s.normal), 0.f);
     const float cosOut = fmaxf(0.f, dot3(light.normal, -toLight));
     if (cosIn <= 0.f || lDistance <= 0.01f) return false;
-    const float solidAngle = (cosOut * light.area) / (lDistance * lDistance);
+    const float solidAngle = A::div(cosOut * light.area, lDistance * lDistance);
     float bsdfPdf = 0.f;
-    const lf3 bsdf = lm_evaluate_bsdf(s.mat, s.normal, s.tangent, -s.incoming, toLight, bsdfPdf);
+    const lf3 bsdf = lm_evaluate_bsdf<A>(s.mat, s.normal, s.tangent, -s.incoming, toLight, bsdfPdf);
     if (bsdfPdf <= LM_EPSILON) return false;
-    lf3 contribution = (bsdf / bsdfPdf) * solidAngle * cosIn * light.radiance;
-    contribution = contribution * ((1.f / pdf) * s.transport);
+    lf3 contribution = lm_scale_inv<A>(bsdf, bsdfPdf) * solidAngle * cosIn * light.radiance;
+    contribution = contribution * (A::rcp(pdf) * s.transport);
     dir = toLight; tmaxOut = lDistance - 0.2f; radiance = contribution;
     return true;
 }

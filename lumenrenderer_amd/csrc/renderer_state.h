@@ -187,6 +187,9 @@ struct lumen_mi_renderer {
     uint32_t refits = 0;                    // refits since the last full build
     int refitEnabled = 1;                   // 0: every transform change triggers a full host rebuild
     bool anyRareMaterial = false;           // some material ever created may need the second (exact) launch of the fast ReSTIR passes
+    int fastShade = 0;                      // the NEE contribution of the shading kernels (depth >= 1) in the fast arithmetic policy (lm_shade.h lm_shade_direct): changes radiance
+                                            // in the last bits only; sampling / Russian roulette stay exact.  Off: measured gain below 2 % (profiles/r03_fast_shade_ab.txt)
+    int spatialLds = 0;                     // fast mode: the first spatial pass stages its probe window in LDS (lm_k_restir_spatial_fast_lds): 1 on, 0 off
     int packetVisibility = 0;               // the ReSTIR visibility rays likewise (lm_k_restir_trace_shade_packet): 1 on, 0 off (default), -1 the primary wave's rule.
                                             // Measured 3x SLOWER on C2 (profiles/r03_packet_visibility_ab.txt): a tile's visibility rays start on surfaces at very
                                             // different depths, the union of their paths is large, and an any-hit packet runs until its last unoccluded ray is through

@@ -1265,6 +1265,31 @@ def test_fast_resampling_mode_stays_within_the_north_star_tolerance(case):
     r.close(); o.close()
 
 
+@pytest.mark.parametrize("case", ["c1", "c2", "c3", "c5", "mixed", "c2t"])
+def test_fast_shade_changes_only_the_last_bits(case):
+    """Tuning key "fast_shade" (on top of fast_resample): the NEE contribution at depth >= 1 is evaluated with hardware reciprocal / square
+    root.  It decides nothing but two thresholds of a shadow ray's emission; sampling and Russian roulette stay exact, so the rays of
+    every wave are the oracle's, and the radiance stays within the north-star tolerance (measured figure printed)."""
+    from lumenrenderer_amd import scenes
+    kind, kw, W, H, D, frames = FAST_CASES[case]
+    d = cornell() if kind == "cornell" else scenes.sponza_standin(**kw) if kind == "sponza" else _textured_scene() if kind == "textured" else scenes.foliage_stress()
+    r = product_from(d, W, H, D, blend=True, tuning={"fast_resample": 1, "fast_shade": 1})
+    o = oracle_from(d, W, H, D, blend=True)
+    for _ in range(frames):
+        assert r.TraceFrameAsync()
+        assert o.trace_frame() == 0
+    r.Synchronize()
+    got, want = r.GetRadiance(), o.radiance()
+    err = rel_l2(got[..., :3], want[..., :3])
+    print(f"fast_shade {case}: rel-L2 {err:.3e}")
+    assert np.isfinite(got).all() and err <= RADIANCE_TOL, (case, err)
+    c, s = r.GetCounters(), o.stats(24)
+    assert list(c[4:4 + D]) == list(s[4:4 + D])                       # which rays exist does not depend on the NEE arithmetic
+    for k in range(3):
+        assert abs(int(c[k]) - int(s[k])) <= 1e-3 * max(1, int(s[k])), (case, k, c[:4], s[:4])
+    r.close(); o.close()
+
+
 def test_fast_mode_with_an_srgb_flagged_metal_roughness_map_takes_the_exact_launch():
     """whether fast mode enqueues the second (exact, LM_RARE) launch of each ReSTIR pass is predicted on the host from the
     smallest green texel of a material's metal-roughness map.  A map created with normalize = 1 is sRGB-decoded by the device fetch
@@ -1296,6 +1321,24 @@ def test_fast_mode_with_an_srgb_flagged_metal_roughness_map_takes_the_exact_laun
     print(f"fast mode, sRGB-flagged metal-roughness map: rel-L2 {err:.3e}, rare surfaces {c[52]}")
     assert err <= RADIANCE_TOL, err
     r.close(); o.close()
+
+
+@pytest.mark.parametrize("shape", [(2560, 1440, 6), (333, 217, 5)])
+def test_spatial_pass_with_probes_in_lds_gives_the_same_image(shape):
+    """Tuning key spatial_lds (fast mode): the first spatial pass stages the probes of a 32 x 32 tile + 30-pixel border in LDS (132 KB) and
+    tests its five neighbours there instead of gathering them; the probes are the same bits, so the image must be the other kernel's to
+    the bit — at the benchmark size and on a window whose edges cut the tiles and the border."""
+    from lumenrenderer_amd.scenes import sponza_standin
+    W, H, D = shape
+    imgs = []
+    for lds in (0, 1):
+        r = product_from(sponza_standin(), W, H, D, blend=True, tuning={"fast_resample": 1, "spatial_lds": lds})
+        for _ in range(3):
+            assert r.TraceFrameAsync()
+        r.Synchronize()
+        imgs.append((r.GetRadiance().copy(), list(r.GetCounters(8))))
+        r.close()
+    assert np.array_equal(imgs[0][0].view(np.uint32), imgs[1][0].view(np.uint32)) and imgs[0][1] == imgs[1][1]
 
 
 def test_c4_4k_depth8_overlapped_schedule_equals_the_serial_one():
