@@ -55,7 +55,7 @@ int ensureFrameBuffers(R* r)
     if (hipMemsetAsync(f.output, 0, (size_t)n * sizeof(uchar4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
     r->fenceNeeded = 2;
     r->haveEst = false; r->cntPending[0] = r->cntPending[1] = false;
-    if (r->dSwap.ensure(2) || hipMemsetAsync(r->dSwap.p, 0, 2 * sizeof(int), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "swap index allocation failed");
+    if (r->dSwap.ensure(4) || hipMemsetAsync(r->dSwap.p, 0, 4 * sizeof(int), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "swap index allocation failed");
     f.swap = r->dSwap.p;
     r->blendCounter = 0; r->frameIndex = 0; r->gbufIndex = 0; r->lastGbuf = 0;
     r->allocN = n;

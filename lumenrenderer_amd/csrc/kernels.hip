@@ -768,7 +768,8 @@ __device__ __forceinline__ void lm_restir_temporal_body(const LmFrame& fr, int c
                     if (lm_role_takes<ROLE>(s.mat)) {              // fast mode: the other launch merges this pixel
                         mine = true;
                         LmReservoir rpv, rcv;
-                        lm_res_load(fr.res[rp], fr.resC[rp], tli, rpv);
+                        // a previous buffer that has not been written since the reset holds zeros: the same reservoir without the 80-byte gather
+                        if (rp > 1 || fr.swap[2 + rp] != 0) lm_res_load(fr.res[rp], fr.resC[rp], tli, rpv); else lm_res_fresh(rpv);
                         lm_res_load(fr.res[rf], fr.resC[rf], li, rcv);
                         if (rpv.weight > 0.f) {                    // ShadeReservoirs on the PREVIOUS reservoir
                             const lf3 add = rpv.s.contribution * (rpv.weight / 3.f);
@@ -1030,6 +1031,7 @@ KN(lm_k_merge_output)(LmFrame fr, int blend, uint32_t blendCount, int depthMax)
     if (blockIdx.x == 0 && threadIdx.x == 0) {     // ReSTIR::SwapBuffers once per executed wave (WaveFrontRenderer.cpp:697,827)
         int executed = 0;
         for (int d = 0; d < depthMax; d++) executed += fr.counters[LM_CNT_RAYS(d)] > 0u;
+        fr.swap[2 + (*fr.swap & 1)] = 1;             // this frame's passes wrote the current swap-chain buffer
         *fr.swap = (*fr.swap + executed) & 1;
         fr.swap[1] = executed;
     }
@@ -1264,6 +1266,7 @@ KN(lm_k_history_copy)(LmFrame fr, uint32_t x0, uint32_t y0, uint32_t w, uint32_t
     const int rp = lm_res_idx(fr, LM_RES_PREV);
     float4* hot = fr.res[rp];
     float4* con = fr.resC[rp];
+    if (import && blockIdx.x == 0 && threadIdx.x == 0) fr.swap[2 + rp] = 1;      // the next temporal pass must read what arrives here
     const uint32_t n = w * h, stride = gridDim.x * LM_BLOCK;
     for (uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x; i < n; i += stride) {
         const uint32_t yy = i / w, xx = i - yy * w;

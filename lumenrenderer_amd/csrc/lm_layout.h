@@ -142,6 +142,9 @@ struct LmFrame {
                                 // wave, and the wave loop ends when a wave's queue is empty (WaveFrontRenderer.cpp:697,827) — a count only
                                 // the device knows without a host round trip.  Kernels take buffer indices as LM_RES_* codes.
                                 // swap[1] = waves the last frame executed (multi-GPU: ranks agree on the maximum, lm_k_wave_sync).
+                                // swap[2], swap[3] = has swap-chain buffer 0 / 1 been written since the reservoirs were reset?  With an even number of
+                                // executed waves per frame the "previous" buffer of the temporal pass never is: the pass then takes the
+                                // reset reservoir it would load (all zero) without loading it.
     uint2* bags;                // 50 x 1000 light-bag entries: (light index, pdf bits)
 };
 // reservoir buffer index codes of the ReSTIR kernels: a literal index >= 0, or the swap-chain front / back buffer
