@@ -763,26 +763,49 @@ __device__ __forceinline__ void lm_restir_temporal_body(const LmFrame& fr, int c
                 const float angle = dot3(v3(pn), v3(cn));
                 if (depthDif < 0.10f && angle > 0.72222222223f) {
                     merged = true;
+#ifndef LM_TEMPORAL_SHORTCUT
+#define LM_TEMPORAL_SHORTCUT 1     // 0: A/B switch, the previous reservoir is always gathered and both samples re-evaluated
+#endif
+                    const bool prevLive = !LM_TEMPORAL_SHORTCUT || rp > 1 || fr.swap[2 + rp] != 0;       // block-uniform
                     LmSurface s;
-                    lm_gbuf_load(fr.gbuf[cur], li, s);
+                    if (prevLive) lm_gbuf_load(fr.gbuf[cur], li, s);
+                    else {                                         // the shortcut below needs the position and the packed parameters only: the first half of the record's line
+                        const float4 q0 = fr.gbuf[cur][8u * li + LM_GB_POSITION], q7 = fr.gbuf[cur][8u * li + LM_GB_PARAMS];
+                        s.position = v3(q0); s.mat.p0 = f2u(q7.x); s.mat.p1 = f2u(q7.y); s.mat.p2 = f2u(q7.z);
+                    }
                     if (lm_role_takes<ROLE>(s.mat)) {              // fast mode: the other launch merges this pixel
                         mine = true;
-                        LmReservoir rpv, rcv;
-                        // a previous buffer that has not been written since the reset holds zeros: the same reservoir without the 80-byte gather
-                        if (rp > 1 || fr.swap[2 + rp] != 0) lm_res_load(fr.res[rp], fr.resC[rp], tli, rpv); else lm_res_fresh(rpv);
+                        LmReservoir rpv, rcv, out;
                         lm_res_load(fr.res[rf], fr.resC[rf], li, rcv);
-                        if (rpv.weight > 0.f) {                    // ShadeReservoirs on the PREVIOUS reservoir
-                            const lf3 add = rpv.s.contribution * (rpv.weight / 3.f);
-                            float4 px = fr.direct[li];
-                            px.x += add.x; px.y += add.y; px.z += add.z;
-                            fr.direct[li] = px;
+                        if (prevLive) {
+                            lm_res_load(fr.res[rp], fr.resC[rp], tli, rpv);
+                            if (rpv.weight > 0.f) {                    // ShadeReservoirs on the PREVIOUS reservoir
+                                const lf3 add = rpv.s.contribution * (rpv.weight / 3.f);
+                                float4 px = fr.direct[li];
+                                px.x += add.x; px.y += add.y; px.z += add.z;
+                                fr.direct[li] = px;
+                            }
+                            const long long cap = rcv.count * 20;
+                            if (cap < rpv.count) rpv.count = cap;
+                            LmTarget target;
+                            lm_target_setup<A>(s, target);
+                            if (LM_TEMPORAL_SHORTCUT) lm_combine2_b_scored_here<A>(out, rpv, rcv, target, lm_wang_hash(seed + gi));     // the fresh sample was scored at this surface by the pick
+                            else lm_combine2<A>(out, rpv, rcv, target, lm_wang_hash(seed + gi));
+                        } else {
+                            // The previous buffer has not been written since the reservoirs were reset (every frame of an even path depth: the
+                            // reference's swap quirk): it holds the reset reservoir — count 0, weight 0, a zero sample.  CombineBiased of that and the
+                            // fresh reservoir needs neither gather nor evaluation: Resample of the zero sample ends at cosOut <= 0 (pdf 0, weight
+                            // (float)0 * 0 * 0), and Resample of the fresh sample at THIS surface returns what the candidate pick stored — the
+                            // same function of the same surface record and light point.  The two Updates, the count and UpdateWeight run as in
+                            // lm_combine2, so the reservoir written is the same, bit for bit (the whole parity suite runs through this branch).
+                            const uint32_t sd = lm_wang_hash(seed + gi);
+                            lm_res_fresh(out);
+                            LmSample zero; lm_sample_zero(zero);
+                            lm_res_update<A>(out, zero, (float)0ll * 0.f * 0.f, sd);
+                            lm_res_update<A>(out, rcv.s, (float)rcv.count * rcv.weight * rcv.s.pdf, sd);
+                            out.count = 0ll + rcv.count;
+                            lm_res_update_weight<A>(out);
                         }
-                        const long long cap = rcv.count * 20;
-                        if (cap < rpv.count) rpv.count = cap;
-                        LmTarget target;
-                        lm_target_setup<A>(s, target);
-                        LmReservoir out;
-                        lm_combine2<A>(out, rpv, rcv, target, lm_wang_hash(seed + gi));
                         lm_res_store(fr.res[rc], fr.resC[rc], li, out);
                         weight = out.weight; vtarget = out.s.p.position; vpos = s.position;
                     }
@@ -992,7 +1015,12 @@ __device__ __forceinline__ void lm_restir_combine_body(const LmFrame& fr, int cu
     LmReservoir a, b, out;
     lm_res_load(fr.res[rc], fr.resC[rc], li, a);
     lm_res_load(fr.res[rs], fr.resC[rs], li, b);
-    lm_combine2<A>(out, a, b, target, lm_wang_hash(seed + gi));
+#ifndef LM_COMBINE_SHORTCUT
+#define LM_COMBINE_SHORTCUT 0      // 1: the current reservoir's sample, scored at this surface by the temporal pass, is not re-evaluated (lm_combine2_a_scored_here).
+#endif                             //    Identical image, 6 M fewer wave instructions per frame — and the frame 0.5 % SLOWER (2454.7 -> 2443.3, same box, spread 0.1 %:
+                                   //    profiles/r03_restir_shortcuts_ab.txt); the pass is an HBM stream.  Off.
+    if (LM_COMBINE_SHORTCUT) lm_combine2_a_scored_here<A>(out, a, b, target, lm_wang_hash(seed + gi));
+    else lm_combine2<A>(out, a, b, target, lm_wang_hash(seed + gi));
     lm_res_store(fr.res[rc], fr.resC[rc], li, out);
 }
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
@@ -1224,7 +1252,7 @@ KN(lm_k_export_aux)(LmFrame fr, int cur, float minD, float maxD, float* __restri
         if (t < 0.f) { if (depth) depth[li] = 0.f; continue; }
         if (depth) depth[li] = (t - fminf(minD, t)) / (fmaxf(maxD, t) - fminf(minD, t));
         if (normalRoughness) {
-            LmMaterial m; m.p0 = f2u(rec[7].x); m.p1 = 0u; m.p2 = 0u;
+            LmMaterial m; m.p0 = f2u(rec[LM_GB_PARAMS].x); m.p1 = 0u; m.p2 = 0u;
             const float rough = LM_P_ROUGHNESS(m);
             normalRoughness[li] = make_uint2(lm_f32_to_f16(b.x) | (lm_f32_to_f16(b.y) << 16), lm_f32_to_f16(b.z) | (lm_f32_to_f16(rough) << 16));
         }

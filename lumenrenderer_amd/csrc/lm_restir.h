@@ -150,3 +150,30 @@ template <class A> __device__ __forceinline__ void lm_combine2(LmReservoir& dst,
     lm_res_update_weight<A>(out);
     dst = out;
 }
+// The same merge where reservoir `a` holds a sample that was last scored AT THIS receiver (the current reservoir of a pixel after the temporal
+// pass: pick, temporal merge and temporal copy all leave the sample's pdf and contribution as lm_score gives them for this very surface
+// record; the visibility pass in between only zeroes the weight).  Resample of it would recompute the stored values from the same
+// operands — the evaluation is skipped, everything else is lm_combine2.
+template <class A> __device__ __forceinline__ void lm_combine2_a_scored_here(LmReservoir& dst, const LmReservoir& a, const LmReservoir& b, const LmTarget& t, uint32_t seed)
+{
+    LmReservoir out; lm_res_fresh(out);
+    lm_res_update<A>(out, a.s, (float)a.count * a.weight * a.s.pdf, seed);
+    LmSample rs;
+    lm_resample<A>(b.s, t, rs);
+    lm_res_update<A>(out, rs, (float)b.count * b.weight * rs.pdf, seed);
+    out.count = a.count + b.count;
+    lm_res_update_weight<A>(out);
+    dst = out;
+}
+// ... and where it is `b` that was scored here (the temporal merge: `a` = the previous frame's reservoir, re-evaluated; `b` = this frame's fresh one)
+template <class A> __device__ __forceinline__ void lm_combine2_b_scored_here(LmReservoir& dst, const LmReservoir& a, const LmReservoir& b, const LmTarget& t, uint32_t seed)
+{
+    LmReservoir out; lm_res_fresh(out);
+    LmSample rs;
+    lm_resample<A>(a.s, t, rs);
+    lm_res_update<A>(out, rs, (float)a.count * a.weight * rs.pdf, seed);
+    lm_res_update<A>(out, b.s, (float)b.count * b.weight * b.s.pdf, seed);
+    out.count = a.count + b.count;
+    lm_res_update_weight<A>(out);
+    dst = out;
+}
