@@ -42,7 +42,8 @@ def run(W, H, depth, tuning, window, tile, sync_each, frames=8):
 
 shapes = [(1280, 720, 5, None, None), (1280, 720, 6, None, None), (2560, 1440, 6, None, None)]
 t8 = tiles.tile_rect(1, 8, 2560, 1440); shapes.append((2560, 1440, 5, tiles.window_rect(t8, 2560, 1440), t8))
-schedules = [{}, {"pick_ahead": 0}, {"shadow_on_wave": 1}, {"tail_below": 0}, {"tail_below": 1 << 30}, {"tail_below": 60000, "tail_lanes": 64}]
+schedules = [{}, {"pick_ahead": 0}, {"shadow_on_wave": 1}, {"tail_below": 0}, {"tail_below": 1 << 30}, {"tail_below": 60000, "tail_lanes": 64},
+             {"tail_pair": 1, "tail_below": 1 << 30}, {"tail_pair": 1, "tail_below": 60000, "tail_lanes": 16}]
 bad = total = 0
 t0 = time.time()
 for (W, H, depth, window, tile) in shapes:

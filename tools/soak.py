@@ -46,19 +46,28 @@ r = LumenRendererMI(); r.Init(depth=6, render_resolution=(W, H), blend_output=Fa
 r.LoadSceneDescription(desc)
 for k in range(50): r.TraceFrameAsync()
 r.Synchronize()
-dev0, rss0, t0 = used(), resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024, time.perf_counter()
-mid = None
+def rss():                                           # CURRENT resident set (ru_maxrss is a high-water mark: one late buffer growth would read as a leak)
+    return int(open("/proc/self/statm").read().split()[1]) * os.sysconf("SC_PAGE_SIZE") / 2**20
+
+
+dev0, rss0, t0 = used(), rss(), time.perf_counter()
+samples = []                                         # (frame, device MiB, host MiB) at every eighth of the run
 for k in range(N):
     edits(r, k)
     assert r.TraceFrameAsync()
-    if k == N // 2:
-        r.Synchronize(); mid = (used(), resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024)
+    if (k + 1) % max(1, N // 8) == 0:
+        r.Synchronize(); samples.append((k + 1, used(), rss()))
 r.Synchronize()
 t1 = time.perf_counter()
-dev1, rss1 = used(), resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024
+dev1, rss1 = used(), rss()
 print(f"{N} frames in {t1 - t0:.1f} s ({(t1 - t0) / N * 1e3:.2f} ms per TraceFrame incl. edits)")
-print(f"device memory in use: start {dev0:.0f} MiB, middle {mid[0]:.0f} MiB, end {dev1:.0f} MiB;  host max RSS: start {rss0:.0f} MiB, middle {mid[1]:.0f} MiB, end {rss1:.0f} MiB")
+print(f"start: device {dev0:.0f} MiB, host {rss0:.0f} MiB; " + "; ".join(f"{f}: {d:.0f} / {h:.0f}" for f, d, h in samples))
 assert np.isfinite(r.GetRadiance()).all()
-assert dev1 - mid[0] < 64 and rss1 - mid[1] < 64, "memory grows"
+# steady state: nothing grows over the last quarter of the run, and what the first three quarters added is bounded (staging buffers and the
+# per-mesh tree cache reach their high-water marks at a frame that depends on how edits and frames in flight interleave: a one-time step of
+# ~190 MiB was seen anywhere between frame 2 000 and 6 000, flat for the 18 000 frames after it — tools/rss_probe.py)
+q3 = samples[-3]
+assert dev1 - q3[1] < 64 and rss1 - q3[2] < 64, "memory grows over the last quarter"
+assert dev1 - dev0 < 256 and rss1 - rss0 < 1024, "memory grew beyond the staging high-water marks"
 print("soak ok")
 r.close()
