@@ -234,7 +234,10 @@ int traceFrameAsync(R* r)
     int tailDepth = (int)depthMax;
     // (fast ReSTIR mode shortens the candidate / reuse kernels: the wave chain is then the critical path at every window size, and the
     // larger threshold measured +4.6 % on C2)
-    const uint32_t tailBelow = r->tailBelow >= 0 ? (uint32_t)r->tailBelow : ((fr.n < (1u << 20) || r->fastResample) ? 65536u : 16384u);
+    // round 3 (the temporal pass got cheaper, the wave chain is the longer one by more): 100 000 in fast mode on large windows, i.e. on C2 the wave of 92 k rays joins the
+    // tail: +1.8 % (C2), +4.2 % (textured C2), +-0 (C4, C5), -0.9 % (C3), five / three interleaved runs each on one box; exact mode keeps 16 384 (65 536: -1.2 %,
+    // 120 000: -2.9 %) — profiles/r03_knobs_ab.txt
+    const uint32_t tailBelow = r->tailBelow >= 0 ? (uint32_t)r->tailBelow : (fr.n < (1u << 20) ? 65536u : r->fastResample ? 100000u : 16384u);
     if (tailBelow && r->haveEst) for (uint32_t dd = 1; dd < depthMax; dd++) if (r->estRays[dd] < tailBelow) { tailDepth = (int)dd; break; }
     int q = 0;
     size_t ev;
