@@ -46,6 +46,8 @@ struct Task { uint32_t first, count, depth; };
 // SAH constants (tunable for experiments through LUMEN_MI_BVH_TRAV_COST / LUMEN_MI_BVH_LEAF_MAX)
 float g_travCost = 1.0f;       // cost of one node step relative to one triangle test
 uint32_t g_leafMax = 4;        // largest leaf the SAH may choose (LM_MAX_LEAF = 8 is the format's limit)
+uint32_t g_sweepBelow = 0;     // nodes of at most this many triangles are split by an exact SAH sweep over the sorted centroids of each axis instead of 16 bins
+                               // (LUMEN_MI_BVH_SWEEP; 0 = binned everywhere).  Measured on C2: see profiles/r03_bvh_sweep_ab.txt
 
 // One builder instance = one output arena (nodes + leaf order with LOCAL indices).  The top-level instance cuts subtrees of
 // at most `taskThreshold` triangles into tasks; the task builders run in parallel on disjoint ranges of the shared index
@@ -104,7 +106,41 @@ struct Builder {
         const bool forceMedian = (int)depth + ilog2ceil(count) + 2 >= LM_BVH2_MAX_DEPTH - 2;
         uint32_t mid = 0;
         bool split = false;
-        if (!forceMedian) {
+        if (!forceMedian && count <= g_sweepBelow) {
+            // exact sweep: every position of the centroid order of every axis is a candidate (same cost function as the bins below)
+            float bestCost = INFINITY; int bestAxis = -1; uint32_t bestK = 0;
+            std::vector<float> rightArea(count);
+            for (int axis = 0; axis < 3; axis++) {
+                if (!(cbox.hi[axis] > cbox.lo[axis])) continue;
+                std::sort(ids + first, ids + first + count, [&](uint32_t a, uint32_t b) {
+                    const float ka = cen[3 * (size_t)a + axis], kb = cen[3 * (size_t)b + axis];
+                    return ka < kb || (ka == kb && a < b);
+                });
+                Box acc; acc.reset();
+                for (uint32_t k = count - 1; k > 0; k--) { acc.grow(tbox[ids[first + k]]); rightArea[k] = acc.area(); }
+                acc.reset();
+                for (uint32_t k = 0; k + 1 < count; k++) {
+                    acc.grow(tbox[ids[first + k]]);
+                    const float cost = acc.area() * (float)(k + 1) + rightArea[k + 1] * (float)(count - k - 1);
+                    if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestK = k + 1; }
+                }
+            }
+            const float leafCost = box.area() * (float)count;
+            if (bestAxis >= 0 && (count > g_leafMax || bestCost + box.area() * g_travCost < leafCost)) {
+                if (bestAxis != 2) std::sort(ids + first, ids + first + count, [&](uint32_t a, uint32_t b) {      // (the ids are in the order of the last axis swept)
+                    const float ka = cen[3 * (size_t)a + bestAxis], kb = cen[3 * (size_t)b + bestAxis];
+                    return ka < kb || (ka == kb && a < b);
+                });
+                else if (!(cbox.hi[2] > cbox.lo[2])) std::sort(ids + first, ids + first + count, [&](uint32_t a, uint32_t b) {
+                    const float ka = cen[3 * (size_t)a + bestAxis], kb = cen[3 * (size_t)b + bestAxis];
+                    return ka < kb || (ka == kb && a < b);
+                });
+                mid = first + bestK;
+                split = true;
+            } else if (count <= g_leafMax) {
+                return makeLeaf(first, count, box);
+            }
+        } else if (!forceMedian) {
             const int NB = 16;
             float bestCost = INFINITY; int bestAxis = -1, bestBin = -1;
             // bins of all three axes in one pass (per thread for big nodes, merged in thread order)
@@ -256,6 +292,7 @@ void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out)
     unsigned threads = std::max(1u, std::min(64u, usableCpus()));
     if (const char* e = getenv("LUMEN_MI_BUILD_THREADS")) threads = (unsigned)std::max(1, atoi(e));
     if (const char* e = getenv("LUMEN_MI_BVH_TRAV_COST")) g_travCost = (float)atof(e);
+    if (const char* e = getenv("LUMEN_MI_BVH_SWEEP")) g_sweepBelow = (uint32_t)std::max(0, atoi(e));
     if (const char* e = getenv("LUMEN_MI_BVH_LEAF_MAX")) g_leafMax = (uint32_t)std::max(1, std::min((int)LM_MAX_LEAF, atoi(e)));
     std::vector<Box> tbox(nTris); std::vector<float> cen(3 * (size_t)nTris); std::vector<uint32_t> ids(nTris);
     std::vector<float> partMax(threads, 0.f);
