@@ -586,6 +586,10 @@ KN(lm_k_fill_bags)(LmScene sc, LmFrame fr, uint32_t seed, uint32_t total)
 #ifndef LM_PICK_LDS_LIGHTS
 #define LM_PICK_LDS_LIGHTS 256u
 #endif
+#ifndef LM_PICK_STATIC_LDS
+#define LM_PICK_STATIC_LDS 1       // 1: the table is a static 16-KB array whatever the light count; 0: sized by the launch (128 B for the benchmark scene's two lights).
+#endif                             // The smaller footprint lets more blocks of this VALU-saturating kernel onto a CU and the frame loses 0.7 % (2551 -> 2533, six runs each,
+                                   // builds interleaved on one box): the 16 KB double as the residency cap the other streams' kernels need.
 template <class A, int ROLE, bool LDSL = false>
 __device__ __forceinline__ void lm_pick_primary_body(const LmScene& sc, const LmFrame& fr, int cur, int rc, uint32_t seed, uint32_t* visCount, uint2* s_bag, uint32_t* s_tmp,
                                                      float4* s_lights = nullptr)
@@ -710,7 +714,11 @@ KN(lm_k_pick_primary_lds)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed
 {
     __shared__ uint2 s_bag[1000];
     __shared__ uint32_t s_tmp[5];
-    __shared__ float4 s_lights[4 * LM_PICK_LDS_LIGHTS + 1];
+#if LM_PICK_STATIC_LDS
+    __shared__ float4 s_lights[4 * LM_PICK_LDS_LIGHTS + 1];      // A/B switch: the 16-KB table of round 2
+#else
+    extern __shared__ float4 s_lights[];             // 64 B per emissive triangle, sized by the launch (l_pick_primary): the benchmark scene's two lights cost 128 B, not 16 KB
+#endif
     lm_pick_primary_body<LmExact, LM_ALL, true>(sc, fr, cur, rc, seed, visCount, s_bag, s_tmp, s_lights);
 }
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_FAST_WAVES)
@@ -718,7 +726,11 @@ KN(lm_k_pick_primary_fast_lds)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t
 {
     __shared__ uint2 s_bag[1000];
     __shared__ uint32_t s_tmp[5];
+#if LM_PICK_STATIC_LDS
     __shared__ float4 s_lights[4 * LM_PICK_LDS_LIGHTS + 1];
+#else
+    extern __shared__ float4 s_lights[];
+#endif
     lm_pick_primary_body<LmFast, LM_COMMON, true>(sc, fr, cur, rc, seed, visCount, s_bag, s_tmp, s_lights);
 }
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
@@ -1544,11 +1556,12 @@ static void l_fill_bags(hipStream_t s, LmScene sc, LmFrame fr, uint32_t seed, ui
 static void l_pick_primary(hipStream_t s, int tiles, LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount, int fast)
 {
     const bool ldsLights = sc.numLights <= LM_PICK_LDS_LIGHTS && LM_PICK_LDS_LIGHTS > 0u;
+    const size_t lightBytes = LM_PICK_STATIC_LDS ? 0u : (size_t)64 * sc.numLights + 16u;         // dynamic LDS of the *_lds kernels
     if (fast) {
-        if (ldsLights) hipLaunchKernelGGL(KN(lm_k_pick_primary_fast_lds), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount);
+        if (ldsLights) hipLaunchKernelGGL(KN(lm_k_pick_primary_fast_lds), dim3((unsigned)tiles), dim3(LM_BLOCK), lightBytes, s, sc, fr, cur, rc, seed, visCount);
         else hipLaunchKernelGGL(KN(lm_k_pick_primary_fast), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount);
         if (fast > 1) hipLaunchKernelGGL(KN(lm_k_pick_primary_rare), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount);
-    } else if (ldsLights) hipLaunchKernelGGL(KN(lm_k_pick_primary_lds), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount);
+    } else if (ldsLights) hipLaunchKernelGGL(KN(lm_k_pick_primary_lds), dim3((unsigned)tiles), dim3(LM_BLOCK), lightBytes, s, sc, fr, cur, rc, seed, visCount);
     else hipLaunchKernelGGL(KN(lm_k_pick_primary), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount);
 }
 static void l_trace_shade(hipStream_t s, int g, LmScene sc, LmFrame fr, int rc, const uint32_t* cnt, int refillBelow, int pass)
