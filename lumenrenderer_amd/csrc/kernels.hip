@@ -584,8 +584,10 @@ KN(lm_k_fill_bags)(LmScene sc, LmFrame fr, uint32_t seed, uint32_t total)
 // candidates of a pixel then read their light with four ds_read_b128 instead of four global gathers (the texture path is what this
 // kernel and the traversal kernels beside it compete for), and the arms are subtracted once per tile instead of once per candidate.
 #ifndef LM_PICK_LDS_LIGHTS
-#define LM_PICK_LDS_LIGHTS 256u
-#endif
+#define LM_PICK_LDS_LIGHTS 384u    // table size = the largest light list that takes the LDS path, AND the kernel's residency cap: 8 KB bag + 24 KB table = five blocks per CU.
+#endif                             // The pick saturates the vector ALUs; at six blocks (256 records) it holds more of every CU against the other streams' kernels than it can use:
+                                   // 256 / 384 / 512 / 768 records = 6 / 5 / 4 / 3 blocks per CU -> 2584 / 2615 / 2469 / 2328 Mrays/s (six runs each, builds interleaved on one box,
+                                   // profiles/r03_pick_residency_ab.txt)
 #ifndef LM_PICK_STATIC_LDS
 #define LM_PICK_STATIC_LDS 1       // 1: the table is a static 16-KB array whatever the light count; 0: sized by the launch (128 B for the benchmark scene's two lights).
 #endif                             // The smaller footprint lets more blocks of this VALU-saturating kernel onto a CU and the frame loses 0.7 % (2551 -> 2533, six runs each,
