@@ -1525,8 +1525,19 @@ extern "C" __global__ void KN(lm_k_spin)(uint32_t ticks)
 }
 
 #define LM_GRID(g) dim3((unsigned)(g)), dim3(LM_BLOCK), 0, s
+// Residency caps: a launch may carry unused dynamic LDS so that fewer blocks of a kernel fit a CU (160 KB of LDS per CU: 40 960 B = four blocks, 54 272 B = three).
+// A kernel that saturates one unit (vector ALUs, the L1's miss queue, HBM) with fewer waves than its registers allow only takes room from the other streams' kernels
+// by holding more.  Defaults below are measured (profiles/r03_residency_caps_ab.txt); LUMEN_MI_CAP_<NAME>=bytes overrides one for experiments.
+#if !LM_INSTRUMENT
+#include <cstdlib>
+static unsigned lm_cap(const char* name, unsigned dflt) { const char* e = getenv(name); return e ? (unsigned)atoi(e) : dflt; }
+#define LM_CAP(NAME, DFLT) ([]() { static const unsigned v = lm_cap("LUMEN_MI_CAP_" NAME, DFLT); return v; }())
+#else
+#define LM_CAP(NAME, DFLT) 0u
+#endif
+#define LM_GRID_CAP(g, NAME, DFLT) dim3((unsigned)(g)), dim3(LM_BLOCK), LM_CAP(NAME, DFLT), s
 
-static void l_primary(hipStream_t s, int g, LmFrame fr, LmCamera cam, uint32_t frameCount) { hipLaunchKernelGGL(KN(lm_k_primary), LM_GRID(g), fr, cam, frameCount); }
+static void l_primary(hipStream_t s, int g, LmFrame fr, LmCamera cam, uint32_t frameCount) { hipLaunchKernelGGL(KN(lm_k_primary), LM_GRID_CAP(g, "PRIMARY", 0u), fr, cam, frameCount); }
 static void l_trace_closest(hipStream_t s, int g, LmScene sc, const float4* o, const float4* d, const uint32_t* cnt, uint4* hits, float tmin, float tmax, uint32_t* counters, int refillBelow, const float* eye)
 {
     const float4 e = eye ? make_float4(eye[0], eye[1], eye[2], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1538,7 +1549,7 @@ static void l_trace_closest(hipStream_t s, int g, LmScene sc, const float4* o, c
     hipLaunchKernelGGL(KN(lm_k_trace_closest), LM_GRID(g), sc, o, d, cnt, hits, tmin, tmax, counters, refillBelow < 0 ? 0 : refillBelow, e);
 }
 static void l_extract0(hipStream_t s, int g, LmScene sc, LmFrame fr, LmCamera cam, int cur, uint32_t seed2, int doIndirect, int outQ, uint32_t* outCount)
-{ hipLaunchKernelGGL(KN(lm_k_extract0), LM_GRID(g), sc, fr, cam, cur, seed2, doIndirect, outQ, outCount); }
+{ hipLaunchKernelGGL(KN(lm_k_extract0), LM_GRID_CAP(g, "EXTRACT", 0u), sc, fr, cam, cur, seed2, doIndirect, outQ, outCount); }
 static void l_shade_wave(hipStream_t s, int g, LmScene sc, LmFrame fr, int inQ, const uint32_t* inCount, uint32_t seed, uint32_t seed2, int doIndirect, uint32_t* outCount, uint32_t* shadowCount)
 {
     // bit 1 of doIndirect / of inQ (path tail): tuning key fast_shade, the NEE contribution in the fast arithmetic policy
@@ -1574,7 +1585,7 @@ static void l_trace_shade(hipStream_t s, int g, LmScene sc, LmFrame fr, int rc, 
     hipLaunchKernelGGL(KN(lm_k_restir_trace_shade), LM_GRID(g), sc, fr, rc, cnt, refillBelow < 0 ? 0 : refillBelow, pass);
 }
 static void l_temporal(hipStream_t s, int g, LmFrame fr, int cur, int prev, int rc, int rp, int rf, uint32_t seed, uint32_t* visCount, int fast)
-{ if (fast) { hipLaunchKernelGGL(KN(lm_k_restir_temporal_fast), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); if (fast > 1) hipLaunchKernelGGL(KN(lm_k_restir_temporal_rare), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); } else hipLaunchKernelGGL(KN(lm_k_restir_temporal), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); }
+{ if (fast) { hipLaunchKernelGGL(KN(lm_k_restir_temporal_fast), LM_GRID_CAP(g, "TEMPORAL", 0u), fr, cur, prev, rc, rp, rf, seed, visCount); if (fast > 1) hipLaunchKernelGGL(KN(lm_k_restir_temporal_rare), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); } else hipLaunchKernelGGL(KN(lm_k_restir_temporal), LM_GRID(g), fr, cur, prev, rc, rp, rf, seed, visCount); }
 static void l_spatial(hipStream_t s, int g, LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin, int pass, int fast)
 {
     // fast | 16: the first pass stages its probe window in LDS (32 x 32 pixel tiles, 1024-thread blocks; tuning key spatial_lds)
@@ -1585,12 +1596,12 @@ static void l_spatial(hipStream_t s, int g, LmFrame fr, int cur, int rin, int ro
         return;
     }
     fast &= 15;
-    if (fast) { hipLaunchKernelGGL(KN(lm_k_restir_spatial_fast), LM_GRID(g), fr, cur, rin, rout, seed, margin, pass); if (fast > 1) hipLaunchKernelGGL(KN(lm_k_restir_spatial_rare), LM_GRID(g), fr, cur, rin, rout, seed, margin, pass); } else hipLaunchKernelGGL(KN(lm_k_restir_spatial), LM_GRID(g), fr, cur, rin, rout, seed, margin, pass);
+    if (fast) { hipLaunchKernelGGL(KN(lm_k_restir_spatial_fast), LM_GRID_CAP(g, "SPATIAL", 0u), fr, cur, rin, rout, seed, margin, pass); if (fast > 1) hipLaunchKernelGGL(KN(lm_k_restir_spatial_rare), LM_GRID(g), fr, cur, rin, rout, seed, margin, pass); } else hipLaunchKernelGGL(KN(lm_k_restir_spatial), LM_GRID(g), fr, cur, rin, rout, seed, margin, pass);
 }
 static void l_combine(hipStream_t s, int g, LmFrame fr, int cur, int rc, int rs, uint32_t seed, int fast)
-{ if (fast) { hipLaunchKernelGGL(KN(lm_k_restir_combine_fast), LM_GRID(g), fr, cur, rc, rs, seed); if (fast > 1) hipLaunchKernelGGL(KN(lm_k_restir_combine_rare), LM_GRID(g), fr, cur, rc, rs, seed); } else hipLaunchKernelGGL(KN(lm_k_restir_combine), LM_GRID(g), fr, cur, rc, rs, seed); }
+{ if (fast) { hipLaunchKernelGGL(KN(lm_k_restir_combine_fast), LM_GRID_CAP(g, "COMBINE", 0u), fr, cur, rc, rs, seed); if (fast > 1) hipLaunchKernelGGL(KN(lm_k_restir_combine_rare), LM_GRID(g), fr, cur, rc, rs, seed); } else hipLaunchKernelGGL(KN(lm_k_restir_combine), LM_GRID(g), fr, cur, rc, rs, seed); }
 static void l_clear(hipStream_t s, int g, float4* p, uint32_t n) { hipLaunchKernelGGL(KN(lm_k_clear_f4), LM_GRID(g), p, n); }
-static void l_merge(hipStream_t s, int g, LmFrame fr, int blend, uint32_t blendCount, int depthMax) { hipLaunchKernelGGL(KN(lm_k_merge_output), LM_GRID(g), fr, blend, blendCount, depthMax); }
+static void l_merge(hipStream_t s, int g, LmFrame fr, int blend, uint32_t blendCount, int depthMax) { hipLaunchKernelGGL(KN(lm_k_merge_output), LM_GRID_CAP(g, "MERGE", 0u), fr, blend, blendCount, depthMax); }
 static void l_query_any(hipStream_t s, int g, LmScene sc, const float4* o, const float4* d, uint32_t n, float tmin, uint32_t* occ, uint32_t* counters) { hipLaunchKernelGGL(KN(lm_k_query_any), LM_GRID(g), sc, o, d, n, tmin, occ, counters); }
 static void l_query_closest(hipStream_t s, int g, LmScene sc, const float4* o, const float4* d, uint32_t n, float tmin, float tmax, uint4* id, float4* uvt, uint32_t* counters)
 { hipLaunchKernelGGL(KN(lm_k_query_closest_raw), LM_GRID(g), sc, o, d, n, tmin, tmax, id, uvt, counters); }
