@@ -1034,7 +1034,9 @@ def test_emissiveness_and_override_material_changes_between_frames():
              lambda: (mi.SetEmissiveness(2, (1.0, 4.0, 1.0), 2.0), o.set_instance_emissiveness(inst, 2, (1.0, 4.0, 1.0), 2.0)),
              lambda: (mi.SetOverrideMaterial(r.m_Materials[red]), o.set_instance_override_material(inst, red)),
              lambda: (mi.SetEmissiveness(1, (0.0, 0.0, 0.0), 1.0), o.set_instance_emissiveness(inst, 1, (0.0, 0.0, 0.0), 1.0)),   # DISABLED
-             lambda: (mi.SetTransform(_rigid(0.9, (0.2, 1.1, -0.2))), o.set_instance_transform(inst, _rigid(0.9, (0.2, 1.1, -0.2))))]
+             lambda: (mi.SetTransform(_rigid(0.9, (0.2, 1.1, -0.2))), o.set_instance_transform(inst, _rigid(0.9, (0.2, 1.1, -0.2)))),
+             # a null override falls back to the mesh's own materials (PTMeshInstance.cpp:163-165): handle 0 clears it
+             lambda: (mi.SetOverrideMaterial(0), o.set_instance_override_material(inst, -1))]
     lights = []
     for k, step in enumerate(steps):
         step()
@@ -1049,6 +1051,28 @@ def test_emissiveness_and_override_material_changes_between_frames():
     assert lights[1] > lights[0] and lights[4] == lights[0]            # the override adds lights, DISABLED removes them again
     assert r.GetBvhInfo()["triangles"] == d.triangle_count()
     r.close(); o.close()
+
+
+def test_counter_totals_sum_every_traceframe_on_the_device():
+    """lumen_mi_get_counter_totals: the frame's last kernel adds its counter block to a 64-bit block on the device, so that a throughput
+    measurement counts the rays of ALL the frames it timed without reading counters back in between (bench.py).  The sums must equal the
+    per-frame counters added up on the host, for frames enqueued back to back, and a reset must start over."""
+    d = cornell()
+    r = product_from(d, 96, 80, 5, blend=True)
+    want = [0] * 12
+    for k in range(6):
+        assert r.TraceFrame()
+        c = r.GetCounters(12)
+        for i in (0, 1, 2, 4, 5, 6, 7, 8): want[i] += c[i]
+    t = r.GetCounterTotals(50)
+    assert t[3] == 6 and [t[i] for i in (0, 1, 2, 4, 5, 6, 7, 8)] == [want[i] for i in (0, 1, 2, 4, 5, 6, 7, 8)], (t[:12], want)
+    assert t[2] == t[48] + t[49]
+    r.GetCounterTotals(4, reset=True)
+    for _ in range(3):
+        assert r.TraceFrameAsync()                      # no synchronisation between frames
+    t2 = r.GetCounterTotals(50)
+    assert t2[3] == 3 and 0 < t2[0] < t[0] and t2[4] == 3 * 96 * 80
+    r.close()
 
 
 def test_render_thread_with_concurrent_scene_edits():
