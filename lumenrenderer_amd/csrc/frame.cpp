@@ -30,7 +30,7 @@ int ensureFrameBuffers(R* r)
     for (int i = 0; i < 4; i++) bad |= r->dSh2[i].ensure(n);
     for (int i = 0; i < 3; i++) bad |= r->dGbuf[i].ensure((size_t)8 * n) | r->dProbe[i].ensure(n);
     for (int i = 0; i < 2; i++) bad |= r->dMotion[i].ensure(n);
-    bad |= r->dReuseMask.ensure(n);
+    bad |= r->dReuseMask.ensure(n) | r->dHazard[0].ensure(n) | r->dHazard[1].ensure(n);
     for (int i = 0; i < 5; i++) bad |= r->dRes[i].ensure((size_t)4 * n) | r->dResC[i].ensure(n);
     for (int i = 0; i < 2; i++) bad |= r->dDirect[i].ensure(n) | r->dIndirect[i].ensure(n);
     bad |= r->dCombined.ensure(n) | r->dHits[0].ensure(n) | r->dHits[1].ensure(n) | r->dOutput.ensure(n);
@@ -55,8 +55,10 @@ int ensureFrameBuffers(R* r)
     if (hipMemsetAsync(f.output, 0, (size_t)n * sizeof(uchar4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
     r->fenceNeeded = 2;
     r->haveEst = false; r->cntPending[0] = r->cntPending[1] = false;
-    if (r->dSwap.ensure(4) || hipMemsetAsync(r->dSwap.p, 0, 4 * sizeof(int), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "swap index allocation failed");
+    if (r->dSwap.ensure(16) || hipMemsetAsync(r->dSwap.p, 0, 16 * sizeof(int), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "swap index allocation failed");
     f.swap = r->dSwap.p;
+    f.deferred = 0; f.owedSet = -1; f.hazardList = nullptr;
+    r->owed.valid = false;                                // the reservoirs were reset: nothing is owed
     r->blendCounter = 0; r->frameIndex = 0; r->gbufIndex = 0; r->lastGbuf = 0;
     r->allocN = n;
     return 0;
@@ -125,6 +127,19 @@ void motionMatrix(const float* prevCamWorld, float fovY, float aspect, float* M)
     proj[10] = -(zf + zn) / (zf - zn); proj[11] = -(2.0f * zf * zn) / (zf - zn); proj[14] = -1.0f;
     invert4(prevCamWorld, invPrev);
     for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { float s = 0.f; for (int k = 0; k < 4; k++) s += proj[i * 4 + k] * invPrev[k * 4 + j]; M[i * 4 + j] = s; }
+}
+
+// The history-building passes of the last frame (ReSTIR.cpp:181-233: both spatial passes, CombineReservoirBuffers), with that frame's parameters; the
+// kernels return at once unless the swap chain has turned since (kernels.hip lm_reuse_owed).  mode 1: inside the next frame, 2: between frames.
+void launchOwedReuse(R* r, hipStream_t s, int mode)
+{
+    const R::OwedReuse& o = r->owed;
+    LmFrame fo = o.fr;
+    fo.swap = r->fr.swap; fo.deferred = mode;
+    const LmKernelTable* K = r->K;
+    K->spatial(s, o.tiles, fo, o.gbuf, LM_RES_OWED, 2, o.seed, 30, 0, o.fast);
+    K->spatial(s, o.tiles, fo, o.gbuf, 2, 3, o.seed, 0, 1, o.fast);
+    K->combine(s, o.tiles, fo, o.gbuf, LM_RES_OWED, 3, wangHash(o.seed), o.fast);
 }
 
 int traceFrameAsync(R* r)
@@ -202,6 +217,8 @@ int traceFrameAsync(R* r)
         fr.shO = r->dSh[3 * b].p; fr.shD = r->dSh[3 * b + 1].p; fr.shR = r->dSh[3 * b + 2].p;
         fr.hits = r->dHits[b].p;
     }
+    fr.deferred = 0;
+    fr.owedSet = r->owed.valid ? r->owed.gbuf : -1; fr.hazardList = r->dHazard[par].p;      // lazy reuse: the extraction lists the entries that outlive this frame's pick
     fr.motion = r->dMotion[par].p;
     fr.direct = r->dDirect[par].p; fr.indirect = r->dIndirect[par].p; fr.counters = r->dCounters.p + (size_t)par * LM_CNT_WORDS;
     if (overlap) {
@@ -241,7 +258,7 @@ int traceFrameAsync(R* r)
     if (tailBelow && r->haveEst) for (uint32_t dd = 1; dd < depthMax; dd++) if (r->estRays[dd] < tailBelow) { tailDepth = (int)dd; break; }
     int q = 0;
     size_t ev;
-    bool tailLaunched = false;
+    bool tailLaunched = false, lazy = false;
     // the queue the path tail reads is its own (double-buffered by frame parity), so that the tail can run on the shadow
     // stream while the wave stream already enqueues the next frame's front into the regular ray queues
     auto withTailQueue = [&](LmFrame f, int queue) {
@@ -258,6 +275,7 @@ int traceFrameAsync(R* r)
             Z(sx); K->trace_closest(sx, gridMain, scx, nullptr, fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters, usePackets ? -1 : r->refillPrimary, cam.eye);    // :678,:703; primary rays start at the eye
             evEnd2(r, ev, sx);
             if (overlap) LM_HIP(hipStreamWaitEvent(sx, r->evTemporal[par], 0));          // the temporal pass two frames back has read what extraction overwrites
+            if (twoWave && r->owed.valid) LM_HIP(hipStreamWaitEvent(sx, r->evFront, 0));     // (that list compares with the previous frame's probe plane, written on the other wave stream)
             evBegin2(r, 2, ev, sx);
             Z(sx); K->extract0(sx, r->gridFor(fr.n, 8), r->dscene, (int)depth + 1 == tailDepth ? withTailQueue(fr, q ^ 1) : fr, cam, currentIndex, seed2, doIndirect, q ^ 1, outCount);   // + depth-0 continuation
             evEnd2(r, ev, sx);
@@ -274,6 +292,17 @@ int traceFrameAsync(R* r)
             // the fresh-candidate buffer is single: the PREVIOUS frame's temporal pass must have consumed it before this frame's
             // candidates overwrite it (the front no longer waits for that pass since the G-buffer rotates through three sets)
             if (pickAhead) LM_HIP(hipStreamWaitEvent(sp, r->evTemporal[par ^ 1], 0));
+            // Lazy reuse: what the previous frame left pending comes first — before this frame's candidates overwrite the buffer it completes.  The device
+            // decides (kernels.hip lm_reuse_owed): if the swap chain has turned, that frame's history passes run now; if not, they are dropped and only the
+            // entries that outlive this frame's pick (pixels flagged in THIS frame: the extraction above has said which) get the count the combine would
+            // have left.  At an even path depth the reference computes a history that its own swap quirk never reads.
+            if (r->owed.valid) {
+                if (overlap && sp != st) LM_HIP(hipStreamWaitEvent(st, r->evFront, 0));
+                Z(st); launchOwedReuse(r, st, 1);
+                if (r->lazyReuse != 2)     // (2: without — wrong on purpose, for the test that shows the completion is observable)
+                { LmFrame fo = r->owed.fr; fo.swap = fr.swap; Z(st); K->reuse_counts(st, fo, r->owed.gbuf, fr.hazardList, fr.counters + LM_CNT_HAZARD, r->owed.seed); }
+                r->owed.valid = false;
+            }
             evBegin2(r, 3, ev, sp);
             const int cur = LM_RES_CUR, tmp = LM_RES_PREV, fresh = pickAhead ? 4 : LM_RES_CUR;
             uint32_t rs = wangHash(seed);
@@ -289,10 +318,12 @@ int traceFrameAsync(R* r)
             if (pickAhead) { LM_HIP(hipEventRecord(r->evPick, sp)); LM_HIP(hipStreamWaitEvent(st, r->evPick, 0)); }
             evBegin(r, 3, ev);
             rs = wangHash(rs);
+            // lazy reuse (tuning key lazy_reuse; -1: at even path depths): this frame's history passes are left to the next frame (above)
+            lazy = r->lazyReuse > 0 || (r->lazyReuse < 0 && (depthMax & 1u) == 0u);
             Z(st); K->temporal(st, tiles, fr, currentIndex, temporalIndex, cur, tmp, fresh, rs, fr.counters + LM_CNT_RESTIR(1), fastRs);         // + visibility rays, pass 2
             if (overlap) LM_HIP(hipEventRecord(r->evTemporal[par], st));
             rs = wangHash(rs);
-            Z(st); K->spatial(st, tiles, fr, currentIndex, cur, 2, rs, 30, 0, fastRs | ((fastRs && r->spatialLds) ? 16 : 0));
+            if (!lazy) { Z(st); K->spatial(st, tiles, fr, currentIndex, cur, 2, rs, 30, 0, fastRs | ((fastRs && r->spatialLds) ? 16 : 0)); }
             // second visibility pass (ReSTIR.cpp:211-212) works on the CURRENT buffer, which the second spatial pass does not
             // touch: trace it beside that pass.  (It must follow the first spatial pass, which reads the current buffer.)
             hipStream_t sv = (overlap && !pickAhead) ? r->aux3 : st;
@@ -301,11 +332,12 @@ int traceFrameAsync(R* r)
                 scv.spill += (size_t)3 * r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS);
                 LM_HIP(hipEventRecord(r->evVis, st)); LM_HIP(hipStreamWaitEvent(sv, r->evVis, 0));
             }
-            Z(sv); K->trace_shade(sv, gridMain, scv, fr, cur, fr.counters + LM_CNT_RESTIR(1), visPackets ? -1 : r->refillVisibility, 1);
+            Z(sv); K->trace_shade(sv, gridMain, scv, fr, cur, fr.counters + LM_CNT_RESTIR(1), visPackets ? -1 : r->refillVisibility, lazy ? 2 : 1);   // 2: parks the weights it zeroes for the deferred first spatial pass
             if (sv != st) LM_HIP(hipEventRecord(r->evVisDone, sv));
-            Z(st); K->spatial(st, tiles, fr, currentIndex, 2, 3, rs, 0, 1, fastRs);      // the same seed as the first pass (ReSTIR.cpp: one seed for both): same candidates, same verdicts
+            if (!lazy) { Z(st); K->spatial(st, tiles, fr, currentIndex, 2, 3, rs, 0, 1, fastRs); }      // the same seed as the first pass (ReSTIR.cpp: one seed for both): same candidates, same verdicts
             if (sv != st) LM_HIP(hipStreamWaitEvent(st, r->evVisDone, 0));
-            Z(st); K->combine(st, tiles, fr, currentIndex, cur, 3, wangHash(rs), fastRs);
+            if (!lazy) { Z(st); K->combine(st, tiles, fr, currentIndex, cur, 3, wangHash(rs), fastRs); }
+            else { r->owed.valid = true; r->owed.fr = fr; r->owed.gbuf = currentIndex; r->owed.seed = rs; r->owed.fast = fastRs; r->owed.tiles = tiles; }
             evEnd(r, ev);
         } else if ((int)depth >= tailDepth) {
             // path tail: the remaining waves in one launch (kernels.hip lm_k_path_tail) on the shadow stream: its INDIRECT adds
@@ -367,7 +399,7 @@ int traceFrameAsync(R* r)
         if (depthMax > 1) LM_HIP(hipStreamWaitEvent(st, r->evJoin2, 0));
         if (tailLaunched) LM_HIP(hipStreamWaitEvent(st, r->evTail, 0));
     }
-    Z(st); K->merge(st, r->gridFor(fr.n, 8), fr, blend ? 1 : 0, r->blendCounter, (int)depthMax);     // + ReSTIR::SwapBuffers per executed wave
+    Z(st); K->merge(st, r->gridFor(fr.n, 8), fr, (blend ? 1 : 0) | (lazy ? 2 : 0), r->blendCounter, (int)depthMax);     // + ReSTIR::SwapBuffers per executed wave
     if (r->pinnedCounters[par]) {     // asynchronous counter read-back: feeds the next frames' schedule (above); before evMerge, which
         // releases this counter block to the frame after next
         LM_HIP(hipMemcpyAsync(r->pinnedCounters[par], fr.counters, LM_CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));

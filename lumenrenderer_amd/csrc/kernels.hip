@@ -233,6 +233,13 @@ KN(lm_k_extract0)(LmScene sc, LmFrame fr, LmCamera cam, int cur, uint32_t seed2,
         // wavefront that sees such a surface (an atomic per wavefront on one address is ~ 88 per microsecond: 0.65 ms at 1440p in a scene of
         // glass or clear coat, on the critical wave chain, in every mode)
         if (__ballot(!s.flags && !lm_quick_contracts(s.mat)) != 0ull && lm_lane() == 0u) fr.counters[LM_CNT_RARE] = 1u;
+        // lazy reuse: the previous frame left its history passes pending.  Pixels that were reuse surfaces then and are flagged now keep their reservoir entry
+        // past this frame's candidate pick: listed for lm_k_reuse_counts (silhouette pixels under sub-pixel jitter; more when the camera moves)
+        if (fr.owedSet >= 0) {
+            const bool keeps = s.flags != 0u && fr.probe[fr.owedSet][li].w >= 0.f;
+            const uint32_t slot = lm_append_slot(fr.counters + LM_CNT_HAZARD, keeps);
+            if (keeps) fr.hazardList[slot] = li;
+        }
         // motion vector
         const uint32_t ly = li / fr.ww, lx = li - ly * fr.ww;
         const uint32_t px = fr.x0 + lx, py = fr.y0 + ly;
@@ -503,8 +510,26 @@ KN(lm_k_trace_shadow)(LmScene sc, LmFrame fr, const uint32_t* __restrict__ count
 __device__ __forceinline__ int lm_res_idx(const LmFrame& fr, int code)
 {
     if (code >= 0) return code;
+    if (code == LM_RES_OWED) return fr.swap[4] & 1;
     const int cur = *fr.swap & 1;
     return code == LM_RES_CUR ? cur : cur ^ 1;
+}
+// Deferred history passes (frame.cpp, "lazy reuse").  Both spatial passes and the combine of a frame only build what a LATER temporal pass reads as
+// "previous"; nothing of the frame itself depends on them.  They are launched at the start of the NEXT frame's ReSTIR chain (fr.deferred != 0) and run
+// only if the swap chain has turned since (swap[0] != swap[4], grid-uniform): the buffer they complete is then the history — every frame of an odd path
+// depth.  Otherwise (even path depth: the reference's swap quirk) this frame's candidate pick overwrites that buffer before anything reads it —
+// except at pixels which are flagged (emitter / miss) now: there the pick only zeroes the weight (ReSTIRKernels.cu:441-447) and the rest of the entry can
+// be read frames later through a probe plane of another age.  lm_k_reuse_counts completes exactly those entries.  swap[5] = 1: run already (history
+// export between frames) or settled.
+__device__ __forceinline__ bool lm_reuse_turned(const LmFrame& fr) { return (fr.swap[4] & 1) != (*fr.swap & 1); }
+__device__ __forceinline__ bool lm_reuse_owed(const LmFrame& fr) { return fr.swap[5] == 0 && lm_reuse_turned(fr); }
+// does a ReSTIR pass of the fast mode's second (exact) launch have anything to do?  (The deferred passes belong to the previous frame: its flag was
+// parked in swap[7] by that frame's merge, its counter block may already belong to the frame after this one.)
+__device__ __forceinline__ bool lm_no_rare(const LmFrame& fr) { return (fr.deferred ? (uint32_t)fr.swap[7] : fr.counters[LM_CNT_RARE]) == 0u; }
+// settle kernel of the between-frames flush (history export / import): the passes above ran iff the chain had turned
+extern "C" __global__ void KN(lm_k_reuse_settle)(LmFrame fr)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0 && fr.swap[5] == 0 && (fr.swap[4] & 1) != (*fr.swap & 1)) fr.swap[5] = 1;
 }
 
 // K6 + K23: resolve the visibility rays (tmin 0.1, WaveFrontShaders.cu:181-216: occluded => reservoir weight = 0) and shade
@@ -524,8 +549,12 @@ KN(lm_k_restir_trace_shade)(LmScene sc, LmFrame fr, int rc, const uint32_t* __re
         [&](uint32_t i, bool occluded, const LmHit&) {
             const uint32_t li = f2u(qD[i].w);
             float* weight = (float*)(hot + 4u * li + 1u);           // quad 1 = (weight, count, normal.xy): lm_restir.h (included below)
-            if (occluded) *weight = 0.f;
-            else {
+            if (occluded) {
+                // pass 2 with the frame's history passes pending (lazy reuse): the first spatial pass, which the reference runs BEFORE this one
+                // (ReSTIR.cpp:181-212), will read this weight later — park it in the two spare words of quad 0 (lm_spatial_weight)
+                if (pass == 2) { float* q0 = (float*)(hot + 4u * li); q0[2] = *weight; q0[3] = 1.f; }
+                *weight = 0.f;
+            } else {
                 const lf3 add = v3(fr.resC[rc][li]) * (*weight / 3.f);
                 float4 px = fr.direct[li];
                 px.x += add.x; px.y += add.y; px.z += add.z;
@@ -552,8 +581,10 @@ KN(lm_k_restir_trace_shade_packet)(LmScene sc, LmFrame fr, int rc, const uint32_
         [&](uint32_t i, bool occluded, const LmHit&) {
             const uint32_t li = f2u(qD[i].w);
             float* weight = (float*)(hot + 4u * li + 1u);
-            if (occluded) *weight = 0.f;
-            else {
+            if (occluded) {
+                if (pass == 2) { float* q0 = (float*)(hot + 4u * li); q0[2] = *weight; q0[3] = 1.f; }     // see lm_k_restir_trace_shade
+                *weight = 0.f;
+            } else {
                 const lf3 add = v3(fr.resC[rc][li]) * (*weight / 3.f);
                 float4 px = fr.direct[li];
                 px.x += add.x; px.y += add.y; px.z += add.z;
@@ -751,6 +782,8 @@ template <class A, int ROLE>
 __device__ __forceinline__ void lm_restir_temporal_body(const LmFrame& fr, int cur, int prev, int rc, int rp, int rf, uint32_t seed, uint32_t* visCount, uint32_t* s_tmp)
 {
     if (ROLE == LM_RARE && fr.counters[LM_CNT_RARE] == 0u) return;
+    // the previous frame's pending history passes were launched before this kernel and have run or returned: nothing is owed any more (lm_reuse_owed)
+    if (ROLE != LM_RARE && blockIdx.x == 0 && threadIdx.x == 0) fr.swap[5] = 1;
     rc = lm_res_idx(fr, rc);
     rp = lm_res_idx(fr, rp);
     rf = lm_res_idx(fr, rf);
@@ -885,9 +918,10 @@ KN(lm_k_restir_temporal_rare)(LmFrame fr, int cur, int prev, int rc, int rp, int
 // instead of gathering five 16-byte probes through the L1.  The probes are the same bits, so the verdicts and the image are unchanged.
 #define LM_SPATIAL_WIN 92u
 template <class A, int ROLE, uint32_t LOG_TS = 4, bool LDS_PROBES = false>
-__device__ __forceinline__ void lm_restir_spatial_body(const LmFrame& fr, int cur, int rin, int rout, uint32_t seed, int margin, int pass, float4* s_probe = nullptr)
+__device__ __forceinline__ void lm_restir_spatial_body(const LmFrame& fr, int cur, int rin, int rout, uint32_t seed, int margin, int pass, float4* s_probe = nullptr, uint32_t vb = blockIdx.x)
 {
-    if (ROLE == LM_RARE && fr.counters[LM_CNT_RARE] == 0u) return;
+    if (fr.deferred && !lm_reuse_owed(fr)) return;
+    if (ROLE == LM_RARE && lm_no_rare(fr)) return;
     rin = lm_res_idx(fr, rin);
     rout = lm_res_idx(fr, rout);
 #ifdef LM_SPATIAL_PRIO
@@ -896,7 +930,7 @@ __device__ __forceinline__ void lm_restir_spatial_body(const LmFrame& fr, int cu
     int wx0 = 0, wy0 = 0;                                           // window origin of the staged probes (window-local pixels, may be negative)
     if constexpr (LDS_PROBES) {
         uint32_t tx, ty;
-        lm_tile_origin<LOG_TS>(fr, tx, ty);
+        lm_tile_origin<LOG_TS>(fr, tx, ty, vb);
         wx0 = (int)(tx << LOG_TS) - 30; wy0 = (int)(ty << LOG_TS) - 30;
         const float4* probe = fr.probe[cur];
         for (uint32_t k = threadIdx.x; k < LM_SPATIAL_WIN * LM_SPATIAL_WIN; k += blockDim.x) {
@@ -906,7 +940,7 @@ __device__ __forceinline__ void lm_restir_spatial_body(const LmFrame& fr, int cu
         __syncthreads();
     }
     uint32_t li = 0, gi = 0;
-    if (!lm_tile_pixel<LOG_TS>(fr, li, gi)) return;
+    if (!lm_tile_pixel<LOG_TS>(fr, li, gi, vb)) return;
     if (!lm_owned(fr, li, margin)) return;                       // pass 1 feeds pass 2 within 30 pixels of the owned tile, pass 2 only the tile
     const float4* hotIn = fr.res[rin];
     // The second pass draws the candidates of the first (same seed) against the same probe plane: the first pass leaves its verdicts
@@ -958,6 +992,9 @@ __device__ __forceinline__ void lm_restir_spatial_body(const LmFrame& fr, int cu
         mask &= mask - 1u;
         const float4* h = hotIn + 4u * nb0;
         float4 p1 = h[1], p2 = h[2], p3 = h[3];                    // the three quads a neighbour's reservoir is gathered by (lm_restir.h)
+        // deferred first pass: the frame's second visibility pass has run meanwhile and zeroed occluded weights — after parking them (lm_k_restir_trace_shade)
+        const bool parked = fr.deferred != 0 && pass == 0;
+        if (parked) { const float2 z = *(const float2*)((const float*)h + 2); if (z.y == 1.f) p1.x = z.x; }
         LmTarget target;
         {
             LmSurface s0;
@@ -981,6 +1018,7 @@ __device__ __forceinline__ void lm_restir_spatial_body(const LmFrame& fr, int cu
             const float4* hn = hotIn + 4u * candAt((uint32_t)__ffs((int)mask) - 1u);
             mask &= mask - 1u;
             p1 = hn[1]; p2 = hn[2]; p3 = hn[3];
+            if (parked) { const float2 z = *(const float2*)((const float*)hn + 2); if (z.y == 1.f) p1.x = z.x; }
         }
         out.count = sum;
         lm_res_update_weight<A>(out);
@@ -1010,13 +1048,15 @@ KN(lm_k_restir_spatial_rare)(LmFrame fr, int cur, int rin, int rout, uint32_t se
 
 // K26 CombineReservoirBuffers — ReSTIRKernels.cu:1407-1436
 template <class A, int ROLE>
-__device__ __forceinline__ void lm_restir_combine_body(const LmFrame& fr, int cur, int rc, int rs, uint32_t seed)
+__device__ __forceinline__ void lm_restir_combine_body(const LmFrame& fr, int cur, int rc, int rs, uint32_t seed, uint32_t vb = blockIdx.x)
 {
-    if (ROLE == LM_RARE && fr.counters[LM_CNT_RARE] == 0u) return;
+    if (fr.deferred && !lm_reuse_owed(fr)) return;
+    if (fr.deferred && ROLE != LM_RARE && vb == 0u && threadIdx.x == 0) ++fr.swap[8];             // statistic: deferred executions
+    if (ROLE == LM_RARE && lm_no_rare(fr)) return;
     rc = lm_res_idx(fr, rc);
     rs = lm_res_idx(fr, rs);
     uint32_t li = 0, gi = 0;
-    if (!lm_tile_pixel(fr, li, gi)) return;
+    if (!lm_tile_pixel(fr, li, gi, vb)) return;
     if (!lm_owned(fr, li, 0)) return;
     if (fr.probe[cur][li].w < 0.f) return;
     LmTarget target;
@@ -1043,6 +1083,81 @@ extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_FAST_WAVES)
 KN(lm_k_restir_combine_fast)(LmFrame fr, int cur, int rc, int rs, uint32_t seed) { lm_restir_combine_body<LmFast, LM_COMMON>(fr, cur, rc, rs, seed); }
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
 KN(lm_k_restir_combine_rare)(LmFrame fr, int cur, int rc, int rs, uint32_t seed) { lm_restir_combine_body<LmExact, LM_RARE>(fr, cur, rc, rs, seed); }
+// The same passes launched for the PREVIOUS frame (lazy reuse, lm_reuse_owed): a grid of at most 2048 blocks that loops over the tiles, so that the usual
+// case — nothing owed, every block returns at once — costs the stream a few microseconds instead of 14 400 block dispatches among the resident kernels.
+#define LM_DEFERRED(NAME, BOUNDS, BODY, PARAMS, ...) \
+    extern "C" __global__ void __launch_bounds__(LM_BLOCK, BOUNDS) KN(NAME) PARAMS \
+    { if (!lm_reuse_owed(fr)) return; for (uint32_t vb = blockIdx.x; vb < (uint32_t)tiles; vb += gridDim.x) BODY(__VA_ARGS__, vb); }
+#define LM_SP_PARAMS (LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin, int pass, int tiles)
+#define LM_CB_PARAMS (LmFrame fr, int cur, int rc, int rs, uint32_t seed, int tiles)
+LM_DEFERRED(lm_k_restir_spatial_deferred, LM_SPATIAL_WAVES, (lm_restir_spatial_body<LmExact, LM_ALL>), LM_SP_PARAMS, fr, cur, rin, rout, seed, margin, pass, nullptr)
+LM_DEFERRED(lm_k_restir_spatial_fast_deferred, LM_SPATIAL_FAST_WAVES, (lm_restir_spatial_body<LmFast, LM_COMMON>), LM_SP_PARAMS, fr, cur, rin, rout, seed, margin, pass, nullptr)
+LM_DEFERRED(lm_k_restir_spatial_rare_deferred, LM_SPATIAL_WAVES, (lm_restir_spatial_body<LmExact, LM_RARE>), LM_SP_PARAMS, fr, cur, rin, rout, seed, margin, pass, nullptr)
+LM_DEFERRED(lm_k_restir_combine_deferred, LM_RESTIR_WAVES, (lm_restir_combine_body<LmExact, LM_ALL>), LM_CB_PARAMS, fr, cur, rc, rs, seed)
+LM_DEFERRED(lm_k_restir_combine_fast_deferred, LM_FAST_WAVES, (lm_restir_combine_body<LmFast, LM_COMMON>), LM_CB_PARAMS, fr, cur, rc, rs, seed)
+LM_DEFERRED(lm_k_restir_combine_rare_deferred, LM_RESTIR_WAVES, (lm_restir_combine_body<LmExact, LM_RARE>), LM_CB_PARAMS, fr, cur, rc, rs, seed)
+
+// Lazy reuse, the other half (see lm_reuse_owed).  The swap chain has NOT turned: the pending history passes of the previous frame are dropped, because
+// this frame's candidate pick / temporal pass rewrites every entry of that buffer — except at pixels that were reuse surfaces then and are flagged now,
+// where only the weight is zeroed.  A weight-0 entry is observable through ONE field: a later temporal pass adds its sampleCount to the merged count and
+// caps it (ReSTIRKernels.cu:1062-1121; its sample is re-scored but enters every Update with weight count * 0 * pdf = 0, and its contribution is only
+// shaded when the weight is positive).  The count CombineReservoirBuffers would have left there is temporal count + count of the second spatial
+// pass = the sum, over that pass's accepted candidates, of the first pass's counts — sums of temporal counts over accepted candidates, zero where fewer
+// than two are accepted (Reset).  Acceptance needs the probe plane only, so the cone (5 + 25 probes, 25 counts) costs no evaluation; it runs for the few
+// silhouette pixels that sub-pixel jitter or motion turns into emitter / miss pixels.  `fo` = the previous frame's parameters, `now` = this frame's set.
+__device__ __forceinline__ uint32_t lm_reuse_verdicts(const LmFrame& fr, const float4* __restrict__ probe, uint32_t li, uint32_t seed, uint32_t (&cand)[5])
+{
+    const int y = (int)(li / fr.ww), x = (int)(li - (uint32_t)y * fr.ww);
+    const uint32_t gi = (fr.y0 + (uint32_t)y) * fr.W + (fr.x0 + (uint32_t)x);
+    uint32_t s = lm_wang_hash(seed + gi);
+    uint32_t mask = 0u;
+    const float4 cn = probe[li];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const int ny = (int)roundf((lm_random_float(s) * 2.f - 1.f) * 30.f) + y;
+        const int nx = (int)roundf((lm_random_float(s) * 2.f - 1.f) * 30.f) + x;
+        cand[k] = 0xffffffffu;
+        if (nx < 0 || nx >= (int)fr.ww || ny < 0 || ny >= (int)fr.wh) continue;
+        cand[k] = (uint32_t)ny * fr.ww + (uint32_t)nx;
+        const float4 pr = probe[cand[k]];
+        if (pr.w < 0.f) continue;
+        const float depthDif = fabsf(pr.w - cn.w) / ((pr.w + cn.w) / 2.f);
+        if (depthDif < 0.10f && dot3(v3(pr), v3(cn)) > 0.72222222223f) mask |= 1u << k;
+    }
+    return mask;
+}
+// two launches over the extraction's list (LmFrame::hazardList of THIS frame): phase 0 gathers the sums (the cone reads the counts of NEIGHBOURING entries,
+// which may be due for completion themselves) into the reuse-mask plane, which is free while the passes that use it are dropped; phase 1 adds them
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_reuse_counts)(LmFrame fo, int was, const uint32_t* __restrict__ list, const uint32_t* __restrict__ listCount, uint32_t seed, int phase)
+{
+    if (fo.swap[5] != 0 || lm_reuse_turned(fo)) return;
+    const float4* __restrict__ probe = fo.probe[was];
+    float4* hot = fo.res[lm_res_idx(fo, LM_RES_OWED)];
+    const uint32_t n = *listCount, stride = gridDim.x * LM_BLOCK;
+    for (uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x; i < n; i += stride) {
+        const uint32_t li = list[i];
+        if (!lm_owned(fo, li, 0)) continue;                       // the combine did not write it
+        if (phase) {
+            float* cnt = (float*)(hot + 4u * li + 1u) + 1;
+            *cnt = u2f(f2u(*cnt) + fo.reuseMask[li]);
+            continue;
+        }
+        uint32_t c2[5];
+        const uint32_t m2 = lm_reuse_verdicts(fo, probe, li, seed, c2);
+        uint32_t sum2 = 0u;
+        if (__popc(m2) > 1) {
+            for (int j = 0; j < 5; j++) {
+                if (!((m2 >> j) & 1u)) continue;
+                uint32_t c1[5];
+                const uint32_t m1 = lm_reuse_verdicts(fo, probe, c2[j], seed, c1);
+                if (__popc(m1) > 1) for (int k = 0; k < 5; k++) if ((m1 >> k) & 1u) sum2 += f2u(hot[4u * c1[k] + 1u].y);
+            }
+        }
+        fo.reuseMask[li] = sum2;
+    }
+    if (phase && blockIdx.x == 0 && threadIdx.x == 0) fo.swap[9] += (int)n;       // statistic: entries completed this way
+}
 
 #if LM_INSTRUMENT
 extern "C" __global__ void lm_k_read_pushes(unsigned long long* out) { out[0] = g_lmPushes[0]; out[1] = g_lmPushes[1]; g_lmPushes[0] = 0; g_lmPushes[1] = 0; }
@@ -1074,6 +1189,9 @@ KN(lm_k_merge_output)(LmFrame fr, int blend, uint32_t blendCount, int depthMax)
         int executed = 0;
         for (int d = 0; d < depthMax; d++) executed += fr.counters[LM_CNT_RAYS(d)] > 0u;
         fr.swap[2 + (*fr.swap & 1)] = 1;             // this frame's passes wrote the current swap-chain buffer
+        fr.swap[4] = *fr.swap & 1;                   // ... which is the one its history passes complete; blend bit 1: they are pending (lm_reuse_owed)
+        fr.swap[5] = (blend & 2) ? 0 : 1;
+        fr.swap[7] = (int)fr.counters[LM_CNT_RARE];
         *fr.swap = (*fr.swap + executed) & 1;
         fr.swap[1] = executed;
     }
@@ -1086,7 +1204,7 @@ KN(lm_k_merge_output)(LmFrame fr, int blend, uint32_t blendCount, int depthMax)
         m = m + fr.direct[li];
         m = m + fr.indirect[li];
         float4 c;
-        if (blend) {
+        if (blend & 1) {
             const float4 old = fr.combined[li];
             const float k = (float)blendCount, k1 = (float)(blendCount + 1u);
             const float4 s = old * k + m;
@@ -1596,10 +1714,23 @@ static void l_spatial(hipStream_t s, int g, LmFrame fr, int cur, int rin, int ro
         return;
     }
     fast &= 15;
+    if (fr.deferred) {        // the previous frame's pass (lazy reuse): looping grid, returns at once unless owed
+        const int gd = g < 2048 ? g : 2048;
+        if (fast) { hipLaunchKernelGGL(KN(lm_k_restir_spatial_fast_deferred), LM_GRID(gd), fr, cur, rin, rout, seed, margin, pass, g); if (fast > 1) hipLaunchKernelGGL(KN(lm_k_restir_spatial_rare_deferred), LM_GRID(gd), fr, cur, rin, rout, seed, margin, pass, g); }
+        else hipLaunchKernelGGL(KN(lm_k_restir_spatial_deferred), LM_GRID(gd), fr, cur, rin, rout, seed, margin, pass, g);
+        return;
+    }
     if (fast) { hipLaunchKernelGGL(KN(lm_k_restir_spatial_fast), LM_GRID_CAP(g, "SPATIAL", 0u), fr, cur, rin, rout, seed, margin, pass); if (fast > 1) hipLaunchKernelGGL(KN(lm_k_restir_spatial_rare), LM_GRID(g), fr, cur, rin, rout, seed, margin, pass); } else hipLaunchKernelGGL(KN(lm_k_restir_spatial), LM_GRID(g), fr, cur, rin, rout, seed, margin, pass);
 }
 static void l_combine(hipStream_t s, int g, LmFrame fr, int cur, int rc, int rs, uint32_t seed, int fast)
-{ if (fast) { hipLaunchKernelGGL(KN(lm_k_restir_combine_fast), LM_GRID_CAP(g, "COMBINE", 0u), fr, cur, rc, rs, seed); if (fast > 1) hipLaunchKernelGGL(KN(lm_k_restir_combine_rare), LM_GRID(g), fr, cur, rc, rs, seed); } else hipLaunchKernelGGL(KN(lm_k_restir_combine), LM_GRID(g), fr, cur, rc, rs, seed); }
+{
+    if (fr.deferred) {
+        const int gd = g < 2048 ? g : 2048;
+        if (fast) { hipLaunchKernelGGL(KN(lm_k_restir_combine_fast_deferred), LM_GRID(gd), fr, cur, rc, rs, seed, g); if (fast > 1) hipLaunchKernelGGL(KN(lm_k_restir_combine_rare_deferred), LM_GRID(gd), fr, cur, rc, rs, seed, g); }
+        else hipLaunchKernelGGL(KN(lm_k_restir_combine_deferred), LM_GRID(gd), fr, cur, rc, rs, seed, g);
+        return;
+    }
+  if (fast) { hipLaunchKernelGGL(KN(lm_k_restir_combine_fast), LM_GRID_CAP(g, "COMBINE", 0u), fr, cur, rc, rs, seed); if (fast > 1) hipLaunchKernelGGL(KN(lm_k_restir_combine_rare), LM_GRID(g), fr, cur, rc, rs, seed); } else hipLaunchKernelGGL(KN(lm_k_restir_combine), LM_GRID(g), fr, cur, rc, rs, seed); }
 static void l_clear(hipStream_t s, int g, float4* p, uint32_t n) { hipLaunchKernelGGL(KN(lm_k_clear_f4), LM_GRID(g), p, n); }
 static void l_merge(hipStream_t s, int g, LmFrame fr, int blend, uint32_t blendCount, int depthMax) { hipLaunchKernelGGL(KN(lm_k_merge_output), LM_GRID_CAP(g, "MERGE", 0u), fr, blend, blendCount, depthMax); }
 static void l_query_any(hipStream_t s, int g, LmScene sc, const float4* o, const float4* d, uint32_t n, float tmin, uint32_t* occ, uint32_t* counters) { hipLaunchKernelGGL(KN(lm_k_query_any), LM_GRID(g), sc, o, d, n, tmin, occ, counters); }
@@ -1616,6 +1747,9 @@ static void l_test_restir(hipStream_t s, int mode, uint32_t n, const float* a, c
 static void l_test_math(hipStream_t s, uint32_t n, int fn, const float* x, const float* y, float* out) { hipLaunchKernelGGL(KN(lm_k_test_math), LM_GRID((n + LM_BLOCK - 1) / LM_BLOCK), n, fn, x, y, out); }
 static void l_history_copy(hipStream_t s, int g, LmFrame fr, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, float4* buf, int import)
 { hipLaunchKernelGGL(KN(lm_k_history_copy), LM_GRID(g), fr, x0, y0, w, h, buf, import); }
+static void l_reuse_counts(hipStream_t s, LmFrame fo, int was, const uint32_t* list, const uint32_t* listCount, uint32_t seed)
+{ for (int phase = 0; phase < 2; phase++) hipLaunchKernelGGL(KN(lm_k_reuse_counts), dim3(64), dim3(LM_BLOCK), 0, s, fo, was, list, listCount, seed, phase); }
+static void l_reuse_settle(hipStream_t s, LmFrame fr) { hipLaunchKernelGGL(KN(lm_k_reuse_settle), dim3(1), dim3(64), 0, s, fr); }
 static void l_wave_sync(hipStream_t s, int* swap, int* io, int import) { hipLaunchKernelGGL(KN(lm_k_wave_sync), dim3(1), dim3(64), 0, s, swap, io, import); }
 static void l_sort_rays(hipStream_t s, int g, LmScene sc, const float4* srcO, const float4* srcD, const float4* srcC, float4* dstO, float4* dstD, float4* dstC,
                         const uint32_t* cnt, uint32_t* bins)
@@ -1635,6 +1769,6 @@ extern "C" const LmKernelTable* lm_kernel_table()
 #endif
 {
     static const LmKernelTable t = {l_primary, l_trace_closest, l_extract0, l_shade_wave, l_trace_shadow, l_path_tail, l_fill_bags, l_pick_primary,
-                                    l_trace_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_export_aux, l_refit_tris, l_refit_quant, l_refit_level, l_test_bsdf, l_test_math, l_spin, l_history_copy, l_wave_sync, l_test_restir, l_build_top, l_export_half4, l_sort_rays};
+                                    l_trace_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_export_aux, l_refit_tris, l_refit_quant, l_refit_level, l_test_bsdf, l_test_math, l_spin, l_history_copy, l_wave_sync, l_test_restir, l_build_top, l_export_half4, l_sort_rays, l_reuse_settle, l_reuse_counts};
     return &t;
 }

@@ -36,6 +36,8 @@ struct LmKernelTable {
     // counting sort of a ray queue by (origin cell, direction octant) into another queue; bins: 2 x 4096 words, zero on entry and on return
     void (*sort_rays)(hipStream_t, int grid, LmScene, const float4* srcO, const float4* srcD, const float4* srcC, float4* dstO, float4* dstD, float4* dstC,
                       const uint32_t* count, uint32_t* bins);
+    void (*reuse_settle)(hipStream_t, LmFrame);       // after deferred history passes launched BETWEEN frames (kernels.hip lm_reuse_owed)
+    void (*reuse_counts)(hipStream_t, LmFrame previous, int was, const uint32_t* list, const uint32_t* listCount, uint32_t seed);      // lazy reuse: completes the entries that outlive a dropped history pass
 };
 extern "C" const LmKernelTable* lm_kernel_table();
 extern "C" const LmKernelTable* lm_kernel_table_instrumented();

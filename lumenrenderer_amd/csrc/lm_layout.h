@@ -145,16 +145,25 @@ struct LmFrame {
                                 // swap[2], swap[3] = has swap-chain buffer 0 / 1 been written since the reservoirs were reset?  With an even number of
                                 // executed waves per frame the "previous" buffer of the temporal pass never is: the pass then takes the
                                 // reset reservoir it would load (all zero) without loading it.
+                                // swap[4..9]: deferred history passes (frame.cpp "lazy reuse"): [4] = swap-chain index that was the FRONT buffer of the last
+                                // merged frame, [5] = 1 when that frame's spatial / combine passes have run or are settled (not owed), [7] = that frame's
+                                // LM_CNT_RARE flag, [8] = deferred executions, [9] = entries completed by lm_k_reuse_counts since the reservoirs were reset
+    uint32_t* hazardList;       // lazy reuse: pixels (window-local) that were reuse surfaces in the previous frame (G-buffer set owedSet, -1 = nothing pending) and are
+    int owedSet;                // flagged in this one, appended by the extraction; LM_CNT_HAZARD counts them (kernels.hip lm_k_reuse_counts)
+    int deferred;               // history-building passes (both spatial passes, combine): 0 = launched with their frame; 1 / 2 = launched later, inside the
+                                // next frame / between frames, and run only if the swap chain has turned (kernels.hip lm_reuse_owed)
     uint2* bags;                // 50 x 1000 light-bag entries: (light index, pdf bits)
 };
 // reservoir buffer index codes of the ReSTIR kernels: a literal index >= 0, or the swap-chain front / back buffer
 #define LM_RES_CUR (-1)
 #define LM_RES_PREV (-2)
+#define LM_RES_OWED (-3)                         // the front buffer of the last merged frame (swap[4]): what a deferred history pass completes
 // counter block layout (uint32 each)
 #define LM_CNT_RAYS(d) (d)                       // rays entering wave d            [0, LM_MAX_DEPTH]
 #define LM_CNT_SHADOW(d) (32 + (d))              // NEE shadow rays emitted by wave d
 #define LM_CNT_RESTIR(p) (70 + (p))              // ReSTIR visibility rays of pass p (0, 1)
 #define LM_CNT_RARE 72                           // flag: 1 when a depth-0 surface of the frame has a lobe outside the contracted evaluation (lm_bsdf.h lm_quick_contracts)
+#define LM_CNT_HAZARD 73                         // lazy reuse: entries of LmFrame::hazardList
 #define LM_CNT_STEP_HIST 96                       // instrumented build only: 16 log2 buckets of per-ray traversal steps (queue kernels)
 #define LM_CNT_STEP_MAX 112                       // instrumented build only: longest per-ray traversal (steps)
 #define LM_CNT_NODES 66                          // instrumented build only: child boxes slab-tested (u64 as 2 words); 2 boxes = one binary node of SURVEY 8 d4

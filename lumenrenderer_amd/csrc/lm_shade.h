@@ -224,22 +224,22 @@ __device__ __forceinline__ void lm_gbuf_load(const float4* __restrict__ g, uint3
 // rows, column-major inside a band, and each XCD (blocks b, b+8, ... share one) gets a contiguous run of that order, so the
 // tiles resident on one XCD form a compact patch and neighbour gathers (+-30 px) hit that XCD's L2.  Speed only.
 template <uint32_t LOG_TS = 4>   // tile edge = 1 << LOG_TS: 16 for 256-thread blocks, 32 for 1024-thread blocks
-__device__ __forceinline__ void lm_tile_origin(const LmFrame& fr, uint32_t& tx, uint32_t& ty)      // the block's tile (block-uniform)
-{
+__device__ __forceinline__ void lm_tile_origin(const LmFrame& fr, uint32_t& tx, uint32_t& ty, uint32_t b = blockIdx.x)      // the block's tile (block-uniform); b: a looping
+{                                                                                                                          // kernel's virtual block (grid a multiple of 8)
     constexpr uint32_t TS = 1u << LOG_TS;
     const uint32_t tilesX = (fr.ww + TS - 1u) >> LOG_TS, tilesY = (fr.wh + TS - 1u) >> LOG_TS, T = tilesX * tilesY;
-    const uint32_t b = blockIdx.x, q = T >> 3, r = T & 7u, xcd = b & 7u;
+    const uint32_t q = T >> 3, r = T & 7u, xcd = b & 7u;
     const uint32_t t = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (b >> 3);
     const uint32_t band = t / (8u * tilesX), within = t - band * 8u * tilesX;
     const uint32_t bh = min(8u, tilesY - band * 8u);
     tx = within / bh; ty = band * 8u + within % bh;
 }
 template <uint32_t LOG_TS = 4>
-__device__ __forceinline__ bool lm_tile_pixel(const LmFrame& fr, uint32_t& li, uint32_t& gi)
+__device__ __forceinline__ bool lm_tile_pixel(const LmFrame& fr, uint32_t& li, uint32_t& gi, uint32_t b = blockIdx.x)
 {
     constexpr uint32_t TS = 1u << LOG_TS;
     uint32_t tx, ty;
-    lm_tile_origin<LOG_TS>(fr, tx, ty);
+    lm_tile_origin<LOG_TS>(fr, tx, ty, b);
     const uint32_t lx = tx * TS + (threadIdx.x & (TS - 1u)), ly = ty * TS + (threadIdx.x >> LOG_TS);
     if (lx >= fr.ww || ly >= fr.wh) return false;
     li = ly * fr.ww + lx;

@@ -28,6 +28,7 @@ int lumen_mi_create(lumen_mi_renderer** out)
     if (const char* e = getenv("LUMEN_MI_PACKET_PRIMARY")) (*out)->packetPrimary = atoi(e);
     if (const char* e = getenv("LUMEN_MI_FAST_SHADE")) (*out)->fastShade = atoi(e);
     if (const char* e = getenv("LUMEN_MI_SPATIAL_LDS")) (*out)->spatialLds = atoi(e);
+    if (const char* e = getenv("LUMEN_MI_LAZY_REUSE")) (*out)->lazyReuse = atoi(e);
     if (const char* e = getenv("LUMEN_MI_PACKET_VISIBILITY")) (*out)->packetVisibility = atoi(e);
     if (const char* e = getenv("LUMEN_MI_SORT_RAYS")) (*out)->sortRays = std::max(0, atoi(e));
     if (const char* e = getenv("LUMEN_MI_FAST_RESAMPLE")) (*out)->fastResample = atoi(e) != 0;
@@ -113,6 +114,7 @@ int lumen_mi_destroy(lumen_mi_renderer* r)
         for (auto& b : r->dResC) b.release();
         for (auto& b : r->dMotion) b.release();
         for (int i = 0; i < 2; i++) { r->dDirect[i].release(); r->dIndirect[i].release(); }
+        r->dReuseMask.release(); r->dHazard[0].release(); r->dHazard[1].release();
         r->dSortBins.release(); r->dExportHalf.release(); r->dTotals.release(); r->dCombined.release(); for (auto& b : r->dHits) b.release(); r->dCounters.release(); r->dSwap.release(); r->dOutput.release(); r->dBags.release();
         for (auto& e : r->evPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     }
@@ -511,6 +513,8 @@ static int historyCopy(lumen_mi_renderer* r, uint32_t x0, uint32_t y0, uint32_t 
     if (x0 >= x1 || y0 >= y1 || x0 < f.x0 || y0 < f.y0 || x1 > f.x0 + f.ww || y1 > f.y0 + f.wh) return fail(LUMEN_MI_ERR_INVALID, "rectangle outside the render window");
     if (hipSetDevice(r->device) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "hipSetDevice failed");
     const uint32_t w = x1 - x0, h = y1 - y0;
+    // the last frame may have left its history passes pending (lazy reuse, frame.cpp): when the swap chain has turned, what is copied here is their result
+    if (r->owed.valid) { launchOwedReuse(r, r->stream, 2); r->K->reuse_settle(r->stream, f); }
     r->K->history_copy(r->stream, r->gridFor(w * h, 8), f, x0 - f.x0, y0 - f.y0, w, h, (float4*)dev, import);
     LM_HIP(hipGetLastError());
     return 0;
@@ -587,6 +591,7 @@ int lumen_mi_get_counters(lumen_mi_renderer* r, uint64_t* out, uint32_t n)
     for (int k = 0; k < 4; k++) v[41 + k] = (uint64_t)c[LM_CNT_OCC + 2 * k] | ((uint64_t)c[LM_CNT_OCC + 2 * k + 1] << 32);
     v[48] = c[LM_CNT_RESTIR(0)]; v[49] = c[LM_CNT_RESTIR(1)];
     v[50] = r->refits; v[51] = r->assemblies;                                          // GPU refits / instance-level assemblies since creation
+    if (r->fr.swap) { int dv[2] = {0, 0}; if (hipMemcpy(dv, r->fr.swap + 8, sizeof dv, hipMemcpyDeviceToHost) == hipSuccess) { v[54] = (uint64_t)dv[0]; v[55] = (uint64_t)dv[1]; } }     // lazy reuse: deferred history passes that ran / entries completed instead
     v[52] = c[LM_CNT_RARE]; v[53] = r->anyRareMaterial ? 1u : 0u;                      // depth-0 surfaces outside the contracted ReSTIR evaluation / can any material produce one
     for (uint32_t i = 0; i < n && i < 64; i++) out[i] = v[i];
     return 0;
@@ -642,6 +647,7 @@ int lumen_mi_set_tuning(lumen_mi_renderer* r, const char* key, int value)
     else if (k == "packet_primary") r->packetPrimary = value;
     else if (k == "packet_visibility") r->packetVisibility = value;
     else if (k == "spatial_lds") r->spatialLds = value;
+    else if (k == "lazy_reuse") r->lazyReuse = value;
     else if (k == "fast_shade") r->fastShade = value;
     else if (k == "sort_rays") { if (r->initialised) { int rc = syncAndCollect(r); if (rc) return rc; } r->sortRays = std::max(0, value); }
     else if (k == "refill") r->refillBelow = value;

@@ -189,6 +189,11 @@ struct lumen_mi_renderer {
     bool anyRareMaterial = false;           // some material ever created may need the second (exact) launch of the fast ReSTIR passes
     int fastShade = 0;                      // the NEE contribution of the shading kernels (depth >= 1) in the fast arithmetic policy (lm_shade.h lm_shade_direct): changes radiance
                                             // in the last bits only; sampling / Russian roulette stay exact.  Off: measured gain below 2 % (profiles/r03_fast_shade_ab.txt)
+    // Lazy reuse (tuning key lazy_reuse; frame.cpp): the spatial passes and the combine of a frame are not launched with the frame but at the start of the
+    // next frame's ReSTIR chain, where the device runs them only if their result can still be read (kernels.hip lm_reuse_owed).  1 on, 0 off (launched with
+    // their frame, every frame), -1 automatic: on at even path depths, where the reference's swap quirk makes every such result dead while the camera rests.
+    int lazyReuse = -1;
+    struct OwedReuse { bool valid = false; LmFrame fr{}; int gbuf = 0; uint32_t seed = 0; int fast = 0; int tiles = 0; } owed;
     int spatialLds = 0;                     // fast mode: the first spatial pass stages its probe window in LDS (lm_k_restir_spatial_fast_lds): 1 on, 0 off
     int packetVisibility = 0;               // the ReSTIR visibility rays likewise (lm_k_restir_trace_shade_packet): 1 on, 0 off (default), -1 the primary wave's rule.
                                             // Measured 3x SLOWER on C2 (profiles/r03_packet_visibility_ab.txt): a tile's visibility rays start on surfaces at very
@@ -214,6 +219,7 @@ struct lumen_mi_renderer {
     uint32_t frameCount = 0, blendCounter = 0;
     int frameIndex = 0;
     int gbufIndex = 0, lastGbuf = 0;        // physical G-buffer set of the frame being enqueued / of the last enqueued frame (3 sets)
+    DevBuf<uint32_t> dHazard[2];            // lazy reuse: LmFrame::hazardList, by frame parity
     DevBuf<int> dSwap;                      // ReSTIR swap-chain index lives on the device (LmFrame::swap)
 
     // flattened scene (host)
@@ -292,5 +298,7 @@ int traceFrameAsync(R* r);
 void cameraVectors(const float* right, const float* up, const float* fwd, float fovY, float aspect, float* U, float* V, float* Wv);
 void motionMatrix(const float* prevCamWorld, float fovY, float aspect, float* M);
 int syncAndCollect(R* r);
+// launches the pending history passes of the last frame (R::owed) on `s`: mode 1 inside the next frame, 2 between frames
+void launchOwedReuse(R* r, hipStream_t s, int mode);
 
 }  // namespace lmr

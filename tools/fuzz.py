@@ -30,6 +30,7 @@ def run(W, H, depth, tuning, window, tile, sync_each, frames=8):
                 t = np.array(dd["transform"], np.float32).reshape(4, 4).copy(); t[0, 3] += 1.5 * (n >= len(desc.instances))
                 mi.SetTransform(t); mi.SetEmissiveness(dd["emission_mode"], dd["override_radiance"], dd["scale"])
             inst = sc.m_MeshInstances
+        if k in (3, 6): r.SetDepth(depth + (k == 3))        # the swap chain's parity changes mid-run (lazy reuse: pending history passes run / are dropped)
         c = desc.camera
         r.SetCamera((c["position"][0] + 0.01 * k, c["position"][1], c["position"][2]), c["right"], c["up"], c["forward"], c["fov"])
         assert r.TraceFrameAsync()
@@ -43,11 +44,12 @@ def run(W, H, depth, tuning, window, tile, sync_each, frames=8):
 shapes = [(1280, 720, 5, None, None), (1280, 720, 6, None, None), (2560, 1440, 6, None, None)]
 t8 = tiles.tile_rect(1, 8, 2560, 1440); shapes.append((2560, 1440, 5, tiles.window_rect(t8, 2560, 1440), t8))
 schedules = [{}, {"pick_ahead": 0}, {"shadow_on_wave": 1}, {"tail_below": 0}, {"tail_below": 1 << 30}, {"tail_below": 60000, "tail_lanes": 64},
-             {"tail_pair": 1, "tail_below": 1 << 30}, {"tail_pair": 1, "tail_below": 60000, "tail_lanes": 16}]
+             {"tail_pair": 1, "tail_below": 1 << 30}, {"tail_pair": 1, "tail_below": 60000, "tail_lanes": 16},
+             {"lazy_reuse": 1}, {"lazy_reuse": 1, "pick_ahead": 0, "tail_below": 0}, {"lazy_reuse": 1, "wave_streams": 2}, {"lazy_reuse": 0}]
 bad = total = 0
 t0 = time.time()
 for (W, H, depth, window, tile) in shapes:
-    ref = run(W, H, depth, {"single_stream": 1, "tail_below": 0, "pick_ahead": 0}, window, tile, True)
+    ref = run(W, H, depth, {"single_stream": 1, "tail_below": 0, "pick_ahead": 0, "lazy_reuse": 0}, window, tile, True)       # serial, history passes with their frame
     for sched, seed in itertools.product(schedules, range(1, SEEDS + 1)):
         if W > 2000 and seed > max(2, SEEDS // 3): continue
         got = run(W, H, depth, dict(sched, fuzz=(0x9E3779B1 * (seed + 17 * len(sched)) + W) & 0x7fffffff), window, tile, False)
