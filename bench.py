@@ -10,6 +10,12 @@ Arithmetic mode: `value` is measured with the fast ReSTIR mode (tuning key fast_
 function in the candidate pick and the reuse passes; radiance within 1e-8 relative L2 of the oracle on every BASELINE configuration, 1e-3
 asserted by tests/test_gpu_parity.py, every ray counter identical).  The same run then times the exact mode (bit-identical to the oracle) the
 same way and reports it as config.other_mode; --mode exact swaps the two, --no-exact skips the second pass.
+
+History passes: `value` is measured with BOTH spatial reuse passes and the reservoir combine launched in every TraceFrame, as the reference launches
+them (tuning key lazy_reuse 0).  The renderer's default at this even path depth is lazy reuse — those passes only build the history of the next
+frame, which the reference's own swap quirk never reads at an even depth, so they run only when the result can be read; every image, counter and ray
+is identical (tests/test_gpu_parity.py::test_history_passes_run_only_when_their_result_can_be_read).  That rate is reported beside the headline as
+`value_lazy_reuse` / `ms_per_step_lazy_reuse` (and `value_exact_lazy_reuse`); --reuse lazy makes it the headline instead.
 """
 import argparse
 import json
@@ -173,6 +179,10 @@ def main():
                     help="arithmetic of the ReSTIR target function for the headline number: 'fast' = hardware rcp / rsq / sqrt + contracted "
                          "evaluation (tuning key fast_resample; held to 1e-3 rel-L2 against the oracle by tests/test_gpu_parity.py, measured 1e-8), "
                          "'exact' = correctly rounded, bit-identical to the oracle")
+    ap.add_argument("--reuse", choices=("eager", "lazy"), default="eager",
+                    help="ReSTIR history passes of the headline: eager = launched with every TraceFrame like the reference's (lazy_reuse 0); lazy = the renderer's "
+                         "default, launched when their result can be read (identical images; reported beside the headline either way)")
+    ap.add_argument("--no-other-reuse", action="store_true", help="skip the timed passes with the other setting of --reuse")
     ap.add_argument("--no-exact", action="store_true", help="skip the second timed pass in exact mode (reported beside the headline)")
     ap.add_argument("--exact-seams", choices=["auto", "on", "off"], default="auto",
                     help="multi-GPU: exchange the halo rings' reservoir history (and the executed-wave count) after every TraceFrame; "
@@ -278,9 +288,10 @@ def main():
     node_records = float(ci[41]) if ci[41] > 0 else ci[22] / 4.0
     r.SetInstrumented(False)
 
-    def timed_pass(fast):
+    def timed_pass(fast, lazy):
         """W warm-up steps, then exactly K steps between barriers; returns the per-rank measurements of the pass."""
         r.SetTuning("fast_resample", 1 if fast else 0)
+        r.SetTuning("lazy_reuse", -1 if lazy else 0)
         del ev_log[:]
         for _ in range(args.warmup):
             frame()
@@ -332,8 +343,15 @@ def main():
                 "counters": c, "kernel_ms": k, "class_ms": kb, "n_traceframes": n_tf, "per_rank": per_rank}
 
     fast = args.mode == "fast"
-    main_pass = timed_pass(fast)
-    other_pass = None if (args.no_exact or world > 1 or emu) else timed_pass(not fast)
+    lazy = args.reuse == "lazy"
+    main_pass = timed_pass(fast, lazy)
+    other_pass = None if (args.no_exact or world > 1 or emu) else timed_pass(not fast, lazy)
+    # the other setting of the history passes, both arithmetic modes (single GPU only: the extra passes would double a scaling run)
+    reuse_pass = None if (args.no_other_reuse or world > 1 or emu) else timed_pass(fast, not lazy)
+    reuse_other = None if (args.no_other_reuse or args.no_exact or world > 1 or emu) else timed_pass(not fast, not lazy)
+    r.SetTuning("fast_resample", 1 if fast else 0); r.SetTuning("lazy_reuse", -1 if lazy else 0)
+    passes = {(fast, lazy): main_pass, (not fast, lazy): other_pass, (fast, not lazy): reuse_pass, (not fast, not lazy): reuse_other}      # (fast?, lazy?) -> pass or None
+    rate = lambda f, l, key="value", nd=3: None if passes[(f, l)] is None else round(passes[(f, l)][key], nd)
     if rank == 0:
         c, k, n_tf = main_pass["counters"], main_pass["kernel_ms"], main_pass["n_traceframes"]
         ms_per_step, value, rays_per_frame = main_pass["ms_per_step"], main_pass["value"], main_pass["rays_per_frame"]
@@ -383,6 +401,11 @@ def main():
             "mode": args.mode, "value_fast": round((main_pass if fast else other_pass)["value"], 3) if (fast or other_pass) else None,
             "value_exact": round((other_pass if fast else main_pass)["value"], 3) if (not fast or other_pass) else None,
             "ms_per_step_exact": round((other_pass if fast else main_pass)["ms_per_step"], 4) if (not fast or other_pass) else None,
+            # history passes (see the module docstring): "eager" = both spatial passes + combine launched in every TraceFrame like the reference's; "lazy" = the
+            # renderer's default, launched when their result can be read.  Identical images, counters and rays; both rates in the mode of `value`
+            "reuse": args.reuse,
+            "value_eager_reuse": rate(fast, False), "value_lazy_reuse": rate(fast, True), "ms_per_step_lazy_reuse": rate(fast, True, "ms_per_step", 4),
+            "value_exact_lazy_reuse": rate(False, True), "value_exact_eager_reuse": rate(False, False),
             "config": {"workload": f"{args.workload}: {'cornell box (the reference asset, tests/golden fixture)' if kind == 'cornell' else kind + ' stand-in'}, {W}x{H}, {spp} spp (blended TraceFrames), depth {depth}, ReSTIR DI on",
                        "resample_mode": ("fast: hardware rcp/rsq/sqrt + contracted target function in the ReSTIR passes (rel-L2 vs oracle 1e-8 measured, 1e-3 asserted: "
                                          "test_fast_resampling_mode_stays_within_the_north_star_tolerance)") if fast else "exact: correctly rounded everywhere, bit-identical to the oracle",

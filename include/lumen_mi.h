@@ -139,7 +139,9 @@ int lumen_mi_get_frame_stat(lumen_mi_renderer*, const char* key, uint64_t* micro
  * [40] the longest per-ray traversal in steps, [41]/[42] active lanes / lane slots over all node steps, [43]/[44] the same
  * over all triangle tests, [45]/[46] traversal-stack pushes into LDS / into the global spill area
  * ([20]..[46] only in the instrumented build), [48]/[49] ReSTIR visibility rays of pass 1 / pass 2, [50] GPU refits and
- * [51] instance-level tree assemblies since the renderer was created */
+ * [51] instance-level tree assemblies since the renderer was created, [52] depth-0 surfaces outside the contracted ReSTIR evaluation seen (flag),
+ * [53] can any material produce one, [54] / [55] lazy reuse (tuning key lazy_reuse): deferred executions of the history passes / reservoir entries whose
+ * sample count was completed instead, since the reservoirs were last reset */
 int lumen_mi_get_counters(lumen_mi_renderer*, uint64_t* out, uint32_t n);
 /* the same counters SUMMED over every TraceFrame since the renderer was created or since the last call with reset != 0 (accumulated on the
  * device by the frame's last kernel, no read-back between frames): [0] closest-hit rays, [1] NEE shadow rays, [2] ReSTIR shadow rays,
@@ -163,7 +165,11 @@ int lumen_mi_set_instrumented(lumen_mi_renderer*, int enable);   /* use the node
  * must not change), "assemble" (1, default: after the first build a topology edit — an instance added or removed — assembles cached
  * per-mesh trees behind a small top tree and refits on the GPU; 0: full host SAH rebuild), "packet_primary" / "packet_visibility" (the primary
  * wave / the ReSTIR visibility rays are traced as wavefront packets — one shared traversal stack per 64 coherent rays: 1 on, 0 off, -1
- * automatic: on when the window has more than 4 pixels per scene triangle; default -1 for the primary wave, 0 for the visibility rays, where packets measured slower), "fast_resample" (arithmetic mode of the ReSTIR passes, see
+ * automatic: on when the window has more than 4 pixels per scene triangle; default -1 for the primary wave, 0 for the visibility rays, where packets measured slower), "lazy_reuse" (the history-building ReSTIR passes of a frame — both spatial reuse passes and CombineReservoirBuffers,
+ * ReSTIR.cpp:181-233 — are launched with the NEXT frame and run only if their result can still be read, i.e. when the reservoir swap chain has turned; if it has
+ * not — every frame of an even path depth, WaveFrontRenderer.cpp:827 — only the sample counts of the entries that outlive the next candidate pick are
+ * completed.  Images, counters and exported history counts equal those of launching the passes with their frame; 1 on, 0 off, -1 (default) automatic: on at
+ * even path depths; DESIGN.md "Lazy reuse"), "fast_resample" (arithmetic mode of the ReSTIR passes, see
  * the only key that changes results, within the stated tolerance). */
 int lumen_mi_set_tuning(lumen_mi_renderer*, const char* key, int value);
 

@@ -820,7 +820,35 @@ __device__ __forceinline__ void lm_restir_temporal_body(const LmFrame& fr, int c
                         const float4 q0 = fr.gbuf[cur][8u * li + LM_GB_POSITION], q7 = fr.gbuf[cur][8u * li + LM_GB_PARAMS];
                         s.position = v3(q0); s.mat.p0 = f2u(q7.x); s.mat.p1 = f2u(q7.y); s.mat.p2 = f2u(q7.z);
                     }
-                    if (lm_role_takes<ROLE>(s.mat)) {              // fast mode: the other launch merges this pixel
+#ifndef LM_TEMPORAL_INPLACE
+#define LM_TEMPORAL_INPLACE 1      // 0: A/B switch, the shortcut loads and stores the whole reservoir
+#endif
+                    if (LM_TEMPORAL_INPLACE && !prevLive && rf == rc && lm_role_takes<ROLE>(s.mat)) {
+                        // The same shortcut IN PLACE (candidates picked on this stream: the fresh reservoir already sits in the current buffer).  The two Updates
+                        // below decide from numbers alone whether the fresh sample is kept, so the sample itself — position, normal, radiance, contribution —
+                        // is neither loaded nor rewritten: quads 0 and 1 in, (weightSum, pdf) and the weight out; the light point only to aim the ray.
+                        mine = true;
+                        float4* h = fr.res[rc] + 4u * li;
+                        const float4 h0 = h[0], h1 = h[1];
+                        const uint32_t sd = lm_wang_hash(seed + gi);
+                        LmReservoir out; lm_res_fresh(out);
+                        (void)lm_res_update_decide<A>(out, (float)0ll * 0.f * 0.f, sd);
+                        const long long cnt = lm_hot_count(h1);
+                        if (lm_res_update_decide<A>(out, (float)cnt * lm_hot_weight(h1) * h0.y, sd)) {
+                            out.s.pdf = h0.y;
+                            out.count = 0ll + cnt;
+                            lm_res_update_weight<A>(out);
+                            h[0] = make_float4(out.weightSum, out.s.pdf, 0.f, 0.f);
+                            *lm_hot_weight_at(fr.res[rc], li) = out.weight;
+                            if (out.weight > 0.f) vtarget = v3(h[3]);
+                        } else {                                   // (weight 0 after the first visibility pass, or a degenerate product): the zero sample survives
+                            out.count = 0ll + cnt;
+                            lm_res_update_weight<A>(out);
+                            lm_res_store(fr.res[rc], fr.resC[rc], li, out);
+                            vtarget = out.s.p.position;
+                        }
+                        weight = out.weight; vpos = s.position;
+                    } else if (lm_role_takes<ROLE>(s.mat)) {       // fast mode: the other launch merges this pixel
                         mine = true;
                         LmReservoir rpv, rcv, out;
                         lm_res_load(fr.res[rf], fr.resC[rf], li, rcv);
