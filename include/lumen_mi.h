@@ -165,7 +165,8 @@ int lumen_mi_set_instrumented(lumen_mi_renderer*, int enable);   /* use the node
  * must not change), "assemble" (1, default: after the first build a topology edit — an instance added or removed — assembles cached
  * per-mesh trees behind a small top tree and refits on the GPU; 0: full host SAH rebuild), "packet_primary" / "packet_visibility" (the primary
  * wave / the ReSTIR visibility rays are traced as wavefront packets — one shared traversal stack per 64 coherent rays: 1 on, 0 off, -1
- * automatic: on when the window has more than 4 pixels per scene triangle; default -1 for the primary wave, 0 for the visibility rays, where packets measured slower), "lazy_reuse" (the history-building ReSTIR passes of a frame — both spatial reuse passes and CombineReservoirBuffers,
+ * automatic: on when the window has more than 4 pixels per scene triangle; default -1 for the primary wave, 0 for the visibility rays, where packets measured slower), "fuse_primary" (1: the packet kernel of the primary wave generates its rays itself instead of reading a plane written by a launch before it; default 0, no gain measured),
+ * "lazy_reuse" (the history-building ReSTIR passes of a frame — both spatial reuse passes and CombineReservoirBuffers,
  * ReSTIR.cpp:181-233 — are launched with the NEXT frame and run only if their result can still be read, i.e. when the reservoir swap chain has turned; if it has
  * not — every frame of an even path depth, WaveFrontRenderer.cpp:827 — only the sample counts of the entries that outlive the next candidate pick are
  * completed.  Images, counters and exported history counts equal those of launching the passes with their frame; 1 on, 0 off, -1 (default) automatic: on at

@@ -232,7 +232,10 @@ int traceFrameAsync(R* r)
 #endif
     if (!blend) { Z(st); K->clear(st, r->gridFor(fr.n, 8), fr.combined, fr.n); }                        // :559
     ++r->frameCount;                                                                          // :593
-    Z(sx); K->primary(sx, r->gridFor(fr.n, 8), fr, cam, r->frameCount);
+    // the packet kernel of the primary wave generates its rays itself (kernels.hip lm_k_trace_primary_packet); the counting build traces per lane, from the plane
+    const bool fusePrimary = usePackets && !r->instrumented && r->fusePrimary != 0;
+    if (!fusePrimary) { Z(sx); K->primary(sx, r->gridFor(fr.n, 8), fr, cam, r->frameCount); }
+    const uint32_t frameCountPrimary = r->frameCount;
     uint32_t seed = wangHash(r->frameCount);                                                  // :685
     LmScene scx = r->dscene;                                                                  // same scene, its own stack-spill area
     if (overlap) scx.spill += (size_t)((twoWave && par) ? 2 : 1) * r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS);
@@ -272,7 +275,8 @@ int traceFrameAsync(R* r)
         const int doIndirect = depth < depthMax - 1 ? 1 : 0;
         if (depth == 0) {
             evBegin2(r, 0, ev, sx);
-            Z(sx); K->trace_closest(sx, gridMain, scx, nullptr, fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters, usePackets ? -1 : r->refillPrimary, cam.eye);    // :678,:703; primary rays start at the eye
+            if (fusePrimary) { Z(sx); K->trace_primary(sx, gridMain, scx, fr, cam, frameCountPrimary, fr.hits, 0.01f, 5000.f); }
+            else { Z(sx); K->trace_closest(sx, gridMain, scx, nullptr, fr.rayD[q], inCount, fr.hits, 0.01f, 5000.f, fr.counters, usePackets ? -1 : r->refillPrimary, cam.eye); }    // :678,:703; primary rays start at the eye
             evEnd2(r, ev, sx);
             if (overlap) LM_HIP(hipStreamWaitEvent(sx, r->evTemporal[par], 0));          // the temporal pass two frames back has read what extraction overwrites
             if (twoWave && r->owed.valid) LM_HIP(hipStreamWaitEvent(sx, r->evFront, 0));     // (that list compares with the previous frame's probe plane, written on the other wave stream)

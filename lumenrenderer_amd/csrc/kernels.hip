@@ -120,6 +120,22 @@ __device__ __forceinline__ void lm_slot_to_pixel(const LmFrame& fr, uint32_t i, 
     j -= rw * h8;
     ly = h8 + j / fr.ww; lx = j % fr.ww;
 }
+// primary ray of queue slot i: its pixel (window-local index) and direction — GPUGeneratePrimRay.cu:28-82 (Halton jitter of index frameCount + pixel)
+__device__ __forceinline__ lf3 lm_primary_dir(const LmFrame& fr, const LmCamera& cam, uint32_t frameCount, uint32_t i, uint32_t& li)
+{
+    uint32_t lx, ly;
+    lm_slot_to_pixel(fr, i, lx, ly);
+    li = ly * fr.ww + lx;
+    const uint32_t sx = fr.x0 + lx, sy = fr.y0 + ly;
+    const uint32_t gi = sy * fr.W + sx;
+    const float jx = lm_halton(frameCount + gi, 2u), jy = lm_halton(frameCount + gi, 3u);
+    float dx = ((float)(int)sx + jx) / (float)fr.W;
+    float dy = ((float)(int)sy + jy) / (float)fr.H;
+    dx = -(dx * 2.0f - 1.0f);
+    dy = -(dy * 2.0f - 1.0f);
+    const lf3 U = v3(cam.U[0], cam.U[1], cam.U[2]), V = v3(cam.V[0], cam.V[1], cam.V[2]), Wv = v3(cam.Wv[0], cam.Wv[1], cam.Wv[2]);
+    return normalize3(dx * U + dy * V + Wv);
+}
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
 KN(lm_k_primary)(LmFrame fr, LmCamera cam, uint32_t frameCount)
 {
@@ -131,18 +147,8 @@ KN(lm_k_primary)(LmFrame fr, LmCamera cam, uint32_t frameCount)
 #endif
     const uint32_t stride = gridDim.x * LM_BLOCK;
     for (uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x; i < fr.n; i += stride) {
-        uint32_t lx, ly;
-        lm_slot_to_pixel(fr, i, lx, ly);
-        const uint32_t li = ly * fr.ww + lx;
-        const uint32_t sx = fr.x0 + lx, sy = fr.y0 + ly;
-        const uint32_t gi = sy * fr.W + sx;
-        const float jx = lm_halton(frameCount + gi, 2u), jy = lm_halton(frameCount + gi, 3u);
-        float dx = ((float)(int)sx + jx) / (float)fr.W;
-        float dy = ((float)(int)sy + jy) / (float)fr.H;
-        dx = -(dx * 2.0f - 1.0f);
-        dy = -(dy * 2.0f - 1.0f);
-        const lf3 U = v3(cam.U[0], cam.U[1], cam.U[2]), V = v3(cam.V[0], cam.V[1], cam.V[2]), Wv = v3(cam.Wv[0], cam.Wv[1], cam.Wv[2]);
-        const lf3 dir = normalize3(dx * U + dy * V + Wv);
+        uint32_t li;
+        const lf3 dir = lm_primary_dir(fr, cam, frameCount, i, li);
         // only the direction plane is written: every primary ray starts at the eye with contribution (1, 1, 1), which the first closest-hit
         // launch and the depth-0 extraction take from their arguments instead of reading 32 bytes per pixel back (IntersectionRayData's
         // origin and contribution, GPUGeneratePrimRay.cu:69-72)
@@ -1243,6 +1249,42 @@ KN(lm_k_merge_output)(LmFrame fr, int blend, uint32_t blendCount, int depthMax)
     }
 }
 
+// K1 + K2-K4 for the primary wave in one launch: the packet kernel generates its rays itself (64 consecutive queue slots = one 8 x 8 pixel tile) and leaves
+// the direction plane for the extraction (tuning key fuse_primary, off).  Alone lm_k_primary is a 27-us stream of 59 MB; at the head of a frame's wave
+// chain, in a machine full of resident long-running blocks, it shows 200 us in the timeline (profiles/r03_c2_timeline_lazy_fast.txt) — but fusing it
+// away changes nothing (- 0.3 %, profiles/r03_fuse_primary_ab.txt): the time was spent waiting for block slots, and the traversal waits for the same slots.
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_TRACE_WAVES)
+KN(lm_k_trace_primary_packet)(LmScene sc, LmFrame fr, LmCamera cam, uint32_t frameCount, uint4* __restrict__ hits, float tmin, float tmax)
+{
+    __shared__ int s_wstack[LM_PACKET_STACK * (LM_BLOCK / 64)];
+    __shared__ uint4 s_top[LM_WIDTH * LM_TOP_NODES + 1];
+    if (blockIdx.x == 0) {              // the frame's first kernel zeroes the frame's counter block (as lm_k_primary does); no other block of this kernel touches it
+#if LM_PRIMARY_CLEARS
+        for (uint32_t w = threadIdx.x; w < LM_CNT_WORDS; w += LM_BLOCK) fr.counters[w] = 0u;
+        __syncthreads();
+#endif
+        if (threadIdx.x == 0) fr.counters[LM_CNT_RAYS(0)] = fr.n;
+    }
+    const lf3 eye = v3(cam.eye[0], cam.eye[1], cam.eye[2]);
+    float4* __restrict__ plane = fr.rayD[0];
+    lm_trace_packets<false>(sc, fr.n, (lm_lds_int*)(s_wstack + LM_PACKET_STACK * (threadIdx.x >> 6)), lm_stage_top(s_top, sc),
+        [&](uint32_t i, lf3& o, lf3& d, float& t0, float& t1) {
+            uint32_t li;
+            o = eye; d = lm_primary_dir(fr, cam, frameCount, i, li); t0 = tmin; t1 = tmax;
+            plane[i] = make_float4(d.x, d.y, d.z, u2f(li));
+        },
+        [&](uint32_t i, bool found, const LmHit& h) {
+            uint4 out = make_uint4(0u, 0u, 0u, f2u(-1.f));
+            if (found) {
+                const uint2 id = sc.triId[h.slot];
+                out.x = id.x; out.y = id.y;
+                out.z = lm_f32_to_f16(h.u) | (lm_f32_to_f16(h.v) << 16);
+                out.w = f2u(h.t);
+            }
+            hits[i] = out;
+        });
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // test / seam kernels (the ray-query seam of OptixWrapper::TraceRays and batch BSDF evaluation for known-answer tests)
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1684,6 +1726,8 @@ static unsigned lm_cap(const char* name, unsigned dflt) { const char* e = getenv
 #define LM_GRID_CAP(g, NAME, DFLT) dim3((unsigned)(g)), dim3(LM_BLOCK), LM_CAP(NAME, DFLT), s
 
 static void l_primary(hipStream_t s, int g, LmFrame fr, LmCamera cam, uint32_t frameCount) { hipLaunchKernelGGL(KN(lm_k_primary), LM_GRID_CAP(g, "PRIMARY", 0u), fr, cam, frameCount); }
+static void l_trace_primary(hipStream_t s, int g, LmScene sc, LmFrame fr, LmCamera cam, uint32_t frameCount, uint4* hits, float tmin, float tmax)
+{ hipLaunchKernelGGL(KN(lm_k_trace_primary_packet), LM_GRID(g), sc, fr, cam, frameCount, hits, tmin, tmax); }
 static void l_trace_closest(hipStream_t s, int g, LmScene sc, const float4* o, const float4* d, const uint32_t* cnt, uint4* hits, float tmin, float tmax, uint32_t* counters, int refillBelow, const float* eye)
 {
     const float4 e = eye ? make_float4(eye[0], eye[1], eye[2], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1797,6 +1841,6 @@ extern "C" const LmKernelTable* lm_kernel_table()
 #endif
 {
     static const LmKernelTable t = {l_primary, l_trace_closest, l_extract0, l_shade_wave, l_trace_shadow, l_path_tail, l_fill_bags, l_pick_primary,
-                                    l_trace_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_export_aux, l_refit_tris, l_refit_quant, l_refit_level, l_test_bsdf, l_test_math, l_spin, l_history_copy, l_wave_sync, l_test_restir, l_build_top, l_export_half4, l_sort_rays, l_reuse_settle, l_reuse_counts};
+                                    l_trace_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_export_aux, l_refit_tris, l_refit_quant, l_refit_level, l_test_bsdf, l_test_math, l_spin, l_history_copy, l_wave_sync, l_test_restir, l_build_top, l_export_half4, l_sort_rays, l_reuse_settle, l_reuse_counts, l_trace_primary};
     return &t;
 }

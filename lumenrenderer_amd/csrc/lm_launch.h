@@ -38,6 +38,7 @@ struct LmKernelTable {
                       const uint32_t* count, uint32_t* bins);
     void (*reuse_settle)(hipStream_t, LmFrame);       // after deferred history passes launched BETWEEN frames (kernels.hip lm_reuse_owed)
     void (*reuse_counts)(hipStream_t, LmFrame previous, int was, const uint32_t* list, const uint32_t* listCount, uint32_t seed);      // lazy reuse: completes the entries that outlive a dropped history pass
+    void (*trace_primary)(hipStream_t, int grid, LmScene, LmFrame, LmCamera, uint32_t frameCount, uint4* hits, float tmin, float tmax);   // primary rays generated inside the packet traversal
 };
 extern "C" const LmKernelTable* lm_kernel_table();
 extern "C" const LmKernelTable* lm_kernel_table_instrumented();

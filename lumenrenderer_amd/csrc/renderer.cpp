@@ -29,6 +29,7 @@ int lumen_mi_create(lumen_mi_renderer** out)
     if (const char* e = getenv("LUMEN_MI_FAST_SHADE")) (*out)->fastShade = atoi(e);
     if (const char* e = getenv("LUMEN_MI_SPATIAL_LDS")) (*out)->spatialLds = atoi(e);
     if (const char* e = getenv("LUMEN_MI_LAZY_REUSE")) (*out)->lazyReuse = atoi(e);
+    if (const char* e = getenv("LUMEN_MI_FUSE_PRIMARY")) (*out)->fusePrimary = atoi(e);
     if (const char* e = getenv("LUMEN_MI_PACKET_VISIBILITY")) (*out)->packetVisibility = atoi(e);
     if (const char* e = getenv("LUMEN_MI_SORT_RAYS")) (*out)->sortRays = std::max(0, atoi(e));
     if (const char* e = getenv("LUMEN_MI_FAST_RESAMPLE")) (*out)->fastResample = atoi(e) != 0;
@@ -648,6 +649,7 @@ int lumen_mi_set_tuning(lumen_mi_renderer* r, const char* key, int value)
     else if (k == "packet_visibility") r->packetVisibility = value;
     else if (k == "spatial_lds") r->spatialLds = value;
     else if (k == "lazy_reuse") r->lazyReuse = value;
+    else if (k == "fuse_primary") r->fusePrimary = value;
     else if (k == "fast_shade") r->fastShade = value;
     else if (k == "sort_rays") { if (r->initialised) { int rc = syncAndCollect(r); if (rc) return rc; } r->sortRays = std::max(0, value); }
     else if (k == "refill") r->refillBelow = value;

@@ -192,6 +192,8 @@ struct lumen_mi_renderer {
     // Lazy reuse (tuning key lazy_reuse; frame.cpp): the spatial passes and the combine of a frame are not launched with the frame but at the start of the
     // next frame's ReSTIR chain, where the device runs them only if their result can still be read (kernels.hip lm_reuse_owed).  1 on, 0 off (launched with
     // their frame, every frame), -1 automatic: on at even path depths, where the reference's swap quirk makes every such result dead while the camera rests.
+    int fusePrimary = 0;                    // 1: primary rays generated inside the packet traversal of the primary wave (tuning key fuse_primary) instead of their own launch first.
+                                            // Same image; measured - 0.3 % (profiles/r03_fuse_primary_ab.txt): the launch it saves only waited for slots the traversal then waits for
     int lazyReuse = -1;
     struct OwedReuse { bool valid = false; LmFrame fr{}; int gbuf = 0; uint32_t seed = 0; int fast = 0; int tiles = 0; } owed;
     int spatialLds = 0;                     // fast mode: the first spatial pass stages its probe window in LDS (lm_k_restir_spatial_fast_lds): 1 on, 0 off

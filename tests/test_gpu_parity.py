@@ -845,6 +845,7 @@ TUNINGS = [{"tail_below": 0}, {"tail_below": 1 << 30}, {"tail_below": 6000}, {"t
            {"tail_pair": 1, "tail_lanes": 5, "tail_below": 1 << 30, "wave_streams": 2},
            {"packet_visibility": 1}, {"packet_visibility": 1, "packet_primary": 1, "pick_ahead": 0}, {"packet_visibility": 0, "packet_primary": 0},
            {"wave_streams": 2}, {"wave_streams": 2, "tail_below": 0}, {"wave_streams": 2, "pick_ahead": 0}, {"wave_streams": 2, "tail_below": 6000, "pick_ahead": 0},
+           {"fuse_primary": 1}, {"fuse_primary": 1, "packet_primary": 1, "wave_streams": 2}, {"fuse_primary": 1, "packet_primary": 1, "single_stream": 1},
            {"lazy_reuse": 1}, {"lazy_reuse": 0}, {"lazy_reuse": 1, "wave_streams": 2}, {"lazy_reuse": 1, "single_stream": 1}, {"lazy_reuse": 1, "pick_ahead": 0, "tail_below": 0},
            {"lazy_reuse": 1, "pick_ahead": 1, "wave_streams": 2, "tail_below": 6000}]
 DEEP = [{"lazy_reuse": 0}, {"lazy_reuse": 1, "wave_streams": 2}, {"lazy_reuse": 1, "pick_ahead": 0, "single_stream": 1}, {}, {"packet_visibility": 1}, {"tail_pair": 1, "tail_below": 1 << 30}, {"tail_pair": 1}, {"pick_ahead": 0, "tail_below": 0}, {"pick_ahead": 1, "tail_below": 1 << 30}, {"single_stream": 1}, {"shadow_on_wave": 1}, {"sort_rays": 16, "tail_below": 0}, {"wave_streams": 2}]

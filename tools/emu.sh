@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: bash tools/emu.sh <tag>  — per-rank time of the tiled multi-GPU path, emulated on one GPU (rank 1 = an interior-column tile)
 tag=${1:-emu}; mkdir -p gpurun_out/$tag
-for e in "1/2" "1/4" "1/8"; do
+for e in "1/2" "1/4" "1/8" "1/2 --reuse lazy" "1/4 --reuse lazy" "1/8 --reuse lazy"; do
   timeout 600 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --emulate-rank $e > gpurun_out/$tag/b.json 2> gpurun_out/$tag/b.err
   python3 - "$e" <<PY
 import json,sys

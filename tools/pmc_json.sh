@@ -8,7 +8,7 @@
 tag=${1:-pmc}; shift; args="$@"; R=$PWD; mkdir -p gpurun_out/$tag
 pass() {  # name, counters...
   name=$1; shift
-  (cd /tmp && export TMPDIR=/tmp GPU_MAX_HW_QUEUES=8 && timeout 900 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/$tag/$name -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-exact $args > $R/gpurun_out/$tag/$name.log 2>&1)
+  (cd /tmp && export TMPDIR=/tmp GPU_MAX_HW_QUEUES=8 && timeout 900 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/$tag/$name -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-exact --no-other-reuse $args > $R/gpurun_out/$tag/$name.log 2>&1)
 }
 pass sq SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES
 pass fetch FETCH_SIZE
