@@ -75,6 +75,26 @@ __device__ __forceinline__ uint32_t lm_append_slot_block(uint32_t* counter, bool
     __syncthreads();                      // s_tmp may be reused by the caller's next iteration
     return slot;
 }
+// two appends behind one set of barriers (s_tmp: 2 x (waves per block + 1) words)
+__device__ __forceinline__ void lm_append_slot_block2(uint32_t* counterA, bool predA, uint32_t& slotA, uint32_t* counterB, bool predB, uint32_t& slotB, uint32_t* s_tmp)
+{
+    const unsigned long long maskA = __ballot(predA), maskB = __ballot(predB);
+    const uint32_t lane = lm_lane(), wave = threadIdx.x >> 6, nWaves = blockDim.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t* tA = s_tmp; uint32_t* tB = s_tmp + nWaves + 1u;
+    if (lane == 0) { tA[wave] = (uint32_t)__popcll(maskA); tB[wave] = (uint32_t)__popcll(maskB); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t totalA = 0, totalB = 0;
+        for (uint32_t w = 0; w < nWaves; w++) { const uint32_t a = tA[w]; tA[w] = totalA; totalA += a; const uint32_t b = tB[w]; tB[w] = totalB; totalB += b; }
+        tA[nWaves] = totalA ? atomicAdd(counterA, totalA) : 0u;
+        tB[nWaves] = totalB ? atomicAdd(counterB, totalB) : 0u;
+    }
+    __syncthreads();
+    slotA = tA[nWaves] + tA[wave] + (uint32_t)__popcll(maskA & below);
+    slotB = tB[nWaves] + tB[wave] + (uint32_t)__popcll(maskB & below);
+    __syncthreads();
+}
 __device__ __forceinline__ void lm_count_block(uint32_t* counter, bool pred, uint32_t* s_tmp)
 {
     const unsigned long long mask = __ballot(pred);
@@ -214,7 +234,7 @@ KN(lm_k_trace_closest_packet)(LmScene sc, const float4* __restrict__ rayO, const
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
 KN(lm_k_extract0)(LmScene sc, LmFrame fr, LmCamera cam, int cur, uint32_t seed2, int doIndirect, int outQ, uint32_t* outCount)
 {
-    __shared__ uint32_t s_tmp[5];
+    __shared__ uint32_t s_tmp[10];
     __shared__ float s_lut[256];
     __shared__ uint4 s_tab[LM_TABLE_QUADS];
     const lm_lds_float* lut = lm_stage_lut(s_lut, sc);
@@ -226,7 +246,8 @@ KN(lm_k_extract0)(LmScene sc, LmFrame fr, LmCamera cam, int cur, uint32_t seed2,
     const uint32_t nIter = (fr.n + stride - 1u) / stride;
     for (uint32_t it = 0; it < nIter; it++) {
         const uint32_t i = it * stride + blockIdx.x * LM_BLOCK + threadIdx.x;
-        bool emit = false;
+        bool emit = false, keeps = false;
+        uint32_t liKeeps = 0u;
         lf3 bo = v3(0.f), bd = v3(0.f), bc = v3(0.f);
         uint32_t liOut = 0u;
         if (i < fr.n) {
@@ -241,11 +262,8 @@ KN(lm_k_extract0)(LmScene sc, LmFrame fr, LmCamera cam, int cur, uint32_t seed2,
         if (__ballot(!s.flags && !lm_quick_contracts(s.mat)) != 0ull && lm_lane() == 0u) fr.counters[LM_CNT_RARE] = 1u;
         // lazy reuse: the previous frame left its history passes pending.  Pixels that were reuse surfaces then and are flagged now keep their reservoir entry
         // past this frame's candidate pick: listed for lm_k_reuse_counts (silhouette pixels under sub-pixel jitter; more when the camera moves)
-        if (fr.owedSet >= 0) {
-            const bool keeps = s.flags != 0u && fr.probe[fr.owedSet][li].w >= 0.f;
-            const uint32_t slot = lm_append_slot(fr.counters + LM_CNT_HAZARD, keeps);
-            if (keeps) fr.hazardList[slot] = li;
-        }
+        // (appended below, with the continuation rays: one atomic per block, not per wavefront — a camera cut can flag every pixel)
+        if (fr.owedSet >= 0) { keeps = s.flags != 0u && fr.probe[fr.owedSet][li].w >= 0.f; liKeeps = li; }
         // motion vector
         const uint32_t ly = li / fr.ww, lx = li - ly * fr.ww;
         const uint32_t px = fr.x0 + lx, py = fr.y0 + ly;
@@ -272,13 +290,15 @@ KN(lm_k_extract0)(LmScene sc, LmFrame fr, LmCamera cam, int cur, uint32_t seed2,
             emit = lm_shade_indirect(s, py * fr.W + px, seed2, bo, bd, bc);
         }
         }
-        if (doIndirect) {                                          // uniform per block
-            const uint32_t slot = lm_append_slot_block(outCount, emit, s_tmp);
+        if (doIndirect || fr.owedSet >= 0) {                       // uniform per block
+            uint32_t slot, slotKeeps;
+            lm_append_slot_block2(outCount, emit, slot, fr.counters + LM_CNT_HAZARD, keeps, slotKeeps, s_tmp);
             if (emit) {
                 fr.rayO[outQ][slot] = v4(bo, 0.f);
                 fr.rayD[outQ][slot] = v4(bd, u2f(liOut));
                 fr.rayC[outQ][slot] = v4(bc, 0.f);
             }
+            if (keeps) fr.hazardList[slotKeeps] = liKeeps;
         }
     }
 }
