@@ -170,7 +170,7 @@ int lumen_mi_set_instrumented(lumen_mi_renderer*, int enable);   /* use the node
  * ReSTIR.cpp:181-233 — are launched with the NEXT frame and run only if their result can still be read, i.e. when the reservoir swap chain has turned; if it has
  * not — every frame of an even path depth, WaveFrontRenderer.cpp:827 — only the sample counts of the entries that outlive the next candidate pick are
  * completed.  Images, counters and exported history counts equal those of launching the passes with their frame; 1 on, 0 off, -1 (default) automatic: on at
- * even path depths; DESIGN.md "Lazy reuse"), "fast_resample" (arithmetic mode of the ReSTIR passes, see
+ * even path depths; 2 = on WITHOUT the count completion, wrong on purpose, for the test that shows the completion is observable; DESIGN.md "Lazy reuse"), "fast_resample" (arithmetic mode of the ReSTIR passes, see
  * the only key that changes results, within the stated tolerance). */
 int lumen_mi_set_tuning(lumen_mi_renderer*, const char* key, int value);
 
