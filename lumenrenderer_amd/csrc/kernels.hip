@@ -577,7 +577,7 @@ KN(lm_k_restir_trace_shade)(LmScene sc, LmFrame fr, int rc, const uint32_t* __re
             float* weight = (float*)(hot + 4u * li + 1u);           // quad 1 = (weight, count, normal.xy): lm_restir.h (included below)
             if (occluded) {
                 // pass 2 with the frame's history passes pending (lazy reuse): the first spatial pass, which the reference runs BEFORE this one
-                // (ReSTIR.cpp:181-212), will read this weight later — park it in the two spare words of quad 0 (lm_spatial_weight)
+                // (ReSTIR.cpp:181-212), will read this weight later — park it in the two spare words of quad 0 (read back in lm_restir_spatial_body, `parked`)
                 if (pass == 2) { float* q0 = (float*)(hot + 4u * li); q0[2] = *weight; q0[3] = 1.f; }
                 *weight = 0.f;
             } else {
