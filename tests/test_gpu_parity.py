@@ -1117,6 +1117,64 @@ def test_history_passes_run_only_when_their_result_can_be_read(case):
         assert any(not np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(broken, eager))
 
 
+def test_pending_history_passes_survive_exports_toggles_and_skipped_frames():
+    """Lazy reuse, the bookkeeping around it: between two frames the history passes of the first may be pending.  Everything that can happen in that gap must
+    find them done or keep them owed: a history export (lumen_mi_export_history: the exported reservoirs are complete, every word, whenever the swap chain has
+    turned), the tuning key switched off and on again, a frame skipped because the scene has no light (WaveFrontRenderer.cpp:456-464), a resolution change
+    (ResizeBuffers drops the history, WaveFrontRenderer.cpp:1424-1540).  Two renderers get the same calls, one with lazy_reuse 1, one with 0."""
+    import torch
+    from lumenrenderer_amd.scenes import sponza_standin
+    d = sponza_standin()
+    W, H = 208, 120
+    lazy = product_from(d, W, H, 3, blend=False, tuning={"lazy_reuse": 1})
+    eager = product_from(d, W, H, 3, blend=False, tuning={"lazy_reuse": 0})
+    both = (lazy, eager)
+    c0 = d.camera
+
+    def frames(n, tag, k0=0):
+        for k in range(n):
+            for r in both:
+                r.SetCamera(*_orbit(c0, k0 + k))
+                assert r.TraceFrameAsync()
+        imgs = []
+        for r in both:
+            r.Synchronize(); imgs.append(r.GetRadiance().copy())
+        assert np.array_equal(imgs[0].view(np.uint32), imgs[1].view(np.uint32)), (tag, int(np.sum(imgs[0] != imgs[1])))
+
+    def history():
+        out = []
+        for r in both:
+            w, h = r.GetRadiance().shape[1], r.GetRadiance().shape[0]
+            buf = torch.zeros(w * h * 20, dtype=torch.float32, device="cuda")
+            r.ExportHistory((0, 0, w, h), buf.data_ptr()); r.Synchronize(); torch.cuda.synchronize()
+            out.append(buf.cpu().numpy().view(np.uint32).reshape(-1, 20))
+        return out
+
+    frames(3, "odd depth")
+    a, b = history()                                        # depth 3: the chain has turned, the export runs the pending passes first
+    assert np.array_equal(a, b), int(np.sum(np.any(a != b, axis=1)))
+    assert a[:, 5].max() > 32                               # (sample counts beyond one frame's 32 candidates: merged history)
+    ran = lazy.GetCounters(64)[54]
+    frames(2, "after the export", 3)
+    assert lazy.GetCounters(64)[54] == ran + 1              # the passes of the frame before the export ran once (in the export), those of the next frame in the frame after it
+    for r in both: r.SetDepth(4)
+    frames(3, "even depth", 5)
+    a, b = history()                                        # the chain has not turned: what is exported is the other buffer, untouched by the pending passes
+    assert np.array_equal(a, b)
+    lazy.SetTuning("lazy_reuse", 0); frames(2, "switched off", 8)
+    lazy.SetTuning("lazy_reuse", 1); frames(2, "switched on", 10)
+    for r in both: r.m_Scene.m_MeshInstances[1].SetEmissiveness(1, (0.0, 0.0, 0.0), 1.0)          # the only light DISABLED: the frame is skipped
+    for r in both: assert r.TraceFrame() is False
+    inst = d.instances[1]
+    for r in both: r.m_Scene.m_MeshInstances[1].SetEmissiveness(inst["emission_mode"], inst["override_radiance"], inst["scale"])
+    frames(3, "after the skipped frame", 12)
+    for r in both: r.SetDepth(5)
+    frames(2, "odd again", 15)
+    for r in both: r.SetRenderResolution(160, 96)
+    frames(3, "resized", 17)
+    for r in both: r.close()
+
+
 def test_counter_totals_sum_every_traceframe_on_the_device():
     """lumen_mi_get_counter_totals: the frame's last kernel adds its counter block to a 64-bit block on the device, so that a throughput
     measurement counts the rays of ALL the frames it timed without reading counters back in between (bench.py).  The sums must equal the
