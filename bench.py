@@ -411,6 +411,10 @@ def main():
                                          "test_fast_resampling_mode_stays_within_the_north_star_tolerance)") if fast else "exact: correctly rounded everywhere, bit-identical to the oracle",
                        "other_mode": None if other_pass is None else {"mode": "exact" if fast else "fast", "value": round(other_pass["value"], 3), "ms_per_step": round(other_pass["ms_per_step"], 4),
                                                                      "device_ms_per_traceframe": dev(other_pass["class_ms"])},
+                       "history_passes": ("eager: both spatial reuse passes and the reservoir combine are launched in every TraceFrame, as the reference launches them (tuning key lazy_reuse 0)"
+                                          if not lazy else "lazy (the renderer's default at even path depths): both spatial reuse passes and the reservoir combine run when their result can be read") +
+                                         "; they only build the next frame's history, which the reference's swap quirk never reads at an even path depth — images, counters and rays are identical "
+                                         "either way (test_history_passes_run_only_when_their_result_can_be_read), both rates are on this line: value_eager_reuse / value_lazy_reuse",
                        "triangles": desc.triangle_count(), "rays_per_frame": int(rays_per_frame), "ms_per_frame": round(ms_per_step, 4),
                        "tiles": f"{tiles.grid_for(world, W, H)[0]}x{tiles.grid_for(world, W, H)[1]} + {tiles.HALO}px halo" if world > 1 else "1x1",
                        "nodes4_per_ray": round(node_records / all_rays_inst, 2), "binary_node_equivalents_per_ray": round(ci[20] / all_rays_inst, 2), "tris_per_ray": round(ci[21] / all_rays_inst, 2),
