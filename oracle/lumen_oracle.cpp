@@ -510,10 +510,12 @@ static uint32_t build_lights(orc_ctx* c)
     return total;
 }
 
+// CalculateLightWeightsInCDF — ReSTIRKernels.cu:165-183 (also the sort key, TriangleLightComparator ReSTIRKernels.cuh:29-35)
+static inline float light_weight(const TriLight& l) { return (l.radiance.x + l.radiance.y + l.radiance.z) / 3.f; }
 // CDF — ReSTIRKernels.cu:49-130,165-190 (sort by mean radiance, weights, inclusive scan)  (D3)
 static void build_cdf(orc_ctx* c)
 {
-    auto key = [](const TriLight& l) { return (l.radiance.x + l.radiance.y + l.radiance.z) / 3.f; };
+    auto key = [](const TriLight& l) { return light_weight(l); };
     std::stable_sort(c->lights.begin(), c->lights.end(), [&](const TriLight& a, const TriLight& b) { return key(a) < key(b); });
     c->cdf.resize(c->lights.size());
     double acc = 0;
@@ -788,8 +790,19 @@ static inline void shade_reservoir(orc_ctx* c, const Reservoir& r, uint32_t outI
 
 static inline bool in_window(const orc_ctx* c, int x, int y) { return x >= (int)c->wx0 && x < (int)c->wx1 && y >= (int)c->wy0 && y < (int)c->wy1; }
 
+// Known-answer hooks (orc_kat_restir_frame below; rows of oracle/ref_kat/gen_kat5.cpp, the reference's own kernel bodies run thread by thread): the SAME
+// restir_run that renders, with the closed parts replaced by what the rows give — the light list arrives sorted with its prefix sums, occlusion comes from
+// a mask per visibility pass instead of the tracer — and with taps that copy out what each kernel left behind.  Single-threaded then: appends in pixel order.
+struct RestirHooks {
+    bool givenCdf = false;                                                  // lights + cdf are set by the caller: no sort, no scan
+    const uint8_t* occluded[2] = {nullptr, nullptr};                        // per pass, per pixel: is the visibility ray blocked?
+    std::vector<RestirShadowRay>* rays[2] = {nullptr, nullptr};             // the rays GenerateShadowRay appended, in order
+    std::vector<uint32_t>* shadeFrom[3] = {nullptr, nullptr, nullptr};      // per call site (after pick / temporal / after spatial): per pixel, 1 + the pixel whose reservoir was shaded into it
+    std::function<void(int)> tap;                                           // after kernel: 0 bags 1 pick 2 temporal 3 spatial-1 4 spatial-2 5 combine
+};
+
 // visibility pass: GenerateShadowRay (ReSTIRKernels.cu:546-582) + ReSTIRRayGen (WaveFrontShaders.cu:181-216), tmin 0.1 (ReSTIR.cpp:310)
-static uint64_t visibility_check(orc_ctx* c, std::vector<Reservoir>& res, const std::vector<Surface>& surf, const std::vector<uint32_t>& pixels)
+static uint64_t visibility_check(orc_ctx* c, std::vector<Reservoir>& res, const std::vector<Surface>& surf, const std::vector<uint32_t>& pixels, const RestirHooks* hooks = nullptr, int pass = 0)
 {
     std::atomic<uint64_t> count{0};
     c->pfor((uint32_t)pixels.size(), [&](uint32_t b, uint32_t e, int) {
@@ -804,15 +817,22 @@ static uint64_t visibility_check(orc_ctx* c, std::vector<Reservoir>& res, const 
             const float l = length(toLight);
             toLight /= l;
             local++;
-            if (any_hit(c, s.position, toLight, 0.1f, l - 0.05f, true)) r.weight = 0.f;
+            if (hooks && hooks->rays[pass]) hooks->rays[pass]->push_back(RestirShadowRay{s.position, toLight, l - 0.05f, i});
+            const bool blocked = (hooks && hooks->occluded[pass]) ? hooks->occluded[pass][i] != 0 : any_hit(c, s.position, toLight, 0.1f, l - 0.05f, true);
+            if (blocked) r.weight = 0.f;
         }
         count += local;
     });
     return count;
 }
 
-static void restir_run(orc_ctx* c, int cur, int prev, uint32_t a_Seed, const std::vector<uint32_t>& pixels)      // Framework/ReSTIR.cpp:65-233
+static void restir_run(orc_ctx* c, int cur, int prev, uint32_t a_Seed, const std::vector<uint32_t>& pixels, const RestirHooks* hooks = nullptr)      // Framework/ReSTIR.cpp:65-233
 {
+    auto tap = [&](int stage) { if (hooks && hooks->tap) hooks->tap(stage); };
+    auto shade = [&](int site, const Reservoir& r, uint32_t from, uint32_t to) {       // ShadeReservoirs (ReSTIRKernels.cu:619-665): reservoir of pixel `from` into pixel `to`
+        if (hooks && hooks->shadeFrom[site]) (*hooks->shadeFrom[site])[to] = from + 1u;
+        shade_reservoir(c, r, to);
+    };
     const uint32_t W = c->W;
     const std::vector<Surface>& curS = c->surface[cur];
     const std::vector<Surface>& prevS = c->surface[prev];
@@ -822,7 +842,7 @@ static void restir_run(orc_ctx* c, int cur, int prev, uint32_t a_Seed, const std
     uint32_t seed = wang_hash(a_Seed);
 
     orc_lap(nullptr);
-    build_cdf(c);                                                           // ReSTIR.cpp:125
+    if (!(hooks && hooks->givenCdf)) build_cdf(c);                          // ReSTIR.cpp:125
     // FillLightBags — ReSTIRKernels.cu:343-370 (seed = a_Seed, ReSTIR.cpp:135-141)
     const uint32_t nBags = 50, perBag = 1000;
     c->bags.resize(nBags * perBag);
@@ -836,6 +856,7 @@ static void restir_run(orc_ctx* c, int cur, int prev, uint32_t a_Seed, const std
         }
     });
     orc_lap("restir cdf+bags");
+    tap(0);
     // PickPrimarySamples — ReSTIRKernels.cu:402-522
     seed = wang_hash(seed);
     {
@@ -874,8 +895,9 @@ static void restir_run(orc_ctx* c, int cur, int prev, uint32_t a_Seed, const std
         });
     }
     orc_lap("restir pick");
-    c->stats[2] += visibility_check(c, RC, curS, pixels);                   // ReSTIR.cpp:161
-    c->pfor((uint32_t)pixels.size(), [&](uint32_t b, uint32_t e, int) { for (uint32_t k = b; k < e; k++) shade_reservoir(c, RC[pixels[k]], pixels[k]); });   // ReSTIR.cpp:162 (ShadeInternal :600-616)
+    tap(1);
+    c->stats[2] += visibility_check(c, RC, curS, pixels, hooks, 0);         // ReSTIR.cpp:161
+    c->pfor((uint32_t)pixels.size(), [&](uint32_t b, uint32_t e, int) { for (uint32_t k = b; k < e; k++) shade(0, RC[pixels[k]], pixels[k], pixels[k]); });   // ReSTIR.cpp:162 (ShadeInternal :600-616)
 
     orc_lap("restir vis1+shade");
     // Temporal — ReSTIRKernels.cu:1015-1121
@@ -899,7 +921,7 @@ static void restir_run(orc_ctx* c, int cur, int prev, uint32_t a_Seed, const std
                     const float depthDif = fabsf(d1 - d2) / ((d1 + d2) / 2.f);
                     const float angle = dot(p0.normal, p1.normal);
                     if (depthDif < 0.10f && angle > 0.72222222223f) {
-                        shade_reservoir(c, RT[tIndex], index);              // shades the *previous* reservoir into this pixel
+                        shade(1, RT[tIndex], tIndex, index);                // shades the *previous* reservoir into this pixel
                         toCombine[0].sampleCount = std::min(toCombine[0].sampleCount, toCombine[1].sampleCount * 20);
                         combine_biased(RC[index], 2, toCombine, p1, wang_hash(s0 + index));
                     }
@@ -907,6 +929,7 @@ static void restir_run(orc_ctx* c, int cur, int prev, uint32_t a_Seed, const std
             }
         });
     }
+    tap(2);
     // Spatial — ReSTIRKernels.cu:745-980 (two ping-pong iterations; returns buffers[3])
     seed = wang_hash(seed);
     {
@@ -952,12 +975,13 @@ static void restir_run(orc_ctx* c, int cur, int prev, uint32_t a_Seed, const std
                     } else res_reset(Out[index]);
                 }
             });
+            tap(3 + it);
             if (it == 0) { from = &c->reservoirs[2]; to = &c->reservoirs[3]; } else std::swap(from, to);
         }
         std::vector<Reservoir>& neighbour = *from;                           // == reservoirs[3]
         orc_lap("restir temporal+spatial");
-        c->stats[2] += visibility_check(c, RC, curS, pixels);               // ReSTIR.cpp:211 (on the CURRENT buffer, quirk 7)
-        c->pfor((uint32_t)pixels.size(), [&](uint32_t b, uint32_t e, int) { for (uint32_t k = b; k < e; k++) shade_reservoir(c, RC[pixels[k]], pixels[k]); });   // ReSTIR.cpp:212
+        c->stats[2] += visibility_check(c, RC, curS, pixels, hooks, 1);     // ReSTIR.cpp:211 (on the CURRENT buffer, quirk 7)
+        c->pfor((uint32_t)pixels.size(), [&](uint32_t b, uint32_t e, int) { for (uint32_t k = b; k < e; k++) shade(2, RC[pixels[k]], pixels[k], pixels[k]); });   // ReSTIR.cpp:212
         orc_lap("restir vis2+shade");
         // CombineReservoirBuffers — ReSTIRKernels.cu:1407-1436, seed WangHash(seed) (ReSTIR.cpp:220)
         const uint32_t s1 = wang_hash(seed);
@@ -970,6 +994,7 @@ static void restir_run(orc_ctx* c, int cur, int prev, uint32_t a_Seed, const std
                 combine_biased(RC[i], 2, two, sf, wang_hash(s1 + i));
             }
         });
+        tap(5);
     }
 }
 
@@ -1495,6 +1520,133 @@ uint32_t orc_lights(orc_ctx* c, float* out, float* cdf)
 }
 // denoiser / upscaler inputs of the last frame — CUDAKernels/WaveFrontKernels/GPUExtractNRD_DLSSdata.cu:6-89 (normalised depth,
 // half4 normal + roughness), GPUExtractDepthData.cu:6-72, motion vectors as stored (half2, MotionVectors.cu:8-55)
+// ---- known-answer entry points for the kernel bodies (tests/golden/ref_kat5.npz, generator oracle/ref_kat/gen_kat5.cpp).  Every array is 32-bit words as the
+// rows store them: floats by bit pattern, flags / counts / indices as integers.
+static inline float wf(uint32_t w) { float f; memcpy(&f, &w, 4); return f; }
+static inline uint32_t fw(float f) { uint32_t w; memcpy(&w, &f, 4); return w; }
+static Surface surface_from40(const uint32_t* w, uint32_t px, uint32_t py)
+{
+    Surface s; memset(&s, 0, sizeof s);
+    s.px = (uint16_t)px; s.py = (uint16_t)py;
+    s.flags = (uint8_t)w[0]; s.t = wf(w[1]);
+    s.position = mk3(wf(w[2]), wf(w[3]), wf(w[4])); s.normal = mk3(wf(w[5]), wf(w[6]), wf(w[7])); s.tangent = mk3(wf(w[8]), wf(w[9]), wf(w[10]));
+    s.incoming = mk3(wf(w[11]), wf(w[12]), wf(w[13])); s.transport = mk3(wf(w[14]), wf(w[15]), wf(w[16]));
+    float m[23]; for (int i = 0; i < 23; i++) m[i] = wf(w[17 + i]);
+    if (s.flags == 0) s.mat = material_from23(m);
+    else s.mat.color = f4{m[0], m[1], m[2], m[3]};                              // an emitter seen directly carries its colour (GPUExtractSurfaceData.cu:120-136); nothing else is read of a flagged surface
+    return s;
+}
+static TriLight light_from16(const uint32_t* w)
+{
+    TriLight l; l.p0 = mk3(wf(w[0]), wf(w[1]), wf(w[2])); l.p1 = mk3(wf(w[3]), wf(w[4]), wf(w[5])); l.p2 = mk3(wf(w[6]), wf(w[7]), wf(w[8]));
+    l.normal = mk3(wf(w[9]), wf(w[10]), wf(w[11])); l.radiance = mk3(wf(w[12]), wf(w[13]), wf(w[14])); l.area = wf(w[15]); return l;
+}
+static Reservoir reservoir_from17w(const uint32_t* w)
+{
+    Reservoir r; r.weightSum = wf(w[0]); r.sampleCount = (long long)w[1]; r.weight = wf(w[2]);
+    LightSample& l = r.sample;
+    l.radiance = mk3(wf(w[3]), wf(w[4]), wf(w[5])); l.normal = mk3(wf(w[6]), wf(w[7]), wf(w[8])); l.position = mk3(wf(w[9]), wf(w[10]), wf(w[11])); l.area = wf(w[12]);
+    l.contribution = mk3(wf(w[13]), wf(w[14]), wf(w[15])); l.solidAnglePdf = wf(w[16]); return r;
+}
+static void reservoir_to17w(const Reservoir& r, uint32_t* w)
+{
+    const LightSample& l = r.sample;
+    const float f[17] = {r.weightSum, 0.f, r.weight, l.radiance.x, l.radiance.y, l.radiance.z, l.normal.x, l.normal.y, l.normal.z, l.position.x, l.position.y, l.position.z, l.area,
+                         l.contribution.x, l.contribution.y, l.contribution.z, l.solidAnglePdf};
+    for (int i = 0; i < 17; i++) w[i] = fw(f[i]);
+    w[1] = (uint32_t)r.sampleCount;
+}
+static void kat_scene(orc_ctx& c, uint32_t W, uint32_t H, uint32_t nLights, const uint32_t* lights16, const uint32_t* cdf)
+{
+    c.W = W; c.H = H; c.wx0 = 0; c.wy0 = 0; c.wx1 = W; c.wy1 = H; c.windowSet = true; c.threads = 1;
+    c.lights.resize(nLights); c.cdf.resize(nLights);
+    for (uint32_t i = 0; i < nLights; i++) { c.lights[i] = light_from16(lights16 + 16u * i); c.cdf[i] = wf(cdf[i]); }
+    c.cdfSum = nLights ? c.cdf.back() : 0.f;                                     // CDF::SetCDFSize (ReSTIRData.h:209-216)
+}
+void orc_kat_light_weights(uint32_t n, const uint32_t* lights16, uint32_t* out) { for (uint32_t i = 0; i < n; i++) out[i] = fw(light_weight(light_from16(lights16 + 16u * i))); }
+void orc_kat_primary_rays(uint32_t W, uint32_t H, uint32_t frameCount, const uint32_t* camUVWeye12, uint32_t* out11)
+{
+    orc_ctx c; c.W = W; c.H = H;
+    const uint32_t* k = camUVWeye12;
+    const f3 U = mk3(wf(k[0]), wf(k[1]), wf(k[2])), V = mk3(wf(k[3]), wf(k[4]), wf(k[5])), Wv = mk3(wf(k[6]), wf(k[7]), wf(k[8])), eye = mk3(wf(k[9]), wf(k[10]), wf(k[11]));
+    for (uint32_t i = 0; i < W * H; i++) {
+        const Ray r = primary_ray(&c, i, U, V, Wv, eye, frameCount);
+        uint32_t* o = out11 + 11u * i;
+        o[0] = r.px; o[1] = r.py;
+        const float f[9] = {r.origin.x, r.origin.y, r.origin.z, r.dir.x, r.dir.y, r.dir.z, r.contribution.x, r.contribution.y, r.contribution.z};
+        for (int j = 0; j < 9; j++) o[2 + j] = fw(f[j]);
+    }
+}
+/* rows: (x, y, seed, surface(40)); out 12 words per row: emitted, origin, direction, maxDistance, radiance, channel (ShadeDirect) — or 10: emitted, origin, direction, contribution (ShadeIndirect) */
+void orc_kat_shade(uint32_t n, uint32_t W, uint32_t H, const uint32_t* rows43, uint32_t nLights, const uint32_t* lights16, const uint32_t* cdf, uint32_t* direct12, uint32_t* indirect10)
+{
+    orc_ctx c; kat_scene(c, W, H, nLights, lights16, cdf);
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t* w = rows43 + 43u * i;
+        const uint32_t px = w[0], py = w[1], seed = w[2], pixelIndex = py * W + px;
+        const Surface s = surface_from40(w + 3, px, py);
+        if (direct12) {
+            uint32_t* o = direct12 + 12u * i; for (int j = 0; j < 12; j++) o[j] = 0u;
+            ShadowRay sr;
+            if (shade_direct(&c, s, pixelIndex, px, py, seed, sr)) {
+                const float f[10] = {sr.origin.x, sr.origin.y, sr.origin.z, sr.dir.x, sr.dir.y, sr.dir.z, sr.maxDist, sr.radiance.x, sr.radiance.y, sr.radiance.z};
+                o[0] = 1u; for (int j = 0; j < 10; j++) o[1 + j] = fw(f[j]); o[11] = sr.channel;
+            }
+        }
+        if (indirect10) {
+            uint32_t* o = indirect10 + 10u * i; for (int j = 0; j < 10; j++) o[j] = 0u;
+            Ray r;
+            if (shade_indirect(s, pixelIndex, px, py, seed, r)) {
+                const float f[9] = {r.origin.x, r.origin.y, r.origin.z, r.dir.x, r.dir.y, r.dir.z, r.contribution.x, r.contribution.y, r.contribution.z};
+                o[0] = 1u; for (int j = 0; j < 9; j++) o[1 + j] = fw(f[j]);
+            }
+        }
+    }
+}
+/* One ReSTIR::Run (Framework/ReSTIR.cpp:65-233) on explicit arrays.  surfPrev40 NULL = the zero-filled buffer of the first frame.  res4: [4][n][17] in / out (the
+ * reference's four reservoir buffers).  stages: [5][n][17] = the buffer each kernel wrote, right after it: pick, temporal, spatial-1, spatial-2, combine.
+ * rays: [2][n][8] (index, origin, direction, distance) in append order, counts in rayCounts[2].  shadeFrom: [3][n], 1 + source pixel of the ShadeReservoirs call
+ * into the pixel at each call site (0 = no call).  direct: [n][4], the DIRECT channel after the frame (fp32 accumulation, D1).  bags: [50000][2] (light index, pdf). */
+void orc_kat_restir_frame(uint32_t W, uint32_t H, const uint32_t* surfCur40, const uint32_t* surfPrev40, const uint32_t* motionHalf2, uint32_t nLights, const uint32_t* lights16,
+                          const uint32_t* cdf, uint32_t a_Seed, int currentIndex, const uint8_t* occ0, const uint8_t* occ1, uint32_t* res4, uint32_t* bags, uint32_t* stages,
+                          uint32_t* rays, uint32_t* rayCounts, uint32_t* shadeFrom, uint32_t* direct)
+{
+    orc_ctx c; kat_scene(c, W, H, nLights, lights16, cdf);
+    c.resize();
+    const uint32_t n = W * H;
+    for (uint32_t i = 0; i < n; i++) {
+        c.surface[0][i] = surface_from40(surfCur40 + 40u * i, i % W, i / W);
+        if (surfPrev40) c.surface[1][i] = surface_from40(surfPrev40 + 40u * i, i % W, i / W);
+        c.motion[i] = f2{f16_to_f32((uint16_t)motionHalf2[2u * i]), f16_to_f32((uint16_t)motionHalf2[2u * i + 1u])};
+        for (int b = 0; b < 4; b++) c.reservoirs[b][i] = reservoir_from17w(res4 + ((size_t)b * n + i) * 17u);
+    }
+    c.swapChainIndex = currentIndex;
+    std::vector<uint32_t> pixels(n); for (uint32_t i = 0; i < n; i++) pixels[i] = i;
+    std::vector<RestirShadowRay> r0, r1; std::vector<uint32_t> sf[3] = {std::vector<uint32_t>(n, 0u), std::vector<uint32_t>(n, 0u), std::vector<uint32_t>(n, 0u)};
+    RestirHooks hooks; hooks.givenCdf = true; hooks.occluded[0] = occ0; hooks.occluded[1] = occ1; hooks.rays[0] = &r0; hooks.rays[1] = &r1;
+    for (int k = 0; k < 3; k++) hooks.shadeFrom[k] = &sf[k];
+    hooks.tap = [&](int stage) {
+        if (stage == 0) { if (bags) for (uint32_t i = 0; i < 50000u; i++) {
+            uint32_t li = 0; while (li < nLights && memcmp(&c.lights[li], &c.bags[i].light, sizeof(TriLight)) != 0) ++li;
+            bags[2u * i] = li; bags[2u * i + 1u] = fw(c.bags[i].pdf); } return; }
+        const int buf = stage == 3 ? 2 : stage == 4 ? 3 : currentIndex;
+        for (uint32_t i = 0; i < n; i++) reservoir_to17w(c.reservoirs[buf][i], stages + ((size_t)(stage - 1) * n + i) * 17u);
+    };
+    restir_run(&c, 0, 1, a_Seed, pixels, &hooks);
+    for (uint32_t i = 0; i < n; i++) for (int b = 0; b < 4; b++) reservoir_to17w(c.reservoirs[b][i], res4 + ((size_t)b * n + i) * 17u);
+    for (int p = 0; p < 2; p++) {
+        const std::vector<RestirShadowRay>& rr = p ? r1 : r0;
+        rayCounts[p] = (uint32_t)rr.size();
+        for (size_t k = 0; k < rr.size(); k++) {
+            uint32_t* o = rays + ((size_t)p * n + k) * 8u;
+            const float f[7] = {rr[k].origin.x, rr[k].origin.y, rr[k].origin.z, rr[k].dir.x, rr[k].dir.y, rr[k].dir.z, rr[k].distance};
+            o[0] = rr[k].index; for (int j = 0; j < 7; j++) o[1 + j] = fw(f[j]);
+        }
+    }
+    for (int k = 0; k < 3; k++) memcpy(shadeFrom + (size_t)k * n, sf[k].data(), n * sizeof(uint32_t));
+    for (uint32_t i = 0; i < n; i++) { const f4 d = c.channel[0][i]; direct[4u * i] = fw(d.x); direct[4u * i + 1u] = fw(d.y); direct[4u * i + 2u] = fw(d.z); direct[4u * i + 3u] = fw(d.w); }
+}
+
 void orc_get_denoiser_inputs(orc_ctx* c, float minD, float maxD, float* depth, uint16_t* normalRoughness, uint16_t* motion)
 {
     const int last = c->frameIndex == 0 ? 1 : 0;

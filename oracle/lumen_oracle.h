@@ -93,6 +93,20 @@ void  orc_make_color(uint32_t n, const float* rgb, uint8_t* rgba);
 uint16_t orc_f32_to_f16(float);
 float orc_f16_to_f32(uint16_t);
 
+/* Known-answer entry points for the reference's KERNEL BODIES (rows of tests/golden/ref_kat5.npz; generator oracle/ref_kat/gen_kat5.cpp runs the reference's own
+ * __global__ text thread by thread).  Arrays are 32-bit words as the rows store them: floats by bit pattern; flags, counts and indices as integers.
+ * surface(40) = flags t position normal tangent incoming transport mat23;  reservoir(17) = weightSum sampleCount weight + sample(14);  light(16) = p0 p1 p2 normal radiance area. */
+void orc_kat_light_weights(uint32_t n, const uint32_t* lights16, uint32_t* out);                                        /* CalculateLightWeightsInCDF ReSTIRKernels.cu:165-183 */
+void orc_kat_primary_rays(uint32_t W, uint32_t H, uint32_t frameCount, const uint32_t* camUVWeye12, uint32_t* out11);  /* GeneratePrimaryRay GPUGeneratePrimRay.cu:28-82: x y origin dir contribution */
+/* ShadeDirect GPUShadeDirect.cu:42-153 / ShadeIndirect GPUShadeIndirect.cu:7-146 on rows (x, y, seed, surface(40)); either output may be NULL.
+ * direct12 = emitted origin direction maxDistance radiance channel; indirect10 = emitted origin direction contribution */
+void orc_kat_shade(uint32_t n, uint32_t W, uint32_t H, const uint32_t* rows43, uint32_t nLights, const uint32_t* lights16, const uint32_t* cdf, uint32_t* direct12, uint32_t* indirect10);
+/* one ReSTIR::Run (Framework/ReSTIR.cpp:65-233; kernels ReSTIRKernels.cu:343-370,402-522,546-582,600-616,787-980,1015-1121,1407-1436) through the same restir_run that
+ * renders, the visibility programs replaced by an occlusion mask per pass; see lumen_oracle.cpp for the array shapes */
+void orc_kat_restir_frame(uint32_t W, uint32_t H, const uint32_t* surfCur40, const uint32_t* surfPrev40, const uint32_t* motionHalf2, uint32_t nLights, const uint32_t* lights16,
+                          const uint32_t* cdf, uint32_t a_Seed, int currentIndex, const uint8_t* occ0, const uint8_t* occ1, uint32_t* res4, uint32_t* bags, uint32_t* stages,
+                          uint32_t* rays, uint32_t* rayCounts, uint32_t* shadeFrom, uint32_t* direct);
+
 /* ray-query seam (OptixWrapper::TraceRays): n rays (origin3, dir3) -> hits (instance, prim, u, v, t) */
 void  orc_trace_closest(orc_ctx*, uint32_t n, const float* origins, const float* dirs, float tmin, float tmax,
                         uint32_t* inst_prim, float* uvt, int use_bvh);

@@ -138,6 +138,15 @@ static Reservoir randres(const WaveFront::SurfaceData& at, int kind)
     return r;
 }
 static void printres(const Reservoir& r) { printf(" %.9g %lld %.9g", r.weightSum, r.sampleCount, r.weight); printsample(r.sample); }
+// The merge functions build their result in a local `Reservoir output;` whose LightSample constructor (ReSTIRData.h:97) initialises every member EXCEPT
+// unshadowedPathContribution.  When no Update() takes a sample (every resampling weight is 0) that member leaves the function as whatever the stack held —
+// pointers under ASLR, so not even this generator reproduces it.  Such a result is recognisable: area is still the constructor's 0 while every generated
+// light has area >= 0.001.  Its three contribution cells are printed as 0 (the value this build's zero-initialised reservoirs hold, decision D5).
+static Reservoir settled(Reservoir r)
+{
+    if (r.sample.area == 0.f) r.sample.unshadowedPathContribution = make_float3(0.f, 0.f, 0.f);
+    return r;
+}
 
 int main()
 {
@@ -158,7 +167,7 @@ int main()
         CombineBiased(&out, count, rs, &s.sd, seed);
         printf("cmbb%d", count); printsurf(s); printf(" %d %u", count, seed);
         for (int k = 0; k < count; k++) printres(rs[k]);
-        printres(out); printf("\n");
+        printres(settled(out)); printf("\n");
     }
     for (int i = 0; i < 600; i++) {
         const Surf s = randsurf(i);
@@ -174,7 +183,7 @@ int main()
         CombineUnbiased(&out, &s.sd, count, rs, sds, seed);
         printf("cmbu%d", count); printsurf(s); printf(" %d %u", count, seed);
         for (int k = 0; k < count; k++) { printres(rs[k]); printsurf(ss[k]); }
-        printres(out); printf("\n");
+        printres(settled(out)); printf("\n");
     }
     for (unsigned i = 0; i < 10000; i++) {
         const unsigned idx = i < 9000 ? i : (i < 9990 ? rng() : 0xffffffffu - (i - 9990));    // 0xffffffff wraps to 0 after the ++index

@@ -45,6 +45,48 @@ subprocess.check_call(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-D_GNU_
 for line in subprocess.check_output([exe], text=True).splitlines():
     tag, *vals = line.split()
     rows.setdefault(tag, []).append([float(v) for v in vals])
+# fifth unit: the __global__ kernel bodies themselves (gen_kat5.cpp: one call per thread, blocks in order), into their own file as uint32
+K = f"{R}/src/CUDAKernels"
+def slice_to(path, first, last, name, edit=None):
+    with open(path, encoding="latin-1") as f:
+        text = "".join(f.readlines()[first - 1:last])
+    if edit:
+        text = edit(text)
+    with open(f"/tmp/lumen_k5_{name}.inc", "w", encoding="latin-1") as f:
+        f.write(text + "\n")
+def d2(text):      # decision D2: the light bag is keyed on the pixel's tile instead of the hardware SM id (the only edit made to reference text)
+    assert text.count("__mysmid()") == 1
+    return text.replace("__mysmid()", "lumen_kat_d2_key(index)")
+slice_to(f"{K}/ReSTIRKernels.cuh", 17, 18, "macros")
+slice_to(f"{K}/ReSTIRKernels.cuh", 29, 35, "comparator")
+slice_to(f"{R}/src/Shaders/CppCommon/WaveFrontDataStructs.h", 13, 13, "pdi")
+for first, last, name, edit in ((165, 183, "cdfw", None), (343, 370, "bags", None), (402, 522, "pick", d2), (546, 582, "genray", None), (600, 617, "shade", None),
+                                (787, 980, "spatial", None), (1015, 1121, "temporal", None), (1123, 1325, "restir_fns", None), (1407, 1436, "combine", None)):
+    slice_to(f"{K}/ReSTIRKernels.cu", first, last, name, edit)
+slice_to(f"{K}/WaveFrontKernels/GPUGeneratePrimRay.cu", 8, 82, "primray")
+slice_to(f"{K}/WaveFrontKernels/GPUShadeDirect.cu", 42, 153, "shadedirect")
+slice_to(f"{K}/WaveFrontKernels/GPUShadeIndirect.cu", 7, 146, "shadeindirect")
+os.makedirs("/tmp/lumen_k5_inc", exist_ok=True)      # IntersectionData.h spells the vendored header "Cuda_fp16.h" (a case-insensitive file system): same file, that name
+if not os.path.exists("/tmp/lumen_k5_inc/Cuda_fp16.h"):
+    os.symlink(f"{R}/vendor/Include/Cuda/cuda_fp16.h", "/tmp/lumen_k5_inc/Cuda_fp16.h")
+exe = "/tmp/lumen_gen_kat5"
+# Compiled with clang++ (the host C++ compiler of the ROCm toolchain), not g++: ShadeIndirect hands SampleBSDF three RandomFloat(seed) calls as ARGUMENTS
+# (GPUShadeIndirect.cu:88-101), and C++ leaves their order open.  clang evaluates arguments left to right, as the EDG front end of nvcc does for the device code the
+# reference ships; g++ evaluates right to left and would swap r0 and r2.  (Decision D7 in DESIGN.md; every other row of this unit is the same under both compilers.)
+subprocess.check_call(["/opt/rocm/lib/llvm/bin/clang++", "-std=c++17", "-O1", "-ffp-contract=off", "-Wno-c++11-narrowing", "-D_GNU_SOURCE", "-DNDEBUG", "-w", "-DGLM_ENABLE_EXPERIMENTAL",
+                       "-I/tmp/lumen_k5_inc", f"-I{R}/vendor/Include", f"-I{R}/vendor/Include/Cuda", f"-I{R}/src", f"-I{L}/vendor/glm", f"-I{R}/vendor/openvdb/nanovdb",
+                       os.path.join(here, "gen_kat5.cpp"), "-o", exe])
+rows5 = {}
+for line in subprocess.check_output([exe], text=True).splitlines():
+    tag, *vals = line.split()
+    rows5.setdefault(tag, []).append([int(v) for v in vals])
+out5 = {k: np.asarray(v, dtype=np.int64) for k, v in rows5.items()}
+for k, v in out5.items():
+    assert v.min() >= -(1 << 31) and v.max() < (1 << 32), k
+out5 = {k: (v.astype(np.uint32) if v.min() >= 0 else v.astype(np.int64)) for k, v in out5.items()}
+dst5 = os.path.join(here, "..", "..", "tests", "golden", "ref_kat5.npz")
+np.savez_compressed(dst5, **out5)
+print({k: v.shape for k, v in out5.items()}, "->", os.path.normpath(dst5), os.path.getsize(dst5), "bytes")
 out = {k: np.asarray(v, dtype=np.float64) for k, v in rows.items()}
 dst = os.path.join(here, "..", "..", "tests", "golden", "ref_kat.npz")
 np.savez_compressed(dst, **out)

@@ -226,6 +226,16 @@ def _close(got, ref, tol):
     return np.nan_to_num(err, nan=1.0)
 
 
+def _strict(got, ref):
+    """relative agreement WITHOUT a floor, zeros matching zeros exactly (round 4: the generator prints the cells the reference leaves indeterminate — the
+    contribution of a merge result that never took a sample — as 0, so no column needs masking any more)"""
+    got = got.astype(np.float64)
+    both_nan = np.isnan(got) & np.isnan(ref)
+    assert np.array_equal((got == 0) | both_nan, (ref == 0) | both_nan)
+    err = np.where(both_nan | (ref == 0), 0.0, np.abs(got - ref) / np.where(ref == 0, 1.0, np.abs(ref)))
+    return np.nan_to_num(err, nan=1.0, posinf=1.0)
+
+
 def resample_rows():
     g = GOLD["rsmp"]
     return f32(g[:, :35]), f32(g[:, 35:49]), g[:, 49:53]
@@ -266,8 +276,8 @@ def test_combine_biased_matches_the_reference_function(count):
     assert np.array_equal(out[:, 1], ref[:, 1].astype(np.float32))                        # sample counts: exact
     # which input sample is held (identified by its light position, copied verbatim by Resample): same choice in every row
     assert np.array_equal(out[:, 9:13], ref[:, 9:13].astype(np.float32))
-    err = _close(out, ref, 0).max(axis=1)
-    assert err.max() < 5e-5, (err.max(), int(err.argmax()))
+    err = _strict(out, ref).max(axis=1)
+    assert err.max() < 5e-7, (err.max(), int(err.argmax()))
     assert (ref[:, 2] == 0).sum() > (10 if count == 2 else 0) and (ref[:, 2] > 0).sum() > n // 3               # both the empty and the weighted outcome occur
 
 
@@ -284,5 +294,127 @@ def test_combine_unbiased_matches_the_reference_function(count):
     assert np.array_equal(out[:, 9:13], ref[:, 9:13].astype(np.float32))
     fin = np.isfinite(ref).all(axis=1)                                                   # correction 0 => weight = weightSum / epsilon^2 may overflow: same on both sides
     assert np.array_equal(np.isfinite(out).all(axis=1), fin)
-    err = _close(out[fin], ref[fin], 0).max(axis=1)
-    assert err.max() < 5e-5, (err.max(), int(err.argmax()))
+    err = _strict(out[fin], ref[fin]).max(axis=1)
+    assert err.max() < 5e-7, (err.max(), int(err.argmax()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Kernel bodies: the reference's own __global__ text run thread by thread (tests/golden/ref_kat5.npz, generator oracle/ref_kat/gen_kat5.cpp).
+# The oracle functions under test are the ones that render: orc_kat_restir_frame drives the same restir_run as orc_trace_frame, orc_kat_shade
+# the same shade_direct / shade_indirect, orc_kat_primary_rays the same primary_ray.
+# ---------------------------------------------------------------------------------------------------------------------
+import kat5
+from oracle_lib import u8ptr
+
+KAT5_FLOAT_TOL = 2e-6      # the oracle's fixed transcendentals vs the host libm behind the reference rows: a few ulp, never a decision
+
+
+def _run_restir_frame(f):
+    L = lib(); lt, cdf, _ = kat5.lights()
+    fr = kat5.frame(f); res4 = kat5.reservoirs_before(f).copy()
+    prev = kat5.frame(f - 1)["surf"] if f else None
+    out = {"bags": np.zeros((50000, 2), np.uint32), "stages": np.zeros((5, kat5.N, 17), np.uint32), "rays": np.zeros((2, kat5.N, 8), np.uint32),
+           "ray_counts": np.zeros(2, np.uint32), "shade_from": np.zeros((3, kat5.N), np.uint32), "direct": np.zeros((kat5.N, 4), np.uint32)}
+    L.orc_kat_restir_frame(kat5.W, kat5.H, u32ptr(fr["surf"]), u32ptr(prev) if prev is not None else None, u32ptr(fr["motion"]), len(lt), u32ptr(lt), u32ptr(cdf),
+                           fr["seed"], fr["current"], u8ptr(fr["occ"][0]), u8ptr(fr["occ"][1]), u32ptr(res4), u32ptr(out["bags"]), u32ptr(out["stages"]),
+                           u32ptr(out["rays"]), u32ptr(out["ray_counts"]), u32ptr(out["shade_from"]), u32ptr(out["direct"]))
+    out["res4"] = res4
+    return fr, out
+
+
+def assert_reservoirs_match(got, ref, what, tol=KAT5_FLOAT_TOL):
+    """got / ref: [N][17] words.  Discrete parts exactly: the sample count, and WHICH light point is held — radiance, normal, position, area are copied verbatim from
+    the light list through every Resample.  Floats that went through arithmetic (weightSum, weight, contribution, solidAnglePdf) within `tol` relative."""
+    assert np.array_equal(got[:, 1], ref[:, 1]), f"{what}: sample counts"
+    held = (got[:, 3:13] == ref[:, 3:13]).all(axis=1)
+    assert held.all(), f"{what}: {int((~held).sum())} pixels hold a different sample, first {int(np.flatnonzero(~held)[0])}"
+    cols = [0, 2, 13, 14, 15, 16]
+    a = kat5.as_f32(got)[:, cols].astype(np.float64); b = kat5.as_f32(ref)[:, cols].astype(np.float64)
+    assert np.array_equal(a == 0, b == 0), f"{what}: zero pattern (occluded / empty reservoirs)"
+    err = np.abs(a - b) / np.maximum(np.abs(b), 1e-30)
+    assert err.max() <= tol, f"{what}: max rel err {err.max():.3g} at pixel {int(err.max(axis=1).argmax())}"
+
+
+def test_kernel_rows_are_not_vacuous():
+    fr = [kat5.frame(f) for f in range(kat5.FRAMES)]
+    flags = fr[0]["surf"][:, 0]
+    assert {int(v) for v in np.unique(flags)} == {0, 1, 2, 4}                               # shaded, emitter, alpha cut-out, miss
+    for f in range(kat5.FRAMES):
+        w = kat5.as_f32(fr[f]["stages"][:, :, 2])
+        assert (w[0] > 0).sum() > 2000 and (w[2] > 0).sum() > 300 and (w[3] > 0).sum() > 150 and (w[4] > 0).sum() > 1000
+        assert len(fr[f]["rays"][0]) > 2000 and len(fr[f]["rays"][1]) > 1500
+    assert (fr[0]["shade_from"][1] != 0).sum() == 0                                          # first frame: the previous surface buffer is zero-filled, nothing is similar
+    moved = fr[2]["shade_from"][1]; to = np.flatnonzero(moved)
+    assert len(to) > 1500 and (moved[to] - 1 != to).sum() > 200                              # live history, fetched through non-zero motion vectors
+    assert fr[2]["stages"][4][:, 1].max() > 640                                              # counts grow over frames (and past the 20x clamp's first bite)
+
+
+def test_light_weights_match_the_reference_kernel():
+    L = lib(); lt, _, cdfw = kat5.lights()
+    out = np.zeros(len(lt), np.uint32)
+    L.orc_kat_light_weights(len(lt), u32ptr(lt), u32ptr(out))
+    assert np.array_equal(out, cdfw)
+
+
+def test_primary_rays_match_the_reference_kernel_bit_for_bit():
+    L = lib(); cam, prim = kat5.primary()
+    counts = np.unique(prim[:, 1])
+    assert len(counts) == 4 and counts.max() > 0xfffffff0 - 1                                # incl. frameCount + i wrapping past 2^32
+    for fc in counts:
+        rows = prim[prim[:, 1] == fc]
+        out = np.zeros((kat5.N, 11), np.uint32)
+        L.orc_kat_primary_rays(kat5.W, kat5.H, int(fc), u32ptr(cam), u32ptr(out))
+        assert np.array_equal(out, rows[:, 2:].astype(np.uint32)), int(fc)
+
+
+def test_shade_direct_matches_the_reference_kernel():
+    L = lib(); lt, cdf, _ = kat5.lights()
+    rin, ref = kat5.shade_rows("sdir"); n = len(rin)
+    out = np.zeros((n, 12), np.uint32)
+    L.orc_kat_shade(n, kat5.W, kat5.H, u32ptr(rin), len(lt), u32ptr(lt), u32ptr(cdf), u32ptr(out), None)
+    assert np.array_equal(out[:, 0], ref[:, 0]) and 0.5 < ref[:, 0].mean() < 0.95             # the same pixels emit a shadow ray (every early-out decides alike)
+    assert np.array_equal(out[:, 11], ref[:, 11]) and set(np.unique(ref[ref[:, 0] == 1][:, 11])) == {1}     # LightChannel::INDIRECT
+    em = ref[:, 0] == 1
+    assert np.array_equal(out[em][:, 1:8], ref[em][:, 1:8])                                  # origin, direction, max distance: no transcendental on the way
+    a = kat5.as_f32(out[em][:, 8:11]).astype(np.float64); b = kat5.as_f32(ref[em][:, 8:11]).astype(np.float64)
+    assert (np.abs(a - b) / np.maximum(np.abs(b), 1e-30)).max() <= KAT5_FLOAT_TOL
+    assert np.all(out[~em] == 0)
+
+
+def test_shade_indirect_matches_the_reference_kernel():
+    L = lib(); lt, cdf, _ = kat5.lights()
+    rin, ref = kat5.shade_rows("sind"); n = len(rin)
+    out = np.zeros((n, 10), np.uint32)
+    L.orc_kat_shade(n, kat5.W, kat5.H, u32ptr(rin), len(lt), u32ptr(lt), u32ptr(cdf), None, u32ptr(out))
+    # continuation decisions (alpha pass-through, grazing cut, pdf cut, Russian roulette): the same pixels continue
+    assert np.array_equal(out[:, 0], ref[:, 0]) and 0.15 < ref[:, 0].mean() < 0.6
+    em = ref[:, 0] == 1
+    assert np.array_equal(out[em][:, 1:4], ref[em][:, 1:4])                                  # origin = the surface position
+    a = kat5.as_f32(out[em][:, 4:]).astype(np.float64); b = kat5.as_f32(ref[em][:, 4:]).astype(np.float64)
+    err = np.abs(a - b) / np.maximum(np.abs(b), 1e-3)
+    # sampled directions go through sincos / sqrt / pow chains (host libm in the rows, the fixed implementations here): the bound of the sample-BSDF rows above
+    assert err.max() < 1e-3, err.max()
+    assert np.median(err.max(axis=1)) < 1e-6
+    alpha = (rin[:, 3] == 2)                                                                 # alpha cut-outs continue straight on with their transport factor, bit for bit
+    assert alpha.sum() > 10 and np.array_equal(out[alpha], ref[alpha]) and np.all(ref[alpha][:, 0] == 1)
+
+
+@pytest.mark.parametrize("f", range(kat5.FRAMES))
+def test_restir_kernels_match_the_reference_kernels(f):
+    fr, out = _run_restir_frame(f)
+    if f == 0:
+        assert np.array_equal(out["bags"], fr["bags"])                                       # FillLightBagsInternal: light index and pdf, bit for bit
+    for p in (0, 1):                                                                         # GenerateShadowRay: the same rays in the same append order, bit for bit
+        n = int(out["ray_counts"][p])
+        assert n == len(fr["rays"][p]) and np.array_equal(out["rays"][p, :n], fr["rays"][p]), p
+    for s, name in enumerate(kat5.STAGES):
+        assert_reservoirs_match(out["stages"][s], fr["stages"][s], f"frame {f} after {name}")
+    assert np.array_equal(out["shade_from"], fr["shade_from"])                               # which reservoir is shaded into which pixel, at all three call sites
+    got = kat5.as_f32(out["direct"])[:, :3]; want = kat5.expected_direct(f)
+    assert np.array_equal(got == 0, want == 0)
+    assert (np.abs(got - want) / np.maximum(np.abs(want), 1e-30)).max() <= KAT5_FLOAT_TOL
+    # the buffers the next frame finds
+    nxt = kat5.reservoirs_before(f + 1) if f + 1 < kat5.FRAMES else None
+    if nxt is not None:
+        for b in range(4):
+            assert_reservoirs_match(out["res4"][b], nxt[b], f"frame {f} buffer {b} handed on")
