@@ -216,6 +216,25 @@ int lumen_mi_test_math(lumen_mi_renderer*, uint32_t n, int fn, const float* x, c
  * lumen_mi_test_bsdf mode 2 = the contracted EvaluateBSDF of the fast policy (disney.cuh:320-405 for the isotropic opaque stack):
  * out8 = (bsdf, pdf, applies, 0, 0, 0). */
 int lumen_mi_test_restir(lumen_mi_renderer*, int mode, uint32_t n, const float* a, const float* b, const uint32_t* c, uint32_t m, float* out);
+/* Known-answer hooks that run whole KERNELS of the hot path on rows (csrc/kat.cpp; rows: tests/golden/ref_kat5.npz = what the reference's own __global__ kernel
+ * bodies computed on a 64 x 48 synthetic image, generator oracle/ref_kat/gen_kat5.cpp).  Arrays are 32-bit words: floats by bit pattern, flags / counts / indices as
+ * integers.  surface(40) = flags t position normal tangent incoming transport mat23; reservoir(17) = weightSum sampleCount weight radiance normal position area
+ * contribution solidAnglePdf; light(16) = p0 p1 p2 normal radiance area (sorted by mean radiance), cdf = its prefix sums.
+ * lumen_mi_test_restir_frame: one ReSTIR::Run (Framework/ReSTIR.cpp:65-233) — FillLightBags, PickPrimarySamples + GenerateShadowRay, temporal reuse, both spatial
+ * passes, CombineReservoirBuffers (ReSTIRKernels.cu:343-370,402-522,546-582,787-980,1015-1121,1407-1436), launched as a frame launches them, on synthetic
+ * surfaces; the visibility programs (closed, OptiX) are replaced by the masks occluded0 / occluded1 (per pixel, pass 1 / pass 2).  surf_prev40 NULL = the zero-filled
+ * buffer of a first frame.  res4 [4][n][17] in / out: the four reservoir buffers.  bags [50000][2] (light index, pdf) or NULL.  stages [5][n][17]: the buffer each
+ * kernel wrote right after it (pick, temporal, spatial 1, spatial 2, combine).  rays [2][n][8] (pixel, origin, direction, distance) in queue order, ray_counts[2].
+ * direct [n][4]: the DIRECT channel (the three ShadeReservoirs passes, ReSTIRKernels.cu:600-665).  fast: 0 exact arithmetic, 2 the fast policy (both launches). */
+int lumen_mi_test_restir_frame(lumen_mi_renderer*, uint32_t W, uint32_t H, const uint32_t* surf_cur40, const uint32_t* surf_prev40, const uint32_t* motion_half2,
+                               uint32_t n_lights, const uint32_t* lights16, const uint32_t* cdf, uint32_t a_seed, int current_index, const uint8_t* occluded0,
+                               const uint8_t* occluded1, int fast, uint32_t* res4, uint32_t* bags, uint32_t* stages, uint32_t* rays, uint32_t* ray_counts, uint32_t* direct);
+/* ShadeDirect (GPUShadeDirect.cu:42-153) / ShadeIndirect (GPUShadeIndirect.cu:7-146) as the wave kernels call them, on rows (x, y, seed, surface(40)).
+ * direct12 = emitted origin direction maxDistance radiance channel; indirect10 = emitted origin direction contribution; either may be NULL.  fast: tuning key fast_shade. */
+int lumen_mi_test_shade(lumen_mi_renderer*, uint32_t n, uint32_t W, uint32_t H, const uint32_t* rows43, uint32_t n_lights, const uint32_t* lights16, const uint32_t* cdf,
+                        int fast, uint32_t* direct12, uint32_t* indirect10);
+/* GeneratePrimaryRay (GPUGeneratePrimRay.cu:28-82): the primary-ray kernel on a W x H image; cam = U V W eye; out11 per pixel = x y origin direction contribution */
+int lumen_mi_test_primary_rays(lumen_mi_renderer*, uint32_t W, uint32_t H, uint32_t frame_count, const uint32_t* cam_uvw_eye12, uint32_t* out11);
 /* Known-answer hook for the host-side camera arithmetic of a frame (no renderer, no GPU): the image-plane vectors U, V, W of
  * Camera::GetVectorData (Lumen/src/Lumen/Renderer/Camera.cpp:79-93,122-128) for the rotation columns right / up / forward, and the matrix
  * projection * inverse(previous camera world matrix) the motion-vector pass receives (WaveFrontRenderer.cpp:763-776,

@@ -78,6 +78,10 @@ SYMBOLS = {
     "lumen_mi_query_any": [_R, C.c_uint32, _FP, _FP, C.c_float, _FP, _U8P],
     "lumen_mi_test_bsdf": [_R, C.c_uint32, C.c_int, _FP, _FP, _FP, _FP, _FP, _FP], "lumen_mi_test_math": [_R, C.c_uint32, C.c_int, _FP, _FP, _FP],
     "lumen_mi_test_restir": [_R, C.c_int, C.c_uint32, _FP, _FP, _U32P, C.c_uint32, _FP],
+    "lumen_mi_test_restir_frame": [_R, C.c_uint32, C.c_uint32, _U32P, _U32P, _U32P, C.c_uint32, _U32P, _U32P, C.c_uint32, C.c_int, _U8P, _U8P, C.c_int,
+                                   _U32P, _U32P, _U32P, _U32P, _U32P, _U32P],
+    "lumen_mi_test_shade": [_R, C.c_uint32, C.c_uint32, C.c_uint32, _U32P, C.c_uint32, _U32P, _U32P, C.c_int, _U32P, _U32P],
+    "lumen_mi_test_primary_rays": [_R, C.c_uint32, C.c_uint32, C.c_uint32, _U32P, _U32P],
     "lumen_mi_test_camera": [_FP, _FP, _FP, _FP, C.c_float, C.c_float, _FP],
     "lumen_mi_get_world_triangles": [_R, _FP, C.c_uint32, _U32P], "lumen_mi_get_lights": [_R, _FP, _FP, C.c_uint32, _U32P],
     "lumen_mi_get_bvh_info": [_R, _U32P, _U32P, _U32P],

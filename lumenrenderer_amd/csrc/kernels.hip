@@ -558,6 +558,25 @@ extern "C" __global__ void KN(lm_k_reuse_settle)(LmFrame fr)
     if (blockIdx.x == 0 && threadIdx.x == 0 && fr.swap[5] == 0 && (fr.swap[4] & 1) != (*fr.swap & 1)) fr.swap[5] = 1;
 }
 
+// What a resolved ReSTIR visibility ray does to its pixel: occluded => reservoir weight = 0 (WaveFrontShaders.cu:181-216); otherwise the reservoir is shaded
+// into DIRECT with weight / 3 (ShadeInternal / ShadeReservoirs, ReSTIRKernels.cu:600-665).  One place: the two traversal kernels below and the
+// known-answer hook lm_k_kat_resolve (which takes `occluded` from a mask instead of the tracer) run these lines.
+__device__ __forceinline__ void lm_vis_resolve(const LmFrame& fr, int rc, float4* hot, uint32_t li, bool occluded, int pass)
+{
+    float* weight = (float*)(hot + 4u * li + 1u);           // quad 1 = (weight, count, normal.xy): lm_restir.h (included below)
+    if (occluded) {
+        // pass 2 with the frame's history passes pending (lazy reuse): the first spatial pass, which the reference runs BEFORE this one
+        // (ReSTIR.cpp:181-212), will read this weight later — park it in the two spare words of quad 0 (read back in lm_restir_spatial_body, `parked`)
+        if (pass == 2) { float* q0 = (float*)(hot + 4u * li); q0[2] = *weight; q0[3] = 1.f; }
+        *weight = 0.f;
+    } else {
+        const lf3 add = v3(fr.resC[rc][li]) * (*weight / 3.f);
+        float4 px = fr.direct[li];
+        px.x += add.x; px.y += add.y; px.z += add.z;
+        fr.direct[li] = px;
+    }
+}
+
 // K6 + K23: resolve the visibility rays (tmin 0.1, WaveFrontShaders.cu:181-216: occluded => reservoir weight = 0) and shade
 // the surviving reservoirs into DIRECT with weight / 3 (ReSTIRKernels.cu:600-665)
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
@@ -572,21 +591,7 @@ KN(lm_k_restir_trace_shade)(LmScene sc, LmFrame fr, int rc, const uint32_t* __re
     const float4* __restrict__ qD = pass ? fr.vis2D : fr.visD;
     lm_trace_queue<true>(sc, n, refillBelow, lm_make_stack(s_stack, sc), lm_stage_top(s_top, sc), fr.counters,
         [&](uint32_t i, lf3& o, lf3& d, float& t0, float& t1) { const float4 o4 = qO[i]; o = v3(o4); d = v3(qD[i]); t0 = 0.1f; t1 = o4.w; },
-        [&](uint32_t i, bool occluded, const LmHit&) {
-            const uint32_t li = f2u(qD[i].w);
-            float* weight = (float*)(hot + 4u * li + 1u);           // quad 1 = (weight, count, normal.xy): lm_restir.h (included below)
-            if (occluded) {
-                // pass 2 with the frame's history passes pending (lazy reuse): the first spatial pass, which the reference runs BEFORE this one
-                // (ReSTIR.cpp:181-212), will read this weight later — park it in the two spare words of quad 0 (read back in lm_restir_spatial_body, `parked`)
-                if (pass == 2) { float* q0 = (float*)(hot + 4u * li); q0[2] = *weight; q0[3] = 1.f; }
-                *weight = 0.f;
-            } else {
-                const lf3 add = v3(fr.resC[rc][li]) * (*weight / 3.f);
-                float4 px = fr.direct[li];
-                px.x += add.x; px.y += add.y; px.z += add.z;
-                fr.direct[li] = px;
-            }
-        });
+        [&](uint32_t i, bool occluded, const LmHit&) { lm_vis_resolve(fr, rc, hot, f2u(qD[i].w), occluded, pass); });
 }
 
 // the same pass for queues of COHERENT visibility rays: the candidate pick / temporal pass append a 16 x 16 pixel tile's rays together, a
@@ -604,19 +609,7 @@ KN(lm_k_restir_trace_shade_packet)(LmScene sc, LmFrame fr, int rc, const uint32_
     const float4* __restrict__ qD = pass ? fr.vis2D : fr.visD;
     lm_trace_packets<true>(sc, n, (lm_lds_int*)(s_wstack + LM_PACKET_STACK * (threadIdx.x >> 6)), lm_stage_top(s_top, sc),
         [&](uint32_t i, lf3& o, lf3& d, float& t0, float& t1) { const float4 o4 = qO[i]; o = v3(o4); d = v3(qD[i]); t0 = 0.1f; t1 = o4.w; },
-        [&](uint32_t i, bool occluded, const LmHit&) {
-            const uint32_t li = f2u(qD[i].w);
-            float* weight = (float*)(hot + 4u * li + 1u);
-            if (occluded) {
-                if (pass == 2) { float* q0 = (float*)(hot + 4u * li); q0[2] = *weight; q0[3] = 1.f; }     // see lm_k_restir_trace_shade
-                *weight = 0.f;
-            } else {
-                const lf3 add = v3(fr.resC[rc][li]) * (*weight / 3.f);
-                float4 px = fr.direct[li];
-                px.x += add.x; px.y += add.y; px.z += add.z;
-                fr.direct[li] = px;
-            }
-        });
+        [&](uint32_t i, bool occluded, const LmHit&) { lm_vis_resolve(fr, rc, hot, f2u(qD[i].w), occluded, pass); });
 }
 
 #include "lm_restir.h"
@@ -1437,6 +1430,91 @@ KN(lm_k_test_restir)(int mode, uint32_t n, const float* __restrict__ a, const fl
         out[i] = (float)lm_srgb8(a[i]);
     }
 }
+// ---------------------------------------------------------------------------------------------------------------------
+// Known-answer hooks for whole KERNELS (tests/golden/ref_kat5.npz: what the reference's own __global__ bodies computed, oracle/ref_kat/gen_kat5.cpp).
+// The host side (kat.cpp) lays synthetic surfaces / reservoirs out with the product's own store functions below, launches the product's kernels
+// through the kernel table exactly as frame.cpp does, and reads the buffers back through the product's load functions.
+// Rows are 32-bit words: floats by bit pattern; surface(40) = flags t position normal tangent incoming transport mat23; reservoir(17) = weightSum
+// sampleCount weight radiance normal position area contribution solidAnglePdf.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ LmSurface lm_kat_surface(const uint32_t* __restrict__ w)
+{
+    LmSurface s;
+    s.flags = w[0]; s.t = u2f(w[1]);
+    s.position = v3(u2f(w[2]), u2f(w[3]), u2f(w[4])); s.normal = v3(u2f(w[5]), u2f(w[6]), u2f(w[7])); s.tangent = v3(u2f(w[8]), u2f(w[9]), u2f(w[10]));
+    s.incoming = v3(u2f(w[11]), u2f(w[12]), u2f(w[13])); s.transport = v3(u2f(w[14]), u2f(w[15]), u2f(w[16]));
+    float m[23];
+    for (int i = 0; i < 23; i++) m[i] = u2f(w[17 + i]);
+    if (s.flags == 0u) s.mat = lm_material_from23(m);
+    else { s.mat.color = make_float4(m[0], m[1], m[2], m[3]); s.mat.tint = make_float4(0.f, 0.f, 0.f, 0.f); s.mat.transmittance = make_float4(0.f, 0.f, 0.f, 0.f); s.mat.p0 = s.mat.p1 = s.mat.p2 = 0u; }
+    return s;
+}
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_kat_pack_surfaces)(const uint32_t* __restrict__ rows40, uint32_t n, float4* gbuf, float4* probe)
+{
+    const uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const LmSurface s = lm_kat_surface(rows40 + 40u * i);
+    lm_gbuf_store(gbuf, probe, i, s);
+}
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_kat_reservoirs)(uint32_t* rows17, uint32_t n, float4* hot, float4* contrib, int unpack)
+{
+    const uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint32_t* w = rows17 + 17u * i;
+    LmReservoir r;
+    if (unpack) {
+        lm_res_load(hot, contrib, i, r);
+        w[0] = f2u(r.weightSum); w[1] = (uint32_t)r.count; w[2] = f2u(r.weight);
+        w[3] = f2u(r.s.p.radiance.x); w[4] = f2u(r.s.p.radiance.y); w[5] = f2u(r.s.p.radiance.z); w[6] = f2u(r.s.p.normal.x); w[7] = f2u(r.s.p.normal.y); w[8] = f2u(r.s.p.normal.z);
+        w[9] = f2u(r.s.p.position.x); w[10] = f2u(r.s.p.position.y); w[11] = f2u(r.s.p.position.z); w[12] = f2u(r.s.p.area);
+        w[13] = f2u(r.s.contribution.x); w[14] = f2u(r.s.contribution.y); w[15] = f2u(r.s.contribution.z); w[16] = f2u(r.s.pdf);
+    } else {
+        r.weightSum = u2f(w[0]); r.count = (long long)w[1]; r.weight = u2f(w[2]);
+        r.s.p.radiance = v3(u2f(w[3]), u2f(w[4]), u2f(w[5])); r.s.p.normal = v3(u2f(w[6]), u2f(w[7]), u2f(w[8])); r.s.p.position = v3(u2f(w[9]), u2f(w[10]), u2f(w[11])); r.s.p.area = u2f(w[12]);
+        r.s.contribution = v3(u2f(w[13]), u2f(w[14]), u2f(w[15])); r.s.pdf = u2f(w[16]);
+        lm_res_store(hot, contrib, i, r);
+    }
+}
+// the visibility queue of pass `pass` resolved from a per-pixel mask instead of the tracer (the OptiX programs are closed; the rows carry a mask)
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_kat_resolve)(LmFrame fr, int rc, const uint32_t* __restrict__ countPtr, const uint8_t* __restrict__ occluded, int pass)
+{
+    rc = lm_res_idx(fr, rc);
+    const uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x;
+    if (i >= *countPtr) return;
+    const float4* __restrict__ qD = pass ? fr.vis2D : fr.visD;
+    const uint32_t li = f2u(qD[i].w);
+    lm_vis_resolve(fr, rc, fr.res[rc], li, occluded[li] != 0, pass);
+}
+// ShadeDirect / ShadeIndirect (GPUShadeDirect.cu:42-153, GPUShadeIndirect.cu:7-146) as the wave kernels call them; rows (x, y, seed, surface(40))
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_kat_shade)(LmScene sc, uint32_t n, uint32_t W, const uint32_t* __restrict__ rows43, int fast, uint32_t* __restrict__ direct12, uint32_t* __restrict__ indirect10)
+{
+    const uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* w = rows43 + 43u * i;
+    const uint32_t gi = w[1] * W + w[0], seed = w[2];
+    const LmSurface s = lm_kat_surface(w + 3);
+    if (direct12) {
+        uint32_t* o = direct12 + 12u * i;
+        lf3 dir = v3(0.f), rad = v3(0.f); float tmax = 0.f;
+        const bool emit = fast ? lm_shade_direct<LmFast>(sc, s, gi, seed, dir, tmax, rad) : lm_shade_direct<LmExact>(sc, s, gi, seed, dir, tmax, rad);
+        for (int k = 0; k < 12; k++) o[k] = 0u;
+        if (emit) {
+            o[0] = 1u; o[1] = f2u(s.position.x); o[2] = f2u(s.position.y); o[3] = f2u(s.position.z); o[4] = f2u(dir.x); o[5] = f2u(dir.y); o[6] = f2u(dir.z); o[7] = f2u(tmax);
+            o[8] = f2u(rad.x); o[9] = f2u(rad.y); o[10] = f2u(rad.z); o[11] = 1u;                     // the wave kernels add NEE light to INDIRECT (LightChannel::INDIRECT = 1)
+        }
+    }
+    if (indirect10) {
+        uint32_t* o = indirect10 + 10u * i;
+        lf3 org = v3(0.f), dir = v3(0.f), con = v3(0.f);
+        const bool emit = lm_shade_indirect(s, gi, seed, org, dir, con);
+        for (int k = 0; k < 10; k++) o[k] = 0u;
+        if (emit) { o[0] = 1u; o[1] = f2u(org.x); o[2] = f2u(org.y); o[3] = f2u(org.z); o[4] = f2u(dir.x); o[5] = f2u(dir.y); o[6] = f2u(dir.z); o[7] = f2u(con.x); o[8] = f2u(con.y); o[9] = f2u(con.z); }
+    }
+}
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
 KN(lm_k_test_math)(uint32_t n, int fn, const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out)
 {
@@ -1836,6 +1914,11 @@ static void l_test_bsdf(hipStream_t s, uint32_t n, int mode, const float* mat, c
 { hipLaunchKernelGGL(KN(lm_k_test_bsdf), LM_GRID((n + LM_BLOCK - 1) / LM_BLOCK), n, mode, mat, N, T, wo, aux, out); }
 static void l_test_restir(hipStream_t s, int mode, uint32_t n, const float* a, const float* b, const uint32_t* c, uint32_t m, float* out)
 { const uint32_t t = mode == 1 ? m : n; hipLaunchKernelGGL(KN(lm_k_test_restir), LM_GRID((t + LM_BLOCK - 1) / LM_BLOCK), mode, n, a, b, c, m, out); }
+static void l_kat_pack_surfaces(hipStream_t s, const uint32_t* rows40, uint32_t n, float4* gbuf, float4* probe) { hipLaunchKernelGGL(KN(lm_k_kat_pack_surfaces), LM_GRID((n + LM_BLOCK - 1) / LM_BLOCK), rows40, n, gbuf, probe); }
+static void l_kat_reservoirs(hipStream_t s, uint32_t* rows17, uint32_t n, float4* hot, float4* contrib, int unpack) { hipLaunchKernelGGL(KN(lm_k_kat_reservoirs), LM_GRID((n + LM_BLOCK - 1) / LM_BLOCK), rows17, n, hot, contrib, unpack); }
+static void l_kat_resolve(hipStream_t s, LmFrame fr, int rc, const uint32_t* count, const uint8_t* occluded, int pass) { hipLaunchKernelGGL(KN(lm_k_kat_resolve), LM_GRID((fr.n + LM_BLOCK - 1) / LM_BLOCK), fr, rc, count, occluded, pass); }
+static void l_kat_shade(hipStream_t s, LmScene sc, uint32_t n, uint32_t W, const uint32_t* rows43, int fast, uint32_t* direct12, uint32_t* indirect10)
+{ hipLaunchKernelGGL(KN(lm_k_kat_shade), LM_GRID((n + LM_BLOCK - 1) / LM_BLOCK), sc, n, W, rows43, fast, direct12, indirect10); }
 static void l_test_math(hipStream_t s, uint32_t n, int fn, const float* x, const float* y, float* out) { hipLaunchKernelGGL(KN(lm_k_test_math), LM_GRID((n + LM_BLOCK - 1) / LM_BLOCK), n, fn, x, y, out); }
 static void l_history_copy(hipStream_t s, int g, LmFrame fr, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, float4* buf, int import)
 { hipLaunchKernelGGL(KN(lm_k_history_copy), LM_GRID(g), fr, x0, y0, w, h, buf, import); }
@@ -1861,6 +1944,7 @@ extern "C" const LmKernelTable* lm_kernel_table()
 #endif
 {
     static const LmKernelTable t = {l_primary, l_trace_closest, l_extract0, l_shade_wave, l_trace_shadow, l_path_tail, l_fill_bags, l_pick_primary,
-                                    l_trace_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_export_aux, l_refit_tris, l_refit_quant, l_refit_level, l_test_bsdf, l_test_math, l_spin, l_history_copy, l_wave_sync, l_test_restir, l_build_top, l_export_half4, l_sort_rays, l_reuse_settle, l_reuse_counts, l_trace_primary};
+                                    l_trace_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_export_aux, l_refit_tris, l_refit_quant, l_refit_level, l_test_bsdf, l_test_math, l_spin, l_history_copy, l_wave_sync, l_test_restir, l_build_top, l_export_half4, l_sort_rays, l_reuse_settle, l_reuse_counts, l_trace_primary,
+                                    l_kat_pack_surfaces, l_kat_reservoirs, l_kat_resolve, l_kat_shade};
     return &t;
 }

@@ -39,6 +39,12 @@ struct LmKernelTable {
     void (*reuse_settle)(hipStream_t, LmFrame);       // after deferred history passes launched BETWEEN frames (kernels.hip lm_reuse_owed)
     void (*reuse_counts)(hipStream_t, LmFrame previous, int was, const uint32_t* list, const uint32_t* listCount, uint32_t seed);      // lazy reuse: completes the entries that outlive a dropped history pass
     void (*trace_primary)(hipStream_t, int grid, LmScene, LmFrame, LmCamera, uint32_t frameCount, uint4* hits, float tmin, float tmax);   // primary rays generated inside the packet traversal
+    // known-answer hooks for whole kernels (kat.cpp; rows of tests/golden/ref_kat5.npz): synthetic surfaces / reservoirs laid out by the product's own store functions,
+    // a visibility queue resolved from a mask, ShadeDirect / ShadeIndirect on surface rows
+    void (*kat_pack_surfaces)(hipStream_t, const uint32_t* rows40, uint32_t n, float4* gbuf, float4* probe);
+    void (*kat_reservoirs)(hipStream_t, uint32_t* rows17, uint32_t n, float4* hot, float4* contrib, int unpack);
+    void (*kat_resolve)(hipStream_t, LmFrame, int rc, const uint32_t* count, const uint8_t* occluded, int pass);
+    void (*kat_shade)(hipStream_t, LmScene, uint32_t n, uint32_t W, const uint32_t* rows43, int fast, uint32_t* direct12, uint32_t* indirect10);
 };
 extern "C" const LmKernelTable* lm_kernel_table();
 extern "C" const LmKernelTable* lm_kernel_table_instrumented();

@@ -314,6 +314,40 @@ class LumenRendererMI:
                                                       None if c is None else c.ctypes.data_as(C.POINTER(C.c_uint32)), m, _fp(out)))
         return out.reshape(n, -1) if mode >= 3 else out
 
+    def TestRestirFrame(self, W, H, surf_cur, surf_prev, motion, lights, cdf, seed, current_index, occluded0, occluded1, res4, fast=0):
+        """Known-answer hook (lumen_mi_test_restir_frame): the kernels of one ReSTIR::Run on rows of 32-bit words; see include/lumen_mi.h.
+        Returns a dict: res4 (the four buffers afterwards), bags, stages [5][n][17], rays [pass] -> [count][8], direct [n][4]."""
+        u32 = lambda a: np.ascontiguousarray(a, np.uint32)
+        up = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint32))
+        u8p = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8))
+        n = W * H
+        surf_cur = u32(surf_cur); motion = u32(motion); lights = u32(lights); cdf = u32(cdf)
+        surf_prev = None if surf_prev is None else u32(surf_prev)
+        o0 = np.ascontiguousarray(occluded0, np.uint8); o1 = np.ascontiguousarray(occluded1, np.uint8)
+        res4 = u32(res4).copy()
+        out = {"res4": res4, "bags": np.zeros((50000, 2), np.uint32), "stages": np.zeros((5, n, 17), np.uint32), "direct": np.zeros((n, 4), np.uint32)}
+        rays = np.zeros((2, n, 8), np.uint32); counts = np.zeros(2, np.uint32)
+        check(self.lib, self.lib.lumen_mi_test_restir_frame(self.h, W, H, up(surf_cur), None if surf_prev is None else up(surf_prev), up(motion), lights.shape[0], up(lights), up(cdf),
+                                                            int(seed), int(current_index), u8p(o0), u8p(o1), int(fast), up(res4), up(out["bags"]), up(out["stages"]), up(rays), up(counts),
+                                                            up(out["direct"])))
+        out["rays"] = [rays[p, :int(counts[p])] for p in (0, 1)]
+        return out
+
+    def TestShade(self, W, H, rows43, lights, cdf, fast=0, direct=True, indirect=True):
+        """Known-answer hook (lumen_mi_test_shade): ShadeDirect / ShadeIndirect on rows (x, y, seed, surface(40)) -> ([n][12], [n][10])."""
+        up = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint32))
+        rows43 = np.ascontiguousarray(rows43, np.uint32); lights = np.ascontiguousarray(lights, np.uint32); cdf = np.ascontiguousarray(cdf, np.uint32)
+        n = rows43.shape[0]
+        d = np.zeros((n, 12), np.uint32) if direct else None; i = np.zeros((n, 10), np.uint32) if indirect else None
+        check(self.lib, self.lib.lumen_mi_test_shade(self.h, n, W, H, up(rows43), lights.shape[0], up(lights), up(cdf), int(fast), None if d is None else up(d), None if i is None else up(i)))
+        return d, i
+
+    def TestPrimaryRays(self, W, H, frame_count, cam12):
+        """Known-answer hook (lumen_mi_test_primary_rays): the primary-ray kernel on a W x H image -> [n][11] words (x y origin direction contribution)."""
+        cam12 = np.ascontiguousarray(cam12, np.uint32); out = np.zeros((W * H, 11), np.uint32)
+        check(self.lib, self.lib.lumen_mi_test_primary_rays(self.h, W, H, int(frame_count), cam12.ctypes.data_as(C.POINTER(C.c_uint32)), out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out
+
     def TestMath(self, fn, x, y=None):
         x = _f32(x).ravel(); y = x if y is None else _f32(y).ravel(); out = np.zeros_like(x)
         check(self.lib, self.lib.lumen_mi_test_math(self.h, x.size, fn, _fp(x), _fp(y), _fp(out)))

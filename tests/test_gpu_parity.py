@@ -182,6 +182,108 @@ def test_device_resample_and_combine_match_the_reference_functions(bare):
     assert np.quantile(rowerr, 0.9) < 1e-5 and rowerr.max() < 5e-3, ferr.max()       # (the same conditioning as above, through both resampled inputs)
 
 
+# ---- round 4: the KERNELS of the hot path against what the reference's own __global__ bodies computed (tests/golden/ref_kat5.npz, oracle/ref_kat/gen_kat5.cpp)
+def _device_restir_frame(bare, f, fast=0, res4=None):
+    import kat5
+    lt, cdf, _ = kat5.lights()
+    fr = kat5.frame(f)
+    prev = kat5.frame(f - 1)["surf"] if f else None
+    out = bare.TestRestirFrame(kat5.W, kat5.H, fr["surf"], prev, fr["motion"], lt, cdf, fr["seed"], fr["current"], fr["occ"][0], fr["occ"][1],
+                               kat5.reservoirs_before(f) if res4 is None else res4, fast=fast)
+    return fr, out
+
+
+def _rays_by_pixel(rows):
+    order = np.argsort(rows[:, 0], kind="stable")
+    return rows[order]
+
+
+@pytest.mark.parametrize("f", [0, 1, 2])
+def test_device_restir_kernels_match_the_reference_kernels(bare, f):
+    """lm_k_fill_bags, lm_k_pick_primary (+ GenerateShadowRay fused), lm_k_restir_temporal (+ the second ray generation, + ShadeReservoirs of the previous
+    reservoir), lm_k_restir_spatial x 2, lm_k_restir_combine — launched with frame.cpp's arguments on the synthetic frames — against the rows the reference's own
+    kernel text produced, and bit for bit against the oracle on the same rows.  Exact arithmetic policy."""
+    import kat5
+    from test_oracle_kat import _run_restir_frame, assert_reservoirs_match, KAT5_FLOAT_TOL
+    fr, out = _device_restir_frame(bare, f)
+    _, orc = _run_restir_frame(f)
+    if f == 0:
+        assert np.array_equal(out["bags"], fr["bags"])
+    for p in (0, 1):
+        got = _rays_by_pixel(out["rays"][p]); want = _rays_by_pixel(fr["rays"][p])          # the device queue is appended block by block: compare by pixel
+        assert np.array_equal(got, want), p
+    for s, name in enumerate(kat5.STAGES):
+        assert_reservoirs_match(out["stages"][s], fr["stages"][s], f"frame {f} after {name}")
+        assert np.array_equal(out["stages"][s], orc["stages"][s]), f"device vs oracle, frame {f} after {name}"
+    got = kat5.as_f32(out["direct"])[:, :3]; want = kat5.expected_direct(f)
+    assert np.array_equal(got == 0, want == 0)
+    assert (np.abs(got - want) / np.maximum(np.abs(want), 1e-30)).max() <= KAT5_FLOAT_TOL
+    assert np.array_equal(out["direct"], orc["direct"])
+    assert np.array_equal(out["res4"], orc["res4"])
+
+
+def test_device_restir_kernels_fast_policy_track_the_reference_kernels(bare):
+    """The same kernels in the fast arithmetic policy (both launches: contracted evaluation + the exact launch for the surfaces it does not cover), each frame started
+    from the reference's own state: decisions may flip where a comparison falls within rounding of its threshold — bounded in number — and what is held
+    agrees to the tolerance of the fast policy."""
+    import kat5
+    flips = 0; total = 0
+    for f in range(kat5.FRAMES):
+        fr, out = _device_restir_frame(bare, f, fast=2)
+        for p in (0, 1):
+            a = set(out["rays"][p][:, 0].tolist()); b = set(fr["rays"][p][:, 0].tolist())
+            assert len(a ^ b) <= 8, (f, p, len(a ^ b))
+        for s, name in enumerate(kat5.STAGES):
+            got = out["stages"][s]; ref = fr["stages"][s]
+            assert np.array_equal(got[:, 1], ref[:, 1]), (f, name)                            # sample counts never depend on the arithmetic
+            held = (got[:, 3:13] == ref[:, 3:13]).all(axis=1)
+            flips += int((~held).sum()); total += len(held)
+            cols = [0, 2, 16]
+            a = kat5.as_f32(got)[held][:, cols].astype(np.float64); b = kat5.as_f32(ref)[held][:, cols].astype(np.float64)
+            live = (b != 0) & (a != 0)
+            err = np.abs(a - b)[live] / np.abs(b)[live]
+            assert np.quantile(err, 0.99) < 2e-4 and err.max() < 5e-2, (f, name, float(np.quantile(err, 0.99)), float(err.max()))
+    print(f"fast policy: {flips} of {total} reservoir decisions differ from the reference rows")
+    assert flips <= total // 500
+
+
+def test_device_primary_ray_kernel_matches_the_reference_kernel(bare):
+    import kat5
+    cam, prim = kat5.primary()
+    for fc in np.unique(prim[:, 1]):
+        rows = prim[prim[:, 1] == fc]
+        out = bare.TestPrimaryRays(kat5.W, kat5.H, int(fc), cam)
+        assert np.array_equal(out, rows[:, 2:].astype(np.uint32)), int(fc)
+
+
+def test_device_shade_direct_and_indirect_match_the_reference_kernels(bare):
+    """lm_shade_direct / lm_shade_indirect (what lm_k_extract0, lm_k_shade_wave and lm_k_path_tail call per surface) on the rows of the reference's ShadeDirect /
+    ShadeIndirect: bit-identical to the oracle, and to the reference as the oracle is (tests/test_oracle_kat.py)."""
+    import kat5
+    from oracle_lib import u32ptr
+    L = orc_lib(); lt, cdf, _ = kat5.lights()
+    rin, ref = kat5.shade_rows("sdir"); n = len(rin)
+    want = np.zeros((n, 12), np.uint32)
+    L.orc_kat_shade(n, kat5.W, kat5.H, u32ptr(rin), len(lt), u32ptr(lt), u32ptr(cdf), u32ptr(want), None)
+    got, _ = bare.TestShade(kat5.W, kat5.H, rin, lt, cdf, indirect=False)
+    assert np.array_equal(got, want)
+    assert np.array_equal(got[:, 0], ref[:, 0]) and np.array_equal(got[ref[:, 0] == 1][:, 1:8], ref[ref[:, 0] == 1][:, 1:8])
+    em = ref[:, 0] == 1
+    a = kat5.as_f32(got[em][:, 8:11]).astype(np.float64); b = kat5.as_f32(ref[em][:, 8:11]).astype(np.float64)
+    assert (np.abs(a - b) / np.maximum(np.abs(b), 1e-30)).max() <= 2e-6
+    fastd, _ = bare.TestShade(kat5.W, kat5.H, rin, lt, cdf, fast=1, indirect=False)         # tuning key fast_shade: the contribution in hardware rcp / rsq
+    assert (fastd[:, 0] != ref[:, 0]).sum() <= 4
+    both = (fastd[:, 0] == 1) & em
+    a = kat5.as_f32(fastd[both][:, 8:11]).astype(np.float64); b = kat5.as_f32(ref[both][:, 8:11]).astype(np.float64)
+    assert np.quantile(np.abs(a - b) / np.maximum(np.abs(b), 1e-30), 0.99) < 1e-4
+    rin, ref = kat5.shade_rows("sind")
+    want = np.zeros((n, 10), np.uint32)
+    L.orc_kat_shade(n, kat5.W, kat5.H, u32ptr(rin), len(lt), u32ptr(lt), u32ptr(cdf), None, u32ptr(want))
+    _, got = bare.TestShade(kat5.W, kat5.H, rin, lt, cdf, direct=False)
+    assert np.array_equal(got, want)
+    assert np.array_equal(got[:, 0], ref[:, 0])
+
+
 def test_device_contracted_bsdf_matches_the_reference_evaluate_bsdf(bare):
     """The contracted evaluation of the fast policy (lm_quick_setup + lm_quick_eval, lm_bsdf.h) against the reference's EvaluateBSDF
     (disney.cuh:320-405) on the reference-header rows of ref_kat.npz it covers, plus the depth-0 surfaces of the Resample rows
