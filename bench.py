@@ -55,7 +55,12 @@ WORKLOADS = {
     "c4": ("sponza", dict(), 3840, 2160, 8, 8),
     "c5": ("foliage", dict(), 1920, 1080, 6, 1),
     "c1": ("cornell", dict(), 256, 256, 2, 1),
+    # the reference's OWN default setting (Sandbox/src/Application.cpp:89-93: 1280x720, depth 5, ReSTIR on) with the camera moving every TraceFrame, which
+    # switches blending off (OutputLayer.cpp:492-495): 1 "spp", an odd depth — the reservoir swap chain turns every frame, the temporal pass reads a live
+    # history through non-zero motion vectors, and the history passes run with their frame (no lazy reuse).  A step = one TraceFrame at the next camera pose.
+    "sandbox": ("sponza", dict(), 1280, 720, 5, 1),
 }
+MOVING = {"sandbox"}             # workloads whose camera moves every TraceFrame (lumenrenderer_amd.scenes.sandbox_camera_pose), blending off
 
 
 def make_scene(kind, kw):
@@ -134,7 +139,15 @@ def self_launch(args, argv):
     return rc
 
 
-def cpu_baseline(kind, kw, depth, spp, full):
+def camera_pose(desc, k):
+    """Pose of the k-th TraceFrame of a moving workload: the 32-frame walk of scenes.sandbox_camera_pose there and back again (the camera stays in the atrium
+    however many steps are timed; every frame still moves by one step)."""
+    from lumenrenderer_amd import scenes
+    k %= 64
+    return scenes.sandbox_camera_pose(desc, k if k < 32 else 64 - k)
+
+
+def cpu_baseline(kind, kw, depth, spp, full, moving=False):
     """The CPU oracle ("port") timed on this box's host cores on a bounded sample of the same workload: the same scene,
     `spp` blended frames, at the largest of a few resolutions expected to need <= ~25 s (probed at 480x270 first).
     Test infrastructure used as a reported baseline only — never as the measured path."""
@@ -144,12 +157,16 @@ def cpu_baseline(kind, kw, depth, spp, full):
     cores = usable_cpus()                                 # affinity mask capped by the cgroup CPU quota: the threads that really run
     scene = make_scene(kind, kw)
 
+    frames = 4 if moving else spp                       # a moving workload: four consecutive poses (one frame alone has no history to read)
+
     def run(w, h):
-        o = oracle_from(scene, w, h, depth, blend=True, threads=cores)
+        o = oracle_from(scene, w, h, depth, blend=not moving, threads=cores)
         o.world_triangles()                               # scene flattening + BVH build outside the timed region (as on the GPU)
         t0 = time.perf_counter()
         rays = 0
-        for _ in range(spp):
+        for k in range(frames):
+            if moving:
+                o.set_camera(*camera_pose(scene, k))
             o.trace_frame()
             s = o.stats(4)
             rays += s[0] + s[1] + s[2]
@@ -165,7 +182,8 @@ def cpu_baseline(kind, kw, depth, spp, full):
             rays, dt = run(w, h)
             break
     return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"{w}x{h} x {spp} blended frames, depth {depth}, same scene: {dt:.1f} s, {rays} rays, {dt * 1e3:.0f} ms/frame"}
+            "sample": (f"{w}x{h} x {frames} TraceFrames at consecutive camera poses, blending off" if moving else f"{w}x{h} x {spp} blended frames") +
+                      f", depth {depth}, same scene: {dt:.1f} s, {rays} rays, {dt * 1e3 / (frames if moving else 1):.0f} ms/frame"}
 
 
 def main():
@@ -220,9 +238,11 @@ def main():
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         warm = torch.zeros(1, device=dev); dist.all_reduce(warm); torch.cuda.synchronize()
     kind, kw, W, H, depth, spp = WORKLOADS[args.workload]
+    moving = args.workload in MOVING
+    blend_on = not moving
     desc = make_scene(kind, kw)
     r = LumenRendererMI()
-    r.Init(depth=depth, render_resolution=(W, H), blend_output=True, device=local_rank)
+    r.Init(depth=depth, render_resolution=(W, H), blend_output=blend_on, device=local_rank)
     r.set_stream(torch.cuda.current_stream().cuda_stream)
     r.LoadSceneDescription(desc)
     emu = tuple(int(x) for x in args.emulate_rank.split("/")) if args.emulate_rank else None
@@ -238,7 +258,7 @@ def main():
     # The renderer's four streams are created and used once BEFORE the RCCL communicator brings its own stream: HIP maps
     # streams onto 4 hardware queues, and two busy streams that end up sharing one serialise (measured -11 % at N = 1 with an
     # idle fifth stream created first).  RCCL's stream only works between frames, when the renderer's streams are idle.
-    r.SetBlendMode(True)
+    r.SetBlendMode(blend_on)
     r.TraceFrame()
     force_pg = os.environ.get("LUMEN_BENCH_FORCE_PG", "")          # A/B aid: "before" / "after" create a 1-rank communicator at N = 1
     if (world > 1 or force_pg) and not dist.is_initialized():
@@ -254,12 +274,17 @@ def main():
 
     ev_log = []                                           # per step: torch events around render / seam exchange / gather (multi-GPU explainers)
 
+    pose_no = [0]
+
     def frame(record=False):
-        r.SetBlendMode(True)                              # a fresh 4-spp accumulation per displayed frame
+        r.SetBlendMode(blend_on)                          # a fresh 4-spp accumulation per displayed frame (a moving camera: blending off, OutputLayer.cpp:492-495)
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if record else None
         if record:
             evs[0].record()
         for _ in range(spp):
+            if moving:
+                pose_no[0] += 1
+                r.SetCamera(*camera_pose(desc, pose_no[0]))
             r.TraceFrameAsync()
             if hx is not None:
                 hx.run(dist)
@@ -280,7 +305,7 @@ def main():
 
     # ---- instrumented pass (outside the timed region): BVH nodes / triangles per closest-hit ray for the roofline
     r.SetInstrumented(True)
-    r.SetBlendMode(True)
+    r.SetBlendMode(blend_on)
     r.TraceFrame()
     ci = r.GetCounters(50)
     # 64-byte node records fetched: lane-level node steps of the queue traversal kernels (counter 41); child boxes tested / 4 where the
@@ -342,13 +367,23 @@ def main():
         return {"dt": dt, "ms_per_step": ms_per_step, "host_submit_ms_per_step": host_dt * 1e3 / args.steps, "rays_per_frame": rays_all / args.steps, "value": rays_all / dt / 1e6,
                 "counters": c, "kernel_ms": k, "class_ms": kb, "n_traceframes": n_tf, "per_rank": per_rank}
 
+    # who took part: the size of the RCCL communicator the gather ran on and every rank's device, so that a scaling record shows its N ranks by itself
+    my_dev = f"{torch.cuda.get_device_name(local_rank)} (cuda:{local_rank})"
+    rccl_world = dist.get_world_size() if dist.is_initialized() else 1
+    devices = [my_dev]
+    if world > 1:
+        devices = [None] * world
+        dist.all_gather_object(devices, my_dev)
+
     fast = args.mode == "fast"
     lazy = args.reuse == "lazy"
     main_pass = timed_pass(fast, lazy)
     other_pass = None if (args.no_exact or world > 1 or emu) else timed_pass(not fast, lazy)
     # the other setting of the history passes, both arithmetic modes (single GPU only: the extra passes would double a scaling run)
-    reuse_pass = None if (args.no_other_reuse or world > 1 or emu) else timed_pass(fast, not lazy)
-    reuse_other = None if (args.no_other_reuse or args.no_exact or world > 1 or emu) else timed_pass(not fast, not lazy)
+    # (an odd path depth has no lazy reuse — the swap chain turns every frame and the history is read — so the two settings are the same run: skipped)
+    odd = depth % 2 == 1
+    reuse_pass = None if (args.no_other_reuse or world > 1 or emu or odd) else timed_pass(fast, not lazy)
+    reuse_other = None if (args.no_other_reuse or args.no_exact or world > 1 or emu or odd) else timed_pass(not fast, not lazy)
     r.SetTuning("fast_resample", 1 if fast else 0); r.SetTuning("lazy_reuse", -1 if lazy else 0)
     passes = {(fast, lazy): main_pass, (not fast, lazy): other_pass, (fast, not lazy): reuse_pass, (not fast, not lazy): reuse_other}      # (fast?, lazy?) -> pass or None
     rate = lambda f, l, key="value", nd=3: None if passes[(f, l)] is None else round(passes[(f, l)][key], nd)
@@ -375,7 +410,7 @@ def main():
         tc = [(b, l) for b, l in tc if b is not None and l]
         traffic_closest = sum(b * l for b, l in tc) / sum(l for _, l in tc) if tc else None
         npix = (win[2] - win[0]) * (win[3] - win[1])
-        alg_tf = algorithmic_bytes_traceframe(c, depth, npix, ci[20], ci[21])
+        alg_tf = algorithmic_bytes_traceframe(c, depth, npix, ci[20], ci[21], blend=blend_on)
         # whole-frame HBM traffic from the PMC replay: sum over kernels of bytes per launch x launches per TraceFrame
         tf_in_pmc = max(1, pmc.get("lm_k_primary", {}).get("launches", 1))
         hbm_tf = sum(v.get("hbm_bytes_per_launch_corrected", 0.0) * v.get("launches", 0) / tf_in_pmc for v in pmc.values()) if pmc else None
@@ -395,7 +430,7 @@ def main():
         out = {
             "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic", "rccl_world": rccl_world, "devices": devices,
             # both arithmetic modes at the top level, so that `value` cannot be read without its mode: "fast" = hardware rcp / rsq / sqrt +
             # contracted target function in the ReSTIR passes (the reference's Release build is -use_fast_math); "exact" = bit-identical to the oracle
             "mode": args.mode, "value_fast": round((main_pass if fast else other_pass)["value"], 3) if (fast or other_pass) else None,
@@ -406,7 +441,9 @@ def main():
             "reuse": args.reuse,
             "value_eager_reuse": rate(fast, False), "value_lazy_reuse": rate(fast, True), "ms_per_step_lazy_reuse": rate(fast, True, "ms_per_step", 4),
             "value_exact_lazy_reuse": rate(False, True), "value_exact_eager_reuse": rate(False, False),
-            "config": {"workload": f"{args.workload}: {'cornell box (the reference asset, tests/golden fixture)' if kind == 'cornell' else kind + ' stand-in'}, {W}x{H}, {spp} spp (blended TraceFrames), depth {depth}, ReSTIR DI on",
+            "config": {"workload": f"{args.workload}: {'cornell box (the reference asset, tests/golden fixture)' if kind == 'cornell' else kind + ' stand-in'}, {W}x{H}, " +
+                                   ("1 TraceFrame per step at a new camera pose (blending off: the Sandbox's own default setting, Application.cpp:89-93, live temporal history)" if moving else f"{spp} spp (blended TraceFrames)") +
+                                   f", depth {depth}, ReSTIR DI on",
                        "resample_mode": ("fast: hardware rcp/rsq/sqrt + contracted target function in the ReSTIR passes (rel-L2 vs oracle 1e-8 measured, 1e-3 asserted: "
                                          "test_fast_resampling_mode_stays_within_the_north_star_tolerance)") if fast else "exact: correctly rounded everywhere, bit-identical to the oracle",
                        "other_mode": None if other_pass is None else {"mode": "exact" if fast else "fast", "value": round(other_pass["value"], 3), "ms_per_step": round(other_pass["ms_per_step"], 4),
@@ -442,7 +479,7 @@ def main():
         if main_pass["per_rank"]:
             out["per_rank"] = main_pass["per_rank"]
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(kind, kw, depth, spp, (W, H))
+            out["cpu_baseline"] = cpu_baseline(kind, kw, depth, spp, (W, H), moving)
         if emu:
             out["emulated_rank"] = {"rank": emu[0], "of": emu[1], "window": list(win), "tile": list(tile),
                                     "note": "per-rank time of the tiled path on one GPU; value counts the tile's rays only"}

@@ -155,7 +155,8 @@ int lumen_mi_get_counter_totals(lumen_mi_renderer*, uint64_t* out, uint32_t n, i
 int lumen_mi_get_kernel_time(lumen_mi_renderer*, int which, float* milliseconds, uint32_t* launches);
 int lumen_mi_enable_kernel_timing(lumen_mi_renderer*, int enable);
 int lumen_mi_set_instrumented(lumen_mi_renderer*, int enable);   /* use the node/triangle counting traversal kernels */
-/* Scheduling knobs (no reference equivalent; none of them changes a result).  Keys: "tail_below" (waves expected to hold fewer rays run
+/* Scheduling knobs (no reference equivalent).  None of them changes a result, except the three arithmetic keys at the end of this list ("fast_resample", "fast_shade":
+ * within the stated tolerance) and the test-only value 2 of "lazy_reuse".  Keys: "tail_below" (waves expected to hold fewer rays run
  * as one path-tail launch; 0 = off, -1 = automatic), "tail_lanes" (paths per wavefront in that launch, 1..64; 0 or less = automatic), "tail_pair" (the NEE
  * shadow ray a path emits at one depth is traced by a partner lane beside the path's closest-hit query of the next depth: 1 on, 0 off, -1 automatic), "single_stream" (1 = no stream
  * overlap, no frame pipelining), "pick_ahead" (ReSTIR candidate generation of the next frame on its own stream: 1 on, 0 off,
@@ -170,8 +171,12 @@ int lumen_mi_set_instrumented(lumen_mi_renderer*, int enable);   /* use the node
  * ReSTIR.cpp:181-233 — are launched with the NEXT frame and run only if their result can still be read, i.e. when the reservoir swap chain has turned; if it has
  * not — every frame of an even path depth, WaveFrontRenderer.cpp:827 — only the sample counts of the entries that outlive the next candidate pick are
  * completed.  Images, counters and exported history counts equal those of launching the passes with their frame; 1 on, 0 off, -1 (default) automatic: on at
- * even path depths; 2 = on WITHOUT the count completion, wrong on purpose, for the test that shows the completion is observable; DESIGN.md "Lazy reuse"), "fast_resample" (arithmetic mode of the ReSTIR passes, see
- * the only key that changes results, within the stated tolerance). */
+ * even path depths; 2 = TEST ONLY: on WITHOUT the count completion, wrong on purpose, for the test that shows the completion is observable — reachable through this key
+ * only, the environment variable LUMEN_MI_LAZY_REUSE is clamped to -1 .. 1; DESIGN.md "Lazy reuse"), "spatial_lds" (1: in the fast mode the first spatial reuse pass stages
+ * the probes of a 32 x 32 pixel tile + its 30-pixel reach in LDS, 132 KB per block; identical image; default 0: it evicts the other streams' kernels, -5 % on the frame),
+ * "fast_resample" (arithmetic mode of the ReSTIR passes: hardware rcp / rsq / sqrt and the contracted target function; radiance within 1e-3 relative L2 of the exact mode,
+ * 1e-8 measured), "fast_shade" (on top of it: the NEE contribution at depth >= 1 with hardware rcp / sqrt: changes the last bits of INDIRECT radiance and, within
+ * rounding of two thresholds, whether a shadow ray is emitted; never which path continues). */
 int lumen_mi_set_tuning(lumen_mi_renderer*, const char* key, int value);
 
 /* ---- tile sharding (new functionality: the reference is single-GPU) */

@@ -24,6 +24,7 @@ int ensureFrameBuffers(R* r)
         return 0;
     }
     r->allocN = 0;                                        // a failure below leaves "nothing allocated": the next call starts over
+    r->owed.valid = false;                                // ... and nothing owed: the deferred history passes would run on the buffers freed below
     int bad = 0;
     for (int i = 0; i < 6; i++) bad |= r->dRay[i].ensure(n) | r->dRay[6 + i].ensure(n) | r->dTailRay[i].ensure(n);
     for (int i = 0; i < 6; i++) bad |= r->dSh[i].ensure(n);
@@ -302,9 +303,11 @@ int traceFrameAsync(R* r)
             // have left.  At an even path depth the reference computes a history that its own swap quirk never reads.
             if (r->owed.valid) {
                 if (overlap && sp != st) LM_HIP(hipStreamWaitEvent(st, r->evFront, 0));
+                size_t evOwed; evBegin(r, 3, evOwed);          // class 3 (ReSTIR): the deferred passes are ReSTIR time whenever they really run (odd depth, or waves running out)
                 Z(st); launchOwedReuse(r, st, 1);
                 if (r->lazyReuse != 2)     // (2: without — wrong on purpose, for the test that shows the completion is observable)
                 { LmFrame fo = r->owed.fr; fo.swap = fr.swap; Z(st); K->reuse_counts(st, fo, r->owed.gbuf, fr.hazardList, fr.counters + LM_CNT_HAZARD, r->owed.seed); }
+                evEnd(r, evOwed);
                 r->owed.valid = false;
             }
             evBegin2(r, 3, ev, sp);

@@ -11,6 +11,10 @@
 // (three loads per neighbour instead of four), quad 0 is only ever read for the pixel itself:
 //   0 (weightSum, solidAnglePdf, 0, 0)   1 (weight, sampleCount bits, normal.x, normal.y)   2 (radiance, area)   3 (position, normal.z)
 // plus a separate plane with the unshadowed contribution (only ever read for the pixel being shaded).
+// Spare words q0[2], q0[3] (lazy reuse, kernels.hip lm_vis_resolve / lm_restir_spatial_body): when a frame's history passes are deferred, the second visibility pass
+// parks the weight it zeroes as (q0[2] = weight, q0[3] = 1.f) for the first spatial pass that runs later.  INVARIANT: nothing else ever reads these two words —
+// lm_res_unpack ignores them, lm_k_history_copy exports the 80-byte reservoir through lm_res_load — and lm_res_store rewrites them to (0, 0).  A parked flag that
+// the deferred combine does not rewrite (passes dropped: the swap chain had not turned) therefore stays in the record harmlessly until the next store to that pixel.
 #pragma once
 
 struct LmLightPoint { lf3 position, normal, radiance; float area; };       // a point on an emissive triangle, as a reservoir remembers it

@@ -28,7 +28,7 @@ int lumen_mi_create(lumen_mi_renderer** out)
     if (const char* e = getenv("LUMEN_MI_PACKET_PRIMARY")) (*out)->packetPrimary = atoi(e);
     if (const char* e = getenv("LUMEN_MI_FAST_SHADE")) (*out)->fastShade = atoi(e);
     if (const char* e = getenv("LUMEN_MI_SPATIAL_LDS")) (*out)->spatialLds = atoi(e);
-    if (const char* e = getenv("LUMEN_MI_LAZY_REUSE")) (*out)->lazyReuse = atoi(e);
+    if (const char* e = getenv("LUMEN_MI_LAZY_REUSE")) (*out)->lazyReuse = std::max(-1, std::min(1, atoi(e)));      // (2 = the deliberately wrong test mode: tuning key only)
     if (const char* e = getenv("LUMEN_MI_FUSE_PRIMARY")) (*out)->fusePrimary = atoi(e);
     if (const char* e = getenv("LUMEN_MI_PACKET_VISIBILITY")) (*out)->packetVisibility = atoi(e);
     if (const char* e = getenv("LUMEN_MI_SORT_RAYS")) (*out)->sortRays = std::max(0, atoi(e));
@@ -509,7 +509,7 @@ static int historyCopy(lumen_mi_renderer* r, uint32_t x0, uint32_t y0, uint32_t 
 {
     if (!r || !dev) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
     ApiLock lk(r);
-    if (!r->fr.combined || !r->fr.n) return fail(LUMEN_MI_ERR_STATE, "no frame has been traced yet");
+    if (!r->fr.combined || !r->fr.n || !r->allocN) return fail(LUMEN_MI_ERR_STATE, "no frame has been traced yet");      // allocN == 0: a failed reallocation left no frame buffers
     const LmFrame& f = r->fr;
     if (x0 >= x1 || y0 >= y1 || x0 < f.x0 || y0 < f.y0 || x1 > f.x0 + f.ww || y1 > f.y0 + f.wh) return fail(LUMEN_MI_ERR_INVALID, "rectangle outside the render window");
     if (hipSetDevice(r->device) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "hipSetDevice failed");
@@ -606,7 +606,8 @@ int lumen_mi_get_counter_totals(lumen_mi_renderer* r, uint64_t* out, uint32_t n,
     if (r->dTotals.p) {
         unsigned long long t[LM_CNT_WORDS + 1];
         LM_HIP(hipMemcpy(t, r->dTotals.p, sizeof t, hipMemcpyDeviceToHost));
-        for (uint32_t d = 0; d < r->lastDepth && d < 16; d++) { v[0] += t[LM_CNT_RAYS(d)]; v[4 + d] = t[LM_CNT_RAYS(d)]; v[1] += t[LM_CNT_SHADOW(d)]; }
+        // every depth slot, not only those of the last frame's depth: SetDepth may have lowered the depth inside the window that is summed (unused slots are zero)
+        for (uint32_t d = 0; d < LM_MAX_DEPTH; d++) { v[0] += t[LM_CNT_RAYS(d)]; v[4 + d] = t[LM_CNT_RAYS(d)]; v[1] += t[LM_CNT_SHADOW(d)]; }
         v[2] = t[LM_CNT_RESTIR(0)] + t[LM_CNT_RESTIR(1)];
         v[3] = t[LM_CNT_WORDS];
         v[48] = t[LM_CNT_RESTIR(0)]; v[49] = t[LM_CNT_RESTIR(1)];
@@ -735,6 +736,7 @@ int lumen_mi_test_bsdf(lumen_mi_renderer* r, uint32_t n, int mode, const float* 
 {
     if (!r || !r->initialised) return fail(LUMEN_MI_ERR_STATE, "not initialised");
     if (!mat23 || !N || !T || !wo || !aux || !out8) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    ApiLock lk(r);                                  // r->stream is the render thread's stream too
     LM_HIP(hipSetDevice(r->device));
     DevBuf<float> dm, dn, dt, dw, da, dout;
     std::vector<float> vm(mat23, mat23 + (size_t)23 * n), vn(N, N + (size_t)3 * n), vt(T, T + (size_t)3 * n), vw(wo, wo + (size_t)3 * n), va(aux, aux + (size_t)3 * n);
@@ -779,6 +781,7 @@ int lumen_mi_test_math(lumen_mi_renderer* r, uint32_t n, int fn, const float* x,
 {
     if (!r || !r->initialised) return fail(LUMEN_MI_ERR_STATE, "not initialised");
     if (!x || !y || !out) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    ApiLock lk(r);
     LM_HIP(hipSetDevice(r->device));
     DevBuf<float> dx, dy, dout;
     std::vector<float> vx(x, x + n), vy(y, y + n);

@@ -541,6 +541,22 @@ def sponza_standin(extra_lights=0, light_radiance=(17.0, 12.0, 4.0), light_scale
     return d
 
 
+def sandbox_camera_pose(desc, k):
+    """Camera of TraceFrame k of the `sandbox` workload (the reference's own default setting with a moving camera: Sandbox/src/Application.cpp:89-93,
+    OutputLayer.cpp:492-495): the scene's camera walking 0.4 % of the view distance per frame forward and sideways while it yaws 0.6 degrees and nods a
+    little.  Returns (position, right, up, forward, fov) as float32 arrays — the arguments of SetCamera."""
+    c = desc.camera
+    pos0 = np.asarray(c["position"], np.float64); fwd0 = np.asarray(c["forward"], np.float64); up0 = np.asarray(c["up"], np.float64); right0 = np.asarray(c["right"], np.float64)
+    step = 0.12                                                    # world units per frame (the stand-in's atrium is ~ 30 long after its 0.008 node scale)
+    yaw, nod = 0.0105 * k, 0.02 * math.sin(0.35 * k)
+    fwd = fwd0 * math.cos(yaw) + right0 * math.sin(yaw) + up0 * nod
+    fwd /= np.linalg.norm(fwd)
+    right = np.cross(up0, fwd); right /= np.linalg.norm(right)    # rotation-matrix columns as the scene's own camera builds them: right = up x forward
+    up = np.cross(fwd, right)
+    pos = pos0 + fwd0 * (step * k) + right0 * (0.05 * k)
+    return (pos.astype(np.float32), right.astype(np.float32), up.astype(np.float32), fwd.astype(np.float32), float(c["fov"]))
+
+
 def _wang_hash(s):
     s = ((s ^ 61) ^ (s >> 16)) & 0xFFFFFFFF
     s = (s * 9) & 0xFFFFFFFF
