@@ -13,12 +13,14 @@
 
 #include <glm/gtc/quaternion.hpp>
 
+#include <cstddef>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <memory>
+#include <string>
 #include <vector>
 
 namespace
@@ -38,10 +40,20 @@ int main(int argc, char** argv)
     if (argc != 7) { std::fprintf(stderr, "usage: %s <scene file> <width> <height> <depth> <frames> <out.ppm>\n", argv[0]); return 64; }
     const unsigned width = static_cast<unsigned>(std::atoi(argv[2])), height = static_cast<unsigned>(std::atoi(argv[3])), depth = static_cast<unsigned>(std::atoi(argv[4]));
     const int frames = std::atoi(argv[5]);
-    Reader in(argv[1]);
-    if (!in.f || in.U32() != 0x314D4C53u) { std::fprintf(stderr, "not a scene file\n"); return 64; }
-    float cam[13];
-    in.Bytes(cam, sizeof cam);
+    // a model file (.ollad / .gltf / .glb) goes through the renderer-side model cache exactly as SceneManager::LoadGLTF does (SceneManager.cpp:56-75); anything
+    // else is this driver's own scene file.  SANDBOX_THREADED=1: StartRendering starts the render thread (the reference's behaviour); default: one frame per
+    // PerformDeferredOperations call, so that the picture is that of exactly <frames> TraceFrames.
+    const std::string scenePath = argv[1];
+    const auto endsWith = [&](const char* e) { const size_t n = std::strlen(e); return scenePath.size() >= n && scenePath.compare(scenePath.size() - n, n, e) == 0; };
+    const bool modelFile = endsWith(".ollad") || endsWith(".gltf") || endsWith(".glb");
+    const bool threaded = std::getenv("SANDBOX_THREADED") != nullptr;
+    float cam[13] = {0.f, 1.f, 3.4f, -1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, -1.f, 90.f};         // the Cornell box pose
+    Reader in(modelFile ? (scenePath + ".cam").c_str() : argv[1]);
+    if (modelFile) { if (in.f) in.Bytes(cam, sizeof cam); }                                          // optional side file: 13 floats (position, right, up, forward, fov)
+    else {
+        if (!in.f || in.U32() != 0x314D4C53u) { std::fprintf(stderr, "not a scene file\n"); return 64; }
+        in.Bytes(cam, sizeof cam);
+    }
 
     // Application.cpp:83-98
     auto renderer = std::make_shared<MI355X::Renderer>();
@@ -50,8 +62,21 @@ int main(int argc, char** argv)
     settings.renderResolution = {width, height};
     settings.outputResolution = {width, height};
     settings.blendOutput = true;
+    settings.renderThread = threaded;
     renderer->Init(settings);
     renderer->CreateDefaultResources();
+
+    std::shared_ptr<Lumen::ILumenScene> scene;
+    unsigned emissiveTriangles = 0;
+    if (modelFile) {
+        // SceneManager::LoadGLTF: first the optimised file, then its creation from the glTF (SceneManager.cpp:56-75)
+        Lumen::SceneManager::GLTFResource res = renderer->OpenCustomFileFormat(scenePath);
+        if (res.m_Path.empty()) res = renderer->CreateCustomFileFormat(scenePath);
+        if (res.m_Path.empty() || res.m_Scenes.empty()) { std::fprintf(stderr, "the renderer could not open %s as a model file\n", scenePath.c_str()); return 65; }
+        scene = res.m_Scenes[0];                                                                     // Application.cpp:143
+        for (auto& mesh : res.m_MeshPool) for (auto& p : mesh->m_Primitives) emissiveTriangles += p->m_NumLights;
+        std::printf("model file: %zu materials, %zu meshes, %zu instances\n", res.m_MaterialPool.size(), res.m_MeshPool.size(), scene->m_MeshInstances.size());
+    } else {
 
     // what SceneManager does per glTF texture / material / primitive / mesh (SceneManager.cpp:277-541,704-822)
     std::vector<std::shared_ptr<Lumen::ILumenTexture>> textures(in.U32());
@@ -79,13 +104,18 @@ int main(int argc, char** argv)
         m = renderer->CreateMaterial(d);
     }
     std::vector<std::shared_ptr<Lumen::ILumenPrimitive>> primitives(in.U32());
-    unsigned emissiveTriangles = 0;
     for (auto& p : primitives) {
         const uint32_t m = in.U32(), nv = in.U32(), ni = in.U32();
         if (m >= materials.size()) { std::fprintf(stderr, "material index out of range\n"); return 64; }
         LumenRenderer::PrimitiveData d;
-        d.m_Interleaved = true;                                   // the 48-byte Vertex layout of ModelStructs.h:21-28
-        d.m_VertexBinary.resize(static_cast<size_t>(nv) * 48); in.Bytes(d.m_VertexBinary.data(), d.m_VertexBinary.size());
+        d.m_Interleaved = true;                                   // `Vertex` records (ModelStructs.h:21-28), filled from the file's 12 floats per vertex
+        d.m_VertexBinary.assign(static_cast<size_t>(nv) * sizeof(Vertex), 0);
+        for (uint32_t v = 0; v < nv; v++) {
+            float f[12]; in.Bytes(f, sizeof f);
+            uint8_t* dst = d.m_VertexBinary.data() + static_cast<size_t>(v) * sizeof(Vertex);
+            std::memcpy(dst + offsetof(Vertex, m_Position), f, 12); std::memcpy(dst + offsetof(Vertex, m_UVCoord), f + 3, 8);
+            std::memcpy(dst + offsetof(Vertex, m_Normal), f + 5, 12); std::memcpy(dst + offsetof(Vertex, m_Tangent), f + 8, 16);
+        }
         d.m_IndexBinary.resize(static_cast<size_t>(ni) * 4); in.Bytes(d.m_IndexBinary.data(), d.m_IndexBinary.size());
         d.m_IndexSize = 4;
         d.m_Material = materials[m];
@@ -99,7 +129,7 @@ int main(int argc, char** argv)
         mesh = renderer->CreateMesh(ps);
     }
     // Application.cpp:134-146: the scene, its instances, the camera
-    std::shared_ptr<Lumen::ILumenScene> scene = renderer->CreateScene();
+    scene = renderer->CreateScene();
     const uint32_t nInst = in.U32();
     for (uint32_t i = 0; i < nInst; i++) {
         const uint32_t m = in.U32();
@@ -114,6 +144,7 @@ int main(int argc, char** argv)
         if (overrideMaterial >= 0) inst->SetOverrideMaterial(materials[static_cast<size_t>(overrideMaterial)]);
         inst->SetEmissiveness(Lumen::MeshInstance::Emissiveness(static_cast<Lumen::EmissionMode>(mode), glm::vec3(rad[0], rad[1], rad[2]), rad[3]));
     }
+    }
     renderer->m_Scene = scene;
     const glm::mat3 basis(glm::vec3(cam[3], cam[4], cam[5]), glm::vec3(cam[6], cam[7], cam[8]), glm::vec3(cam[9], cam[10], cam[11]));   // columns right / up / forward (Camera.cpp:128-140)
     scene->m_Camera->SetRotation(glm::quat_cast(basis));
@@ -123,7 +154,22 @@ int main(int argc, char** argv)
     // calls PerformDeferredOperations once per displayed frame (LumenApp.cpp:50-78 -> OutputLayer.cpp:119-168)
     renderer->SetBlendMode(true);
     renderer->StartRendering();
-    for (int k = 0; k < frames; k++) renderer->PerformDeferredOperations();
+    if (!threaded) for (int k = 0; k < frames; k++) renderer->PerformDeferredOperations();
+    else {
+        // the render thread free-runs; the main loop keeps calling PerformDeferredOperations (LumenApp::Run) and, half way, moves the first instance the way the
+        // tool UI does: the edit must reach the frames traced after it
+        bool moved = false;
+        for (int spins = 0; static_cast<int>(renderer->GetLastFrameStats().m_Id) < frames && spins < 200000; spins++) {
+            renderer->PerformDeferredOperations();
+            if (!moved && static_cast<int>(renderer->GetLastFrameStats().m_Id) >= frames / 2 && !scene->m_MeshInstances.empty() && std::getenv("SANDBOX_MOVE")) {
+                glm::mat4 w = scene->m_MeshInstances[0]->m_Transform.GetWorldTransformationMatrix();
+                w[3].y += 0.25f;
+                scene->m_MeshInstances[0]->m_Transform = w;
+                moved = true;
+            }
+        }
+        if (static_cast<int>(renderer->GetLastFrameStats().m_Id) < frames) { std::fprintf(stderr, "the render thread did not reach %d frames\n", frames); return 66; }
+    }
 
     uint32_t w = 0, h = 0;
     const std::vector<uint8_t> rgba = renderer->GetOutputTexturePixels(w, h);       // OutputLayer.cpp:882-896 (the screenshot path)

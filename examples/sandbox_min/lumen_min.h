@@ -19,6 +19,19 @@
 
 class FrameSnapshot {};
 
+// The vertex of an interleaved PrimitiveData, with the layout the reference's compilers give its `Vertex` (Shaders/CppCommon/ModelStructs.h:21-28): the members there
+// are CUDA's float3 / float2 / float3 / float4, float2 is 8-byte and float4 16-byte aligned, hence 64 bytes with padding after the position and after the normal.
+struct alignas(16) Vertex
+{
+    float m_Position[3];
+    float m_PadAfterPosition;
+    float m_UVCoord[2];
+    float m_Normal[3];
+    float m_PadAfterNormal[3];
+    float m_Tangent[4];
+};
+static_assert(sizeof(Vertex) == 64, "Vertex must have the reference's size");
+
 class Camera
 {
 public:
@@ -174,6 +187,20 @@ namespace Lumen
         virtual void Clear() { m_MeshInstances.clear(); }
         std::vector<std::unique_ptr<MeshInstance>> m_MeshInstances;
         const std::unique_ptr<Camera> m_Camera;
+        std::string m_Name;
+    };
+
+    // what a model file turns into (SceneManager.h:106-122), reduced to the pools the renderer-side loaders fill
+    class SceneManager
+    {
+    public:
+        struct GLTFResource
+        {
+            std::string m_Path;                                         // empty = no file was loaded
+            std::vector<std::shared_ptr<ILumenMesh>> m_MeshPool;
+            std::vector<std::shared_ptr<ILumenMaterial>> m_MaterialPool;
+            std::vector<std::shared_ptr<ILumenScene>> m_Scenes;
+        };
     };
 }
 
@@ -212,8 +239,9 @@ public:
     };
     struct SceneData
     {
-        glm::vec3 m_CameraPosition{0.f, 0.f, 0.f};
-        glm::vec3 m_CameraUp{0.f, 1.f, 0.f};
+        SceneData() : m_CameraPosition(0.f, 0.f, 0.f), m_CameraUp(0.f, 1.f, 0.f) {}      // (a constructor instead of member initialisers: usable as a default argument below)
+        glm::vec3 m_CameraPosition;
+        glm::vec3 m_CameraUp;
     };
 
     LumenRenderer() = default;
@@ -221,11 +249,13 @@ public:
 
     virtual void StartRendering() = 0;
     virtual void PerformDeferredOperations() {}
+    virtual Lumen::SceneManager::GLTFResource OpenCustomFileFormat(const std::string&) { return {}; }      // LumenRenderer.h:154-155: renderer-side model cache
+    virtual Lumen::SceneManager::GLTFResource CreateCustomFileFormat(const std::string&) { return {}; }
     virtual std::unique_ptr<Lumen::ILumenPrimitive> CreatePrimitive(PrimitiveData&) = 0;
     virtual std::shared_ptr<Lumen::ILumenMesh> CreateMesh(std::vector<std::shared_ptr<Lumen::ILumenPrimitive>>&) = 0;
     virtual std::shared_ptr<Lumen::ILumenTexture> CreateTexture(void* rgba8, uint32_t width, uint32_t height, bool normalize) = 0;
     virtual std::shared_ptr<Lumen::ILumenMaterial> CreateMaterial(const MaterialData&) = 0;
-    virtual std::shared_ptr<Lumen::ILumenScene> CreateScene(SceneData) { return std::make_shared<Lumen::ILumenScene>(); }
+    virtual std::shared_ptr<Lumen::ILumenScene> CreateScene(SceneData = SceneData()) { return std::make_shared<Lumen::ILumenScene>(); }
     virtual std::shared_ptr<Lumen::ILumenVolume> CreateVolume(const std::string&) = 0;
     virtual void InitNGX() = 0;
     void CreateDefaultResources()     // three 1x1 textures, not normalised: white, default normal (128,128,255,0), white diffuse

@@ -52,11 +52,15 @@ typedef struct lumen_mi_material_data {
     float transmittance[3];
 } lumen_mi_material_data;
 
-/* LumenRenderer::PrimitiveData (LumenRenderer.h:44-61).  Either interleaved 48-byte vertices
- * (pos3 uv2 normal3 tangent4, ModelStructs.h:21-28) or separate attribute arrays (any of uv/normal/tangent may be NULL). */
+/* LumenRenderer::PrimitiveData (LumenRenderer.h:44-61).  Either interleaved vertices or separate attribute arrays (any of uv/normal/tangent may be NULL).
+ * interleaved: 0 = separate arrays; 1 = 48-byte vertices, tightly packed floats (position 3, uv 2, normal 3, tangent 4);
+ * 2 = the reference's `Vertex` (Shaders/CppCommon/ModelStructs.h:21-28) AS ITS COMPILERS LAY IT OUT: the members are CUDA vector types (`LUMEN` is defined nowhere in
+ * the reference's build), float2 is 8-byte and float4 16-byte aligned, so a Vertex is 64 bytes — position at byte 0, uv at 16, normal at 24, tangent at 48 — which is
+ * what an interleaved PrimitiveData from the reference's model converter (and every .ollad file) carries.  The adapter passes 2. */
+enum { LUMEN_MI_VERTICES_SEPARATE = 0, LUMEN_MI_VERTICES_PACKED48 = 1, LUMEN_MI_VERTICES_REFERENCE64 = 2 };
 typedef struct lumen_mi_primitive_data {
     int32_t interleaved;
-    const void* vertex_binary;      /* interleaved: n_vertices * 48 bytes */
+    const void* vertex_binary;      /* interleaved: n_vertices * 48 (layout 1) or * 64 (layout 2) bytes */
     const float* positions;         /* 3 floats per vertex */
     const float* tex_coords;        /* 2 */
     const float* normals;           /* 3 */
@@ -131,7 +135,8 @@ int lumen_mi_get_gbuffer(lumen_mi_renderer*, float* planes8x4, size_t capacity_b
  * (Camera.h:60 default {0.1, 1000}) as fp32, normal.xyz + roughness as half4, motion vector as half2; any pointer may be NULL */
 int lumen_mi_get_denoiser_inputs(lumen_mi_renderer*, float min_distance, float max_distance, float* depth, uint16_t* normal_roughness_half4, uint16_t* motion_half2);
 
-/* FrameStats (LumenRenderer.h:29-34, GetLastFrameStats :203): key/value pairs in microseconds under the reference's key names */
+/* FrameStats (LumenRenderer.h:29-34, GetLastFrameStats :203): key/value pairs in microseconds under the reference's key names; plus the key "Frames Traced" =
+ * the number of TraceFrames enqueued since the renderer was created (what FrameStats::m_Id counts; readable while the render thread runs) */
 int lumen_mi_get_frame_stat(lumen_mi_renderer*, const char* key, uint64_t* microseconds);
 /* counters of the last completed frame: [0] closest-hit rays, [1] NEE shadow rays, [2] ReSTIR shadow rays, [3] lights,
  * [4..4+depth) rays per wave, [20] BVH nodes visited in binary-node equivalents (= [22] / 2), [21] triangles tested,

@@ -22,6 +22,8 @@
 #include "Lumen/ModelLoading/MeshInstance.h"
 #include "Lumen/Renderer/Camera.h"
 #include "Tools/FrameSnapshot.h"            // LumenPT/src: EndSnapshot() returns a unique_ptr of the complete type
+#include "Shaders/CppCommon/ModelStructs.h" // LumenPT/src: struct Vertex — what an interleaved PrimitiveData holds (64 bytes under CUDA's vector-type alignment)
+#include "Tools/LumenPTModelConverter.h"    // LumenPT/src: the reference's own .ollad reader / glTF converter — plain host C++ that only needs a LumenRenderer&
 
 #include <glm/glm.hpp>
 #include <glm/gtc/type_ptr.hpp>
@@ -29,6 +31,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
+#include <string>
 #include <vector>
 
 namespace MI355X
@@ -197,30 +200,66 @@ namespace MI355X
     {
     public:
         // WaveFrontSettings (LumenPT/src/Framework/WaveFrontRenderer.h:31-48) without the PTX paths
-        struct Settings { unsigned depth = 5; glm::uvec2 renderResolution{1280, 720}; glm::uvec2 outputResolution{1280, 720}; bool blendOutput = false; int device = 0; };
+        // renderThread: true (the reference's behaviour) = StartRendering starts a render thread that loops TraceFrame (WaveFrontRenderer.cpp:1109-1117);
+        // false = frames are traced from PerformDeferredOperations on the caller's thread, one per call (deterministic frame counts: tests, offline rendering)
+        struct Settings { unsigned depth = 5; glm::uvec2 renderResolution{1280, 720}; glm::uvec2 outputResolution{1280, 720}; bool blendOutput = false; int device = 0; bool renderThread = true; };
 
         Renderer() { Check(lumen_mi_create(&m_R), "create"); }
-        ~Renderer() override { lumen_mi_destroy(m_R); }
+        ~Renderer() override { if (m_ThreadRunning) lumen_mi_stop_rendering(m_R); lumen_mi_destroy(m_R); }      // WaveFrontRenderer.cpp:1360-1371: the thread is joined first
 
         void Init(const Settings& s)
         {
             lumen_mi_settings c{s.depth, s.renderResolution.x, s.renderResolution.y, s.outputResolution.x, s.outputResolution.y, s.blendOutput ? 1 : 0, s.device};
             Check(lumen_mi_init(m_R, &c), "init");
+            m_UseThread = s.renderThread;
+            AttachModelConverter();                                         // WaveFrontRenderer.cpp:305
         }
 
-        void StartRendering() override { m_Threaded = true; /* frames are driven from PerformDeferredOperations so that scene edits are picked up */ }
-        void PerformDeferredOperations() override { if (m_Threaded) TraceFrame(); }
+        // The model cache the reference's SceneManager::LoadGLTF asks for FIRST (SceneManager.cpp:56-64): `<model>.ollad` beside the glTF, read — or written from
+        // the glTF and then read — by LumenPTModelConverter, which creates every texture / material / primitive / mesh / scene through this renderer's own
+        // virtuals: base-colour and emissive maps sRGB-decoded, no V flip, 48-byte interleaved vertices.  WaveFrontRenderer.cpp:1135-1146.
+        Lumen::SceneManager::GLTFResource OpenCustomFileFormat(const std::string& originalFilePath) override
+        {
+            std::string p = originalFilePath;
+            const size_t dot = p.find_last_of('.'), slash = p.find_last_of("/\\");
+            if (dot != std::string::npos && (slash == std::string::npos || dot > slash)) p.erase(dot);      // std::filesystem::path::replace_extension
+            AttachModelConverter();
+            return m_ModelConverter.LoadFile(p + LumenPTModelConverter::ms_ExtensionName);
+        }
+        Lumen::SceneManager::GLTFResource CreateCustomFileFormat(const std::string& originalFilePath) override { AttachModelConverter(); return m_ModelConverter.ConvertGLTF(originalFilePath); }
+
+        // StartRendering (LumenRenderer.h:151): the render thread of the C ABI loops TraceFrame; the application keeps editing m_Scene on its own thread
+        // and PerformDeferredOperations — called once per displayed frame by LumenApp::Run — pushes those edits (instance transforms, emissiveness, override
+        // materials, camera) through the C ABI's setters, which serialise with the frame in flight; the next TraceFrame picks them up through the scene's
+        // dirty flags, as the reference's does (PTMeshInstance.cpp:28-49,123-178; PTScene.cpp:62-72).
+        void StartRendering() override
+        {
+            m_Started = true;
+            if (!m_UseThread) return;
+            PushSceneState();
+            Check(lumen_mi_start_rendering(m_R), "start_rendering");
+            m_ThreadRunning = true;
+        }
+        void PerformDeferredOperations() override
+        {
+            if (!m_Started) return;
+            if (m_ThreadRunning) { PushSceneState(); CollectFrameStats(); }
+            else TraceFrame();
+        }
 
         std::unique_ptr<Lumen::ILumenPrimitive> CreatePrimitive(PrimitiveData& d) override
         {
             lumen_mi_primitive_data c{};
-            c.interleaved = d.m_Interleaved ? 1 : 0;
+            // interleaved vertices are the reference's own `Vertex` records, whatever the compiler makes of them: 64 bytes with CUDA's aligned vector types
+            // (the reference's build), 48 if a build ever packs it
+            static_assert(sizeof(Vertex) == 64 || sizeof(Vertex) == 48, "unexpected Vertex layout");
+            c.interleaved = d.m_Interleaved ? (sizeof(Vertex) == 64 ? LUMEN_MI_VERTICES_REFERENCE64 : LUMEN_MI_VERTICES_PACKED48) : LUMEN_MI_VERTICES_SEPARATE;
             c.vertex_binary = d.m_VertexBinary.data();
-            c.positions = reinterpret_cast<const float*>(&d.m_Positions[0]);
+            c.positions = d.m_Positions.Empty() ? nullptr : reinterpret_cast<const float*>(&d.m_Positions[0]);      // (an interleaved primitive has no attribute views: VectorView::operator[] asserts on them)
             c.tex_coords = d.m_TexCoords.Empty() ? nullptr : reinterpret_cast<const float*>(&d.m_TexCoords[0]);
             c.normals = d.m_Normals.Empty() ? nullptr : reinterpret_cast<const float*>(&d.m_Normals[0]);
             c.tangents = d.m_Tangents.Empty() ? nullptr : reinterpret_cast<const float*>(&d.m_Tangents[0]);
-            c.n_vertices = static_cast<uint32_t>(d.m_Interleaved ? d.m_VertexBinary.size() / 48 : d.m_Positions.Size());
+            c.n_vertices = static_cast<uint32_t>(d.m_Interleaved ? d.m_VertexBinary.size() / sizeof(Vertex) : d.m_Positions.Size());
             c.index_binary = d.m_IndexBinary.data();
             c.index_size = static_cast<uint32_t>(d.m_IndexSize);
             c.n_indices = static_cast<uint32_t>(d.m_IndexBinary.size() / d.m_IndexSize);
@@ -274,7 +313,18 @@ namespace MI355X
         // body of WaveFrontRenderer::TraceFrame: push the app-side scene state, then render one frame
         void TraceFrame()
         {
-            if (!m_Scene) return;
+            if (!PushSceneState()) return;
+            Check(lumen_mi_trace_frame(m_R), "trace_frame");
+            CollectFrameStats();
+        }
+
+        lumen_mi_renderer* Native() { return m_R; }
+
+    private:
+        // what the application edits directly on m_Scene (instance transforms, camera), sent to the native scene
+        bool PushSceneState()
+        {
+            if (!m_Scene) return false;
             auto* scene = static_cast<Scene*>(m_Scene.get());
             Check(lumen_mi_set_scene(m_R, scene->m_Handle), "set_scene");
             for (auto& mi : scene->m_MeshInstances) static_cast<MeshInstance*>(mi.get())->Sync();
@@ -282,17 +332,24 @@ namespace MI355X
             scene->m_Camera->GetMatrixData(prev, cur);            // columns: right, up, forward, position (Camera.cpp:122-140)
             const float pos[3] = {cur[3].x, cur[3].y, cur[3].z}, right[3] = {cur[0].x, cur[0].y, cur[0].z}, up[3] = {cur[1].x, cur[1].y, cur[1].z}, fwd[3] = {cur[2].x, cur[2].y, cur[2].z};
             Check(lumen_mi_camera_set(m_R, pos, right, up, fwd, 90.0f), "camera_set");   // Camera::m_FovY is fixed at 90 (Camera.h:63)
-            Check(lumen_mi_trace_frame(m_R), "trace_frame");
+            return true;
+        }
+        void CollectFrameStats()
+        {
+            uint64_t frames = 0;
+            const bool haveCount = lumen_mi_get_frame_stat(m_R, "Frames Traced", &frames) == LUMEN_MI_OK;
             std::lock_guard<std::mutex> lk(m_FrameStatsMutex);
             static const char* keys[] = {"Wavefront Iteration", "Shadow Rays", "ReSTIR", "Total Frame Time"};
             for (const char* k : keys) { uint64_t us = 0; if (lumen_mi_get_frame_stat(m_R, k, &us) == LUMEN_MI_OK) m_LastFrameStats.m_Times[k] = us; }
-            ++m_LastFrameStats.m_Id;
+            if (haveCount) m_LastFrameStats.m_Id = frames; else ++m_LastFrameStats.m_Id;      // FrameStats::m_Id counts traced frames (WaveFrontRenderer.cpp:1078-1083)
         }
 
-        lumen_mi_renderer* Native() { return m_R; }
+        // the converter creates its four default 1x1 textures through this renderer (LumenPTModelConverter::SetRendererRef); resources are host-side objects of the
+        // C ABI, so a model may be loaded before Init (once: the reference attaches in Init, WaveFrontRenderer.cpp:305)
+        void AttachModelConverter() { if (!m_ConverterAttached) { m_ConverterAttached = true; m_ModelConverter.SetRendererRef(*this); } }
 
-    private:
         lumen_mi_renderer* m_R = nullptr;
-        bool m_Threaded = false;
+        LumenPTModelConverter m_ModelConverter;
+        bool m_UseThread = true, m_Started = false, m_ThreadRunning = false, m_ConverterAttached = false;
     };
 }  // namespace MI355X

@@ -361,7 +361,7 @@ int traceFrameAsync(R* r)
             // (automatic: on small windows, where the tail is the longest launch of the frame — 1/4 tile of 1440p +4.8 %, 1/8 tile +1.6 %; off from
             // 1.5 Mpixel, where it hides behind the other streams and 64 paths per wavefront cost fewer issue slots: profiles/r03_tail_pair_ab.txt)
             const bool pair = r->tailPair > 0 || (r->tailPair < 0 && fr.n < 1500000u);
-            const int tailShape = pair ? -std::min(32, tailL) : tailL;
+            const int tailShape = r->tailRepack > 0 ? 1000 : pair ? -std::min(32, tailL) : tailL;      // 1000: the repacking variant (tuning key tail_repack, kernels.hip)
             evBegin2(r, 5, ev, stl);
             Z(stl); K->path_tail(stl, r->numCU * 8, sct, withTailQueue(fr, q), q | (r->fastShade ? 2 : 0), inCount, (int)depth, (int)depthMax, seed, tailShape);
             evEnd2(r, ev, stl);
@@ -423,6 +423,7 @@ int traceFrameAsync(R* r)
     r->lastGbuf = r->gbufIndex; r->gbufIndex = (r->gbufIndex + 1) % 3;
     memcpy(r->prevCamWorld, camWorld, sizeof camWorld);                                      // :1051
     ++r->frameCount;                                                                         // :1052
+    r->framesTraced.fetch_add(1);
     return 0;
 }
 

@@ -498,6 +498,106 @@ __device__ __forceinline__ void lm_path_tail_body(const LmScene& sc, const LmFra
     }
     }
 }
+// REPACK variant (tuning key tail_repack): a block takes 256 paths, one per lane, and after every depth the surviving paths are packed
+// into the block's lowest lanes through LDS (40 bytes of path state: origin, direction, contribution, pixel), so that a wavefront is either full or has no path
+// at all — it then skips the depth and only meets the barriers.  Same device functions, RNG streams and per-pixel order of the INDIRECT adds (a pixel has one
+// path; its adds are separated by the block barriers): identical image and counters.  Cost: three block barriers per depth, i.e. a depth takes as long as the
+// block's slowest wavefront (the plain variant lets every wavefront run ahead on its own).  A/B: profiles/r04_tail_repack_ab.txt.
+template <class NEE>
+__device__ __forceinline__ void lm_path_tail_repack_body(const LmScene& sc, const LmFrame& fr, int inQ, const uint32_t* __restrict__ inCount, int depth0, int depthMax, uint32_t seed0)
+{
+    __shared__ int s_stack[LM_STACK_LDS * LM_BLOCK];
+    __shared__ float s_lut[256];
+    __shared__ uint4 s_tab[LM_TABLE_QUADS];
+    __shared__ uint32_t s_pack[10 * LM_BLOCK];                   // [word][slot]: consecutive lanes touch consecutive banks
+    __shared__ uint32_t s_cnt[LM_BLOCK / 64];
+    const lm_lds_float* lut = lm_stage_lut(s_lut, sc);
+    const LmTables tab = lm_stage_tables(s_tab, sc);
+    const LmStack stack = lm_make_stack(s_stack, sc);
+    const uint32_t n = *inCount;
+    __builtin_amdgcn_s_setprio(3);
+    const uint32_t lane = lm_lane(), wave = threadIdx.x >> 6;
+    for (uint32_t base = blockIdx.x * LM_BLOCK; base < n; base += gridDim.x * LM_BLOCK) {     // block-uniform
+        const uint32_t i = base + threadIdx.x;
+        bool alive = i < n;
+        lf3 o = v3(0.f), d = v3(0.f), c = v3(0.f);
+        uint32_t li = 0u;
+        if (alive) {
+            const float4 o4 = fr.rayO[inQ][i], d4 = fr.rayD[inQ][i], c4 = fr.rayC[inQ][i];
+            o = v3(o4); d = v3(d4); c = v3(c4); li = f2u(d4.w);
+        }
+        uint32_t seed = seed0;
+        uint32_t live = min(n - base, (uint32_t)LM_BLOCK);        // paths the block still carries (block-uniform); they sit in threads [0, live)
+        for (int depth = depth0; depth < depthMax && live != 0u; depth++) {
+            const uint32_t seed2 = lm_wang_hash(seed);
+            bool emitRay = false;
+            lf3 o2 = v3(0.f), d2 = v3(0.f), c2 = v3(0.f);
+            if (wave * 64u < live) {                              // wave-uniform: this wavefront holds paths
+                if (depth > depth0) lm_count(fr.counters + LM_CNT_RAYS(depth), alive);
+                bool emitShadow = false;
+                lf3 sdir = v3(0.f), srad = v3(0.f), spos = v3(0.f);
+                float stmax = 0.f;
+                if (alive) {
+                    LmHit h; h.t = -1.f; h.u = 0.f; h.v = 0.f; h.slot = 0;
+                    const bool found = lm_traverse<false>(sc, o, d, 0.01f, 5000.f, stack, h, fr.counters);
+                    uint4 rec = make_uint4(0u, 0u, 0u, f2u(-1.f));
+                    if (found) {
+                        const uint2 id = sc.triId[h.slot];
+                        rec = make_uint4(id.x, id.y, lm_f32_to_f16(h.u) | (lm_f32_to_f16(h.v) << 16), f2u(h.t));
+                    }
+                    LmSurface s;
+                    lm_extract(sc, lut, tab, rec, o, d, c, s);
+                    const uint32_t ly = li / fr.ww, lx = li - ly * fr.ww;
+                    const uint32_t gi = (fr.y0 + ly) * fr.W + (fr.x0 + lx);
+                    emitShadow = lm_shade_direct<NEE>(sc, s, gi, seed, sdir, stmax, srad);
+                    spos = s.position;
+                    if (depth < depthMax - 1) emitRay = lm_shade_indirect(s, gi, seed2, o2, d2, c2);
+                }
+                lm_count(fr.counters + LM_CNT_SHADOW(depth), emitShadow);
+                if (emitShadow) {
+                    LmHit hs;
+                    if (!lm_traverse<true>(sc, spos, sdir, 0.01f, stmax, stack, hs, fr.counters)) {
+                        float4 px = fr.indirect[li];
+                        px.x += srad.x; px.y += srad.y; px.z += srad.z;
+                        fr.indirect[li] = px;
+                    }
+                }
+            }
+            // pack the continuing paths into the lowest threads of the block
+            const unsigned long long mask = __ballot(emitRay);
+            if (lane == 0u) s_cnt[wave] = (uint32_t)__popcll(mask);
+            __syncthreads();
+            uint32_t before = 0u, total = 0u;
+#pragma unroll
+            for (uint32_t w = 0; w < LM_BLOCK / 64u; w++) { const uint32_t k = s_cnt[w]; before += w < wave ? k : 0u; total += k; }
+            if (emitRay) {
+                const uint32_t slot = before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                s_pack[slot] = f2u(o2.x); s_pack[LM_BLOCK + slot] = f2u(o2.y); s_pack[2 * LM_BLOCK + slot] = f2u(o2.z);
+                s_pack[3 * LM_BLOCK + slot] = f2u(d2.x); s_pack[4 * LM_BLOCK + slot] = f2u(d2.y); s_pack[5 * LM_BLOCK + slot] = f2u(d2.z);
+                s_pack[6 * LM_BLOCK + slot] = f2u(c2.x); s_pack[7 * LM_BLOCK + slot] = f2u(c2.y); s_pack[8 * LM_BLOCK + slot] = f2u(c2.z);
+                s_pack[9 * LM_BLOCK + slot] = li;
+            }
+            __syncthreads();
+            alive = threadIdx.x < total;
+            if (alive) {
+                const uint32_t t = threadIdx.x;
+                o = v3(u2f(s_pack[t]), u2f(s_pack[LM_BLOCK + t]), u2f(s_pack[2 * LM_BLOCK + t]));
+                d = v3(u2f(s_pack[3 * LM_BLOCK + t]), u2f(s_pack[4 * LM_BLOCK + t]), u2f(s_pack[5 * LM_BLOCK + t]));
+                c = v3(u2f(s_pack[6 * LM_BLOCK + t]), u2f(s_pack[7 * LM_BLOCK + t]), u2f(s_pack[8 * LM_BLOCK + t]));
+                li = s_pack[9 * LM_BLOCK + t];
+            }
+            live = total;
+            __syncthreads();                                      // s_cnt / s_pack are rewritten in the next depth (and the INDIRECT adds of this depth are visible to it)
+            seed = lm_wang_hash(seed);
+        }
+    }
+}
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_path_tail_repack)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict__ inCount, int depth0, int depthMax, uint32_t seed0)
+{ lm_path_tail_repack_body<LmExact>(sc, fr, inQ, inCount, depth0, depthMax, seed0); }
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_path_tail_repack_fs)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict__ inCount, int depth0, int depthMax, uint32_t seed0)
+{ lm_path_tail_repack_body<LmFast>(sc, fr, inQ, inCount, depth0, depthMax, seed0); }
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
 KN(lm_k_path_tail)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict__ inCount, int depth0, int depthMax, uint32_t seed0, int lanesPerWave)
 { lm_path_tail_body<false, LmExact>(sc, fr, inQ, inCount, depth0, depthMax, seed0, lanesPerWave); }
@@ -1847,6 +1947,11 @@ static void l_shade_wave(hipStream_t s, int g, LmScene sc, LmFrame fr, int inQ, 
 static void l_path_tail(hipStream_t s, int g, LmScene sc, LmFrame fr, int inQ, const uint32_t* inCount, int depth0, int depthMax, uint32_t seed0, int lanesPerWave)
 {
     const bool fs = (inQ & 2) != 0; inQ &= 1;
+    if (lanesPerWave >= 1000) {      // tuning key tail_repack: 256 paths per block, repacked after every depth
+        if (fs) hipLaunchKernelGGL(KN(lm_k_path_tail_repack_fs), LM_GRID(g), sc, fr, inQ, inCount, depth0, depthMax, seed0);
+        else hipLaunchKernelGGL(KN(lm_k_path_tail_repack), LM_GRID(g), sc, fr, inQ, inCount, depth0, depthMax, seed0);
+        return;
+    }
     if (lanesPerWave < 0) { if (fs) hipLaunchKernelGGL(KN(lm_k_path_tail_pair_fs), LM_GRID(g), sc, fr, inQ, inCount, depth0, depthMax, seed0, lanesPerWave);
                             else hipLaunchKernelGGL(KN(lm_k_path_tail_pair), LM_GRID(g), sc, fr, inQ, inCount, depth0, depthMax, seed0, lanesPerWave); }
     else if (fs) hipLaunchKernelGGL(KN(lm_k_path_tail_fs), LM_GRID(g), sc, fr, inQ, inCount, depth0, depthMax, seed0, lanesPerWave);

@@ -28,6 +28,7 @@ int lumen_mi_create(lumen_mi_renderer** out)
     if (const char* e = getenv("LUMEN_MI_PACKET_PRIMARY")) (*out)->packetPrimary = atoi(e);
     if (const char* e = getenv("LUMEN_MI_FAST_SHADE")) (*out)->fastShade = atoi(e);
     if (const char* e = getenv("LUMEN_MI_SPATIAL_LDS")) (*out)->spatialLds = atoi(e);
+    if (const char* e = getenv("LUMEN_MI_TAIL_REPACK")) (*out)->tailRepack = atoi(e);
     if (const char* e = getenv("LUMEN_MI_LAZY_REUSE")) (*out)->lazyReuse = std::max(-1, std::min(1, atoi(e)));      // (2 = the deliberately wrong test mode: tuning key only)
     if (const char* e = getenv("LUMEN_MI_FUSE_PRIMARY")) (*out)->fusePrimary = atoi(e);
     if (const char* e = getenv("LUMEN_MI_PACKET_VISIBILITY")) (*out)->packetVisibility = atoi(e);
@@ -248,9 +249,18 @@ int lumen_mi_create_primitive(lumen_mi_renderer* r, const lumen_mi_primitive_dat
     Primitive p;
     p.material = mat;
     p.verts.resize(d->n_vertices);
-    if (d->interleaved) {
+    if (d->interleaved == LUMEN_MI_VERTICES_REFERENCE64) {
+        // the reference's Vertex under CUDA's alignment rules (ModelStructs.h:21-28): position @0, uv @16, normal @24, tangent @48, 64 bytes
+        if (!d->vertex_binary) return fail(LUMEN_MI_ERR_INVALID, "interleaved primitive without vertex_binary");
+        const uint8_t* src = (const uint8_t*)d->vertex_binary;
+        for (uint32_t i = 0; i < d->n_vertices; i++, src += 64) {
+            memcpy(p.verts[i].pos, src, 12); memcpy(p.verts[i].uv, src + 16, 8); memcpy(p.verts[i].normal, src + 24, 12); memcpy(p.verts[i].tangent, src + 48, 16);
+        }
+    } else if (d->interleaved == LUMEN_MI_VERTICES_PACKED48) {
         if (!d->vertex_binary) return fail(LUMEN_MI_ERR_INVALID, "interleaved primitive without vertex_binary");
         memcpy(p.verts.data(), d->vertex_binary, (size_t)d->n_vertices * 48);
+    } else if (d->interleaved != LUMEN_MI_VERTICES_SEPARATE) {
+        return fail(LUMEN_MI_ERR_INVALID, "unknown vertex layout");
     } else {
         // InterleaveVertexData (WaveFrontRenderer.cpp:1091-1107): absent attributes stay zero
         if (!d->positions) return fail(LUMEN_MI_ERR_INVALID, "primitive without positions");
@@ -566,6 +576,8 @@ int lumen_mi_get_denoiser_inputs(lumen_mi_renderer* r, float minD, float maxD, f
 int lumen_mi_get_frame_stat(lumen_mi_renderer* r, const char* key, uint64_t* us)
 {
     if (!r || !key || !us) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    if (std::string(key) == "Frames Traced") { *us = r->framesTraced.load(); return 0; }      // TraceFrames enqueued since the renderer was created (FrameStats::m_Id of the adapter)
+    ApiLock lk(r);                                  // the render thread rewrites the map when it collects a frame's events
     auto it = r->frameStats.find(key);
     if (it == r->frameStats.end()) return fail(LUMEN_MI_ERR_INVALID, std::string("no such frame-stat key: ") + key);
     *us = it->second;
@@ -649,6 +661,7 @@ int lumen_mi_set_tuning(lumen_mi_renderer* r, const char* key, int value)
     else if (k == "packet_primary") r->packetPrimary = value;
     else if (k == "packet_visibility") r->packetVisibility = value;
     else if (k == "spatial_lds") r->spatialLds = value;
+    else if (k == "tail_repack") r->tailRepack = value;
     else if (k == "lazy_reuse") r->lazyReuse = value;
     else if (k == "fuse_primary") r->fusePrimary = value;
     else if (k == "fast_shade") r->fastShade = value;

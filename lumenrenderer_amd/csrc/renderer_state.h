@@ -196,6 +196,8 @@ struct lumen_mi_renderer {
                                             // Same image; measured - 0.3 % (profiles/r03_fuse_primary_ab.txt): the launch it saves only waited for slots the traversal then waits for
     int lazyReuse = -1;
     struct OwedReuse { bool valid = false; LmFrame fr{}; int gbuf = 0; uint32_t seed = 0; int fast = 0; int tiles = 0; } owed;
+    std::atomic<uint64_t> framesTraced{0};   // TraceFrames enqueued since creation (frame-stat key "Frames Traced")
+    int tailRepack = 0;                     // path tail: 1 = the repacking variant (256 paths per block, survivors packed through LDS after every depth); 0 = one path per lane to the end
     int spatialLds = 0;                     // fast mode: the first spatial pass stages its probe window in LDS (lm_k_restir_spatial_fast_lds): 1 on, 0 off
     int packetVisibility = 0;               // the ReSTIR visibility rays likewise (lm_k_restir_trace_shade_packet): 1 on, 0 off (default), -1 the primary wave's rule.
                                             // Measured 3x SLOWER on C2 (profiles/r03_packet_visibility_ab.txt): a tile's visibility rays start on surfaces at very

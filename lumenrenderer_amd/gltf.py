@@ -67,19 +67,33 @@ def _read_container(path):
 
 
 def _node_local(node):
-    if "matrix" in node:
-        return np.asarray(node["matrix"], np.float64).reshape(4, 4).T      # glTF matrices are column-major
-    T, R, S = np.eye(4), np.eye(4), np.eye(4)
-    if "translation" in node:
-        T[:3, 3] = node["translation"]
-    if "rotation" in node:
-        x, y, z, w = node["rotation"]
-        R[:3, :3] = [[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
-                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
-                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]]
-    if "scale" in node:
-        S[0, 0], S[1, 1], S[2, 2] = node["scale"]
-    return T @ R @ S
+    """Local matrix of a glTF node in FLOAT32 with the reference's arithmetic (LumenPTModelConverter::LoadNodeTransform, LumenPTModelConverter.cpp:994-1023 ->
+    Lumen::Transform::UpdateLocalMatrix, Transform.cpp:265-280): a `matrix` is taken as given; otherwise glm::translate(I, t) * glm::mat4_cast(q), then
+    glm::scale(., s), every product and sum rounded to float in glm's order.  Row-major numpy array [row][column].  Pinned in round 4 against the .ollad file the
+    reference's own converter writes (tests/test_cpu_host.py): the node matrices in it are bit-identical."""
+    f = np.float32
+    if "matrix" in node and not np.array_equal(np.asarray(node["matrix"], np.float32), np.eye(4, dtype=np.float32).ravel()):
+        return np.asarray(node["matrix"], np.float32).reshape(4, 4).T      # glTF matrices are column-major
+    t = [f(v) for v in node.get("translation", (0, 0, 0))]
+    x, y, z, w = [f(v) for v in node.get("rotation", (0, 0, 0, 1))]
+    s = [f(v) for v in node.get("scale", (1, 1, 1))]
+    one, two = f(1), f(2)
+    qxx, qyy, qzz, qxz, qxy, qyz, qwx, qwy, qwz = x * x, y * y, z * z, x * z, x * y, y * z, w * x, w * y, w * z
+    # glm::mat3_cast (gtc/quaternion.inl): columns of the rotation
+    c0 = [one - two * (qyy + qzz), two * (qxy + qwz), two * (qxz - qwy)]
+    c1 = [two * (qxy - qwz), one - two * (qxx + qzz), two * (qyz + qwx)]
+    c2 = [two * (qxz + qwy), two * (qyz - qwx), one - two * (qxx + qyy)]
+    rot = np.zeros((4, 4), np.float32)                                      # [column][row], glm's storage
+    rot[0, :3], rot[1, :3], rot[2, :3], rot[3, 3] = c0, c1, c2, one
+    tr = np.eye(4, dtype=np.float32); tr[3, :3] = t                         # glm::translate(I, t): column 3 = I0*tx + I1*ty + I2*tz + I3, exact
+    m = np.zeros((4, 4), np.float32)                                        # translate * rotation: Result[c] = A0*B[c][0] + A1*B[c][1] + A2*B[c][2] + A3*B[c][3], summed left to right
+    for c in range(4):
+        acc = tr[0] * rot[c, 0]
+        acc = (acc + tr[1] * rot[c, 1]).astype(np.float32)
+        acc = (acc + tr[2] * rot[c, 2]).astype(np.float32)
+        m[c] = (acc + tr[3] * rot[c, 3]).astype(np.float32)
+    m[0] = m[0] * s[0]; m[1] = m[1] * s[1]; m[2] = m[2] * s[2]              # glm::scale: the first three columns scaled
+    return m.T.copy()                                                       # -> [row][column]
 
 
 def compose(parent, local):
@@ -199,9 +213,15 @@ def load_gltf(path, image_loader=None):
 
     def walk(ni, parent):
         node = doc["nodes"][ni]
-        world = compose(parent, _node_local(node).astype(np.float32))      # local matrices are stored as floats (.ollad node header)
+        local = _node_local(node).astype(np.float32)                       # local matrices are stored as floats (.ollad node header)
+        world = compose(parent, local)
         if "mesh" in node:
             d.add_instance(meshes[node["mesh"]], world)
+            # Reference quirk (LumenPTModelConverter::LoadNode, LumenPTModelConverter.cpp:275-316): for a node WITH a mesh only the mesh instance's transform is
+            # attached to the parent's (:296-297); the node's own transform, which its children attach to, stays without a parent.  Children of a mesh node
+            # therefore inherit that node's LOCAL matrix only — the ancestors above it drop out (the wheels of the Cesium milk truck lose the root's Y-up
+            # correction).  Reproduced; pinned by running the reference's own loader (tests/test_cpu_host.py).
+            world = local
         for c in node.get("children", []):
             walk(c, world)
 

@@ -11,11 +11,13 @@ nodes, :336-560 content, :563-621 header / output; structs LumenPTModelConverter
              u64 nMesh  { u32 nPrim, { u64 vtxOffset, u64 vtxBytes, u64 idxOffset, u64 idxBytes, u32 indexSize, u32 materialId } x nPrim } x nMesh
              u64 nScene { u32 nRootNodes, u32 nameLength, name, nodes depth-first:
                           { u32 nameLength, u32 nChildren, f32[16] local matrix (column-major), i32 meshId (-1 = none) }, name, children ... }
-    blob:    the image files as they are (PNG / JPEG, decoded at load time), interleaved 48-byte vertices
-             (position 3f, uv 2f, normal 3f, tangent 4f), raw indices (16 or 32 bit)
+    blob:    the image files as they are (PNG / JPEG, decoded at load time), interleaved 64-BYTE vertices, raw indices (16 or 32 bit)
 
-No ``.ollad`` file ships with the reference, so the byte layout is pinned by its reader / writer source only; the tests
-round-trip the reference's sample glTF assets (glTF -> .ollad -> scene) against the direct glTF ingest of ``gltf.py``.
+The vertex record is the reference's ``Vertex`` (Shaders/CppCommon/ModelStructs.h:21-28) as its compilers lay it out.  ``LUMEN`` is defined nowhere in
+the reference's build, so the members are CUDA's vector types, whose float2 is 8-byte and float4 16-byte aligned: position 3f at byte 0, uv 2f at 16,
+normal 3f at 24, tangent 4f at 48, zero padding in between — 64 bytes, not the 48 a packed struct would take (rounds 1-3 wrote 48).  Pinned in round 4 by
+running the reference's own converter: tests/test_cpu_host.py builds SceneManager.cpp + LumenPTModelConverter.cpp from the mounted tree, lets them
+convert CornellBox/scene.gltf, and holds this module's writer to the file they wrote, byte for byte.
 """
 import base64
 import os
@@ -29,6 +31,24 @@ from .scenes import SceneDescription, generate_tangents, interleave
 
 # TextureType (LumenPTModelConverter.h:66-77)
 T_UNSPECIFIED, T_DIFFUSE, T_NORMAL, T_EMISSIVE, T_METAL_ROUGHNESS, T_TRANSMISSIVE, T_CLEARCOAT, T_CLEARCOAT_ROUGHNESS, T_TINT = range(9)
+
+VERTEX_STRIDE = 64                               # sizeof(Vertex) under CUDA's alignment rules (see the module docstring)
+
+
+def pack_vertices(v12):
+    """[n][12] floats (position uv normal tangent, the 48-byte order every other module uses) -> the file's 64-byte records"""
+    v12 = np.ascontiguousarray(v12, "<f4").reshape(-1, 12)
+    out = np.zeros((v12.shape[0], 16), "<f4")
+    out[:, 0:3] = v12[:, 0:3]; out[:, 4:6] = v12[:, 3:5]; out[:, 6:9] = v12[:, 5:8]; out[:, 12:16] = v12[:, 8:12]
+    return out.tobytes()
+
+
+def unpack_vertices(raw):
+    if len(raw) % VERTEX_STRIDE:
+        raise ValueError(f"vertex buffer of {len(raw)} bytes is not a whole number of {VERTEX_STRIDE}-byte vertices")
+    v = np.frombuffer(raw, "<f4").reshape(-1, 16)
+    return np.ascontiguousarray(np.concatenate([v[:, 0:3], v[:, 4:6], v[:, 6:9], v[:, 12:16]], axis=1), np.float32)
+
 
 _MAT = struct.Struct("<4f3f8i13f3f3f")          # HeaderMaterial, 136 bytes
 _PRIM = struct.Struct("<4Q2I")                  # HeaderPrimitive, 40 bytes
@@ -119,7 +139,7 @@ def write_ollad(gltf_path, dst_path):
                 tang = _gltf._accessor(doc, buffers, at["TANGENT"]).astype(np.float32)
             else:
                 tang = generate_tangents(pos, nrm if nrm is not None else np.tile(np.float32([0, 1, 0]), (len(pos), 1)), uv, idx)
-            v_off, v_size = put(interleave(pos, uv, nrm, tang).astype("<f4").tobytes())
+            v_off, v_size = put(pack_vertices(interleave(pos, uv, nrm, tang)))
             i_off, i_size = put(idx.astype("<u2" if index_size == 2 else "<u4").tobytes())
             prims.append(_PRIM.pack(v_off, v_size, i_off, i_size, index_size, p.get("material", 0)))
         meshes.append(prims)
@@ -205,7 +225,7 @@ def read_ollad(path, image_loader=None, scene=0):
         prims = []
         for _ in range(n_prim):
             v_off, v_size, i_off, i_size, index_size, material = take("<4Q2I")
-            verts = np.frombuffer(blob[v_off: v_off + v_size], "<f4").reshape(-1, 12).copy()
+            verts = unpack_vertices(bytes(blob[v_off: v_off + v_size]))
             idx = np.frombuffer(blob[i_off: i_off + i_size], "<u2" if index_size == 2 else "<u4").astype(np.uint32)
             prims.append(d.add_primitive(verts, idx, mats[material], index_size))
         meshes.append(d.add_mesh(prims))
@@ -218,8 +238,10 @@ def read_ollad(path, image_loader=None, scene=0):
         local = np.asarray(rest[:16], np.float32).reshape(4, 4).T            # glm::make_mat4: column-major
         mesh_id = rest[16]
         world = _gltf.compose(parent, local)
-        if keep and mesh_id != -1:
-            d.add_instance(meshes[mesh_id], world)
+        if mesh_id != -1:
+            if keep:
+                d.add_instance(meshes[mesh_id], world)
+            world = local                                                    # reference quirk: children of a mesh node inherit its local matrix only (gltf.py walk)
         for _ in range(n_children):
             node(world, keep)
 
@@ -229,3 +251,84 @@ def read_ollad(path, image_loader=None, scene=0):
         for _ in range(n_roots):
             node(np.eye(4, dtype=np.float32), s == scene)
     return d
+
+
+def _png_rgba8(px):
+    """RGBA8 image -> PNG bytes (8-bit RGBA, filter 0 on every row, one IDAT): what an .ollad blob holds per image."""
+    import zlib
+    px = np.ascontiguousarray(px, np.uint8)
+    h, w = px.shape[:2]
+
+    def chunk(kind, data):
+        body = kind + data
+        return struct.pack(">I", len(data)) + body + struct.pack(">I", zlib.crc32(body) & 0xFFFFFFFF)
+
+    raw = b"".join(b"\x00" + px[y].tobytes() for y in range(h))
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b"")
+
+
+def write_ollad_from_description(desc, dst_path):
+    """SceneDescription -> .ollad (the layout above): every texture a material uses as a PNG image typed by its use, the materials, one mesh per
+    description mesh, and ONE scene whose root nodes are the mesh instances (local matrix = the instance's world matrix).  What the format cannot say is
+    refused: emission overrides / override materials of an instance (LoadNode creates ENABLED instances, LumenPTModelConverter.cpp:275-316), and an sRGB flag
+    that disagrees with the texture's use (LoadFile derives it from the type: base colour and emissive only, :130-133)."""
+    defaults = {desc.tex_white, desc.tex_normal, desc.tex_metal_rough, desc.tex_emissive}
+    slots = (("diffuse_texture", T_DIFFUSE), ("normal_map", T_NORMAL), ("metallic_roughness_texture", T_METAL_ROUGHNESS), ("emissive_texture", T_EMISSIVE),
+             ("transmission_texture", T_TRANSMISSIVE), ("clearcoat_texture", T_CLEARCOAT), ("clearcoat_roughness_texture", T_CLEARCOAT_ROUGHNESS), ("tint_texture", T_TINT))
+    blob = bytearray()
+
+    def put(data):
+        off = len(blob)
+        blob.extend(data)
+        return off, len(data)
+
+    image_of, textures = {}, []                     # description texture index -> image id; [offset, size, type] per image
+    materials = []
+    for m in desc.materials:
+        ids = []
+        for field, ttype in slots:
+            t = m[field]
+            if t in defaults:
+                ids.append(-1)
+                continue
+            if t not in image_of:
+                off, size = put(_png_rgba8(desc.textures[t]["pixels"]))
+                image_of[t] = len(textures); textures.append([off, size, ttype])
+            if textures[image_of[t]][2] != ttype:
+                raise ValueError("a texture used in two different slots cannot be typed in an .ollad file")
+            if desc.textures[t]["srgb"] != (ttype in (T_DIFFUSE, T_EMISSIVE)):
+                raise ValueError(f"texture {t}: sRGB flag disagrees with its use as {field}")
+            ids.append(image_of[t])
+        scalars = [m[k] for k in ("transmission_factor", "clearcoat_factor", "clearcoat_roughness_factor", "index_of_refraction", "specular_factor", "specular_tint_factor",
+                                  "subsurface_factor", "luminance", "anisotropic", "sheen_factor", "sheen_tint_factor", "metallic_factor", "roughness_factor")]
+        materials.append(_MAT.pack(*m["diffuse_color"], *m["emission"], *ids, *scalars, *m["tint_factor"], *m["transmittance"]))
+    meshes = []
+    for prims in desc.meshes:
+        out = []
+        for pi in prims:
+            p = desc.primitives[pi]
+            index_size = p["index_size"]
+            v_off, v_size = put(pack_vertices(p["vertices"]))
+            i_off, i_size = put(p["indices"].astype("<u2" if index_size == 2 else "<u4").tobytes())
+            out.append(_PRIM.pack(v_off, v_size, i_off, i_size, index_size, p["material"]))
+        meshes.append(out)
+    header = bytearray()
+    header += struct.pack("<Q", len(textures))
+    for off, size, ttype in textures:
+        header += struct.pack("<3Q", off, size, ttype)
+    header += struct.pack("<Q", len(materials)) + b"".join(materials)
+    header += struct.pack("<Q", len(meshes))
+    for prims in meshes:
+        header += struct.pack("<I", len(prims)) + b"".join(prims)
+    name = b"scene"
+    header += struct.pack("<Q", 1) + struct.pack("<2I", len(desc.instances), len(name)) + name
+    for k, inst in enumerate(desc.instances):
+        if inst["emission_mode"] != 0 or inst["override_material"] >= 0:
+            raise ValueError("an .ollad node cannot carry an emission override or an override material")
+        nm = f"instance{k}".encode()
+        header += _NODE.pack(len(nm), 0, *np.asarray(inst["transform"], np.float32).T.ravel().tolist(), inst["mesh"]) + nm
+    with open(dst_path, "wb") as f:
+        f.write(struct.pack("<Q", len(header)))
+        f.write(header)
+        f.write(blob)
+    return dst_path

@@ -93,7 +93,8 @@ def generate_tangents(pos, normal, uv, indices):
             uv0, uv1, uv2 = _DEFAULT_UV
         else:
             uv0, uv1, uv2 = uv[tri[0]], uv[tri[1]], uv[tri[2]]
-            d0, d1, d2 = np.linalg.norm(uv0 - uv1), np.linalg.norm(uv0 - uv2), np.linalg.norm(uv2 - uv1)
+            len2 = lambda d: np.sqrt(np.float32(np.float32(d[0] * d[0]) + np.float32(d[1] * d[1])), dtype=np.float32)      # glm::length of a vec2
+            d0, d1, d2 = len2(uv0 - uv1), len2(uv0 - uv2), len2(uv2 - uv1)
             if d0 < eps or d1 < eps or d2 < eps:
                 uv0, uv1, uv2 = _DEFAULT_UV
         dp1, dp2 = v1 - v0, v2 - v0
@@ -104,11 +105,25 @@ def generate_tangents(pos, normal, uv, indices):
             duv1, duv2 = uv1 - uv0, uv2 - uv0
         t = (duv2[1] * dp1 - duv1[1] * dp2) / np.float32(duv1[0] * duv2[1] - duv2[0] * duv1[1])
         for k in range(3):
-            ng = normal[tri[k]] / np.float32(np.linalg.norm(normal[tri[k]]))
-            tt = t - ng * np.float32(np.dot(ng, t))
-            tt = tt / np.float32(np.linalg.norm(tt))
+            ng = _glm_normalize3(normal[tri[k]])
+            tt = _glm_normalize3(t - ng * _glm_dot3(ng, t))
             tang[tri[k]] = (tt[0], tt[1], tt[2], 1.0)
     return tang
+
+
+def _glm_dot3(a, b):
+    """glm::dot for vec3 in float: the three products, summed left to right (glm/detail/func_geometric.inl compute_dot<vec<3,...>>)"""
+    t = (np.asarray(a, np.float32) * np.asarray(b, np.float32)).astype(np.float32)
+    return np.float32(np.float32(t[0] + t[1]) + t[2])
+
+
+def _glm_normalize3(v):
+    """glm::normalize: v * inversesqrt(dot(v, v)), inversesqrt(x) = 1 / sqrt(x) in float — a multiplication by the rounded reciprocal, not a division by the length
+    (the two differ in the last bit; pinned against the reference converter's own .ollad output, tests/test_cpu_host.py)"""
+    v = np.asarray(v, np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = np.float32(1.0) / np.sqrt(_glm_dot3(v, v), dtype=np.float32)
+    return (v * inv).astype(np.float32)
 
 
 def generate_tangents_fast(pos, normal, uv, indices):

@@ -97,7 +97,7 @@ def build_sandbox_driver(tmp_path):
     exe = str(tmp_path / "sandbox_driver")
     libdir = os.path.join(ROOT, "lumenrenderer_amd")
     cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "examples", "sandbox_min"),
-           os.path.join(ROOT, "examples", "sandbox_driver.cpp"), "-o", exe, "-L" + libdir, "-llumen_mi", "-Wl,-rpath," + libdir]
+           os.path.join(ROOT, "examples", "sandbox_driver.cpp"), "-o", exe, "-L" + libdir, "-llumen_mi", "-lz", "-Wl,-rpath," + libdir]      # -lz: the minimal tree's .ollad reader inflates PNG images
     build = subprocess.run(cmd, capture_output=True, text=True)
     assert build.returncode == 0, build.stderr[-3000:]
     return exe

