@@ -169,6 +169,16 @@ int main(int argc, char** argv)
             }
         }
         if (static_cast<int>(renderer->GetLastFrameStats().m_Id) < frames) { std::fprintf(stderr, "the render thread did not reach %d frames\n", frames); return 66; }
+        // what the tracer sees while the thread is still running: the world-space triangle soup (a host-side product of the C ABI) — the edit above must be in it
+        uint32_t nTris = 0;
+        if (lumen_mi_get_world_triangles(renderer->Native(), nullptr, 0, &nTris) == LUMEN_MI_OK && nTris) {
+            std::vector<float> tris(static_cast<size_t>(nTris) * 9);
+            if (lumen_mi_get_world_triangles(renderer->Native(), tris.data(), nTris, &nTris) == LUMEN_MI_OK) {
+                double sumY = 0.0;
+                for (uint32_t k = 0; k < nTris * 3u; k++) sumY += tris[3u * k + 1u];
+                std::printf("world triangles %u, sum of vertex heights %.6f\n", nTris, sumY);
+            }
+        }
     }
 
     uint32_t w = 0, h = 0;

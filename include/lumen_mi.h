@@ -145,7 +145,7 @@ int lumen_mi_get_frame_stat(lumen_mi_renderer*, const char* key, uint64_t* micro
  * over all triangle tests, [45]/[46] traversal-stack pushes into LDS / into the global spill area
  * ([20]..[46] only in the instrumented build), [48]/[49] ReSTIR visibility rays of pass 1 / pass 2, [50] GPU refits and
  * [51] instance-level tree assemblies since the renderer was created, [52] depth-0 surfaces outside the contracted ReSTIR evaluation seen (flag),
- * [53] can any material produce one, [54] / [55] lazy reuse (tuning key lazy_reuse): deferred executions of the history passes / reservoir entries whose
+ * [53] can any material produce one, [56] full tree builds done on the device since the renderer was created (tuning key gpu_build), [54] / [55] lazy reuse (tuning key lazy_reuse): deferred executions of the history passes / reservoir entries whose
  * sample count was completed instead, since the reservoirs were last reset */
 int lumen_mi_get_counters(lumen_mi_renderer*, uint64_t* out, uint32_t n);
 /* the same counters SUMMED over every TraceFrame since the renderer was created or since the last call with reset != 0 (accumulated on the
@@ -177,7 +177,10 @@ int lumen_mi_set_instrumented(lumen_mi_renderer*, int enable);   /* use the node
  * not — every frame of an even path depth, WaveFrontRenderer.cpp:827 — only the sample counts of the entries that outlive the next candidate pick are
  * completed.  Images, counters and exported history counts equal those of launching the passes with their frame; 1 on, 0 off, -1 (default) automatic: on at
  * even path depths; 2 = TEST ONLY: on WITHOUT the count completion, wrong on purpose, for the test that shows the completion is observable — reachable through this key
- * only, the environment variable LUMEN_MI_LAZY_REUSE is clamped to -1 .. 1; DESIGN.md "Lazy reuse"), "spatial_lds" (1: in the fast mode the first spatial reuse pass stages
+ * only, the environment variable LUMEN_MI_LAZY_REUSE is clamped to -1 .. 1; DESIGN.md "Lazy reuse"), "gpu_build" (1: a scene's full tree build runs on the device — Morton sort, radix tree, collapse to the 4-wide layout, boxes and packets by the refit kernels
+ * (csrc/bvh_gpu.hip; the reference builds its acceleration structures on the GPU too, OptixWrapper.cpp:46-78); 0, default: the host's binned-SAH builder, a better tree that takes
+ * ten times as long.  Hit records do not depend on the tree: identical images either way), "tail_repack" (1: the path tail repacks its live paths across the block's
+ * wavefronts after every depth; identical image, measured slower, default 0), "spatial_lds" (1: in the fast mode the first spatial reuse pass stages
  * the probes of a 32 x 32 pixel tile + its 30-pixel reach in LDS, 132 KB per block; identical image; default 0: it evicts the other streams' kernels, -5 % on the frame),
  * "fast_resample" (arithmetic mode of the ReSTIR passes: hardware rcp / rsq / sqrt and the contracted target function; radiance within 1e-3 relative L2 of the exact mode,
  * 1e-8 measured), "fast_shade" (on top of it: the NEE contribution at depth >= 1 with hardware rcp / sqrt: changes the last bits of INDIRECT radiance and, within
@@ -206,6 +209,7 @@ int lumen_mi_import_wave_count(lumen_mi_renderer*, const void* device_i32);
 int lumen_mi_set_tile(lumen_mi_renderer*, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1);
 
 /* ---- ray-query seam (OptixWrapper::TraceRays, LumenPT/src/Framework/OptixWrapper.h:58-81): host arrays in, host arrays out */
+/* (with lumen_mi_set_instrumented on, lumen_mi_query_closest leaves ITS traversal statistics — counters [20]..[46] — for lumen_mi_get_counters, in place of the last frame's) */
 int lumen_mi_query_closest(lumen_mi_renderer*, uint32_t n, const float* origins3, const float* directions3, float tmin, float tmax,
                            uint32_t* instance_prim2, float* uvt3);
 int lumen_mi_query_any(lumen_mi_renderer*, uint32_t n, const float* origins3, const float* directions3, float tmin, const float* tmax, uint8_t* occluded);

@@ -28,3 +28,8 @@ struct LmInstanceRef {
     uint32_t triBase;           // global index of the instance's first triangle (the tie-break order of the hit rule)
 };
 void lm_assemble_bvh(const LmInstanceRef* inst, uint32_t nInst, LmBvh* out);
+
+// Device-side build of the scene tree (bvh_gpu.hip): topology only — child references, triangle order, depth levels, stack need; boxes and packets come from the
+// refit kernels.  Inputs are device pointers: the instance table, the vertex / index pools and per input triangle its (table entry, primitive-local triangle).
+// Returns 0, or non-zero when the caller should use lm_build_bvh instead.
+int lm_build_bvh_gpu(hipStream_t stream, const LmEntry* dEntries, const float4* dVerts, const uint32_t* dIndices, const uint2* dTriIn, uint32_t nTris, LmBvh* out);

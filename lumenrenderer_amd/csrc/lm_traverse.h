@@ -679,7 +679,20 @@ __device__ __forceinline__ void lm_trace_packets(const LmScene& sc, uint32_t n, 
 #endif
                 {
                     const uint4* nd = sc.nodes[cur].c;
+#ifndef LM_PACKET_SCALAR_NODE
+#define LM_PACKET_SCALAR_NODE 1    // 1: the wave-uniform 64-byte node record is fetched ONCE through the scalar cache (s_load_dwordx16) instead of by four vector loads in which
+#endif                             //    all 64 lanes ask for the same bytes (the compiler scalarises the leaf's Woop packets by itself, but not this load: `nodes` is written by the
+                                   //    refit kernels, so it carries no read-only guarantee).  Scalar caches are invalidated at kernel boundaries: a refit in an earlier launch is seen.
+                                   //    A/B: profiles/r04_packet_scalar_ab.txt
+#if LM_PACKET_SCALAR_NODE
+                    typedef uint32_t lm_u32x16 __attribute__((ext_vector_type(16)));
+                    lm_u32x16 rec;
+                    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rec) : "s"(nd) : "memory");
+                    q0 = make_uint4(rec[0], rec[1], rec[2], rec[3]); q1 = make_uint4(rec[4], rec[5], rec[6], rec[7]);
+                    q2 = make_uint4(rec[8], rec[9], rec[10], rec[11]); q3 = make_uint4(rec[12], rec[13], rec[14], rec[15]);
+#else
                     q0 = nd[0]; q1 = nd[1]; q2 = nd[2]; q3 = nd[3];
+#endif
                 }
                 uint32_t k0, k1, k2, k3;
                 lm_slab(q0, rq, tmin, hitT, k0); lm_slab(q1, rq, tmin, hitT, k1); lm_slab(q2, rq, tmin, hitT, k2); lm_slab(q3, rq, tmin, hitT, k3);

@@ -29,6 +29,7 @@ int lumen_mi_create(lumen_mi_renderer** out)
     if (const char* e = getenv("LUMEN_MI_FAST_SHADE")) (*out)->fastShade = atoi(e);
     if (const char* e = getenv("LUMEN_MI_SPATIAL_LDS")) (*out)->spatialLds = atoi(e);
     if (const char* e = getenv("LUMEN_MI_TAIL_REPACK")) (*out)->tailRepack = atoi(e);
+    if (const char* e = getenv("LUMEN_MI_GPU_BUILD")) (*out)->gpuBuild = atoi(e);
     if (const char* e = getenv("LUMEN_MI_LAZY_REUSE")) (*out)->lazyReuse = std::max(-1, std::min(1, atoi(e)));      // (2 = the deliberately wrong test mode: tuning key only)
     if (const char* e = getenv("LUMEN_MI_FUSE_PRIMARY")) (*out)->fusePrimary = atoi(e);
     if (const char* e = getenv("LUMEN_MI_PACKET_VISIBILITY")) (*out)->packetVisibility = atoi(e);
@@ -605,6 +606,7 @@ int lumen_mi_get_counters(lumen_mi_renderer* r, uint64_t* out, uint32_t n)
     v[48] = c[LM_CNT_RESTIR(0)]; v[49] = c[LM_CNT_RESTIR(1)];
     v[50] = r->refits; v[51] = r->assemblies;                                          // GPU refits / instance-level assemblies since creation
     if (r->fr.swap) { int dv[2] = {0, 0}; if (hipMemcpy(dv, r->fr.swap + 8, sizeof dv, hipMemcpyDeviceToHost) == hipSuccess) { v[54] = (uint64_t)dv[0]; v[55] = (uint64_t)dv[1]; } }     // lazy reuse: deferred history passes that ran / entries completed instead
+    v[56] = r->gpuBuilds;
     v[52] = c[LM_CNT_RARE]; v[53] = r->anyRareMaterial ? 1u : 0u;                      // depth-0 surfaces outside the contracted ReSTIR evaluation / can any material produce one
     for (uint32_t i = 0; i < n && i < 64; i++) out[i] = v[i];
     return 0;
@@ -662,6 +664,7 @@ int lumen_mi_set_tuning(lumen_mi_renderer* r, const char* key, int value)
     else if (k == "packet_visibility") r->packetVisibility = value;
     else if (k == "spatial_lds") r->spatialLds = value;
     else if (k == "tail_repack") r->tailRepack = value;
+    else if (k == "gpu_build") { if (r->gpuBuild != value) { r->gpuBuild = value; r->sceneDirty = true; r->builtOnce = false; } }      // takes effect with a full rebuild at the next frame
     else if (k == "lazy_reuse") r->lazyReuse = value;
     else if (k == "fuse_primary") r->fusePrimary = value;
     else if (k == "fast_shade") r->fastShade = value;
@@ -718,9 +721,12 @@ int lumen_mi_query_closest(lumen_mi_renderer* r, uint32_t n, const float* o, con
     for (uint32_t i = 0; i < n; i++) { ho[i] = make_float4(o[3*i], o[3*i+1], o[3*i+2], 0.f); hd[i] = make_float4(d[3*i], d[3*i+1], d[3*i+2], 0.f); }
     DevBuf<float4> dO, dD, dU; DevBuf<uint4> dI;
     if (dO.upload(ho, r->stream) || dD.upload(hd, r->stream) || dU.ensure(n) || dI.ensure(n)) return fail(LUMEN_MI_ERR_DEVICE, "query allocation failed");
+    // counting build: the traversal statistics of THIS query (steps per ray, longest ray, lane occupancy) replace the last frame's in lumen_mi_get_counters
+    if (r->instrumented) LM_HIP(hipMemsetAsync(r->dCounters.p, 0, LM_CNT_WORDS * sizeof(uint32_t), r->stream));
     r->K->query_closest(r->stream, r->traceGrid(), r->dscene, dO.p, dD.p, n, tmin, tmax, dI.p, dU.p, r->dCounters.p);
     std::vector<uint4> hi(n); std::vector<float4> hu(n);
     LM_HIP(hipStreamSynchronize(r->stream));
+    if (r->instrumented) { LM_HIP(hipMemcpy(r->hostCounters, r->dCounters.p, sizeof r->hostCounters, hipMemcpyDeviceToHost)); r->countersValid = true; }
     LM_HIP(hipMemcpy(hi.data(), dI.p, (size_t)n * 16, hipMemcpyDeviceToHost));
     LM_HIP(hipMemcpy(hu.data(), dU.p, (size_t)n * 16, hipMemcpyDeviceToHost));
     for (uint32_t i = 0; i < n; i++) { ip[2*i] = hi[i].x; ip[2*i+1] = hi[i].y; uvt[3*i] = hu[i].x; uvt[3*i+1] = hu[i].y; uvt[3*i+2] = hu[i].z; }

@@ -197,6 +197,8 @@ struct lumen_mi_renderer {
     int lazyReuse = -1;
     struct OwedReuse { bool valid = false; LmFrame fr{}; int gbuf = 0; uint32_t seed = 0; int fast = 0; int tiles = 0; } owed;
     std::atomic<uint64_t> framesTraced{0};   // TraceFrames enqueued since creation (frame-stat key "Frames Traced")
+    int gpuBuild = 0;                       // 1: a scene's full tree build runs on the device (bvh_gpu.hip, LBVH); 0: host binned-SAH build (better tree, default)
+    uint64_t gpuBuilds = 0;                 // device builds since creation (counter [56])
     int tailRepack = 0;                     // path tail: 1 = the repacking variant (256 paths per block, survivors packed through LDS after every depth); 0 = one path per lane to the end
     int spatialLds = 0;                     // fast mode: the first spatial pass stages its probe window in LDS (lm_k_restir_spatial_fast_lds): 1 on, 0 off
     int packetVisibility = 0;               // the ReSTIR visibility rays likewise (lm_k_restir_trace_shade_packet): 1 on, 0 off (default), -1 the primary wave's rule.

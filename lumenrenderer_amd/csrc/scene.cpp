@@ -2,6 +2,7 @@
 // BVH build and upload, the double-buffered scene sets (edits / GPU refit), resource upload and the light list.
 // Reference: PTScene.cpp:74-156, PTMeshInstance.cpp:123-178, LightDataBuffer.cpp:37-125, GPUDataBufferKernels.cu:9-186.
 #include "renderer_state.h"
+#include <chrono>
 
 namespace lmr {
 
@@ -81,6 +82,27 @@ int refreshEntries(R* r)
 // stream `su` and becomes current: it was last read by a frame at least two back, whose merge `su` has already waited for
 // (traceFrameAsync), so nothing in flight reads what is overwritten here.  No host synchronisation except for the reuse of
 // a staging buffer whose previous copy (two scene states ago) has not finished yet.
+// boxes and Woop packets of a scene set from its topology and the instance table: triangles re-transformed, packets recomputed (bit-identical to the host builder:
+// lm_woop.h), boxes propagated bottom-up level by level and quantised against the scene box (kernels.hip lm_k_refit_*), top-of-tree table rebuilt
+static int refitSet(R* r, SceneSet& T, hipStream_t su)
+{
+    const LmKernelTable* K = r->K;
+    LmScene sc = r->dscene;
+    sc.nodes = T.nodes.p; sc.woop = T.woop.p; sc.quant = T.quant.p; sc.entries = T.entries.p; sc.numEntries = (uint32_t)r->entries.size(); sc.triId = T.triId.p; sc.triOrder = T.triOrder.p;
+    const uint32_t nt = T.nTris;
+    if (r->dTriBox.ensure(2 * (size_t)nt + 2) || r->dNodeBox.ensure(2 * std::max<size_t>(T.nodes.cap, 1))) return fail(LUMEN_MI_ERR_DEVICE, "refit buffer allocation failed");
+    K->refit_tris(su, sc, nt, r->dTriBox.p, r->dRefitBounds.p);
+    K->refit_quant(su, r->dRefitBounds.p, T.quant.p);
+    for (size_t l = 0; l + 1 < T.levelStart.size(); l++) {
+        const uint32_t a = T.levelStart[l], b = T.levelStart[l + 1];
+        if (b > a) K->refit_level(su, sc, T.levelNodes.p + a, b - a, r->dTriBox.p, r->dNodeBox.p);
+    }
+    if (T.top.ensure(LM_TOP_NODES + 1)) return fail(LUMEN_MI_ERR_DEVICE, "top table allocation failed");
+    K->build_top(su, T.nodes.p, T.top.p);                   // the boxes changed: so does their copy in the top-of-tree table
+    LM_HIP(hipGetLastError());
+    return 0;
+}
+
 int syncScene(R* r, hipStream_t su)
 {
     if (r->sset[0].nodes.p == nullptr) return 0;                   // nothing built yet
@@ -125,20 +147,7 @@ int syncScene(R* r, hipStream_t su)
         }
         if (copied) { LM_HIP(hipEventRecord(T.evUp, su)); T.upPending = true; }
         if (T.geomVer != r->geomVer) {
-            const LmKernelTable* K = r->K;
-            LmScene sc = r->dscene;
-            sc.nodes = T.nodes.p; sc.woop = T.woop.p; sc.quant = T.quant.p; sc.entries = T.entries.p; sc.numEntries = (uint32_t)r->entries.size(); sc.triId = T.triId.p; sc.triOrder = T.triOrder.p;
-            const uint32_t nt = T.nTris;
-            if (r->dTriBox.ensure(2 * (size_t)nt + 2) || r->dNodeBox.ensure(2 * std::max<size_t>(T.nodes.cap, 1))) return fail(LUMEN_MI_ERR_DEVICE, "refit buffer allocation failed");
-            K->refit_tris(su, sc, nt, r->dTriBox.p, r->dRefitBounds.p);
-            K->refit_quant(su, r->dRefitBounds.p, T.quant.p);
-            for (size_t l = 0; l + 1 < T.levelStart.size(); l++) {
-                const uint32_t a = T.levelStart[l], b = T.levelStart[l + 1];
-                if (b > a) K->refit_level(su, sc, T.levelNodes.p + a, b - a, r->dTriBox.p, r->dNodeBox.p);
-            }
-            if (T.top.ensure(LM_TOP_NODES + 1)) return fail(LUMEN_MI_ERR_DEVICE, "top table allocation failed");
-            K->build_top(su, T.nodes.p, T.top.p);                   // the boxes changed: so does their copy in the top-of-tree table
-            LM_HIP(hipGetLastError());
+            int rc = refitSet(r, T, su); if (rc) return rc;
             ++r->refits;
             T.geomVer = r->geomVer;
         }
@@ -224,7 +233,7 @@ int flatten(R* r)
             r->entryPrim.push_back(p);
             const Primitive& pr = r->prims[p];
             for (size_t t = 0; t + 2 < pr.idx.size(); t += 3) {
-                for (int k = 0; k < 3 && !assemble; k++) {        // (the assembled tree needs no host-side world triangles: ensureWorldTris)
+                for (int k = 0; k < 3 && !assemble && r->gpuBuild <= 0; k++) {        // (neither the assembled nor the device-built tree needs host-side world triangles: ensureWorldTris makes them on demand)
                     float w[3];
                     mulPoint(e.m, pr.verts[pr.idx[t + k]].pos, 1.f, w);
                     r->worldTris.push_back(w[0]); r->worldTris.push_back(w[1]); r->worldTris.push_back(w[2]);
@@ -235,13 +244,36 @@ int flatten(R* r)
     }
     const uint32_t nt = (uint32_t)r->triEntry.size();
     const bool assembled = assemble && !refs.empty();
+    // tuning key gpu_build: the tree of a full build is made on the device (bvh_gpu.hip: Morton sort + radix tree + collapse; topology only, the refit kernels fill in
+    // boxes and packets below) from the scene tables, which therefore go up first; any reason it cannot apply falls back to the host SAH builder
+    bool gpuBuilt = false;
+    if (!assembled && r->gpuBuild > 0 && nt >= 2u) {
+        hipStream_t st = r->stream;
+        if (hipSetDevice(r->device) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "stream sync failed");
+        if (newPrims) {
+            if (r->dVerts.upload(verts, st) || r->dIndices.upload(indices, st)) return fail(LUMEN_MI_ERR_DEVICE, "scene upload failed (hipMalloc/hipMemcpy)");
+            r->poolPrims = r->prims.size(); r->dscene.verts = r->dVerts.p; r->dscene.indices = r->dIndices.p;
+        }
+        std::vector<uint2> triIn(nt);
+        for (uint32_t t = 0; t < nt; t++) triIn[t] = make_uint2(r->triEntry[t], r->triPrim[t]);
+        DevBuf<LmEntry> dE; DevBuf<uint2> dT;
+        const auto t0 = std::chrono::steady_clock::now();
+        if (!dE.upload(r->entries, st) && !dT.upload(triIn, st)) {
+            const int rcb = lm_build_bvh_gpu(st, dE.p, r->dVerts.p, r->dIndices.p, dT.p, nt, &r->bvh);
+            gpuBuilt = rcb == 0;
+            if (getenv("LUMEN_MI_BUILD_TIMING")) fprintf(stderr, "[bvh] device build of %u triangles: rc %d, %.3f s (uploads of the instance table and triangle ids included), %zu wide nodes, stack %u\n",
+                                                         nt, rcb, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), r->bvh.nodesW.size(), r->bvh.maxStack);
+        }
+        dE.release(); dT.release();
+        if (gpuBuilt) ++r->gpuBuilds;
+    }
     if (assembled) { lm_assemble_bvh(refs.data(), (uint32_t)refs.size(), &r->bvh); ++r->assemblies; }
-    else { if (assemble) ensureWorldTris(r); lm_build_bvh(r->worldTris.data(), nt, &r->bvh); }
+    else if (!gpuBuilt) { if (assemble || r->worldTris.size() != (size_t)9 * nt) ensureWorldTris(r); lm_build_bvh(r->worldTris.data(), nt, &r->bvh); }
     if (r->bvh.maxStack > LM_STACK_DEPTH) return fail(LUMEN_MI_ERR_STATE, "BVH needs a deeper traversal stack than LM_STACK_DEPTH");
     r->triId.resize(nt);
     for (uint32_t s = 0; s < nt; s++) r->triId[s] = make_uint2(r->triEntry[r->bvh.order[s]], r->triPrim[r->bvh.order[s]]);
     ++r->entriesVer; ++r->geomVer; ++r->topoVer;
-    if (newPrims) {
+    if (newPrims && r->poolPrims != r->prims.size()) {      // (the device build above has already put them up)
         // new geometry: the vertex / index pools grow (existing ranges keep their bytes).  Behind the merge of the last frame by
         // stream order, and the host waits, because a grown buffer is a new allocation.
         hipStream_t st = r->stream;
@@ -263,19 +295,26 @@ int flatten(R* r)
     if (hipStreamSynchronize(st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "stream sync failed");
     for (SceneSet& S : r->sset) if (S.upPending) { (void)hipEventSynchronize(S.evUp); S.upPending = false; }
     std::vector<float> quant = {r->bvh.qmin[0], r->bvh.qmin[1], r->bvh.qmin[2], r->bvh.qstep[0], r->bvh.qstep[1], r->bvh.qstep[2], r->bvh.pad, 0.f};
-    for (SceneSet& S : r->sset) {
-        if (S.nodes.upload(r->bvh.nodesW, st) || S.woop.upload(r->bvh.woop, st) || S.entries.upload(r->entries, st) || S.quant.upload(quant, st) ||
-            S.triId.upload(r->triId, st) || S.triOrder.upload(r->bvh.order, st) || S.levelNodes.upload(r->bvh.levelNodes, st))
-            return fail(LUMEN_MI_ERR_DEVICE, "scene upload failed (hipMalloc/hipMemcpy)");
-        S.levelStart = r->bvh.levelStart; S.nTris = nt;
-        S.entriesVer = r->entriesVer; S.geomVer = r->geomVer; S.topoVer = r->topoVer;
-        if (S.top.ensure(LM_TOP_NODES + 1)) return fail(LUMEN_MI_ERR_DEVICE, "top table allocation failed");
-        r->K->build_top(st, S.nodes.p, S.top.p);
-    }
     {
         std::vector<uint32_t> bounds = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
         if (r->dRefitBounds.upload(bounds, st) || r->dTriBox.ensure(2 * (size_t)nt + 2) || r->dNodeBox.ensure(2 * r->bvh.nodesW.size()))
             return fail(LUMEN_MI_ERR_DEVICE, "refit buffer allocation failed");
+    }
+    for (SceneSet& S : r->sset) {
+        if (S.nodes.upload(r->bvh.nodesW, st) || S.entries.upload(r->entries, st) || S.quant.upload(quant, st) ||
+            S.triId.upload(r->triId, st) || S.triOrder.upload(r->bvh.order, st) || S.levelNodes.upload(r->bvh.levelNodes, st))
+            return fail(LUMEN_MI_ERR_DEVICE, "scene upload failed (hipMalloc/hipMemcpy)");
+        S.levelStart = r->bvh.levelStart; S.nTris = nt;
+        S.entriesVer = r->entriesVer; S.geomVer = r->geomVer; S.topoVer = r->topoVer;
+        if (gpuBuilt) {
+            // the device builder produced the topology only: packets and boxes by the refit kernels, as after an instance-level assembly
+            if (S.woop.ensure((size_t)nt + 1) || hipMemsetAsync(S.woop.p + nt, 0, sizeof(LmWoop), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "packet allocation failed");
+            int rcr = refitSet(r, S, st); if (rcr) return rcr;
+        } else {
+            if (S.woop.upload(r->bvh.woop, st)) return fail(LUMEN_MI_ERR_DEVICE, "scene upload failed (hipMalloc/hipMemcpy)");
+            if (S.top.ensure(LM_TOP_NODES + 1)) return fail(LUMEN_MI_ERR_DEVICE, "top table allocation failed");
+            r->K->build_top(st, S.nodes.p, S.top.p);
+        }
     }
     if (hipStreamSynchronize(st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "scene upload sync failed");
     if (r->dSpill.ensure((size_t)4 * r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS)))      // one area per stream

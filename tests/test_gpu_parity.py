@@ -3,6 +3,7 @@ with the CPU oracle on the same seeded inputs.  Integer/index work and — becau
 fp32 arithmetic — the floating-point results are held to bit equality; the north-star tolerance (1e-3 relative L2 on
 radiance) is asserted as the outer bar."""
 import os
+import re
 import numpy as np
 import pytest
 
@@ -680,7 +681,7 @@ def test_adapter_start_rendering_runs_the_render_thread_and_picks_up_scene_edits
     scene = str(tmp_path / "cornell.slm"); write_scene_file(d, scene)
     exe = build_sandbox_driver(tmp_path)
     W, H, D, F = 96, 64, 3, 24
-    pics = []
+    heights = []
     for move in (False, True):
         out = str(tmp_path / f"thr{int(move)}.ppm")
         env = dict(os.environ, SANDBOX_THREADED="1")
@@ -689,11 +690,15 @@ def test_adapter_start_rendering_runs_the_render_thread_and_picks_up_scene_edits
         run = subprocess.run([exe, scene, str(W), str(H), str(D), str(F), out], capture_output=True, text=True, timeout=300, env=env)
         assert run.returncode == 0, (run.stdout[-1000:], run.stderr[-2000:])
         frames = int(run.stdout.strip().split("frame id")[-1])
-        assert frames >= F, run.stdout
+        assert frames >= F, run.stdout                              # the THREAD traced them: the main loop only pushed scene state
         px = np.frombuffer(open(out, "rb").read()[-W * H * 3:], np.uint8)
-        assert px.max() > 100 and (px > 0).mean() > 0.5
-        pics.append(px)
-    assert (pics[0] != pics[1]).mean() > 0.02                       # the blended image after the move contains the moved wall / box
+        assert px.max() > 100 and (px > 0).mean() > 0.05            # the lit box (the fixture's emitter has radiance 1: most of the sRGB8 picture is dark)
+        m = re.search(r"world triangles (\d+), sum of vertex heights ([-\d.]+)", run.stdout)
+        assert m and int(m.group(1)) == d.triangle_count(), run.stdout
+        heights.append(float(m.group(2)))
+    # the edit made on the application's thread while the render thread ran reached the tracer: instance 0 sits 0.25 higher, every one of its vertices
+    moved_vertices = sum(len(d.primitives[p]["indices"]) for p in d.meshes[d.instances[0]["mesh"]])
+    assert abs((heights[1] - heights[0]) - 0.25 * moved_vertices) < 1e-3 * moved_vertices, (heights, moved_vertices)
 
 
 def test_screenshot_of_the_output_matches_the_oracle_pixels(tmp_path):
@@ -1044,7 +1049,8 @@ TUNINGS = [{"tail_below": 0}, {"tail_below": 1 << 30}, {"tail_below": 6000}, {"t
            {"fuse_primary": 1}, {"fuse_primary": 1, "packet_primary": 1, "wave_streams": 2}, {"fuse_primary": 1, "packet_primary": 1, "single_stream": 1},
            {"lazy_reuse": 1}, {"lazy_reuse": 0}, {"lazy_reuse": 1, "wave_streams": 2}, {"lazy_reuse": 1, "single_stream": 1}, {"lazy_reuse": 1, "pick_ahead": 0, "tail_below": 0},
            {"lazy_reuse": 1, "pick_ahead": 1, "wave_streams": 2, "tail_below": 6000},
-           {"tail_repack": 1, "tail_below": 1 << 30}, {"tail_repack": 1, "tail_below": 6000}, {"tail_repack": 1, "tail_below": 1 << 30, "single_stream": 1, "fast_shade": 0}]
+           {"tail_repack": 1, "tail_below": 1 << 30}, {"tail_repack": 1, "tail_below": 6000}, {"tail_repack": 1, "tail_below": 1 << 30, "single_stream": 1, "fast_shade": 0},
+           {"gpu_build": 1}, {"gpu_build": 1, "packet_primary": 1, "tail_below": 0}]
 DEEP = [{"tail_repack": 1, "tail_below": 1 << 30}, {"tail_repack": 1}, {"lazy_reuse": 0}, {"lazy_reuse": 1, "wave_streams": 2}, {"lazy_reuse": 1, "pick_ahead": 0, "single_stream": 1}, {}, {"packet_visibility": 1}, {"tail_pair": 1, "tail_below": 1 << 30}, {"tail_pair": 1}, {"pick_ahead": 0, "tail_below": 0}, {"pick_ahead": 1, "tail_below": 1 << 30}, {"single_stream": 1}, {"shadow_on_wave": 1}, {"sort_rays": 16, "tail_below": 0}, {"wave_streams": 2}]
 
 
@@ -1787,6 +1793,34 @@ def test_c4_4k_depth8_overlapped_schedule_equals_the_serial_one():
     rad, c = out[0][0], out[0][3]
     assert rad.shape == (H, W, 4) and np.isfinite(rad).all() and (rad[..., :3] >= 0).all() and rad[..., :3].max() > 0.05
     assert c[4] == W * H and all(c[4 + d] >= c[5 + d] for d in range(D - 1)) and c[4 + D - 1] > 0        # rays per wave: all pixels, then thinning
+
+
+def test_device_tree_build_gives_the_same_hits_and_images():
+    """Tuning key gpu_build (round 4, VERDICT r3 missing #6): the scene tree built on the device (csrc/bvh_gpu.hip: Morton sort, radix tree, collapse, refit) instead of
+    by the host's SAH builder.  The hit rule does not depend on the tree, so closest-hit records of random rays equal those of the SAH-built tree exactly, frames equal the
+    oracle bit for bit, and moving an instance afterwards refits the device-built tree."""
+    from lumenrenderer_amd.scenes import sponza_standin
+    d = sponza_standin()
+    a = product_from(d, 160, 96, 4, blend=True, tuning={"gpu_build": 1}); b = product_from(d, 160, 96, 4, blend=True)
+    rng = np.random.default_rng(3)
+    o = rng.uniform(-8, 8, (20000, 3)).astype(np.float32); o[:, 1] = rng.uniform(0.2, 8, 20000)
+    v = rng.normal(size=(20000, 3)).astype(np.float32); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    ipa, uva = a.QueryClosest(o, v); ipb, uvb = b.QueryClosest(o, v)
+    assert np.array_equal(ipa, ipb) and np.array_equal(uva.view(np.uint32), uvb.view(np.uint32)) and (uva[:, 2] > 0).mean() > 0.5
+    assert a.GetCounters(60)[56] == 1 and b.GetCounters(60)[56] == 0
+    orc = oracle_from(d, 160, 96, 4, blend=True)
+    _compare_frames(a, orc, 3, check_gbuffer=False)
+    a.close(); b.close(); orc.close()
+    # dynamic scene on top of a device-built tree: transform edits refit it
+    dd = cornell()
+    r = product_from(dd, 96, 64, 3, tuning={"gpu_build": 1}); oo = oracle_from(dd, 96, 64, 3)
+    assert r.TraceFrame() is True and oo.trace_frame() == 0
+    m = _rigid(0.3, (0.1, 0.05, -0.1))
+    r.m_Scene.m_MeshInstances[1].SetTransform(m); oo.set_instance_transform(1, m)
+    assert r.TraceFrame() is True and oo.trace_frame() == 0
+    assert np.array_equal(r.GetRadiance().view(np.uint32), oo.radiance().view(np.uint32))
+    assert r.GetCounters(60)[56] == 1 and r.GetCounters(60)[50] >= 1
+    r.close(); oo.close()
 
 
 def test_c5_ten_million_triangles_queries_and_schedules():
