@@ -34,7 +34,9 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak, /opt/skills/guides/MI355X_
 # 78.6 T lane-ops/s = 1 229 G wave instructions/s (a wave64 v_fma_f32 takes 2 cycles on a CDNA4 SIMD, MI355X_MICROARCH.md; 157.3 TFLOPS =
 # this x 2 for FMA).  Measured on the box with tools/valu_peak.hip -> profiles/r03_valu_peak.txt.  (Round 2 divided by 39.3: wrong by 2x.)
 VALU_PEAK_TLANEOPS = 78.6432
-PMC_FILE = os.path.join("profiles", "r03_c2_pmc.json")      # tools/pmc_json.sh on the GPU box; replayed here, never measured by this run
+WAVEINST_PEAK = 1055.8e9         # VALU wave-instructions/s the chip sustains with dependent chains at 8 waves per SIMD (measured, profiles/r03_valu_peak.txt: 2.33 cycles per instruction per SIMD)
+TRAV_T0_US, TRAV_RAYS_PER_US = 60.0, 4600.0   # closest-hit launch of incoherent rays on the C2 scene: T = T0 + rays / R (profiles/r04_step_latency.txt)
+PMC_FILE = os.path.join("profiles", "r04_c2_pmc.json")      # tools/pmc_json.sh on the GPU box; replayed here, never measured by this run
 
 
 def kernel_source_id():
@@ -426,6 +428,27 @@ def main():
                 valu.append({"kernel": name, "bound": "valu", "achieved": round(ach, 2), "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-ops/s",
                              "frac": round(ach / VALU_PEAK_TLANEOPS, 4), "alone_us": round(us, 1), "active_lanes_per_inst": round(pk(name, "active_lanes_per_valu_inst") or 0.0, 1),
                              "valu_insts_per_launch": int(pk(name, "SQ_INSTS_VALU_per_launch") or 0), "source": PMC_FILE + " (replayed)"})
+        # ---- what binds the frame, and what binds the traversal class
+        # frame level: wave-instructions the vector ALUs issued per TraceFrame (PMC replay, all kernels) against what the chip issues with dependent chains at 8 waves
+        # per SIMD (1 055.8 G wave-instructions/s measured, profiles/r03_valu_peak.txt), beside the HBM fraction: neither is near 1 — the frame is latency-bound
+        frame_valu = sum(v.get("SQ_INSTS_VALU_per_launch", 0.0) * v.get("launches", 0) / tf_in_pmc for v in pmc.values()) if pmc else None
+        frame_valu_frac = None if not frame_valu else round(frame_valu / (tf_ms * 1e-3) / WAVEINST_PEAK, 4)
+        frame_hbm_frac = None if hbm_tf is None else round(hbm_tf / (tf_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)
+        # traversal class: a launch of incoherent rays takes T0 + rays / R — T0 the dependent chain of its longest ray, R the VALU issue rate at the lane occupancy
+        # divergence leaves (both measured on this scene: profiles/r04_step_latency.txt).  `issue_bound_ms` = the launch's own wave-instructions at the issue peak.
+        queue_launches = max(0, int(round(launches_per_tf)) - 1)            # the primary wave is the packet kernel; waves 1.. are the queue kernel
+        rays_queue = float(sum(c[4 + d] for d in range(1, 1 + queue_launches)))
+        tm_pred_ms = (queue_launches * TRAV_T0_US + rays_queue / TRAV_RAYS_PER_US) * 1e-3 if queue_launches else None
+        v_tc = pk("lm_k_trace_closest", "SQ_INSTS_VALU_per_launch")
+        traversal_model = None if not queue_launches else {
+            "kernel": "lm_k_trace_closest (waves 1.." + str(queue_launches) + ")", "launches_per_traceframe": queue_launches, "rays_per_traceframe": int(rays_queue),
+            "model": "T = T0 + rays / R per launch; T0 = dependent chain of the longest ray, R = issue-limited rate at the measured lane occupancy (profiles/r04_step_latency.txt)",
+            "t0_us": TRAV_T0_US, "rays_per_us": TRAV_RAYS_PER_US, "predicted_ms_per_traceframe_alone": round(tm_pred_ms, 4),
+            "issue_bound_ms_per_traceframe": None if not v_tc else round(queue_launches * v_tc / WAVEINST_PEAK * 1e3, 4),
+            "alone_ms_per_traceframe": None if not pk("lm_k_trace_closest", "alone_us") else round(queue_launches * pk("lm_k_trace_closest", "alone_us") * 1e-3, 4),
+            "active_lanes_per_valu_inst": pk("lm_k_trace_closest", "active_lanes_per_valu_inst"),
+            "steps_per_ray_mean": round((ci[22] / 4.0 + ci[21]) / all_rays_inst, 2), "steps_longest_ray": int(ci[40]),
+            "note": "alone ~ predicted means the launches sit ON the chain + issue bound; the live launch_ms of `roofline` is longer because three other streams share the machine"}
         dev = lambda kk: {n: round(kk[n][0] / max(1, kk["total"][1]), 3) for n in kk}
         out = {
             "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -474,6 +497,10 @@ def main():
                          "algorithmic_bytes_per_launch": int(alg / max(1.0, launches_per_tf)),
                          "achieved_d4_binary_node_pricing": round(gbs(alg_d4), 2)},
             "roofline_valu": valu,
+            "frame_valu_frac": frame_valu_frac, "frame_hbm_frac": frame_hbm_frac,
+            "frame_bound_note": "fractions of the chip's VALU issue peak (wave-instructions, measured) and of HBM peak over one TraceFrame, from the PMC replay: both well below 1 — "
+                                "the frame is bound by dependent-chain latency inside the traversal launches and by how well four streams fill each other's stalls",
+            "traversal_model": traversal_model,
             "device_ms_per_traceframe": dev(main_pass["class_ms"]),
         }
         if main_pass["per_rank"]:

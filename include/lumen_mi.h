@@ -247,6 +247,13 @@ int lumen_mi_test_restir_frame(lumen_mi_renderer*, uint32_t W, uint32_t H, const
  * direct12 = emitted origin direction maxDistance radiance channel; indirect10 = emitted origin direction contribution; either may be NULL.  fast: tuning key fast_shade. */
 int lumen_mi_test_shade(lumen_mi_renderer*, uint32_t n, uint32_t W, uint32_t H, const uint32_t* rows43, uint32_t n_lights, const uint32_t* lights16, const uint32_t* cdf,
                         int fast, uint32_t* direct12, uint32_t* indirect10);
+/* ExtractSurfaceDataGpu (GPUExtractSurfaceData.cu:8-228) as every wave kernel runs it, on (hit record, ray) rows against the renderer's CURRENT scene (rows of
+ * tests/golden/ref_kat6.npz: a scene of 1 x 1 textures, where no texture filtering can happen).  hits9 per row: table entry, primitive-local triangle, barycentric u, v
+ * (binary16 bits), t, pixel x, y, two unused; rays9: origin direction contribution.  out35: flags t position normal geomNormal(0) tangent incoming transport color4 tint4
+ * transmittance4 params3.  lumen_mi_test_extract0 runs the depth-0 KERNEL (surface extraction + GenerateMotionVector MotionVectors.cu:8-55 + ResolveDirectLightHits
+ * GPUShadeDirect.cu:11-40, fused) on hit records for every pixel of the render resolution (row-major): G-buffer records [n][8][4], motion vectors (half2 bits), DIRECT [n][4]. */
+int lumen_mi_test_extract(lumen_mi_renderer*, uint32_t n, const uint32_t* hits9, const uint32_t* rays9, uint32_t* out35);
+int lumen_mi_test_extract0(lumen_mi_renderer*, const uint32_t* hits9, const uint32_t* dirs3, const uint32_t* eye3, const uint32_t* matrix16, float* gbuffer, uint32_t* motion, float* direct);
 /* GeneratePrimaryRay (GPUGeneratePrimRay.cu:28-82): the primary-ray kernel on a W x H image; cam = U V W eye; out11 per pixel = x y origin direction contribution */
 int lumen_mi_test_primary_rays(lumen_mi_renderer*, uint32_t W, uint32_t H, uint32_t frame_count, const uint32_t* cam_uvw_eye12, uint32_t* out11);
 /* Known-answer hook for the host-side camera arithmetic of a frame (no renderer, no GPU): the image-plane vectors U, V, W of

@@ -81,6 +81,8 @@ SYMBOLS = {
     "lumen_mi_test_restir_frame": [_R, C.c_uint32, C.c_uint32, _U32P, _U32P, _U32P, C.c_uint32, _U32P, _U32P, C.c_uint32, C.c_int, _U8P, _U8P, C.c_int,
                                    _U32P, _U32P, _U32P, _U32P, _U32P, _U32P],
     "lumen_mi_test_shade": [_R, C.c_uint32, C.c_uint32, C.c_uint32, _U32P, C.c_uint32, _U32P, _U32P, C.c_int, _U32P, _U32P],
+    "lumen_mi_test_extract": [_R, C.c_uint32, _U32P, _U32P, _U32P],
+    "lumen_mi_test_extract0": [_R, _U32P, _U32P, _U32P, _U32P, _FP, _U32P, _FP],
     "lumen_mi_test_primary_rays": [_R, C.c_uint32, C.c_uint32, C.c_uint32, _U32P, _U32P],
     "lumen_mi_test_camera": [_FP, _FP, _FP, _FP, C.c_float, C.c_float, _FP],
     "lumen_mi_get_world_triangles": [_R, _FP, C.c_uint32, _U32P], "lumen_mi_get_lights": [_R, _FP, _FP, C.c_uint32, _U32P],

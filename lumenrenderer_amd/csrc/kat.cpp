@@ -151,6 +151,72 @@ int lumen_mi_test_shade(lumen_mi_renderer* r, uint32_t n, uint32_t W, uint32_t H
     return 0;
 }
 
+int lumen_mi_test_extract(lumen_mi_renderer* r, uint32_t n, const uint32_t* hits9, const uint32_t* rays9, uint32_t* out35)
+{
+    if (!r || !r->initialised) return fail(LUMEN_MI_ERR_STATE, "not initialised");
+    if (!n || !hits9 || !rays9 || !out35) return fail(LUMEN_MI_ERR_INVALID, "bad argument");
+    ApiLock lk(r);
+    LM_HIP(hipSetDevice(r->device));
+    int rc;
+    if ((rc = uploadResources(r))) return rc;
+    if ((rc = flatten(r))) return rc;
+    LM_HIP(hipStreamSynchronize(r->stream));
+    if ((rc = syncScene(r, r->stream))) return rc;
+    for (uint32_t i = 0; i < n; i++) if (hits9[9u * i] >= r->entries.size()) return fail(LUMEN_MI_ERR_INVALID, "hit record names a table entry the scene does not have");
+    Bufs b;
+    uint32_t* dH = b.put<uint32_t>(hits9, (size_t)9 * n); uint32_t* dR = b.put<uint32_t>(rays9, (size_t)9 * n); uint32_t* dO = b.get<uint32_t>((size_t)35 * n);
+    if (!dH || !dR || !dO) return fail(LUMEN_MI_ERR_DEVICE, "allocation failed");
+    lm_kernel_table()->kat_extract(r->stream, r->dscene, n, dH, dR, dO);
+    LM_HIP(hipGetLastError());
+    LM_HIP(hipStreamSynchronize(r->stream));
+    LM_HIP(hipMemcpy(out35, dO, (size_t)35 * n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+/* The depth-0 kernel itself (lm_k_extract0: ExtractSurfaceDataGpu + GenerateMotionVector MotionVectors.cu:8-55 + ResolveDirectLightHits GPUShadeDirect.cu:11-40 fused) on given
+ * hit records of the renderer's current render resolution: hits9 / dirs3 per pixel of the window in row-major pixel order, the eye, the motion matrix; results: the G-buffer
+ * record the kernel stored ([n][8][4] floats as lumen_mi_get_gbuffer gives them), motion vectors (half2 bits) and the DIRECT channel it initialised. */
+int lumen_mi_test_extract0(lumen_mi_renderer* r, const uint32_t* hits9, const uint32_t* dirs3, const uint32_t* eye3, const uint32_t* matrix16, float* gbuffer, uint32_t* motion, float* direct)
+{
+    if (!r || !r->initialised) return fail(LUMEN_MI_ERR_STATE, "not initialised");
+    if (!hits9 || !dirs3 || !eye3 || !matrix16 || !gbuffer || !motion || !direct) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    ApiLock lk(r);
+    LM_HIP(hipSetDevice(r->device));
+    { std::lock_guard<std::mutex> sl(r->settingsMutex); r->settings = r->pending; }
+    int rc;
+    if ((rc = uploadResources(r))) return rc;
+    if ((rc = flatten(r))) return rc;
+    LM_HIP(hipStreamSynchronize(r->stream));
+    if ((rc = syncScene(r, r->stream))) return rc;
+    if ((rc = ensureFrameBuffers(r))) return rc;
+    LmFrame fr = r->fr;
+    const uint32_t n = fr.n;
+    std::vector<float4> rd(n); std::vector<uint4> hh(n);
+    for (uint32_t i = 0; i < n; i++) {                            // queue slot i = pixel i here (any permutation of the pixels is a valid queue: the pixel rides in rayD.w)
+        const uint32_t* h = hits9 + 9u * i;
+        if (h[0] >= r->entries.size()) return fail(LUMEN_MI_ERR_INVALID, "hit record names a table entry the scene does not have");
+        float d[3]; memcpy(d, dirs3 + 3u * i, 12);
+        float w; const uint32_t li = h[6] * fr.ww + h[5]; memcpy(&w, &li, 4);
+        rd[i] = make_float4(d[0], d[1], d[2], w);
+        hh[i] = make_uint4(h[0], h[1], (h[2] & 0xffffu) | (h[3] << 16), h[4]);
+    }
+    fr.motion = r->dMotion[0].p; fr.direct = r->dDirect[0].p; fr.indirect = r->dIndirect[0].p; fr.counters = r->dCounters.p; fr.hits = r->dHits[0].p;
+    fr.rayD[0] = r->dRay[1].p; fr.owedSet = -1; fr.deferred = 0;
+    LM_HIP(hipMemcpy(fr.rayD[0], rd.data(), (size_t)n * 16, hipMemcpyHostToDevice));
+    LM_HIP(hipMemcpy(fr.hits, hh.data(), (size_t)n * 16, hipMemcpyHostToDevice));
+    LM_HIP(hipMemset(fr.counters, 0, LM_CNT_WORDS * 4));
+    LmCamera cam{};
+    for (int k = 0; k < 3; k++) cam.eye[k] = wordToFloat(eye3[k]);
+    for (int k = 0; k < 16; k++) cam.prevViewProj[k] = wordToFloat(matrix16[k]);
+    lm_kernel_table()->extract0(r->stream, r->gridFor(n, 8), r->dscene, fr, cam, 0, 0u, 0, 1, fr.counters + LM_CNT_RAYS(1));
+    LM_HIP(hipGetLastError());
+    LM_HIP(hipStreamSynchronize(r->stream));
+    LM_HIP(hipMemcpy(gbuffer, fr.gbuf[0], (size_t)n * 8 * 16, hipMemcpyDeviceToHost));
+    LM_HIP(hipMemcpy(motion, fr.motion, (size_t)n * 4, hipMemcpyDeviceToHost));
+    LM_HIP(hipMemcpy(direct, fr.direct, (size_t)n * 16, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int lumen_mi_test_primary_rays(lumen_mi_renderer* r, uint32_t W, uint32_t H, uint32_t frame_count, const uint32_t* cam_uvw_eye12, uint32_t* out11)
 {
     if (!r || !r->initialised) return fail(LUMEN_MI_ERR_STATE, "not initialised");

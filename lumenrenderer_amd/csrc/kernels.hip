@@ -1588,6 +1588,30 @@ KN(lm_k_kat_resolve)(LmFrame fr, int rc, const uint32_t* __restrict__ countPtr, 
     const uint32_t li = f2u(qD[i].w);
     lm_vis_resolve(fr, rc, fr.res[rc], li, occluded[li] != 0, pass);
 }
+// ExtractSurfaceDataGpu (GPUExtractSurfaceData.cu:8-228) as every wave kernel runs it: lm_extract on (hit record, ray) rows against the renderer's current scene.
+// hits9: entry prim baryU baryV (binary16 bits) t px py - -; rays9: origin direction contribution.  out35: flags t position normal geomNormal(0: not kept by this
+// build, the reference never reads it) tangent incoming transport color4 tint4 transmittance4 params3
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_kat_extract)(LmScene sc, uint32_t n, const uint32_t* __restrict__ hits9, const uint32_t* __restrict__ rays9, uint32_t* __restrict__ out35)
+{
+    __shared__ float s_lut[256];
+    __shared__ uint4 s_tab[LM_TABLE_QUADS];
+    const lm_lds_float* lut = lm_stage_lut(s_lut, sc);
+    const LmTables tab = lm_stage_tables(s_tab, sc);
+    const uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* h = hits9 + 9u * i; const uint32_t* r = rays9 + 9u * i;
+    const uint4 rec = make_uint4(h[0], h[1], (h[2] & 0xffffu) | (h[3] << 16), h[4]);
+    LmSurface s;
+    lm_extract(sc, lut, tab, rec, v3(u2f(r[0]), u2f(r[1]), u2f(r[2])), v3(u2f(r[3]), u2f(r[4]), u2f(r[5])), v3(u2f(r[6]), u2f(r[7]), u2f(r[8])), s);
+    uint32_t* o = out35 + 35u * i;
+    o[0] = s.flags; o[1] = f2u(s.t);
+    const lf3 v[6] = {s.position, s.normal, v3(0.f), s.tangent, s.incoming, s.transport};
+    for (int k = 0; k < 6; k++) { o[2 + 3 * k] = f2u(v[k].x); o[3 + 3 * k] = f2u(v[k].y); o[4 + 3 * k] = f2u(v[k].z); }
+    const float4 q[3] = {s.mat.color, s.mat.tint, s.mat.transmittance};
+    for (int k = 0; k < 3; k++) { o[20 + 4 * k] = f2u(q[k].x); o[21 + 4 * k] = f2u(q[k].y); o[22 + 4 * k] = f2u(q[k].z); o[23 + 4 * k] = f2u(q[k].w); }
+    o[32] = s.mat.p0; o[33] = s.mat.p1; o[34] = s.mat.p2;
+}
 // ShadeDirect / ShadeIndirect (GPUShadeDirect.cu:42-153, GPUShadeIndirect.cu:7-146) as the wave kernels call them; rows (x, y, seed, surface(40))
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
 KN(lm_k_kat_shade)(LmScene sc, uint32_t n, uint32_t W, const uint32_t* __restrict__ rows43, int fast, uint32_t* __restrict__ direct12, uint32_t* __restrict__ indirect10)
@@ -2022,6 +2046,7 @@ static void l_test_restir(hipStream_t s, int mode, uint32_t n, const float* a, c
 static void l_kat_pack_surfaces(hipStream_t s, const uint32_t* rows40, uint32_t n, float4* gbuf, float4* probe) { hipLaunchKernelGGL(KN(lm_k_kat_pack_surfaces), LM_GRID((n + LM_BLOCK - 1) / LM_BLOCK), rows40, n, gbuf, probe); }
 static void l_kat_reservoirs(hipStream_t s, uint32_t* rows17, uint32_t n, float4* hot, float4* contrib, int unpack) { hipLaunchKernelGGL(KN(lm_k_kat_reservoirs), LM_GRID((n + LM_BLOCK - 1) / LM_BLOCK), rows17, n, hot, contrib, unpack); }
 static void l_kat_resolve(hipStream_t s, LmFrame fr, int rc, const uint32_t* count, const uint8_t* occluded, int pass) { hipLaunchKernelGGL(KN(lm_k_kat_resolve), LM_GRID((fr.n + LM_BLOCK - 1) / LM_BLOCK), fr, rc, count, occluded, pass); }
+static void l_kat_extract(hipStream_t s, LmScene sc, uint32_t n, const uint32_t* hits9, const uint32_t* rays9, uint32_t* out35) { hipLaunchKernelGGL(KN(lm_k_kat_extract), LM_GRID((n + LM_BLOCK - 1) / LM_BLOCK), sc, n, hits9, rays9, out35); }
 static void l_kat_shade(hipStream_t s, LmScene sc, uint32_t n, uint32_t W, const uint32_t* rows43, int fast, uint32_t* direct12, uint32_t* indirect10)
 { hipLaunchKernelGGL(KN(lm_k_kat_shade), LM_GRID((n + LM_BLOCK - 1) / LM_BLOCK), sc, n, W, rows43, fast, direct12, indirect10); }
 static void l_test_math(hipStream_t s, uint32_t n, int fn, const float* x, const float* y, float* out) { hipLaunchKernelGGL(KN(lm_k_test_math), LM_GRID((n + LM_BLOCK - 1) / LM_BLOCK), n, fn, x, y, out); }
@@ -2050,6 +2075,6 @@ extern "C" const LmKernelTable* lm_kernel_table()
 {
     static const LmKernelTable t = {l_primary, l_trace_closest, l_extract0, l_shade_wave, l_trace_shadow, l_path_tail, l_fill_bags, l_pick_primary,
                                     l_trace_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_export_aux, l_refit_tris, l_refit_quant, l_refit_level, l_test_bsdf, l_test_math, l_spin, l_history_copy, l_wave_sync, l_test_restir, l_build_top, l_export_half4, l_sort_rays, l_reuse_settle, l_reuse_counts, l_trace_primary,
-                                    l_kat_pack_surfaces, l_kat_reservoirs, l_kat_resolve, l_kat_shade};
+                                    l_kat_pack_surfaces, l_kat_reservoirs, l_kat_resolve, l_kat_shade, l_kat_extract};
     return &t;
 }

@@ -45,6 +45,7 @@ struct LmKernelTable {
     void (*kat_reservoirs)(hipStream_t, uint32_t* rows17, uint32_t n, float4* hot, float4* contrib, int unpack);
     void (*kat_resolve)(hipStream_t, LmFrame, int rc, const uint32_t* count, const uint8_t* occluded, int pass);
     void (*kat_shade)(hipStream_t, LmScene, uint32_t n, uint32_t W, const uint32_t* rows43, int fast, uint32_t* direct12, uint32_t* indirect10);
+    void (*kat_extract)(hipStream_t, LmScene, uint32_t n, const uint32_t* hits9, const uint32_t* rays9, uint32_t* out35);      // lm_extract on (hit, ray) rows against the current scene
 };
 extern "C" const LmKernelTable* lm_kernel_table();
 extern "C" const LmKernelTable* lm_kernel_table_instrumented();

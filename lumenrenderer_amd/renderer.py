@@ -342,6 +342,22 @@ class LumenRendererMI:
         check(self.lib, self.lib.lumen_mi_test_shade(self.h, n, W, H, up(rows43), lights.shape[0], up(lights), up(cdf), int(fast), None if d is None else up(d), None if i is None else up(i)))
         return d, i
 
+    def TestExtract(self, hits9, rays9):
+        """Known-answer hook (lumen_mi_test_extract): lm_extract on (hit record, ray) rows against the current scene -> [n][35] words."""
+        up = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint32))
+        hits9 = np.ascontiguousarray(hits9, np.uint32); rays9 = np.ascontiguousarray(rays9, np.uint32); out = np.zeros((hits9.shape[0], 35), np.uint32)
+        check(self.lib, self.lib.lumen_mi_test_extract(self.h, hits9.shape[0], up(hits9), up(rays9), up(out)))
+        return out
+
+    def TestExtract0(self, hits9, dirs3, eye3, matrix16):
+        """Known-answer hook (lumen_mi_test_extract0): the depth-0 kernel on hit records for every pixel -> (gbuffer [n][8][4], motion half2 bits [n], direct [n][4])."""
+        up = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint32))
+        hits9 = np.ascontiguousarray(hits9, np.uint32); dirs3 = np.ascontiguousarray(dirs3, np.uint32); n = hits9.shape[0]
+        eye3 = np.ascontiguousarray(eye3, np.uint32); matrix16 = np.ascontiguousarray(matrix16, np.uint32)
+        g = np.zeros((n, 8, 4), np.float32); mv = np.zeros(n, np.uint32); d = np.zeros((n, 4), np.float32)
+        check(self.lib, self.lib.lumen_mi_test_extract0(self.h, up(hits9), up(dirs3), up(eye3), up(matrix16), _fp(g), up(mv), _fp(d)))
+        return g, mv, d
+
     def TestPrimaryRays(self, W, H, frame_count, cam12):
         """Known-answer hook (lumen_mi_test_primary_rays): the primary-ray kernel on a W x H image -> [n][11] words (x y origin direction contribution)."""
         cam12 = np.ascontiguousarray(cam12, np.uint32); out = np.zeros((W * H, 11), np.uint32)

@@ -1001,6 +1001,21 @@ static void restir_run(orc_ctx* c, int cur, int prev, uint32_t a_Seed, const std
 // ----------------------------------------------------------------------------------------------------------
 // motion vectors — CUDAKernels/MotionVectors.cu:8-55; matrices WaveFrontRenderer.cpp:760-781, Camera.cpp:106-109
 // ----------------------------------------------------------------------------------------------------------
+// GenerateMotionVector — CUDAKernels/MotionVectors.cu:8-55: where the surface point was on the previous frame's screen minus where it is now, stored as half2
+static f2 motion_vector(const float* M, const Surface& s, uint32_t px, uint32_t py, uint32_t W, uint32_t H)
+{
+    f2 mv{0.f, 0.f};
+    if (s.t > 0.f) {
+        f2 cur{(float)px, (float)py};
+        cur.x += 0.5f; cur.y += 0.5f;
+        cur.x /= (float)W; cur.y /= (float)H;
+        const f4 clip = mat4_mul(M, mk4(s.position, 1.0f));
+        const f3 ndc = mk3(clip.x, clip.y, clip.z) / clip.w;
+        const f2 prevScreen{ndc.x * 0.5f + 0.5f, ndc.y * 0.5f + 0.5f};
+        mv = f2{quantize_f16(prevScreen.x - cur.x), quantize_f16(prevScreen.y - cur.y)};
+    }
+    return mv;
+}
 static void mat4_mul44(const float* a, const float* b, float* out)        // row-major a*b, sutil Matrix operator* order
 {
     for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) {
@@ -1129,18 +1144,7 @@ static int trace_frame(orc_ctx* c)
                 for (uint32_t k = b; k < e; k++) {
                     const uint32_t i = pixels[k];
                     const uint32_t py = i / W, px = i - py * W;
-                    f2 mv{0.f, 0.f};
-                    const Surface& s = c->surface[currentIndex][i];
-                    if (s.t > 0.f) {
-                        f2 cur{(float)px, (float)py};
-                        cur.x += 0.5f; cur.y += 0.5f;
-                        cur.x /= (float)W; cur.y /= (float)H;
-                        const f4 clip = mat4_mul(M, mk4(s.position, 1.0f));
-                        const f3 ndc = mk3(clip.x, clip.y, clip.z) / clip.w;
-                        const f2 prevScreen{ndc.x * 0.5f + 0.5f, ndc.y * 0.5f + 0.5f};
-                        mv = f2{quantize_f16(prevScreen.x - cur.x), quantize_f16(prevScreen.y - cur.y)};
-                    }
-                    c->motion[i] = mv;
+                    c->motion[i] = motion_vector(M, c->surface[currentIndex][i], px, py, W, H);
                 }
             });
         }
@@ -1602,6 +1606,58 @@ void orc_kat_shade(uint32_t n, uint32_t W, uint32_t H, const uint32_t* rows43, u
             }
         }
     }
+}
+/* Scene-facing kernel bodies on a scene built through the ordinary orc_add_* calls (rows of tests/golden/ref_kat6.npz, generator oracle/ref_kat/gen_kat6.cpp).
+ * orc_kat_extract: ExtractSurfaceDataGpu (GPUExtractSurfaceData.cu:8-228).  hits9 per ray: entry prim baryU baryV (binary16 bits) t px py + 2 unused; rays9: origin dir contribution.
+ * out35 per ray: flags t position normal geomNormal tangent incoming transport color4 tint4 transmittance4 params3 — the record the target buffer holds afterwards,
+ * starting from a zero-filled one (WaveFrontRenderer.cpp:652,818).  orc_kat_motion_vectors: GenerateMotionVector (MotionVectors.cu:8-55) on positions / t.
+ * orc_kat_emissives: FindEmissivesGpu (GPUEmissiveLookup.cu:13-109) as orc_add_primitive ran it: per-triangle flags, returns the light count. */
+void orc_kat_extract(orc_ctx* c, uint32_t n, const uint32_t* hits9, const uint32_t* rays9, uint32_t* out35)
+{
+    c->flatten();
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t* h = hits9 + 9u * i; const uint32_t* r = rays9 + 9u * i;
+        Hit hit{h[0], h[1], (uint16_t)h[2], (uint16_t)h[3], wf(h[4])};
+        Ray ray{(uint16_t)h[5], (uint16_t)h[6], mk3(wf(r[0]), wf(r[1]), wf(r[2])), mk3(wf(r[3]), wf(r[4]), wf(r[5])), mk3(wf(r[6]), wf(r[7]), wf(r[8]))};
+        Surface s; memset(&s, 0, sizeof s);
+        extract_surface(c, hit, ray, s);
+        uint32_t* o = out35 + 35u * i;
+        o[0] = s.flags; o[1] = fw(s.t);
+        const f3 v[6] = {s.position, s.normal, s.geomNormal, s.tangent, s.incoming, s.transport};
+        for (int k = 0; k < 6; k++) { o[2 + 3 * k] = fw(v[k].x); o[3 + 3 * k] = fw(v[k].y); o[4 + 3 * k] = fw(v[k].z); }
+        const f4 q[3] = {s.mat.color, s.mat.tint, s.mat.transmittance};
+        for (int k = 0; k < 3; k++) { o[20 + 4 * k] = fw(q[k].x); o[21 + 4 * k] = fw(q[k].y); o[22 + 4 * k] = fw(q[k].z); o[23 + 4 * k] = fw(q[k].w); }
+        o[32] = s.mat.params[0]; o[33] = s.mat.params[1]; o[34] = s.mat.params[2];
+    }
+}
+void orc_kat_motion_vectors(uint32_t W, uint32_t H, const uint32_t* matrix16, const uint32_t* position_t4, uint32_t* out_half2)
+{
+    float M[16]; for (int k = 0; k < 16; k++) M[k] = wf(matrix16[k]);
+    for (uint32_t i = 0; i < W * H; i++) {
+        Surface s; memset(&s, 0, sizeof s);
+        s.position = mk3(wf(position_t4[4u * i]), wf(position_t4[4u * i + 1u]), wf(position_t4[4u * i + 2u])); s.t = wf(position_t4[4u * i + 3u]);
+        const f2 mv = motion_vector(M, s, i % W, i / W, W, H);
+        out_half2[2u * i] = f32_to_f16(mv.x); out_half2[2u * i + 1u] = f32_to_f16(mv.y);
+    }
+}
+uint32_t orc_kat_emissives(orc_ctx* c, int primitive, uint8_t* flags)
+{
+    const Primitive& p = c->prims[primitive];
+    for (size_t t = 0; t < p.emissive.size(); t++) flags[t] = p.emissive[t];
+    return p.numLights;
+}
+/* the light list in the SLOT ORDER of the light buffer, before ReSTIR sorts it: 16 floats per slot (reserved-but-unset slots are zero) */
+uint32_t orc_kat_light_slots(orc_ctx* c, uint32_t* out16, uint32_t capacity)
+{
+    c->flatten();
+    build_lights(c);
+    const uint32_t n = (uint32_t)c->lights.size();
+    for (uint32_t i = 0; i < n && i < capacity; i++) {
+        const TriLight& l = c->lights[i];
+        const float f[16] = {l.p0.x, l.p0.y, l.p0.z, l.p1.x, l.p1.y, l.p1.z, l.p2.x, l.p2.y, l.p2.z, l.normal.x, l.normal.y, l.normal.z, l.radiance.x, l.radiance.y, l.radiance.z, l.area};
+        for (int k = 0; k < 16; k++) out16[16u * i + k] = fw(f[k]);
+    }
+    return n;
 }
 /* One ReSTIR::Run (Framework/ReSTIR.cpp:65-233) on explicit arrays.  surfPrev40 NULL = the zero-filled buffer of the first frame.  res4: [4][n][17] in / out (the
  * reference's four reservoir buffers).  stages: [5][n][17] = the buffer each kernel wrote, right after it: pick, temporal, spatial-1, spatial-2, combine.

@@ -101,6 +101,12 @@ void orc_kat_primary_rays(uint32_t W, uint32_t H, uint32_t frameCount, const uin
 /* ShadeDirect GPUShadeDirect.cu:42-153 / ShadeIndirect GPUShadeIndirect.cu:7-146 on rows (x, y, seed, surface(40)); either output may be NULL.
  * direct12 = emitted origin direction maxDistance radiance channel; indirect10 = emitted origin direction contribution */
 void orc_kat_shade(uint32_t n, uint32_t W, uint32_t H, const uint32_t* rows43, uint32_t nLights, const uint32_t* lights16, const uint32_t* cdf, uint32_t* direct12, uint32_t* indirect10);
+/* scene-facing kernel bodies (rows of tests/golden/ref_kat6.npz) on a scene built through orc_add_*: ExtractSurfaceDataGpu GPUExtractSurfaceData.cu:8-228, GenerateMotionVector
+ * MotionVectors.cu:8-55, FindEmissivesGpu GPUEmissiveLookup.cu:13-109, BuildLightDataBufferGPU GPUDataBufferKernels.cu:9-186; array shapes in lumen_oracle.cpp */
+void orc_kat_extract(orc_ctx*, uint32_t n, const uint32_t* hits9, const uint32_t* rays9, uint32_t* out35);
+void orc_kat_motion_vectors(uint32_t W, uint32_t H, const uint32_t* matrix16, const uint32_t* position_t4, uint32_t* out_half2);
+uint32_t orc_kat_emissives(orc_ctx*, int primitive, uint8_t* flags);
+uint32_t orc_kat_light_slots(orc_ctx*, uint32_t* out16, uint32_t capacity);
 /* one ReSTIR::Run (Framework/ReSTIR.cpp:65-233; kernels ReSTIRKernels.cu:343-370,402-522,546-582,600-616,787-980,1015-1121,1407-1436) through the same restir_run that
  * renders, the visibility programs replaced by an occlusion mask per pass; see lumen_oracle.cpp for the array shapes */
 void orc_kat_restir_frame(uint32_t W, uint32_t H, const uint32_t* surfCur40, const uint32_t* surfPrev40, const uint32_t* motionHalf2, uint32_t nLights, const uint32_t* lights16,

@@ -87,6 +87,37 @@ out5 = {k: (v.astype(np.uint32) if v.min() >= 0 else v.astype(np.int64)) for k, 
 dst5 = os.path.join(here, "..", "..", "tests", "golden", "ref_kat5.npz")
 np.savez_compressed(dst5, **out5)
 print({k: v.shape for k, v in out5.items()}, "->", os.path.normpath(dst5), os.path.getsize(dst5), "bytes")
+# sixth unit: the scene-facing kernel bodies (surface extraction, motion vectors, light list, emissive lookup) on a scene of 1 x 1 textures (gen_kat6.cpp)
+def slice6(path, first, last, name, edit=None):
+    with open(path, encoding="latin-1") as f:
+        text = "".join(f.readlines()[first - 1:last])
+    if edit:
+        text = edit(text)
+    with open(f"/tmp/lumen_k6_{name}", "w", encoding="latin-1") as f:
+        f.write(text + "\n")
+def bary(text):    # the second (and last) edit made to reference text: an initialiser spelling that is ambiguous against the host-side constructors of the vendored __half2
+    assert text.count("m_Barycentrics({0.f, 0.f})") == 1
+    cc = f"{R}/src/Shaders/CppCommon"                      # (the copy lives in /tmp: its relative includes are pointed back at the reference tree)
+    return (text.replace("m_Barycentrics({0.f, 0.f})", "m_Barycentrics()").replace('#include "Cuda_fp16.h"', "#include <cuda_fp16.h>")
+                .replace('#include "../', f'#include "{cc}/').replace('#include "IntersectionRayData.h"', f'#include "{cc}/WaveFrontDataStructs/IntersectionRayData.h"'))
+slice6(f"{R}/src/Shaders/CppCommon/WaveFrontDataStructs/IntersectionData.h", 1, 10 ** 6, "intersectiondata.h", bary)
+slice6(f"{R}/src/Shaders/CppCommon/WaveFrontDataStructs.h", 13, 13, "pdi.inc")
+slice6(f"{K}/WaveFrontKernels/GPUExtractSurfaceData.cu", 8, 228, "extract.inc")
+slice6(f"{K}/MotionVectors.cu", 8, 55, "motion.inc")
+slice6(f"{K}/WaveFrontKernels/GPUDataBufferKernels.cu", 9, 186, "lights.inc")
+slice6(f"{K}/WaveFrontKernels/GPUEmissiveLookup.cu", 13, 109, "emissives.inc")
+exe = "/tmp/lumen_gen_kat6"
+subprocess.check_call(["/opt/rocm/lib/llvm/bin/clang++", "-std=c++17", "-O1", "-ffp-contract=off", "-Wno-c++11-narrowing", "-D_GNU_SOURCE", "-DNDEBUG", "-w", "-DGLM_ENABLE_EXPERIMENTAL",
+                       "-I/tmp/lumen_k5_inc", f"-I{R}/vendor/Include", f"-I{R}/vendor/Include/Cuda", f"-I{R}/src", f"-I{L}/vendor/glm", f"-I{L}/src", f"-I{R}/vendor/openvdb/nanovdb",
+                       os.path.join(here, "gen_kat6.cpp"), "-o", exe])
+rows6 = {}
+for line in subprocess.check_output([exe], text=True).splitlines():
+    tag, *vals = line.split()
+    rows6.setdefault(tag, []).append([int(v) for v in vals])
+out6 = {k: np.asarray(v, dtype=np.int64) for k, v in rows6.items()}
+dst6 = os.path.join(here, "..", "..", "tests", "golden", "ref_kat6.npz")
+np.savez_compressed(dst6, **out6)
+print({k: v.shape for k, v in out6.items()}, "->", os.path.normpath(dst6), os.path.getsize(dst6), "bytes")
 out = {k: np.asarray(v, dtype=np.float64) for k, v in rows.items()}
 dst = os.path.join(here, "..", "..", "tests", "golden", "ref_kat.npz")
 np.savez_compressed(dst, **out)

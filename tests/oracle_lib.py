@@ -75,6 +75,10 @@ def lib():
             ("orc_world_triangles", [C.c_void_p, fp], C.c_uint32),
             ("orc_lights", [C.c_void_p, fp, fp], C.c_uint32),
             ("orc_get_gbuffer", [C.c_void_p, fp], None),
+            ("orc_kat_extract", [C.c_void_p, C.c_uint32, u32p, u32p, u32p], None),
+            ("orc_kat_motion_vectors", [C.c_uint32, C.c_uint32, u32p, u32p, u32p], None),
+            ("orc_kat_emissives", [C.c_void_p, C.c_int, u8p], C.c_uint32),
+            ("orc_kat_light_slots", [C.c_void_p, u32p, C.c_uint32], C.c_uint32),
             ("orc_kat_light_weights", [C.c_uint32, u32p, u32p], None),
             ("orc_kat_primary_rays", [C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p], None),
             ("orc_kat_shade", [C.c_uint32, C.c_uint32, C.c_uint32, u32p, C.c_uint32, u32p, u32p, u32p, u32p], None),

@@ -285,6 +285,78 @@ def test_device_shade_direct_and_indirect_match_the_reference_kernels(bare):
     assert np.array_equal(got[:, 0], ref[:, 0])
 
 
+@pytest.fixture(scope="module")
+def kat6_pair():
+    import kat6
+    d = kat6.scene()
+    r = product_from(d, kat6.W, kat6.H, 3); o = oracle_from(d, kat6.W, kat6.H, 3)
+    yield r, o
+    r.close(); o.close()
+
+
+KEPT35 = [c for c in range(35) if not 8 <= c < 11]      # geomNormal is not kept by this build (no reference kernel reads it: DESIGN.md)
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_device_surface_extraction_matches_the_reference_kernel(kat6_pair, which):
+    """lm_extract — what lm_k_extract0, lm_k_shade_wave, lm_k_path_tail run per hit — on the hit / ray rows of the reference's own ExtractSurfaceDataGpu text, against
+    the scene loaded through the ordinary API: every kept word bit for bit, for both ray sets (the primary wave; a deeper wave with its own origins and transport)."""
+    import kat6
+    from oracle_lib import u32ptr
+    r, o = kat6_pair
+    h9, r9, want = kat6.hits(which)
+    got = r.TestExtract(h9, r9)
+    orc = np.zeros((kat6.N, 35), np.uint32)
+    o.L.orc_kat_extract(o.h, kat6.N, u32ptr(h9), u32ptr(r9), u32ptr(orc))
+    assert np.array_equal(orc, want)
+    bad = np.flatnonzero((got[:, KEPT35] != want[:, KEPT35]).any(axis=1))
+    assert len(bad) == 0, (len(bad), int(bad[0]), int(want[bad[0], 0]), np.flatnonzero(got[bad[0]] != want[bad[0]]).tolist())
+    assert not got[:, 8:11].any()
+
+
+def test_device_depth0_kernel_matches_the_reference_extraction_and_motion_vector_kernels(kat6_pair):
+    """lm_k_extract0 itself, launched as frame.cpp launches it, on the primary-wave rows: the G-buffer record it stores is the reference's SurfaceData, the motion vector
+    it stores is GenerateMotionVector's (MotionVectors.cu:8-55), and the DIRECT channel starts at the emitter's radiance where one is seen directly
+    (ResolveDirectLightHits, GPUShadeDirect.cu:11-40) and 0 elsewhere."""
+    import kat6
+    r, o = kat6_pair
+    h9, r9, want = kat6.hits(0)
+    M, mv = kat6.motion()
+    eye = np.ascontiguousarray(kat6.gold()["xeye"][0], dtype=np.uint32)
+    assert np.array_equal(r9[:, :3], np.broadcast_to(eye, (kat6.N, 3)))
+    g, got_mv, direct = r.TestExtract0(h9, r9[:, 3:6], eye, M)
+    g = g.view(np.uint32)
+    rows = np.zeros((kat6.N, 35), np.uint32)
+    rows[:, 0] = g[:, 1, 3]; rows[:, 1] = g[:, 0, 3]; rows[:, 2:5] = g[:, 0, :3]; rows[:, 5:8] = g[:, 1, :3]; rows[:, 11:14] = g[:, 2, :3]; rows[:, 14:17] = g[:, 3, :3]
+    rows[:, 17:20] = np.float32(1.0).view(np.uint32)                                          # transport of a primary ray (GPUGeneratePrimRay.cu:77)
+    rows[:, 20:24] = g[:, 4]; rows[:, 24:28] = g[:, 5]; rows[:, 28:32] = g[:, 6]; rows[:, 32:35] = g[:, 7, :3]
+    keep = [c for c in KEPT35 if not 17 <= c < 20]
+    bad = np.flatnonzero((rows[:, keep] != want[:, keep]).any(axis=1))
+    assert len(bad) == 0, (len(bad), int(bad[0]), int(want[bad[0], 0]), np.flatnonzero(rows[bad[0]] != want[bad[0]]).tolist())
+    assert np.array_equal(np.stack([got_mv & 0xffff, got_mv >> 16], axis=1), mv)
+    emit = (want[:, 0] & 1) != 0
+    assert emit.sum() > 400
+    assert np.array_equal(direct[emit, :3].view(np.uint32), want[emit, 20:23]) and not direct[~emit, :3].any()
+
+
+def test_device_light_list_matches_the_reference_kernel(kat6_pair):
+    """lm_k_build_lights on the scene of the rows against BuildLightDataBufferGPU's list (an atomic append on both sides: compared as sets).  Bit for bit with the oracle;
+    against the rows everything but the area bit for bit, the area within 1 ulp (the rows' host compiler evaluated pow(float, int) in double: test_oracle_kat.py)."""
+    import kat6
+    from oracle_lib import u32ptr
+    from test_oracle_kat import _sorted_rows
+    r, o = kat6_pair
+    want, n, _ = kat6.lights()
+    assert r.TraceFrame() is True
+    got = np.ascontiguousarray(r.GetLights()[0]).view(np.uint32).reshape(-1, 16)
+    orc = np.zeros((n + 8, 16), np.uint32)
+    assert o.L.orc_kat_light_slots(o.h, u32ptr(orc), n + 8) == n and len(got) == n
+    a = _sorted_rows(got); b = _sorted_rows(want)
+    assert np.array_equal(a, _sorted_rows(orc[:n]))
+    assert np.array_equal(a[:, :15], b[:, :15])
+    assert np.abs(a[:, 15].astype(np.int64) - b[:, 15].astype(np.int64)).max() <= 1
+
+
 def test_device_contracted_bsdf_matches_the_reference_evaluate_bsdf(bare):
     """The contracted evaluation of the fast policy (lm_quick_setup + lm_quick_eval, lm_bsdf.h) against the reference's EvaluateBSDF
     (disney.cuh:320-405) on the reference-header rows of ref_kat.npz it covers, plus the depth-0 surfaces of the Resample rows

@@ -418,3 +418,78 @@ def test_restir_kernels_match_the_reference_kernels(f):
     if nxt is not None:
         for b in range(4):
             assert_reservoirs_match(out["res4"][b], nxt[b], f"frame {f} buffer {b} handed on")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Scene-facing kernel bodies (tests/golden/ref_kat6.npz, generator oracle/ref_kat/gen_kat6.cpp): ExtractSurfaceDataGpu, GenerateMotionVector, FindEmissivesGpu,
+# BuildLightDataBufferGPU run thread by thread on a scene of 1 x 1 textures.  The oracle loads the same scene through orc_add_* and runs the functions that render.
+# ---------------------------------------------------------------------------------------------------------------------
+import kat6
+
+
+@pytest.fixture(scope="module")
+def kat6_oracle():
+    from helpers import oracle_from
+    return oracle_from(kat6.scene(), kat6.W, kat6.H, 3)
+
+
+def test_scene_rows_are_not_vacuous():
+    g = kat6.gold()
+    for which in (0, 1):
+        _, _, want = kat6.hits(which)
+        flags = {int(v) for v in np.unique(want[:, 0])}
+        assert flags == {0, 1, 2, 4}, flags                                                  # shaded, emitter, alpha cut-out, miss
+        shaded = want[want[:, 0] == 0]
+        assert len(shaded) > 1500 and len(np.unique(shaded[:, 20:35], axis=0)) >= 5          # several distinct materials reach a shaded surface
+        assert len(np.unique(want[want[:, 0] == 1][:, 20:23], axis=0)) >= 3                  # emitters of several radiances (modes ENABLED / OVERRIDE)
+    assert len(np.unique(g["xinst"][:, 2])) == 3                                             # all three EmissionModes (ModelStructs.h:66-71)
+    _, mv = kat6.motion()
+    assert len(np.unique(mv, axis=0)) > 1000
+    lt, n, total = kat6.lights()
+    assert n == len(lt) and n > 16 and total > 0
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_extract_surface_data_matches_the_reference_kernel_bit_for_bit(kat6_oracle, which):
+    h9, r9, want = kat6.hits(which)
+    out = np.zeros((kat6.N, 35), np.uint32)
+    kat6_oracle.L.orc_kat_extract(kat6_oracle.h, kat6.N, u32ptr(h9), u32ptr(r9), u32ptr(out))
+    bad = np.flatnonzero((out != want).any(axis=1))
+    assert len(bad) == 0, (len(bad), int(bad[0]), np.flatnonzero(out[bad[0]] != want[bad[0]]).tolist())
+
+
+def test_motion_vectors_match_the_reference_kernel_bit_for_bit():
+    M, mv = kat6.motion()
+    _, _, want = kat6.hits(0)
+    pos = np.zeros((kat6.N, 4), np.uint32); pos[:, :3] = want[:, 2:5]; pos[:, 3] = want[:, 1]
+    out = np.zeros((kat6.N, 2), np.uint32)
+    lib().orc_kat_motion_vectors(kat6.W, kat6.H, u32ptr(M), u32ptr(pos), u32ptr(out))
+    assert np.array_equal(out, mv)
+
+
+def test_find_emissives_matches_the_reference_kernel(kat6_oracle):
+    g = kat6.gold()
+    for prow in g["xprim"]:
+        p = int(prow[0]); want = g["xemis"][g["xemis"][:, 0] == p][:, 2]
+        flags = np.zeros(len(want), np.uint8)
+        n = kat6_oracle.L.orc_kat_emissives(kat6_oracle.h, p, u8ptr(flags))
+        assert n == int(prow[2]) and np.array_equal(flags, want), p
+
+
+def _sorted_rows(a):
+    return a[np.lexsort(a.view(np.float32).T[::-1])]
+
+
+def test_light_list_matches_the_reference_kernel(kat6_oracle):
+    """BuildLightDataBufferGPU (SceneDataTableAccessor.cu:11-111) appends through an atomic counter: the list is a set, compared sorted.  Vertices, normal and radiance
+    bit for bit.  The area (:96-99) is written with pow(float, int): nvcc resolves that to the float overload powif, the host compiler behind the rows to
+    std::pow(float, int) -> double, so the rows carry sqrt of a double sum rounded once where the device rounds each square — 1 ulp apart at most."""
+    want, n, total = kat6.lights()
+    out = np.zeros((n + 8, 16), np.uint32)
+    got = kat6_oracle.L.orc_kat_light_slots(kat6_oracle.h, u32ptr(out), n + 8)
+    assert got == n
+    a = _sorted_rows(out[:got]); b = _sorted_rows(want)
+    assert np.array_equal(a[:, :15], b[:, :15])
+    fa = a[:, 15].view(np.float32).astype(np.float64); fb = b[:, 15].view(np.float32).astype(np.float64)
+    assert (np.abs(fa - fb) <= np.spacing(fb.astype(np.float32)).astype(np.float64)).all()
+    assert np.abs(a[:, 15].astype(np.int64) - b[:, 15].astype(np.int64)).max() <= 1
