@@ -181,7 +181,7 @@ int lumen_mi_set_instrumented(lumen_mi_renderer*, int enable);   /* use the node
  * (csrc/bvh_gpu.hip; the reference builds its acceleration structures on the GPU too, OptixWrapper.cpp:46-78); 0, default: the host's binned-SAH builder, a better tree that takes
  * ten times as long.  Hit records do not depend on the tree: identical images either way), "tail_repack" (1: the path tail repacks its live paths across the block's
  * wavefronts after every depth; identical image, measured slower, default 0), "spatial_lds" (1: in the fast mode the first spatial reuse pass stages
- * the probes of a 32 x 32 pixel tile + its 30-pixel reach in LDS, 132 KB per block; identical image; default 0: it evicts the other streams' kernels, -5 % on the frame),
+ * the probes of a 32 x 32 pixel tile + its 30-pixel reach in LDS, 132 KB per block; 2: the same with the ordinary 16 x 16 tile, 92 KB per block; identical image; default 0: either evicts the other streams' kernels, measured slower on the frame),
  * "fast_resample" (arithmetic mode of the ReSTIR passes: hardware rcp / rsq / sqrt and the contracted target function; radiance within 1e-3 relative L2 of the exact mode,
  * 1e-8 measured), "fast_shade" (on top of it: the NEE contribution at depth >= 1 with hardware rcp / sqrt: changes the last bits of INDIRECT radiance and, within
  * rounding of two thresholds, whether a shadow ray is emitted; never which path continues). */

@@ -330,7 +330,7 @@ int traceFrameAsync(R* r)
             Z(st); K->temporal(st, tiles, fr, currentIndex, temporalIndex, cur, tmp, fresh, rs, fr.counters + LM_CNT_RESTIR(1), fastRs);         // + visibility rays, pass 2
             if (overlap) LM_HIP(hipEventRecord(r->evTemporal[par], st));
             rs = wangHash(rs);
-            if (!lazy) { Z(st); K->spatial(st, tiles, fr, currentIndex, cur, 2, rs, 30, 0, fastRs | ((fastRs && r->spatialLds) ? 16 : 0)); }
+            if (!lazy) { Z(st); K->spatial(st, tiles, fr, currentIndex, cur, 2, rs, 30, 0, fastRs | ((fastRs && r->spatialLds) ? (r->spatialLds == 2 ? 32 : 16) : 0)); }
             // second visibility pass (ReSTIR.cpp:211-212) works on the CURRENT buffer, which the second spatial pass does not
             // touch: trace it beside that pass.  (It must follow the first spatial pass, which reads the current buffer.)
             hipStream_t sv = (overlap && !pickAhead) ? r->aux3 : st;

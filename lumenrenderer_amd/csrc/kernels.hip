@@ -1063,7 +1063,7 @@ KN(lm_k_restir_temporal_rare)(LmFrame fr, int cur, int prev, int rc, int rp, int
 // LDS_PROBES (first pass only, 1024-thread blocks = 32 x 32 pixel tiles): the block stages the probes of its tile grown by the 30-pixel reach of
 // the neighbour draw — 92 x 92 x 16 B = 132 KB of the CU's 160 KB LDS — with coalesced loads, and the five similarity tests of a pixel read LDS
 // instead of gathering five 16-byte probes through the L1.  The probes are the same bits, so the verdicts and the image are unchanged.
-#define LM_SPATIAL_WIN 92u
+#define LM_SPATIAL_WIN ((1u << LOG_TS) + 60u)
 template <class A, int ROLE, uint32_t LOG_TS = 4, bool LDS_PROBES = false>
 __device__ __forceinline__ void lm_restir_spatial_body(const LmFrame& fr, int cur, int rin, int rout, uint32_t seed, int margin, int pass, float4* s_probe = nullptr, uint32_t vb = blockIdx.x)
 {
@@ -1187,8 +1187,15 @@ KN(lm_k_restir_spatial_fast)(LmFrame fr, int cur, int rin, int rout, uint32_t se
 extern "C" __global__ void __launch_bounds__(1024, 1)
 KN(lm_k_restir_spatial_fast_lds)(LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin)
 {
-    __shared__ float4 s_probe[LM_SPATIAL_WIN * LM_SPATIAL_WIN];
+    __shared__ float4 s_probe[92u * 92u];
     lm_restir_spatial_body<LmFast, LM_COMMON, 5, true>(fr, cur, rin, rout, seed, margin, 0, s_probe);
+}
+// the same with the ordinary 16 x 16 tile (round 4): 76 x 76 probes = 92 KB, one 256-thread block per CU; spatial_lds = 2
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, 1)
+KN(lm_k_restir_spatial_fast_lds16)(LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin)
+{
+    __shared__ float4 s_probe[76u * 76u];
+    lm_restir_spatial_body<LmFast, LM_COMMON, 4, true>(fr, cur, rin, rout, seed, margin, 0, s_probe);
 }
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_SPATIAL_WAVES)
 KN(lm_k_restir_spatial_rare)(LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin, int pass) { lm_restir_spatial_body<LmExact, LM_RARE>(fr, cur, rin, rout, seed, margin, pass); }
@@ -2006,6 +2013,11 @@ static void l_temporal(hipStream_t s, int g, LmFrame fr, int cur, int prev, int 
 static void l_spatial(hipStream_t s, int g, LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin, int pass, int fast)
 {
     // fast | 16: the first pass stages its probe window in LDS (32 x 32 pixel tiles, 1024-thread blocks; tuning key spatial_lds)
+    if ((fast & 32) && pass == 0) {
+        hipLaunchKernelGGL(KN(lm_k_restir_spatial_fast_lds16), LM_GRID(g), fr, cur, rin, rout, seed, margin);
+        if ((fast & 15) > 1) hipLaunchKernelGGL(KN(lm_k_restir_spatial_rare), LM_GRID(g), fr, cur, rin, rout, seed, margin, pass);
+        return;
+    }
     if ((fast & 16) && pass == 0) {
         const int g32 = (int)(((fr.ww + 31u) / 32u) * ((fr.wh + 31u) / 32u));
         hipLaunchKernelGGL(KN(lm_k_restir_spatial_fast_lds), dim3((unsigned)g32), dim3(1024), 0, s, fr, cur, rin, rout, seed, margin);
