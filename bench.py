@@ -35,7 +35,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak, /opt/skills/guides/MI355X_
 # this x 2 for FMA).  Measured on the box with tools/valu_peak.hip -> profiles/r03_valu_peak.txt.  (Round 2 divided by 39.3: wrong by 2x.)
 VALU_PEAK_TLANEOPS = 78.6432
 WAVEINST_PEAK = 1055.8e9         # VALU wave-instructions/s the chip sustains with dependent chains at 8 waves per SIMD (measured, profiles/r03_valu_peak.txt: 2.33 cycles per instruction per SIMD)
-TRAV_T0_US, TRAV_RAYS_PER_US = 60.0, 4600.0   # closest-hit launch of incoherent rays on the C2 scene: T = T0 + rays / R (profiles/r04_step_latency.txt)
+TRAV_T0_US, TRAV_STEPS_PER_US = 60.0, 75000.0  # closest-hit launch of incoherent rays: T = T0 + rays x steps per ray / S; calibration 4.6 G rays/s at 16.3 steps per ray (profiles/r04_step_latency.txt)
 PMC_FILE = os.path.join("profiles", "r04_c2_pmc.json")      # tools/pmc_json.sh on the GPU box; replayed here, never measured by this run
 
 
@@ -438,16 +438,18 @@ def main():
         # divergence leaves (both measured on this scene: profiles/r04_step_latency.txt).  `issue_bound_ms` = the launch's own wave-instructions at the issue peak.
         queue_launches = max(0, int(round(launches_per_tf)) - 1)            # the primary wave is the packet kernel; waves 1.. are the queue kernel
         rays_queue = float(sum(c[4 + d] for d in range(1, 1 + queue_launches)))
-        tm_pred_ms = (queue_launches * TRAV_T0_US + rays_queue / TRAV_RAYS_PER_US) * 1e-3 if queue_launches else None
+        steps_mean = (ci[22] / 4.0 + ci[21]) / all_rays_inst                # traversal steps per ray of this frame (4-wide node steps + triangle tests, counting build)
+        rays_per_us = TRAV_STEPS_PER_US / max(1.0, steps_mean)
+        tm_pred_ms = (queue_launches * TRAV_T0_US + rays_queue / rays_per_us) * 1e-3 if queue_launches else None
         v_tc = pk("lm_k_trace_closest", "SQ_INSTS_VALU_per_launch")
         traversal_model = None if not queue_launches else {
             "kernel": "lm_k_trace_closest (waves 1.." + str(queue_launches) + ")", "launches_per_traceframe": queue_launches, "rays_per_traceframe": int(rays_queue),
-            "model": "T = T0 + rays / R per launch; T0 = dependent chain of the longest ray, R = issue-limited rate at the measured lane occupancy (profiles/r04_step_latency.txt)",
-            "t0_us": TRAV_T0_US, "rays_per_us": TRAV_RAYS_PER_US, "predicted_ms_per_traceframe_alone": round(tm_pred_ms, 4),
+            "model": "T = T0 + rays x steps_per_ray / S per launch; T0 = dependent chain of the longest ray, S = traversal steps per microsecond the chip sustains at the lane occupancy divergence leaves (4.6 G rays/s x 16.3 steps measured on incoherent rays, profiles/r04_step_latency.txt)",
+            "t0_us": TRAV_T0_US, "steps_per_us": TRAV_STEPS_PER_US, "rays_per_us": round(rays_per_us, 1), "predicted_ms_per_traceframe_alone": round(tm_pred_ms, 4),
             "issue_bound_ms_per_traceframe": None if not v_tc else round(queue_launches * v_tc / WAVEINST_PEAK * 1e3, 4),
             "alone_ms_per_traceframe": None if not pk("lm_k_trace_closest", "alone_us") else round(queue_launches * pk("lm_k_trace_closest", "alone_us") * 1e-3, 4),
             "active_lanes_per_valu_inst": pk("lm_k_trace_closest", "active_lanes_per_valu_inst"),
-            "steps_per_ray_mean": round((ci[22] / 4.0 + ci[21]) / all_rays_inst, 2), "steps_longest_ray": int(ci[40]),
+            "steps_per_ray_mean": round(steps_mean, 2), "steps_longest_ray": int(ci[40]),
             "note": "alone ~ predicted means the launches sit ON the chain + issue bound; the live launch_ms of `roofline` is longer because three other streams share the machine"}
         dev = lambda kk: {n: round(kk[n][0] / max(1, kk["total"][1]), 3) for n in kk}
         out = {
