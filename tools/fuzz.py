@@ -45,7 +45,8 @@ shapes = [(1280, 720, 5, None, None), (1280, 720, 6, None, None), (2560, 1440, 6
 t8 = tiles.tile_rect(1, 8, 2560, 1440); shapes.append((2560, 1440, 5, tiles.window_rect(t8, 2560, 1440), t8))
 schedules = [{}, {"pick_ahead": 0}, {"shadow_on_wave": 1}, {"tail_below": 0}, {"tail_below": 1 << 30}, {"tail_below": 60000, "tail_lanes": 64},
              {"tail_pair": 1, "tail_below": 1 << 30}, {"tail_pair": 1, "tail_below": 60000, "tail_lanes": 16},
-             {"lazy_reuse": 1}, {"lazy_reuse": 1, "pick_ahead": 0, "tail_below": 0}, {"lazy_reuse": 1, "wave_streams": 2}, {"lazy_reuse": 0}]
+             {"lazy_reuse": 1}, {"lazy_reuse": 1, "pick_ahead": 0, "tail_below": 0}, {"lazy_reuse": 1, "wave_streams": 2}, {"lazy_reuse": 0},
+             {"tail_repack": 1}, {"tail_repack": 1, "lazy_reuse": 1, "tail_below": 1 << 30}, {"gpu_build": 1}, {"gpu_build": 1, "lazy_reuse": 1, "refit": 0}]        # round 4's options
 bad = total = 0
 t0 = time.time()
 for (W, H, depth, window, tile) in shapes:
