@@ -36,7 +36,9 @@ class PrimitiveData(C.Structure):
 
 
 def library_path():
-    return os.path.join(_HERE, "liblumen_mi.so")
+    """The in-tree library; LUMEN_MI_LIBRARY names another BUILD of the same sources (tools/ab_lib.sh: compile-time variants built beforehand and compared on one GPU box
+    without rebuilding there).  Either way it is the HIP library: there is nothing else to load."""
+    return os.environ.get("LUMEN_MI_LIBRARY") or os.path.join(_HERE, "liblumen_mi.so")
 
 
 # every symbol include/lumen_mi.h declares: (name, argtypes); all return int except last_error

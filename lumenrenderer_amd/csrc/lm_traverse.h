@@ -78,6 +78,68 @@ __device__ __forceinline__ bool lm_woop(const LmWoop* __restrict__ woop, uint32_
     return u + v <= 1.0f;
 }
 
+// The test on rows already in registers (same operations, same order as lm_woop)
+__device__ __forceinline__ bool lm_woop_rows(const float4& r0, const float4& r1, const float4& r2, const lf3& o, const lf3& d,
+                                             float tmin, float tmax, float& t, float& u, float& v)
+{
+    const float Oz = fmaf(r2.x, o.x, fmaf(r2.y, o.y, fmaf(r2.z, o.z, r2.w)));
+    const float Dz = fmaf(r2.x, d.x, fmaf(r2.y, d.y, r2.z * d.z));
+    t = -Oz / Dz;
+    if (!(t > tmin && t < tmax)) return false;
+    const float Ox = fmaf(r0.x, o.x, fmaf(r0.y, o.y, fmaf(r0.z, o.z, r0.w)));
+    const float Dx = fmaf(r0.x, d.x, fmaf(r0.y, d.y, r0.z * d.z));
+    u = fmaf(t, Dx, Ox);
+    if (!(u >= 0.0f)) return false;
+    const float Oy = fmaf(r1.x, o.x, fmaf(r1.y, o.y, fmaf(r1.z, o.z, r1.w)));
+    const float Dy = fmaf(r1.x, d.x, fmaf(r1.y, d.y, r1.z * d.z));
+    v = fmaf(t, Dy, Oy);
+    if (!(v >= 0.0f)) return false;
+    return u + v <= 1.0f;
+}
+// The triangles of one leaf against a lane's ray, in leaf order: visit(slot, t, u, v) for every triangle hit inside (tmin, tmax); it returns true to stop (any-hit).
+// `tested()` runs once per triangle tested (counting build).  LM_LEAF_PAIR (round 4, measured, off): bit 0 — the packets are fetched TWO at a time (six independent 16-byte
+// loads in flight, one wait), so a leaf of c triangles costs ceil(c / 2) dependent round trips instead of c; bit 1 — the leaf's further 128-byte lines are touched at entry
+// so that later iterations hit the L1.  Same tests on the same triangles in the same order: hit records cannot change (the GPU suite passes under every value).  All three
+// are SLOWER on the frame (-1.7 %, -0.7 %, -4.2 %: profiles/r04_leaf_fetch_ab.txt): 12 more live registers spill in the 64-VGPR closest-hit kernel and cost the any-hit
+// kernels a wave per SIMD, and a leaf's packets are contiguous, so most of its later fetches were L1 hits already.
+#ifndef LM_LEAF_PAIR
+#define LM_LEAF_PAIR 0
+#endif
+template <class Visit, class Tested>
+__device__ __forceinline__ void lm_leaf_walk(const LmWoop* __restrict__ woop, uint32_t first, uint32_t count, const lf3& o, const lf3& d, float tmin, float tmax,
+                                             Visit visit, Tested tested)
+{
+#if LM_LEAF_PAIR & 2
+    // touch the leaf's further 128-byte lines now (a leaf's packets are contiguous: <= 384 bytes), so that the later iterations' fetches hit the L1
+    const char* base = (const char*)(woop + first);
+    const uint32_t lastWord = count * 48u - 4u;
+    uint32_t pf1 = *(const uint32_t*)(base + min(128u, lastWord)), pf2 = *(const uint32_t*)(base + min(256u, lastWord));
+#endif
+#if LM_LEAF_PAIR & 1
+    for (uint32_t k = 0; k < count; k += 2u) {
+        const uint32_t s0 = first + k, s1 = first + min(k + 1u, count - 1u);          // an odd leaf's last round fetches its last packet twice (same lines)
+        float4 a2 = woop[s0].r2, a0 = woop[s0].r0, a1 = woop[s0].r1, b2 = woop[s1].r2, b0 = woop[s1].r0, b1 = woop[s1].r1;
+        asm volatile("" : "+v"(a0.x), "+v"(a1.x), "+v"(a2.x), "+v"(b0.x), "+v"(b1.x), "+v"(b2.x));     // all six loads before the first use
+        float t, u, v;
+        tested();
+        if (lm_woop_rows(a0, a1, a2, o, d, tmin, tmax, t, u, v) && visit(s0, t, u, v)) break;
+        if (k + 1u < count) {
+            tested();
+            if (lm_woop_rows(b0, b1, b2, o, d, tmin, tmax, t, u, v) && visit(s1, t, u, v)) break;
+        }
+    }
+#else
+    for (uint32_t k = 0; k < count; k++) {
+        float t, u, v;
+        tested();
+        if (lm_woop(woop, first + k, o, d, tmin, tmax, t, u, v) && visit(first + k, t, u, v)) break;
+    }
+#endif
+#if LM_LEAF_PAIR & 2
+    asm volatile("" :: "v"(pf1), "v"(pf2));
+#endif
+}
+
 __device__ __forceinline__ float lm_safe_rcp(float d)
 {
     const float ooeps = 1e-20f;
@@ -348,20 +410,19 @@ __device__ __forceinline__ bool lm_traverse(const LmScene& sc, const lf3& o, con
         // leaf
         const uint32_t leaf = (uint32_t)(~cur);
         const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
-        for (uint32_t k = 0; k < count; k++) {
-            float t, u, v;
+        lm_leaf_walk(sc.woop, first, count, o, d, tmin, tmax, [&](uint32_t slot, float t, float u, float v) {
+            if (ANY) { found = true; return true; }
+            const uint32_t order = sc.triOrder[slot];
+            if (t < hitT || (t == hitT && found && order < hitOrder)) {
+                hitT = t; hitOrder = order; found = true;
+                hit.t = t; hit.u = u; hit.v = v; hit.slot = slot;
+            }
+            return false;
+        }, [&]() {
 #if LM_INSTRUMENT
             nTris++;
 #endif
-            if (lm_woop(sc.woop, first + k, o, d, tmin, tmax, t, u, v)) {
-                if (ANY) { found = true; break; }
-                const uint32_t order = sc.triOrder[first + k];
-                if (t < hitT || (t == hitT && found && order < hitOrder)) {
-                    hitT = t; hitOrder = order; found = true;
-                    hit.t = t; hit.u = u; hit.v = v; hit.slot = first + k;
-                }
-            }
-        }
+        });
         if (ANY && found) break;
         if (sp == 0) break;
         cur = lm_pop(stack, sp);
@@ -402,20 +463,19 @@ __device__ __forceinline__ bool lm_traverse_mixed(const LmScene& sc, const lf3& 
         if (cur == 0x7fffffff) break;
         const uint32_t leaf = (uint32_t)(~cur);
         const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
-        for (uint32_t k = 0; k < count; k++) {
-            float t, u, v;
+        lm_leaf_walk(sc.woop, first, count, o, d, tmin, tmax, [&](uint32_t slot, float t, float u, float v) {
+            if (any) { found = true; return true; }
+            const uint32_t order = sc.triOrder[slot];
+            if (t < hitT || (t == hitT && found && order < hitOrder)) {
+                hitT = t; hitOrder = order; found = true;
+                hit.t = t; hit.u = u; hit.v = v; hit.slot = slot;
+            }
+            return false;
+        }, [&]() {
 #if LM_INSTRUMENT
             nTris++;
 #endif
-            if (lm_woop(sc.woop, first + k, o, d, tmin, tmax, t, u, v)) {
-                if (any) { found = true; break; }
-                const uint32_t order = sc.triOrder[first + k];
-                if (t < hitT || (t == hitT && found && order < hitOrder)) {
-                    hitT = t; hitOrder = order; found = true;
-                    hit.t = t; hit.u = u; hit.v = v; hit.slot = first + k;
-                }
-            }
-        }
+        });
         if (any && found) break;
         if (sp == 0) break;
         cur = lm_pop(stack, sp);
@@ -478,22 +538,21 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
     auto testLeaf = [&](int ref) {
         const uint32_t leaf = (uint32_t)(~ref);
         const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
-        for (uint32_t k = 0; k < count; k++) {
-            float t, u, v;
+        lm_leaf_walk(sc.woop, first, count, o, d, tmin, tmax, [&](uint32_t slot, float t, float u, float v) {
+            if (ANY) { found = true; return true; }
+            const uint32_t order = sc.triOrder[slot];
+            if (t < hitT || (t == hitT && found && order < hitOrder)) {
+                hitT = t; hitOrder = order; found = true;
+                hit.t = t; hit.u = u; hit.v = v; hit.slot = slot;
+            }
+            return false;
+        }, [&]() {
 #if LM_INSTRUMENT
             nTris++; raySteps++;
             { const unsigned long long m = __ballot(true);       // lane occupancy of this triangle-test issue
               if ((int)lane == __ffsll((long long)m) - 1) { atomicAdd((unsigned long long*)(cnt + LM_CNT_OCC + 4), (unsigned long long)__popcll(m)); atomicAdd((unsigned long long*)(cnt + LM_CNT_OCC + 6), 64ull); } }
 #endif
-            if (lm_woop(sc.woop, first + k, o, d, tmin, tmax, t, u, v)) {
-                if (ANY) { found = true; break; }
-                const uint32_t order = sc.triOrder[first + k];
-                if (t < hitT || (t == hitT && found && order < hitOrder)) {
-                    hitT = t; hitOrder = order; found = true;
-                    hit.t = t; hit.u = u; hit.v = v; hit.slot = first + k;
-                }
-            }
-        }
+        });
     };
     for (;;) {
         // ---- refill idle lanes from the wave's groups
