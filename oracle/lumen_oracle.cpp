@@ -634,6 +634,9 @@ static void extract_surface(const orc_ctx* c, const Hit& h, const Ray& ray, Surf
     dst = out;
 }
 
+// ResolveDirectLightHits — GPUShadeDirect.cu:11-40: an emitter seen directly stores its colour in the (cleared) DIRECT channel
+static inline void resolve_direct_hit(const Surface& s, f4& direct) { if (s.flags & SF_EMISSIVE) direct = s.mat.color; }
+
 // ----------------------------------------------------------------------------------------------------------
 // ShadeDirect — GPUShadeDirect.cu:42-153
 // ----------------------------------------------------------------------------------------------------------
@@ -1151,10 +1154,7 @@ static int trace_frame(orc_ctx* c)
         // Shade()
         std::vector<Ray> next;
         if (depth == 0) {
-            for (uint32_t i : pixels) {                                    // ResolveDirectLightHits, GPUShadeDirect.cu:11-40
-                const Surface& s = S[i];
-                if (s.flags & SF_EMISSIVE) c->channel[0][i] = s.mat.color;
-            }
+            for (uint32_t i : pixels) resolve_direct_hit(S[i], c->channel[0][i]);
             orc_lap("motion+resolve");
             restir_run(c, currentIndex, temporalIndex, seed, pixels);
             orc_lap("restir combine");
@@ -1628,6 +1628,17 @@ void orc_kat_extract(orc_ctx* c, uint32_t n, const uint32_t* hits9, const uint32
         const f4 q[3] = {s.mat.color, s.mat.tint, s.mat.transmittance};
         for (int k = 0; k < 3; k++) { o[20 + 4 * k] = fw(q[k].x); o[21 + 4 * k] = fw(q[k].y); o[22 + 4 * k] = fw(q[k].z); o[23 + 4 * k] = fw(q[k].w); }
         o[32] = s.mat.params[0]; o[33] = s.mat.params[1]; o[34] = s.mat.params[2];
+    }
+}
+/* ResolveDirectLightHits on rows (flags, colour bits x 4): the DIRECT channel afterwards, cleared before, as the reference STORES it (binary16 x 4) */
+void orc_kat_resolve(uint32_t n, const uint32_t* flags, const uint32_t* color4, uint32_t* out_half4)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        Surface s; memset(&s, 0, sizeof s);
+        s.flags = (uint8_t)flags[i]; s.mat.color = f4{wf(color4[4u * i]), wf(color4[4u * i + 1u]), wf(color4[4u * i + 2u]), wf(color4[4u * i + 3u])};
+        f4 d{0.f, 0.f, 0.f, 0.f};
+        resolve_direct_hit(s, d);
+        out_half4[4u * i] = f32_to_f16(d.x); out_half4[4u * i + 1u] = f32_to_f16(d.y); out_half4[4u * i + 2u] = f32_to_f16(d.z); out_half4[4u * i + 3u] = f32_to_f16(d.w);
     }
 }
 void orc_kat_motion_vectors(uint32_t W, uint32_t H, const uint32_t* matrix16, const uint32_t* position_t4, uint32_t* out_half2)

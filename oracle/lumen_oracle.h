@@ -104,6 +104,7 @@ void orc_kat_shade(uint32_t n, uint32_t W, uint32_t H, const uint32_t* rows43, u
 /* scene-facing kernel bodies (rows of tests/golden/ref_kat6.npz) on a scene built through orc_add_*: ExtractSurfaceDataGpu GPUExtractSurfaceData.cu:8-228, GenerateMotionVector
  * MotionVectors.cu:8-55, FindEmissivesGpu GPUEmissiveLookup.cu:13-109, BuildLightDataBufferGPU GPUDataBufferKernels.cu:9-186; array shapes in lumen_oracle.cpp */
 void orc_kat_extract(orc_ctx*, uint32_t n, const uint32_t* hits9, const uint32_t* rays9, uint32_t* out35);
+void orc_kat_resolve(uint32_t n, const uint32_t* flags, const uint32_t* color4, uint32_t* out_half4);
 void orc_kat_motion_vectors(uint32_t W, uint32_t H, const uint32_t* matrix16, const uint32_t* position_t4, uint32_t* out_half2);
 uint32_t orc_kat_emissives(orc_ctx*, int primitive, uint8_t* flags);
 uint32_t orc_kat_light_slots(orc_ctx*, uint32_t* out16, uint32_t capacity);

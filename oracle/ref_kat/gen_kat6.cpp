@@ -2,6 +2,7 @@
 // thread on the host (container-only; contains no reference source text).  make_kat.py slices into /tmp/lumen_k6_*.inc:
 //   WaveFrontKernels/GPUExtractSurfaceData.cu:8-228   ExtractSurfaceDataGpu        (hit record + ray -> SurfaceData: the G-buffer of depth 0 and every deeper wave)
 //   MotionVectors.cu:8-55                             GenerateMotionVector
+//   WaveFrontKernels/GPUShadeDirect.cu:11-40          ResolveDirectLightHits (rows xres k half4 bits: the DIRECT channel after the kernel, cleared before)
 //   WaveFrontKernels/GPUDataBufferKernels.cu:9-186    BuildLightDataBufferGPU + BuildLightDataInstance   (the per-frame emissive-triangle list)
 //   WaveFrontKernels/GPUEmissiveLookup.cu:13-109      FindEmissivesGpu             (per-primitive emissive flags at load time)
 //   WaveFrontDataStructs.h:13 (PIXEL_DATA_INDEX), and Shaders/CppCommon/WaveFrontDataStructs/IntersectionData.h whole, with ONE token changed: the default
@@ -45,7 +46,17 @@ static inline __half2 __float22half2_rn(const float2 f) { __half2 h; h.x = __flo
 static inline float2 __half22float2(const __half2 h) { return make_float2(__half2float(h.x), __half2float(h.y)); }
 static inline float saturate(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
 static std::vector<ushort2> g_mvImage; static unsigned g_mvWidth;
-template <class T> static inline void surf2Dwrite(T v, cudaSurfaceObject_t, int xBytes, int y, int) { static_assert(sizeof(T) == 4, "motion vectors only"); memcpy(&g_mvImage[(size_t)y * g_mvWidth + (size_t)xBytes / 4], &v, 4); }
+static std::vector<ushort4> g_directImage;                // the DIRECT light channel (a half4 surface) as ResolveDirectLightHits writes it
+template <class T> static inline void surf2Dwrite(T v, cudaSurfaceObject_t, int xBytes, int y, int)
+{
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "motion vectors (ushort2) and half4 pixels (ushort4) only");
+    if (sizeof(T) == 4) memcpy(&g_mvImage[(size_t)y * g_mvWidth + (size_t)xBytes / 4], &v, 4);
+    else memcpy(&g_directImage[(size_t)y * g_mvWidth + (size_t)xBytes / 8], &v, 8);
+}
+// Half4.h does not compile on the host (its arithmetic is device intrinsics); ResolveDirectLightHits only CONSTRUCTS a half4 from a float4 and stores its bits:
+// the same two members filled by the same per-element conversion as Half4.h:34-38 (the vendored header's host __float2half)
+struct half4 { __half2 m_Elements[2]; half4(const float4& f) { m_Elements[0].x = __float2half(f.x); m_Elements[0].y = __float2half(f.y); m_Elements[1].x = __float2half(f.z); m_Elements[1].y = __float2half(f.w); } };
+union half4Ushort4 { half4 m_Half4; ushort4 m_Ushort4; half4Ushort4(const float4& f) : m_Half4(f) {} };
 template <class T> static inline T tex2D(cudaTextureObject_t t, float, float) { static_assert(sizeof(T) == 16, "float4 fetches only"); if (!t) return T{0.f, 0.f, 0.f, 0.f}; return *reinterpret_cast<const T*>(t); }
 
 #include "Shaders/CppCommon/MaterialStructs.h"
@@ -69,6 +80,7 @@ GPU_ONLY void BuildLightDataInstance(const LightInstanceData&, const SceneDataTa
 #include "/tmp/lumen_k6_motion.inc"
 #include "/tmp/lumen_k6_lights.inc"
 #include "/tmp/lumen_k6_emissives.inc"
+#include "/tmp/lumen_k6_resolve.inc"
 
 template <class F> static void launch1d(unsigned numBlocks, unsigned blockSize, F body)
 {
@@ -258,6 +270,13 @@ int main()
         g_mvImage.assign(N, ushort2{0, 0}); g_mvWidth = W;
         launch2d((W + 15u) / 16u, (H + 15u) / 16u, 16u, 16u, [&] { GenerateMotionVector(1, surf0.data(), make_uint2(W, H), &M); });
         for (unsigned k = 0; k < N; k++) printf("xmv %u %u %u\n", k, (unsigned)g_mvImage[k].x, (unsigned)g_mvImage[k].y);
+    }
+    // ---- ResolveDirectLightHits on the depth-0 surfaces (GPUShadeDirect.cu:11-40; launch shape CPUShadingKernels.cu:60-77: 2-D over the image): emitters seen directly
+    // store their colour in the (cleared) DIRECT channel
+    {
+        g_directImage.assign(N, ushort4{0, 0, 0, 0}); g_mvWidth = W;
+        launch2d((W + 15u) / 16u, (H + 15u) / 16u, 16u, 16u, [&] { ResolveDirectLightHits(surf0.data(), make_uint2(W, H), 0); });
+        for (unsigned k = 0; k < N; k++) printf("xres %u %u %u %u %u\n", k, (unsigned)g_directImage[k].x, (unsigned)g_directImage[k].y, (unsigned)g_directImage[k].z, (unsigned)g_directImage[k].w);
     }
     // ---- the per-frame light list: LightDataBuffer::BuildLightDataBuffer's instance list (LightDataBuffer.cpp:37-125) and launch shape (CPUDataBufferKernels.cu:36-56), then the kernel
     {

@@ -106,6 +106,7 @@ slice6(f"{K}/WaveFrontKernels/GPUExtractSurfaceData.cu", 8, 228, "extract.inc")
 slice6(f"{K}/MotionVectors.cu", 8, 55, "motion.inc")
 slice6(f"{K}/WaveFrontKernels/GPUDataBufferKernels.cu", 9, 186, "lights.inc")
 slice6(f"{K}/WaveFrontKernels/GPUEmissiveLookup.cu", 13, 109, "emissives.inc")
+slice6(f"{K}/WaveFrontKernels/GPUShadeDirect.cu", 11, 40, "resolve.inc")
 exe = "/tmp/lumen_gen_kat6"
 subprocess.check_call(["/opt/rocm/lib/llvm/bin/clang++", "-std=c++17", "-O1", "-ffp-contract=off", "-Wno-c++11-narrowing", "-D_GNU_SOURCE", "-DNDEBUG", "-w", "-DGLM_ENABLE_EXPERIMENTAL",
                        "-I/tmp/lumen_k5_inc", f"-I{R}/vendor/Include", f"-I{R}/vendor/Include/Cuda", f"-I{R}/src", f"-I{L}/vendor/glm", f"-I{L}/src", f"-I{R}/vendor/openvdb/nanovdb",

@@ -68,3 +68,10 @@ def motion():
 def lights():
     g = gold()
     return np.ascontiguousarray(g["xlight"][:, 1:], dtype=np.uint32), int(g["xnlights"][0, 0]), int(g["xnlights"][0, 1])
+
+
+def resolved():
+    """DIRECT channel after ResolveDirectLightHits on the primary-wave surfaces: [N][4] binary16 bit patterns (0 where the kernel wrote nothing)"""
+    g = gold()
+    assert np.array_equal(g["xres"][:, 0], np.arange(N))
+    return np.ascontiguousarray(g["xres"][:, 1:], dtype=np.uint32)

@@ -77,6 +77,7 @@ def lib():
             ("orc_get_gbuffer", [C.c_void_p, fp], None),
             ("orc_kat_extract", [C.c_void_p, C.c_uint32, u32p, u32p, u32p], None),
             ("orc_kat_motion_vectors", [C.c_uint32, C.c_uint32, u32p, u32p, u32p], None),
+            ("orc_kat_resolve", [C.c_uint32, u32p, u32p, u32p], None),
             ("orc_kat_emissives", [C.c_void_p, C.c_int, u8p], C.c_uint32),
             ("orc_kat_light_slots", [C.c_void_p, u32p, C.c_uint32], C.c_uint32),
             ("orc_kat_light_weights", [C.c_uint32, u32p, u32p], None),

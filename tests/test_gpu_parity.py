@@ -337,6 +337,8 @@ def test_device_depth0_kernel_matches_the_reference_extraction_and_motion_vector
     emit = (want[:, 0] & 1) != 0
     assert emit.sum() > 400
     assert np.array_equal(direct[emit, :3].view(np.uint32), want[emit, 20:23]) and not direct[~emit, :3].any()
+    # ... and, rounded once to the binary16 the reference stores, it is what the reference's own ResolveDirectLightHits text wrote (rows xres)
+    assert np.array_equal(direct[:, :3].astype(np.float16).view(np.uint16).astype(np.uint32), kat6.resolved()[:, :3])
 
 
 def test_device_light_list_matches_the_reference_kernel(kat6_pair):

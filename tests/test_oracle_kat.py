@@ -467,6 +467,18 @@ def test_motion_vectors_match_the_reference_kernel_bit_for_bit():
     assert np.array_equal(out, mv)
 
 
+def test_resolve_direct_light_hits_matches_the_reference_kernel():
+    """ResolveDirectLightHits (GPUShadeDirect.cu:11-40): emitters seen directly put their colour into the DIRECT channel, nobody else writes.  The reference stores
+    binary16; this build keeps fp32 (decision D1), so the comparison is on the value the reference stores: the fp32 colour rounded once."""
+    _, _, want = kat6.hits(0)
+    out = np.zeros((kat6.N, 4), np.uint32)
+    lib().orc_kat_resolve(kat6.N, u32ptr(np.ascontiguousarray(want[:, 0])), u32ptr(np.ascontiguousarray(want[:, 20:24])), u32ptr(out))
+    res = kat6.resolved()
+    assert np.array_equal(out, res)
+    emit = (want[:, 0] & 1) != 0
+    assert res[emit].any(axis=1).all() and not res[~emit].any()
+
+
 def test_find_emissives_matches_the_reference_kernel(kat6_oracle):
     g = kat6.gold()
     for prow in g["xprim"]:
