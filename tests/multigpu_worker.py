@@ -1,4 +1,5 @@
-"""One rank of the tiled multi-GPU path on real GPUs (backend nccl = RCCL).  Launched by tests/test_gpu_parity.py through
+"""One rank of the tiled multi-GPU path on real GPUs (backend nccl = RCCL; with LUMEN_WORKER_ONE_GPU=1 every rank renders on GPU 0 and the same
+operations travel over gloo through host staging: the multi-PROCESS path — rendezvous, halo plan, exchange order, gather — with real rendering on a 1-GPU box).  Launched by tests/test_gpu_parity.py through
 torch.distributed.run when the box has at least two GPUs:  python -m torch.distributed.run --nproc-per-node N tests/multigpu_worker.py
 Every rank renders its window (tile + 60-px halo) of the Cornell box at an odd depth (temporal history is live, so the seam exchange of
 the halo rings' reservoirs runs after every TraceFrame), the tiles are gathered on rank 0 with one RCCL gather per displayed frame, and
@@ -11,19 +12,66 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
+class HostStaged:
+    """torch.distributed look-alike for SEVERAL RANKS ON ONE GPU (LUMEN_WORKER_ONE_GPU=1): RCCL refuses two ranks on one device and gloo does not move device tensors
+    between processes, so every operation tiles.py issues (all_reduce, batch_isend_irecv of P2POp(isend / irecv), gather) is staged device -> host -> gloo -> device.
+    `.cpu()` / `copy_` run on torch's current stream, which is the renderer's stream: the ordering is the production one."""
+
+    def __init__(self, dist):
+        self.d = dist; self.ReduceOp = dist.ReduceOp; self.isend = "isend"; self.irecv = "irecv"
+
+    class P2POp:
+        def __init__(self, op, tensor, peer):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    class _Req:
+        def __init__(self, req, host, dev):
+            self.req, self.host, self.dev = req, host, dev
+
+        def wait(self):
+            self.req.wait()
+            if self.dev is not None:
+                self.dev.copy_(self.host)
+
+    def all_reduce(self, t, op=None):
+        h = t.cpu(); self.d.all_reduce(h, op=op); t.copy_(h)
+
+    def batch_isend_irecv(self, ops):
+        real, pairs = [], []
+        for o in ops:
+            h = o.tensor.cpu() if o.op == "isend" else __import__("torch").empty(o.tensor.shape, dtype=o.tensor.dtype)
+            real.append(self.d.P2POp(self.d.isend if o.op == "isend" else self.d.irecv, h, o.peer))
+            pairs.append((h, None if o.op == "isend" else o.tensor))
+        return [HostStaged._Req(r, h, t) for r, (h, t) in zip(self.d.batch_isend_irecv(real), pairs)]
+
+    def gather(self, send, parts, dst=0):
+        hs = send.contiguous().cpu()
+        hp = [__import__("torch").empty(p.shape, dtype=p.dtype) for p in parts] if parts else None
+        self.d.gather(hs, hp, dst=dst)
+        if parts:
+            for p, h in zip(parts, hp):
+                p.copy_(h)
+
+
 def main():
     import numpy as np
     import torch
     import torch.distributed as dist
     from helpers import cornell, product_from
     from lumenrenderer_amd import tiles
-    rank, world, local_rank = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    one_gpu = os.environ.get("LUMEN_WORKER_ONE_GPU") == "1"
+    rank, world, local_rank = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), 0 if one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     W, H, D, frames = 320, 256, 5, 4
     d = cornell()
     tile = tiles.tile_rect(rank, world, W, H); win = tiles.window_rect(tile, W, H)
-    dist.init_process_group("nccl", device_id=dev)
+    if one_gpu:
+        dist.init_process_group("gloo")
+        real_dist, dist = dist, HostStaged(dist)
+    else:
+        dist.init_process_group("nccl", device_id=dev)
+        real_dist = dist
     r = product_from(d, W, H, D, blend=True, window=win, device=local_rank)
     r.set_stream(torch.cuda.current_stream().cuda_stream)
     r.SetTile(*tile)
@@ -45,12 +93,12 @@ def main():
             mism = int(np.sum(got.view(np.uint32) != want.view(np.uint32)))
             print(f"frame {f}: {mism} differing words", flush=True)
             bad += mism
-    verdict = torch.tensor([bad], dtype=torch.int64, device=dev)
-    dist.broadcast(verdict, src=0)
+    verdict = torch.tensor([bad], dtype=torch.int64, device="cpu" if one_gpu else dev)
+    real_dist.broadcast(verdict, src=0)
     r.close()
     if full is not None:
         full.close()
-    dist.destroy_process_group()
+    real_dist.destroy_process_group()
     if int(verdict[0]) != 0:
         raise SystemExit(f"rank {rank}: stitched frames differ from the single-GPU render")
     if rank == 0:

@@ -2065,6 +2065,21 @@ def test_tiled_path_on_real_gpus_over_rccl(n_ranks):
     assert res.returncode == 0 and "MULTIGPU OK" in res.stdout, res.stdout[-3000:] + res.stderr[-5000:]
 
 
+@pytest.mark.parametrize("n_ranks", [2, 4, 8])
+def test_tiled_worker_processes_share_the_one_gpu(n_ranks):
+    """The production worker as N real processes on the ONE GPU of the development boxes: every rank renders its window on GPU 0, the wave-count agreement, the seam
+    exchange of the halo rings' reservoirs and the tile gather run between the processes (gloo, staged through the host: RCCL does not accept two ranks on one device),
+    and rank 0 compares every blended frame of the stitched image bit for bit with its own full-frame render.  What this does not cover is RCCL itself over xGMI
+    (test_tiled_path_on_real_gpus_over_rccl, skipped without N GPUs)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", LUMEN_WORKER_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29560 + n_ranks), os.path.join(root, "tests", "multigpu_worker.py")]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and "MULTIGPU OK" in res.stdout, res.stdout[-3000:] + res.stderr[-5000:]
+
+
 def test_tiled_worker_single_rank_communicator():
     """The same worker with one rank: the nccl communicator, the preallocated gather buffers and the frame loop on the GPU that is there
     (the 2 / 4 / 8-rank forms above need a multi-GPU box)."""
