@@ -227,8 +227,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # LUMEN_BENCH_ONE_GPU=1: a REHEARSAL of the N-rank path where only one GPU exists — every rank renders on GPU 0, the collectives run over gloo staged through the
+    # host (tiles.HostStagedDist).  It executes every line the N-GPU run executes (windows, seam exchange, gather, per-rank statistics); its rate means nothing and
+    # the JSON line says so ("rehearsal").
+    one_gpu = os.environ.get("LUMEN_BENCH_ONE_GPU", "") == "1" and world > 1
+    if one_gpu:
+        local_rank = 0
     present = torch.cuda.device_count()                   # counting devices does not initialise the GPU
-    if present < world:
+    if present < world and not one_gpu:
         raise SystemExit(f"bench.py: {world} GPUs requested, {present} present")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
@@ -265,7 +271,11 @@ def main():
     force_pg = os.environ.get("LUMEN_BENCH_FORCE_PG", "")          # A/B aid: "before" / "after" create a 1-rank communicator at N = 1
     if (world > 1 or force_pg) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist = tiles.HostStagedDist(dist)
+        else:
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         warm = torch.zeros(1, device=dev); dist.all_reduce(warm)                                   # communicator + stream exist now
         torch.cuda.synchronize()
 
@@ -456,6 +466,7 @@ def main():
             "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "rccl_world": rccl_world, "devices": devices,
+            **({"rehearsal": f"{world} ranks share ONE GPU over gloo with host staging (LUMEN_BENCH_ONE_GPU=1): the N-rank code path executed, NOT a measurement"} if one_gpu else {}),
             # both arithmetic modes at the top level, so that `value` cannot be read without its mode: "fast" = hardware rcp / rsq / sqrt +
             # contracted target function in the ReSTIR passes (the reference's Release build is -use_fast_math); "exact" = bit-identical to the oracle
             "mode": args.mode, "value_fast": round((main_pass if fast else other_pass)["value"], 3) if (fast or other_pass) else None,

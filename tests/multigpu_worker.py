@@ -12,47 +12,6 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
-class HostStaged:
-    """torch.distributed look-alike for SEVERAL RANKS ON ONE GPU (LUMEN_WORKER_ONE_GPU=1): RCCL refuses two ranks on one device and gloo does not move device tensors
-    between processes, so every operation tiles.py issues (all_reduce, batch_isend_irecv of P2POp(isend / irecv), gather) is staged device -> host -> gloo -> device.
-    `.cpu()` / `copy_` run on torch's current stream, which is the renderer's stream: the ordering is the production one."""
-
-    def __init__(self, dist):
-        self.d = dist; self.ReduceOp = dist.ReduceOp; self.isend = "isend"; self.irecv = "irecv"
-
-    class P2POp:
-        def __init__(self, op, tensor, peer):
-            self.op, self.tensor, self.peer = op, tensor, peer
-
-    class _Req:
-        def __init__(self, req, host, dev):
-            self.req, self.host, self.dev = req, host, dev
-
-        def wait(self):
-            self.req.wait()
-            if self.dev is not None:
-                self.dev.copy_(self.host)
-
-    def all_reduce(self, t, op=None):
-        h = t.cpu(); self.d.all_reduce(h, op=op); t.copy_(h)
-
-    def batch_isend_irecv(self, ops):
-        real, pairs = [], []
-        for o in ops:
-            h = o.tensor.cpu() if o.op == "isend" else __import__("torch").empty(o.tensor.shape, dtype=o.tensor.dtype)
-            real.append(self.d.P2POp(self.d.isend if o.op == "isend" else self.d.irecv, h, o.peer))
-            pairs.append((h, None if o.op == "isend" else o.tensor))
-        return [HostStaged._Req(r, h, t) for r, (h, t) in zip(self.d.batch_isend_irecv(real), pairs)]
-
-    def gather(self, send, parts, dst=0):
-        hs = send.contiguous().cpu()
-        hp = [__import__("torch").empty(p.shape, dtype=p.dtype) for p in parts] if parts else None
-        self.d.gather(hs, hp, dst=dst)
-        if parts:
-            for p, h in zip(parts, hp):
-                p.copy_(h)
-
-
 def main():
     import numpy as np
     import torch
@@ -68,7 +27,7 @@ def main():
     tile = tiles.tile_rect(rank, world, W, H); win = tiles.window_rect(tile, W, H)
     if one_gpu:
         dist.init_process_group("gloo")
-        real_dist, dist = dist, HostStaged(dist)
+        real_dist, dist = dist, tiles.HostStagedDist(dist)          # device tensors staged through the host: RCCL refuses two ranks on one device
     else:
         dist.init_process_group("nccl", device_id=dev)
         real_dist = dist

@@ -2080,6 +2080,27 @@ def test_tiled_worker_processes_share_the_one_gpu(n_ranks):
     assert res.returncode == 0 and "MULTIGPU OK" in res.stdout, res.stdout[-3000:] + res.stderr[-5000:]
 
 
+@pytest.mark.parametrize("n_ranks,workload", [(2, "sandbox"), (8, "c2")])
+def test_bench_multi_rank_path_rehearsed_on_the_one_gpu(n_ranks, workload):
+    """`python bench.py --gpus N` end to end where only one GPU exists (LUMEN_BENCH_ONE_GPU=1: every rank on GPU 0, collectives over gloo with host staging): the
+    self-launch, the windows and tiles, the seam exchange after every TraceFrame (sandbox: odd depth), the gather, the barrier-bracketed timing with the maximum over
+    ranks and the per-rank statistics all execute, and rank 0 prints ONE well-formed line that names itself a rehearsal.  The rate is not looked at."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", LUMEN_BENCH_ONE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n_ranks), "--workload", workload, "--steps", "2", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=1200)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == n_ranks and j["rccl_world"] == n_ranks and len(j["devices"]) == n_ranks and "rehearsal" in j
+    assert len(j["per_rank"]) == n_ranks and all(p["render_ms_per_step"] > 0 for p in j["per_rank"])
+    assert j["value"] > 0 and j["scaling"] == "strong" and j["config"]["tiles"].split(" ")[0] in ("2x1", "1x2", "4x2", "2x4")
+
+
 def test_tiled_worker_single_rank_communicator():
     """The same worker with one rank: the nccl communicator, the preallocated gather buffers and the frame loop on the GPU that is there
     (the 2 / 4 / 8-rank forms above need a multi-GPU box)."""
