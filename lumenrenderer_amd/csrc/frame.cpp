@@ -185,7 +185,7 @@ int traceFrameAsync(R* r)
     const int fastRs = r->fastResample ? (r->anyRareMaterial ? 2 : 1) : 0;
     // visibility rays of the ReSTIR passes: packets under the same rule (tuning key packet_visibility: 1 on, 0 off, -1 automatic)
     const bool visPackets = r->packetVisibility > 0 || (r->packetVisibility < 0 && (uint64_t)r->triEntry.size() * 4u < (uint64_t)r->fr.n && r->fr.n > 0);
-    const bool usePackets = r->packetPrimary > 0 || (r->packetPrimary < 0 && (uint64_t)r->triEntry.size() * 4u < (uint64_t)r->fr.n && r->fr.n > 0);
+    const bool usePackets = r->packetPrimary > 0 || (r->packetPrimary < 0 && (uint64_t)r->triEntry.size() * 3u < (uint64_t)r->fr.n && r->fr.n > 0);
 
     // camera (Camera.cpp:79-93,122-140; aspect = render W/H, WaveFrontRenderer.cpp:577)
     LmCamera cam;

@@ -205,8 +205,9 @@ struct lumen_mi_renderer {
                                             // Measured 3x SLOWER on C2 (profiles/r03_packet_visibility_ab.txt): a tile's visibility rays start on surfaces at very
                                             // different depths, the union of their paths is large, and an any-hit packet runs until its last unoccluded ray is through
     int packetPrimary = -1;                 // the primary wave is traced as packets (one shared stack per wavefront, lm_trace_packets): 1 on, 0 off,
-                                            // -1 auto = when the window has more than 4 pixels per scene triangle (a wavefront's 8 x 8 pixel tile then meets
-                                            // few distinct leaves: C2 / C3 +1.2 %; with sub-pixel geometry the union of 64 rays' nodes costs more: C5 -11 %)
+                                            // -1 auto = when the window has more than 3 pixels per scene triangle (a wavefront's 8 x 8 pixel tile then meets
+                                            // few distinct leaves: C2 / C3 +1.2 % at 14 pixels per triangle, the Sandbox's 720p window +0.85 % at 3.5, profiles/
+                                            // r04_sandbox_packet_ab.txt; with sub-pixel geometry the union of 64 rays' nodes costs more: C5 -11 % at 0.2)
     int sortRays = 0;                       // > 0: continuation-ray queues of waves 1 .. sortRays are reordered by (origin cell, octant) before their closest-hit launch
     DevBuf<uint32_t> dSortBins;             // 2 x 4096 words (histogram + cursors)
     int fastResample = 0;                   // 1: the ReSTIR target function and resampling weights use hardware rcp / rsq / sqrt (LmFast): within 1e-3 rel-L2
