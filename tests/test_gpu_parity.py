@@ -2080,7 +2080,7 @@ def test_tiled_worker_processes_share_the_one_gpu(n_ranks):
     assert res.returncode == 0 and "MULTIGPU OK" in res.stdout, res.stdout[-3000:] + res.stderr[-5000:]
 
 
-@pytest.mark.parametrize("n_ranks,workload", [(2, "sandbox"), (8, "c2")])
+@pytest.mark.parametrize("n_ranks,workload", [(2, "sandbox"), (8, "c2"), (8, "c4")])      # c4 = BASELINE's 8-GPU configuration (4K, 8 spp, depth 8)
 def test_bench_multi_rank_path_rehearsed_on_the_one_gpu(n_ranks, workload):
     """`python bench.py --gpus N` end to end where only one GPU exists (LUMEN_BENCH_ONE_GPU=1: every rank on GPU 0, collectives over gloo with host staging): the
     self-launch, the windows and tiles, the seam exchange after every TraceFrame (sandbox: odd depth), the gather, the barrier-bracketed timing with the maximum over
