@@ -231,7 +231,13 @@ KN(lm_k_trace_closest_packet)(LmScene sc, const float4* __restrict__ rayO, const
 // K7 (depth 0) + K9 motion vectors (MotionVectors.cu:8-55) + K10 ResolveDirectLightHits (GPUShadeDirect.cu:11-40) + channel clear
 // + K12 at depth 0 (GPUShadeIndirect.cu:7-146): the path continuation is sampled from the surface while it is still in
 // registers; survivors of a block iteration are appended to the wave-1 queue with ONE atomic.
-extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+#ifndef LM_EXTRACT_WAVES
+#define LM_EXTRACT_WAVES 1       // minimum waves per SIMD asked of the compiler for the depth-0 kernel / the wave shading kernel (1 = no bound: 120 / 124 VGPRs, four waves)
+#endif
+#ifndef LM_SHADE_WAVES
+#define LM_SHADE_WAVES 1
+#endif
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_EXTRACT_WAVES)
 KN(lm_k_extract0)(LmScene sc, LmFrame fr, LmCamera cam, int cur, uint32_t seed2, int doIndirect, int outQ, uint32_t* outCount)
 {
     __shared__ uint32_t s_tmp[10];
@@ -352,7 +358,7 @@ __device__ __forceinline__ void lm_shade_wave_body(const LmScene& sc, const LmFr
         }
     }
 }
-extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_SHADE_WAVES)
 KN(lm_k_shade_wave)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict__ inCount, uint32_t seed, uint32_t seed2, int doIndirect, uint32_t* outCount, uint32_t* shadowCount)
 { lm_shade_wave_body<LmExact>(sc, fr, inQ, inCount, seed, seed2, doIndirect, outCount, shadowCount); }
 // tuning key fast_shade: the NEE contribution with hardware reciprocal / square root (lm_shade.h lm_shade_direct)
