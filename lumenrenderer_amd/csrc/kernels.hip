@@ -750,7 +750,7 @@ KN(lm_k_fill_bags)(LmScene sc, LmFrame fr, uint32_t seed, uint32_t total)
                                    // builds interleaved on one box): the 16 KB double as the residency cap the other streams' kernels need.
 template <class A, int ROLE, bool LDSL = false>
 __device__ __forceinline__ void lm_pick_primary_body(const LmScene& sc, const LmFrame& fr, int cur, int rc, uint32_t seed, uint32_t* visCount, uint2* s_bag, uint32_t* s_tmp,
-                                                     float4* s_lights = nullptr)
+                                                     float4* s_lights = nullptr, uint32_t vb = blockIdx.x)
 {
     if (ROLE == LM_RARE && fr.counters[LM_CNT_RARE] == 0u) return;      // grid-uniform: no surface of this frame needs the second launch
     if constexpr (LDSL) {
@@ -767,7 +767,7 @@ __device__ __forceinline__ void lm_pick_primary_body(const LmScene& sc, const Lm
     const uint32_t tilesX = (fr.W + 15u) / 16u;
     const uint32_t tx0 = fr.x0 / 16u, ty0 = fr.y0 / 16u;
     const uint32_t wtx = (fr.x0 + fr.ww + 15u) / 16u - tx0;
-    const uint32_t tileX = tx0 + blockIdx.x % wtx, tileY = ty0 + blockIdx.x / wtx;
+    const uint32_t tileX = tx0 + vb % wtx, tileY = ty0 + vb / wtx;
     uint32_t bagSeed = lm_wang_hash(seed + (tileY * tilesX + tileX));
     const float rb = lm_random_float(bagSeed);
     const int bagIndex = (int)roundf((float)(50 - 1) * rb);
@@ -890,6 +890,23 @@ KN(lm_k_pick_primary_fast_lds)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t
     extern __shared__ float4 s_lights[];
 #endif
     lm_pick_primary_body<LmFast, LM_COMMON, true>(sc, fr, cur, rc, seed, visCount, s_bag, s_tmp, s_lights);
+}
+// LM_PICK_PERSIST = N > 0 (round 4): the same kernel as a PERSISTENT grid of N blocks per CU that loops over the tiles, with the light table sized by the launch.  The
+// residency cap of the static table (five blocks per CU, above) is then the grid's size and no longer 24 KB of LDS per block that nobody reads: 8 KB + 64 B per light stay,
+// and the kernels of the other streams (19.5 KB per block of the shading kernels, 17.7 KB of the traversal kernels) find room on the CU while the pick runs.
+#ifndef LM_PICK_PERSIST
+#define LM_PICK_PERSIST 0
+#endif
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_FAST_WAVES)
+KN(lm_k_pick_primary_fast_lds_persist)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount, uint32_t tiles)
+{
+    __shared__ uint2 s_bag[1000];
+    __shared__ uint32_t s_tmp[5];
+    extern __shared__ float4 s_lights[];
+    for (uint32_t vb = blockIdx.x; vb < tiles; vb += gridDim.x) {
+        lm_pick_primary_body<LmFast, LM_COMMON, true>(sc, fr, cur, rc, seed, visCount, s_bag, s_tmp, s_lights, vb);
+        __syncthreads();                                        // the next tile's bag overwrites s_bag / s_tmp
+    }
 }
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
 KN(lm_k_pick_primary_rare)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount)
@@ -2001,7 +2018,11 @@ static void l_pick_primary(hipStream_t s, int tiles, LmScene sc, LmFrame fr, int
     const bool ldsLights = sc.numLights <= LM_PICK_LDS_LIGHTS && LM_PICK_LDS_LIGHTS > 0u;
     const size_t lightBytes = LM_PICK_STATIC_LDS ? 0u : (size_t)64 * sc.numLights + 16u;         // dynamic LDS of the *_lds kernels
     if (fast) {
-        if (ldsLights) hipLaunchKernelGGL(KN(lm_k_pick_primary_fast_lds), dim3((unsigned)tiles), dim3(LM_BLOCK), lightBytes, s, sc, fr, cur, rc, seed, visCount);
+        if (ldsLights && LM_PICK_PERSIST > 0) {
+            int dev = 0, cus = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            const unsigned grid = (unsigned)std::min(tiles, cus * (int)LM_PICK_PERSIST);
+            hipLaunchKernelGGL(KN(lm_k_pick_primary_fast_lds_persist), dim3(grid), dim3(LM_BLOCK), (size_t)64 * sc.numLights + 16u, s, sc, fr, cur, rc, seed, visCount, (uint32_t)tiles);
+        } else if (ldsLights) hipLaunchKernelGGL(KN(lm_k_pick_primary_fast_lds), dim3((unsigned)tiles), dim3(LM_BLOCK), lightBytes, s, sc, fr, cur, rc, seed, visCount);
         else hipLaunchKernelGGL(KN(lm_k_pick_primary_fast), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount);
         if (fast > 1) hipLaunchKernelGGL(KN(lm_k_pick_primary_rare), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount);
     } else if (ldsLights) hipLaunchKernelGGL(KN(lm_k_pick_primary_lds), dim3((unsigned)tiles), dim3(LM_BLOCK), lightBytes, s, sc, fr, cur, rc, seed, visCount);
