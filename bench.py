@@ -61,8 +61,12 @@ WORKLOADS = {
     # switches blending off (OutputLayer.cpp:492-495): 1 "spp", an odd depth — the reservoir swap chain turns every frame, the temporal pass reads a live
     # history through non-zero motion vectors, and the history passes run with their frame (no lazy reuse).  A step = one TraceFrame at the next camera pose.
     "sandbox": ("sponza", dict(), 1280, 720, 5, 1),
+    # the same setting on the reference's own DEFAULT MODEL (Sandbox/src/AppConfigDefaults.h:11: LowpolyRoom/scene.glb, 20 501 triangles, lit by its three emissive
+    # materials only = 414 triangle lights; tests/golden/ref_lowpoly_room.npz) from the camera Application.cpp:145-146 sets, walking as OutputLayer.cpp's input handling
+    # moves the reference's own Camera class (W held + mouse drag; 64 poses in the fixture)
+    "lowpoly": ("lowpoly", dict(), 1280, 720, 5, 1),
 }
-MOVING = {"sandbox"}             # workloads whose camera moves every TraceFrame (lumenrenderer_amd.scenes.sandbox_camera_pose), blending off
+MOVING = {"sandbox", "lowpoly"}             # workloads whose camera moves every TraceFrame (lumenrenderer_amd.scenes.sandbox_camera_pose), blending off
 
 
 def make_scene(kind, kw):
@@ -71,6 +75,8 @@ def make_scene(kind, kw):
         return scenes.sponza_standin(**kw)
     if kind == "foliage":
         return scenes.foliage_stress(**kw)
+    if kind == "lowpoly":
+        return scenes.lowpoly_room(os.path.join(ROOT, "tests", "golden", "ref_lowpoly_room.npz"))
     return scenes.cornell_box(fixture=os.path.join(ROOT, "tests", "golden", "cornell_box.npz"))
 
 
@@ -121,16 +127,22 @@ def self_launch(args, argv):
     import subprocess
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    # LUMEN_BENCH_LOG_DIR: every rank's stdout / stderr also lands in <dir>/<run>/attempt_0/<rank>/{stdout,stderr}.log, so that a rank that dies can be read afterwards
+    logs = ["--log-dir", os.environ["LUMEN_BENCH_LOG_DIR"], "--tee", "3"] if os.environ.get("LUMEN_BENCH_LOG_DIR") else []
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + [a for a in argv if a != "--dry-launch"]
+           "--master-port", str(port)] + logs + [os.path.abspath(__file__)] + [a for a in argv if a != "--dry-launch"]
     if args.dry_launch:
         print(json.dumps({"launch": cmd}))
         return 0
     env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
     line_json = None
+    import re
     for line in p.stdout:
         s = line.strip()
+        m = re.match(r"^\[[A-Za-z_]+\d+\]:(.*)$", s)      # --tee prefixes every line with its rank ("[default0]:")
+        if m and m.group(1).startswith("{") and '"metric"' in m.group(1):
+            s = m.group(1)
         if s.startswith("{") and '"metric"' in s:
             line_json = s                                   # held back: printed last
         else:
@@ -145,6 +157,9 @@ def camera_pose(desc, k):
     """Pose of the k-th TraceFrame of a moving workload: the 32-frame walk of scenes.sandbox_camera_pose there and back again (the camera stays in the atrium
     however many steps are timed; every frame still moves by one step)."""
     from lumenrenderer_amd import scenes
+    if hasattr(desc, "camera_poses"):                     # LowpolyRoom: the fixture's 64 poses of the reference's Camera class, there and back
+        k %= 126
+        return scenes.lowpoly_camera_pose(desc, k if k < 64 else 126 - k)
     k %= 64
     return scenes.sandbox_camera_pose(desc, k if k < 32 else 64 - k)
 
@@ -218,6 +233,8 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args, sys.argv[1:]))
 
+    import faulthandler
+    faulthandler.enable()                                 # a rank that dies on a signal (SIGABRT / SIGSEGV from a library) leaves its Python stack on stderr
     import torch
     import torch.distributed as dist
     from lumenrenderer_amd import LumenRendererMI, tiles
@@ -228,7 +245,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     # LUMEN_BENCH_ONE_GPU=1: a REHEARSAL of the N-rank path where only one GPU exists — every rank renders on GPU 0, the collectives run over gloo staged through the
-    # host (tiles.HostStagedDist).  It executes every line the N-GPU run executes (windows, seam exchange, gather, per-rank statistics); its rate means nothing and
+    # host (tests/host_staged_dist.py).  It executes every line the N-GPU run executes (windows, seam exchange, gather, per-rank statistics); its rate means nothing and
     # the JSON line says so ("rehearsal").
     one_gpu = os.environ.get("LUMEN_BENCH_ONE_GPU", "") == "1" and world > 1
     if one_gpu:
@@ -262,7 +279,7 @@ def main():
     if world > 1 or emu:
         r.SetTile(*tile)                                  # halo pixels only get the work the tile's ReSTIR reuse needs
     wh, ww = win[3] - win[1], win[2] - win[0]
-    window_buf = torch.empty((wh, ww, 4), dtype=torch.float32, device=dev)
+    emu_tile_buf = torch.empty((tile[3] - tile[1], tile[2] - tile[0], 4), dtype=torch.float32, device=dev) if emu else None
     # The renderer's four streams are created and used once BEFORE the RCCL communicator brings its own stream: HIP maps
     # streams onto 4 hardware queues, and two busy streams that end up sharing one serialise (measured -11 % at N = 1 with an
     # idle fifth stream created first).  RCCL's stream only works between frames, when the renderer's streams are idle.
@@ -273,7 +290,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         if one_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
-            dist = tiles.HostStagedDist(dist)
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from host_staged_dist import HostStagedDist          # test infrastructure (tests/): gloo through host staging, rehearsal only
+            dist = HostStagedDist(dist)
         else:
             dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         warm = torch.zeros(1, device=dev); dist.all_reduce(warm)                                   # communicator + stream exist now
@@ -300,11 +319,14 @@ def main():
             r.TraceFrameAsync()
             if hx is not None:
                 hx.run(dist)
-        r.CopyRadianceToDevice(window_buf.data_ptr())
         if record:
             evs[1].record()
-        local = window_buf[tile[1] - win[1]: tile[3] - win[1], tile[0] - win[0]: tile[2] - win[0]]
-        out = local if emu else tiles.gather_tiles(local, rank, world, W, H, dist)
+        # the tile (halo removed) goes from the renderer's merged radiance straight into the gather's send buffer, the gathered tiles into the frame on rank 0: the
+        # library's own pitched-copy kernel on the renderer's stream (tiles.TileGather.run_renderer), then ONE gather (RCCL over xGMI)
+        if emu:
+            r.CopyRadianceRectToDevice(tile, emu_tile_buf.data_ptr(), tile[2] - tile[0]); out = emu_tile_buf
+        else:
+            out = tiles.gather_from_renderer(r, rank, world, W, H, dist, dev)
         if record:
             evs[2].record(); ev_log.append(evs)
         return out
@@ -477,7 +499,7 @@ def main():
             "reuse": args.reuse,
             "value_eager_reuse": rate(fast, False), "value_lazy_reuse": rate(fast, True), "ms_per_step_lazy_reuse": rate(fast, True, "ms_per_step", 4),
             "value_exact_lazy_reuse": rate(False, True), "value_exact_eager_reuse": rate(False, False),
-            "config": {"workload": f"{args.workload}: {'cornell box (the reference asset, tests/golden fixture)' if kind == 'cornell' else kind + ' stand-in'}, {W}x{H}, " +
+            "config": {"workload": f"{args.workload}: {'cornell box (the reference asset, tests/golden fixture)' if kind == 'cornell' else 'LowpolyRoom/scene.glb (the Sandbox default model, tests/golden fixture)' if kind == 'lowpoly' else kind + ' stand-in'}, {W}x{H}, " +
                                    ("1 TraceFrame per step at a new camera pose (blending off: the Sandbox's own default setting, Application.cpp:89-93, live temporal history)" if moving else f"{spp} spp (blended TraceFrames)") +
                                    f", depth {depth}, ReSTIR DI on",
                        "resample_mode": ("fast: hardware rcp/rsq/sqrt + contracted target function in the ReSTIR passes (rel-L2 vs oracle 1e-8 measured, 1e-3 asserted: "

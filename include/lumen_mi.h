@@ -127,6 +127,11 @@ int lumen_mi_get_radiance(lumen_mi_renderer*, float* rgba32f, size_t capacity_by
  * GPUMergeOutputChannels.cu:5-88, Half4.h:9-96).  8 bytes per pixel of the render window. */
 int lumen_mi_get_radiance_half4(lumen_mi_renderer*, uint16_t* rgba16f, size_t capacity_bytes);
 int lumen_mi_copy_radiance_device(lumen_mi_renderer*, void* device_rgba32f);              /* same, device-to-device on the renderer's stream (RCCL gather source) */
+/* Tile gather (multi-GPU; no reference equivalent): the rectangle [x0, x1) x [y0, y1) of the IMAGE, which must lie inside the render window, copied
+ * out of the merged radiance into a device image of `dst_pitch` RGBA32F pixels per row (dst = the rectangle's first pixel); and a w x h rectangle between two pitched
+ * device images (a gathered tile into the assembled frame).  Both run on the renderer's stream as a kernel of this library. */
+int lumen_mi_copy_radiance_rect_device(lumen_mi_renderer*, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, void* device_dst, uint32_t dst_pitch);
+int lumen_mi_copy_rect_device(lumen_mi_renderer*, void* device_dst, uint32_t dst_pitch, const void* device_src, uint32_t src_pitch, uint32_t w, uint32_t h);
 int lumen_mi_get_channel(lumen_mi_renderer*, int channel, float* rgba32f, size_t capacity_bytes);   /* 0 DIRECT, 1 INDIRECT */
 int lumen_mi_get_gbuffer(lumen_mi_renderer*, float* planes8x4, size_t capacity_bytes);   /* depth-0 surface data of the last frame, pixel-major [n][8][4] */
 
@@ -253,6 +258,10 @@ int lumen_mi_test_shade(lumen_mi_renderer*, uint32_t n, uint32_t W, uint32_t H, 
  * transmittance4 params3.  lumen_mi_test_extract0 runs the depth-0 KERNEL (surface extraction + GenerateMotionVector MotionVectors.cu:8-55 + ResolveDirectLightHits
  * GPUShadeDirect.cu:11-40, fused) on hit records for every pixel of the render resolution (row-major): G-buffer records [n][8][4], motion vectors (half2 bits), DIRECT [n][4]. */
 int lumen_mi_test_extract(lumen_mi_renderer*, uint32_t n, const uint32_t* hits9, const uint32_t* rays9, uint32_t* out35);
+/* tex2D<float4>(texture object, u, v) as ExtractSurfaceDataGpu fetches it (GPUExtractSurfaceData.cu:59-60,169-181; texture object of PTTexture.cpp:35-74: linear filter,
+ * wrap, normalised float read, sRGB decode per texel when created with normalize) on n coordinates uv2 of one texture -> out4 [n][4].  The filter is the rule the CUDA C
+ * Programming Guide publishes for that unit (weights in 1.8 fixed point); tuning key "tex_filter" 1 selects unquantised fp32 weights instead. */
+int lumen_mi_test_tex2d(lumen_mi_renderer*, lumen_mi_handle texture, uint32_t n, const float* uv2, float* out4);
 int lumen_mi_test_extract0(lumen_mi_renderer*, const uint32_t* hits9, const uint32_t* dirs3, const uint32_t* eye3, const uint32_t* matrix16, float* gbuffer, uint32_t* motion, float* direct);
 /* GeneratePrimaryRay (GPUGeneratePrimRay.cu:28-82): the primary-ray kernel on a W x H image; cam = U V W eye; out11 per pixel = x y origin direction contribution */
 int lumen_mi_test_primary_rays(lumen_mi_renderer*, uint32_t W, uint32_t H, uint32_t frame_count, const uint32_t* cam_uvw_eye12, uint32_t* out11);

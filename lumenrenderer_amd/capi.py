@@ -65,6 +65,8 @@ SYMBOLS = {
     "lumen_mi_get_output_pixels": [_R, _U8P, C.c_size_t, _U32P, _U32P], "lumen_mi_get_radiance": [_R, _FP, C.c_size_t],
     "lumen_mi_get_radiance_half4": [_R, C.POINTER(C.c_uint16), C.c_size_t],
     "lumen_mi_copy_radiance_device": [_R, C.c_void_p], "lumen_mi_get_channel": [_R, C.c_int, _FP, C.c_size_t],
+    "lumen_mi_copy_radiance_rect_device": [_R, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32],
+    "lumen_mi_copy_rect_device": [_R, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32],
     "lumen_mi_get_gbuffer": [_R, _FP, C.c_size_t],
     "lumen_mi_get_frame_stat": [_R, C.c_char_p, _U64P], "lumen_mi_get_counters": [_R, _U64P, C.c_uint32],
     "lumen_mi_get_counter_totals": [_R, _U64P, C.c_uint32, C.c_int],
@@ -84,6 +86,7 @@ SYMBOLS = {
                                    _U32P, _U32P, _U32P, _U32P, _U32P, _U32P],
     "lumen_mi_test_shade": [_R, C.c_uint32, C.c_uint32, C.c_uint32, _U32P, C.c_uint32, _U32P, _U32P, C.c_int, _U32P, _U32P],
     "lumen_mi_test_extract": [_R, C.c_uint32, _U32P, _U32P, _U32P],
+    "lumen_mi_test_tex2d": [_R, C.c_uint64, C.c_uint32, _FP, _FP],
     "lumen_mi_test_extract0": [_R, _U32P, _U32P, _U32P, _U32P, _FP, _U32P, _FP],
     "lumen_mi_test_primary_rays": [_R, C.c_uint32, C.c_uint32, C.c_uint32, _U32P, _U32P],
     "lumen_mi_test_camera": [_FP, _FP, _FP, _FP, C.c_float, C.c_float, _FP],

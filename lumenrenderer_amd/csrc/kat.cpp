@@ -173,6 +173,28 @@ int lumen_mi_test_extract(lumen_mi_renderer* r, uint32_t n, const uint32_t* hits
     return 0;
 }
 
+/* The texture fetch of the extraction kernels (lm_tex2D) on n normalised coordinates of one texture: what tex2D<float4>(PTTexture object, u, v) returns in the reference
+ * (PTTexture.cpp:35-74: linear filter, wrap, normalised float read, sRGB decode per texel) under the filter rule in force (tuning key tex_filter, decision D6). */
+int lumen_mi_test_tex2d(lumen_mi_renderer* r, lumen_mi_handle texture, uint32_t n, const float* uv2, float* out4)
+{
+    if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer");
+    ApiLock lk(r);
+    if (!r->initialised) return fail(LUMEN_MI_ERR_STATE, "not initialised");
+    size_t id;
+    if (!n || !uv2 || !out4 || !unh(texture, H_TEXTURE, r->textures.size(), id)) return fail(LUMEN_MI_ERR_INVALID, "bad argument");
+    LM_HIP(hipSetDevice(r->device));
+    int rc;
+    if ((rc = uploadResources(r))) return rc;
+    Bufs b;
+    float2* dU = (float2*)b.put<float>(uv2, (size_t)2 * n); float4* dO = (float4*)b.get<float>((size_t)4 * n);
+    if (!dU || !dO) return fail(LUMEN_MI_ERR_DEVICE, "allocation failed");
+    lm_kernel_table()->kat_tex2d(r->stream, r->dscene, n, (int)id, dU, dO);
+    LM_HIP(hipGetLastError());
+    LM_HIP(hipStreamSynchronize(r->stream));
+    LM_HIP(hipMemcpy(out4, dO, (size_t)16 * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 /* The depth-0 kernel itself (lm_k_extract0: ExtractSurfaceDataGpu + GenerateMotionVector MotionVectors.cu:8-55 + ResolveDirectLightHits GPUShadeDirect.cu:11-40 fused) on given
  * hit records of the renderer's current render resolution: hits9 / dirs3 per pixel of the window in row-major pixel order, the eye, the motion matrix; results: the G-buffer
  * record the kernel stored ([n][8][4] floats as lumen_mi_get_gbuffer gives them), motion vectors (half2 bits) and the DIRECT channel it initialised. */

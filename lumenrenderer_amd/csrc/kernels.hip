@@ -1642,6 +1642,15 @@ KN(lm_k_kat_extract)(LmScene sc, uint32_t n, const uint32_t* __restrict__ hits9,
     for (int k = 0; k < 3; k++) { o[20 + 4 * k] = f2u(q[k].x); o[21 + 4 * k] = f2u(q[k].y); o[22 + 4 * k] = f2u(q[k].z); o[23 + 4 * k] = f2u(q[k].w); }
     o[32] = s.mat.p0; o[33] = s.mat.p1; o[34] = s.mat.p2;
 }
+// the texture fetch every extraction runs (lm_tex2D: tex2D<float4> on a PTTexture object, PTTexture.cpp:35-74) on given coordinates of one texture
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_kat_tex2d)(LmScene sc, uint32_t n, int id, const float2* __restrict__ uv, float4* __restrict__ out)
+{
+    __shared__ float s_lut[256];
+    const lm_lds_float* lut = lm_stage_lut(s_lut, sc);
+    const uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x;
+    if (i < n) out[i] = lm_tex2D(sc, lut, id, uv[i].x, uv[i].y);
+}
 // ShadeDirect / ShadeIndirect (GPUShadeDirect.cu:42-153, GPUShadeIndirect.cu:7-146) as the wave kernels call them; rows (x, y, seed, surface(40))
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
 KN(lm_k_kat_shade)(LmScene sc, uint32_t n, uint32_t W, const uint32_t* __restrict__ rows43, int fast, uint32_t* __restrict__ direct12, uint32_t* __restrict__ indirect10)
@@ -1723,6 +1732,19 @@ KN(lm_k_export_half4)(const float4* __restrict__ src, uint2* __restrict__ dst, u
     for (uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x; i < n; i += stride) {
         const float4 c = src[i];
         dst[i] = make_uint2(lm_f32_to_f16(c.x) | (lm_f32_to_f16(c.y) << 16), lm_f32_to_f16(c.z) | (lm_f32_to_f16(c.w) << 16));
+    }
+}
+
+// Multi-GPU tiles: a w x h rectangle of RGBA32F pixels between two pitched device images (a rank's tile out of its render window into the gather's send buffer; a
+// gathered tile into the assembled frame).  One float4 per lane, rows contiguous: a plain HBM stream.  Kept in this module so that the per-frame path of the tiled
+// renderer launches nothing but kernels that are already resident (LOG.md round 5 item 1: a lazily loaded PyTorch copy kernel faulted at its first launch there).
+extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+KN(lm_k_copy_rect)(float4* __restrict__ dst, uint32_t dstPitch, const float4* __restrict__ src, uint32_t srcPitch, uint32_t w, uint32_t h)
+{
+    const uint32_t n = w * h, stride = gridDim.x * LM_BLOCK;
+    for (uint32_t i = blockIdx.x * LM_BLOCK + threadIdx.x; i < n; i += stride) {
+        const uint32_t y = i / w, x = i - y * w;
+        dst[(size_t)y * dstPitch + x] = src[(size_t)y * srcPitch + x];
     }
 }
 
@@ -2086,6 +2108,7 @@ static void l_kat_pack_surfaces(hipStream_t s, const uint32_t* rows40, uint32_t 
 static void l_kat_reservoirs(hipStream_t s, uint32_t* rows17, uint32_t n, float4* hot, float4* contrib, int unpack) { hipLaunchKernelGGL(KN(lm_k_kat_reservoirs), LM_GRID((n + LM_BLOCK - 1) / LM_BLOCK), rows17, n, hot, contrib, unpack); }
 static void l_kat_resolve(hipStream_t s, LmFrame fr, int rc, const uint32_t* count, const uint8_t* occluded, int pass) { hipLaunchKernelGGL(KN(lm_k_kat_resolve), LM_GRID((fr.n + LM_BLOCK - 1) / LM_BLOCK), fr, rc, count, occluded, pass); }
 static void l_kat_extract(hipStream_t s, LmScene sc, uint32_t n, const uint32_t* hits9, const uint32_t* rays9, uint32_t* out35) { hipLaunchKernelGGL(KN(lm_k_kat_extract), LM_GRID((n + LM_BLOCK - 1) / LM_BLOCK), sc, n, hits9, rays9, out35); }
+static void l_kat_tex2d(hipStream_t s, LmScene sc, uint32_t n, int id, const float2* uv, float4* out) { hipLaunchKernelGGL(KN(lm_k_kat_tex2d), LM_GRID((n + LM_BLOCK - 1) / LM_BLOCK), sc, n, id, uv, out); }
 static void l_kat_shade(hipStream_t s, LmScene sc, uint32_t n, uint32_t W, const uint32_t* rows43, int fast, uint32_t* direct12, uint32_t* indirect10)
 { hipLaunchKernelGGL(KN(lm_k_kat_shade), LM_GRID((n + LM_BLOCK - 1) / LM_BLOCK), sc, n, W, rows43, fast, direct12, indirect10); }
 static void l_test_math(hipStream_t s, uint32_t n, int fn, const float* x, const float* y, float* out) { hipLaunchKernelGGL(KN(lm_k_test_math), LM_GRID((n + LM_BLOCK - 1) / LM_BLOCK), n, fn, x, y, out); }
@@ -2103,6 +2126,7 @@ static void l_sort_rays(hipStream_t s, int g, LmScene sc, const float4* srcO, co
     hipLaunchKernelGGL(KN(lm_k_sort_scatter), LM_GRID(g), sc, srcO, srcD, srcC, dstO, dstD, dstC, cnt, bins + LM_SORT_BINS);
 }
 static void l_export_half4(hipStream_t s, int g, const float4* src, uint2* dst, uint32_t n) { hipLaunchKernelGGL(KN(lm_k_export_half4), LM_GRID(g), src, dst, n); }
+static void l_copy_rect(hipStream_t s, int g, float4* dst, uint32_t dp, const float4* src, uint32_t sp, uint32_t w, uint32_t h) { hipLaunchKernelGGL(KN(lm_k_copy_rect), LM_GRID(g), dst, dp, src, sp, w, h); }
 static void l_build_top(hipStream_t s, const LmNodeW* nodes, LmNodeW* top) { hipLaunchKernelGGL(KN(lm_k_build_top), dim3(1), dim3(64), 0, s, nodes, top); }
 static void l_spin(hipStream_t s, uint32_t ticks) { hipLaunchKernelGGL(KN(lm_k_spin), dim3(1), dim3(64), 0, s, ticks); }
 
@@ -2114,6 +2138,6 @@ extern "C" const LmKernelTable* lm_kernel_table()
 {
     static const LmKernelTable t = {l_primary, l_trace_closest, l_extract0, l_shade_wave, l_trace_shadow, l_path_tail, l_fill_bags, l_pick_primary,
                                     l_trace_shade, l_temporal, l_spatial, l_combine, l_clear, l_merge, l_query_any, l_query_closest, l_export_aux, l_refit_tris, l_refit_quant, l_refit_level, l_test_bsdf, l_test_math, l_spin, l_history_copy, l_wave_sync, l_test_restir, l_build_top, l_export_half4, l_sort_rays, l_reuse_settle, l_reuse_counts, l_trace_primary,
-                                    l_kat_pack_surfaces, l_kat_reservoirs, l_kat_resolve, l_kat_shade, l_kat_extract};
+                                    l_kat_pack_surfaces, l_kat_reservoirs, l_kat_resolve, l_kat_shade, l_kat_extract, l_kat_tex2d, l_copy_rect};
     return &t;
 }

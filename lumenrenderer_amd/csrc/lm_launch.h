@@ -46,6 +46,8 @@ struct LmKernelTable {
     void (*kat_resolve)(hipStream_t, LmFrame, int rc, const uint32_t* count, const uint8_t* occluded, int pass);
     void (*kat_shade)(hipStream_t, LmScene, uint32_t n, uint32_t W, const uint32_t* rows43, int fast, uint32_t* direct12, uint32_t* indirect10);
     void (*kat_extract)(hipStream_t, LmScene, uint32_t n, const uint32_t* hits9, const uint32_t* rays9, uint32_t* out35);      // lm_extract on (hit, ray) rows against the current scene
+    void (*kat_tex2d)(hipStream_t, LmScene, uint32_t n, int id, const float2* uv, float4* out);                                // lm_tex2D on one texture of the current scene
+    void (*copy_rect)(hipStream_t, int grid, float4* dst, uint32_t dstPitch, const float4* src, uint32_t srcPitch, uint32_t w, uint32_t h);      // pitched RGBA32F rectangle (tile gather)
 };
 extern "C" const LmKernelTable* lm_kernel_table();
 extern "C" const LmKernelTable* lm_kernel_table_instrumented();

@@ -79,7 +79,7 @@ struct LmDevMaterial {
     uint32_t constMask, pad[3];
     float4 texConst[8];
 };
-struct LmTexDesc { uint32_t offset, w, h, srgb; };
+struct LmTexDesc { uint32_t offset, w, h, srgb; };      // srgb: bit 0 = decode sRGB per texel, bit 1 = unquantised fp32 filter weights (lm_shade.h lm_tex2D)
 // emissive triangle, 64 bytes, memory order of TriangleLight (LightData.h:21-27)
 struct LmLight { float4 a, b, c, d; };   // a = p0.xyz p1.x | b = p1.yz p2.xy | c = p2.z n.xyz | d = radiance.xyz area
 

@@ -3,7 +3,10 @@
 #pragma once
 
 // ---------------------------------------------------------------------------------------------------------------------
-// texture fetch: RGBA8, bilinear, wrap, normalised coordinates, optional sRGB decode (reference PTTexture.cpp:35-74)
+// texture fetch: RGBA8, bilinear, wrap, normalised coordinates, optional sRGB decode per texel before filtering (reference PTTexture.cpp:35-74).
+// The filter follows the linear-filtering rule the CUDA C Programming Guide publishes for the texture unit the reference samples with (decision D6): wrap = the
+// fractional part of the normalised coordinate, x = N frac(u); xB = x - 0.5, i = floor(xB), alpha = frac(xB) held in 1.8 fixed point (rounded to nearest here),
+// nested fp32 lerps.  LmTexDesc::srgb bit 1 selects the rule of rounds 1-4 instead (no frac step, unquantised fp32 weights: tuning key tex_filter 1).
 // ---------------------------------------------------------------------------------------------------------------------
 // `lut` = the 256-entry sRGB decode table staged in LDS by the calling kernel (lm_stage_lut): three table reads per texel of an sRGB
 // texture are ds_read_b32 instead of dependent global gathers
@@ -18,7 +21,7 @@ __device__ __forceinline__ float4 lm_texel(const LmScene& sc, const lm_lds_float
 {
     const uint32_t p = sc.texels[t.offset + (uint32_t)y * t.w + (uint32_t)x];
     const uint32_t r = p & 255u, g = (p >> 8) & 255u, b = (p >> 16) & 255u, a = p >> 24;
-    if (t.srgb) return make_float4(lut[r], lut[g], lut[b], (float)a / 255.0f);
+    if (t.srgb & 1u) return make_float4(lut[r], lut[g], lut[b], (float)a / 255.0f);
     return make_float4((float)r / 255.0f, (float)g / 255.0f, (float)b / 255.0f, (float)a / 255.0f);
 }
 __device__ __forceinline__ int lm_wrapi(int i, int n) { const int m = i % n; return m < 0 ? m + n : m; }
@@ -27,9 +30,11 @@ __device__ float4 lm_tex2D(const LmScene& sc, const lm_lds_float* lut, int id, f
     if (id < 0) return make_float4(0.f, 0.f, 0.f, 0.f);
     const LmTexDesc t = sc.texDesc[id];
     if (t.w == 1u && t.h == 1u) return lm_texel(sc, lut, t, 0, 0);           // lerp(a, a, w) == a exactly
-    const float x = u * (float)t.w - 0.5f, y = v * (float)t.h - 0.5f;
+    const bool cudaRule = (t.srgb & 2u) == 0u;
+    const float x = (cudaRule ? u - floorf(u) : u) * (float)t.w - 0.5f, y = (cudaRule ? v - floorf(v) : v) * (float)t.h - 0.5f;
     const float fx0 = floorf(x), fy0 = floorf(y);
-    const float ax = x - fx0, ay = y - fy0;
+    float ax = x - fx0, ay = y - fy0;
+    if (cudaRule) { ax = floorf(ax * 256.0f + 0.5f) * (1.0f / 256.0f); ay = floorf(ay * 256.0f + 0.5f) * (1.0f / 256.0f); }      // 1.8 fixed point, round to nearest
     const int x0 = lm_wrapi((int)fx0, (int)t.w), y0 = lm_wrapi((int)fy0, (int)t.h);
     const int x1 = lm_wrapi(x0 + 1, (int)t.w), y1 = lm_wrapi(y0 + 1, (int)t.h);
     const float4 t00 = lm_texel(sc, lut, t, x0, y0), t10 = lm_texel(sc, lut, t, x1, y0), t01 = lm_texel(sc, lut, t, x0, y1), t11 = lm_texel(sc, lut, t, x1, y1);

@@ -515,6 +515,33 @@ int lumen_mi_copy_radiance_device(lumen_mi_renderer* r, void* dst)
     LM_HIP(hipMemcpyAsync(dst, r->fr.combined, (size_t)r->fr.n * 16, hipMemcpyDeviceToDevice, r->stream));
     return 0;
 }
+// multi-GPU tiles (tiles.py TileGather): the rectangle [x0, x1) x [y0, y1) of the IMAGE (inside the render window) out of the merged radiance into a pitched device
+// image, and a pitched rectangle between two device images — both on the renderer's stream, both by a kernel of this library (nothing is loaded at the first call)
+int lumen_mi_copy_radiance_rect_device(lumen_mi_renderer* r, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, void* dst, uint32_t dstPitch)
+{
+    if (!r || !dst) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    ApiLock lk(r);
+    if (!r->fr.combined || !r->fr.n) return fail(LUMEN_MI_ERR_STATE, "no frame has been traced yet");
+    const LmFrame& f = r->fr;
+    if (x0 >= x1 || y0 >= y1 || x0 < f.x0 || y0 < f.y0 || x1 > f.x0 + f.ww || y1 > f.y0 + f.wh) return fail(LUMEN_MI_ERR_INVALID, "rectangle outside the render window");
+    if (dstPitch < x1 - x0) return fail(LUMEN_MI_ERR_INVALID, "destination pitch smaller than the rectangle");
+    if (hipSetDevice(r->device) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "hipSetDevice failed");
+    const uint32_t w = x1 - x0, h = y1 - y0;
+    r->K->copy_rect(r->stream, r->gridFor(w * h, 8), (float4*)dst, dstPitch, f.combined + (size_t)(y0 - f.y0) * f.ww + (x0 - f.x0), f.ww, w, h);
+    LM_HIP(hipGetLastError());
+    return 0;
+}
+int lumen_mi_copy_rect_device(lumen_mi_renderer* r, void* dst, uint32_t dstPitch, const void* src, uint32_t srcPitch, uint32_t w, uint32_t h)
+{
+    if (!r || !dst || !src) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
+    if (!w || !h || dstPitch < w || srcPitch < w) return fail(LUMEN_MI_ERR_INVALID, "empty rectangle or pitch smaller than the rectangle");
+    ApiLock lk(r);
+    if (!r->initialised) return fail(LUMEN_MI_ERR_STATE, "not initialised");
+    if (hipSetDevice(r->device) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "hipSetDevice failed");
+    r->K->copy_rect(r->stream, r->gridFor(w * h, 8), (float4*)dst, dstPitch, (const float4*)src, srcPitch, w, h);
+    LM_HIP(hipGetLastError());
+    return 0;
+}
 // multi-GPU seams: see lm_k_history_copy (kernels.hip) and tiles.py exchange_history
 static int historyCopy(lumen_mi_renderer* r, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, void* dev, int import)
 {
@@ -669,6 +696,10 @@ int lumen_mi_set_tuning(lumen_mi_renderer* r, const char* key, int value)
     else if (k == "fuse_primary") r->fusePrimary = value;
     else if (k == "fast_shade") r->fastShade = value;
     else if (k == "sort_rays") { if (r->initialised) { int rc = syncAndCollect(r); if (rc) return rc; } r->sortRays = std::max(0, value); }
+    else if (k == "tex_filter") {                         // every emissive-triangle verdict and the texture descriptors depend on it
+        if (r->initialised) { int rc = syncAndCollect(r); if (rc) return rc; }
+        if (r->texFilter != (value != 0)) { r->texFilter = value != 0; r->texturesDirty = true; for (Primitive& p : r->prims) findEmissives(r, p); r->lightsDirty = true; r->sceneDirty = true; }
+    }
     else if (k == "refill") r->refillBelow = value;
     else if (k == "refill_visibility") r->refillVisibility = value;
     else if (k == "refill_primary") r->refillPrimary = value;

@@ -182,6 +182,7 @@ struct lumen_mi_renderer {
     std::vector<Instance> instances;
     long activeScene = -1;
     bool sceneDirty = true, texturesDirty = true, materialsDirty = true;
+    int texFilter = 0;              // 0: CUDA's published linear-filter rule (1.8 fixed-point weights), 1: unquantised fp32 weights (tuning key tex_filter; decision D6)
     bool transformsDirty = false;           // only instance matrices changed since the last build: the BVH is refitted on the GPU
     bool entriesDirty = false;              // emissive mode / radiance / override material of an instance changed: scene table + lights only
     uint32_t refits = 0;                    // refits since the last full build

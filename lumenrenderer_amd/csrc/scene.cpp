@@ -20,9 +20,11 @@ void tex2D(const R* r, int id, float u, float v, float out[4])
     if (id < 0) { out[0] = out[1] = out[2] = out[3] = 0.f; return; }
     const Texture& t = r->textures[id];
     if (t.w == 1 && t.h == 1) { texel(t, 0, 0, out); return; }
-    const float x = u * (float)t.w - 0.5f, y = v * (float)t.h - 0.5f;
+    const bool cudaRule = r->texFilter == 0;               // the same rule as lm_shade.h lm_tex2D (decision D6)
+    const float x = (cudaRule ? u - floorf(u) : u) * (float)t.w - 0.5f, y = (cudaRule ? v - floorf(v) : v) * (float)t.h - 0.5f;
     const float fx0 = floorf(x), fy0 = floorf(y);
-    const float ax = x - fx0, ay = y - fy0;
+    float ax = x - fx0, ay = y - fy0;
+    if (cudaRule) { ax = floorf(ax * 256.0f + 0.5f) * (1.0f / 256.0f); ay = floorf(ay * 256.0f + 0.5f) * (1.0f / 256.0f); }
     const int x0 = wrapi((int)fx0, (int)t.w), y0 = wrapi((int)fy0, (int)t.h);
     const int x1 = wrapi(x0 + 1, (int)t.w), y1 = wrapi(y0 + 1, (int)t.h);
     float t00[4], t10[4], t01[4], t11[4];
@@ -356,7 +358,7 @@ int uploadResources(R* r)
     hipStream_t st = r->stream;
     if (r->texturesDirty) {
         std::vector<LmTexDesc> desc; std::vector<uint32_t> texels;
-        for (const Texture& t : r->textures) { desc.push_back(LmTexDesc{(uint32_t)texels.size(), t.w, t.h, t.srgb ? 1u : 0u}); texels.insert(texels.end(), t.px.begin(), t.px.end()); }
+        for (const Texture& t : r->textures) { desc.push_back(LmTexDesc{(uint32_t)texels.size(), t.w, t.h, (t.srgb ? 1u : 0u) | (r->texFilter ? 2u : 0u)}); texels.insert(texels.end(), t.px.begin(), t.px.end()); }
         std::vector<float> lut(g_srgbLut, g_srgbLut + 256);
         if (r->dTexDesc.upload(desc, st) || r->dTexels.upload(texels, st) || r->dLut.upload(lut, st)) return fail(LUMEN_MI_ERR_DEVICE, "texture upload failed");
         if (hipStreamSynchronize(st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "texture upload sync failed");

@@ -257,6 +257,14 @@ class LumenRendererMI:
     def CopyRadianceToDevice(self, device_ptr):
         check(self.lib, self.lib.lumen_mi_copy_radiance_device(self.h, C.c_void_p(int(device_ptr))))
 
+    def CopyRadianceRectToDevice(self, rect, device_ptr, pitch):
+        """The image rectangle (x0, y0, x1, y1) — inside the render window — of the merged radiance into a device image of `pitch` RGBA32F pixels per row, on the renderer's stream."""
+        check(self.lib, self.lib.lumen_mi_copy_radiance_rect_device(self.h, int(rect[0]), int(rect[1]), int(rect[2]), int(rect[3]), C.c_void_p(int(device_ptr)), int(pitch)))
+
+    def CopyRectDevice(self, dst_ptr, dst_pitch, src_ptr, src_pitch, w, h):
+        """A w x h RGBA32F rectangle between two pitched device images on the renderer's stream (tile assembly)."""
+        check(self.lib, self.lib.lumen_mi_copy_rect_device(self.h, C.c_void_p(int(dst_ptr)), int(dst_pitch), C.c_void_p(int(src_ptr)), int(src_pitch), int(w), int(h)))
+
     def GetCounters(self, n=24):
         out = (C.c_uint64 * n)(); check(self.lib, self.lib.lumen_mi_get_counters(self.h, out, n)); return list(out)
 
@@ -347,6 +355,13 @@ class LumenRendererMI:
         up = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint32))
         hits9 = np.ascontiguousarray(hits9, np.uint32); rays9 = np.ascontiguousarray(rays9, np.uint32); out = np.zeros((hits9.shape[0], 35), np.uint32)
         check(self.lib, self.lib.lumen_mi_test_extract(self.h, hits9.shape[0], up(hits9), up(rays9), up(out)))
+        return out
+
+    def TestTex2D(self, texture, uv):
+        """Known-answer hook (lumen_mi_test_tex2d): the extraction kernels' texture fetch on [n][2] normalised coordinates of one texture -> [n][4] float32."""
+        uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2); out = np.zeros((uv.shape[0], 4), np.float32)
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        check(self.lib, self.lib.lumen_mi_test_tex2d(self.h, texture, uv.shape[0], fp(uv), fp(out)))
         return out
 
     def TestExtract0(self, hits9, dirs3, eye3, matrix16):

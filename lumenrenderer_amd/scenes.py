@@ -186,13 +186,38 @@ def cornell_box(path=None, fixture=None):
     return desc
 
 
+def lowpoly_room(fixture):
+    """The reference Sandbox's DEFAULT model (Sandbox/src/AppConfigDefaults.h:11, LowpolyRoom/scene.glb: 20 501 triangles, 10 primitives, 10 materials of which
+    three are emissive — the only lights: no OVERRIDE instance —, one 512 x 512 sRGB base-colour map) from the committed numbers of
+    tests/golden/ref_lowpoly_room.npz (tests/golden/make_lowpoly_fixture.py), with the camera Application.cpp:145-146 sets.  ``desc.camera_poses`` holds 64 poses of
+    the reference's own Camera class driven by OutputLayer.cpp's input handling (W held, mouse drag): rows of eye, right, up, forward."""
+    desc = scene_from_npz(fixture)
+    desc.camera_poses = np.load(fixture)["camera_poses"]
+    return desc
+
+
+def lowpoly_camera_pose(desc, k):
+    """Pose k (0..63) of the LowpolyRoom walk as SetCamera arguments."""
+    p = desc.camera_poses[k]
+    return (p[0:3].copy(), p[3:6].copy(), p[6:9].copy(), p[9:12].copy(), 90.0)
+
+
 _MAT_SCALARS = ("transmission_factor", "clearcoat_factor", "clearcoat_roughness_factor", "index_of_refraction", "specular_factor", "specular_tint_factor",
                 "subsurface_factor", "luminance", "anisotropic", "sheen_factor", "sheen_tint_factor", "metallic_factor", "roughness_factor")
 
 
-def scene_to_npz(desc, path):
-    """Numbers only: vertices, indices, material factors, instance transforms (no textures beyond the defaults)."""
+def scene_to_npz(desc, path, textures=False):
+    """Numbers only: vertices, indices, material factors, instance transforms; with ``textures`` also the RGBA8 texels of every texture
+    behind the four defaults, their sRGB flags and each material's eight texture slots (without it every slot reads its default texture)."""
     out = {"n_prims": np.int64(len(desc.primitives)), "n_mats": np.int64(len(desc.materials))}
+    if textures:
+        out["n_tex"] = np.int64(len(desc.textures))
+        for i, t in enumerate(desc.textures[4:], 4):
+            out[f"t{i}_px"], out[f"t{i}_srgb"] = t["pixels"], np.int64(t["srgb"])
+        for i, m in enumerate(desc.materials):
+            out[f"m{i}_tex"] = np.asarray([m[k] for k in TEXTURE_FIELDS], np.int64)
+    c = desc.camera
+    out["camera"] = np.asarray(list(c["position"]) + list(c["right"]) + list(c["up"]) + list(c["forward"]) + [c["fov"]], np.float32)
     for i, p in enumerate(desc.primitives):
         out[f"p{i}_v"], out[f"p{i}_i"], out[f"p{i}_m"], out[f"p{i}_s"] = p["vertices"], p["indices"], np.int64(p["material"]), np.int64(p["index_size"])
     for i, m in enumerate(desc.materials):
@@ -212,8 +237,12 @@ def scene_to_npz(desc, path):
 def scene_from_npz(path):
     z = np.load(path)
     d = SceneDescription()
+    for i in range(4, int(z["n_tex"]) if "n_tex" in z else 0):
+        d.add_texture(z[f"t{i}_px"], bool(z[f"t{i}_srgb"]))
     for i in range(int(z["n_mats"])):
         kw = dict(zip(_MAT_SCALARS, [float(x) for x in z[f"m{i}_scalars"]]))
+        if f"m{i}_tex" in z:
+            kw.update(zip(TEXTURE_FIELDS, [int(x) for x in z[f"m{i}_tex"]]))
         d.add_material(diffuse_color=tuple(z[f"m{i}_color"]), emission=tuple(z[f"m{i}_emission"]), tint_factor=tuple(z[f"m{i}_tint"]),
                        transmittance=tuple(z[f"m{i}_transmittance"]), **kw)
     for i in range(int(z["n_prims"])):
@@ -223,6 +252,9 @@ def scene_from_npz(path):
         d.add_mesh([int(p) for p in z["mesh_prims"][k:k + int(n)]]); k += int(n)
     for j in range(len(z["inst_mesh"])):
         d.add_instance(int(z["inst_mesh"][j]), z["inst_xf"][j], int(z["inst_mode"][j]), tuple(z["inst_rad"][j]), float(z["inst_scale"][j]))
+    if "camera" in z:
+        c = z["camera"]
+        d.set_camera(tuple(c[0:3]), tuple(c[3:6]), tuple(c[6:9]), tuple(c[9:12]), float(c[12]))
     return d
 
 

@@ -105,6 +105,7 @@ static inline f4 mat4_mul(const float* m, const f4& v)                    // sut
 // ----------------------------------------------------------------------------------------------------------
 struct orc_ctx {
     int threads = 1;
+    int texFilter = 0;             // 0: CUDA's published linear-filter rule (1.8 fixed-point weights), 1: unquantised fp32 weights (D6)
     std::vector<Texture> textures;
     std::vector<DeviceMaterial> materials;
     std::vector<Primitive> prims;
@@ -198,7 +199,13 @@ void orc_ctx::resize()
 }
 
 // ----------------------------------------------------------------------------------------------------------
-// Textures — PTTexture.cpp:35-74: RGBA8, bilinear, wrap, normalised coords, optional sRGB decode  (D6)
+// Textures — PTTexture.cpp:35-74: RGBA8, cudaFilterModeLinear, cudaAddressModeWrap, normalised coordinates, cudaReadModeNormalizedFloat, optional sRGB
+// decode per texel BEFORE filtering.  Decision D6 (round 5): the filter follows the rule the CUDA C Programming Guide publishes for the texture unit the reference
+// samples with (appendix "Texture Fetching", "Linear Filtering"): wrap mode replaces the normalised coordinate by its fractional part, x = N frac(u); xB = x - 0.5,
+// i = floor(xB), alpha = frac(xB) — and alpha, beta are "stored in 9-bit fixed point format with 8 bits of fractional value (1.0 is exactly represented)".  The
+// Guide fixes the weight FORMAT, not how alpha is rounded into it nor the unit's internal arithmetic; defined here: round to nearest (floor(256 alpha + 0.5) / 256),
+// fp32 lerps nested as (x, then y) — algebraically the Guide's four-term sum, and a constant neighbourhood returns its value exactly.
+// texFilter 1 = the rule of rounds 1-4 (x = u N - 0.5 without the frac step, unquantised fp32 weights), kept to measure the distance between the two.
 // ----------------------------------------------------------------------------------------------------------
 static f4 texel(const Texture& t, int x, int y)
 {
@@ -211,9 +218,11 @@ static f4 tex2D(const orc_ctx* c, int id, float u, float v)
 {
     if (id < 0) return f4{0, 0, 0, 0};                     // null texture object (quirk 12): defined as 0
     const Texture& t = c->textures[id];
-    const float x = u * (float)t.w - 0.5f, y = v * (float)t.h - 0.5f;
+    const bool cudaRule = c->texFilter == 0;
+    const float x = (cudaRule ? u - floorf(u) : u) * (float)t.w - 0.5f, y = (cudaRule ? v - floorf(v) : v) * (float)t.h - 0.5f;
     const float fx0 = floorf(x), fy0 = floorf(y);
-    const float ax = x - fx0, ay = y - fy0;
+    float ax = x - fx0, ay = y - fy0;
+    if (cudaRule) { ax = floorf(ax * 256.0f + 0.5f) * (1.0f / 256.0f); ay = floorf(ay * 256.0f + 0.5f) * (1.0f / 256.0f); }      // 1.8 fixed point, round to nearest
     const int x0 = wrapi((int)fx0, (int)t.w), y0 = wrapi((int)fy0, (int)t.h);
     const int x1 = wrapi(x0 + 1, (int)t.w), y1 = wrapi(y0 + 1, (int)t.h);
     const f4 t00 = texel(t, x0, y0), t10 = texel(t, x1, y0), t01 = texel(t, x0, y1), t11 = texel(t, x1, y1);
@@ -1258,6 +1267,11 @@ extern "C" {
 orc_ctx* orc_create(void) { init_srgb_lut(); return new orc_ctx(); }
 void orc_destroy(orc_ctx* c) { delete c; }
 void orc_set_threads(orc_ctx* c, int n) { c->threads = std::max(1, n); }
+void orc_set_tex_filter(orc_ctx* c, int mode) { c->texFilter = mode != 0; }
+void orc_kat_tex2d(orc_ctx* c, int texture, uint32_t n, const float* uv2, float* out4)
+{
+    for (uint32_t i = 0; i < n; i++) { const f4 t = tex2D(c, texture, uv2[2 * i], uv2[2 * i + 1]); out4[4 * i] = t.x; out4[4 * i + 1] = t.y; out4[4 * i + 2] = t.z; out4[4 * i + 3] = t.w; }
+}
 
 int orc_add_texture(orc_ctx* c, const uint8_t* rgba8, uint32_t w, uint32_t h, int srgb)
 {

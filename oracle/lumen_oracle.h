@@ -8,7 +8,7 @@
  * SURVEY.md §0 F10).  The header-only parts (RNG, material packing, Disney BSDF, Reservoir update / weight / reset,
  * CDF::Get / BinarySearch, make_color, binary16 conversion) ARE pinned against the reference's own headers through
  * tests/golden/ref_kat.npz (generator: oracle/ref_kat/).  Everything that
- * lives in __global__ kernels, OptiX programs or closed libraries (traversal, texture filtering, thrust
+ * lives in OptiX programs or closed libraries (traversal, the texture unit's internal arithmetic — its published weight format IS followed —, thrust
  * sort/scan order, %smid bag choice, racy fp16 accumulation) has no reference-side vectors:
  * for those stages this oracle is "parity unpinned" and is the definition the HIP path is held to.
  */
@@ -36,7 +36,11 @@ typedef struct orc_material_desc {
 orc_ctx* orc_create(void);
 void     orc_destroy(orc_ctx*);
 void     orc_set_threads(orc_ctx*, int n);
+/* bilinear filter: 0 (default) = the linear-filter rule the CUDA C Programming Guide publishes (weights in 1.8 fixed point), 1 = unquantised fp32 weights (decision D6) */
+void     orc_set_tex_filter(orc_ctx*, int mode);
 
+/* tex2D<float4>(texture, u, v) of the extraction (GPUExtractSurfaceData.cu:59-60,169-181) on n coordinates */
+void orc_kat_tex2d(orc_ctx*, int texture, uint32_t n, const float* uv2, float* out4);
 int  orc_add_texture(orc_ctx*, const uint8_t* rgba8, uint32_t w, uint32_t h, int srgb);
 int  orc_add_material(orc_ctx*, const orc_material_desc*);
 /* vertices: n * 12 floats (pos3 uv2 normal3 tangent4 = the 48-byte Vertex of ModelStructs.h:21-28) */

@@ -27,7 +27,8 @@ def main():
     tile = tiles.tile_rect(rank, world, W, H); win = tiles.window_rect(tile, W, H)
     if one_gpu:
         dist.init_process_group("gloo")
-        real_dist, dist = dist, tiles.HostStagedDist(dist)          # device tensors staged through the host: RCCL refuses two ranks on one device
+        from host_staged_dist import HostStagedDist
+        real_dist, dist = dist, HostStagedDist(dist)          # device tensors staged through the host: RCCL refuses two ranks on one device
     else:
         dist.init_process_group("nccl", device_id=dev)
         real_dist = dist
@@ -36,15 +37,13 @@ def main():
     r.SetTile(*tile)
     hx = tiles.HistoryExchange(r, rank, world, W, H, dev) if world > 1 else None     # from the first frame on: every frame's history crosses the seams
     gather = tiles.TileGather(rank, world, W, H, torch.float32, dev)
-    buf = torch.empty((win[3] - win[1], win[2] - win[0], 4), dtype=torch.float32, device=dev)
     full = product_from(d, W, H, D, blend=True, device=local_rank) if rank == 0 else None
     bad = 0
     for f in range(frames):
         r.TraceFrameAsync()
         if hx is not None:
             hx.run(dist)
-        r.CopyRadianceToDevice(buf.data_ptr())
-        img = gather.run(buf[tile[1] - win[1]: tile[3] - win[1], tile[0] - win[0]: tile[2] - win[0]], dist)
+        img = gather.run_renderer(r, dist)                       # tile -> send buffer -> ONE gather -> assembled frame on rank 0 (pitched copies by the library's own kernel)
         if rank == 0:
             assert full.TraceFrame() is True
             want = full.GetRadiance()

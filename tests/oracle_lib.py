@@ -36,8 +36,9 @@ def lib():
         fp, u32p, u8p, i32p = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
         L.orc_create.restype = C.c_void_p
         for name, args, res in [
-            ("orc_destroy", [C.c_void_p], None), ("orc_set_threads", [C.c_void_p, C.c_int], None),
+            ("orc_destroy", [C.c_void_p], None), ("orc_set_threads", [C.c_void_p, C.c_int], None), ("orc_set_tex_filter", [C.c_void_p, C.c_int], None),
             ("orc_add_texture", [C.c_void_p, u8p, C.c_uint32, C.c_uint32, C.c_int], C.c_int),
+            ("orc_kat_tex2d", [C.c_void_p, C.c_int, C.c_uint32, fp, fp], None),
             ("orc_add_material", [C.c_void_p, C.POINTER(MaterialDesc)], C.c_int),
             ("orc_add_primitive", [C.c_void_p, fp, C.c_uint32, u32p, C.c_uint32, C.c_int], C.c_int),
             ("orc_add_mesh", [C.c_void_p, i32p, C.c_uint32], C.c_int),
@@ -181,6 +182,12 @@ class Oracle:
     def set_depth(self, d): self.L.orc_set_depth(self.h, d)
     def set_blend(self, b): self.L.orc_set_blend(self.h, int(b))
     def set_window(self, x0, y0, x1, y1): self.L.orc_set_window(self.h, x0, y0, x1, y1)
+    def set_tex_filter(self, mode): self.L.orc_set_tex_filter(self.h, int(mode))
+
+    def tex2d(self, texture, uv):
+        uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2); out = np.zeros((uv.shape[0], 4), np.float32)
+        self.L.orc_kat_tex2d(self.h, texture, uv.shape[0], fptr(uv), fptr(out))
+        return out
     def trace_frame(self): return self.L.orc_trace_frame(self.h)
 
     def radiance(self):

@@ -870,3 +870,48 @@ def test_shortcut_halton_equals_the_digit_loop_bit_for_bit(tmp_path):
     assert build.returncode == 0, build.stderr[-2000:]
     run = subprocess.run([exe, "3000000"], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0 and " 0 mismatches" in run.stdout, run.stdout[-500:]
+
+
+def test_lowpoly_room_fixture_is_the_reference_sandbox_default_model():
+    """tests/golden/ref_lowpoly_room.npz = the Sandbox's default model (AppConfigDefaults.h:11) as numbers: 20 501 triangles, 10 primitives, 10 materials of which three
+    are emissive, one 512 x 512 sRGB base-colour map, 64 poses of the reference's Camera class starting at Application.cpp:145-146.  The oracle lights it from its own
+    emissive materials (414 triangle lights, no override instance).  In the build container the fixture is re-derived from the reference's file and its Camera.cpp
+    (tests/golden/make_lowpoly_fixture.py) and must come out identical."""
+    from lumenrenderer_amd.scenes import lowpoly_room, lowpoly_camera_pose
+    from helpers import oracle_from, GOLDEN
+    fx = os.path.join(GOLDEN, "ref_lowpoly_room.npz")
+    d = lowpoly_room(fx)
+    assert d.triangle_count() == 20501 and len(d.primitives) == 10 and len(d.materials) == 10 and len(d.instances) == 10
+    assert sum(1 for m in d.materials if any(m["emission"])) == 3
+    assert [t["pixels"].shape for t in d.textures][4:] == [(512, 512, 4)] and d.textures[4]["srgb"] and d.materials[0]["diffuse_texture"] == 4
+    assert d.camera_poses.shape == (64, 12)
+    p0 = d.camera_poses[0]
+    assert tuple(p0[:3]) == (-150.0, 300.0, 150.0)                                                  # Application.cpp:145
+    assert np.allclose(p0[9:12], -np.float32([-1, 0.5, 1]) / np.sqrt(2.25), atol=1e-6)             # camera matrix column 2 = -direction of quatLookAtRH (:146)
+    R = p0[3:12].reshape(3, 3)
+    assert np.allclose(R @ R.T, np.eye(3), atol=1e-6) and abs(np.linalg.det(R) - 1.0) < 1e-5
+    assert np.allclose(np.linalg.norm(np.diff(d.camera_poses[:, :3], axis=0), axis=1), 5.0, atol=1e-3)      # W held: 300 / 60 units per frame (OutputLayer.cpp:523-558)
+    o = oracle_from(d, 160, 90, 5, blend=False, threads=4)
+    for k in range(2):
+        o.set_camera(*lowpoly_camera_pose(d, k))
+        assert o.trace_frame() == 0
+    rad = o.radiance()
+    assert np.isfinite(rad).all() and (rad[..., :3].sum(-1) > 0).mean() > 0.3 and o.stats(4)[3] == 414
+    o.close()
+    if not os.path.exists("/root/reference/Lumen_Engine/Sandbox/assets/models/LowpolyRoom/scene.glb"):
+        return
+    from lumenrenderer_amd.gltf import load_gltf
+    fresh = load_gltf("/root/reference/Lumen_Engine/Sandbox/assets/models/LowpolyRoom/scene.glb")
+    assert len(fresh.primitives) == len(d.primitives)
+    for a, b in zip(fresh.primitives, d.primitives):
+        assert np.array_equal(a["vertices"], b["vertices"]) and np.array_equal(a["indices"], b["indices"]) and a["material"] == b["material"]
+    for a, b in zip(fresh.textures, d.textures):
+        assert np.array_equal(a["pixels"], b["pixels"]) and a["srgb"] == b["srgb"]
+    for a, b in zip(fresh.instances, d.instances):
+        assert np.array_equal(a["transform"], b["transform"])
+    L = "/root/reference/Lumen_Engine/Lumen"
+    exe = "/tmp/lumen_lowpoly_camera_test"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-DNDEBUG", "-w", "-DGLM_ENABLE_EXPERIMENTAL", f"-I{L}/vendor/glm", f"-I{L}/src",
+                           os.path.join(GOLDEN, "lowpoly_camera.cpp"), f"{L}/src/Lumen/Renderer/Camera.cpp", "-o", exe])
+    poses = np.asarray([[float(x) for x in line.split()] for line in subprocess.check_output([exe], text=True).splitlines()], np.float32)
+    assert np.array_equal(poses, d.camera_poses)

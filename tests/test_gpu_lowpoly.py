@@ -1,0 +1,89 @@
+"""GPU parity on the reference Sandbox's own default model (VERDICT r4 missing #1): LowpolyRoom/scene.glb (Sandbox/src/AppConfigDefaults.h:11), camera of
+Application.cpp:145-146, 1280 x 720, depth 5, blending off (Application.cpp:89-93), the camera walking as OutputLayer.cpp:512-559 moves the reference's Camera.
+The geometry, materials, the 512 x 512 base-colour map and the 64 poses are numbers in tests/golden/ref_lowpoly_room.npz (make_lowpoly_fixture.py).
+Unlike the stand-in atrium this scene has NO override light: every one of its 414 triangle lights comes from FindEmissives over emissive MATERIALS
+(GPUEmissiveLookup.cu:13-109, emission factor x the emissive texture), and the light list is BuildLightDataBufferGPU's (GPUDataBufferKernels.cu:66-186)."""
+import os
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, oracle_from, product_from, rel_l2
+
+pytestmark = pytest.mark.gpu
+RADIANCE_TOL = 1e-3           # BASELINE.json north_star
+FIXTURE = os.path.join(GOLDEN, "ref_lowpoly_room.npz")
+
+
+def _scene():
+    from lumenrenderer_amd.scenes import lowpoly_room
+    return lowpoly_room(FIXTURE)
+
+
+def test_lowpoly_room_default_workload_is_bit_exact_and_the_fast_mode_stays_within_tolerance():
+    """16 TraceFrames at the Sandbox's own setting against the oracle at full size: exact mode — radiance, DIRECT / INDIRECT, motion vectors, the depth-0 G-buffer and
+    every counter bit-identical at frames 1, 2, 8, 16 (live temporal history from frame 2 on: odd depth); fast mode <= 1e-3 relative L2 at frame 16, same rays."""
+    from lumenrenderer_amd.scenes import lowpoly_camera_pose
+    W, H, D, FRAMES = 1280, 720, 5, 16
+    d = _scene()
+    r = product_from(d, W, H, D, blend=False)
+    rf = product_from(d, W, H, D, blend=False, tuning={"fast_resample": 1})
+    o = oracle_from(d, W, H, D, blend=False)
+    errs = {}
+    for k in range(FRAMES):
+        pose = lowpoly_camera_pose(d, k)
+        r.SetCamera(*pose); rf.SetCamera(*pose); o.set_camera(*pose)
+        assert r.TraceFrameAsync() and rf.TraceFrameAsync()
+        assert o.trace_frame() == 0
+        if k + 1 in (1, 2, 8, 16):
+            r.Synchronize(); rf.Synchronize()
+            got, want = r.GetRadiance(), o.radiance()
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (k, int(np.sum(got.view(np.uint32) != want.view(np.uint32))), rel_l2(got, want))
+            for ch in (0, 1):
+                assert np.array_equal(r.GetChannel(ch).view(np.uint32), o.channel(ch).view(np.uint32)), (k, ch)
+            c, s = r.GetCounters(), o.stats(24)
+            assert list(c[:4 + D]) == list(s[:4 + D]), (k, c[:12], s[:12])
+            assert c[3] == 414 == s[3]                                                     # triangle lights, all from emissive materials
+            _, _, mv = r.GetDenoiserInputs(); _, _, omv = o.denoiser_inputs()
+            assert np.array_equal(mv.reshape(-1, 2), omv), k
+            assert np.array_equal(r.GetGBuffer().view(np.uint32), o.gbuffer().view(np.uint32)), k
+            assert np.array_equal(r.GetOutputTexturePixels(), o.output_pixels()), k
+            fast = rf.GetRadiance()
+            assert np.isfinite(fast).all()
+            errs[k + 1] = rel_l2(fast[..., :3], want[..., :3])
+            assert list(rf.GetCounters()[4:4 + D]) == list(s[4:4 + D])
+    print("LowpolyRoom, fast mode rel-L2 vs oracle by frame:", {k: f"{v:.3e}" for k, v in errs.items()})
+    assert errs[16] <= RADIANCE_TOL, errs
+    want = o.radiance()
+    assert (want[..., :3].sum(-1) > 0).mean() > 0.5                                        # the room is lit by its own emissive materials
+    r.close(); rf.close(); o.close()
+
+
+def test_lowpoly_room_through_the_adapters_ollad_path(tmp_path):
+    """The same model the way the Sandbox really loads it: SceneManager::LoadGLTF asks the renderer first (OpenCustomFileFormat, SceneManager.cpp:56-64 ->
+    LumenPTModelConverter::LoadFile); an .ollad cache of the room (lumenrenderer_amd/ollad.py writes the reference converter's byte layout) opened through
+    MI355X::Renderer::OpenCustomFileFormat by examples/sandbox_driver.cpp, every resource arriving through the adapter's LumenRenderer virtuals, rendered from the
+    Application.cpp camera.  The picture must be, byte for byte, the oracle's picture of the scene ollad.py reads back from the same file."""
+    import subprocess
+    from helpers import build_sandbox_driver
+    from lumenrenderer_amd import ollad
+    d = _scene()
+    path = str(tmp_path / "scene.ollad")
+    ollad.write_ollad_from_description(d, path)
+    c = d.camera
+    np.float32(list(c["position"]) + list(c["right"]) + list(c["up"]) + list(c["forward"]) + [c["fov"]]).tofile(path + ".cam")
+    back = ollad.read_ollad(path)
+    back.camera = d.camera
+    assert back.triangle_count() == d.triangle_count() == 20501
+    W, H, D, F = 640, 360, 5, 3
+    exe = build_sandbox_driver(tmp_path)
+    out = str(tmp_path / "room.ppm")
+    run = subprocess.run([exe, str(tmp_path / "scene.glb"), str(W), str(H), str(D), str(F), out], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, (run.stdout[-1000:], run.stderr[-2000:])
+    o = oracle_from(back, W, H, D, blend=True)
+    for _ in range(F):
+        assert o.trace_frame() == 0
+    want = o.output_pixels()[..., :3].tobytes()
+    got = open(out, "rb").read()
+    assert got.endswith(want), sum(a != b for a, b in zip(got[-len(want):], want))
+    assert o.stats(4)[3] == 414
+    o.close()

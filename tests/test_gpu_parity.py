@@ -905,6 +905,26 @@ def test_textured_materials_match_oracle():
     r.close(); o.close()
 
 
+def test_device_texture_fetch_follows_the_published_cuda_filter_rule(bare):
+    """lm_tex2D (the fetch of every extraction kernel, through lumen_mi_test_tex2d) against the oracle bit for bit, and against the CUDA C Programming Guide's
+    linear-filtering rule restated independently in tests/tex_rule.py (1.8 fixed-point weights, wrap by frac, sRGB decode per texel) to fp32 rounding — under both
+    settings of the tuning key tex_filter (decision D6)."""
+    import tex_rule
+    from oracle_lib import Oracle
+    from lumenrenderer_amd import LumenRendererMI
+    uv = tex_rule.test_coordinates()
+    for mode in (0, 1):
+        r = LumenRendererMI(); r.Init(depth=2, render_resolution=(16, 16)); r.SetTuning("tex_filter", mode)
+        o = Oracle(1); o.set_tex_filter(mode)
+        for px, srgb in tex_rule.test_textures():
+            got = r.TestTex2D(r.CreateTexture(px, normalize=srgb), uv)
+            want = o.tex2d(o.add_texture(px, srgb), uv)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (mode, px.shape, int(np.sum(got.view(np.uint32) != want.view(np.uint32))))
+            rule = tex_rule.guide_tex2d(px, srgb, uv, quantise=mode == 0)
+            assert np.abs(got.astype(np.float64) - rule).max() <= (4e-7 if mode == 0 else 2e-5), (mode, px.shape)
+        r.close(); o.close()
+
+
 def test_single_texel_slots_folded_at_upload_equal_the_real_fetch():
     """A material slot with a 1x1 texture is folded into the material record when the material is created (LmDevMaterial::constMask); the
     same texel repeated over a 3x2 image is not, and goes through descriptor + bilinear fetch + sRGB table.  Both must give the same frame
@@ -2046,71 +2066,6 @@ def test_seam_history_exchange_makes_odd_depth_tiles_exact(n_ranks, size, scene,
     if scene == "cornell":
         assert any(e[0] != e[-1] for e in executed), executed                                   # the ranks did disagree in some frame
     assert tiles.history_needed(5) and not tiles.history_needed(6)
-
-
-@pytest.mark.parametrize("n_ranks", [2, 4, 8])
-def test_tiled_path_on_real_gpus_over_rccl(n_ranks):
-    """The multi-GPU path as it runs in production: one process per GPU (torch.distributed.run, backend nccl = RCCL over xGMI),
-    tiles + 60-px halo, seam exchange of reservoir history after every TraceFrame (odd depth), one RCCL gather per displayed frame;
-    rank 0 compares the stitched blended frames bit for bit with a single-GPU render (tests/multigpu_worker.py).  Needs n_ranks GPUs
-    on the box: skipped on the single-GPU boxes of the development pool, runs wherever the driver has a multi-GPU node."""
-    import subprocess, sys, torch
-    if torch.cuda.device_count() < n_ranks:
-        pytest.skip(f"{torch.cuda.device_count()} GPU(s) on this box, {n_ranks} needed")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
-           "--master-port", str(29540 + n_ranks), os.path.join(root, "tests", "multigpu_worker.py")]
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)      # children start fresh: nothing GPU-side is inherited
-    assert res.returncode == 0 and "MULTIGPU OK" in res.stdout, res.stdout[-3000:] + res.stderr[-5000:]
-
-
-@pytest.mark.parametrize("n_ranks", [2, 4, 8])
-def test_tiled_worker_processes_share_the_one_gpu(n_ranks):
-    """The production worker as N real processes on the ONE GPU of the development boxes: every rank renders its window on GPU 0, the wave-count agreement, the seam
-    exchange of the halo rings' reservoirs and the tile gather run between the processes (gloo, staged through the host: RCCL does not accept two ranks on one device),
-    and rank 0 compares every blended frame of the stitched image bit for bit with its own full-frame render.  What this does not cover is RCCL itself over xGMI
-    (test_tiled_path_on_real_gpus_over_rccl, skipped without N GPUs)."""
-    import subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", LUMEN_WORKER_ONE_GPU="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
-           "--master-port", str(29560 + n_ranks), os.path.join(root, "tests", "multigpu_worker.py")]
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
-    assert res.returncode == 0 and "MULTIGPU OK" in res.stdout, res.stdout[-3000:] + res.stderr[-5000:]
-
-
-@pytest.mark.parametrize("n_ranks,workload", [(2, "sandbox"), (8, "c2"), (8, "c4")])      # c4 = BASELINE's 8-GPU configuration (4K, 8 spp, depth 8)
-def test_bench_multi_rank_path_rehearsed_on_the_one_gpu(n_ranks, workload):
-    """`python bench.py --gpus N` end to end where only one GPU exists (LUMEN_BENCH_ONE_GPU=1: every rank on GPU 0, collectives over gloo with host staging): the
-    self-launch, the windows and tiles, the seam exchange after every TraceFrame (sandbox: odd depth), the gather, the barrier-bracketed timing with the maximum over
-    ranks and the per-rank statistics all execute, and rank 0 prints ONE well-formed line that names itself a rehearsal.  The rate is not looked at."""
-    import json, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", LUMEN_BENCH_ONE_GPU="1")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
-        env.pop(k, None)
-    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n_ranks), "--workload", workload, "--steps", "2", "--warmup", "1"],
-                         env=env, capture_output=True, text=True, timeout=1200)
-    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
-    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, res.stdout[-2000:]
-    j = json.loads(lines[0])
-    assert j["n_gpus"] == n_ranks and j["rccl_world"] == n_ranks and len(j["devices"]) == n_ranks and "rehearsal" in j
-    assert len(j["per_rank"]) == n_ranks and all(p["render_ms_per_step"] > 0 for p in j["per_rank"])
-    assert j["value"] > 0 and j["scaling"] == "strong" and j["config"]["tiles"].split(" ")[0] in ("2x1", "1x2", "4x2", "2x4")
-
-
-def test_tiled_worker_single_rank_communicator():
-    """The same worker with one rank: the nccl communicator, the preallocated gather buffers and the frame loop on the GPU that is there
-    (the 2 / 4 / 8-rank forms above need a multi-GPU box)."""
-    import subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", "29539",
-           os.path.join(root, "tests", "multigpu_worker.py")]
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-    assert res.returncode == 0 and "MULTIGPU OK" in res.stdout, res.stdout[-3000:] + res.stderr[-5000:]
 
 
 def test_full_size_moving_scene_async_equals_serial():

@@ -505,3 +505,38 @@ def test_light_list_matches_the_reference_kernel(kat6_oracle):
     fa = a[:, 15].view(np.float32).astype(np.float64); fb = b[:, 15].view(np.float32).astype(np.float64)
     assert (np.abs(fa - fb) <= np.spacing(fb.astype(np.float32)).astype(np.float64)).all()
     assert np.abs(a[:, 15].astype(np.int64) - b[:, 15].astype(np.int64)).max() <= 1
+
+
+# ----------------------------------------------------------------------------------------------------------
+# texture filter: the oracle against the CUDA C Programming Guide's published linear-filtering rule, restated independently in tests/tex_rule.py (decision D6)
+# ----------------------------------------------------------------------------------------------------------
+def test_texture_filter_follows_the_published_cuda_rule():
+    """tex2D<float4> of the oracle (oracle/lumen_oracle.cpp tex2D) on ragged / tiny / sRGB maps at random, integer and texel-centre coordinates incl. negative ones
+    (wrap) against the Guide's four-term formula with 1.8 fixed-point weights in float64: agreement to fp32 rounding (the oracle nests fp32 lerps, the Guide's formula is
+    a four-term sum; same real number).  The weights ARE quantised: against unquantised weights the same fetches differ by up to 1/512 of the texel step per axis."""
+    import tex_rule
+    from oracle_lib import Oracle
+    o = Oracle(1)
+    uv = tex_rule.test_coordinates()
+    worst_q = 0.0
+    for px, srgb in tex_rule.test_textures():
+        t = o.add_texture(px, srgb)
+        got = o.tex2d(t, uv).astype(np.float64)
+        want = tex_rule.guide_tex2d(px, srgb, uv)
+        assert np.abs(got - want).max() <= 4e-7, (px.shape, np.abs(got - want).max())
+        plain = tex_rule.guide_tex2d(px, srgb, uv, quantise=False)
+        worst_q = max(worst_q, float(np.abs(plain - want).max()))
+        # a texel centre returns the texel; a constant neighbourhood returns its value exactly
+        h, w = px.shape[:2]
+        centres = np.float32([[(x + 0.5) / w, (y + 0.5) / h] for y in range(min(h, 5)) for x in range(min(w, 5))])
+        c = o.tex2d(t, centres).reshape(min(h, 5), min(w, 5), 4)
+        wantc = tex_rule.guide_tex2d(px, srgb, centres).reshape(min(h, 5), min(w, 5), 4)
+        assert np.abs(c - wantc).max() <= 1e-7
+    assert 1e-3 < worst_q <= 1.0 / 256.0 + 1e-9, worst_q          # the quantisation is visible, and bounded by half a weight step per axis on a full-range edge
+    # the other rule (tuning key tex_filter 1 / orc_set_tex_filter(1)): unquantised fp32 weights, no frac step
+    o.set_tex_filter(1)
+    px, srgb = tex_rule.test_textures()[1]
+    t = o.add_texture(px, srgb)
+    got = o.tex2d(t, uv).astype(np.float64)
+    assert np.abs(got - tex_rule.guide_tex2d(px, srgb, uv, quantise=False)).max() <= 2e-5      # u N - 0.5 without frac: fewer fraction bits at |u| ~ 4
+    o.close()

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""usage (GPU box): python tools/tex_filter_gap.py > profiles/r05_tex_filter_gap.txt — how far apart are the two bilinear rules (decision D6) on whole frames?
+CUDA's published rule (weights in 1.8 fixed point, wrap by frac: the default) against unquantised fp32 weights (tuning key tex_filter 1, the rule of rounds 1-4):
+relative L2 of the radiance, exact mode, on the textured C2 workload (c2t: 1024^2 procedural maps on 22 materials) at 1440p x 4 blended frames and on the
+reference's own LowpolyRoom (one 512^2 base-colour map) at 720p, plus the depth-0 base-colour plane alone (no Monte-Carlo decisions in between)."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import product_from, rel_l2
+from lumenrenderer_amd import scenes
+
+def run(desc, W, H, D, frames, mode):
+    r = product_from(desc, W, H, D, blend=True, tuning={"tex_filter": mode})
+    for _ in range(frames):
+        assert r.TraceFrame()
+    out = (r.GetRadiance().copy(), r.GetGBuffer()[..., 4, :3].copy(), list(r.GetCounters()[:12]))
+    r.close()
+    return out
+
+for name, desc, W, H, D, F in (("c2t (sponza stand-in, 1024^2 maps)", scenes.sponza_standin(textured=True), 2560, 1440, 6, 4),
+                               ("lowpoly (LowpolyRoom/scene.glb, 512^2 map)", scenes.lowpoly_room(os.path.join(ROOT, "tests", "golden", "ref_lowpoly_room.npz")), 1280, 720, 5, 4)):
+    a = run(desc, W, H, D, F, 0); b = run(desc, W, H, D, F, 1)
+    col = np.abs(a[1].astype(np.float64) - b[1])
+    print(f"{name}, {W}x{H}, depth {D}, {F} blended frames, exact mode")
+    print(f"  radiance rel-L2 (fixed-point weights vs fp32 weights)      {rel_l2(a[0][..., :3], b[0][..., :3]):.3e}")
+    print(f"  depth-0 base colour: rel-L2 {rel_l2(a[1], b[1]):.3e}, max abs {col.max():.3e}, pixels that differ {np.mean(np.any(col > 0, axis=-1)):.3f}")
+    print(f"  ray counters (closest, NEE, ReSTIR, lights, waves...): {a[2]} vs {b[2]}")
