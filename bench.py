@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak, /opt/skills/guides/MI355X_
 VALU_PEAK_TLANEOPS = 78.6432
 WAVEINST_PEAK = 1055.8e9         # VALU wave-instructions/s the chip sustains with dependent chains at 8 waves per SIMD (measured, profiles/r03_valu_peak.txt: 2.33 cycles per instruction per SIMD)
 TRAV_T0_US, TRAV_STEPS_PER_US = 60.0, 75000.0  # closest-hit launch of incoherent rays: T = T0 + rays x steps per ray / S; calibration 4.6 G rays/s at 16.3 steps per ray (profiles/r04_step_latency.txt)
-PMC_FILE = os.path.join("profiles", "r04_c2_pmc.json")      # tools/pmc_json.sh on the GPU box; replayed here, never measured by this run
+PMC_FILE = os.path.join("profiles", "r05_c2_pmc.json")      # tools/pmc_json.sh on the GPU box; replayed here, never measured by this run
 
 
 def kernel_source_id():
@@ -132,7 +132,25 @@ def self_launch(args, argv):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port)] + logs + [os.path.abspath(__file__)] + [a for a in argv if a != "--dry-launch"]
     if args.dry_launch:
-        print(json.dumps({"launch": cmd}))
+        # the launch command and what every rank would render and send: its tile, its window (tile + 60-px halo, clipped), the redundant halo pixels, the bytes it
+        # contributes to the one gather per displayed frame and, for path depths with temporal history, the seam exchange after every TraceFrame — without touching a GPU
+        from lumenrenderer_amd import tiles
+        _, _, W, H, depth, spp = WORKLOADS[args.workload]
+        cols, rows = tiles.grid_for(args.gpus, W, H)
+        mh, mw = tiles.max_tile_shape(args.gpus, W, H)
+        ranks = []
+        for rk in range(args.gpus):
+            t = tiles.tile_rect(rk, args.gpus, W, H); w = tiles.window_rect(t, W, H)
+            tp, wp = (t[2] - t[0]) * (t[3] - t[1]), (w[2] - w[0]) * (w[3] - w[1])
+            plan = tiles.halo_plan(rk, args.gpus, W, H) if tiles.history_needed(depth) else []
+            area = lambda q: 0 if q is None else (q[2] - q[0]) * (q[3] - q[1])
+            ranks.append({"rank": rk, "tile": list(t), "window": list(w), "tile_pixels": tp, "window_pixels": wp, "halo_pixels": wp - tp, "halo_over_tile": round((wp - tp) / tp, 4),
+                          "gather_send_bytes": mh * mw * 16, "seam_send_bytes_per_traceframe": sum(area(sd) for _, sd, _ in plan) * tiles.HISTORY_FLOATS * 4,
+                          "seam_recv_bytes_per_traceframe": sum(area(rv) for _, _, rv in plan) * tiles.HISTORY_FLOATS * 4, "seam_peers": [p_ for p_, _, _ in plan]})
+        print(json.dumps({"launch": cmd, "workload": args.workload, "image": [W, H], "depth": depth, "spp": spp, "grid": f"{cols}x{rows}", "halo_px": tiles.HALO,
+                          "gather": {"collective": "gather to rank 0 (RCCL over xGMI), one per displayed frame", "bytes_per_rank": mh * mw * 16, "bytes_total": args.gpus * mh * mw * 16},
+                          "seam_exchange": "after every TraceFrame (odd path depth: temporal history is live)" if tiles.history_needed(depth) else "none (even path depth: no temporal history)",
+                          "worst_window_pixels": max(r_["window_pixels"] for r_ in ranks), "single_gpu_pixels": W * H, "ranks": ranks}))
         return 0
     env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
@@ -252,7 +270,8 @@ def main():
         local_rank = 0
     present = torch.cuda.device_count()                   # counting devices does not initialise the GPU
     if present < world and not one_gpu:
-        raise SystemExit(f"bench.py: {world} GPUs requested, {present} present")
+        raise SystemExit(f"bench.py: --gpus {world} needs {world} visible GPUs, this node shows {present} (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?); "
+                         f"`python bench.py --gpus {world} --dry-launch` prints the launch command and every rank's tile plan without touching a GPU")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -294,7 +313,12 @@ def main():
             from host_staged_dist import HostStagedDist          # test infrastructure (tests/): gloo through host staging, rehearsal only
             dist = HostStagedDist(dist)
         else:
-            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+            import datetime
+            try:                                                                                     # an explicit timeout: a rank that never arrives ends the run with a message, not a hang
+                dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=int(os.environ.get("LUMEN_BENCH_RCCL_TIMEOUT_S", "300"))))
+            except Exception as ex:
+                raise SystemExit(f"bench.py rank {rank}: the RCCL communicator over {world} GPUs could not be created ({type(ex).__name__}: {ex}); "
+                                 f"{present} GPU(s) visible here — is HSA_ENABLE_IPC_MODE_LEGACY=0 exported and does every rank see its device?")
         warm = torch.zeros(1, device=dev); dist.all_reduce(warm)                                   # communicator + stream exist now
         torch.cuda.synchronize()
 
@@ -443,6 +467,17 @@ def main():
         tc = [(pk(n, "hbm_bytes_per_launch_corrected"), pk(n, "launches")) for n in ("lm_k_trace_closest", "lm_k_trace_closest_packet")]
         tc = [(b, l) for b, l in tc if b is not None and l]
         traffic_closest = sum(b * l for b, l in tc) / sum(l for _, l in tc) if tc else None
+        # the same algorithmic bytes over the ALONE launch time (PMC passes serialise the dispatches): what the kernels reach when nothing else is resident
+        ta = [(pk(n, "alone_us"), pk(n, "launches")) for n in ("lm_k_trace_closest", "lm_k_trace_closest_packet")]
+        ta = [(u, l) for u, l in ta if u and l]
+        alone_us = sum(u * l for u, l in ta) / sum(l for _, l in ta) if ta else None
+        frac_alone = None if not alone_us else round((alg / max(1.0, launches_per_tf)) / (alone_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
+        # PHYSICAL HBM fraction of every kernel that moves more than 50 MB per launch: PMC bytes / alone time / peak (which passes are byte-bound, which are not)
+        hbm_kernels = sorted(({"kernel": n, "hbm_mb_per_launch": round(v["hbm_bytes_per_launch_corrected"] / 1e6, 1), "alone_us": round(v["alone_us"], 1),
+                               "frac": round(v["hbm_bytes_per_launch_corrected"] / (v["alone_us"] * 1e-6) / (HBM_PEAK_GBS * 1e9), 4),
+                               "active_lanes_per_valu_inst": round(v.get("active_lanes_per_valu_inst") or 0.0, 1)}
+                              for n, v in pmc.items() if v.get("alone_us") and v.get("hbm_bytes_per_launch_corrected", 0.0) > 50e6 and v.get("launches", 0) > 2),
+                             key=lambda e: -e["frac"])
         npix = (win[2] - win[0]) * (win[3] - win[1])
         alg_tf = algorithmic_bytes_traceframe(c, depth, npix, ci[20], ci[21], blend=blend_on)
         # whole-frame HBM traffic from the PMC replay: sum over kernels of bytes per launch x launches per TraceFrame
@@ -521,8 +556,11 @@ def main():
                        "hbm_traffic_bytes_per_traceframe": None if hbm_tf is None else int(hbm_tf),
                        "hbm_traffic_frac": None if hbm_tf is None else round(hbm_tf / (tf_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
                        "hbm_traffic_source": None if hbm_tf is None else PMC_FILE + " (replayed: PMC passes of the builder's run, 2 x FETCH_SIZE + WRITE_SIZE per kernel)"},
-            "roofline": {"bound": "hbm", "kernel": "lm_k_trace_closest (+ lm_k_trace_closest_packet: the primary wave)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic_closest,
+            # `bound`: the kernel is NOT HBM-bound — the tree is served by L2 / Infinity Cache (frac_hbm_physical: a few % of peak); what bounds a launch is the dependent
+            # chain of its longest rays x the lanes divergence leaves idle (traversal_model).  `frac` stays the contract's figure (SURVEY d4 algorithmic bytes / live
+            # launch time / HBM peak) so that rounds compare; `frac_alone` is the same bytes over the kernels' serialised (alone) time from the PMC replay.
+            "roofline": {"bound": "latency/divergence", "kernel": "lm_k_trace_closest (+ lm_k_trace_closest_packet: the primary wave)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_alone": frac_alone, "traffic": traffic_closest,
                          # the PHYSICAL fraction beside the algorithmic one: PMC bytes per launch / live launch time / peak
                          "frac_hbm_physical": None if (not traffic_closest or per_launch_ms <= 0) else round(traffic_closest / (per_launch_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 5),
                          "traffic_source": None if traffic_closest is None else PMC_FILE + " (replayed, not measured by this run)",
@@ -532,6 +570,7 @@ def main():
                          "algorithmic_bytes_per_launch": int(alg / max(1.0, launches_per_tf)),
                          "achieved_d4_binary_node_pricing": round(gbs(alg_d4), 2)},
             "roofline_valu": valu,
+            "roofline_hbm_kernels": hbm_kernels,
             "frame_valu_frac": frame_valu_frac, "frame_hbm_frac": frame_hbm_frac,
             "frame_bound_note": "fractions of the chip's VALU issue peak (wave-instructions, measured) and of HBM peak over one TraceFrame, from the PMC replay: both well below 1 — "
                                 "the frame is bound by dependent-chain latency inside the traversal launches and by how well four streams fill each other's stalls",

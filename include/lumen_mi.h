@@ -256,7 +256,8 @@ int lumen_mi_test_shade(lumen_mi_renderer*, uint32_t n, uint32_t W, uint32_t H, 
  * tests/golden/ref_kat6.npz: a scene of 1 x 1 textures, where no texture filtering can happen).  hits9 per row: table entry, primitive-local triangle, barycentric u, v
  * (binary16 bits), t, pixel x, y, two unused; rays9: origin direction contribution.  out35: flags t position normal geomNormal(0) tangent incoming transport color4 tint4
  * transmittance4 params3.  lumen_mi_test_extract0 runs the depth-0 KERNEL (surface extraction + GenerateMotionVector MotionVectors.cu:8-55 + ResolveDirectLightHits
- * GPUShadeDirect.cu:11-40, fused) on hit records for every pixel of the render resolution (row-major): G-buffer records [n][8][4], motion vectors (half2 bits), DIRECT [n][4]. */
+ * GPUShadeDirect.cu:11-40, fused) on hit records for every pixel of the render resolution (row-major): G-buffer records [n][8][4], motion vectors (half2 bits), DIRECT [n][4].
+ * lumen_mi_test_extract0 runs on the renderer's live frame buffers and INVALIDATES its history: the next TraceFrame starts as after a resize (reservoirs reset, frame counter 0). */
 int lumen_mi_test_extract(lumen_mi_renderer*, uint32_t n, const uint32_t* hits9, const uint32_t* rays9, uint32_t* out35);
 /* tex2D<float4>(texture object, u, v) as ExtractSurfaceDataGpu fetches it (GPUExtractSurfaceData.cu:59-60,169-181; texture object of PTTexture.cpp:35-74: linear filter,
  * wrap, normalised float read, sRGB decode per texel when created with normalize) on n coordinates uv2 of one texture -> out4 [n][4].  The filter is the rule the CUDA C
@@ -273,6 +274,8 @@ int lumen_mi_test_camera(const float right[3], const float up[3], const float fo
 /* host-side scene products, for tests: world-space triangles (9 floats each) and the sorted light list (16 floats each) + CDF */
 int lumen_mi_get_world_triangles(lumen_mi_renderer*, float* out, uint32_t capacity_triangles, uint32_t* count);
 int lumen_mi_get_lights(lumen_mi_renderer*, float* lights16, float* cdf, uint32_t capacity, uint32_t* count);
+/* nodes / max_depth describe the tree as it was BUILT: binary nodes and binary depth of the host SAH build; 4-wide nodes and the number of wide levels for a tree
+ * assembled from per-mesh trees or built on the device (tuning key gpu_build, which applies to full builds only: meshes added later are built per mesh on the host). */
 int lumen_mi_get_bvh_info(lumen_mi_renderer*, uint32_t* nodes, uint32_t* triangles, uint32_t* max_depth);
 
 #ifdef __cplusplus

@@ -118,8 +118,11 @@ __global__ void k_fit(const Bin2* __restrict__ nodes, const int* __restrict__ pa
     if (s >= n) return;
     int p = parentLeaf[s];
     while (p >= 0) {
-        __threadfence();
+        __threadfence();                                  // release: this thread's box is visible before it announces itself
         if (atomicAdd(arrived + p, 1u) == 0u) return;
+        __threadfence();                                  // acquire: the sibling's box (written by another wave, maybe on another CU) is read after the counter, not from a
+                                                          // line this CU's vector L1 already held — a stale area would only change which child the collapse expands, but that
+                                                          // made the tree's shape differ from run to run
         const Bin2 b = nodes[p];
         const float4 alo = b.left >= 0 ? nodeLo[b.left] : boxLo[sortedTri[~b.left]], ahi = b.left >= 0 ? nodeHi[b.left] : boxHi[sortedTri[~b.left]];
         const float4 blo = b.right >= 0 ? nodeLo[b.right] : boxLo[sortedTri[~b.right]], bhi = b.right >= 0 ? nodeHi[b.right] : boxHi[sortedTri[~b.right]];

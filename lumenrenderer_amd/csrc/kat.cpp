@@ -39,14 +39,15 @@ int lumen_mi_test_restir_frame(lumen_mi_renderer* r, uint32_t W, uint32_t H, con
                                uint32_t n_lights, const uint32_t* lights16, const uint32_t* cdf, uint32_t a_seed, int current_index, const uint8_t* occluded0,
                                const uint8_t* occluded1, int fast, uint32_t* res4, uint32_t* bags, uint32_t* stages, uint32_t* rays, uint32_t* ray_counts, uint32_t* direct)
 {
-    if (!r || !r->initialised) return fail(LUMEN_MI_ERR_STATE, "not initialised");
+    if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer");
+    ApiLock lk(r);                                        // before any renderer state is read (a render thread may be running)
+    if (!r->initialised) return fail(LUMEN_MI_ERR_STATE, "not initialised");
     if (!W || !H || !surf_cur40 || !motion_half2 || !n_lights || !lights16 || !cdf || !occluded0 || !occluded1 || !res4 || !stages || !rays || !ray_counts || !direct ||
         (current_index != 0 && current_index != 1) || fast < 0 || fast > 2) return fail(LUMEN_MI_ERR_INVALID, "bad argument");
-    ApiLock lk(r);
     LM_HIP(hipSetDevice(r->device));
     LM_HIP(hipStreamSynchronize(r->stream));
     const uint32_t n = W * H;
-    const LmKernelTable* K = lm_kernel_table();
+    const LmKernelTable* K = r->K;                        // the table lumen_mi_set_instrumented selected
     hipStream_t st = r->stream;
     Bufs b;
     LmFrame fr{};
@@ -130,9 +131,10 @@ int lumen_mi_test_restir_frame(lumen_mi_renderer* r, uint32_t W, uint32_t H, con
 int lumen_mi_test_shade(lumen_mi_renderer* r, uint32_t n, uint32_t W, uint32_t H, const uint32_t* rows43, uint32_t n_lights, const uint32_t* lights16, const uint32_t* cdf,
                         int fast, uint32_t* direct12, uint32_t* indirect10)
 {
-    if (!r || !r->initialised) return fail(LUMEN_MI_ERR_STATE, "not initialised");
+    if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer");
+    ApiLock lk(r);                                        // before any renderer state is read
+    if (!r->initialised) return fail(LUMEN_MI_ERR_STATE, "not initialised");
     if (!n || !W || !H || !rows43 || !n_lights || !lights16 || !cdf || (!direct12 && !indirect10)) return fail(LUMEN_MI_ERR_INVALID, "bad argument");
-    ApiLock lk(r);
     LM_HIP(hipSetDevice(r->device));
     Bufs b;
     LmScene sc{};
@@ -153,9 +155,10 @@ int lumen_mi_test_shade(lumen_mi_renderer* r, uint32_t n, uint32_t W, uint32_t H
 
 int lumen_mi_test_extract(lumen_mi_renderer* r, uint32_t n, const uint32_t* hits9, const uint32_t* rays9, uint32_t* out35)
 {
-    if (!r || !r->initialised) return fail(LUMEN_MI_ERR_STATE, "not initialised");
+    if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer");
+    ApiLock lk(r);                                        // before any renderer state is read
+    if (!r->initialised) return fail(LUMEN_MI_ERR_STATE, "not initialised");
     if (!n || !hits9 || !rays9 || !out35) return fail(LUMEN_MI_ERR_INVALID, "bad argument");
-    ApiLock lk(r);
     LM_HIP(hipSetDevice(r->device));
     int rc;
     if ((rc = uploadResources(r))) return rc;
@@ -200,9 +203,10 @@ int lumen_mi_test_tex2d(lumen_mi_renderer* r, lumen_mi_handle texture, uint32_t 
  * record the kernel stored ([n][8][4] floats as lumen_mi_get_gbuffer gives them), motion vectors (half2 bits) and the DIRECT channel it initialised. */
 int lumen_mi_test_extract0(lumen_mi_renderer* r, const uint32_t* hits9, const uint32_t* dirs3, const uint32_t* eye3, const uint32_t* matrix16, float* gbuffer, uint32_t* motion, float* direct)
 {
-    if (!r || !r->initialised) return fail(LUMEN_MI_ERR_STATE, "not initialised");
+    if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer");
+    ApiLock lk(r);                                        // before any renderer state is read
+    if (!r->initialised) return fail(LUMEN_MI_ERR_STATE, "not initialised");
     if (!hits9 || !dirs3 || !eye3 || !matrix16 || !gbuffer || !motion || !direct) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
-    ApiLock lk(r);
     LM_HIP(hipSetDevice(r->device));
     { std::lock_guard<std::mutex> sl(r->settingsMutex); r->settings = r->pending; }
     int rc;
@@ -236,14 +240,18 @@ int lumen_mi_test_extract0(lumen_mi_renderer* r, const uint32_t* hits9, const ui
     LM_HIP(hipMemcpy(gbuffer, fr.gbuf[0], (size_t)n * 8 * 16, hipMemcpyDeviceToHost));
     LM_HIP(hipMemcpy(motion, fr.motion, (size_t)n * 4, hipMemcpyDeviceToHost));
     LM_HIP(hipMemcpy(direct, fr.direct, (size_t)n * 16, hipMemcpyDeviceToHost));
+    // the hook wrote the renderer's LIVE G-buffer, motion, DIRECT and counter buffers: what a traced frame left there (temporal history, a deferred history pass) is gone.
+    // The next frame therefore starts as after a resize — buffers cleared, reservoirs reset, frame and blend counters at 0 (ensureFrameBuffers) — instead of reading them.
+    r->owed.valid = false; r->allocN = 0;
     return 0;
 }
 
 int lumen_mi_test_primary_rays(lumen_mi_renderer* r, uint32_t W, uint32_t H, uint32_t frame_count, const uint32_t* cam_uvw_eye12, uint32_t* out11)
 {
-    if (!r || !r->initialised) return fail(LUMEN_MI_ERR_STATE, "not initialised");
+    if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer");
+    ApiLock lk(r);                                        // before any renderer state is read
+    if (!r->initialised) return fail(LUMEN_MI_ERR_STATE, "not initialised");
     if (!W || !H || !cam_uvw_eye12 || !out11) return fail(LUMEN_MI_ERR_INVALID, "bad argument");
-    ApiLock lk(r);
     LM_HIP(hipSetDevice(r->device));
     const uint32_t n = W * H;
     Bufs b;

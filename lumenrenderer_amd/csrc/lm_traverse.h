@@ -743,7 +743,7 @@ __device__ __forceinline__ void lm_trace_packets(const LmScene& sc, uint32_t n, 
 #endif                             //    all 64 lanes ask for the same bytes (the compiler scalarises the leaf's Woop packets by itself, but not this load: `nodes` is written by the
                                    //    refit kernels, so it carries no read-only guarantee).  Scalar caches are invalidated at kernel boundaries: a refit in an earlier launch is seen.
                                    //    A/B: profiles/r04_packet_scalar_ab.txt
-#if LM_PACKET_SCALAR_NODE
+#if LM_PACKET_SCALAR_NODE && (defined(__gfx950__) || defined(__gfx942__) || defined(__gfx90a__))      // the mnemonic and the single lgkmcnt counter are gfx9's: any other ARCH takes the vector loads
                     typedef uint32_t lm_u32x16 __attribute__((ext_vector_type(16)));
                     lm_u32x16 rec;
                     asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rec) : "s"(nd) : "memory");

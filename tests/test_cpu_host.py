@@ -1,6 +1,7 @@
 """CPU-only tests: the C-ABI library loads and exports every declared symbol, host-side logic (scene descriptions,
 glTF ingest rules, tile partition), the oracle's end-to-end behaviour, and the N>1 path with gloo (world size 2)."""
 import ctypes as C
+import json
 import os
 import re
 import subprocess
@@ -858,7 +859,21 @@ def test_bench_self_launch_fails_clearly_when_the_gpus_are_not_there():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                          capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode != 0
-    assert "2 GPUs requested, 0 present" in out.stderr + out.stdout
+    assert "--gpus 2 needs 2 visible GPUs, this node shows 0" in out.stderr + out.stdout
+
+
+def test_bench_dry_launch_prints_every_ranks_tile_plan():
+    """`bench.py --gpus N --dry-launch` (no GPU touched): the launch command and, per rank, tile / window / halo pixels / gather bytes / seam-exchange bytes — BASELINE's
+    8-GPU configuration (C4: 4K as a 4 x 2 grid, even depth: no seam exchange) and the 2-rank Sandbox setting (odd depth: the halo rings' reservoirs travel every TraceFrame)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    j = json.loads(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", "c4", "--dry-launch"], capture_output=True, text=True, env=env, timeout=120, check=True).stdout)
+    assert j["grid"] == "4x2" and len(j["ranks"]) == 8 and "torch.distributed.run" in j["launch"] and "--nproc-per-node=8" in j["launch"]
+    assert sum(r["tile_pixels"] for r in j["ranks"]) == 3840 * 2160 == j["single_gpu_pixels"]
+    assert all(r["gather_send_bytes"] == 960 * 1080 * 16 and r["seam_peers"] == [] for r in j["ranks"]) and j["gather"]["bytes_total"] == 8 * 960 * 1080 * 16
+    assert j["worst_window_pixels"] == 1080 * 1140 and 0.12 < min(r["halo_over_tile"] for r in j["ranks"]) < max(r["halo_over_tile"] for r in j["ranks"]) < 0.19
+    j = json.loads(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "sandbox", "--dry-launch"], capture_output=True, text=True, env=env, timeout=120, check=True).stdout)
+    assert j["grid"] == "2x1" and [r["seam_peers"] for r in j["ranks"]] == [[1], [0]]
+    assert all(r["seam_send_bytes_per_traceframe"] == 60 * 720 * 80 == r["seam_recv_bytes_per_traceframe"] for r in j["ranks"])
 
 
 def test_shortcut_halton_equals_the_digit_loop_bit_for_bit(tmp_path):

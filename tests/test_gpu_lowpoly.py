@@ -70,7 +70,8 @@ def test_lowpoly_room_through_the_adapters_ollad_path(tmp_path):
     path = str(tmp_path / "scene.ollad")
     ollad.write_ollad_from_description(d, path)
     c = d.camera
-    np.float32(list(c["position"]) + list(c["right"]) + list(c["up"]) + list(c["forward"]) + [c["fov"]]).tofile(path + ".cam")
+    # the driver's optional side file <model path as asked for>.cam: 13 floats (position, right, up, forward, fov) = the pose Application.cpp:145-146 sets
+    np.float32(list(c["position"]) + list(c["right"]) + list(c["up"]) + list(c["forward"]) + [c["fov"]]).tofile(str(tmp_path / "scene.glb") + ".cam")
     back = ollad.read_ollad(path)
     back.camera = d.camera
     assert back.triangle_count() == d.triangle_count() == 20501

@@ -1080,6 +1080,28 @@ def test_fp16_quantised_radiance_report():
         r.close(); o.close()
 
 
+def test_fp16_blend_chain_as_the_reference_stores_it_report():
+    """Decision D1 on the blend, as a number (VERDICT r4 missing #4): the reference blends in binary16 (GPUMergeOutputChannels.cu:53-72, Half4.h:105-196), this build in fp32
+    with one rounding on export.  Per-frame fp32 channels of the product (blending off) replayed through both chains on the host (tools/fp16_blend_chain.py; numpy float16 is
+    correctly rounded per operation = the best case of __hmul2 / __hadd2 / __h2div): the two stay within a few binary16 ulp of each other — 4 frames ~ 5e-4, 8 frames
+    ~ 7e-4 relative L2 — i.e. the fp16 chain alone uses up most of the 1e-3 tolerance, which is why fp32 is the contract."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from fp16_blend_chain import chains, rel_l2_finite
+    from lumenrenderer_amd.scenes import sponza_standin
+    r = product_from(sponza_standin(), 640, 360, 6, blend=False)
+    fd, fi = [], []
+    for _ in range(8):
+        assert r.TraceFrame()
+        fd.append(r.GetChannel(0).copy()); fi.append(r.GetChannel(1).copy())
+    r.close()
+    c = chains(fd, fi)
+    errs = {n: rel_l2_finite(c[n][0], c[n][1])[0] for n in (1, 4, 8)}
+    print("fp32 blend rounded once vs binary16 blend chain, rel-L2 by blended frames:", {n: f"{e:.3e}" for n, e in errs.items()})
+    assert errs[1] < 6e-4 and errs[4] < 2e-3 and errs[8] < 2e-3, errs          # frame 1: two roundings of the channels against one of the sum
+    assert errs[4] > 1e-5 and errs[8] > 1e-5, errs                             # ... and the chains do differ: the report is not vacuous
+
+
 def test_cornell_blended_frames_depth5():
     d = cornell()
     r = product_from(d, 160, 120, 5, blend=True); o = oracle_from(d, 160, 120, 5, blend=True)
