@@ -95,6 +95,40 @@ __device__ __forceinline__ void lm_append_slot_block2(uint32_t* counterA, bool p
     slotB = tB[nWaves] + tB[wave] + (uint32_t)__popcll(maskB & below);
     __syncthreads();
 }
+// Block-aggregated append that also ORDERS the block's appended rays by a 3-bit key (the direction octant), so that the 64 consecutive queue slots a traversal
+// wavefront takes hold one or two octants of rays from neighbouring pixels instead of all eight mixed (coherence created where the queue is written,
+// no sort pass).  Same single atomic per block; the per-key, per-wave counts are scanned by the first 32 lanes.  `s_key` = 8 x (waves per block) + 1 words, waves <= 4.
+// Compile-time switch LM_APPEND_OCTANT (A/B: profiles/r05_append_octant_ab.txt).
+#ifndef LM_APPEND_OCTANT
+#define LM_APPEND_OCTANT 0
+#endif
+__device__ __forceinline__ uint32_t lm_octant(const lf3& d) { return (d.x < 0.f ? 1u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 4u : 0u); }
+__device__ __forceinline__ uint32_t lm_append_slot_block_keyed(uint32_t* counter, bool pred, uint32_t key, uint32_t* s_key)
+{
+    const uint32_t lane = lm_lane(), wave = threadIdx.x >> 6, nWaves = blockDim.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t mine = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; k++) {
+        const unsigned long long m = __ballot(pred && key == k);
+        if (lane == 0) s_key[k * nWaves + wave] = (uint32_t)__popcll(m);
+        if (key == k) mine = (uint32_t)__popcll(m & below);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64u) {                                  // exclusive scan of the 8 x nWaves (<= 32) counts in key-major order by wave 0
+        const uint32_t cnt = threadIdx.x < 8u * nWaves ? s_key[threadIdx.x] : 0u;
+        uint32_t inc = cnt;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) { const uint32_t up = (uint32_t)__shfl_up((int)inc, o, 64); if ((int)lane >= o) inc += up; }
+        const uint32_t total = (uint32_t)__shfl((int)inc, 31, 64);
+        if (threadIdx.x < 8u * nWaves) s_key[threadIdx.x] = inc - cnt;
+        if (threadIdx.x == 0) s_key[8u * nWaves] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    const uint32_t slot = s_key[8u * nWaves] + s_key[key * nWaves + wave] + mine;
+    __syncthreads();
+    return slot;
+}
 __device__ __forceinline__ void lm_count_block(uint32_t* counter, bool pred, uint32_t* s_tmp)
 {
     const unsigned long long mask = __ballot(pred);
@@ -241,6 +275,9 @@ extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_EXTRACT_WAVES)
 KN(lm_k_extract0)(LmScene sc, LmFrame fr, LmCamera cam, int cur, uint32_t seed2, int doIndirect, int outQ, uint32_t* outCount)
 {
     __shared__ uint32_t s_tmp[10];
+#if LM_APPEND_OCTANT
+    __shared__ uint32_t s_key[8 * (LM_BLOCK / 64) + 1];
+#endif
     __shared__ float s_lut[256];
     __shared__ uint4 s_tab[LM_TABLE_QUADS];
     const lm_lds_float* lut = lm_stage_lut(s_lut, sc);
@@ -298,7 +335,12 @@ KN(lm_k_extract0)(LmScene sc, LmFrame fr, LmCamera cam, int cur, uint32_t seed2,
         }
         if (doIndirect || fr.owedSet >= 0) {                       // uniform per block
             uint32_t slot, slotKeeps;
+#if LM_APPEND_OCTANT
+            slot = lm_append_slot_block_keyed(outCount, emit, lm_octant(bd), s_key);
+            slotKeeps = fr.owedSet >= 0 ? lm_append_slot_block(fr.counters + LM_CNT_HAZARD, keeps, s_tmp) : 0u;
+#else
             lm_append_slot_block2(outCount, emit, slot, fr.counters + LM_CNT_HAZARD, keeps, slotKeeps, s_tmp);
+#endif
             if (emit) {
                 fr.rayO[outQ][slot] = v4(bo, 0.f);
                 fr.rayD[outQ][slot] = v4(bd, u2f(liOut));
@@ -316,6 +358,9 @@ __device__ __forceinline__ void lm_shade_wave_body(const LmScene& sc, const LmFr
                 uint32_t* outCount, uint32_t* shadowCount)
 {
     __shared__ uint32_t s_tmp[5];
+#if LM_APPEND_OCTANT
+    __shared__ uint32_t s_key[8 * (LM_BLOCK / 64) + 1];
+#endif
     __shared__ float s_lut[256];
     __shared__ uint4 s_tab[LM_TABLE_QUADS];
     const lm_lds_float* lut = lm_stage_lut(s_lut, sc);
@@ -344,13 +389,21 @@ __device__ __forceinline__ void lm_shade_wave_body(const LmScene& sc, const LmFr
             spos = s.position;
             if (doIndirect) emitRay = lm_shade_indirect(s, gi, seed2, o, d, c);
         }
+#if LM_APPEND_OCTANT
+        const uint32_t ss = lm_append_slot_block_keyed(shadowCount, emitShadow, lm_octant(sdir), s_key);
+#else
         const uint32_t ss = lm_append_slot_block(shadowCount, emitShadow, s_tmp);
+#endif
         if (emitShadow) {
             fr.shO[ss] = v4(spos, stmax);
             fr.shD[ss] = v4(sdir, u2f(li));
             fr.shR[ss] = v4(srad, 0.f);
         }
+#if LM_APPEND_OCTANT
+        const uint32_t rs = lm_append_slot_block_keyed(outCount, emitRay, lm_octant(d), s_key);
+#else
         const uint32_t rs = lm_append_slot_block(outCount, emitRay, s_tmp);
+#endif
         if (emitRay) {
             fr.rayO[outQ][rs] = v4(o, 0.f);
             fr.rayD[outQ][rs] = v4(d, u2f(li));

@@ -58,6 +58,30 @@ def test_lowpoly_room_default_workload_is_bit_exact_and_the_fast_mode_stays_with
     r.close(); rf.close(); o.close()
 
 
+def _through_a_quaternion(right, up, forward):
+    """The camera basis as the Sandbox call sequence hands it over: examples/sandbox_driver.cpp sets the scene camera by SetRotation(glm::quat_cast(basis)), and the camera
+    class turns the quaternion back into a matrix (glm::toMat4: Camera.cpp:128-140) — for a general rotation that round trip moves the columns by an ulp or two.
+    The same fp32 operations in glm's order (glm/gtc/quaternion.inl quat_cast / mat3_cast), so that the oracle renders from exactly the vectors the renderer received."""
+    f = np.float32
+    m = [[f(x) for x in right], [f(x) for x in up], [f(x) for x in forward]]                   # columns
+    fx = m[0][0] - m[1][1] - m[2][2]; fy = m[1][1] - m[0][0] - m[2][2]; fz = m[2][2] - m[0][0] - m[1][1]; fw = m[0][0] + m[1][1] + m[2][2]
+    big, best = 0, fw
+    if fx > best: best, big = fx, 1
+    if fy > best: best, big = fy, 2
+    if fz > best: best, big = fz, 3
+    v = np.sqrt(best + f(1)) * f(0.5); k = f(0.25) / v
+    if big == 0: w, x, y, z = v, (m[1][2] - m[2][1]) * k, (m[2][0] - m[0][2]) * k, (m[0][1] - m[1][0]) * k
+    elif big == 1: w, x, y, z = (m[1][2] - m[2][1]) * k, v, (m[0][1] + m[1][0]) * k, (m[2][0] + m[0][2]) * k
+    elif big == 2: w, x, y, z = (m[2][0] - m[0][2]) * k, (m[0][1] + m[1][0]) * k, v, (m[1][2] + m[2][1]) * k
+    else: w, x, y, z = (m[0][1] - m[1][0]) * k, (m[2][0] + m[0][2]) * k, (m[1][2] + m[2][1]) * k, v
+    xx, yy, zz, xz, xy, yz, wx, wy, wz = x * x, y * y, z * z, x * z, x * y, y * z, w * x, w * y, w * z
+    one, two = f(1), f(2)
+    c0 = (one - two * (yy + zz), two * (xy + wz), two * (xz - wy))
+    c1 = (two * (xy - wz), one - two * (xx + zz), two * (yz + wx))
+    c2 = (two * (xz + wy), two * (yz - wx), one - two * (xx + yy))
+    return np.float32(c0), np.float32(c1), np.float32(c2)
+
+
 def test_lowpoly_room_through_the_adapters_ollad_path(tmp_path):
     """The same model the way the Sandbox really loads it: SceneManager::LoadGLTF asks the renderer first (OpenCustomFileFormat, SceneManager.cpp:56-64 ->
     LumenPTModelConverter::LoadFile); an .ollad cache of the room (lumenrenderer_amd/ollad.py writes the reference converter's byte layout) opened through
@@ -73,7 +97,9 @@ def test_lowpoly_room_through_the_adapters_ollad_path(tmp_path):
     # the driver's optional side file <model path as asked for>.cam: 13 floats (position, right, up, forward, fov) = the pose Application.cpp:145-146 sets
     np.float32(list(c["position"]) + list(c["right"]) + list(c["up"]) + list(c["forward"]) + [c["fov"]]).tofile(str(tmp_path / "scene.glb") + ".cam")
     back = ollad.read_ollad(path)
-    back.camera = d.camera
+    r_, u_, f_ = _through_a_quaternion(c["right"], c["up"], c["forward"])
+    assert max(np.abs(r_ - np.float32(c["right"])).max(), np.abs(u_ - np.float32(c["up"])).max(), np.abs(f_ - np.float32(c["forward"])).max()) < 1e-6
+    back.set_camera(c["position"], r_, u_, f_, c["fov"])
     assert back.triangle_count() == d.triangle_count() == 20501
     W, H, D, F = 640, 360, 5, 3
     exe = build_sandbox_driver(tmp_path)
