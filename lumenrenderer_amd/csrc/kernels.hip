@@ -944,6 +944,28 @@ KN(lm_k_pick_primary_fast_lds)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t
 #endif
     lm_pick_primary_body<LmFast, LM_COMMON, true>(sc, fr, cur, rc, seed, visCount, s_bag, s_tmp, s_lights);
 }
+// ... and for light lists of LM_PICK_LDS_LIGHTS + 1 .. LM_PICK_LDS_LIGHTS_BIG records (round 5: the reference's default model, LowpolyRoom, has 414 triangle lights and fell
+// off the 384-record table onto the global-gather path): a 32-KB table, four blocks per CU.  A/B on one box, interleaved (profiles/r05_pick_lds_big_ab.txt): LowpolyRoom
+// 2 418 -> 2 480 Mrays/s fast (+2.5 %), 2 205 -> 2 274 exact (+3.1 %); scenes at or below 384 lights keep the smaller table (C2 loses 5 % at four blocks per CU, above).
+#ifndef LM_PICK_LDS_LIGHTS_BIG
+#define LM_PICK_LDS_LIGHTS_BIG 512u
+#endif
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_RESTIR_WAVES)
+KN(lm_k_pick_primary_lds_big)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount)
+{
+    __shared__ uint2 s_bag[1000];
+    __shared__ uint32_t s_tmp[5];
+    __shared__ float4 s_lights[4 * LM_PICK_LDS_LIGHTS_BIG + 1];
+    lm_pick_primary_body<LmExact, LM_ALL, true>(sc, fr, cur, rc, seed, visCount, s_bag, s_tmp, s_lights);
+}
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, 4)      // 40 KB of LDS per block: four blocks = four waves per SIMD is what fits
+KN(lm_k_pick_primary_fast_lds_big)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount)
+{
+    __shared__ uint2 s_bag[1000];
+    __shared__ uint32_t s_tmp[5];
+    __shared__ float4 s_lights[4 * LM_PICK_LDS_LIGHTS_BIG + 1];
+    lm_pick_primary_body<LmFast, LM_COMMON, true>(sc, fr, cur, rc, seed, visCount, s_bag, s_tmp, s_lights);
+}
 // LM_PICK_PERSIST = N > 0 (round 4): the same kernel as a PERSISTENT grid of N blocks per CU that loops over the tiles, with the light table sized by the launch.  The
 // residency cap of the static table (five blocks per CU, above) is then the grid's size and no longer 24 KB of LDS per block that nobody reads: 8 KB + 64 B per light stay,
 // and the kernels of the other streams (19.5 KB per block of the shading kernels, 17.7 KB of the traversal kernels) find room on the CU while the pick runs.
@@ -2091,6 +2113,7 @@ static void l_fill_bags(hipStream_t s, LmScene sc, LmFrame fr, uint32_t seed, ui
 static void l_pick_primary(hipStream_t s, int tiles, LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount, int fast)
 {
     const bool ldsLights = sc.numLights <= LM_PICK_LDS_LIGHTS && LM_PICK_LDS_LIGHTS > 0u;
+    const bool ldsBig = !ldsLights && LM_PICK_STATIC_LDS && sc.numLights <= LM_PICK_LDS_LIGHTS_BIG && LM_PICK_LDS_LIGHTS_BIG > LM_PICK_LDS_LIGHTS;      // the 32-KB table
     const size_t lightBytes = LM_PICK_STATIC_LDS ? 0u : (size_t)64 * sc.numLights + 16u;         // dynamic LDS of the *_lds kernels
     if (fast) {
         if (ldsLights && LM_PICK_PERSIST > 0) {
@@ -2098,9 +2121,11 @@ static void l_pick_primary(hipStream_t s, int tiles, LmScene sc, LmFrame fr, int
             const unsigned grid = (unsigned)std::min(tiles, cus * (int)LM_PICK_PERSIST);
             hipLaunchKernelGGL(KN(lm_k_pick_primary_fast_lds_persist), dim3(grid), dim3(LM_BLOCK), (size_t)64 * sc.numLights + 16u, s, sc, fr, cur, rc, seed, visCount, (uint32_t)tiles);
         } else if (ldsLights) hipLaunchKernelGGL(KN(lm_k_pick_primary_fast_lds), dim3((unsigned)tiles), dim3(LM_BLOCK), lightBytes, s, sc, fr, cur, rc, seed, visCount);
+        else if (ldsBig) hipLaunchKernelGGL(KN(lm_k_pick_primary_fast_lds_big), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount);
         else hipLaunchKernelGGL(KN(lm_k_pick_primary_fast), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount);
         if (fast > 1) hipLaunchKernelGGL(KN(lm_k_pick_primary_rare), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount);
     } else if (ldsLights) hipLaunchKernelGGL(KN(lm_k_pick_primary_lds), dim3((unsigned)tiles), dim3(LM_BLOCK), lightBytes, s, sc, fr, cur, rc, seed, visCount);
+    else if (ldsBig) hipLaunchKernelGGL(KN(lm_k_pick_primary_lds_big), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount);
     else hipLaunchKernelGGL(KN(lm_k_pick_primary), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount);
 }
 static void l_trace_shade(hipStream_t s, int g, LmScene sc, LmFrame fr, int rc, const uint32_t* cnt, int refillBelow, int pass)
