@@ -6,7 +6,8 @@ tag=${1:-round_end}; R=$PWD; mkdir -p gpurun_out/$tag
 timeout 1800 python -m pytest tests -m gpu -q 2>&1 | tail -5 > gpurun_out/$tag/pytest.log; cat gpurun_out/$tag/pytest.log
 python bench.py > gpurun_out/$tag/bench_c2.json 2> gpurun_out/$tag/bench_c2.err; tail -1 gpurun_out/$tag/bench_c2.json | cut -c1-300
 timeout 900 python bench.py --workload sandbox --steps 32 --warmup 8 > gpurun_out/$tag/bench_sandbox.json 2> gpurun_out/$tag/bench_sandbox.err; tail -1 gpurun_out/$tag/bench_sandbox.json | cut -c1-300
-for w in c2t c3 c4 c5 c1 lowpoly; do
+timeout 900 python bench.py --workload lowpoly --steps 64 --warmup 8 > gpurun_out/$tag/bench_lowpoly.json 2> gpurun_out/$tag/bench_lowpoly.err; tail -1 gpurun_out/$tag/bench_lowpoly.json | cut -c1-300
+for w in c2t c3 c4 c5 c1; do
   timeout 900 python bench.py --workload $w --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/$tag/bench_$w.json 2> gpurun_out/$tag/bench_$w.err
   python3 - "$w" "gpurun_out/$tag/bench_$w.json" <<'PY'
 import json,sys
