@@ -1,6 +1,7 @@
 // frame.cpp — frame buffers and the frame graph of one TraceFrame (streams, events, cross-frame pipelining).
 // Follows WaveFrontRenderer::TraceFrame (WaveFrontRenderer.cpp:435-1089) for order of operations, seed evolution and counters,
 // but enqueues the whole frame without host round trips (the reference synchronises ~40 times per frame).
+#include <cmath>
 #include "renderer_state.h"
 
 namespace lmr {
@@ -258,7 +259,17 @@ int traceFrameAsync(R* r)
     // round 3 (the temporal pass got cheaper, the wave chain is the longer one by more): 100 000 in fast mode on large windows, i.e. on C2 the wave of 92 k rays joins the
     // tail: +1.8 % (C2), +4.2 % (textured C2), +-0 (C4, C5), -0.9 % (C3), five / three interleaved runs each on one box; exact mode keeps 16 384 (65 536: -1.2 %,
     // 120 000: -2.9 %) — profiles/r03_knobs_ab.txt
-    const uint32_t tailBelow = r->tailBelow >= 0 ? (uint32_t)r->tailBelow : (fr.n < (1u << 20) ? 65536u : r->fastResample ? 100000u : 16384u);
+    // round 5: on small windows the threshold also follows the TREE.  A wave that stays on the queue kernels costs the critical chain three launches of about T0 each, and
+    // T0 is the dependent chain of the longest ray — it grows with the depth of the tree; what it saves is the time the same paths would spend in the tail at ~9 of 64
+    // lanes.  720p, fast mode, interleaved on one box (profiles/r05_tail_threshold_ab.txt): the stand-in atrium (262 k triangles; waves 198 k / 54 k / 19 k) loses 11 % when
+    // the 54 k wave leaves the tail (threshold 32 768), the reference's default model (LowpolyRoom, 20.5 k triangles; waves 297 k / 55 k / 10 k) GAINS 4.3 % from exactly
+    // that.  Rule: 65 536 scaled by (log2(triangles) - 10) / 8, clamped to [1/4, 1] — 1 for the atrium (35 k would be wrong there), 0.54 for the room (35 k: the 55 k
+    // wave runs on the queue kernels, the 10 k wave joins the tail).
+    const double lt = std::log2((double)std::max<size_t>(2, r->triEntry.size()));
+    // Exact mode: the ReSTIR chain is the longer one and the wave chain has slack, as on large windows — half the threshold (the atrium at 720p, exact: 32 768 against
+    // 65 536 = +8.0 %, the 54 k wave stays on the queue kernels; the room is indifferent between 16 384 and 32 768).
+    const uint32_t smallWindow = (uint32_t)((r->fastResample ? 65536.0 : 32768.0) * std::min(1.0, std::max(0.25, (lt - 10.0) / 8.0)));
+    const uint32_t tailBelow = r->tailBelow >= 0 ? (uint32_t)r->tailBelow : (fr.n < (1u << 20) ? smallWindow : r->fastResample ? 100000u : 16384u);
     if (tailBelow && r->haveEst) for (uint32_t dd = 1; dd < depthMax; dd++) if (r->estRays[dd] < tailBelow) { tailDepth = (int)dd; break; }
     int q = 0;
     size_t ev;
