@@ -33,6 +33,8 @@ int ensureFrameBuffers(R* r)
     for (int i = 0; i < 3; i++) bad |= r->dGbuf[i].ensure((size_t)8 * n) | r->dProbe[i].ensure(n);
     for (int i = 0; i < 2; i++) bad |= r->dMotion[i].ensure(n);
     bad |= r->dReuseMask.ensure(n) | r->dHazard[0].ensure(n) | r->dHazard[1].ensure(n);
+    const size_t nTiles = (size_t)((ww + 15u) / 16u) * ((wh + 15u) / 16u);
+    for (int i = 0; i < 3; i++) bad |= r->dRareTile[i].ensure(nTiles);
     for (int i = 0; i < 5; i++) bad |= r->dRes[i].ensure((size_t)4 * n) | r->dResC[i].ensure(n);
     for (int i = 0; i < 2; i++) bad |= r->dDirect[i].ensure(n) | r->dIndirect[i].ensure(n);
     bad |= r->dCombined.ensure(n) | r->dHits[0].ensure(n) | r->dHits[1].ensure(n) | r->dOutput.ensure(n);
@@ -47,6 +49,7 @@ int ensureFrameBuffers(R* r)
     for (int i = 0; i < 3; i++) { f.gbuf[i] = r->dGbuf[i].p; f.probe[i] = r->dProbe[i].p; }
     for (int i = 0; i < 5; i++) { f.res[i] = r->dRes[i].p; f.resC[i] = r->dResC[i].p; }
     f.reuseMask = r->dReuseMask.p;
+    for (int i = 0; i < 3; i++) f.rareTile[i] = r->dRareTile[i].p;
     f.motion = r->dMotion[0].p; f.direct = r->dDirect[0].p; f.indirect = r->dIndirect[0].p; f.combined = r->dCombined.p; f.output = r->dOutput.p;
     f.counters = r->dCounters.p; f.bags = r->dBags.p;
     // ResizeBuffers (WaveFrontRenderer.cpp:1424-1540): history is dropped; reservoirs reset (ReSTIRKernels.cu:36-47)
@@ -54,6 +57,7 @@ int ensureFrameBuffers(R* r)
     for (int i = 0; i < 3; i++) if (hipMemsetAsync(f.gbuf[i], 0, (size_t)8 * n * sizeof(float4), st) != hipSuccess || hipMemsetAsync(f.probe[i], 0, (size_t)n * sizeof(float4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
     for (int i = 0; i < 5; i++) if (hipMemsetAsync(f.res[i], 0, (size_t)4 * n * sizeof(float4), st) != hipSuccess || hipMemsetAsync(f.resC[i], 0, (size_t)n * sizeof(float4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
     if (hipMemsetAsync(f.combined, 0, (size_t)n * sizeof(float4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
+    for (int i = 0; i < 3; i++) if (hipMemsetAsync(f.rareTile[i], 0, nTiles * sizeof(uint32_t), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
     if (hipMemsetAsync(f.output, 0, (size_t)n * sizeof(uchar4), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "memset failed");
     r->fenceNeeded = 2;
     r->haveEst = false; r->cntPending[0] = r->cntPending[1] = false;
@@ -232,6 +236,9 @@ int traceFrameAsync(R* r)
 #if !LM_PRIMARY_CLEARS
     LM_HIP(hipMemsetAsync(fr.counters, 0, LM_CNT_WORDS * sizeof(uint32_t), sx));
 #endif
+    // the map of tiles that need the exact launch of the fast ReSTIR passes, of the G-buffer set this frame's extraction fills (its last readers belonged to the frame
+    // three back, which the wait for evMerge above has seen end).  Only scenes with a material outside the contracted evaluation ever read it.
+    if (fastRs == 2) LM_HIP(hipMemsetAsync(fr.rareTile[currentIndex], 0, (size_t)((fr.ww + 15u) / 16u) * ((fr.wh + 15u) / 16u) * sizeof(uint32_t), sx));
     if (!blend) { Z(st); K->clear(st, r->gridFor(fr.n, 8), fr.combined, fr.n); }                        // :559
     ++r->frameCount;                                                                          // :593
     // the packet kernel of the primary wave generates its rays itself (kernels.hip lm_k_trace_primary_packet); the counting build traces per lane, from the plane

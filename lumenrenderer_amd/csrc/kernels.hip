@@ -302,7 +302,12 @@ KN(lm_k_extract0)(LmScene sc, LmFrame fr, LmCamera cam, int cur, uint32_t seed2,
         // does any surface of the frame need the second (exact) launch of the fast ReSTIR passes?  A FLAG, not a count: one plain store per
         // wavefront that sees such a surface (an atomic per wavefront on one address is ~ 88 per microsecond: 0.65 ms at 1440p in a scene of
         // glass or clear coat, on the critical wave chain, in every mode)
-        if (__ballot(!s.flags && !lm_quick_contracts(s.mat)) != 0ull && lm_lane() == 0u) fr.counters[LM_CNT_RARE] = 1u;
+        const bool rareSurface = !s.flags && !lm_quick_contracts(s.mat);
+        if (__ballot(rareSurface) != 0ull && lm_lane() == 0u) fr.counters[LM_CNT_RARE] = 1u;
+        if (rareSurface && fr.rareTile[cur]) {                      // ... and WHERE: the pixel's 16 x 16 tile of the window (lm_rare_near)
+            const uint32_t ry = li / fr.ww, rx = li - ry * fr.ww;
+            fr.rareTile[cur][(ry >> 4) * ((fr.ww + 15u) >> 4) + (rx >> 4)] = 1u;
+        }
         // lazy reuse: the previous frame left its history passes pending.  Pixels that were reuse surfaces then and are flagged now keep their reservoir entry
         // past this frame's candidate pick: listed for lm_k_reuse_counts (silhouette pixels under sub-pixel jitter; more when the camera moves)
         // (appended below, with the continuation rays: one atomic per block, not per wavefront — a camera cut can flag every pixel)
@@ -710,6 +715,25 @@ __device__ __forceinline__ bool lm_reuse_turned(const LmFrame& fr) { return (fr.
 __device__ __forceinline__ bool lm_reuse_owed(const LmFrame& fr) { return fr.swap[5] == 0 && lm_reuse_turned(fr); }
 // does a ReSTIR pass of the fast mode's second (exact) launch have anything to do?  (The deferred passes belong to the previous frame: its flag was
 // parked in swap[7] by that frame's merge, its counter block may already belong to the frame after this one.)
+// Fast mode, second (exact) launch of a ReSTIR pass: does the window-local pixel rectangle [x0, x1] x [y0, y1] touch a tile in which the extraction of G-buffer set `cur` saw a
+// surface outside the contracted evaluation?  Block-uniform (contains a barrier: every thread of the block calls it, all return the same).  Before round 5 every block of
+// the second launch loaded each pixel's 128-byte surface record to learn that it had nothing to do: 4 launches x 30 - 40 us per 720p TraceFrame of the reference's default
+// model for the 0.08 % of its surfaces that are glass, and ~ 0.4 ms at 1440p for a single such pixel.
+__device__ __forceinline__ bool lm_rare_near(const LmFrame& fr, int cur, int x0, int y0, int x1, int y1)
+{
+#ifndef LM_RARE_TILES
+#define LM_RARE_TILES 1            // 0: A/B switch, every block of the second launch looks at its pixels (profiles/r05_rare_tiles_ab.txt)
+#endif
+    const uint32_t* __restrict__ map = fr.rareTile[cur];
+    if (!LM_RARE_TILES || !map) return true;
+    const int tilesX = (int)((fr.ww + 15u) >> 4), tilesY = (int)((fr.wh + 15u) >> 4);
+    const int tx0 = max(x0, 0) >> 4, ty0 = max(y0, 0) >> 4, tx1 = min(x1 >> 4, tilesX - 1), ty1 = min(y1 >> 4, tilesY - 1);
+    const int nx = tx1 - tx0 + 1, ny = ty1 - ty0 + 1;
+    int any = 0;
+    if (x1 >= 0 && y1 >= 0 && nx > 0 && ny > 0)
+        for (int k = (int)threadIdx.x; k < nx * ny; k += (int)blockDim.x) any |= (int)map[(ty0 + k / nx) * tilesX + tx0 + k % nx];
+    return __syncthreads_or(any) != 0;
+}
 __device__ __forceinline__ bool lm_no_rare(const LmFrame& fr) { return (fr.deferred ? (uint32_t)fr.swap[7] : fr.counters[LM_CNT_RARE]) == 0u; }
 // settle kernel of the between-frames flush (history export / import): the passes above ran iff the chain had turned
 extern "C" __global__ void KN(lm_k_reuse_settle)(LmFrame fr)
@@ -821,6 +845,10 @@ __device__ __forceinline__ void lm_pick_primary_body(const LmScene& sc, const Lm
     const uint32_t tx0 = fr.x0 / 16u, ty0 = fr.y0 / 16u;
     const uint32_t wtx = (fr.x0 + fr.ww + 15u) / 16u - tx0;
     const uint32_t tileX = tx0 + vb % wtx, tileY = ty0 + vb / wtx;
+    if constexpr (ROLE == LM_RARE) {                                // this block's pixels (a tile of the GLOBAL grid) in window-local coordinates
+        const int bx = (int)(tileX * 16u) - (int)fr.x0, by = (int)(tileY * 16u) - (int)fr.y0;
+        if (!lm_rare_near(fr, cur, bx, by, bx + 15, by + 15)) return;
+    }
     uint32_t bagSeed = lm_wang_hash(seed + (tileY * tilesX + tileX));
     const float rb = lm_random_float(bagSeed);
     const int bagIndex = (int)roundf((float)(50 - 1) * rb);
@@ -1004,6 +1032,10 @@ __device__ __forceinline__ void lm_restir_temporal_body(const LmFrame& fr, int c
     rc = lm_res_idx(fr, rc);
     rp = lm_res_idx(fr, rp);
     rf = lm_res_idx(fr, rf);
+    if constexpr (ROLE == LM_RARE) {                                // the role follows the pixel's own current surface
+        uint32_t ttx, tty; lm_tile_origin(fr, ttx, tty);
+        if (!lm_rare_near(fr, cur, (int)(ttx << 4), (int)(tty << 4), (int)(ttx << 4) + 15, (int)(tty << 4) + 15)) return;
+    }
     uint32_t li = 0, gi = 0;
     const bool valid = lm_tile_pixel(fr, li, gi);
     bool shoot = false;
@@ -1169,6 +1201,10 @@ __device__ __forceinline__ void lm_restir_spatial_body(const LmFrame& fr, int cu
     if (ROLE == LM_RARE && lm_no_rare(fr)) return;
     rin = lm_res_idx(fr, rin);
     rout = lm_res_idx(fr, rout);
+    if constexpr (ROLE == LM_RARE) {                                // the role follows the FIRST accepted neighbour's surface: anywhere within the 30-pixel reach of the draw
+        uint32_t ttx, tty; lm_tile_origin<LOG_TS>(fr, ttx, tty, vb);
+        if (!lm_rare_near(fr, cur, (int)(ttx << LOG_TS) - 30, (int)(tty << LOG_TS) - 30, (int)(ttx << LOG_TS) + (1 << LOG_TS) + 29, (int)(tty << LOG_TS) + (1 << LOG_TS) + 29)) return;
+    }
 #ifdef LM_SPATIAL_PRIO
     __builtin_amdgcn_s_setprio(LM_SPATIAL_PRIO);
 #endif
@@ -1307,6 +1343,10 @@ __device__ __forceinline__ void lm_restir_combine_body(const LmFrame& fr, int cu
     if (ROLE == LM_RARE && lm_no_rare(fr)) return;
     rc = lm_res_idx(fr, rc);
     rs = lm_res_idx(fr, rs);
+    if constexpr (ROLE == LM_RARE) {                                // the role follows the pixel's own current surface
+        uint32_t ttx, tty; lm_tile_origin(fr, ttx, tty, vb);
+        if (!lm_rare_near(fr, cur, (int)(ttx << 4), (int)(tty << 4), (int)(ttx << 4) + 15, (int)(tty << 4) + 15)) return;
+    }
     uint32_t li = 0, gi = 0;
     if (!lm_tile_pixel(fr, li, gi, vb)) return;
     if (!lm_owned(fr, li, 0)) return;

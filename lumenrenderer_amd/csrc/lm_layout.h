@@ -125,6 +125,9 @@ struct LmFrame {
     // (current, previous, and the one the NEXT frame's extraction already fills while this frame's temporal pass still reads)
     float4* gbuf[3];
     float4* probe[3];
+    uint32_t* rareTile[3];      // fast ReSTIR mode, per G-buffer set: one word per 16 x 16 pixel tile of the WINDOW (row-major, (ww + 15) / 16 per row), non-zero when the tile holds a depth-0
+                                // surface outside the contracted evaluation (written by the extraction, cleared at the frame's start): the second, exact launch of every ReSTIR pass leaves
+                                // blocks whose neighbourhood holds none at once instead of loading every pixel's surface to find that out.  NULL = not tracked (every block looks)
     uint32_t* reuseMask;        // per pixel: which of its five spatial-reuse candidates passed the similarity test (bits 0..4), or LM_REUSE_FLAGGED; written
                                 // by the first spatial pass, read by the second (both draw the same candidates: the reference passes one seed to both)
     // reservoirs, 5 buffers (the reference's two swap-chain and two spatial buffers + [4], fresh candidates when candidate

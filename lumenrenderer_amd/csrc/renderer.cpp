@@ -117,7 +117,7 @@ int lumen_mi_destroy(lumen_mi_renderer* r)
         for (auto& b : r->dResC) b.release();
         for (auto& b : r->dMotion) b.release();
         for (int i = 0; i < 2; i++) { r->dDirect[i].release(); r->dIndirect[i].release(); }
-        r->dReuseMask.release(); r->dHazard[0].release(); r->dHazard[1].release();
+        r->dReuseMask.release(); r->dHazard[0].release(); r->dHazard[1].release(); for (auto& b : r->dRareTile) b.release();
         r->dSortBins.release(); r->dExportHalf.release(); r->dTotals.release(); r->dCombined.release(); for (auto& b : r->dHits) b.release(); r->dCounters.release(); r->dSwap.release(); r->dOutput.release(); r->dBags.release();
         for (auto& e : r->evPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     }

@@ -259,7 +259,7 @@ struct lumen_mi_renderer {
     hipEvent_t evTail = nullptr, evScene = nullptr;
     DevBuf<float4> dRay[12], dSh[6], dSh2[4];      // ray queues and the NEE shadow queue once per frame parity (two wave streams: consecutive frames trace concurrently)
     DevBuf<float4> dGbuf[3], dProbe[3], dRes[5], dResC[5], dDirect[2], dIndirect[2], dCombined;
-    DevBuf<uint4> dHits[2]; DevBuf<uint32_t> dMotion[2], dCounters, dReuseMask; DevBuf<uchar4> dOutput; DevBuf<uint2> dBags;
+    DevBuf<uint4> dHits[2]; DevBuf<uint32_t> dMotion[2], dCounters, dReuseMask, dRareTile[3]; DevBuf<uchar4> dOutput; DevBuf<uint2> dBags;
     DevBuf<uint2> dExportHalf;                          // lumen_mi_get_radiance_half4
     DevBuf<unsigned long long> dTotals;                 // LmFrame::totals
     uint32_t hostCounters[LM_CNT_WORDS] = {0};
