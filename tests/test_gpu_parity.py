@@ -611,6 +611,55 @@ def _compare_frames(r, o, frames, check_gbuffer=True):
         assert np.array_equal(g.view(np.uint32), og.view(np.uint32))
 
 
+def test_tile_copy_entry_points_move_exactly_the_rectangle_and_refuse_bad_ones():
+    """lumen_mi_copy_radiance_rect_device / lumen_mi_copy_rect_device (the tile gather's frame path, kernel lm_k_copy_rect): an image rectangle of the merged radiance lands in
+    a pitched device image bit for bit and nothing around it is touched; a pitched rectangle moves between two device images; rectangles outside the render window, pitches
+    smaller than the rectangle and NULL pointers come back as status 1 with a message; a window-relative renderer takes IMAGE coordinates."""
+    import torch
+    from lumenrenderer_amd.capi import LumenMIError
+    d = cornell()
+    for window in (None, (8, 4, 72, 52)):
+        r = product_from(d, 96, 64, 3, window=window)
+        r.set_stream(torch.cuda.current_stream().cuda_stream)
+        with pytest.raises(LumenMIError) as e:                              # before any frame: nothing to copy
+            r.CopyRadianceRectToDevice((0, 0, 8, 8), torch.zeros(64 * 4, device="cuda").data_ptr(), 8)
+        assert e.value.code == 3
+        assert r.TraceFrame()
+        rad = r.GetRadiance()                                               # window-shaped
+        x0, y0 = (window[0], window[1]) if window else (0, 0)
+        rect = (x0 + 5, y0 + 3, x0 + 37, y0 + 30)                            # image coordinates
+        pitch = 40
+        dst = torch.full((40, pitch, 4), -7.0, dtype=torch.float32, device="cuda")
+        r.CopyRadianceRectToDevice(rect, dst[2, 3].data_ptr(), pitch)       # the rectangle's first pixel sits at row 2, column 3 of the destination
+        torch.cuda.synchronize()
+        got = dst.cpu().numpy()
+        w, h = rect[2] - rect[0], rect[3] - rect[1]
+        want = rad[rect[1] - y0: rect[3] - y0, rect[0] - x0: rect[2] - x0]
+        assert np.array_equal(got[2:2 + h, 3:3 + w].view(np.uint32), want.view(np.uint32))
+        mask = np.ones(got.shape[:2], bool); mask[2:2 + h, 3:3 + w] = False
+        assert (got[mask] == -7.0).all()                                    # nothing outside the rectangle was written
+        img = torch.zeros((50, 64, 4), dtype=torch.float32, device="cuda")
+        r.CopyRectDevice(img[10, 20].data_ptr(), 64, dst[2, 3].data_ptr(), pitch, w, h)
+        torch.cuda.synchronize()
+        moved = img.cpu().numpy()
+        assert np.array_equal(moved[10:10 + h, 20:20 + w].view(np.uint32), want.view(np.uint32))
+        moved[10:10 + h, 20:20 + w] = 0.0
+        assert not moved.any()
+        for bad in ((rect[0], rect[1], rect[0], rect[3]), (x0 + 60, y0 + 10, x0 + 200, y0 + 20), (90, 60, 100, 70)):      # empty; past the window's right edge; past the image
+            with pytest.raises(LumenMIError) as e:
+                r.CopyRadianceRectToDevice(bad, dst.data_ptr(), pitch)
+            assert e.value.code == 1 and "rectangle" in str(e.value)
+        with pytest.raises(LumenMIError) as e:
+            r.CopyRadianceRectToDevice(rect, dst.data_ptr(), w - 1)
+        assert e.value.code == 1 and "pitch" in str(e.value)
+        with pytest.raises(LumenMIError):
+            r.CopyRectDevice(0, 64, dst.data_ptr(), pitch, w, h)
+        with pytest.raises(LumenMIError):
+            r.CopyRectDevice(img.data_ptr(), 4, dst.data_ptr(), pitch, w, h)
+        assert r.TraceFrame()                                               # the renderer is still usable
+        r.close()
+
+
 def test_cornell_c1_frame_bit_exact():
     """BASELINE config C1: Cornell box 256x256, 1 path/pixel, depth 2."""
     d = cornell()
