@@ -110,8 +110,18 @@ def compose(parent, local):
     return out
 
 
+# material extensions this reader maps onto MaterialData (LumenPTModelConverter.cpp:336-560); anything else a file REQUIRES cannot be honoured
+_SUPPORTED_EXTENSIONS = {"KHR_materials_transmission", "KHR_materials_sheen", "KHR_materials_ior", "KHR_materials_clearcoat", "KHR_materials_specular"}
+
+
 def load_gltf(path, image_loader=None):
     doc, glb_blob = _read_container(path)
+    # glTF 2.0, 3.12: a loader that does not implement an extension listed in extensionsRequired must fail.  The reference's sample set has such a file
+    # (Buggy/glTF-Draco: KHR_draco_mesh_compression — its accessors have no buffer views, so reading it "as zeros" yields 532 k degenerate triangles); the reference's
+    # own loader (fx-gltf, no Draco decoder) cannot show that model either.
+    unsupported = sorted(set(doc.get("extensionsRequired", [])) - _SUPPORTED_EXTENSIONS)
+    if unsupported:
+        raise ValueError(f"{os.path.basename(path)} requires glTF extension(s) this reader does not implement: {', '.join(unsupported)}")
     base = os.path.dirname(path)
     if image_loader is None:
         try:

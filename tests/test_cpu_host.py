@@ -207,6 +207,23 @@ dist.destroy_process_group()
 '''
 
 
+def test_gltf_reader_refuses_a_file_that_requires_an_extension_it_does_not_implement(tmp_path):
+    """glTF 2.0 (3.12): extensionsRequired the loader cannot honour = fail, by name — not a silent read of missing buffer views as zeros (the reference's Buggy/glTF-Draco
+    sample would otherwise ingest as 532 k degenerate triangles).  Extensions the reader maps onto MaterialData pass."""
+    from lumenrenderer_amd.gltf import load_gltf
+    doc = {"asset": {"version": "2.0"}, "extensionsRequired": ["KHR_draco_mesh_compression"], "extensionsUsed": ["KHR_draco_mesh_compression"], "scenes": [{"nodes": []}], "nodes": []}
+    p = tmp_path / "draco.gltf"; p.write_text(json.dumps(doc))
+    with pytest.raises(ValueError, match="KHR_draco_mesh_compression"):
+        load_gltf(str(p))
+    doc["extensionsRequired"] = ["KHR_materials_transmission"]
+    p.write_text(json.dumps(doc))
+    assert load_gltf(str(p)).triangle_count() == 0
+    real = os.path.join(REF_MODELS, "Buggy/glTF-Draco/Buggy.gltf") if "REF_MODELS" in globals() else ""
+    if real and os.path.exists(real):
+        with pytest.raises(ValueError, match="KHR_draco_mesh_compression"):
+            load_gltf(real)
+
+
 def test_two_rank_tile_gather_gloo(tmp_path):
     script = tmp_path / "worker.py"; script.write_text(_WORKER)
     out = tmp_path / "img.npy"
@@ -222,7 +239,7 @@ REF_MODELS = "/root/reference/Lumen_Engine/Sandbox/assets/models"
 REF_ASSETS = ["CornellBox/scene.gltf", "cube/Cube.gltf", "Lantern.gltf", "EmissiveSphere/EmissiveSphere.gltf", "BoomBox/glTF/BoomBox.gltf",
               "BarramundiFish/glTF/BarramundiFish.gltf", "CesiumMilkTruck/glTF/CesiumMilkTruck.gltf",
               "CesiumMilkTruck/glTF-Embedded/CesiumMilkTruck.gltf", "CesiumMilkTruck/glTF-Binary/CesiumMilkTruck.glb", "box/box.glb",
-              "Glass/scene.gltf", "LowpolyRoom/scene.glb"]
+              "Glass/scene.gltf", "LowpolyRoom/scene.glb", "BoomBoxWithAxes/glTF/BoomBoxWithAxes.gltf"]
 
 
 @pytest.mark.parametrize("asset", REF_ASSETS)
