@@ -114,3 +114,27 @@ def test_lowpoly_room_through_the_adapters_ollad_path(tmp_path):
     assert got.endswith(want), sum(a != b for a, b in zip(got[-len(want):], want))
     assert o.stats(4)[3] == 414
     o.close()
+
+
+def test_fast_mode_window_over_glass_equals_the_full_frame_inside_the_halo():
+    """The fast ReSTIR mode's second (exact) launch finds its pixels through the tile map the extraction writes (LmFrame::rareTile, lm_rare_near) — in WINDOW-local tiles, while the
+    candidate pick runs on tiles of the global 16 x 16 grid.  An unaligned render window over the room's glass object (pose 40: 759 glass pixels at 640 x 360) must give, inside
+    the reach of its halo, exactly the full frame's pixels: frame 1 from 60 pixels inside the window (two spatial passes x 30), frame 2 from 120 (its temporal pass reads frame 1)."""
+    from lumenrenderer_amd.scenes import lowpoly_camera_pose
+    W, H, D = 640, 360, 5
+    win = (37, 19, 437, 319)
+    d = _scene()
+    pose = lowpoly_camera_pose(d, 40)
+    full = product_from(d, W, H, D, blend=False, tuning={"fast_resample": 1})
+    part = product_from(d, W, H, D, blend=False, window=win, tuning={"fast_resample": 1})
+    full.SetCamera(*pose); part.SetCamera(*pose)
+    for frame, margin in ((1, 60), (2, 120)):
+        assert full.TraceFrame() and part.TraceFrame()
+        y0, y1, x0, x1 = win[1] + margin, win[3] - margin, win[0] + margin, win[2] - margin
+        for get in (lambda r: r.GetRadiance(), lambda r: r.GetChannel(0)):
+            a = get(full)[y0:y1, x0:x1]; b = get(part)[margin:-margin, margin:-margin]
+            assert a.shape == b.shape and np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32)), (frame, int(np.sum(a != b)))
+        g = full.GetGBuffer()[y0:y1, x0:x1]
+        glass = (g[..., 1, 3].copy().view(np.uint32) == 0) & (((g[..., 7, 2].copy().view(np.uint32) >> 16) & 0xff) != 0)
+        assert glass.sum() > (300 if frame == 1 else 50), (frame, int(glass.sum()))       # the compared region does hold surfaces of the second launch
+    full.close(); part.close()
