@@ -1057,10 +1057,12 @@ def test_kernel_timing_classes_and_modes():
     r.close()
 
 
-@pytest.mark.parametrize("fixture", ["ref_cube_textured.npz", "ref_milk_truck.npz"])
+@pytest.mark.parametrize("fixture", ["ref_cube_textured.npz", "ref_milk_truck.npz", "ref_emissive_sphere.npz", "ref_box.npz", "ref_glass.npz"])
 def test_reference_sample_assets_match_oracle(fixture):
-    """Two of the reference's own textured sample models (ingested in the build container by tests/golden/
-    make_textured_fixture.py: 512x512 / 2048x2048 PNG textures, node hierarchy, several materials), lit by a quad light."""
+    """Five of the reference's own sample models, geometry AND texels (ingested in the build container by tests/golden/make_textured_fixture.py): the textured cube (two 512 x 512
+    maps), the Cesium milk truck (2048 x 2048 map, node hierarchy, several materials), EmissiveSphere (an emissive MATERIAL on a real mesh: 1 472 triangle lights out of FindEmissives),
+    box.glb (eight materials), Glass/scene.gltf (77 124 triangles, alpha-blended materials — camera and indirect rays pass through them, shadow rays do not —, an emissive
+    material worth 15 359 triangle lights: the candidate pick's global-gather path, a 14-level CDF search in the NEE).  Lit by a quad light on top of whatever they emit."""
     from lumenrenderer_amd.scenes import scene_from_npz, interleave
     d = scene_from_npz(os.path.join(GOLDEN, fixture))
     lo = np.full(3, np.inf); hi = np.full(3, -np.inf)
