@@ -83,6 +83,24 @@ def test_product_sources_never_touch_the_oracle():
     assert "oracle" not in src
 
 
+def test_product_package_imports_nothing_from_tests_and_the_process_tests_sort_last():
+    """Round 5: the gloo-through-host shim of the one-GPU rehearsals lives under tests/ (host_staged_dist.py), not in the product package; and the multi-process GPU tests sit
+    in the file that pytest collects LAST, so that `-x` cannot stop in front of the parity tests again (GPUTEST_r04: 15 tests never ran behind a failed rehearsal)."""
+    import re
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "lumenrenderer_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "HostStagedDist" not in text and not re.search(r"^\s*(from|import)\s+(helpers|oracle_lib|host_staged_dist|kat5|kat6|tex_rule)\b", text, re.M), (dirpath, f)
+    names = sorted(f for f in os.listdir(os.path.join(ROOT, "tests")) if f.startswith("test_") and f.endswith(".py"))
+    assert names[-1] == "test_zz_multiprocess.py", names
+    multi = open(os.path.join(ROOT, "tests", "test_zz_multiprocess.py")).read()
+    for other in names[:-1]:
+        body = open(os.path.join(ROOT, "tests", other)).read()
+        assert "torch.distributed.run" not in body or "gpu" not in re.findall(r"pytestmark\s*=\s*pytest\.mark\.(\w+)", body), other      # GPU files launch no ranks
+    assert multi.count("--log-dir") >= 1 and "_rank_logs" in multi                         # every launcher keeps per-rank logs
+
+
 def test_cornell_fixture_is_the_reference_asset():
     d = cornell()
     assert d.triangle_count() == 32 and len(d.primitives) == 8 and len(d.materials) == 8
