@@ -182,6 +182,19 @@ def camera_pose(desc, k):
     return scenes.sandbox_camera_pose(desc, k if k < 32 else 64 - k)
 
 
+def cpu_model():
+    """Model string of the host CPU (BASELINE.md §3 asks for model + nproc + threads beside every CPU number)."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
 def cpu_baseline(kind, kw, depth, spp, full, moving=False):
     """The CPU oracle ("port") timed on this box's host cores on a bounded sample of the same workload: the same scene,
     `spp` blended frames, at the largest of a few resolutions expected to need <= ~25 s (probed at 480x270 first).
@@ -216,7 +229,7 @@ def cpu_baseline(kind, kw, depth, spp, full, moving=False):
             w, h = cw, ch
             rays, dt = run(w, h)
             break
-    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "threads": cores, "cpu_model": cpu_model(), "nproc": os.cpu_count(), "kind": "port",
             "sample": (f"{w}x{h} x {frames} TraceFrames at consecutive camera poses, blending off" if moving else f"{w}x{h} x {spp} blended frames") +
                       f", depth {depth}, same scene: {dt:.1f} s, {rays} rays, {dt * 1e3 / (frames if moving else 1):.0f} ms/frame"}
 
@@ -242,6 +255,9 @@ def main():
                          "auto = only for path depths that have temporal history (odd number of waves per frame)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: no HIP events around the kernels in the timed region (the roofline "
                     "entry then has no live launch time)")
+    ap.add_argument("--transport", choices=["native", "torch"], default=os.environ.get("LUMEN_BENCH_TRANSPORT", "native"),
+                    help="multi-GPU: native = the tile group of the C ABI (csrc/group.cpp: plan, seam exchange and the double-buffered gather in C++, RCCL resolved by the library; "
+                         "torch.distributed over gloo only carries the communicator id, the barriers and the statistics); torch = rounds 1 - 5: tiles.py over torch.distributed (backend nccl)")
     ap.add_argument("--dry-launch", action="store_true", help="with --gpus N > 1 and no launcher environment: print the child command as JSON and exit")
     ap.add_argument("--emulate-rank", default="", help="R/N: on ONE GPU render only rank R's window of an N-GPU tile grid (no gather); "
                     "design aid for the per-rank time of the tiled path, never the reported benchmark line")
@@ -281,6 +297,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         warm = torch.zeros(1, device=dev); dist.all_reduce(warm); torch.cuda.synchronize()
+    if world > 1 and "LUMEN_MI_BUILD_THREADS" not in os.environ:          # N ranks build the same tree at the same time on one host: share its cores
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        try:
+            from oracle_lib import usable_cpus
+            os.environ["LUMEN_MI_BUILD_THREADS"] = str(max(1, usable_cpus() // world))
+        except Exception:
+            os.environ["LUMEN_MI_BUILD_THREADS"] = str(max(1, (os.cpu_count() or world) // world))
+    native = args.transport == "native" and world > 1
     kind, kw, W, H, depth, spp = WORKLOADS[args.workload]
     moving = args.workload in MOVING
     blend_on = not moving
@@ -294,17 +318,51 @@ def main():
         raise SystemExit("--emulate-rank is a single-GPU design aid")
     tile = tiles.tile_rect(*emu, W, H) if emu else tiles.tile_rect(rank, world, W, H)
     win = tiles.window_rect(tile, W, H) if (world > 1 or emu) else (0, 0, W, H)
-    r.SetWindow(*win)
-    if world > 1 or emu:
-        r.SetTile(*tile)                                  # halo pixels only get the work the tile's ReSTIR reuse needs
+    if not native:                                        # (the native group sets window and tile itself when it is created, below)
+        r.SetWindow(*win)
+        if world > 1 or emu:
+            r.SetTile(*tile)                              # halo pixels only get the work the tile's ReSTIR reuse needs
     wh, ww = win[3] - win[1], win[2] - win[0]
     emu_tile_buf = torch.empty((tile[3] - tile[1], tile[2] - tile[0], 4), dtype=torch.float32, device=dev) if emu else None
     # The renderer's four streams are created and used once BEFORE the RCCL communicator brings its own stream: HIP maps
     # streams onto 4 hardware queues, and two busy streams that end up sharing one serialise (measured -11 % at N = 1 with an
     # idle fifth stream created first).  RCCL's stream only works between frames, when the renderer's streams are idle.
     r.SetBlendMode(blend_on)
+    if native:
+        r.SetWindow(*win); r.SetTile(*tile)              # the first frame (streams, buffers) at the size the group will render
     r.TraceFrame()
     force_pg = os.environ.get("LUMEN_BENCH_FORCE_PG", "")          # A/B aid: "before" / "after" create a 1-rank communicator at N = 1
+    grp = None
+    if native:
+        # ---- the native tile group: torch.distributed (gloo, CPU) hands rank 0's communicator id round, synchronises the timed region and collects the statistics;
+        # every byte of the frame path moves through csrc/group.cpp (RCCL, or — rehearsal on one GPU — a host transport over the same gloo group)
+        import threading
+        from lumenrenderer_amd import group as lm_group
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        import datetime
+        limit = int(os.environ.get("LUMEN_BENCH_RCCL_TIMEOUT_S", "300"))
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=limit))
+        state = {"stage": "communicator id"}
+
+        def watchdog():                                   # RCCL has no timeout of its own: a rank that cannot reach its peers says so and ends the run instead of hanging it
+            sys.stderr.write(f"bench.py rank {rank} of {world} ({my_dev_early}): native tile group stuck in '{state['stage']}' for {limit} s — peers unreachable? "
+                             f"(HSA_ENABLE_IPC_MODE_LEGACY=0 exported? every rank on its own GPU? LUMEN_BENCH_TRANSPORT=torch selects the torch.distributed path)\n")
+            sys.stderr.flush()
+            os._exit(3)
+        my_dev_early = f"cuda:{local_rank}"
+        timer = threading.Timer(limit, watchdog); timer.daemon = True; timer.start()
+        if one_gpu:
+            transport, gid = lm_group.DistHostTransport(dist), None
+        else:
+            box = [lm_group.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            transport, gid = None, box[0]
+        state["stage"] = "communicator creation"
+        grp = lm_group.TileGroup(r, rank, world, group_id=gid, transport=transport)
+        assert grp.tile == tuple(tile) and grp.window == tuple(win), (grp.tile, tile, grp.window, win)
+        state["stage"] = "self-test (all-reduce on both communicators + a full-size gather)"
+        self_test_ms = grp.SelfTest()
+        timer.cancel()
     if (world > 1 or force_pg) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         if one_gpu:
@@ -325,7 +383,7 @@ def main():
     # temporal history across tile seams: only a path depth with an odd number of waves per frame has any (tiles.history_needed);
     # then every TraceFrame is followed by one grouped RCCL send / recv of the halo rings' reservoirs
     exact = args.exact_seams == "on" or (args.exact_seams == "auto" and tiles.history_needed(depth))
-    hx = tiles.HistoryExchange(r, rank, world, W, H, dev) if (world > 1 and exact) else None
+    hx = tiles.HistoryExchange(r, rank, world, W, H, dev) if (world > 1 and exact and not native) else None
 
     ev_log = []                                           # per step: torch events around render / seam exchange / gather (multi-GPU explainers)
 
@@ -340,7 +398,10 @@ def main():
             if moving:
                 pose_no[0] += 1
                 r.SetCamera(*camera_pose(desc, pose_no[0]))
-            r.TraceFrameAsync()
+            if grp is not None and exact:
+                grp.TraceFrame()                          # TraceFrame + (odd depths) wave-count agreement + ONE grouped seam exchange, in C++
+            else:
+                r.TraceFrameAsync()
             if hx is not None:
                 hx.run(dist)
         if record:
@@ -349,6 +410,8 @@ def main():
         # library's own pitched-copy kernel on the renderer's stream (tiles.TileGather.run_renderer), then ONE gather (RCCL over xGMI)
         if emu:
             r.CopyRadianceRectToDevice(tile, emu_tile_buf.data_ptr(), tile[2] - tile[0]); out = emu_tile_buf
+        elif grp is not None:
+            grp.Gather(); out = None                      # enqueue only: tile -> send tile -> rank 0 on the gather stream, overlapping the next step's rendering
         else:
             out = tiles.gather_from_renderer(r, rank, world, W, H, dist, dev)
         if record:
@@ -411,14 +474,17 @@ def main():
         rays_tile = (ct[4] + ct[48]) * tile_share + (ct[0] - ct[4]) + ct[1] + ct[49] if (world > 1 or emu) else float(ct[0] + ct[1] + ct[2])      # all timed steps
         render_ms = sum(e[0].elapsed_time(e[1]) for e in ev_log) / max(1, len(ev_log)) if ev_log else None
         gather_ms = sum(e[1].elapsed_time(e[2]) for e in ev_log) / max(1, len(ev_log)) if ev_log else None
-        stats = torch.tensor([dt, float(rays_tile), render_ms or 0.0, gather_ms or 0.0], dtype=torch.float64, device=dev)
+        if grp is not None:
+            gather_ms = grp.Stats()["mean_gather_ms"]     # HIP events on the gather stream (transport + placement), not a stall of the render stream
+        stats = torch.tensor([dt, float(rays_tile), render_ms or 0.0, gather_ms or 0.0], dtype=torch.float64, device="cpu" if grp is not None else dev)
         per_rank = None
         if world > 1:
             allst = [torch.zeros_like(stats) for _ in range(world)]
             dist.all_gather(allst, stats)
             dt = max(float(t[0]) for t in allst); rays_all = sum(float(t[1]) for t in allst)
+            halo = lambda i: (lambda t_, w_: round(((w_[2] - w_[0]) * (w_[3] - w_[1])) / float((t_[2] - t_[0]) * (t_[3] - t_[1])) - 1.0, 4))(tiles.tile_rect(i, world, W, H), tiles.window_rect(tiles.tile_rect(i, world, W, H), W, H))
             per_rank = [{"rank": i, "wall_ms_per_step": round(float(t[0]) * 1e3 / args.steps, 3), "render_ms_per_step": round(float(t[2]), 3),
-                         "gather_ms_per_step": round(float(t[3]), 3)} for i, t in enumerate(allst)]
+                         "gather_ms_per_step": round(float(t[3]), 3), "gather_ms": round(float(t[3]), 3), "halo_over_tile": halo(i)} for i, t in enumerate(allst)]
         else:
             rays_all = float(rays_tile)
         ms_per_step = dt * 1e3 / args.steps
@@ -427,7 +493,7 @@ def main():
 
     # who took part: the size of the RCCL communicator the gather ran on and every rank's device, so that a scaling record shows its N ranks by itself
     my_dev = f"{torch.cuda.get_device_name(local_rank)} (cuda:{local_rank})"
-    rccl_world = dist.get_world_size() if dist.is_initialized() else 1
+    rccl_world = world if grp is not None else (dist.get_world_size() if dist.is_initialized() else 1)
     devices = [my_dev]
     if world > 1:
         devices = [None] * world
@@ -523,6 +589,8 @@ def main():
             "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "rccl_world": rccl_world, "devices": devices,
+            **({"transport": ("native tile group (csrc/group.cpp): " + ("host transport over gloo, rehearsal" if one_gpu else "RCCL resolved by the library, two communicators, gather on its own stream, double-buffered")) if grp is not None else "torch.distributed (tiles.py)",
+                "group_self_test_ms": round(self_test_ms, 2) if grp is not None else None} if world > 1 else {}),
             **({"rehearsal": f"{world} ranks share ONE GPU over gloo with host staging (LUMEN_BENCH_ONE_GPU=1): the N-rank code path executed, NOT a measurement"} if one_gpu else {}),
             # both arithmetic modes at the top level, so that `value` cannot be read without its mode: "fast" = hardware rcp / rsq / sqrt +
             # contracted target function in the ReSTIR passes (the reference's Release build is -use_fast_math); "exact" = bit-identical to the oracle
@@ -590,6 +658,11 @@ def main():
         except Exception:
             pass
         print(json.dumps(out), flush=True)
+    if grp is not None:
+        if rank == 0:
+            img = grp.GetFrame()                          # the last gathered frame exists and holds light
+            assert float(img[..., :3].sum()) > 0.0
+        grp.close()
     r.close()
     if world > 1 or force_pg:
         dist.destroy_process_group()

@@ -20,7 +20,10 @@
 #include <cstring>
 #include <fstream>
 #include <memory>
+#include <algorithm>
+#include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace
@@ -65,6 +68,28 @@ int main(int argc, char** argv)
     settings.renderThread = threaded;
     renderer->Init(settings);
     renderer->CreateDefaultResources();
+    // SANDBOX_GROUP=<rank>/<world>/<id file>: this process is one rank of a tile group (MI355X::Renderer::SetGroup; one process per GPU, rank 0 shows the stitched
+    // frame).  Rank 0 obtains the communicator id from RCCL and leaves it in the file, the other ranks read it there.
+    if (const char* spec = std::getenv("SANDBOX_GROUP")) {
+        unsigned rank = 0, world = 0; char path[2048] = {0};
+        if (std::sscanf(spec, "%u/%u/%2047s", &rank, &world, path) != 3 || rank >= world) { std::fprintf(stderr, "SANDBOX_GROUP=<rank>/<world>/<id file>\n"); return 64; }
+        std::vector<uint8_t> id;
+        if (rank == 0) {
+            id = MI355X::Renderer::GroupUniqueId();
+            const std::string tmp = std::string(path) + ".tmp";
+            { std::ofstream w(tmp, std::ios::binary); w.write(reinterpret_cast<const char*>(id.data()), static_cast<std::streamsize>(id.size())); }
+            std::rename(tmp.c_str(), path);
+        } else {
+            id.resize(LUMEN_MI_GROUP_ID_BYTES);
+            for (int tries = 0; tries < 600; tries++) {
+                std::ifstream r(path, std::ios::binary);
+                if (r && r.read(reinterpret_cast<char*>(id.data()), static_cast<std::streamsize>(id.size()))) break;
+                if (tries == 599) { std::fprintf(stderr, "rank %u: no communicator id in %s\n", rank, path); return 64; }
+                std::this_thread::sleep_for(std::chrono::milliseconds(100));
+            }
+        }
+        renderer->SetGroup(rank, world, id);
+    }
 
     std::shared_ptr<Lumen::ILumenScene> scene;
     unsigned emissiveTriangles = 0;
@@ -158,17 +183,23 @@ int main(int argc, char** argv)
     else {
         // the render thread free-runs; the main loop keeps calling PerformDeferredOperations (LumenApp::Run) and, half way, moves the first instance the way the
         // tool UI does: the edit must reach the frames traced after it
+        // (the thread may trace many frames between two iterations of this loop: the edit is made at the first iteration that sees half of the frames done, and the
+        // loop then waits for two MORE frames, so that the edit is in the picture however fast the thread runs)
         bool moved = false;
-        for (int spins = 0; static_cast<int>(renderer->GetLastFrameStats().m_Id) < frames && spins < 200000; spins++) {
+        unsigned long long target = static_cast<unsigned long long>(frames);
+        for (int spins = 0; spins < 200000; spins++) {
             renderer->PerformDeferredOperations();
-            if (!moved && static_cast<int>(renderer->GetLastFrameStats().m_Id) >= frames / 2 && !scene->m_MeshInstances.empty() && std::getenv("SANDBOX_MOVE")) {
+            const unsigned long long id = renderer->GetLastFrameStats().m_Id;
+            if (!moved && id >= static_cast<unsigned long long>(frames / 2) && !scene->m_MeshInstances.empty() && std::getenv("SANDBOX_MOVE")) {
                 glm::mat4 w = scene->m_MeshInstances[0]->m_Transform.GetWorldTransformationMatrix();
                 w[3].y += 0.25f;
                 scene->m_MeshInstances[0]->m_Transform = w;
                 moved = true;
+                target = std::max(target, id + 2ull);
             }
+            if (id >= target) break;
         }
-        if (static_cast<int>(renderer->GetLastFrameStats().m_Id) < frames) { std::fprintf(stderr, "the render thread did not reach %d frames\n", frames); return 66; }
+        if (renderer->GetLastFrameStats().m_Id < target) { std::fprintf(stderr, "the render thread did not reach %d frames\n", frames); return 66; }
         // what the tracer sees while the thread is still running: the world-space triangle soup (a host-side product of the C ABI) — the edit above must be in it
         uint32_t nTris = 0;
         if (lumen_mi_get_world_triangles(renderer->Native(), nullptr, 0, &nTris) == LUMEN_MI_OK && nTris) {

@@ -213,6 +213,48 @@ int lumen_mi_import_wave_count(lumen_mi_renderer*, const void* device_i32);
  * combine, and their radiance is undefined.  Owned pixels are unaffected (no reference equivalent: the reference is single-GPU). */
 int lumen_mi_set_tile(lumen_mi_renderer*, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1);
 
+/* ---- tile groups: N processes, one per GPU, render ONE image (new functionality; north_star: "frames shard by tile across the 8 GPUs of one node with RCCL
+ * gather over xGMI of the final radiance buffer").  csrc/group.cpp: the tile / window / halo plan, the seam exchange of temporal history, and the gather, in
+ * C++ behind this ABI.  The plan functions are pure (no GPU).  Rectangles are x0 y0 x1 y1 in global pixels; an empty rectangle is all zero.
+ *   plan:   a cols x rows grid (the one whose largest window is smallest); a rank owns `tile` and renders `window` = tile + 60-px halo clipped to the image
+ *           (two spatial reuse passes x 30 px); every tile is sent in the common shape max_tile_w x max_tile_h.
+ *   seams:  per peer, `send` = my tile inside the peer's window, `recv` = the peer's tile inside my window: what is exchanged after a frame at odd path depths. */
+typedef struct lumen_mi_tile_plan { uint32_t cols, rows, halo; uint32_t tile[4]; uint32_t window[4]; uint32_t max_tile_w, max_tile_h; } lumen_mi_tile_plan;
+typedef struct lumen_mi_seam { uint32_t peer; uint32_t send[4]; uint32_t recv[4]; } lumen_mi_seam;
+int lumen_mi_group_plan(uint32_t width, uint32_t height, uint32_t world, uint32_t rank, lumen_mi_tile_plan* out);
+int lumen_mi_group_seams(uint32_t width, uint32_t height, uint32_t world, uint32_t rank, lumen_mi_seam* out, uint32_t capacity, uint32_t* count);   /* out may be NULL: count only */
+/* Transport.  Default: RCCL (two communicators: seam traffic on the renderer's stream, the gather on a stream of its own) — rank 0 obtains the id and hands the
+ * bytes to the other ranks by any means (a file, an environment variable, MPI, a socket).  RCCL is resolved when first needed (dlopen "librccl.so.1", or the path
+ * in LUMEN_MI_RCCL_LIBRARY): the library has no link-time dependency on it.  Alternative: a HOST transport — callbacks on host buffers; the group stages device data
+ * through pinned memory around them.  exchange() posts all operations of one call together and returns when all have completed (ncclGroupStart / End semantics;
+ * matching send / recv pairs appear in the same call on both sides); both callbacks return 0 on success. */
+#define LUMEN_MI_GROUP_ID_BYTES 256
+typedef struct lumen_mi_transport_op { uint32_t peer; int32_t send; void* host; size_t bytes; } lumen_mi_transport_op;      /* send != 0: to peer; else from peer */
+typedef struct lumen_mi_transport {
+    void* user;
+    int (*exchange)(void* user, uint32_t n_ops, const lumen_mi_transport_op* ops);
+    int (*allreduce_max_i32)(void* user, int32_t* value);
+} lumen_mi_transport;
+typedef struct lumen_mi_group lumen_mi_group;
+int lumen_mi_group_unique_id(uint8_t id[LUMEN_MI_GROUP_ID_BYTES]);
+/* The renderer must be initialised at the FULL image resolution; the group sets its window and tile.  id: the bytes of rank 0's lumen_mi_group_unique_id (may be NULL for
+ * world == 1: then no communicator is created; with an id, world == 1 runs over RCCL too).  transport: NULL = RCCL.  Collective: every rank calls it. */
+int lumen_mi_group_create(lumen_mi_renderer*, uint32_t rank, uint32_t world, const uint8_t* id, const lumen_mi_transport* transport, lumen_mi_group** out);
+int lumen_mi_group_destroy(lumen_mi_group*);          /* the renderer returns to the whole image */
+int lumen_mi_group_get_plan(lumen_mi_group*, lumen_mi_tile_plan* out);
+/* one 1-element all-reduce per communicator and one full-size gather of empty tiles, synchronised: a rank that cannot reach its peers fails here, naming itself */
+int lumen_mi_group_self_test(lumen_mi_group*, float* milliseconds);
+/* TraceFrame of this rank's window (enqueue only); at odd path depths followed by the wave-count agreement and ONE grouped exchange of the halo rings' reservoirs,
+ * all ordered on the renderer's stream ahead of the next frame */
+int lumen_mi_group_trace_frame(lumen_mi_group*);
+/* The rank's tile of the merged radiance -> one of two send tiles -> rank 0, on the gather stream (grouped send / recv), where each tile is placed in the assembled
+ * frame; enqueue only.  Two send tiles and two assembled frames alternate, so the gather of frame i overlaps the rendering of frame i + 1. */
+int lumen_mi_group_gather(lumen_mi_group*);
+int lumen_mi_group_synchronize(lumen_mi_group*);
+int lumen_mi_group_get_frame(lumen_mi_group*, float* rgba32f, size_t capacity_bytes);     /* rank 0: the last gathered frame, width x height RGBA32F (waits for it) */
+int lumen_mi_group_frame_device(lumen_mi_group*, void** device_rgba32f);                  /* rank 0: the same, as a device pointer valid until the gather after next */
+int lumen_mi_group_get_stats(lumen_mi_group*, uint64_t* gathers, float* mean_gather_ms); /* gather time = HIP events on the gather stream around transport + placement, sampled when a send tile is reused */
+
 /* ---- ray-query seam (OptixWrapper::TraceRays, LumenPT/src/Framework/OptixWrapper.h:58-81): host arrays in, host arrays out */
 /* (with lumen_mi_set_instrumented on, lumen_mi_query_closest leaves ITS traversal statistics — counters [20]..[46] — for lumen_mi_get_counters, in place of the last frame's) */
 int lumen_mi_query_closest(lumen_mi_renderer*, uint32_t n, const float* origins3, const float* directions3, float tmin, float tmax,

@@ -29,8 +29,10 @@
 #include <glm/gtc/type_ptr.hpp>
 
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
 #include <memory>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -205,7 +207,25 @@ namespace MI355X
         struct Settings { unsigned depth = 5; glm::uvec2 renderResolution{1280, 720}; glm::uvec2 outputResolution{1280, 720}; bool blendOutput = false; int device = 0; bool renderThread = true; };
 
         Renderer() { Check(lumen_mi_create(&m_R), "create"); }
-        ~Renderer() override { if (m_ThreadRunning) lumen_mi_stop_rendering(m_R); lumen_mi_destroy(m_R); }      // WaveFrontRenderer.cpp:1360-1371: the thread is joined first
+        ~Renderer() override { if (m_ThreadRunning) lumen_mi_stop_rendering(m_R); if (m_Group) lumen_mi_group_destroy(m_Group); lumen_mi_destroy(m_R); }      // WaveFrontRenderer.cpp:1360-1371: the thread is joined first
+
+        // Tile group (new functionality: the reference is single-GPU): this process becomes rank `rank` of `world` processes, one per GPU, that render ONE image.  Call after
+        // Init (at the full image resolution) on every rank; `id` = the LUMEN_MI_GROUP_ID_BYTES rank 0 obtained from GroupUniqueId(), handed over by the application (file,
+        // environment, socket).  From then on TraceFrame renders this rank's tile + halo, exchanges the seam history where the path depth needs it and gathers the tiles on
+        // rank 0 over RCCL (csrc/group.cpp), and rank 0's GetOutputTexturePixels returns the stitched frame; other ranks return no pixels.  Frames are traced from
+        // PerformDeferredOperations on the caller's thread (every rank must trace the same number of frames: a free-running render thread per rank could not promise that).
+        static std::vector<uint8_t> GroupUniqueId() { std::vector<uint8_t> id(LUMEN_MI_GROUP_ID_BYTES); Check(lumen_mi_group_unique_id(id.data()), "group_unique_id"); return id; }
+        void SetGroup(uint32_t rank, uint32_t world, const std::vector<uint8_t>& id, const lumen_mi_transport* hostTransport = nullptr)
+        {
+            if (m_ThreadRunning) throw std::runtime_error("MI355X::Renderer::SetGroup: call before StartRendering");
+            if (!id.empty() && id.size() != LUMEN_MI_GROUP_ID_BYTES) throw std::runtime_error("MI355X::Renderer::SetGroup: the id must be LUMEN_MI_GROUP_ID_BYTES long");
+            if (m_Group) { Check(lumen_mi_group_destroy(m_Group), "group_destroy"); m_Group = nullptr; }
+            Check(lumen_mi_group_create(m_R, rank, world, id.empty() ? nullptr : id.data(), hostTransport, &m_Group), "group_create");
+            float ms = 0.f;
+            Check(lumen_mi_group_self_test(m_Group, &ms), "group_self_test");
+            m_GroupRank = rank; m_UseThread = false;
+        }
+        lumen_mi_group* NativeGroup() { return m_Group; }
 
         void Init(const Settings& s)
         {
@@ -296,6 +316,7 @@ namespace MI355X
             // with capacity 0 reports it
             uint8_t none = 0;
             w = h = 0;
+            if (m_Group) return GroupPixels(w, h);
             (void)lumen_mi_get_output_pixels(m_R, &none, 0, &w, &h);
             std::vector<uint8_t> px(static_cast<size_t>(w) * h * 4);
             if (!px.empty()) Check(lumen_mi_get_output_pixels(m_R, px.data(), px.size(), &w, &h), "get_output_pixels");
@@ -314,6 +335,7 @@ namespace MI355X
         void TraceFrame()
         {
             if (!PushSceneState()) return;
+            if (m_Group) { Check(lumen_mi_group_trace_frame(m_Group), "group_trace_frame"); Check(lumen_mi_group_gather(m_Group), "group_gather"); m_GroupFrames++; return; }
             Check(lumen_mi_trace_frame(m_R), "trace_frame");
             CollectFrameStats();
         }
@@ -348,7 +370,22 @@ namespace MI355X
         // C ABI, so a model may be loaded before Init (once: the reference attaches in Init, WaveFrontRenderer.cpp:305)
         void AttachModelConverter() { if (!m_ConverterAttached) { m_ConverterAttached = true; m_ModelConverter.SetRendererRef(*this); } }
 
+        // rank 0 of a tile group: the stitched fp32 frame through the sRGB transfer function (IEC 61966-2-1, 256 levels, clamped), alpha 255; other ranks: nothing
+        std::vector<uint8_t> GroupPixels(uint32_t& w, uint32_t& h)
+        {
+            if (m_GroupRank != 0 || !m_GroupFrames) { Check(lumen_mi_group_synchronize(m_Group), "group_synchronize"); return {}; }
+            lumen_mi_get_render_resolution(m_R, &w, &h);
+            std::vector<float> frame(static_cast<size_t>(w) * h * 4);
+            Check(lumen_mi_group_get_frame(m_Group, frame.data(), frame.size() * sizeof(float)), "group_get_frame");
+            std::vector<uint8_t> px(frame.size());
+            auto level = [](float c) { const float s = c <= 0.0031308f ? 12.92f * c : 1.055f * std::pow(c, 1.0f / 2.4f) - 0.055f; const float q = (s < 0.f ? 0.f : s > 1.f ? 1.f : s) * 256.f; return static_cast<uint8_t>(q > 255.f ? 255.f : q); };
+            for (size_t i = 0; i < px.size(); i += 4) { px[i] = level(frame[i]); px[i + 1] = level(frame[i + 1]); px[i + 2] = level(frame[i + 2]); px[i + 3] = 255; }
+            return px;
+        }
+
         lumen_mi_renderer* m_R = nullptr;
+        lumen_mi_group* m_Group = nullptr;
+        uint32_t m_GroupRank = 0; uint64_t m_GroupFrames = 0;
         LumenPTModelConverter m_ModelConverter;
         bool m_UseThread = true, m_Started = false, m_ThreadRunning = false, m_ConverterAttached = false;
     };

@@ -35,6 +35,30 @@ class PrimitiveData(C.Structure):
                 ("n_indices", C.c_uint32), ("index_size", C.c_uint32), ("material", C.c_uint64)]
 
 
+class TilePlan(C.Structure):
+    _fields_ = [("cols", C.c_uint32), ("rows", C.c_uint32), ("halo", C.c_uint32), ("tile", C.c_uint32 * 4), ("window", C.c_uint32 * 4),
+                ("max_tile_w", C.c_uint32), ("max_tile_h", C.c_uint32)]
+
+
+class Seam(C.Structure):
+    _fields_ = [("peer", C.c_uint32), ("send", C.c_uint32 * 4), ("recv", C.c_uint32 * 4)]
+
+
+class TransportOp(C.Structure):
+    _fields_ = [("peer", C.c_uint32), ("send", C.c_int32), ("host", C.c_void_p), ("bytes", C.c_size_t)]
+
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.POINTER(TransportOp))
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32))
+
+
+class Transport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("exchange", EXCHANGE_FN), ("allreduce_max_i32", ALLREDUCE_FN)]
+
+
+GROUP_ID_BYTES = 256
+
+
 def library_path():
     """The in-tree library; LUMEN_MI_LIBRARY names another BUILD of the same sources (tools/ab_lib.sh: compile-time variants built beforehand and compared on one GPU box
     without rebuilding there).  Either way it is the HIP library: there is nothing else to load."""
@@ -92,6 +116,15 @@ SYMBOLS = {
     "lumen_mi_test_camera": [_FP, _FP, _FP, _FP, C.c_float, C.c_float, _FP],
     "lumen_mi_get_world_triangles": [_R, _FP, C.c_uint32, _U32P], "lumen_mi_get_lights": [_R, _FP, _FP, C.c_uint32, _U32P],
     "lumen_mi_get_bvh_info": [_R, _U32P, _U32P, _U32P],
+    "lumen_mi_group_plan": [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(TilePlan)],
+    "lumen_mi_group_seams": [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Seam), C.c_uint32, _U32P],
+    "lumen_mi_group_unique_id": [_U8P],
+    "lumen_mi_group_create": [_R, C.c_uint32, C.c_uint32, _U8P, C.POINTER(Transport), C.POINTER(C.c_void_p)],
+    "lumen_mi_group_destroy": [C.c_void_p], "lumen_mi_group_get_plan": [C.c_void_p, C.POINTER(TilePlan)],
+    "lumen_mi_group_self_test": [C.c_void_p, _FP],
+    "lumen_mi_group_trace_frame": [C.c_void_p], "lumen_mi_group_gather": [C.c_void_p], "lumen_mi_group_synchronize": [C.c_void_p],
+    "lumen_mi_group_get_frame": [C.c_void_p, _FP, C.c_size_t], "lumen_mi_group_frame_device": [C.c_void_p, C.POINTER(C.c_void_p)],
+    "lumen_mi_group_get_stats": [C.c_void_p, _U64P, _FP],
 }
 
 
@@ -131,7 +164,9 @@ def load_library():
     _share_the_hip_runtime_with_torch()
     lib = C.CDLL(path)
     for name, args in SYMBOLS.items():
-        f = getattr(lib, name)
+        f = getattr(lib, name, None)
+        if f is None:                                  # an older build selected with LUMEN_MI_LIBRARY (A/B runs); __graft_entry__.build() and the CPU suite hold the
+            continue                                   # in-tree library to the full symbol list of include/lumen_mi.h
         f.argtypes = args
         f.restype = C.c_int
     lib.lumen_mi_last_error.argtypes = []

@@ -7,7 +7,7 @@
 // every transform change anyway, PTScene.cpp:145-153).  Node boxes are padded by 2^-15 * (largest |coordinate|)
 // so that box tests are conservative with respect to the fp32 Woop triangle test (DESIGN.md "Traversal").
 #include "bvh.h"
-#include "lm_woop.h"
+#include "lm_tri.h"
 
 #include <sched.h>
 
@@ -285,7 +285,7 @@ static void lm_assign_slots(int n, const float (*b)[6], int* slotOf)
 
 void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out)
 {
-    out->nodes.clear(); out->order.clear(); out->woop.clear();
+    out->nodes.clear(); out->order.clear(); out->packets.clear();
     const bool timing = getenv("LUMEN_MI_BUILD_TIMING") != nullptr;
     auto tLast = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (!timing) return; const auto now = std::chrono::steady_clock::now(); fprintf(stderr, "[bvh] %-28s %.3f s\n", what, std::chrono::duration<double>(now - tLast).count()); tLast = now; };
@@ -374,11 +374,11 @@ void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out)
     lap("concatenation");
     out->maxDepth = b.maxDepth + 1;
     const size_t nSlots = out->order.size();
-    out->woop.resize(nSlots + 1);
-    parallelChunks(nSlots, threads, [&](unsigned, size_t lo, size_t hi) { for (size_t s = lo; s < hi; s++) out->woop[s] = lm_make_woop(tris + 9 * (size_t)out->order[s]); });
-    memset(&out->woop[nSlots], 0, sizeof(LmWoop));               // sentinel packet: t = -0/0 = NaN, never a hit
+    out->packets.resize(nSlots + 1);
+    parallelChunks(nSlots, threads, [&](unsigned, size_t lo, size_t hi) { for (size_t s = lo; s < hi; s++) out->packets[s] = lm_make_packet(tris + 9 * (size_t)out->order[s]); });
+    memset(&out->packets[nSlots], 0, sizeof(LmTriPacket));               // sentinel packet: zero edge functions, never a hit
 
-    lap("woop packets");
+    lap("packets packets");
     // ---- 16-bit quantisation relative to the (padded) scene box, rounded outward by LM_QUANT_MARGIN extra steps
     float smin[3] = {INFINITY, INFINITY, INFINITY}, smax[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (uint32_t t = 0; t < nTris; t++) for (int k = 0; k < 3; k++) { smin[k] = std::min(smin[k], tbox[t].lo[k]); smax[k] = std::max(smax[k], tbox[t].hi[k]); }
@@ -608,7 +608,7 @@ void lm_assemble_bvh(const LmInstanceRef* inst, uint32_t nInst, LmBvh* out)
         }
         for (size_t s = 0; s < m.order.size(); s++) out->order[slotBase[i] + s] = inst[i].triBase + m.order[s];
     }
-    out->woop.assign((size_t)nSlots + 1, LmWoop{});                   // refit_tris writes the packets; the sentinel stays zero
+    out->packets.assign((size_t)nSlots + 1, LmTriPacket{});                   // refit_tris writes the packets; the sentinel stays zero
     // depth of every node, worst-case stack occupancy (the rule of lm_build_bvh's collapse), refit levels deepest first
     std::vector<uint32_t> depthOf(out->nodesW.size(), 0);
     struct Item { uint32_t node, depth, stack; };

@@ -8,7 +8,7 @@ struct LmBvh {
     std::vector<LmNodeW> nodesW;        // the tree collapsed to 4-wide nodes with 16-bit boxes (what the kernels read); node 0 = root
     float qmin[3] = {0, 0, 0}, qstep[3] = {1, 1, 1};
     std::vector<uint32_t> order;        // BVH triangle slot -> input triangle index
-    std::vector<LmWoop> woop;           // per slot, plus one all-zero sentinel packet at index order.size()
+    std::vector<LmTriPacket> packets;           // per slot, plus one all-zero sentinel packet at index order.size()
     uint32_t maxDepth = 0;              // of the binary tree
     uint32_t maxStack = 0;              // worst-case traversal stack occupancy of the 4-wide tree
     float pad = 0.f;

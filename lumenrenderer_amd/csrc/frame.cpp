@@ -238,6 +238,10 @@ int traceFrameAsync(R* r)
 #endif
     // the map of tiles that need the exact launch of the fast ReSTIR passes, of the G-buffer set this frame's extraction fills (its last readers belonged to the frame
     // three back, which the wait for evMerge above has seen end).  Only scenes with a material outside the contracted evaluation ever read it.
+    // The extraction (lm_k_extract0) marks tiles only while the map can be read: the frame's view of the pointers is the buffers in the fast mode with such a material
+    // (fastRs == 2) and NULL otherwise, so exact-mode frames of a glass-heavy scene no longer pay same-address stores for nothing.  Invariant of the map: a
+    // SUPERSET — a set bit only ever makes a block of the second launch look at its pixels; a frame that switches to fastRs == 2 clears its set right here first.
+    for (int i = 0; i < 3; i++) fr.rareTile[i] = fastRs == 2 ? r->dRareTile[i].p : nullptr;
     if (fastRs == 2) LM_HIP(hipMemsetAsync(fr.rareTile[currentIndex], 0, (size_t)((fr.ww + 15u) / 16u) * ((fr.wh + 15u) / 16u) * sizeof(uint32_t), sx));
     if (!blend) { Z(st); K->clear(st, r->gridFor(fr.n, 8), fr.combined, fr.n); }                        // :559
     ++r->frameCount;                                                                          // :593
@@ -381,7 +385,7 @@ int traceFrameAsync(R* r)
             const bool pair = r->tailPair > 0 || (r->tailPair < 0 && fr.n < 1500000u);
             const int tailShape = r->tailRepack > 0 ? 1000 : pair ? -std::min(32, tailL) : tailL;      // 1000: the repacking variant (tuning key tail_repack, kernels.hip)
             evBegin2(r, 5, ev, stl);
-            Z(stl); K->path_tail(stl, r->numCU * 8, sct, withTailQueue(fr, q), q | (r->fastShade ? 2 : 0), inCount, (int)depth, (int)depthMax, seed, tailShape);
+            Z(stl); K->path_tail(stl, r->numCU * r->tailGrid, sct, withTailQueue(fr, q), q | (r->fastShade ? 2 : 0), inCount, (int)depth, (int)depthMax, seed, tailShape);
             evEnd2(r, ev, stl);
             if (overlap) LM_HIP(hipEventRecord(r->evTail, stl));
             tailLaunched = true;

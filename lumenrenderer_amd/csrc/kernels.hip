@@ -9,7 +9,7 @@
 // grid-stride over device-side counters so a frame needs no host round trip.
 #include "lm_layout.h"
 #include "lm_bsdf.h"
-#include "lm_woop.h"
+#include "lm_tri.h"
 
 #define LM_BLOCK 256
 #ifndef LM_RESTIR_WAVES
@@ -656,28 +656,42 @@ __device__ __forceinline__ void lm_path_tail_repack_body(const LmScene& sc, cons
         }
     }
 }
-extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+// Residency of the path tail.  The tail is one long launch beside the frame's critical ReSTIR chain: every wave slot and register it holds is taken from the kernels
+// that bound the frame, while its own length is the dependent chain of its longest path.  LM_TAIL_MAX_WAVES caps its waves per SIMD (0: whatever its registers allow);
+// interleaved A/B: profiles/r06_build_flags_ab.txt.
+#ifndef LM_TAIL_MAX_WAVES
+#define LM_TAIL_MAX_WAVES 3
+#endif
+#if LM_TAIL_MAX_WAVES
+#define LM_TAIL_OCCUPANCY __attribute__((amdgpu_waves_per_eu(1, LM_TAIL_MAX_WAVES)))
+#else
+#define LM_TAIL_OCCUPANCY
+#endif
+extern "C" __global__ void __launch_bounds__(LM_BLOCK) LM_TAIL_OCCUPANCY
 KN(lm_k_path_tail_repack)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict__ inCount, int depth0, int depthMax, uint32_t seed0)
 { lm_path_tail_repack_body<LmExact>(sc, fr, inQ, inCount, depth0, depthMax, seed0); }
-extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+extern "C" __global__ void __launch_bounds__(LM_BLOCK) LM_TAIL_OCCUPANCY
 KN(lm_k_path_tail_repack_fs)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict__ inCount, int depth0, int depthMax, uint32_t seed0)
 { lm_path_tail_repack_body<LmFast>(sc, fr, inQ, inCount, depth0, depthMax, seed0); }
-extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+extern "C" __global__ void __launch_bounds__(LM_BLOCK) LM_TAIL_OCCUPANCY
 KN(lm_k_path_tail)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict__ inCount, int depth0, int depthMax, uint32_t seed0, int lanesPerWave)
 { lm_path_tail_body<false, LmExact>(sc, fr, inQ, inCount, depth0, depthMax, seed0, lanesPerWave); }
-extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+extern "C" __global__ void __launch_bounds__(LM_BLOCK) LM_TAIL_OCCUPANCY
 KN(lm_k_path_tail_pair)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict__ inCount, int depth0, int depthMax, uint32_t seed0, int lanesPerWave)
 { lm_path_tail_body<true, LmExact>(sc, fr, inQ, inCount, depth0, depthMax, seed0, lanesPerWave); }
-extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+extern "C" __global__ void __launch_bounds__(LM_BLOCK) LM_TAIL_OCCUPANCY
 KN(lm_k_path_tail_fs)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict__ inCount, int depth0, int depthMax, uint32_t seed0, int lanesPerWave)
 { lm_path_tail_body<false, LmFast>(sc, fr, inQ, inCount, depth0, depthMax, seed0, lanesPerWave); }
-extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+extern "C" __global__ void __launch_bounds__(LM_BLOCK) LM_TAIL_OCCUPANCY
 KN(lm_k_path_tail_pair_fs)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict__ inCount, int depth0, int depthMax, uint32_t seed0, int lanesPerWave)
 { lm_path_tail_body<true, LmFast>(sc, fr, inQ, inCount, depth0, depthMax, seed0, lanesPerWave); }
 
 // K5: NEE shadow rays — reference WaveFrontShaders.cu:114-179 (tmin 0.01; unoccluded => channel += radiance).
 // At most one shadow ray per pixel per wave, so the add is a plain fp32 read-modify-write.
-extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+#ifndef LM_ANYHIT_WAVES
+#define LM_ANYHIT_WAVES 8      // minimum waves per SIMD of the two any-hit queue kernels: capped at 64 VGPRs like the closest-hit kernel (the watertight triangle test took them to 68 / 72 = seven waves; A/B profiles/r06_watertight_ab.txt)
+#endif
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_ANYHIT_WAVES)
 KN(lm_k_trace_shadow)(LmScene sc, LmFrame fr, const uint32_t* __restrict__ countPtr, float tmin, int refillBelow)
 {
     __shared__ int s_stack[LM_STACK_LDS * LM_BLOCK];
@@ -762,7 +776,7 @@ __device__ __forceinline__ void lm_vis_resolve(const LmFrame& fr, int rc, float4
 
 // K6 + K23: resolve the visibility rays (tmin 0.1, WaveFrontShaders.cu:181-216: occluded => reservoir weight = 0) and shade
 // the surviving reservoirs into DIRECT with weight / 3 (ReSTIRKernels.cu:600-665)
-extern "C" __global__ void __launch_bounds__(LM_BLOCK)
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_ANYHIT_WAVES)
 KN(lm_k_restir_trace_shade)(LmScene sc, LmFrame fr, int rc, const uint32_t* __restrict__ countPtr, int refillBelow, int pass)
 {
     rc = lm_res_idx(fr, rc);
@@ -1899,7 +1913,7 @@ KN(lm_k_history_copy)(LmFrame fr, uint32_t x0, uint32_t y0, uint32_t w, uint32_t
 // ---------------------------------------------------------------------------------------------------------------------
 // BVH refit for moved instances (reference: the per-frame instance acceleration-structure rebuild of PTScene.cpp:74-156,
 // PTMeshInstance.cpp:123-178).  Topology and leaf contents stay; triangles are re-transformed, Woop packets recomputed
-// (bit-identical to the host builder: lm_woop.h), boxes propagated bottom-up level by level and re-quantised against the
+// (bit-identical to the host builder: lm_tri.h), boxes propagated bottom-up level by level and re-quantised against the
 // new scene box.  Boxes only cull, so the hit records equal those of a freshly built tree.
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t lm_ordered(float f) { const uint32_t u = f2u(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
@@ -1924,7 +1938,7 @@ KN(lm_k_refit_tris)(LmScene sc, uint32_t nSlots, float4* __restrict__ triBox, ui
             tri[3 * k + 1] = e.m[4] * p.x + e.m[5] * p.y + e.m[6] * p.z + e.m[7] * 1.f;
             tri[3 * k + 2] = e.m[8] * p.x + e.m[9] * p.y + e.m[10] * p.z + e.m[11] * 1.f;
         }
-        sc.woop[s] = lm_make_woop(tri);
+        sc.packets[s] = lm_make_packet(tri);
         for (int k = 0; k < 9; k++) { lo[k % 3] = fminf(lo[k % 3], tri[k]); hi[k % 3] = fmaxf(hi[k % 3], tri[k]); maxAbs = fmaxf(maxAbs, fabsf(tri[k])); }
         triBox[2u * s] = make_float4(lo[0], lo[1], lo[2], 0.f);
         triBox[2u * s + 1u] = make_float4(hi[0], hi[1], hi[2], 0.f);

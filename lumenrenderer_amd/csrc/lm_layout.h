@@ -56,8 +56,10 @@ struct LmNode {
 struct LmNodeW {
     uint4 c[LM_WIDTH];     // per child  x: lo.x | hi.x << 16   y: lo.y | hi.y << 16   z: lo.z | hi.z << 16   w: reference
 };
-// Woop unit-triangle packet, 48 bytes: rows of the affine map world -> (u, v, w)
-struct LmWoop { float4 r0, r1, r2; };
+// Triangle packet of the traversal, 64 bytes = one aligned cache line, in leaf order: the three world-space vertices as x y z x y each (lm_tri.h), so that
+// a ray reads its cyclically permuted axes (kx, ky, kz: lm_traverse.h lm_tri_test) by one 12-byte load per vertex at float offset kx.  The all-zero packet
+// (sentinel behind the last slot) never reports a hit: its three 2-D points coincide, every edge function and the determinant are zero for every ray.
+struct alignas(64) LmTriPacket { float f[16]; };
 
 // scene data table entry (reference: DevicePrimitiveInstance, ModelStructs.h:73-80)
 struct LmEntry {
@@ -89,7 +91,7 @@ struct LmScene {
                                 // where the child is in the table too (lm_k_build_top, rebuilt whenever `nodes` changes)
     const float* quant;         // dequantisation of node boxes, in device memory so that a refit can move it without a host
                                 // round trip: [0..2] qmin, [3..5] qstep (world = qmin + q * qstep), [6] box padding
-    LmWoop* woop;               // written only by the refit kernels
+    LmTriPacket* packets;               // written only by the refit kernels
     const uint2* triId;         // per BVH triangle slot: (table entry, primitive-local triangle), .x|0x80000000 never used
     const uint32_t* triOrder;   // per BVH triangle slot: global triangle index (tie-break key)
     const float4* verts;        // 3 float4 per vertex: (pos.xyz, uv.x) (uv.y, n.xyz) (tangent.xyzw)

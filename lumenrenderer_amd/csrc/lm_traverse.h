@@ -1,13 +1,14 @@
-// lm_traverse.h — device code: 4-wide BVH traversal (Woop unit-triangle test, hybrid LDS / global stack) and the queue
+// lm_traverse.h — device code: 4-wide BVH traversal (watertight ray / triangle test, hybrid LDS / global stack) and the queue
 // traversal with per-lane ray replacement.  Included by kernels.hip only (one translation unit, compiled twice: LM_INSTRUMENT).
 #pragma once
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Traversal of the 4-wide BVH (bvh.cpp) with the Woop unit-triangle test.  Per-lane stack: 16 entries in LDS, interleaved by lane
+// Traversal of the 4-wide BVH (bvh.cpp) with the watertight triangle test (lm_tri_test).  Per-lane stack: 16 entries in LDS, interleaved by lane
 // (bank-conflict free), deeper entries spill to a per-thread global area.
 // Closest hit: minimum t in (tmin, tmax); equal t -> lower global triangle index (order independent).
 // ---------------------------------------------------------------------------------------------------------------------
 struct LmHit { float t, u, v; uint32_t slot; };
+typedef float lm_f2 __attribute__((ext_vector_type(2)));
 
 // Per-lane traversal stack: the first LM_STACK_LDS entries live in LDS ([level][lane]: one bank per lane), deeper entries
 // (rare) spill to a per-thread global array, so that the LDS footprint (16 KB per 256-thread block) does not cap occupancy.
@@ -56,45 +57,68 @@ __device__ __forceinline__ LmStack lm_make_stack(int* s_stack, const LmScene& sc
     return st;
 }
 
-// The whole 48-byte packet is fetched up front (three independent 16-byte loads, one wait) instead of row by row behind
-// the early-outs: a leaf visit then costs one memory round trip per triangle, not up to three.
-__device__ __forceinline__ bool lm_woop(const LmWoop* __restrict__ woop, uint32_t slot, const lf3& o, const lf3& d,
-                                        float tmin, float tmax, float& t, float& u, float& v)
+// ---------------------------------------------------------------------------------------------------------------------
+// Watertight ray / triangle test: Woop, Benthin, Wald, "Watertight Ray/Triangle Intersection", JCGT 2(1), 2013.  The reference's queries run on OptiX
+// (OptixWrapper.cpp:46-131, WaveFrontShaders.cu:63-76), where no ray passes between two triangles that share an edge or a vertex; an affine
+// unit-triangle packet rounded per triangle (rounds 1 - 5) cannot give that: tests/test_gpu_watertight.py found a quarter of the rays aimed at a shared
+// edge escaping.  Here the triangle is translated to the ray origin, the axes are permuted so that kz is the ray's dominant one, x and y are sheared
+// along z, and the three 2-D edge functions are evaluated.  Each 2-D point is a function of (vertex, ray) alone, so neighbours see the same point; the
+// sign of fl(a b) - fl(c d) is never wrong, only possibly zero, and a zero is resolved exactly by the difference of the two products' rounding errors
+// (one fma each; the paper goes to double there).  The 2-D inside test is therefore EXACT on the points it is given.
+// GPU form: the permutation costs no instruction per triangle — a packet stores every vertex as x y z x y (lm_tri.h), the permutation is cyclic, so
+// (v[kx], v[ky], v[kz]) are the three consecutive floats at float offset kx of the record: one 12-byte load per vertex at a per-ray offset.  The ray's
+// origin is permuted once at setup, where 1 / d[kz] is already at hand from the slab test; x and y travel as register pairs (packed fp32 subtract,
+// fma and multiply: 9 + 6 instructions for the three sheared vertices and the three edge functions).  Per-ray state: 7 registers in place of
+// origin + direction.
+// Operation order is part of the definition: the CPU checker (tri_hit, under oracle/) performs the same fp32 operations.
+// ---------------------------------------------------------------------------------------------------------------------
+struct LmRayTri { lm_f2 oxy; float oz; lm_f2 sxy; float sz; uint32_t row; };      // (o[kx], o[ky]), o[kz]; shear (Sx, Sy), Sz; byte offset 4 kx into a vertex record
+struct LmV3 { float x, y, z; };                                         // one permuted vertex: 12 bytes at 4-byte alignment
+__device__ __forceinline__ LmV3 lm_load_v3(const char* p) { LmV3 v; __builtin_memcpy(&v, p, 12); return v; }
+__device__ __forceinline__ float lm_edge_exact(float a, float b, float c, float d)      // a b - c d when its rounded value is zero: the exact sign
 {
-    float4 r2 = woop[slot].r2, r0 = woop[slot].r0, r1 = woop[slot].r1;
-    asm volatile("" : "+v"(r0.x), "+v"(r1.x), "+v"(r2.x));     // keep the three loads together (the compiler would sink two behind the early-outs)
-    const float Oz = fmaf(r2.x, o.x, fmaf(r2.y, o.y, fmaf(r2.z, o.z, r2.w)));
-    const float Dz = fmaf(r2.x, d.x, fmaf(r2.y, d.y, r2.z * d.z));
-    t = -Oz / Dz;
-    if (!(t > tmin && t < tmax)) return false;
-    const float Ox = fmaf(r0.x, o.x, fmaf(r0.y, o.y, fmaf(r0.z, o.z, r0.w)));
-    const float Dx = fmaf(r0.x, d.x, fmaf(r0.y, d.y, r0.z * d.z));
-    u = fmaf(t, Dx, Ox);
-    if (!(u >= 0.0f)) return false;
-    const float Oy = fmaf(r1.x, o.x, fmaf(r1.y, o.y, fmaf(r1.z, o.z, r1.w)));
-    const float Dy = fmaf(r1.x, d.x, fmaf(r1.y, d.y, r1.z * d.z));
-    v = fmaf(t, Dy, Oy);
-    if (!(v >= 0.0f)) return false;
-    return u + v <= 1.0f;
+    asm volatile("" ::: "memory");          // a rare path: kept a branch of its own (no speculation, no packing with its siblings: those cost six registers in every traversal kernel)
+    const float p = a * b;
+    const float ep = fmaf(a, b, -p);
+    const float q = c * d;
+    return ep - fmaf(c, d, -q);
 }
-
-// The test on rows already in registers (same operations, same order as lm_woop)
-__device__ __forceinline__ bool lm_woop_rows(const float4& r0, const float4& r1, const float4& r2, const lf3& o, const lf3& d,
-                                             float tmin, float tmax, float& t, float& u, float& v)
+// a, b, c = the three vertices as (v[kx], v[ky], v[kz]); true and (t, u, v) for a hit with tmin < t < tmax; u / v = barycentric weight of the second / third vertex
+__device__ __forceinline__ bool lm_tri_test(const LmV3& a, const LmV3& b, const LmV3& c, const LmRayTri& q, float tmin, float tmax, float& t, float& u, float& v)
 {
-    const float Oz = fmaf(r2.x, o.x, fmaf(r2.y, o.y, fmaf(r2.z, o.z, r2.w)));
-    const float Dz = fmaf(r2.x, d.x, fmaf(r2.y, d.y, r2.z * d.z));
-    t = -Oz / Dz;
+    const float az = a.z - q.oz, bz = b.z - q.oz, cz = c.z - q.oz;
+    const lm_f2 nS = -q.sxy;
+    const lm_f2 A = __builtin_elementwise_fma(nS, (lm_f2){az, az}, (lm_f2){a.x, a.y} - q.oxy);
+    const lm_f2 B = __builtin_elementwise_fma(nS, (lm_f2){bz, bz}, (lm_f2){b.x, b.y} - q.oxy);
+    const lm_f2 C = __builtin_elementwise_fma(nS, (lm_f2){cz, cz}, (lm_f2){c.x, c.y} - q.oxy);
+    const lm_f2 pu = C * B.yx, pv = A * C.yx, pw = B * A.yx;                    // (Cx By, Cy Bx), (Ax Cy, Ay Cx), (Bx Ay, By Ax)
+    float U, V, W;                              // as instructions: the optimiser would pair two of the three subtractions behind three register moves
+    asm("v_sub_f32 %0, %1, %2" : "=v"(U) : "v"(pu.x), "v"(pu.y));
+    asm("v_sub_f32 %0, %1, %2" : "=v"(V) : "v"(pv.x), "v"(pv.y));
+    asm("v_sub_f32 %0, %1, %2" : "=v"(W) : "v"(pw.x), "v"(pw.y));
+    if (fminf(fminf(U, V), W) < 0.f && fmaxf(fmaxf(U, V), W) > 0.f) return false;           // signs of non-zero edge functions are exact: outside
+    if (U == 0.f || V == 0.f || W == 0.f) {                    // on an edge within fp32 (rare): exact signs for the zeros, then the inside test again
+        if (U == 0.f) U = lm_edge_exact(C.x, B.y, C.y, B.x);
+        if (V == 0.f) V = lm_edge_exact(A.x, C.y, A.y, C.x);
+        if (W == 0.f) W = lm_edge_exact(B.x, A.y, B.y, A.x);
+        if ((U < 0.f || V < 0.f || W < 0.f) && (U > 0.f || V > 0.f || W > 0.f)) return false;
+    }
+    const float det = U + V + W;
+    if (det == 0.f) return false;
+    const float T = fmaf(W, q.sz * cz, fmaf(V, q.sz * bz, U * (q.sz * az)));
+    const float rdet = 1.0f / det;
+    t = T * rdet;
     if (!(t > tmin && t < tmax)) return false;
-    const float Ox = fmaf(r0.x, o.x, fmaf(r0.y, o.y, fmaf(r0.z, o.z, r0.w)));
-    const float Dx = fmaf(r0.x, d.x, fmaf(r0.y, d.y, r0.z * d.z));
-    u = fmaf(t, Dx, Ox);
-    if (!(u >= 0.0f)) return false;
-    const float Oy = fmaf(r1.x, o.x, fmaf(r1.y, o.y, fmaf(r1.z, o.z, r1.w)));
-    const float Dy = fmaf(r1.x, d.x, fmaf(r1.y, d.y, r1.z * d.z));
-    v = fmaf(t, Dy, Oy);
-    if (!(v >= 0.0f)) return false;
-    return u + v <= 1.0f;
+    u = V * rdet; v = W * rdet;
+    return true;
+}
+// The whole packet is fetched up front (three independent 12-byte loads from one cache line, one wait): a leaf visit costs one memory round trip per triangle.
+__device__ __forceinline__ bool lm_tri(const LmTriPacket* __restrict__ packets, uint32_t slot, const LmRayTri& q,
+                                       float tmin, float tmax, float& t, float& u, float& v)
+{
+    const char* base = (const char*)(packets + slot) + q.row;
+    const LmV3 a = lm_load_v3(base), b = lm_load_v3(base + 20), c = lm_load_v3(base + 40);
+    return lm_tri_test(a, b, c, q, tmin, tmax, t, u, v);
 }
 // The triangles of one leaf against a lane's ray, in leaf order: visit(slot, t, u, v) for every triangle hit inside (tmin, tmax); it returns true to stop (any-hit).
 // `tested()` runs once per triangle tested (counting build).  LM_LEAF_PAIR (round 4, measured, off): bit 0 — the packets are fetched TWO at a time (six independent 16-byte
@@ -106,33 +130,34 @@ __device__ __forceinline__ bool lm_woop_rows(const float4& r0, const float4& r1,
 #define LM_LEAF_PAIR 0
 #endif
 template <class Visit, class Tested>
-__device__ __forceinline__ void lm_leaf_walk(const LmWoop* __restrict__ woop, uint32_t first, uint32_t count, const lf3& o, const lf3& d, float tmin, float tmax,
+__device__ __forceinline__ void lm_leaf_walk(const LmTriPacket* __restrict__ packets, uint32_t first, uint32_t count, const LmRayTri& rt, float tmin, float tmax,
                                              Visit visit, Tested tested)
 {
 #if LM_LEAF_PAIR & 2
     // touch the leaf's further 128-byte lines now (a leaf's packets are contiguous: <= 384 bytes), so that the later iterations' fetches hit the L1
-    const char* base = (const char*)(woop + first);
-    const uint32_t lastWord = count * 48u - 4u;
+    const char* base = (const char*)(packets + first);
+    const uint32_t lastWord = count * 64u - 4u;
     uint32_t pf1 = *(const uint32_t*)(base + min(128u, lastWord)), pf2 = *(const uint32_t*)(base + min(256u, lastWord));
 #endif
 #if LM_LEAF_PAIR & 1
     for (uint32_t k = 0; k < count; k += 2u) {
         const uint32_t s0 = first + k, s1 = first + min(k + 1u, count - 1u);          // an odd leaf's last round fetches its last packet twice (same lines)
-        float4 a2 = woop[s0].r2, a0 = woop[s0].r0, a1 = woop[s0].r1, b2 = woop[s1].r2, b0 = woop[s1].r0, b1 = woop[s1].r1;
+        const char* pa = (const char*)(packets + s0) + rt.row; const char* pb = (const char*)(packets + s1) + rt.row;
+        LmV3 a0 = lm_load_v3(pa), a1 = lm_load_v3(pa + 20), a2 = lm_load_v3(pa + 40), b0 = lm_load_v3(pb), b1 = lm_load_v3(pb + 20), b2 = lm_load_v3(pb + 40);
         asm volatile("" : "+v"(a0.x), "+v"(a1.x), "+v"(a2.x), "+v"(b0.x), "+v"(b1.x), "+v"(b2.x));     // all six loads before the first use
         float t, u, v;
         tested();
-        if (lm_woop_rows(a0, a1, a2, o, d, tmin, tmax, t, u, v) && visit(s0, t, u, v)) break;
+        if (lm_tri_test(a0, a1, a2, rt, tmin, tmax, t, u, v) && visit(s0, t, u, v)) break;
         if (k + 1u < count) {
             tested();
-            if (lm_woop_rows(b0, b1, b2, o, d, tmin, tmax, t, u, v) && visit(s1, t, u, v)) break;
+            if (lm_tri_test(b0, b1, b2, rt, tmin, tmax, t, u, v) && visit(s1, t, u, v)) break;
         }
     }
 #else
     for (uint32_t k = 0; k < count; k++) {
         float t, u, v;
         tested();
-        if (lm_woop(woop, first + k, o, d, tmin, tmax, t, u, v) && visit(first + k, t, u, v)) break;
+        if (lm_tri(packets, first + k, rt, tmin, tmax, t, u, v) && visit(first + k, t, u, v)) break;
     }
 #endif
 #if LM_LEAF_PAIR & 2
@@ -152,7 +177,6 @@ __device__ __forceinline__ float lm_safe_rcp(float d)
 #ifndef LM_ANY_ORDERED
 #define LM_ANY_ORDERED 0      // 1: any-hit queries also visit children near to far (finds close occluders sooner, costs the sort)
 #endif
-typedef float lm_f2 __attribute__((ext_vector_type(2)));
 #ifndef LM_SLAB_PERM
 #define LM_SLAB_PERM 3       // 0: min / max of the two plane distances per axis;
                              // 1: the near / far plane per axis picked by the sign of the direction (one v_perm_b32 on the packed lo|hi word), then 2 conversions
@@ -171,7 +195,7 @@ struct LmRayQ { lm_f2 x, y, z; uint32_t nx, fx, ny, fy, nz, fz;
                 uint32_t k23;
 #endif
                 uint32_t oct; };     // 8-wide tree: (direction octant) << 4 = byte offset of the slot a ray visits first; slot of visit p = p ^ octant
-__device__ __forceinline__ void lm_ray_setup(const LmScene& sc, const lf3& o, const lf3& d, LmRayQ& r)
+__device__ __forceinline__ void lm_ray_setup(const LmScene& sc, const lf3& o, const lf3& d, LmRayQ& r, LmRayTri& q)
 {
     const float idx = lm_safe_rcp(d.x), idy = lm_safe_rcp(d.y), idz = lm_safe_rcp(d.z);
     // node boxes are 16-bit fixed point: world = qmin + q * qstep, so t = q * (qstep * idir) + (qmin - o) * idir
@@ -193,6 +217,13 @@ __device__ __forceinline__ void lm_ray_setup(const LmScene& sc, const lf3& o, co
     r.k23 = 0x4b000000u; asm volatile("" : "+v"(r.k23));           // opaque to the compiler: stays a VGPR
 #endif
     r.oct = ((d.x < 0.f ? 1u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 4u : 0u)) << 4;
+    // the triangle test's view of the ray (lm_tri_test): kz = dominant axis (ties: x before y before z), (kx, ky, kz) cyclic
+    const float ax_ = fabsf(d.x), ay_ = fabsf(d.y), az_ = fabsf(d.z);
+    const bool k0 = ax_ >= ay_ && ax_ >= az_, k1 = !k0 && ay_ >= az_;
+    q.oxy = (lm_f2){k0 ? o.y : k1 ? o.z : o.x, k0 ? o.z : k1 ? o.x : o.y}; q.oz = k0 ? o.x : k1 ? o.y : o.z;
+    q.sz = k0 ? idx : k1 ? idy : idz;
+    q.sxy = (lm_f2){(k0 ? d.y : k1 ? d.z : d.x) * q.sz, (k0 ? d.z : k1 ? d.x : d.y) * q.sz};
+    q.row = k0 ? 4u : k1 ? 8u : 0u;
 }
 // Slab test of one quantised child box against [tmin, hitT]: key = entry distance (its bit pattern orders like the value: tn >= tmin >= 0), or
 // 0xffffffff for a miss.  An absent child carries an inverted box (lo = 0xffff, hi = 0: near > far on every axis), so it misses without a test.
@@ -389,9 +420,9 @@ __device__ __forceinline__ bool lm_traverse(const LmScene& sc, const lf3& o, con
                                             const LmStack& stack, LmHit& hit, uint32_t* cnt)
 {
     LmRayQ rq;
-    lm_ray_setup(sc, o, d, rq);
+    LmRayTri rt;
+    lm_ray_setup(sc, o, d, rq, rt);
     float hitT = tmax;
-    uint32_t hitOrder = 0xffffffffu;
     bool found = false;
     int sp = 0;
     int cur = 0;
@@ -410,11 +441,10 @@ __device__ __forceinline__ bool lm_traverse(const LmScene& sc, const lf3& o, con
         // leaf
         const uint32_t leaf = (uint32_t)(~cur);
         const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
-        lm_leaf_walk(sc.woop, first, count, o, d, tmin, tmax, [&](uint32_t slot, float t, float u, float v) {
+        lm_leaf_walk(sc.packets, first, count, rt, tmin, tmax, [&](uint32_t slot, float t, float u, float v) {
             if (ANY) { found = true; return true; }
-            const uint32_t order = sc.triOrder[slot];
-            if (t < hitT || (t == hitT && found && order < hitOrder)) {
-                hitT = t; hitOrder = order; found = true;
+            if (t < hitT || (t == hitT && found && sc.triOrder[slot] < sc.triOrder[hit.slot])) {      // (the tie-break keys are fetched on a tie only)
+                hitT = t; found = true;
                 hit.t = t; hit.u = u; hit.v = v; hit.slot = slot;
             }
             return false;
@@ -443,9 +473,9 @@ __device__ __forceinline__ bool lm_traverse_mixed(const LmScene& sc, const lf3& 
 {
     if (!valid) return false;
     LmRayQ rq;
-    lm_ray_setup(sc, o, d, rq);
+    LmRayTri rt;
+    lm_ray_setup(sc, o, d, rq, rt);
     float hitT = tmax;
-    uint32_t hitOrder = 0xffffffffu;
     bool found = false;
     int sp = 0;
     int cur = 0;
@@ -463,11 +493,10 @@ __device__ __forceinline__ bool lm_traverse_mixed(const LmScene& sc, const lf3& 
         if (cur == 0x7fffffff) break;
         const uint32_t leaf = (uint32_t)(~cur);
         const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
-        lm_leaf_walk(sc.woop, first, count, o, d, tmin, tmax, [&](uint32_t slot, float t, float u, float v) {
+        lm_leaf_walk(sc.packets, first, count, rt, tmin, tmax, [&](uint32_t slot, float t, float u, float v) {
             if (any) { found = true; return true; }
-            const uint32_t order = sc.triOrder[slot];
-            if (t < hitT || (t == hitT && found && order < hitOrder)) {
-                hitT = t; hitOrder = order; found = true;
+            if (t < hitT || (t == hitT && found && sc.triOrder[slot] < sc.triOrder[hit.slot])) {      // (the tie-break keys are fetched on a tie only)
+                hitT = t; found = true;
                 hit.t = t; hit.u = u; hit.v = v; hit.slot = slot;
             }
             return false;
@@ -524,7 +553,7 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
     lf3 o = v3(0.f), d = v3(0.f);
     float tmin = 0.f, tmax = 0.f, hitT = 0.f;
     LmRayQ rq = {(lm_f2){0.f, 0.f}, (lm_f2){0.f, 0.f}, (lm_f2){0.f, 0.f}, 0u, 0u, 0u, 0u, 0u, 0u};
-    uint32_t hitOrder = 0xffffffffu;
+    LmRayTri rt = {(lm_f2){0.f, 0.f}, 0.f, (lm_f2){0.f, 0.f}, 0.f, 0u};
     bool found = false;
     int sp = 0, cur = 0;
 #if LM_SPECULATE
@@ -538,11 +567,10 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
     auto testLeaf = [&](int ref) {
         const uint32_t leaf = (uint32_t)(~ref);
         const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
-        lm_leaf_walk(sc.woop, first, count, o, d, tmin, tmax, [&](uint32_t slot, float t, float u, float v) {
+        lm_leaf_walk(sc.packets, first, count, rt, tmin, tmax, [&](uint32_t slot, float t, float u, float v) {
             if (ANY) { found = true; return true; }
-            const uint32_t order = sc.triOrder[slot];
-            if (t < hitT || (t == hitT && found && order < hitOrder)) {
-                hitT = t; hitOrder = order; found = true;
+            if (t < hitT || (t == hitT && found && sc.triOrder[slot] < sc.triOrder[hit.slot])) {      // (the tie-break keys are fetched on a tie only)
+                hitT = t; found = true;
                 hit.t = t; hit.u = u; hit.v = v; hit.slot = slot;
             }
             return false;
@@ -567,8 +595,8 @@ __device__ __forceinline__ void lm_trace_queue(const LmScene& sc, uint32_t n, in
             if (!active && rank < give) {
                 rayIdx = base + used + rank;
                 fetch(rayIdx, o, d, tmin, tmax);
-                lm_ray_setup(sc, o, d, rq);
-                hitT = tmax; hitOrder = 0xffffffffu; found = false; sp = 0; cur = root;
+                lm_ray_setup(sc, o, d, rq, rt);
+                hitT = tmax; found = false; sp = 0; cur = root;
 #if LM_SPECULATE
                 pending = LM_REF_NONE;
 #endif
@@ -674,10 +702,10 @@ __device__ __forceinline__ void lm_trace_packets(const LmScene& sc, uint32_t n, 
         float tmin = 0.f, tmax = 0.f;
         if (valid) fetch(i, o, d, tmin, tmax);
         LmRayQ rq;
-        lm_ray_setup(sc, o, d, rq);
+        LmRayTri rt;
+        lm_ray_setup(sc, o, d, rq, rt);
         float hitT = valid ? tmax : -1.f;                          // a lane without a ray (or, any-hit, with its answer) fails every box test: tf < tmin
-        uint32_t hitOrder = 0xffffffffu;
-        bool found = false;
+            bool found = false;
         LmHit hit; hit.t = -1.f; hit.u = 0.f; hit.v = 0.f; hit.slot = 0;
         int sp = 0, cur = root;                                    // wave-uniform
         for (;;) {
@@ -740,7 +768,7 @@ __device__ __forceinline__ void lm_trace_packets(const LmScene& sc, uint32_t n, 
                     const uint4* nd = sc.nodes[cur].c;
 #ifndef LM_PACKET_SCALAR_NODE
 #define LM_PACKET_SCALAR_NODE 1    // 1: the wave-uniform 64-byte node record is fetched ONCE through the scalar cache (s_load_dwordx16) instead of by four vector loads in which
-#endif                             //    all 64 lanes ask for the same bytes (the compiler scalarises the leaf's Woop packets by itself, but not this load: `nodes` is written by the
+#endif                             //    all 64 lanes ask for the same bytes (the compiler scalarises the leaf's triangle packets by itself, but not this load: `nodes` is written by the
                                    //    refit kernels, so it carries no read-only guarantee).  Scalar caches are invalidated at kernel boundaries: a refit in an earlier launch is seen.
                                    //    A/B: profiles/r04_packet_scalar_ab.txt
 #if LM_PACKET_SCALAR_NODE && (defined(__gfx950__) || defined(__gfx942__) || defined(__gfx90a__))      // the mnemonic and the single lgkmcnt counter are gfx9's: any other ARCH takes the vector loads
@@ -782,14 +810,23 @@ __device__ __forceinline__ void lm_trace_packets(const LmScene& sc, uint32_t n, 
             // leaf: every lane tests its ray against the leaf's triangles (a lane that cannot hit any more has hitT < tmin and fails the interval test)
             const uint32_t leaf = (uint32_t)(~cur);
             const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
-            for (uint32_t k = 0; k < count; k++) {
-                float t, u, v;
-                if (lm_woop(sc.woop, first + k, o, d, tmin, ANY ? hitT : tmax, t, u, v) && hitT >= tmin) {
-                    if (ANY) { found = true; hitT = -1.f; continue; }
-                    const uint32_t order = sc.triOrder[first + k];
-                    if (t < hitT || (t == hitT && found && order < hitOrder)) {
-                        hitT = t; hitOrder = order; found = true;
-                        hit.t = t; hit.u = u; hit.v = v; hit.slot = first + k;
+            // the rays of a pixel tile almost always share their dominant axis, so the packet's three rows are selected wave-uniformly (scalar loads) and the
+            // few wavefronts that straddle a diagonal direction take the leaf once per axis present
+            unsigned long long todo = __ballot(true);
+            while (todo != 0ull) {
+                const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)rt.row, __ffsll((long long)todo) - 1);
+                const bool mine = rt.row == row;
+                todo &= ~__ballot(mine);
+                for (uint32_t k = 0; k < count; k++) {
+                    const char* base = (const char*)(sc.packets + first + k) + row;
+                    const LmV3 a = lm_load_v3(base), b = lm_load_v3(base + 20), c = lm_load_v3(base + 40);
+                    float t, u, v;
+                    if (mine && lm_tri_test(a, b, c, rt, tmin, ANY ? hitT : tmax, t, u, v) && hitT >= tmin) {
+                        if (ANY) { found = true; hitT = -1.f; continue; }
+                        if (t < hitT || (t == hitT && found && sc.triOrder[first + k] < sc.triOrder[hit.slot])) {
+                            hitT = t; found = true;
+                            hit.t = t; hit.u = u; hit.v = v; hit.slot = first + k;
+                        }
                     }
                 }
             }

@@ -37,6 +37,7 @@ int lumen_mi_create(lumen_mi_renderer** out)
     if (const char* e = getenv("LUMEN_MI_FAST_RESAMPLE")) (*out)->fastResample = atoi(e) != 0;
     if (const char* e = getenv("LUMEN_MI_WAVE_STREAMS")) (*out)->waveStreams = atoi(e) == 2 ? 2 : 1;
     if (const char* e = getenv("LUMEN_MI_TAIL_PAIR")) (*out)->tailPair = atoi(e);
+    if (const char* e = getenv("LUMEN_MI_TAIL_GRID")) (*out)->tailGrid = std::max(1, std::min(8, atoi(e)));      // (<= 8: the stack-spill area is sized for 8 blocks per CU)
     if (const char* e = getenv("LUMEN_MI_TAIL_LANES")) { const int v = atoi(e); (*out)->tailLanes = v <= 0 ? -1 : std::min(64, v); }
     return 0;
 }
@@ -535,6 +536,7 @@ int lumen_mi_copy_rect_device(lumen_mi_renderer* r, void* dst, uint32_t dstPitch
 {
     if (!r || !dst || !src) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");
     if (!w || !h || dstPitch < w || srcPitch < w) return fail(LUMEN_MI_ERR_INVALID, "empty rectangle or pitch smaller than the rectangle");
+    if ((uint64_t)w * h > 0xffffffffull) return fail(LUMEN_MI_ERR_INVALID, "rectangle of 2^32 pixels or more (the copy kernel indexes pixels with 32 bits)");
     ApiLock lk(r);
     if (!r->initialised) return fail(LUMEN_MI_ERR_STATE, "not initialised");
     if (hipSetDevice(r->device) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "hipSetDevice failed");

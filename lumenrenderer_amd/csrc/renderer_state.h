@@ -95,7 +95,7 @@ template <class T> struct HostBuf {                 // pinned staging memory for
 // refit kernels) on the wave stream, so frames keep overlapping while the scene changes.
 struct SceneSet {
     DevBuf<LmNodeW> top;                                                     // top-of-tree table of `nodes` (lm_k_build_top)
-    DevBuf<LmNodeW> nodes; DevBuf<LmWoop> woop; DevBuf<float> quant; DevBuf<LmEntry> entries; DevBuf<LmLight> lights; DevBuf<float> cdf;
+    DevBuf<LmNodeW> nodes; DevBuf<LmTriPacket> packets; DevBuf<float> quant; DevBuf<LmEntry> entries; DevBuf<LmLight> lights; DevBuf<float> cdf;
     DevBuf<uint2> triId; DevBuf<uint32_t> triOrder, levelNodes;            // topology of the tree in `nodes` (what an instance add / remove rewrites)
     std::vector<uint32_t> levelStart; uint32_t nTris = 0;
     HostBuf<LmEntry> hEntries; HostBuf<LmLight> hLights; HostBuf<float> hCdf;
@@ -103,7 +103,7 @@ struct SceneSet {
     hipEvent_t evUp = nullptr; bool upPending = false;      // the staging buffers are free again once this event has passed
     uint64_t entriesVer = 0, geomVer = 0, lightsVer = 0, topoVer = 0;    // state of the host scene this set holds
     void release() {
-        top.release(); nodes.release(); woop.release(); quant.release(); entries.release(); lights.release(); cdf.release();
+        top.release(); nodes.release(); packets.release(); quant.release(); entries.release(); lights.release(); cdf.release();
         triId.release(); triOrder.release(); levelNodes.release();
         hEntries.release(); hLights.release(); hCdf.release(); hNodes.release(); hTriId.release(); hOrder.release(); hLevelNodes.release();
         if (evUp) { (void)hipEventDestroy(evUp); evUp = nullptr; }
@@ -162,6 +162,7 @@ struct lumen_mi_renderer {
                                             // + 1.5 % on one box, - 3 % on two others (tiles - 6 ... - 8 %), toy frames + 24 %: off by default
     int tailPair = -1;                      // path tail in pair mode (shadow ray of depth d traced by a partner lane beside the closest-hit query of depth d + 1):
                                             // 1 on (at most 32 paths per wavefront), 0 off, -1 automatic: on for windows under 1.5 Mpixel
+    int tailGrid = 8;                       // blocks per CU of the path-tail launch (environment LUMEN_MI_TAIL_GRID: A/B knob, profiles/r06_tail_grid_ab.txt)
     int tailLanes = -1;                     // ... with this many paths per wavefront (-1 = auto: 64 for windows from 0.75 Mpixel, where the tail hides behind
                                             // the other streams and fuller wavefronts save VALU issue slots; 16 for smaller windows, where the tail IS the critical path)
     uint32_t* pinnedCounters[2] = {nullptr, nullptr}; hipEvent_t evCnt[2] = {nullptr, nullptr}; bool cntPending[2] = {false, false};

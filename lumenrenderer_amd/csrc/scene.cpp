@@ -85,12 +85,12 @@ int refreshEntries(R* r)
 // (traceFrameAsync), so nothing in flight reads what is overwritten here.  No host synchronisation except for the reuse of
 // a staging buffer whose previous copy (two scene states ago) has not finished yet.
 // boxes and Woop packets of a scene set from its topology and the instance table: triangles re-transformed, packets recomputed (bit-identical to the host builder:
-// lm_woop.h), boxes propagated bottom-up level by level and quantised against the scene box (kernels.hip lm_k_refit_*), top-of-tree table rebuilt
+// lm_tri.h), boxes propagated bottom-up level by level and quantised against the scene box (kernels.hip lm_k_refit_*), top-of-tree table rebuilt
 static int refitSet(R* r, SceneSet& T, hipStream_t su)
 {
     const LmKernelTable* K = r->K;
     LmScene sc = r->dscene;
-    sc.nodes = T.nodes.p; sc.woop = T.woop.p; sc.quant = T.quant.p; sc.entries = T.entries.p; sc.numEntries = (uint32_t)r->entries.size(); sc.triId = T.triId.p; sc.triOrder = T.triOrder.p;
+    sc.nodes = T.nodes.p; sc.packets = T.packets.p; sc.quant = T.quant.p; sc.entries = T.entries.p; sc.numEntries = (uint32_t)r->entries.size(); sc.triId = T.triId.p; sc.triOrder = T.triOrder.p;
     const uint32_t nt = T.nTris;
     if (r->dTriBox.ensure(2 * (size_t)nt + 2) || r->dNodeBox.ensure(2 * std::max<size_t>(T.nodes.cap, 1))) return fail(LUMEN_MI_ERR_DEVICE, "refit buffer allocation failed");
     K->refit_tris(su, sc, nt, r->dTriBox.p, r->dRefitBounds.p);
@@ -118,14 +118,14 @@ int syncScene(R* r, hipStream_t su)
             const LmBvh& b = r->bvh;
             const size_t nn = b.nodesW.size(), ns = b.order.size(), nl = b.levelNodes.size();
             if (T.hNodes.ensure(nn) || T.hTriId.ensure(ns) || T.hOrder.ensure(ns) || T.hLevelNodes.ensure(nl) || T.nodes.ensure(nn) || T.triId.ensure(ns) ||
-                T.triOrder.ensure(ns) || T.levelNodes.ensure(nl) || T.woop.ensure(ns + 1) || T.quant.ensure(8))
+                T.triOrder.ensure(ns) || T.levelNodes.ensure(nl) || T.packets.ensure(ns + 1) || T.quant.ensure(8))
                 return fail(LUMEN_MI_ERR_DEVICE, "scene tree allocation failed");
             memcpy(T.hNodes.p, b.nodesW.data(), nn * sizeof(LmNodeW)); memcpy(T.hTriId.p, r->triId.data(), ns * sizeof(uint2));
             memcpy(T.hOrder.p, b.order.data(), ns * sizeof(uint32_t)); memcpy(T.hLevelNodes.p, b.levelNodes.data(), nl * sizeof(uint32_t));
             LM_HIP(hipMemcpyAsync(T.nodes.p, T.hNodes.p, nn * sizeof(LmNodeW), hipMemcpyHostToDevice, su));
             if (ns) { LM_HIP(hipMemcpyAsync(T.triId.p, T.hTriId.p, ns * sizeof(uint2), hipMemcpyHostToDevice, su)); LM_HIP(hipMemcpyAsync(T.triOrder.p, T.hOrder.p, ns * sizeof(uint32_t), hipMemcpyHostToDevice, su)); }
             if (nl) LM_HIP(hipMemcpyAsync(T.levelNodes.p, T.hLevelNodes.p, nl * sizeof(uint32_t), hipMemcpyHostToDevice, su));
-            LM_HIP(hipMemsetAsync(T.woop.p + ns, 0, sizeof(LmWoop), su));            // sentinel packet
+            LM_HIP(hipMemsetAsync(T.packets.p + ns, 0, sizeof(LmTriPacket), su));            // sentinel packet
             T.levelStart = b.levelStart; T.nTris = (uint32_t)ns;
             T.topoVer = r->topoVer; T.geomVer = 0;                  // no boxes yet
             copied = true;
@@ -156,7 +156,7 @@ int syncScene(R* r, hipStream_t su)
         r->sgen ^= 1;
     }
     const SceneSet& S = r->sset[r->sgen];
-    r->dscene.nodes = S.nodes.p; r->dscene.woop = S.woop.p; r->dscene.quant = S.quant.p; r->dscene.entries = S.entries.p; r->dscene.numEntries = (uint32_t)r->entries.size();
+    r->dscene.nodes = S.nodes.p; r->dscene.packets = S.packets.p; r->dscene.quant = S.quant.p; r->dscene.entries = S.entries.p; r->dscene.numEntries = (uint32_t)r->entries.size();
     r->dscene.triId = S.triId.p; r->dscene.triOrder = S.triOrder.p; r->dscene.top = S.top.p;
     r->dscene.lights = S.lights.p; r->dscene.cdf = S.cdf.p;
     return 0;
@@ -206,7 +206,7 @@ int flatten(R* r)
                 mesh.bvh = std::make_shared<LmBvh>();
                 lm_build_bvh(local.data(), mesh.tris, mesh.bvh.get());
                 // the assembly only needs the 4-wide topology and the triangle order: drop the binary tree, packets and level lists
-                std::vector<LmNode>().swap(mesh.bvh->nodes); std::vector<LmWoop>().swap(mesh.bvh->woop);
+                std::vector<LmNode>().swap(mesh.bvh->nodes); std::vector<LmTriPacket>().swap(mesh.bvh->packets);
                 std::vector<uint32_t>().swap(mesh.bvh->levelNodes); std::vector<uint32_t>().swap(mesh.bvh->levelStart);
                 for (int a = 0; a < 3; a++) { mesh.lo[a] = INFINITY; mesh.hi[a] = -INFINITY; }
                 for (size_t f = 0; f < local.size(); f++) { mesh.lo[f % 3] = std::min(mesh.lo[f % 3], local[f]); mesh.hi[f % 3] = std::max(mesh.hi[f % 3], local[f]); }
@@ -310,10 +310,10 @@ int flatten(R* r)
         S.entriesVer = r->entriesVer; S.geomVer = r->geomVer; S.topoVer = r->topoVer;
         if (gpuBuilt) {
             // the device builder produced the topology only: packets and boxes by the refit kernels, as after an instance-level assembly
-            if (S.woop.ensure((size_t)nt + 1) || hipMemsetAsync(S.woop.p + nt, 0, sizeof(LmWoop), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "packet allocation failed");
+            if (S.packets.ensure((size_t)nt + 1) || hipMemsetAsync(S.packets.p + nt, 0, sizeof(LmTriPacket), st) != hipSuccess) return fail(LUMEN_MI_ERR_DEVICE, "packet allocation failed");
             int rcr = refitSet(r, S, st); if (rcr) return rcr;
         } else {
-            if (S.woop.upload(r->bvh.woop, st)) return fail(LUMEN_MI_ERR_DEVICE, "scene upload failed (hipMalloc/hipMemcpy)");
+            if (S.packets.upload(r->bvh.packets, st)) return fail(LUMEN_MI_ERR_DEVICE, "scene upload failed (hipMalloc/hipMemcpy)");
             if (S.top.ensure(LM_TOP_NODES + 1)) return fail(LUMEN_MI_ERR_DEVICE, "top table allocation failed");
             r->K->build_top(st, S.nodes.p, S.top.p);
         }
@@ -325,7 +325,7 @@ int flatten(R* r)
     r->dscene.verts = r->dVerts.p; r->dscene.indices = r->dIndices.p;
     {
         const SceneSet& S = r->sset[r->sgen];
-        r->dscene.nodes = S.nodes.p; r->dscene.woop = S.woop.p; r->dscene.quant = S.quant.p; r->dscene.entries = S.entries.p; r->dscene.numEntries = (uint32_t)r->entries.size();
+        r->dscene.nodes = S.nodes.p; r->dscene.packets = S.packets.p; r->dscene.quant = S.quant.p; r->dscene.entries = S.entries.p; r->dscene.numEntries = (uint32_t)r->entries.size();
         r->dscene.triId = S.triId.p; r->dscene.triOrder = S.triOrder.p; r->dscene.top = S.top.p;
     }
     r->sceneDirty = false;

@@ -14,32 +14,20 @@ import math
 HALO = 60
 
 
+def _plan(rank, n, width, height):
+    from . import group
+    return group.plan(width, height, n, rank)
+
+
 def grid_for(n, width, height):
     """cols x rows with cols*rows == n whose LARGEST rank window (tile + halo, clipped to the image) is smallest: the frame time
-    of the slowest rank is what the gather waits for."""
-    best = None
-    for cols in range(1, n + 1):
-        if n % cols:
-            continue
-        rows = n // cols
-        worst = 0
-        for cy in range(rows):
-            for cx in range(cols):
-                x0, x1 = (width * cx) // cols, (width * (cx + 1)) // cols
-                y0, y1 = (height * cy) // rows, (height * (cy + 1)) // rows
-                wx0, wy0, wx1, wy1 = max(0, x0 - HALO), max(0, y0 - HALO), min(width, x1 + HALO), min(height, y1 + HALO)
-                worst = max(worst, (wx1 - wx0) * (wy1 - wy0))
-        if best is None or worst < best[0]:
-            best = (worst, cols, rows)
-    return best[1], best[2]
+    of the slowest rank is what the gather waits for.  One implementation: csrc/group.cpp (lumen_mi_group_plan)."""
+    p = _plan(0, n, width, height)
+    return p["cols"], p["rows"]
 
 
 def tile_rect(rank, n, width, height):
-    cols, rows = grid_for(n, width, height)
-    cx, cy = rank % cols, rank // cols
-    x0, x1 = (width * cx) // cols, (width * (cx + 1)) // cols
-    y0, y1 = (height * cy) // rows, (height * (cy + 1)) // rows
-    return x0, y0, x1, y1
+    return _plan(rank, n, width, height)["tile"]
 
 
 def window_rect(tile, width, height, halo=HALO):
@@ -48,8 +36,8 @@ def window_rect(tile, width, height, halo=HALO):
 
 
 def max_tile_shape(n, width, height):
-    rects = [tile_rect(r, n, width, height) for r in range(n)]
-    return max(r[3] - r[1] for r in rects), max(r[2] - r[0] for r in rects)
+    w, h = _plan(0, n, width, height)["max_tile"]
+    return h, w
 
 
 class TileGather:
@@ -85,7 +73,12 @@ class TileGather:
     def run_renderer(self, renderer, dist):
         """The per-frame form: the rank's tile goes from the renderer's merged radiance straight into the send buffer, and on ``dst`` the gathered tiles into the
         assembled image, by the renderer library's own pitched-copy kernel on the renderer's stream (LumenRendererMI.CopyRadianceRectToDevice / CopyRectDevice) — no
-        window-sized intermediate and no framework kernel in the frame path.  Returns the assembled image on ``dst``, None elsewhere."""
+        window-sized intermediate and no framework kernel in the frame path.  Returns the assembled image on ``dst``, None elsewhere.
+        PRECONDITION: the renderer's stream is torch's current stream (``renderer.set_stream(torch.cuda.current_stream().cuda_stream)``): ``dist.gather`` orders itself
+        against torch's current stream only, so a renderer on a stream of its own would have a half-written send tile gathered.  RGBA32F only (16 bytes per pixel).
+        The native tile group (lumenrenderer_amd.group.TileGroup, csrc/group.cpp) has neither restriction and overlaps the gather with the next frame."""
+        import torch
+        assert self.send.dtype == torch.float32, "run_renderer moves RGBA32F pixels"
         x0, y0, x1, y1 = self.tile
         if self.world == 1:
             renderer.CopyRadianceRectToDevice(self.tile, self.image.data_ptr() + (y0 * self.width + x0) * 16, self.width)
@@ -128,27 +121,13 @@ def gather_from_renderer(renderer, rank, world, width, height, dist, device, dst
 HISTORY_FLOATS = 20        # per pixel: the 64-byte reservoir record + the contribution plane (include/lumen_mi.h lumen_mi_export_history)
 
 
-def _intersect(a, b):
-    x0, y0, x1, y1 = max(a[0], b[0]), max(a[1], b[1]), min(a[2], b[2]), min(a[3], b[3])
-    return (x0, y0, x1, y1) if x0 < x1 and y0 < y1 else None
-
-
 def halo_plan(rank, n, width, height):
     """What rank exchanges after every frame so that temporal reuse in its halo ring sees the owners' reservoirs: a list of
     (peer, send_rect, recv_rect) in global pixels — send = my tile inside the peer's window, recv = the peer's tile inside my
-    window (either may be None).  The halo ring of a window is the disjoint union of the recv rectangles."""
-    mine = tile_rect(rank, n, width, height)
-    my_window = window_rect(mine, width, height)
-    plan = []
-    for peer in range(n):
-        if peer == rank:
-            continue
-        theirs = tile_rect(peer, n, width, height)
-        send = _intersect(mine, window_rect(theirs, width, height))
-        recv = _intersect(theirs, my_window)
-        if send or recv:
-            plan.append((peer, send, recv))
-    return plan
+    window (either may be None).  The halo ring of a window is the disjoint union of the recv rectangles.  One implementation:
+    csrc/group.cpp (lumen_mi_group_seams)."""
+    from . import group
+    return group.seams(width, height, n, rank)
 
 
 def history_needed(depth):

@@ -8,7 +8,8 @@
 //   D3 light sort is stable on (mean radiance, build order); the CDF prefix sum is accumulated in double and
 //      rounded to float per entry (thrust order is unspecified);
 //   D4 closest hit = minimum t, ties broken by lower global triangle index; hit interval is tmin < t < tmax;
-//      ray/triangle test is the Woop unit-triangle form on world-space triangles (OptiX is closed source);
+//      ray/triangle test is the watertight test of Woop, Benthin, Wald (JCGT 2013) on world-space triangles (OptiX is closed
+//      source; like it, the test lets no ray pass between triangles that share an edge or a vertex);
 //   D5 uninitialised reads in the reference are defined as zero; camera "previous matrix" of the first frame
 //      equals the current one;
 //   D6 texture filtering is exact fp32 bilinear (CUDA uses 8-bit fixed-point weights), sRGB decode per texel.
@@ -74,7 +75,6 @@ struct TableEntry {                                                       // Dev
 };
 struct MeshInstance { int mesh; float M[16]; int mode; f3 overrideRadiance; float scale; int overrideMaterial; std::vector<int> entries; };
 
-struct Woop { float r0[4], r1[4], r2[4]; };
 struct BvhNode { float lo[3], hi[3]; int left, right; uint32_t first, count; };
 
 // ----------------------------------------------------------------------------------------------------------
@@ -132,7 +132,6 @@ struct orc_ctx {
     // geometry the tracer sees
     std::vector<f3> worldTris;                 // 3 per triangle
     std::vector<uint32_t> triEntry, triPrim;   // global triangle -> (table entry, primitive-local index)
-    std::vector<Woop> woop;
     std::vector<BvhNode> bvh; std::vector<uint32_t> bvhTris;
     float bvhPad = 0.f;
 
@@ -236,44 +235,58 @@ static f4 tex2D(const orc_ctx* c, int id, float u, float v)
 }
 
 // ----------------------------------------------------------------------------------------------------------
-// Scene flattening: world-space triangle soup + Woop packets + a simple median-split BVH  (D4)
+// Scene flattening: world-space triangle soup + a simple median-split BVH  (D4)
 // ----------------------------------------------------------------------------------------------------------
-static Woop make_woop(const f3& a, const f3& b, const f3& c)
+// Ray / triangle test (D4).  The reference's queries run on OptiX triangle GASes (OptixWrapper.cpp:46-131, WaveFrontShaders.cu:63-76), whose traversal
+// is closed source but WATERTIGHT: a ray cannot pass between two triangles that share an edge or a vertex.  The restatement therefore uses the
+// published watertight test — Woop, Benthin, Wald, "Watertight Ray/Triangle Intersection", JCGT 2(1), 2013 — on the world-space vertices themselves:
+// translate the triangle to the ray origin, permute the axes so that kz is the ray's dominant one, shear x and y along z (Sx = d[kx] / d[kz], ...) and
+// evaluate the three 2-D edge functions U, V, W.  Every 2-D point is a function of (vertex, ray) only, so two triangles that share a vertex see
+// the same point, and the sign of fl(a b) - fl(c d) is never wrong (rounding is monotonic), only possibly zero.  A zero is resolved EXACTLY: with
+// p = fl(a b) == q = fl(c d), a b - c d = (a b - p) - (c d - q), both product errors are binary32 numbers that one fma each delivers, and the sign of
+// their difference is exact (the paper falls back to double there; the error-free transformation decides the same sign without leaving fp32).  The 2-D
+// inside test is thus EXACT on the points it is given, which is what makes shared edges and vertices watertight.  Differences to the paper's listing,
+// none of which touches that argument: kx / ky are not swapped for negative d[kz] (no back-face culling here: the winding is irrelevant), the sheared
+// coordinate is one fma, Sx = d[kx] * (1 / d[kz]), and t = T * (1 / det).
+// Operation order is part of the definition (the device code, csrc/lm_traverse.h lm_tri_test, performs the same fp32 operations).
+struct RayTri { float ox, oy, oz, sx, sy, sz; int kx, ky, kz; };
+static inline float safe_rcp(float d) { const float ooeps = 1e-20f; return 1.0f / (fabsf(d) > ooeps ? d : copysignf(ooeps, d)); }
+static inline float pick(const f3& a, int k) { return k == 0 ? a.x : k == 1 ? a.y : a.z; }
+static inline RayTri ray_tri(const f3& o, const f3& d)
 {
-    const double v0[3] = {a.x, a.y, a.z};
-    const double e1[3] = {(double)b.x - a.x, (double)b.y - a.y, (double)b.z - a.z};
-    const double e2[3] = {(double)c.x - a.x, (double)c.y - a.y, (double)c.z - a.z};
-    const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
-    const double det = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
-    Woop w; memset(&w, 0, sizeof w);
-    if (!(det > 0.0) || !std::isfinite(det)) return w;     // degenerate: all-zero packet never hits
-    const double ru[3] = {e2[1] * n[2] - e2[2] * n[1], e2[2] * n[0] - e2[0] * n[2], e2[0] * n[1] - e2[1] * n[0]};
-    const double rv[3] = {n[1] * e1[2] - n[2] * e1[1], n[2] * e1[0] - n[0] * e1[2], n[0] * e1[1] - n[1] * e1[0]};
-    double du = 0, dv = 0, dw = 0;
-    for (int i = 0; i < 3; i++) {
-        w.r0[i] = (float)(ru[i] / det); w.r1[i] = (float)(rv[i] / det); w.r2[i] = (float)(n[i] / det);
-        du -= ru[i] / det * v0[i]; dv -= rv[i] / det * v0[i]; dw -= n[i] / det * v0[i];
-    }
-    w.r0[3] = (float)du; w.r1[3] = (float)dv; w.r2[3] = (float)dw;
-    return w;
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    RayTri r;
+    r.kz = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+    r.kx = (r.kz + 1) % 3; r.ky = (r.kz + 2) % 3;
+    r.ox = pick(o, r.kx); r.oy = pick(o, r.ky); r.oz = pick(o, r.kz);
+    r.sz = safe_rcp(pick(d, r.kz));
+    r.sx = pick(d, r.kx) * r.sz; r.sy = pick(d, r.ky) * r.sz;
+    return r;
 }
-
-// ray/triangle test on a Woop packet; returns true and (t,u,v) for tmin < t < tmax
-static inline bool woop_hit(const Woop& w, const f3& o, const f3& d, float tmin, float tmax, float& t, float& u, float& v)
+// a b - c d with an exact sign: the rounded difference unless it is zero, then the difference of the two products' rounding errors
+static inline float edge_fn(float a, float b, float c, float d)
 {
-    const float Oz = fmaf(w.r2[0], o.x, fmaf(w.r2[1], o.y, fmaf(w.r2[2], o.z, w.r2[3])));
-    const float Dz = fmaf(w.r2[0], d.x, fmaf(w.r2[1], d.y, w.r2[2] * d.z));
-    t = -Oz / Dz;
+    const float p = a * b, q = c * d;
+    const float e = p - q;
+    return e != 0.f ? e : fmaf(a, b, -p) - fmaf(c, d, -q);
+}
+// returns true and (t, u, v) for tmin < t < tmax; u / v = barycentric weight of the second / third vertex
+static inline bool tri_hit(const f3* tv, const RayTri& r, float tmin, float tmax, float& t, float& u, float& v)
+{
+    const float az = pick(tv[0], r.kz) - r.oz, bz = pick(tv[1], r.kz) - r.oz, cz = pick(tv[2], r.kz) - r.oz;
+    const float Ax = fmaf(-r.sx, az, pick(tv[0], r.kx) - r.ox), Ay = fmaf(-r.sy, az, pick(tv[0], r.ky) - r.oy);
+    const float Bx = fmaf(-r.sx, bz, pick(tv[1], r.kx) - r.ox), By = fmaf(-r.sy, bz, pick(tv[1], r.ky) - r.oy);
+    const float Cx = fmaf(-r.sx, cz, pick(tv[2], r.kx) - r.ox), Cy = fmaf(-r.sy, cz, pick(tv[2], r.ky) - r.oy);
+    const float U = edge_fn(Cx, By, Cy, Bx), V = edge_fn(Ax, Cy, Ay, Cx), W = edge_fn(Bx, Ay, By, Ax);
+    if ((U < 0.f || V < 0.f || W < 0.f) && (U > 0.f || V > 0.f || W > 0.f)) return false;
+    const float det = U + V + W;
+    if (det == 0.f) return false;
+    const float T = fmaf(W, r.sz * cz, fmaf(V, r.sz * bz, U * (r.sz * az)));
+    const float rdet = 1.0f / det;
+    t = T * rdet;
     if (!(t > tmin && t < tmax)) return false;
-    const float Ox = fmaf(w.r0[0], o.x, fmaf(w.r0[1], o.y, fmaf(w.r0[2], o.z, w.r0[3])));
-    const float Dx = fmaf(w.r0[0], d.x, fmaf(w.r0[1], d.y, w.r0[2] * d.z));
-    u = fmaf(t, Dx, Ox);
-    if (!(u >= 0.0f)) return false;
-    const float Oy = fmaf(w.r1[0], o.x, fmaf(w.r1[1], o.y, fmaf(w.r1[2], o.z, w.r1[3])));
-    const float Dy = fmaf(w.r1[0], d.x, fmaf(w.r1[1], d.y, w.r1[2] * d.z));
-    v = fmaf(t, Dy, Oy);
-    if (!(v >= 0.0f)) return false;
-    return u + v <= 1.0f;
+    u = V * rdet; v = W * rdet;
+    return true;
 }
 
 static int build_bvh(orc_ctx* c, std::vector<uint32_t>& ids, uint32_t first, uint32_t count, const std::vector<f3>& cen)
@@ -328,7 +341,7 @@ void orc_ctx::flatten()
             table.push_back(e);
         }
     }
-    worldTris.clear(); triEntry.clear(); triPrim.clear(); woop.clear();
+    worldTris.clear(); triEntry.clear(); triPrim.clear();
     float maxAbs = 0.f;
     for (size_t e = 0; e < table.size(); e++) {
         const Primitive& pr = prims[table[e].prim];
@@ -341,7 +354,6 @@ void orc_ctx::flatten()
                 worldTris.push_back(wp[k]);
             }
             triEntry.push_back((uint32_t)e); triPrim.push_back((uint32_t)(t / 3));
-            woop.push_back(make_woop(wp[0], wp[1], wp[2]));
         }
     }
     const uint32_t nt = (uint32_t)triEntry.size();
@@ -372,14 +384,15 @@ struct HitRec { float t, u, v; uint32_t tri; bool hit; };
 static HitRec closest_hit(const orc_ctx* c, const f3& o, const f3& d, float tmin, float tmax, bool useBvh)
 {
     HitRec best{tmax, 0, 0, 0xffffffffu, false};
+    const RayTri rp = ray_tri(o, d);
     auto test = [&](uint32_t tri) {
         float t, u, v;
-        if (woop_hit(c->woop[tri], o, d, tmin, tmax, t, u, v)) {
+        if (tri_hit(&c->worldTris[3 * (size_t)tri], rp, tmin, tmax, t, u, v)) {
             if (t < best.t || (t == best.t && best.hit && tri < best.tri)) { best = HitRec{t, u, v, tri, true}; }
         }
     };
     if (!useBvh || c->bvh.empty()) {
-        for (uint32_t tri = 0; tri < c->woop.size(); tri++) test(tri);
+        for (uint32_t tri = 0; tri < c->triEntry.size(); tri++) test(tri);
         return best;
     }
     const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -395,8 +408,9 @@ static HitRec closest_hit(const orc_ctx* c, const f3& o, const f3& d, float tmin
 static bool any_hit(const orc_ctx* c, const f3& o, const f3& d, float tmin, float tmax, bool useBvh)
 {
     float t, u, v;
+    const RayTri rp = ray_tri(o, d);
     if (!useBvh || c->bvh.empty()) {
-        for (uint32_t tri = 0; tri < c->woop.size(); tri++) if (woop_hit(c->woop[tri], o, d, tmin, tmax, t, u, v)) return true;
+        for (uint32_t tri = 0; tri < c->triEntry.size(); tri++) if (tri_hit(&c->worldTris[3 * (size_t)tri], rp, tmin, tmax, t, u, v)) return true;
         return false;
     }
     const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -404,7 +418,7 @@ static bool any_hit(const orc_ctx* c, const f3& o, const f3& d, float tmin, floa
     while (sp) {
         const BvhNode& n = c->bvh[stack[--sp]];
         if (!slab(n, o, inv, tmin, tmax)) continue;
-        if (n.left < 0) { for (uint32_t i = 0; i < n.count; i++) if (woop_hit(c->woop[c->bvhTris[n.first + i]], o, d, tmin, tmax, t, u, v)) return true; }
+        if (n.left < 0) { for (uint32_t i = 0; i < n.count; i++) if (tri_hit(&c->worldTris[3 * (size_t)c->bvhTris[n.first + i]], rp, tmin, tmax, t, u, v)) return true; }
         else { stack[sp++] = n.left; stack[sp++] = n.right; }
     }
     return false;

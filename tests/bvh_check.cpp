@@ -3,12 +3,12 @@
 //   structure    : the triangle order is a permutation; the leaves of the 4-wide tree partition the slots; every quantised child
 //                  box contains the triangles below it; the refit level lists are bottom-up and complete; the reported worst-case
 //                  stack occupancy covers the tree and fits the kernels' stack
-//   Woop packets : bit-identical to lm_make_woop (the function the GPU refit runs) of the ordered triangle, zero sentinel
+//   Woop packets : bit-identical to lm_make_packet (the function the GPU refit runs) of the ordered triangle, zero sentinel
 //   determinism  : 1 thread and N threads produce the same bytes
 //   assembly     : lm_assemble_bvh (instance-level trees for topology edits) passes the same structural checks
 // usage: bvh_check <threads> <nTris>...      prints "ok <n> ..." per size, exits non-zero on the first violation
 #include "bvh.h"
-#include "lm_woop.h"
+#include "lm_tri.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -90,12 +90,12 @@ int check(const LmBvh& b, const float* tris, uint32_t n, bool built = true)
     std::vector<uint8_t> seen(n, 0);
     for (uint32_t s = 0; s < n; s++) { if (b.order[s] >= n || seen[b.order[s]]++) return fail("order is not a permutation", s); }
     if (b.nodesW.empty()) return fail("no root node");
-    if (b.woop.size() != (size_t)n + 1) return fail("woop packet count", (long)b.woop.size());
+    if (b.packets.size() != (size_t)n + 1) return fail("packets packet count", (long)b.packets.size());
     for (uint32_t s = 0; built && s < n; s++) {
-        const LmWoop w = lm_make_woop(tris + 9 * (size_t)b.order[s]);
-        if (memcmp(&w, &b.woop[s], sizeof w) != 0) return fail("woop packet differs from lm_make_woop", s);
+        const LmTriPacket w = lm_make_packet(tris + 9 * (size_t)b.order[s]);
+        if (memcmp(&w, &b.packets[s], sizeof w) != 0) return fail("packets packet differs from lm_make_packet", s);
     }
-    { LmWoop z; memset(&z, 0, sizeof z); if (memcmp(&z, &b.woop[n], sizeof z) != 0) return fail("sentinel packet is not zero"); }
+    { LmTriPacket z; memset(&z, 0, sizeof z); if (memcmp(&z, &b.packets[n], sizeof z) != 0) return fail("sentinel packet is not zero"); }
     Walk w(b, tris);
     w.boxes = built;
     double lo[3], hi[3];
@@ -125,7 +125,7 @@ int check(const LmBvh& b, const float* tris, uint32_t n, bool built = true)
 bool same(const LmBvh& a, const LmBvh& b)
 {
     auto eq = [](const auto& x, const auto& y) { return x.size() == y.size() && (x.empty() || memcmp(x.data(), y.data(), x.size() * sizeof(x[0])) == 0); };
-    return eq(a.nodesW, b.nodesW) && eq(a.order, b.order) && eq(a.woop, b.woop) && eq(a.levelNodes, b.levelNodes) && eq(a.levelStart, b.levelStart) &&
+    return eq(a.nodesW, b.nodesW) && eq(a.order, b.order) && eq(a.packets, b.packets) && eq(a.levelNodes, b.levelNodes) && eq(a.levelStart, b.levelStart) &&
            memcmp(a.qmin, b.qmin, sizeof a.qmin) == 0 && memcmp(a.qstep, b.qstep, sizeof a.qstep) == 0 && a.pad == b.pad && a.maxStack == b.maxStack && a.maxDepth == b.maxDepth;
 }
 

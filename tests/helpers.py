@@ -84,7 +84,7 @@ def build_c_example(tmp_path):
     exe = str(tmp_path / "render_scene")
     libdir = os.path.join(ROOT, "lumenrenderer_amd")
     cmd = ["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-O2", "-I" + os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "examples", "render_scene.c"), "-o", exe, "-L" + libdir, "-llumen_mi", "-Wl,-rpath," + libdir]
+           os.path.join(ROOT, "examples", "render_scene.c"), "-o", exe, "-L" + libdir, "-llumen_mi", "-lm", "-Wl,-rpath," + libdir]
     build = subprocess.run(cmd, capture_output=True, text=True)
     assert build.returncode == 0, build.stderr[-3000:]
     return exe

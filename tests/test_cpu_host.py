@@ -194,6 +194,81 @@ def test_tile_partition_covers_the_image():
     assert tiles.grid_for(8, 3840, 2160) == (4, 2)
 
 
+def test_native_tile_plan_equals_the_python_restatement():
+    """lumen_mi_group_plan / lumen_mi_group_seams (csrc/group.cpp: the ONE implementation; lumenrenderer_amd/tiles.py calls into it) against tests/tile_plan_ref.py, the plain
+    Python plan rounds 1 - 5 shipped: grid, tile, window, common send-tile shape and the seam plan of every rank, for BASELINE's sizes, ragged sizes and worlds 1 .. 8; bad
+    arguments are refused with a message."""
+    import tile_plan_ref as ref
+    from lumenrenderer_amd import capi, group, tiles
+    lib = capi.load_library()
+    for W, H in ((2560, 1440), (3840, 2160), (1920, 1080), (1280, 720), (320, 256), (257, 131), (61, 59), (8, 8)):
+        for n in (1, 2, 3, 4, 5, 6, 7, 8):
+            assert tiles.grid_for(n, W, H) == ref.grid_for(n, W, H) and tiles.max_tile_shape(n, W, H) == ref.max_tile_shape(n, W, H)
+            for r in range(n):
+                p = group.plan(W, H, n, r)
+                t = ref.tile_rect(r, n, W, H)
+                assert p["tile"] == t and p["window"] == ref.window_rect(t, W, H) and p["halo"] == ref.HALO == tiles.HALO
+                assert group.seams(W, H, n, r) == ref.halo_plan(r, n, W, H)
+    plan = capi.TilePlan()
+    for args in ((0, 10, 1, 0), (10, 0, 1, 0), (10, 10, 0, 0), (10, 10, 2, 2), (2, 2, 8, 0)):
+        assert lib.lumen_mi_group_plan(*args, plan) == capi.ERR_INVALID and lib.lumen_mi_last_error()
+    with pytest.raises(capi.LumenMIError):
+        group.plan(3, 1, 4, 0)                    # more ranks than pixels
+
+
+_TRANSPORT_WORKER = r'''
+import ctypes as C, os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch.distributed as dist
+from lumenrenderer_amd import capi, group
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+t = group.DistHostTransport(dist)
+# every rank sends a distinct block to every other rank and receives theirs, in ONE exchange call (what the seam step of csrc/group.cpp posts)
+n = 4099
+send = {p: np.full(n, 16 * rank + p, np.uint8) for p in range(world) if p != rank}
+recv = {p: np.zeros(n, np.uint8) for p in range(world) if p != rank}
+ops = (capi.TransportOp * (2 * (world - 1)))()
+k = 0
+for p in sorted(send):
+    ops[k] = capi.TransportOp(p, 0, recv[p].ctypes.data, n); k += 1
+    ops[k] = capi.TransportOp(p, 1, send[p].ctypes.data, n); k += 1
+assert t.struct.exchange(None, k, ops) == 0, t.errors
+for p in recv:
+    assert (recv[p] == 16 * p + rank).all(), (rank, p, recv[p][:4])
+# gather shape: everybody to rank 0
+buf = np.full(1000, rank, np.uint8)
+parts = np.zeros((world, 1000), np.uint8)
+if rank == 0:
+    g = (capi.TransportOp * (world - 1))(*[capi.TransportOp(p, 0, parts[p].ctypes.data, 1000) for p in range(1, world)])
+    assert t.struct.exchange(None, world - 1, g) == 0
+    assert all((parts[p] == p).all() for p in range(1, world))
+else:
+    g = (capi.TransportOp * 1)(capi.TransportOp(0, 1, buf.ctypes.data, 1000))
+    assert t.struct.exchange(None, 1, g) == 0
+v = C.c_int32(10 * rank + 3)
+assert t.struct.allreduce_max_i32(None, C.byref(v)) == 0 and v.value == 10 * (world - 1) + 3
+dist.barrier()
+if rank == 0:
+    open(sys.argv[2], "w").write("ok")
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_group_host_transport_callbacks_gloo(world, tmp_path):
+    """The host transport the suite injects into the native tile group (lumenrenderer_amd.group.DistHostTransport = lumen_mi_transport over gloo point-to-point calls), called
+    through its C function pointers between real processes: an all-to-all exchange posted as ONE call, a gather to rank 0, the MAX all-reduce."""
+    script = tmp_path / "transport_worker.py"; script.write_text(_TRANSPORT_WORKER)
+    out = tmp_path / "ok.txt"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
+           "--master-port", str(29525 + world), str(script), ROOT]
+    res = subprocess.run(cmd + [str(out)], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert os.path.exists(out)
+
+
 _WORKER = r'''
 import os, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))

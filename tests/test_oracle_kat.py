@@ -540,3 +540,43 @@ def test_texture_filter_follows_the_published_cuda_rule():
     got = o.tex2d(t, uv).astype(np.float64)
     assert np.abs(got - tex_rule.guide_tex2d(px, srgb, uv, quantise=False)).max() <= 2e-5      # u N - 0.5 without frac: fewer fraction bits at |u| ~ 4
     o.close()
+
+
+def test_oracle_hit_rule_is_watertight_at_shared_edges_and_vertices():
+    """The hit rule (decision D4: Woop / Benthin / Wald 2013 on world-space vertices, exact 2-D edge functions) on the CPU side: rays aimed at shared edges and vertices
+    of a closed icosphere (from inside) and of a coplanar quad grid at the stand-in's 0.008 x 0.1 scale never escape, brute force and BVH agree bit for bit, and the hit
+    distance is the float64 distance to the target.  The GPU form of the same property, ten million rays through the C ABI: tests/test_gpu_watertight.py."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import oracle_from
+    from watertight import icosphere, quad_grid, mesh_scene, seam_rays
+    rng = np.random.default_rng(7)
+    # closed surface, awkward transform
+    ang = 0.7; c, s_ = np.cos(ang), np.sin(ang)
+    xf = np.eye(4, dtype=np.float32); xf[:3, :3] = np.float32([[c, -s_, 0], [s_, c, 0], [0, 0, 1]]) * np.float32(0.008); xf[:3, 3] = (0.31, 0.17, -0.23)
+    pos, faces = icosphere(3)
+    o = oracle_from(mesh_scene(pos, faces, xf), 16, 16, 2)
+    wt = o.world_triangles().reshape(-1, 3, 3)[: len(faces)]
+    n = 60000
+    inside = rng.normal(size=(n, 3)); inside *= (0.5 * rng.uniform(size=(n, 1)) ** (1 / 3)) / np.linalg.norm(inside, axis=1, keepdims=True)
+    origin = (inside @ xf[:3, :3].astype(np.float64).T + xf[:3, 3].astype(np.float64)).astype(np.float32)
+    org, dr, target = seam_rays(wt, origin, n, seed=11)
+    ip, uvt = o.trace_closest(org, dr, 1e-6, 1e30, use_bvh=True)
+    ipb, uvtb = o.trace_closest(org[:4000], dr[:4000], 1e-6, 1e30, use_bvh=False)
+    assert (uvt[:, 2] > 0).all() and o.trace_any(org, dr, np.full(n, 1e30, np.float32), 1e-6, use_bvh=True).all()
+    assert np.array_equal(uvt[:4000].view(np.uint32), uvtb.view(np.uint32)) and np.array_equal(ip[:4000], ipb)
+    want = np.linalg.norm(target - org.astype(np.float64), axis=1); got = uvt[:, 2].astype(np.float64) * np.linalg.norm(dr.astype(np.float64), axis=1)
+    assert (np.abs(got - want) / want).max() < 2e-5
+    o.close()
+    # coplanar quads, 0.008 x 0.1, interior seams
+    nu, nv = 48, 32
+    pos, faces = quad_grid(nu, nv, (13.7, 2.9, -7.3), (0.008, 0, 0), (0, 0, 0.1))
+    o = oracle_from(mesh_scene(pos, faces), 16, 16, 2)
+    wt_all = o.world_triangles().reshape(-1, 3, 3)[: len(faces)]
+    gi, gj = np.divmod(faces.astype(np.int64), nv + 1)
+    wt = wt_all[((gi > 0) & (gi < nu) & (gj > 0) & (gj < nv)).all(axis=1)]
+    origin = (np.float64([13.7 + 0.004 * nu, 2.9, -7.3 + 0.05 * nv]) + np.float64([0, 1, 0]) * rng.uniform(0.3, 3.0, (n, 1)) + rng.uniform(-0.1, 0.1, (n, 3))).astype(np.float32)
+    org, dr, target = seam_rays(wt, origin, n, seed=12)
+    ip, uvt = o.trace_closest(org, dr, 1e-6, 1e30, use_bvh=True)
+    assert (uvt[:, 2] > 0).all() and o.trace_any(org, dr, np.full(n, 1e30, np.float32), 1e-6, use_bvh=True).all()
+    o.close()

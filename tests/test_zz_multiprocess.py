@@ -27,16 +27,18 @@ def _rank_logs(log_dir, lines=60):
     return "\n".join(out) if out else "(no per-rank logs found)"
 
 
-def _launch_worker(n_ranks, port, log_dir, one_gpu, timeout=900):
+def _launch_worker(n_ranks, port, log_dir, one_gpu, timeout=900, worker="multigpu_worker.py", ok="MULTIGPU OK", depth=None):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     if one_gpu:
         env["LUMEN_WORKER_ONE_GPU"] = "1"
+    if depth is not None:
+        env["LUMEN_WORKER_DEPTH"] = str(depth)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           "--log-dir", str(log_dir), "--tee", "3", os.path.join(ROOT, "tests", "multigpu_worker.py")]
+           "--log-dir", str(log_dir), "--tee", "3", os.path.join(ROOT, "tests", worker)]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)      # children start fresh: nothing GPU-side is inherited
-    assert res.returncode == 0 and "MULTIGPU OK" in res.stdout, res.stdout[-2000:] + "\n" + res.stderr[-2000:] + "\n" + _rank_logs(log_dir)
+    assert res.returncode == 0 and ok in res.stdout, res.stdout[-2000:] + "\n" + res.stderr[-2000:] + "\n" + _rank_logs(log_dir)
 
 
 @pytest.mark.parametrize("n_ranks", [2, 4, 8])
@@ -64,6 +66,74 @@ def test_tiled_worker_single_rank_communicator(tmp_path):
     """The same worker with one rank: the nccl communicator, the preallocated gather buffers and the frame loop on the GPU that is there
     (the 2 / 4 / 8-rank forms above need a multi-GPU box)."""
     _launch_worker(1, 29539, tmp_path, one_gpu=False, timeout=600)
+
+
+@pytest.mark.parametrize("n_ranks", [2, 4, 8])
+def test_native_group_on_real_gpus_over_rccl(n_ranks, tmp_path):
+    """The NATIVE tile group (csrc/group.cpp behind lumen_mi_group_*: plan, seam exchange, double-buffered gather in C++, RCCL resolved by the library itself) as N
+    processes on N GPUs; rank 0 compares pipelined and frame-by-frame gathers bit for bit with a single-GPU render (tests/group_worker.py).  Needs N GPUs."""
+    import torch
+    if torch.cuda.device_count() < n_ranks:
+        pytest.skip(f"{torch.cuda.device_count()} GPU(s) on this box, {n_ranks} needed")
+    _launch_worker(n_ranks, 29580 + n_ranks, tmp_path, one_gpu=False, worker="group_worker.py", ok="GROUP OK")
+
+
+@pytest.mark.parametrize("n_ranks,depth", [(2, 5), (4, 5), (8, 5), (4, 4)])
+def test_native_group_processes_share_the_one_gpu(n_ranks, depth, tmp_path):
+    """The same C++ group code as N real processes on the ONE GPU of a development box, with a host transport injected through the C ABI (lumen_mi_transport: the group
+    stages its device buffers through pinned memory around gloo point-to-point calls): tile plan, windows, wave-count agreement and seam exchange (odd depth; depth 4
+    has no history to exchange), the double-buffered gather with frame f + 1 enqueued before frame f is read — stitched frames bit-identical to the full-frame render."""
+    _launch_worker(n_ranks, 29600 + n_ranks + depth, tmp_path, one_gpu=True, worker="group_worker.py", ok="GROUP OK", depth=depth)
+
+
+def test_native_group_single_rank_over_rccl(tmp_path):
+    """One rank, RCCL transport: the library resolves librccl by itself, creates both communicators from its own unique id, passes the self-test (all-reduce on either
+    communicator) and delivers the frame (the N-rank RCCL forms need N GPUs)."""
+    _launch_worker(1, 29579, tmp_path, one_gpu=False, worker="group_worker.py", ok="GROUP OK", timeout=600)
+
+
+@pytest.mark.parametrize("n_ranks", [1, 2, 4, 8])
+def test_plain_c_program_renders_as_a_tile_group(n_ranks, tmp_path):
+    """examples/render_scene.c --ranks N: the C99 caller as N processes, one per GPU, no Python and no torch in them — rank 0 takes the communicator id from RCCL through
+    lumen_mi_group_unique_id and passes it on in a file; every rank renders its window, the tiles travel over RCCL and rank 0 writes the stitched PPM, which must equal the
+    PPM of `--ranks 1` byte for byte (and `--ranks 1` itself runs over RCCL: the library resolves librccl on its own).  N > 1 needs N GPUs."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import build_c_example, cornell
+    from lumenrenderer_amd.scenes import write_scene_file
+    if torch.cuda.device_count() < n_ranks:
+        pytest.skip(f"{torch.cuda.device_count()} GPU(s) on this box, {n_ranks} needed")
+    scene = str(tmp_path / "cornell.slm")
+    write_scene_file(cornell(), scene)
+    exe = build_c_example(tmp_path)
+    W, H, depth, frames = 320, 256, 5, 4
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+
+    def run(n, tag):
+        idf = str(tmp_path / f"id_{tag}")
+        procs = [subprocess.Popen([exe, scene, str(W), str(H), str(depth), str(frames), str(tmp_path / f"out_{tag}_{k}.ppm"), "--ranks", str(n), "--rank", str(k), "--id-file", idf],
+                                  env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for k in range(n)]
+        outs = [p.communicate(timeout=600) for p in procs]
+        assert all(p.returncode == 0 for p in procs), [(p.returncode, o[0][-500:], o[1][-1500:]) for p, o in zip(procs, outs)]
+        return open(tmp_path / f"out_{tag}_0.ppm", "rb").read(), outs
+
+    one, outs1 = run(1, "one")
+    assert "stitched from 1 tile(s)" in outs1[0][0] and "self-test" in outs1[0][0]
+    header = b"P6\n%d %d\n255\n" % (W, H)
+    assert one.startswith(header) and len(one) == len(header) + W * H * 3 and np.frombuffer(one[len(header):], np.uint8).mean() > 1
+    if n_ranks > 1:
+        many, outs = run(n_ranks, "many")
+        assert many == one
+    else:
+        # the reference-shaped C++ adapter as rank 0 of a one-rank group (MI355X::Renderer::SetGroup): the same picture through LumenRenderer's virtuals
+        from helpers import build_sandbox_driver
+        xexe = build_sandbox_driver(tmp_path)
+        xout = str(tmp_path / "adapter.ppm")
+        res = subprocess.run([xexe, scene, str(W), str(H), str(depth), str(frames), xout], env=dict(env, SANDBOX_GROUP="0/1/" + str(tmp_path / "id_adapter")),
+                             capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, (res.stdout[-1000:], res.stderr[-2000:])
+        assert open(xout, "rb").read() == one
 
 
 @pytest.mark.parametrize("n_ranks,workload", [(2, "sandbox"), (8, "c2"), (8, "c4")])      # c4 = BASELINE's 8-GPU configuration (4K, 8 spp, depth 8)
