@@ -530,7 +530,10 @@ def main():
         pmc = load_pmc() if args.workload == "c2" and world == 1 and not emu else {}
         pk = lambda name, key: pmc.get(name, {}).get(key)
         # per launch, averaged over both closest-hit kernels (per-lane queue kernel + the packet kernel of the primary wave)
-        tc = [(pk(n, "hbm_bytes_per_launch_corrected"), pk(n, "launches")) for n in ("lm_k_trace_closest", "lm_k_trace_closest_packet")]
+        # HBM bytes per launch from the PMC replay: FETCH_SIZE x 2 for streaming kernels, x 1 for gather kernels (tools/pmc_json.sh: field `access`), + WRITE_SIZE;
+        # a replay file of rounds 2 - 5 only has the all-x2 upper bound (`hbm_bytes_per_launch_corrected`), which stays beside it as *_upper
+        hb = lambda v: v.get("hbm_bytes_per_launch", v.get("hbm_bytes_per_launch_corrected", 0.0))
+        tc = [(hb(pmc.get(n, {})) or None, pk(n, "launches")) for n in ("lm_k_trace_closest", "lm_k_trace_closest_packet")]
         tc = [(b, l) for b, l in tc if b is not None and l]
         traffic_closest = sum(b * l for b, l in tc) / sum(l for _, l in tc) if tc else None
         # the same algorithmic bytes over the ALONE launch time (PMC passes serialise the dispatches): what the kernels reach when nothing else is resident
@@ -539,8 +542,8 @@ def main():
         alone_us = sum(u * l for u, l in ta) / sum(l for _, l in ta) if ta else None
         frac_alone = None if not alone_us else round((alg / max(1.0, launches_per_tf)) / (alone_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
         # PHYSICAL HBM fraction of every kernel that moves more than 50 MB per launch: PMC bytes / alone time / peak (which passes are byte-bound, which are not)
-        hbm_kernels = sorted(({"kernel": n, "hbm_mb_per_launch": round(v["hbm_bytes_per_launch_corrected"] / 1e6, 1), "alone_us": round(v["alone_us"], 1),
-                               "frac": round(v["hbm_bytes_per_launch_corrected"] / (v["alone_us"] * 1e-6) / (HBM_PEAK_GBS * 1e9), 4),
+        hbm_kernels = sorted(({"kernel": n, "access": v.get("access"), "hbm_mb_per_launch": round(hb(v) / 1e6, 1), "hbm_mb_per_launch_upper": round(v["hbm_bytes_per_launch_corrected"] / 1e6, 1), "alone_us": round(v["alone_us"], 1),
+                               "frac": round(hb(v) / (v["alone_us"] * 1e-6) / (HBM_PEAK_GBS * 1e9), 4),
                                "active_lanes_per_valu_inst": round(v.get("active_lanes_per_valu_inst") or 0.0, 1)}
                               for n, v in pmc.items() if v.get("alone_us") and v.get("hbm_bytes_per_launch_corrected", 0.0) > 50e6 and v.get("launches", 0) > 2),
                              key=lambda e: -e["frac"])
@@ -548,7 +551,8 @@ def main():
         alg_tf = algorithmic_bytes_traceframe(c, depth, npix, ci[20], ci[21], blend=blend_on)
         # whole-frame HBM traffic from the PMC replay: sum over kernels of bytes per launch x launches per TraceFrame
         tf_in_pmc = max(1, pmc.get("lm_k_primary", {}).get("launches", 1))
-        hbm_tf = sum(v.get("hbm_bytes_per_launch_corrected", 0.0) * v.get("launches", 0) / tf_in_pmc for v in pmc.values()) if pmc else None
+        hbm_tf = sum(hb(v) * v.get("launches", 0) / tf_in_pmc for v in pmc.values()) if pmc else None
+        hbm_tf_upper = sum(v.get("hbm_bytes_per_launch_corrected", 0.0) * v.get("launches", 0) / tf_in_pmc for v in pmc.values()) if pmc else None
         tf_ms = ms_per_step / spp
         # ---- VALU-bound kernels (candidate pick; spatial reuse): executed lane-operations / alone time against the fp32 issue peak
         valu = []
@@ -623,7 +627,7 @@ def main():
                        "d4_note": "SURVEY d4 prices the reference's AoS data flow; above 1.0 means most of those bytes are cache hits or never move here — it is not a roofline",
                        "hbm_traffic_bytes_per_traceframe": None if hbm_tf is None else int(hbm_tf),
                        "hbm_traffic_frac": None if hbm_tf is None else round(hbm_tf / (tf_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
-                       "hbm_traffic_source": None if hbm_tf is None else PMC_FILE + " (replayed: PMC passes of the builder's run, 2 x FETCH_SIZE + WRITE_SIZE per kernel)"},
+                       "hbm_traffic_source": None if hbm_tf is None else PMC_FILE + " (replayed: PMC passes of the builder's run; FETCH_SIZE x 2 for streaming kernels, x 1 for gather kernels, + WRITE_SIZE; frame_hbm_frac_upper = x 2 everywhere)"},
             # `bound`: the kernel is NOT HBM-bound — the tree is served by L2 / Infinity Cache (frac_hbm_physical: a few % of peak); what bounds a launch is the dependent
             # chain of its longest rays x the lanes divergence leaves idle (traversal_model).  `frac` stays the contract's figure (SURVEY d4 algorithmic bytes / live
             # launch time / HBM peak) so that rounds compare; `frac_alone` is the same bytes over the kernels' serialised (alone) time from the PMC replay.
@@ -640,6 +644,7 @@ def main():
             "roofline_valu": valu,
             "roofline_hbm_kernels": hbm_kernels,
             "frame_valu_frac": frame_valu_frac, "frame_hbm_frac": frame_hbm_frac,
+            "frame_hbm_frac_upper": None if not pmc or hbm_tf_upper is None else round(hbm_tf_upper / (tf_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
             "frame_bound_note": "fractions of the chip's VALU issue peak (wave-instructions, measured) and of HBM peak over one TraceFrame, from the PMC replay: both well below 1 — "
                                 "the frame is bound by dependent-chain latency inside the traversal launches and by how well four streams fill each other's stalls",
             "traversal_model": traversal_model,

@@ -261,7 +261,9 @@ int lumen_mi_query_closest(lumen_mi_renderer*, uint32_t n, const float* origins3
                            uint32_t* instance_prim2, float* uvt3);
 int lumen_mi_query_any(lumen_mi_renderer*, uint32_t n, const float* origins3, const float* directions3, float tmin, const float* tmax, uint8_t* occluded);
 
-/* ---- known-answer hooks: run the device BSDF / math on host arrays */
+/* ---- known-answer hooks: run the device BSDF / math, device functions and whole kernels of the hot path on host arrays.  TEST SURFACE, not part of the reference's
+ * interface: present in the default build (the test suite needs them); `make -C lumenrenderer_amd/csrc HOOKS=0` builds the library without any lumen_mi_test_* symbol,
+ * without csrc/kat.cpp and without the hook kernels (csrc/lm_hooks.h). */
 int lumen_mi_test_bsdf(lumen_mi_renderer*, uint32_t n, int mode, const float* mat23, const float* N, const float* T, const float* wo, const float* aux3, float* out8);
 int lumen_mi_test_math(lumen_mi_renderer*, uint32_t n, int fn, const float* x, const float* y, float* out);
 /* Known-answer hook for the device-side Reservoir::Update / UpdateWeight (ReSTIRData.h:115-163), CDF::Get (ReSTIRData.h:230-306) and

@@ -6,6 +6,10 @@
 // kernel table with the arguments, order and seed evolution of frame.cpp (Framework/ReSTIR.cpp:65-233), and the buffers are read back through the product's load
 // functions.  The only stand-in is the tracer: the reference's visibility programs are closed (OptiX), so the rows carry an occlusion mask per pass and
 // lm_k_kat_resolve hands it to the same lines the traversal kernels run on a resolved ray (lm_vis_resolve).
+#ifndef LUMEN_MI_TEST_HOOKS
+#define LUMEN_MI_TEST_HOOKS 1
+#endif
+#if LUMEN_MI_TEST_HOOKS      // the whole file is test surface: `make HOOKS=0` builds the library without it (csrc/lm_hooks.h)
 #include "renderer_state.h"
 
 using namespace lmr;
@@ -284,3 +288,5 @@ int lumen_mi_test_primary_rays(lumen_mi_renderer* r, uint32_t W, uint32_t H, uin
 }
 
 }  // extern "C"
+
+#endif   // LUMEN_MI_TEST_HOOKS

@@ -784,6 +784,10 @@ int lumen_mi_query_any(lumen_mi_renderer* r, uint32_t n, const float* o, const f
     return 0;
 }
 
+#ifndef LUMEN_MI_TEST_HOOKS
+#define LUMEN_MI_TEST_HOOKS 1
+#endif
+#if LUMEN_MI_TEST_HOOKS      // known-answer hooks (test surface; `make HOOKS=0` leaves them out: csrc/lm_hooks.h)
 int lumen_mi_test_bsdf(lumen_mi_renderer* r, uint32_t n, int mode, const float* mat23, const float* N, const float* T, const float* wo, const float* aux, float* out8)
 {
     if (!r || !r->initialised) return fail(LUMEN_MI_ERR_STATE, "not initialised");
@@ -846,6 +850,8 @@ int lumen_mi_test_math(lumen_mi_renderer* r, uint32_t n, int fn, const float* x,
 }
 
 // host-only scene products (no device needed beyond what flatten uploads)
+#endif   // LUMEN_MI_TEST_HOOKS
+
 int lumen_mi_get_world_triangles(lumen_mi_renderer* r, float* out, uint32_t cap, uint32_t* count)
 {
     if (!r || !count) return fail(LUMEN_MI_ERR_INVALID, "NULL argument");

@@ -1061,3 +1061,24 @@ def test_reference_sample_fixtures_load_with_their_texels_and_the_oracle_lights_
         if lights:
             assert n == lights, n
         o.close()
+
+
+def test_library_builds_without_its_test_surface(tmp_path):
+    """`make HOOKS=0` (LUMEN_MI_TEST_HOOKS=0): the product ABI without the known-answer hooks — the host translation units then define no lumen_mi_test_* symbol and the
+    device translation unit no hook kernel (csrc/lm_hooks.h), while the default build (what the suite runs against) exports all of them.  Compiled here file by file into
+    a temporary directory (the in-tree objects are the default build's and stay untouched)."""
+    csrc = os.path.join(ROOT, "lumenrenderer_amd", "csrc")
+    common = ["/opt/rocm/bin/hipcc", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-DLUMEN_MI_TEST_HOOKS=0"]
+    for src, extra in (("renderer.cpp", ["-O0", "-x", "hip"]), ("kat.cpp", ["-O0", "-x", "hip"]), ("kernels.hip", ["-O1", "-DLM_INSTRUMENT=0"])):      # (the traversal's scalar-load asm needs an optimised build)
+        obj = str(tmp_path / (src + ".o"))
+        res = subprocess.run(common + extra + ["-c", os.path.join(csrc, src), "-o", obj], capture_output=True, text=True, timeout=1200)
+        assert res.returncode == 0, res.stderr[-3000:]
+        names = subprocess.run(["nm", obj], capture_output=True, text=True).stdout
+        assert "lumen_mi_test_" not in names and "lm_k_kat_" not in names and "lm_k_test_" not in names, src
+        if src == "renderer.cpp":
+            assert "lumen_mi_trace_frame" in names and "lumen_mi_query_closest" in names
+    from lumenrenderer_amd import capi
+    lib = capi.load_library()
+    assert all(hasattr(lib, n) for n in capi.SYMBOLS if n.startswith("lumen_mi_test_"))
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    assert "HOOKS ?= 1" in mk and "-DLUMEN_MI_TEST_HOOKS=$(HOOKS)" in mk
