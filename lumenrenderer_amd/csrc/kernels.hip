@@ -25,8 +25,16 @@
 #define LM_SHADE_PRIO 3          // s_setprio of the surface-extraction / shading kernels of the wave chain: with the fast ReSTIR mode that chain is the
 #endif                           // critical path, and its VALU-heavy kernels otherwise queue behind the candidate pick on every SIMD (+1.5 % on C2)
 // the file is compiled twice into one library: kernel symbols of the counting build get a suffix
+// LM_NOSLP_VARIANT: the same kernels once more under the names *_ns, from a compilation with -fno-slp-vectorize (Makefile: kernels_ns.o).  The compiler's packed-fp32 pairing
+// buys no issue slots on this chip and costs moves and register pairs; which kernels run from which compilation is a run-time choice of the renderer (renderer.cpp
+// `noslp_kernels`, environment LUMEN_MI_NOSLP_KERNELS), so that one build can be A/B-ed kernel by kernel on one box (profiles/r06_noslp_kernels_ab.txt).
+#ifndef LM_NOSLP_VARIANT
+#define LM_NOSLP_VARIANT 0
+#endif
 #if LM_INSTRUMENT
 #define KN(x) x##_inst
+#elif LM_NOSLP_VARIANT
+#define KN(x) x##_ns
 #else
 #define KN(x) x
 #endif
@@ -844,6 +852,9 @@ __device__ __forceinline__ void lm_pick_primary_body(const LmScene& sc, const Lm
                                                      float4* s_lights = nullptr, uint32_t vb = blockIdx.x)
 {
     if (ROLE == LM_RARE && fr.counters[LM_CNT_RARE] == 0u) return;      // grid-uniform: no surface of this frame needs the second launch
+#ifdef LM_PICK_PRIO
+    __builtin_amdgcn_s_setprio(LM_PICK_PRIO);          // the pick sits on the frame's critical chain (eager history passes) and is pure VALU: it must not be the kernel that waits (r06_pick_prio_ab.txt)
+#endif
     if constexpr (LDSL) {
         for (uint32_t k = threadIdx.x; k < sc.numLights; k += LM_BLOCK) {
             const LmTriLight l = lm_load_light(sc.lights, k);
@@ -2037,6 +2048,8 @@ static void l_spin(hipStream_t s, uint32_t ticks) { hipLaunchKernelGGL(KN(lm_k_s
 
 #if LM_INSTRUMENT
 extern "C" const LmKernelTable* lm_kernel_table_instrumented()
+#elif LM_NOSLP_VARIANT
+extern "C" const LmKernelTable* lm_kernel_table_noslp()
 #else
 extern "C" const LmKernelTable* lm_kernel_table()
 #endif

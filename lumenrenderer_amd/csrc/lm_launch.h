@@ -50,4 +50,5 @@ struct LmKernelTable {
     void (*copy_rect)(hipStream_t, int grid, float4* dst, uint32_t dstPitch, const float4* src, uint32_t srcPitch, uint32_t w, uint32_t h);      // pitched RGBA32F rectangle (tile gather)
 };
 extern "C" const LmKernelTable* lm_kernel_table();
+extern "C" const LmKernelTable* lm_kernel_table_noslp();        // the same kernels compiled with -fno-slp-vectorize (kernels.hip LM_NOSLP_VARIANT)
 extern "C" const LmKernelTable* lm_kernel_table_instrumented();

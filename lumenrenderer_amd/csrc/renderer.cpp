@@ -13,12 +13,39 @@ extern "C" {
 
 const char* lumen_mi_last_error(void) { return g_lastError.c_str(); }
 
+// Which kernel classes run from the compilation without the SLP vectoriser (kernels.hip LM_NOSLP_VARIANT): comma-separated table entries, "all" or "none".  Two lists: one
+// that always applies and one that is added while the ReSTIR passes run in the EXACT arithmetic mode (the exact instantiations of temporal / spatial / combine gain without the
+// pairing, the fast ones — short kernels on the frame's critical chain — lose: profiles/r06_noslp_kernels_ab.txt).  Environment LUMEN_MI_NOSLP_KERNELS / LUMEN_MI_NOSLP_KERNELS_EXACT
+// override the defaults.  Results do not depend on the choice: the two compilations differ in instruction selection only (-ffp-contract=off in both; the suite runs under "all" too).
+#ifndef LM_NOSLP_DEFAULT
+#define LM_NOSLP_DEFAULT "pick_primary,extract0,shade_wave,merge"
+#endif
+#ifndef LM_NOSLP_DEFAULT_EXACT
+#define LM_NOSLP_DEFAULT_EXACT "temporal,spatial,combine"
+#endif
+static void applyNoSlpKernels(lumen_mi_renderer* r)
+{
+    const LmKernelTable* a = lm_kernel_table();
+    const LmKernelTable* b = lm_kernel_table_noslp();
+    const char* e0 = getenv("LUMEN_MI_NOSLP_KERNELS");
+    const char* e1 = getenv("LUMEN_MI_NOSLP_KERNELS_EXACT");
+    std::string s = std::string(",") + (e0 ? e0 : LM_NOSLP_DEFAULT) + ",";
+    if (!r->fastResample) s += std::string(e1 ? e1 : LM_NOSLP_DEFAULT_EXACT) + ",";
+    const bool all = s.find(",all,") != std::string::npos;
+    auto on = [&](const char* name) { return all || s.find(std::string(",") + name + ",") != std::string::npos; };
+    r->Kmix = *a;
+#define LM_MIX(entry) if (on(#entry)) r->Kmix.entry = b->entry;
+    LM_MIX(primary) LM_MIX(trace_closest) LM_MIX(extract0) LM_MIX(shade_wave) LM_MIX(trace_shadow) LM_MIX(path_tail) LM_MIX(fill_bags) LM_MIX(pick_primary)
+    LM_MIX(trace_shade) LM_MIX(temporal) LM_MIX(spatial) LM_MIX(combine) LM_MIX(clear) LM_MIX(merge) LM_MIX(trace_primary)
+#undef LM_MIX
+    if (!r->instrumented) r->K = &r->Kmix;
+}
+
 int lumen_mi_create(lumen_mi_renderer** out)
 {
     if (!out) return fail(LUMEN_MI_ERR_INVALID, "out is NULL");
     initLut();
     *out = new lumen_mi_renderer();
-    (*out)->K = lm_kernel_table();
     if (const char* e = getenv("LUMEN_MI_REFILL")) (*out)->refillBelow = atoi(e);
     if (const char* e = getenv("LUMEN_MI_REFILL_VIS")) (*out)->refillVisibility = atoi(e);
     if (const char* e = getenv("LUMEN_MI_REFILL_PRIMARY")) (*out)->refillPrimary = atoi(e);
@@ -39,6 +66,7 @@ int lumen_mi_create(lumen_mi_renderer** out)
     if (const char* e = getenv("LUMEN_MI_TAIL_PAIR")) (*out)->tailPair = atoi(e);
     if (const char* e = getenv("LUMEN_MI_TAIL_GRID")) (*out)->tailGrid = std::max(1, std::min(8, atoi(e)));      // (<= 8: the stack-spill area is sized for 8 blocks per CU)
     if (const char* e = getenv("LUMEN_MI_TAIL_LANES")) { const int v = atoi(e); (*out)->tailLanes = v <= 0 ? -1 : std::min(64, v); }
+    applyNoSlpKernels(*out);
     return 0;
 }
 
@@ -688,7 +716,7 @@ int lumen_mi_set_tuning(lumen_mi_renderer* r, const char* key, int value)
     else if (k == "fuzz") r->fuzz = (uint32_t)value;
     else if (k == "assemble") r->assembleEnabled = value;
     else if (k == "shadow_on_wave") { if (r->initialised) { int rc = syncAndCollect(r); if (rc) return rc; } r->shadowOnWave = value; }
-    else if (k == "fast_resample") { if (r->initialised) { int rc = syncAndCollect(r); if (rc) return rc; } r->fastResample = value != 0; }
+    else if (k == "fast_resample") { if (r->initialised) { int rc = syncAndCollect(r); if (rc) return rc; } r->fastResample = value != 0; applyNoSlpKernels(r); }
     else if (k == "packet_primary") r->packetPrimary = value;
     else if (k == "packet_visibility") r->packetVisibility = value;
     else if (k == "spatial_lds") r->spatialLds = value;
@@ -708,7 +736,7 @@ int lumen_mi_set_tuning(lumen_mi_renderer* r, const char* key, int value)
     else return fail(LUMEN_MI_ERR_INVALID, std::string("unknown tuning key: ") + key);
     return 0;
 }
-int lumen_mi_set_instrumented(lumen_mi_renderer* r, int e) { if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer"); ApiLock lk(r); r->instrumented = e != 0; r->K = e ? lm_kernel_table_instrumented() : lm_kernel_table(); return 0; }
+int lumen_mi_set_instrumented(lumen_mi_renderer* r, int e) { if (!r) return fail(LUMEN_MI_ERR_INVALID, "NULL renderer"); ApiLock lk(r); r->instrumented = e != 0; r->K = e ? lm_kernel_table_instrumented() : &r->Kmix; return 0; }
 
 int lumen_mi_set_tile(lumen_mi_renderer* r, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1)
 {

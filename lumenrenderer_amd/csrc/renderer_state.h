@@ -153,6 +153,7 @@ struct lumen_mi_renderer {
     int traceBlocksMain = 8, traceBlocksAux = 8;
     int numCU = 256;
     const LmKernelTable* K = nullptr;
+    LmKernelTable Kmix;                     // the renderer's own table: every entry from the default compilation or, per kernel class, from the -fno-slp-vectorize one (renderer.cpp applyNoSlpKernels)
     bool instrumented = false;
     int tailBelow = -1;                     // waves expected to hold fewer rays than this run as one path-tail launch (0 = off,
                                             // -1 = auto: 65536 for windows under 1 Mpixel, where the wave chain is the critical path, else 16384) ...

@@ -119,6 +119,27 @@ out6 = {k: np.asarray(v, dtype=np.int64) for k, v in rows6.items()}
 dst6 = os.path.join(here, "..", "..", "tests", "golden", "ref_kat6.npz")
 np.savez_compressed(dst6, **out6)
 print({k: v.shape for k, v in out6.items()}, "->", os.path.normpath(dst6), os.path.getsize(dst6), "bytes")
+# seventh unit: the two callees that store radiance as binary16 — ShadeReservoirs and MergeOutputChannels — from the reference's text on its own Half4.h (gen_kat7.cpp)
+def slice7(path, first, last, name):
+    with open(path, encoding="latin-1") as f:
+        text = "".join(f.readlines()[first - 1:last])
+    with open(f"/tmp/lumen_k7_{name}.inc", "w", encoding="latin-1") as f:
+        f.write(text + "\n")
+slice7(f"{K}/ReSTIRKernels.cuh", 17, 18, "macros")
+slice7(f"{R}/src/Shaders/CppCommon/WaveFrontDataStructs.h", 13, 13, "pdi")
+slice7(f"{K}/ReSTIRKernels.cu", 619, 665, "shade")
+slice7(f"{K}/WaveFrontKernels/GPUMergeOutputChannels.cu", 5, 88, "merge")
+exe = "/tmp/lumen_gen_kat7"
+subprocess.check_call(["/opt/rocm/lib/llvm/bin/clang++", "-std=c++17", "-O1", "-ffp-contract=off", "-Wno-c++11-narrowing", "-D_GNU_SOURCE", "-DNDEBUG", "-w", "-DGLM_ENABLE_EXPERIMENTAL",
+                       "-I/tmp/lumen_k5_inc", f"-I{R}/vendor/Include", f"-I{R}/vendor/Include/Cuda", f"-I{R}/src", f"-I{L}/vendor/glm", os.path.join(here, "gen_kat7.cpp"), "-o", exe])
+rows7 = {}
+for line in subprocess.check_output([exe], text=True).splitlines():
+    tag, *vals = line.split()
+    rows7.setdefault(tag, []).append([int(v) for v in vals])
+out7 = {k: np.asarray(v, dtype=np.uint32) for k, v in rows7.items()}
+dst7 = os.path.join(here, "..", "..", "tests", "golden", "ref_kat7.npz")
+np.savez_compressed(dst7, **out7)
+print({k: v.shape for k, v in out7.items()}, "->", os.path.normpath(dst7), os.path.getsize(dst7), "bytes")
 out = {k: np.asarray(v, dtype=np.float64) for k, v in rows.items()}
 dst = os.path.join(here, "..", "..", "tests", "golden", "ref_kat.npz")
 np.savez_compressed(dst, **out)

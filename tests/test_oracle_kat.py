@@ -580,3 +580,44 @@ def test_oracle_hit_rule_is_watertight_at_shared_edges_and_vertices():
     ip, uvt = o.trace_closest(org, dr, 1e-6, 1e30, use_bvh=True)
     assert (uvt[:, 2] > 0).all() and o.trace_any(org, dr, np.full(n, 1e30, np.float32), 1e-6, use_bvh=True).all()
     o.close()
+
+
+def test_binary16_callees_of_the_reference_run_as_text_and_bound_decision_d1():
+    """tests/golden/ref_kat7.npz: ShadeReservoirs (ReSTIRKernels.cu:619-665) and MergeOutputChannels (GPUMergeOutputChannels.cu:5-88) run from the reference's own text on its
+    own Half4.h (oracle/ref_kat/gen_kat7.cpp; the five device-only binary16 intrinsics defined as the IEEE operations their documentation states).  Two statements:
+    (1) what those lines compute IS the binary16 chain this suite has priced the reference with since round 3 — out = half(in) + half(contribution * (weight / 3)) for a positive
+    weight; merged = half(DIRECT) + half(INDIRECT) + half(SPECULAR), then ((old * half(n)) + merged) / half(n + 1) — numpy float16 arithmetic reproduces every row bit for bit;
+    (2) decision D1 (fp32 in product and oracle) against it, per operation: the fp32 result of the same inputs, rounded once to binary16, is within 1 unit in the last place of
+    the reference's value for the shading add and within 2 for the three-operation blend, wherever the reference's chain stays finite."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_kat7.npz"))
+    h = lambda a: np.ascontiguousarray(a.astype(np.uint16)).view(np.float16)
+    f = lambda a: np.ascontiguousarray(a.astype(np.uint32)).view(np.float32)
+    with np.errstate(over="ignore", invalid="ignore", divide="ignore"):
+        # ---- ShadeReservoirs
+        r = z["shd7"]
+        cin, w, c, cout = h(r[:, 1:5]), f(r[:, 5]), f(r[:, 6:9]), h(r[:, 9:13])
+        add16 = (c * (w / np.float32(3.0))[:, None]).astype(np.float16)
+        want = cin.copy(); pos = w > 0
+        want[pos, :3] = cin[pos, :3] + add16[pos]
+        assert np.array_equal(want.view(np.uint16), cout.view(np.uint16))
+        assert pos.sum() > 2000 and (~pos).sum() > 300 and cout[:, :3].astype(np.float32).max() > 1000.0     # the rows reach the early-out (weight <= 0) and large values
+        d1 = (cin[:, :3].astype(np.float32) + c * (w / np.float32(3.0))[:, None]).astype(np.float16)            # D1: fp32 add, rounded once on export
+        fin = pos[:, None] & np.isfinite(cout[:, :3].astype(np.float32)) & np.isfinite(d1.astype(np.float32))
+        ulps = np.abs(d1.view(np.uint16).astype(np.int64) - cout[:, :3].view(np.uint16).astype(np.int64))[fin]
+        assert ulps.max() <= 1 and (ulps == 0).mean() > 0.7, (ulps.max(), (ulps == 0).mean())
+        # ---- MergeOutputChannels
+        r = z["mrg7"]
+        blend, n = r[:, 1], r[:, 2].astype(np.float32)
+        D, I, S, V, old, new = (h(r[:, 3 + 4 * k: 7 + 4 * k]) for k in range(6))
+        merged = ((np.float16(0) + D) + I) + S
+        alpha = V[:, 3:4].astype(np.float32)
+        merged = (merged.astype(np.float32) * (np.float32(1) - alpha) + V.astype(np.float32) * alpha).astype(np.float16)
+        n16, n1 = n.astype(np.float16)[:, None], (n + 1).astype(np.float16)[:, None]
+        want = np.where(blend[:, None] == 1, ((old * n16) + merged) / n1, merged)
+        assert np.array_equal(want.view(np.uint16), new.view(np.uint16))
+        m32 = D.astype(np.float32) + I.astype(np.float32)                                                        # D1: channel sum and running mean in fp32
+        d1 = np.where(blend[:, None] == 1, (old.astype(np.float32) * n[:, None] + m32) / (n[:, None] + 1), m32).astype(np.float16)
+        fin = np.isfinite(new.astype(np.float32)) & np.isfinite(d1.astype(np.float32)) & np.isfinite((old * n16).astype(np.float32))
+        ulps = np.abs(d1.view(np.uint16).astype(np.int64) - new.view(np.uint16).astype(np.int64))[fin]
+        assert ulps.max() <= 2 and (ulps <= 1).mean() > 0.97, (ulps.max(), (ulps <= 1).mean())
+        assert fin.mean() > 0.95 and set(np.unique(r[:, 2])) == {0, 3, 9}
