@@ -2,8 +2,10 @@
 """bench.py — BASELINE.json's metric on its config: Mrays/s and ms/frame at 1440p, 4 spp, depth 6, Sponza (stand-in).
 
 A "step" is one displayed frame = 4 blended TraceFrame() calls (the reference has no spp parameter: SURVEY.md F3) over
-synthetic geometry already resident in HBM.  N GPUs shard the frame by tile (lumenrenderer_amd/tiles.py) and gather the
-radiance on rank 0 with one RCCL collective; the total work is fixed, so scaling is "strong".
+synthetic geometry already resident in HBM.  N GPUs shard the frame by tile and gather the radiance on rank 0 over RCCL; the total work is fixed, so
+scaling is "strong".  The N-GPU frame path is the tile group of the C ABI (csrc/group.cpp behind lumen_mi_group_*: plan, seam exchange, double-buffered gather
+on its own stream, in C++; --transport native, the default) — torch.distributed over gloo then only carries rank 0's communicator id, the barriers of the timed
+region and the statistics; --transport torch is rounds 1 - 5's lumenrenderer_amd/tiles.py over torch.distributed (backend nccl).
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` and `cpu_baseline`.
 
 Arithmetic mode: `value` is measured with the fast ReSTIR mode (tuning key fast_resample: hardware rcp / rsq / sqrt and the contracted target
@@ -36,7 +38,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak, /opt/skills/guides/MI355X_
 VALU_PEAK_TLANEOPS = 78.6432
 WAVEINST_PEAK = 1055.8e9         # VALU wave-instructions/s the chip sustains with dependent chains at 8 waves per SIMD (measured, profiles/r03_valu_peak.txt: 2.33 cycles per instruction per SIMD)
 TRAV_T0_US, TRAV_STEPS_PER_US = 60.0, 75000.0  # closest-hit launch of incoherent rays: T = T0 + rays x steps per ray / S; calibration 4.6 G rays/s at 16.3 steps per ray (profiles/r04_step_latency.txt)
-PMC_FILE = os.path.join("profiles", "r05_c2_pmc.json")      # tools/pmc_json.sh on the GPU box; replayed here, never measured by this run
+PMC_FILE = os.path.join("profiles", "r06_c2_pmc.json")      # tools/pmc_json.sh on the GPU box; replayed here, never measured by this run
 
 
 def kernel_source_id():
@@ -557,8 +559,9 @@ def main():
         # ---- VALU-bound kernels (candidate pick; spatial reuse): executed lane-operations / alone time against the fp32 issue peak
         valu = []
         pick = "lm_k_pick_primary_fast" if fast else "lm_k_pick_primary"
-        pick = pick + "_lds" if pick + "_lds" in pmc else pick           # scenes whose light table fits in LDS run that instantiation
-        for name in (pick, "lm_k_restir_spatial_fast" if fast else "lm_k_restir_spatial"):
+        ns = lambda n: n + "_ns" if n + "_ns" in pmc else n              # kernels that run from the compilation without the SLP vectoriser carry the suffix (renderer.cpp applyNoSlpKernels)
+        pick = ns(pick + "_lds") if ns(pick + "_lds") in pmc else ns(pick)           # scenes whose light table fits in LDS run that instantiation
+        for name in (pick, ns("lm_k_restir_spatial_fast" if fast else "lm_k_restir_spatial")):
             lane_ops, us = pk(name, "SQ_THREAD_CYCLES_VALU_per_launch"), pk(name, "alone_us")
             if lane_ops and us:
                 ach = lane_ops / (us * 1e-6) / 1e12
@@ -621,6 +624,8 @@ def main():
                        "tiles": f"{tiles.grid_for(world, W, H)[0]}x{tiles.grid_for(world, W, H)[1]} + {tiles.HALO}px halo" if world > 1 else "1x1",
                        "nodes4_per_ray": round(node_records / all_rays_inst, 2), "binary_node_equivalents_per_ray": round(ci[20] / all_rays_inst, 2), "tris_per_ray": round(ci[21] / all_rays_inst, 2),
                        "rays_per_wave": [int(c[4 + d]) for d in range(depth)], "nee_shadow_rays": int(c[1]), "restir_shadow_rays": int(c[2]),
+                       "kernel_mix": "kernels from the compilation without the SLP vectoriser: " + os.environ.get("LUMEN_MI_NOSLP_KERNELS", "pick_primary,extract0,shade_wave,merge") +
+                                     " (+ in the exact mode: " + os.environ.get("LUMEN_MI_NOSLP_KERNELS_EXACT", "temporal,spatial,combine") + "); profiles/r06_noslp_kernels_ab.txt",
                        "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "host_submit_ms_per_step": round(main_pass["host_submit_ms_per_step"], 3),
                        "d4_accounting_bytes_per_traceframe": int(alg_tf),
                        "d4_accounting_over_hbm_peak": round(alg_tf * spp / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9), 4) if world == 1 else None,
