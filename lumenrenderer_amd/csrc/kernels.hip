@@ -103,40 +103,14 @@ __device__ __forceinline__ void lm_append_slot_block2(uint32_t* counterA, bool p
     slotB = tB[nWaves] + tB[wave] + (uint32_t)__popcll(maskB & below);
     __syncthreads();
 }
-// Block-aggregated append that also ORDERS the block's appended rays by a 3-bit key (the direction octant), so that the 64 consecutive queue slots a traversal
-// wavefront takes hold one or two octants of rays from neighbouring pixels instead of all eight mixed (coherence created where the queue is written,
-// no sort pass).  Same single atomic per block; the per-key, per-wave counts are scanned by the first 32 lanes.  `s_key` = 8 x (waves per block) + 1 words, waves <= 4.
-// Compile-time switch LM_APPEND_OCTANT (A/B: profiles/r05_append_octant_ab.txt).
 #ifndef LM_APPEND_OCTANT
 #define LM_APPEND_OCTANT 0
 #endif
 __device__ __forceinline__ uint32_t lm_octant(const lf3& d) { return (d.x < 0.f ? 1u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 4u : 0u); }
-__device__ __forceinline__ uint32_t lm_append_slot_block_keyed(uint32_t* counter, bool pred, uint32_t key, uint32_t* s_key)
-{
-    const uint32_t lane = lm_lane(), wave = threadIdx.x >> 6, nWaves = blockDim.x >> 6;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    uint32_t mine = 0u;
-#pragma unroll
-    for (uint32_t k = 0; k < 8u; k++) {
-        const unsigned long long m = __ballot(pred && key == k);
-        if (lane == 0) s_key[k * nWaves + wave] = (uint32_t)__popcll(m);
-        if (key == k) mine = (uint32_t)__popcll(m & below);
-    }
-    __syncthreads();
-    if (threadIdx.x < 64u) {                                  // exclusive scan of the 8 x nWaves (<= 32) counts in key-major order by wave 0
-        const uint32_t cnt = threadIdx.x < 8u * nWaves ? s_key[threadIdx.x] : 0u;
-        uint32_t inc = cnt;
-#pragma unroll
-        for (int o = 1; o < 32; o <<= 1) { const uint32_t up = (uint32_t)__shfl_up((int)inc, o, 64); if ((int)lane >= o) inc += up; }
-        const uint32_t total = (uint32_t)__shfl((int)inc, 31, 64);
-        if (threadIdx.x < 8u * nWaves) s_key[threadIdx.x] = inc - cnt;
-        if (threadIdx.x == 0) s_key[8u * nWaves] = total ? atomicAdd(counter, total) : 0u;
-    }
-    __syncthreads();
-    const uint32_t slot = s_key[8u * nWaves] + s_key[key * nWaves + wave] + mine;
-    __syncthreads();
-    return slot;
-}
+#if LM_APPEND_OCTANT
+#define LM_EXPERIMENTS_PART 3      // octant-ordered block append (round 5: measured, -0.4 %)
+#include "lm_experiments.h"
+#endif
 __device__ __forceinline__ void lm_count_block(uint32_t* counter, bool pred, uint32_t* s_tmp)
 {
     const unsigned long long mask = __ballot(pred);
@@ -274,10 +248,10 @@ KN(lm_k_trace_closest_packet)(LmScene sc, const float4* __restrict__ rayO, const
 // + K12 at depth 0 (GPUShadeIndirect.cu:7-146): the path continuation is sampled from the surface while it is still in
 // registers; survivors of a block iteration are appended to the wave-1 queue with ONE atomic.
 #ifndef LM_EXTRACT_WAVES
-#define LM_EXTRACT_WAVES 1       // minimum waves per SIMD asked of the compiler for the depth-0 kernel / the wave shading kernel (1 = no bound: 120 / 124 VGPRs, four waves)
-#endif
-#ifndef LM_SHADE_WAVES
-#define LM_SHADE_WAVES 1
+#define LM_EXTRACT_WAVES 5       // minimum waves per SIMD asked of the compiler for the depth-0 kernel / the wave shading kernel.  Round 6: 5 / 5 — the instantiations that run
+#endif                           // (from the compilation without the SLP vectoriser: 104 / 112 registers unbounded) fit 96 registers with 0 / 11 scratch instructions: five waves instead of
+#ifndef LM_SHADE_WAVES           // four, +1.1 % fast eager, +1.2 % exact (profiles/r06_extract_waves_ab.txt).  Rounds 1 - 5: 1 = no bound (120 / 124 registers with the SLP pass: the bound spilled).
+#define LM_SHADE_WAVES 5
 #endif
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_EXTRACT_WAVES)
 KN(lm_k_extract0)(LmScene sc, LmFrame fr, LmCamera cam, int cur, uint32_t seed2, int doIndirect, int outQ, uint32_t* outCount)
@@ -570,100 +544,6 @@ __device__ __forceinline__ void lm_path_tail_body(const LmScene& sc, const LmFra
     }
     }
 }
-// REPACK variant (tuning key tail_repack): a block takes 256 paths, one per lane, and after every depth the surviving paths are packed
-// into the block's lowest lanes through LDS (40 bytes of path state: origin, direction, contribution, pixel), so that a wavefront is either full or has no path
-// at all — it then skips the depth and only meets the barriers.  Same device functions, RNG streams and per-pixel order of the INDIRECT adds (a pixel has one
-// path; its adds are separated by the block barriers): identical image and counters.  Cost: three block barriers per depth, i.e. a depth takes as long as the
-// block's slowest wavefront (the plain variant lets every wavefront run ahead on its own).  A/B: profiles/r04_tail_repack_ab.txt.
-template <class NEE>
-__device__ __forceinline__ void lm_path_tail_repack_body(const LmScene& sc, const LmFrame& fr, int inQ, const uint32_t* __restrict__ inCount, int depth0, int depthMax, uint32_t seed0)
-{
-    __shared__ int s_stack[LM_STACK_LDS * LM_BLOCK];
-    __shared__ float s_lut[256];
-    __shared__ uint4 s_tab[LM_TABLE_QUADS];
-    __shared__ uint32_t s_pack[10 * LM_BLOCK];                   // [word][slot]: consecutive lanes touch consecutive banks
-    __shared__ uint32_t s_cnt[LM_BLOCK / 64];
-    const lm_lds_float* lut = lm_stage_lut(s_lut, sc);
-    const LmTables tab = lm_stage_tables(s_tab, sc);
-    const LmStack stack = lm_make_stack(s_stack, sc);
-    const uint32_t n = *inCount;
-    __builtin_amdgcn_s_setprio(3);
-    const uint32_t lane = lm_lane(), wave = threadIdx.x >> 6;
-    for (uint32_t base = blockIdx.x * LM_BLOCK; base < n; base += gridDim.x * LM_BLOCK) {     // block-uniform
-        const uint32_t i = base + threadIdx.x;
-        bool alive = i < n;
-        lf3 o = v3(0.f), d = v3(0.f), c = v3(0.f);
-        uint32_t li = 0u;
-        if (alive) {
-            const float4 o4 = fr.rayO[inQ][i], d4 = fr.rayD[inQ][i], c4 = fr.rayC[inQ][i];
-            o = v3(o4); d = v3(d4); c = v3(c4); li = f2u(d4.w);
-        }
-        uint32_t seed = seed0;
-        uint32_t live = min(n - base, (uint32_t)LM_BLOCK);        // paths the block still carries (block-uniform); they sit in threads [0, live)
-        for (int depth = depth0; depth < depthMax && live != 0u; depth++) {
-            const uint32_t seed2 = lm_wang_hash(seed);
-            bool emitRay = false;
-            lf3 o2 = v3(0.f), d2 = v3(0.f), c2 = v3(0.f);
-            if (wave * 64u < live) {                              // wave-uniform: this wavefront holds paths
-                if (depth > depth0) lm_count(fr.counters + LM_CNT_RAYS(depth), alive);
-                bool emitShadow = false;
-                lf3 sdir = v3(0.f), srad = v3(0.f), spos = v3(0.f);
-                float stmax = 0.f;
-                if (alive) {
-                    LmHit h; h.t = -1.f; h.u = 0.f; h.v = 0.f; h.slot = 0;
-                    const bool found = lm_traverse<false>(sc, o, d, 0.01f, 5000.f, stack, h, fr.counters);
-                    uint4 rec = make_uint4(0u, 0u, 0u, f2u(-1.f));
-                    if (found) {
-                        const uint2 id = sc.triId[h.slot];
-                        rec = make_uint4(id.x, id.y, lm_f32_to_f16(h.u) | (lm_f32_to_f16(h.v) << 16), f2u(h.t));
-                    }
-                    LmSurface s;
-                    lm_extract(sc, lut, tab, rec, o, d, c, s);
-                    const uint32_t ly = li / fr.ww, lx = li - ly * fr.ww;
-                    const uint32_t gi = (fr.y0 + ly) * fr.W + (fr.x0 + lx);
-                    emitShadow = lm_shade_direct<NEE>(sc, s, gi, seed, sdir, stmax, srad);
-                    spos = s.position;
-                    if (depth < depthMax - 1) emitRay = lm_shade_indirect(s, gi, seed2, o2, d2, c2);
-                }
-                lm_count(fr.counters + LM_CNT_SHADOW(depth), emitShadow);
-                if (emitShadow) {
-                    LmHit hs;
-                    if (!lm_traverse<true>(sc, spos, sdir, 0.01f, stmax, stack, hs, fr.counters)) {
-                        float4 px = fr.indirect[li];
-                        px.x += srad.x; px.y += srad.y; px.z += srad.z;
-                        fr.indirect[li] = px;
-                    }
-                }
-            }
-            // pack the continuing paths into the lowest threads of the block
-            const unsigned long long mask = __ballot(emitRay);
-            if (lane == 0u) s_cnt[wave] = (uint32_t)__popcll(mask);
-            __syncthreads();
-            uint32_t before = 0u, total = 0u;
-#pragma unroll
-            for (uint32_t w = 0; w < LM_BLOCK / 64u; w++) { const uint32_t k = s_cnt[w]; before += w < wave ? k : 0u; total += k; }
-            if (emitRay) {
-                const uint32_t slot = before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                s_pack[slot] = f2u(o2.x); s_pack[LM_BLOCK + slot] = f2u(o2.y); s_pack[2 * LM_BLOCK + slot] = f2u(o2.z);
-                s_pack[3 * LM_BLOCK + slot] = f2u(d2.x); s_pack[4 * LM_BLOCK + slot] = f2u(d2.y); s_pack[5 * LM_BLOCK + slot] = f2u(d2.z);
-                s_pack[6 * LM_BLOCK + slot] = f2u(c2.x); s_pack[7 * LM_BLOCK + slot] = f2u(c2.y); s_pack[8 * LM_BLOCK + slot] = f2u(c2.z);
-                s_pack[9 * LM_BLOCK + slot] = li;
-            }
-            __syncthreads();
-            alive = threadIdx.x < total;
-            if (alive) {
-                const uint32_t t = threadIdx.x;
-                o = v3(u2f(s_pack[t]), u2f(s_pack[LM_BLOCK + t]), u2f(s_pack[2 * LM_BLOCK + t]));
-                d = v3(u2f(s_pack[3 * LM_BLOCK + t]), u2f(s_pack[4 * LM_BLOCK + t]), u2f(s_pack[5 * LM_BLOCK + t]));
-                c = v3(u2f(s_pack[6 * LM_BLOCK + t]), u2f(s_pack[7 * LM_BLOCK + t]), u2f(s_pack[8 * LM_BLOCK + t]));
-                li = s_pack[9 * LM_BLOCK + t];
-            }
-            live = total;
-            __syncthreads();                                      // s_cnt / s_pack are rewritten in the next depth (and the INDIRECT adds of this depth are visible to it)
-            seed = lm_wang_hash(seed);
-        }
-    }
-}
 // Residency of the path tail.  The tail is one long launch beside the frame's critical ReSTIR chain: every wave slot and register it holds is taken from the kernels
 // that bound the frame, while its own length is the dependent chain of its longest path.  LM_TAIL_MAX_WAVES caps its waves per SIMD (0: whatever its registers allow);
 // interleaved A/B: profiles/r06_build_flags_ab.txt.
@@ -675,12 +555,8 @@ __device__ __forceinline__ void lm_path_tail_repack_body(const LmScene& sc, cons
 #else
 #define LM_TAIL_OCCUPANCY
 #endif
-extern "C" __global__ void __launch_bounds__(LM_BLOCK) LM_TAIL_OCCUPANCY
-KN(lm_k_path_tail_repack)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict__ inCount, int depth0, int depthMax, uint32_t seed0)
-{ lm_path_tail_repack_body<LmExact>(sc, fr, inQ, inCount, depth0, depthMax, seed0); }
-extern "C" __global__ void __launch_bounds__(LM_BLOCK) LM_TAIL_OCCUPANCY
-KN(lm_k_path_tail_repack_fs)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict__ inCount, int depth0, int depthMax, uint32_t seed0)
-{ lm_path_tail_repack_body<LmFast>(sc, fr, inQ, inCount, depth0, depthMax, seed0); }
+#define LM_EXPERIMENTS_PART 4      // the repacking path tail (round 4: measured, -1.4 %; tuning key tail_repack keeps it reachable)
+#include "lm_experiments.h"
 extern "C" __global__ void __launch_bounds__(LM_BLOCK) LM_TAIL_OCCUPANCY
 KN(lm_k_path_tail)(LmScene sc, LmFrame fr, int inQ, const uint32_t* __restrict__ inCount, int depth0, int depthMax, uint32_t seed0, int lanesPerWave)
 { lm_path_tail_body<false, LmExact>(sc, fr, inQ, inCount, depth0, depthMax, seed0, lanesPerWave); }

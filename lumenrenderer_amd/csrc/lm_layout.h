@@ -59,7 +59,7 @@ struct LmNodeW {
 // Triangle packet of the traversal, 64 bytes = one aligned cache line, in leaf order: the three world-space vertices as x y z x y each (lm_tri.h), so that
 // a ray reads its cyclically permuted axes (kx, ky, kz: lm_traverse.h lm_tri_test) by one 12-byte load per vertex at float offset kx.  The all-zero packet
 // (sentinel behind the last slot) never reports a hit: its three 2-D points coincide, every edge function and the determinant are zero for every ray.
-struct alignas(64) LmTriPacket { float f[16]; };
+struct LmTriPacket { float f[16]; };      // (64 bytes; device buffers come from hipMalloc: line-aligned.  No alignas: over-aligned host vectors went through memalign and fragmented the heap under topology edits — tools/soak.py)
 
 // scene data table entry (reference: DevicePrimitiveInstance, ModelStructs.h:73-80)
 struct LmEntry {

@@ -275,53 +275,8 @@ __device__ __forceinline__ void lm_cex(uint32_t& ka, int& ra, uint32_t& kb, int&
     ka = k0; kb = k1; ra = r0; rb = r1;
 }
 #if LM_WIDTH == 8
-// 8-wide node step.  The eight child records are fetched in the ray's VISITING order — record p from octant slot p ^ octant(direction): a
-// per-lane address inside the node's one 128-byte line — so everything behind the loads is compile-time ordered: p = 0 is the child
-// nearest along the ray, p = 7 the farthest.  No sorting network: every hit child is pushed far to near, and the nearest, which ends on top,
-// is taken back at once.  The pushes of the common case are unconditional LDS stores whose stack pointer only advances for a hit (no
-// branches); a lane whose LDS share of the stack could overflow within this step takes the branching lm_push path.
-template <bool ANY>
-__device__ __forceinline__ int lm_node_step(const LmScene& sc, int cur, const LmRayQ& rq, float tmin, float hitT, const LmStack& stack, int& sp,
-                                            const lm_lds_u4* top, uint32_t* boxes = nullptr)
-{
-    uint4 q[8];
-#if LM_TOP_NODES
-    if (cur >= LM_TOP_BASE) {                                    // (only kernels that staged the table ever hold such a reference)
-        const uint32_t off = ((uint32_t)(cur - LM_TOP_BASE) << 7) | rq.oct;
-        typedef __attribute__((address_space(3))) char lm_lds_char;
-        const lm_lds_char* tb = (const lm_lds_char*)top;
-#pragma unroll
-        for (int p = 0; p < 8; p++) q[p] = lm_lds_read4((const lm_lds_u4*)(tb + (off ^ ((uint32_t)p << 4))));
-    } else
-#endif
-    {
-        const uint32_t off = ((uint32_t)cur << 7) | rq.oct;
-        const char* nb = (const char*)sc.nodes;
-#pragma unroll
-        for (int p = 0; p < 8; p++) q[p] = *(const uint4*)(nb + (off ^ ((uint32_t)p << 4)));
-    }
-    if (boxes) { for (int p = 0; p < 8; p++) *boxes += (int)q[p].w != LM_REF_NONE; }      // counting build
-    uint32_t k[8];
-#pragma unroll
-    for (int p = 0; p < 8; p++) lm_slab(q[p], rq, tmin, hitT, k[p]);
-    int next = LM_REF_NONE;
-    if (sp + 8 <= LM_STACK_LDS) {
-        lm_lds_int* sl = stack.lds + sp * LM_BLOCK;
-#pragma unroll
-        for (int p = 7; p >= 0; p--) {
-            const bool h = k[p] != 0xffffffffu;
-            *sl = (int)q[p].w;                                   // overwritten by the next store unless this child is hit
-            sl += h ? LM_BLOCK : 0; sp += h ? 1 : 0;
-            next = h ? (int)q[p].w : next;
-        }
-    } else {
-#pragma unroll
-        for (int p = 7; p >= 0; p--) if (k[p] != 0xffffffffu) { lm_push(stack, sp, (int)q[p].w); next = (int)q[p].w; }
-    }
-    if (next == LM_REF_NONE) return sp == 0 ? LM_REF_NONE : lm_pop(stack, sp);
-    --sp;                                                        // the nearest hit child is on top: continue with it
-    return next;
-}
+#define LM_EXPERIMENTS_PART 1      // the 8-wide node step (round 3: measured, -5 ... -15 %)
+#include "lm_experiments.h"
 #else
 template <bool ANY>
 __device__ __forceinline__ int lm_node_step(const LmScene& sc, int cur, const LmRayQ& rq, float tmin, float hitT, const LmStack& stack, int& sp,
@@ -359,60 +314,13 @@ __device__ __forceinline__ int lm_node_step(const LmScene& sc, int cur, const Lm
     return next;
 }
 
-// The same step in two halves for the queue kernels (LM_NODE_PIPELINE): the record fetch, and the evaluation, which issues the fetch of the
-// child it continues with as soon as that child is known — after three of the five comparators (closest hit) or the first-hit select
-// (any hit) — so that the rest of the ordering and the stack pushes run under the load instead of in front of it.  `pre` tells the
-// caller that q0..q3 already hold the records of the returned node.  Visiting order, stack contents and results are those of lm_node_step.
-// Measured and NOT used: the records in flight stay live across the pushes, which costs 12 more VGPRs — closest hit spills at eight
-// waves per SIMD (200 -> 400 us) or runs with six (230 us), visibility 228 -> 300 us, NEE shadow 91 -> 106 us, frame -5 %
-// (profiles/r02_node_pipeline_ab.txt): occupancy hides the load better than the overlap does.
 #ifndef LM_NODE_PIPELINE
 #define LM_NODE_PIPELINE 0
 #endif
-__device__ __forceinline__ void lm_node_fetch(const LmScene& sc, int cur, const lm_lds_u4* top, uint4& q0, uint4& q1, uint4& q2, uint4& q3)
-{
-#if LM_TOP_NODES
-    if (cur >= LM_TOP_BASE) {                                    // (only kernels that staged the table ever hold such a reference)
-        const lm_lds_u4* nd = top + 4u * (uint32_t)(cur - LM_TOP_BASE);
-        q0 = lm_lds_read4(nd); q1 = lm_lds_read4(nd + 1); q2 = lm_lds_read4(nd + 2); q3 = lm_lds_read4(nd + 3);
-    } else
+#if LM_NODE_PIPELINE
+#define LM_EXPERIMENTS_PART 2      // node fetch / evaluation in two halves (round 2: measured, -5 %)
+#include "lm_experiments.h"
 #endif
-    {
-        const uint4* nd = sc.nodes[cur].c;
-        q0 = nd[0]; q1 = nd[1]; q2 = nd[2]; q3 = nd[3];
-    }
-}
-template <bool ANY>
-__device__ __forceinline__ int lm_node_eval(const LmScene& sc, uint4& q0, uint4& q1, uint4& q2, uint4& q3, bool& pre, const LmRayQ& rq, float tmin, float hitT,
-                                            const LmStack& stack, int& sp, const lm_lds_u4* top, uint32_t* boxes = nullptr)
-{
-    if (boxes) *boxes += ((int)q0.w != LM_REF_NONE) + ((int)q1.w != LM_REF_NONE) + ((int)q2.w != LM_REF_NONE) + ((int)q3.w != LM_REF_NONE);   // counting build
-    uint32_t k0, k1, k2, k3;
-    lm_slab(q0, rq, tmin, hitT, k0); lm_slab(q1, rq, tmin, hitT, k1); lm_slab(q2, rq, tmin, hitT, k2); lm_slab(q3, rq, tmin, hitT, k3);
-    int r0 = (int)q0.w, r1 = (int)q1.w, r2 = (int)q2.w, r3 = (int)q3.w;
-    pre = false;
-    if (!ANY || LM_ANY_ORDERED) {
-        lm_cex(k0, r0, k1, r1); lm_cex(k2, r2, k3, r3); lm_cex(k0, r0, k2, r2);          // (k0, r0) is the nearest hit child now
-        if (k0 == 0xffffffffu) return sp == 0 ? LM_REF_NONE : lm_pop(stack, sp);
-        pre = r0 >= 0;
-        if (pre) lm_node_fetch(sc, r0, top, q0, q1, q2, q3);
-        lm_cex(k1, r1, k3, r3); lm_cex(k1, r1, k2, r2);
-        if (k3 != 0xffffffffu) lm_push(stack, sp, r3);
-        if (k2 != 0xffffffffu) lm_push(stack, sp, r2);
-        if (k1 != 0xffffffffu) lm_push(stack, sp, r1);
-        return r0;
-    }
-    // any hit: continue with the first hit child in node order, push the others (highest index first: the same stack as lm_node_step)
-    const bool h0 = k0 != 0xffffffffu, h1 = k1 != 0xffffffffu, h2 = k2 != 0xffffffffu, h3 = k3 != 0xffffffffu;
-    const int next = h0 ? r0 : h1 ? r1 : h2 ? r2 : h3 ? r3 : LM_REF_NONE;
-    if (next == LM_REF_NONE) return sp == 0 ? LM_REF_NONE : lm_pop(stack, sp);
-    pre = next >= 0;
-    if (pre) lm_node_fetch(sc, next, top, q0, q1, q2, q3);
-    if (h3 && (h0 || h1 || h2)) lm_push(stack, sp, r3);
-    if (h2 && (h0 || h1)) lm_push(stack, sp, r2);
-    if (h1 && h0) lm_push(stack, sp, r1);
-    return next;
-}
 #endif   // LM_WIDTH
 
 template <bool ANY>

@@ -2266,3 +2266,34 @@ def test_full_size_properties_1440p():
     b = r3.GetRadiance()
     assert np.array_equal(b.view(np.uint32), (a * np.float32(2.0)).view(np.uint32))
     r3.close()
+
+
+def test_exact_mode_is_the_same_image_whichever_compilation_a_kernel_comes_from():
+    """The library holds every kernel twice — compiled with and without the SLP vectoriser (kernels.hip LM_NOSLP_VARIANT) — and the renderer picks per kernel class
+    (LUMEN_MI_NOSLP_KERNELS / _EXACT; renderer.cpp applyNoSlpKernels).  Both compilations are -ffp-contract=off: in the exact mode every mix must render the same bits.
+    Three processes (the lists are read when a renderer is created): everything with SLP, everything without, the default mix; radiance, channels and counters identical,
+    and identical to the oracle."""
+    import subprocess, sys
+    body = ("import sys, hashlib; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from helpers import cornell, product_from\n"
+            "r = product_from(cornell(), 160, 120, 5, blend=True)\n"
+            "for _ in range(3): assert r.TraceFrame()\n"
+            "h = hashlib.sha256(); h.update(r.GetRadiance().tobytes()); h.update(r.GetChannel(0).tobytes()); h.update(r.GetChannel(1).tobytes()); h.update(str(r.GetCounters()[:8]).encode())\n"
+            "print('IMG', h.hexdigest())\n") % (os.path.dirname(GOLDEN), os.path.dirname(os.path.dirname(GOLDEN)))
+    digests = []
+    for mix in ({"LUMEN_MI_NOSLP_KERNELS": "none", "LUMEN_MI_NOSLP_KERNELS_EXACT": "none"}, {"LUMEN_MI_NOSLP_KERNELS": "all"}, {}):
+        env = dict(os.environ, **mix)
+        run = subprocess.run([sys.executable, "-c", body], capture_output=True, text=True, timeout=600, env=env)
+        assert run.returncode == 0 and "IMG " in run.stdout, (mix, run.stdout[-500:], run.stderr[-2000:])
+        digests.append(run.stdout.split("IMG ")[1].split()[0])
+    assert digests[0] == digests[1] == digests[2], digests
+    import hashlib
+    o = oracle_from(cornell(), 160, 120, 5, blend=True)
+    for _ in range(3):
+        assert o.trace_frame() == 0
+    r = product_from(cornell(), 160, 120, 5, blend=True)
+    for _ in range(3):
+        assert r.TraceFrame()
+    assert np.array_equal(r.GetRadiance().view(np.uint32), o.radiance().view(np.uint32))
+    r.close(); o.close()
