@@ -694,6 +694,12 @@ KN(lm_k_restir_trace_shade_packet)(LmScene sc, LmFrame fr, int rc, const uint32_
 }
 
 #include "lm_restir.h"
+// Issue priority of the EXACT instantiations of the ReSTIR history kernels (bit 0 spatial, 1 temporal, 2 combine).  In the exact mode the ReSTIR stream is the frame's critical chain
+// and its kernels are long VALU kernels (IEEE division / square-root sequences) that otherwise queue behind the wave chain's priority-3 kernels on every SIMD; the fast instantiations
+// are memory-bound and do not respond (profiles/r06_prio_ab.txt).
+#ifndef LM_EXACT_RESTIR_PRIO
+#define LM_EXACT_RESTIR_PRIO 1
+#endif
 
 // K20 FillLightBags — ReSTIRKernels.cu:343-370
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
@@ -928,6 +934,7 @@ template <class A, int ROLE>
 __device__ __forceinline__ void lm_restir_temporal_body(const LmFrame& fr, int cur, int prev, int rc, int rp, int rf, uint32_t seed, uint32_t* visCount, uint32_t* s_tmp)
 {
     if (ROLE == LM_RARE && fr.counters[LM_CNT_RARE] == 0u) return;
+    if constexpr (!A::contracted && (LM_EXACT_RESTIR_PRIO & 2)) __builtin_amdgcn_s_setprio(3);
     // the previous frame's pending history passes were launched before this kernel and have run or returned: nothing is owed any more (lm_reuse_owed)
     if (ROLE != LM_RARE && blockIdx.x == 0 && threadIdx.x == 0) fr.swap[5] = 1;
     rc = lm_res_idx(fr, rc);
@@ -1108,6 +1115,8 @@ __device__ __forceinline__ void lm_restir_spatial_body(const LmFrame& fr, int cu
     }
 #ifdef LM_SPATIAL_PRIO
     __builtin_amdgcn_s_setprio(LM_SPATIAL_PRIO);
+#else
+    if constexpr (!A::contracted && (LM_EXACT_RESTIR_PRIO & 1)) __builtin_amdgcn_s_setprio(3);      // exact instantiation: LM_EXACT_RESTIR_PRIO (top of the ReSTIR section)
 #endif
     int wx0 = 0, wy0 = 0;                                           // window origin of the staged probes (window-local pixels, may be negative)
     if constexpr (LDS_PROBES) {
@@ -1242,6 +1251,7 @@ __device__ __forceinline__ void lm_restir_combine_body(const LmFrame& fr, int cu
     if (fr.deferred && !lm_reuse_owed(fr)) return;
     if (fr.deferred && ROLE != LM_RARE && vb == 0u && threadIdx.x == 0) ++fr.swap[8];             // statistic: deferred executions
     if (ROLE == LM_RARE && lm_no_rare(fr)) return;
+    if constexpr (!A::contracted && (LM_EXACT_RESTIR_PRIO & 4)) __builtin_amdgcn_s_setprio(3);
     rc = lm_res_idx(fr, rc);
     rs = lm_res_idx(fr, rs);
     if constexpr (ROLE == LM_RARE) {                                // the role follows the pixel's own current surface
