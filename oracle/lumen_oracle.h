@@ -7,10 +7,14 @@
  * Parity status: the reference as a whole cannot be built or run here (CUDA 10 + OptiX 7.1 + D3D11,
  * SURVEY.md §0 F10).  The header-only parts (RNG, material packing, Disney BSDF, Reservoir update / weight / reset,
  * CDF::Get / BinarySearch, make_color, binary16 conversion) ARE pinned against the reference's own headers through
- * tests/golden/ref_kat.npz (generator: oracle/ref_kat/).  Everything that
+ * tests/golden/ref_kat.npz, the kernel bodies of the ReSTIR chain, shading, primary rays, surface extraction, motion vectors and the light list through ref_kat5 / ref_kat6.npz
+ * (line-range slices of the reference's .cu text run thread by thread), and the binary16 arithmetic of ShadeReservoirs / MergeOutputChannels — which decision D1 replaces by fp32 here —
+ * through ref_kat7.npz (generator of all: oracle/ref_kat/, container-only).  Everything that
  * lives in OptiX programs or closed libraries (traversal, the texture unit's internal arithmetic — its published weight format IS followed —, thrust
- * sort/scan order, %smid bag choice, racy fp16 accumulation) has no reference-side vectors:
- * for those stages this oracle is "parity unpinned" and is the definition the HIP path is held to.
+ * sort/scan order, %smid bag choice) has no reference-side vectors:
+ * for those stages this oracle is "parity unpinned" and is the definition the HIP path is held to.  Traversal: the hit rule is the published watertight test
+ * (Woop, Benthin, Wald, JCGT 2013; lumen_oracle.cpp tri_hit) — like OptiX, it lets no ray pass between triangles that share an edge or a vertex
+ * (tests/test_oracle_kat.py::test_oracle_hit_rule_is_watertight_at_shared_edges_and_vertices).
  */
 #ifndef LUMEN_ORACLE_H
 #define LUMEN_ORACLE_H

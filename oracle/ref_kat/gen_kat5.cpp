@@ -21,7 +21,8 @@
 // exact), saturate, and min / max / abs / isnan / isinf from <cmath> / <algorithm>.  ShadeReservoirs (ReSTIRKernels.cu:619-665), the callee that adds a
 // reservoir's contribution to the fp16 DIRECT surface with half4 arithmetic (device-only intrinsics; and a non-atomic fp16 read-modify-write this build
 // replaces by fp32 accumulation, decision D1) is NOT compiled: a recorder with the declared signature (ReSTIRKernels.cuh) logs every call — which
-// reservoir is shaded into which pixel — and the tests price each call as contribution * (weight / 3) in fp32.  The OptiX visibility programs
+// reservoir is shaded into which pixel — and the tests price each call as contribution * (weight / 3) in fp32 (since round 6 the callee's own text runs in gen_kat7.cpp, on the
+// reference's Half4.h, and the tests bound the distance between that price and its binary16 result per operation).  The OptiX visibility programs
 // (WaveFrontShaders.cu:181-216: occluded => reservoir weight = 0) are closed; occlusion comes from a committed pseudo-random mask instead.
 // VolumetricShadeDirect (VolumetricKernels/GPUVolumetricShadeDirect.cu:8-101), the first callee of ShadeDirect, is out of scope (volumes): its
 // whole body sits under `if (exit T > entry T)` (:23) and draws from the seed only inside; the stand-in below checks that condition is false for every
