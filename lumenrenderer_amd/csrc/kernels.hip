@@ -1588,13 +1588,16 @@ __device__ __forceinline__ uint32_t lm_ordered(float f) { const uint32_t u = f2u
 __device__ __forceinline__ float lm_unordered(uint32_t u) { return u2f((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
 __device__ __forceinline__ float lm_wave_min(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o)); return v; }
 __device__ __forceinline__ float lm_wave_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
-// bounds[0..2] min, [3..5] max (order-preserving encoding), [6] max |coordinate| (bits of a non-negative float)
+// bounds[0..2] min, [3..5] max (order-preserving encoding), [6] max |coordinate| (bits of a non-negative float).
+// The seven bounds sit in one cache line, and atomics on one line retire at ~ 88 per microsecond: one set per WAVEFRONT (rounds 1 - 5: 4 098 wavefronts x 7 for C2) was
+// 326 of the kernel's 333 us.  Now a grid of at most two blocks per CU loops over the slots, a block reduces its bounds through LDS and issues ONE set of atomics
+// (min / max are order independent: the same bits).
 extern "C" __global__ void __launch_bounds__(LM_BLOCK)
 KN(lm_k_refit_tris)(LmScene sc, uint32_t nSlots, float4* __restrict__ triBox, uint32_t* bounds)
 {
-    const uint32_t s = blockIdx.x * LM_BLOCK + threadIdx.x;
+    __shared__ float s_red[7 * (LM_BLOCK / 64)];
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, maxAbs = 0.f;
-    if (s < nSlots) {
+    for (uint32_t s = blockIdx.x * LM_BLOCK + threadIdx.x; s < nSlots; s += gridDim.x * LM_BLOCK) {
         const uint2 id = sc.triId[s];
         const LmEntry e = sc.entries[id.x];
         float tri[9];
@@ -1607,15 +1610,25 @@ KN(lm_k_refit_tris)(LmScene sc, uint32_t nSlots, float4* __restrict__ triBox, ui
             tri[3 * k + 2] = e.m[8] * p.x + e.m[9] * p.y + e.m[10] * p.z + e.m[11] * 1.f;
         }
         sc.packets[s] = lm_make_packet(tri);
-        for (int k = 0; k < 9; k++) { lo[k % 3] = fminf(lo[k % 3], tri[k]); hi[k % 3] = fmaxf(hi[k % 3], tri[k]); maxAbs = fmaxf(maxAbs, fabsf(tri[k])); }
-        triBox[2u * s] = make_float4(lo[0], lo[1], lo[2], 0.f);
-        triBox[2u * s + 1u] = make_float4(hi[0], hi[1], hi[2], 0.f);
+        float tlo[3] = {INFINITY, INFINITY, INFINITY}, thi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int k = 0; k < 9; k++) { tlo[k % 3] = fminf(tlo[k % 3], tri[k]); thi[k % 3] = fmaxf(thi[k % 3], tri[k]); maxAbs = fmaxf(maxAbs, fabsf(tri[k])); }
+        triBox[2u * s] = make_float4(tlo[0], tlo[1], tlo[2], 0.f);
+        triBox[2u * s + 1u] = make_float4(thi[0], thi[1], thi[2], 0.f);
+        for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], tlo[k]); hi[k] = fmaxf(hi[k], thi[k]); }
     }
     for (int k = 0; k < 3; k++) { lo[k] = lm_wave_min(lo[k]); hi[k] = lm_wave_max(hi[k]); }
     maxAbs = lm_wave_max(maxAbs);
-    if (lm_lane() == 0u && lo[0] <= hi[0]) {
-        for (int k = 0; k < 3; k++) { atomicMin(bounds + k, lm_ordered(lo[k])); atomicMax(bounds + 3 + k, lm_ordered(hi[k])); }
-        atomicMax(bounds + 6, f2u(maxAbs));
+    const uint32_t wave = threadIdx.x >> 6;
+    if (lm_lane() == 0u) { for (int k = 0; k < 3; k++) { s_red[7u * wave + k] = lo[k]; s_red[7u * wave + 3 + k] = hi[k]; } s_red[7u * wave + 6] = maxAbs; }
+    __syncthreads();
+    if (threadIdx.x < 7u) {
+        const uint32_t k = threadIdx.x;
+        float v = s_red[k];
+        for (uint32_t w = 1; w < LM_BLOCK / 64; w++) v = k < 3u ? fminf(v, s_red[7u * w + k]) : fmaxf(v, s_red[7u * w + k]);
+        // an empty block (no slot) holds +inf / -inf / 0: harmless for min / max, skipped anyway
+        if (k < 3u) { if (v != INFINITY) atomicMin(bounds + k, lm_ordered(v)); }
+        else if (k < 6u) { if (v != -INFINITY) atomicMax(bounds + k, lm_ordered(v)); }
+        else atomicMax(bounds + 6, f2u(v));
     }
 }
 // scene box -> quantisation frame (the formulas of lm_build_bvh), then re-arm the bounds for the next refit
@@ -1897,7 +1910,8 @@ static void l_query_any(hipStream_t s, int g, LmScene sc, const float4* o, const
 static void l_query_closest(hipStream_t s, int g, LmScene sc, const float4* o, const float4* d, uint32_t n, float tmin, float tmax, uint4* id, float4* uvt, uint32_t* counters)
 { hipLaunchKernelGGL(KN(lm_k_query_closest_raw), LM_GRID(g), sc, o, d, n, tmin, tmax, id, uvt, counters); }
 static void l_export_aux(hipStream_t s, int g, LmFrame fr, int cur, float minD, float maxD, float* depth, uint2* nr) { hipLaunchKernelGGL(KN(lm_k_export_aux), LM_GRID(g), fr, cur, minD, maxD, depth, nr); }
-static void l_refit_tris(hipStream_t s, LmScene sc, uint32_t nSlots, float4* triBox, uint32_t* bounds) { hipLaunchKernelGGL(KN(lm_k_refit_tris), LM_GRID((nSlots + LM_BLOCK - 1) / LM_BLOCK), sc, nSlots, triBox, bounds); }
+static void l_refit_tris(hipStream_t s, LmScene sc, uint32_t nSlots, float4* triBox, uint32_t* bounds)
+{ const uint32_t g = std::max(1u, std::min((nSlots + LM_BLOCK - 1) / LM_BLOCK, 512u)); hipLaunchKernelGGL(KN(lm_k_refit_tris), LM_GRID(g), sc, nSlots, triBox, bounds); }      // <= two blocks per CU: one set of bound atomics per block
 static void l_refit_quant(hipStream_t s, uint32_t* bounds, float* quant) { hipLaunchKernelGGL(KN(lm_k_refit_quant), dim3(1), dim3(64), 0, s, bounds, quant); }
 static void l_refit_level(hipStream_t s, LmScene sc, const uint32_t* levelNodes, uint32_t count, const float4* triBox, float4* nodeBox) { hipLaunchKernelGGL(KN(lm_k_refit_level), LM_GRID((count + LM_BLOCK - 1) / LM_BLOCK), sc, levelNodes, count, triBox, nodeBox); }
 #if LUMEN_MI_TEST_HOOKS

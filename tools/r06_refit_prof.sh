@@ -1,5 +1,5 @@
 R=$PWD
-for v in woop cur; do
+for v in ${LIBS:-woop cur}; do
   export LUMEN_MI_LIBRARY=$R/lumenrenderer_amd/ab/liblumen_mi_$v.so
   rm -rf gpurun_out/rp
   (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/rp -- python3 $R/tools/refit.py > $R/gpurun_out/rp.log 2>&1)
