@@ -378,7 +378,7 @@ void lm_build_bvh(const float* tris, uint32_t nTris, LmBvh* out)
     parallelChunks(nSlots, threads, [&](unsigned, size_t lo, size_t hi) { for (size_t s = lo; s < hi; s++) out->packets[s] = lm_make_packet(tris + 9 * (size_t)out->order[s]); });
     memset(&out->packets[nSlots], 0, sizeof(LmTriPacket));               // sentinel packet: zero edge functions, never a hit
 
-    lap("packets packets");
+    lap("triangle packets");
     // ---- 16-bit quantisation relative to the (padded) scene box, rounded outward by LM_QUANT_MARGIN extra steps
     float smin[3] = {INFINITY, INFINITY, INFINITY}, smax[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (uint32_t t = 0; t < nTris; t++) for (int k = 0; k < 3; k++) { smin[k] = std::min(smin[k], tbox[t].lo[k]); smax[k] = std::max(smax[k], tbox[t].hi[k]); }

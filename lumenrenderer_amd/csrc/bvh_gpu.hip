@@ -46,10 +46,26 @@ __global__ void k_tri_boxes(const LmEntry* __restrict__ entries, const float4* _
             for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], w[a]); hi[a] = fmaxf(hi[a], w[a]); }
         }
         boxLo[t] = make_float4(lo[0], lo[1], lo[2], 0.f); boxHi[t] = make_float4(hi[0], hi[1], hi[2], 0.f);
-        for (int a = 0; a < 3; a++) {
-            const float c = 0.5f * (lo[a] + hi[a]);
-            if (c == c) { atomicMin(cbounds + a, ordf(c)); atomicMax(cbounds + 3 + a, ordf(c)); }
-        }
+    }
+    // scene box of the centroids: reduced over the wavefront and the block first, ONE set of atomics per block (round 6: six atomics per TRIANGLE on six words of one
+    // cache line were most of this kernel — 60 M of them for the 10 M-triangle scene; min / max are order independent, so the bounds are the same bits)
+    __shared__ float s_red[6 * 16];
+    float cmin[3], cmax[3];
+    for (int a = 0; a < 3; a++) {
+        const float c = 0.5f * (lo[a] + hi[a]);
+        const bool ok = t < n && c == c;
+        cmin[a] = ok ? c : INFINITY; cmax[a] = ok ? c : -INFINITY;
+        for (int o = 32; o > 0; o >>= 1) { cmin[a] = fminf(cmin[a], __shfl_xor(cmin[a], o)); cmax[a] = fmaxf(cmax[a], __shfl_xor(cmax[a], o)); }
+    }
+    const uint32_t wave = threadIdx.x >> 6, nWaves = (blockDim.x + 63u) >> 6;
+    if ((threadIdx.x & 63u) == 0u) for (int a = 0; a < 3; a++) { s_red[6u * wave + a] = cmin[a]; s_red[6u * wave + 3 + a] = cmax[a]; }
+    __syncthreads();
+    if (threadIdx.x < 6u) {
+        const uint32_t k = threadIdx.x;
+        float v = s_red[k];
+        for (uint32_t w = 1; w < nWaves; w++) v = k < 3u ? fminf(v, s_red[6u * w + k]) : fmaxf(v, s_red[6u * w + k]);
+        if (k < 3u) { if (v != INFINITY) atomicMin(cbounds + k, ordf(v)); }
+        else if (v != -INFINITY) atomicMax(cbounds + k, ordf(v));
     }
 }
 __device__ __forceinline__ unsigned long long spread21(unsigned long long v)      // 21 bits -> every third bit
