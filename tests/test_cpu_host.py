@@ -1082,3 +1082,33 @@ def test_library_builds_without_its_test_surface(tmp_path):
     assert all(hasattr(lib, n) for n in capi.SYMBOLS if n.startswith("lumen_mi_test_"))
     mk = open(os.path.join(csrc, "Makefile")).read()
     assert "HOOKS ?= 1" in mk and "-DLUMEN_MI_TEST_HOOKS=$(HOOKS)" in mk
+
+
+def test_group_entry_points_refuse_bad_arguments_without_a_gpu():
+    """The tile-group C ABI (include/lumen_mi.h "tile groups") on a box without a GPU: every entry point refuses NULL handles and impossible worlds with LUMEN_MI_ERR_INVALID and a
+    message, the plan functions are pure (no device needed), and creating a group on a renderer that was never initialised is a state error, not a crash."""
+    import ctypes as C
+    from lumenrenderer_amd import capi
+    lib = capi.load_library()
+    plan = capi.TilePlan(); n = C.c_uint32(0); ms = C.c_float(0); h = C.c_void_p()
+    assert lib.lumen_mi_group_plan(2560, 1440, 8, 3, None) == capi.ERR_INVALID
+    assert lib.lumen_mi_group_seams(2560, 1440, 8, 3, None, 0, None) == capi.ERR_INVALID
+    assert lib.lumen_mi_group_seams(2560, 1440, 8, 3, None, 0, C.byref(n)) == capi.OK and n.value >= 3        # an interior tile of the 4 x 2 grid has at least three neighbours
+    small = (capi.Seam * 1)()
+    assert lib.lumen_mi_group_seams(2560, 1440, 8, 3, small, 1, C.byref(n)) == capi.ERR_INVALID and b"capacity" in lib.lumen_mi_last_error()
+    for fn, args in (("lumen_mi_group_destroy", (None,)), ("lumen_mi_group_trace_frame", (None,)), ("lumen_mi_group_gather", (None,)), ("lumen_mi_group_synchronize", (None,)),
+                     ("lumen_mi_group_self_test", (None, C.byref(ms))), ("lumen_mi_group_get_plan", (None, C.byref(plan))), ("lumen_mi_group_get_frame", (None, None, 0)),
+                     ("lumen_mi_group_frame_device", (None, None)), ("lumen_mi_group_get_stats", (None, None, None)), ("lumen_mi_group_unique_id", (None,))):
+        assert getattr(lib, fn)(*args) == capi.ERR_INVALID, fn
+    assert lib.lumen_mi_group_create(None, 0, 1, None, None, C.byref(h)) == capi.ERR_INVALID
+    r = C.c_void_p()
+    assert lib.lumen_mi_create(C.byref(r)) == capi.OK
+    assert lib.lumen_mi_group_create(r, 2, 2, None, None, C.byref(h)) == capi.ERR_INVALID            # rank >= world
+    assert lib.lumen_mi_group_create(r, 0, 2, None, None, C.byref(h)) == capi.ERR_INVALID and b"lumen_mi_group_unique_id" in lib.lumen_mi_last_error()      # RCCL transport without an id
+    bad = capi.Transport(None, capi.EXCHANGE_FN(0), capi.ALLREDUCE_FN(0))
+    assert lib.lumen_mi_group_create(r, 0, 2, None, C.byref(bad), C.byref(h)) == capi.ERR_INVALID    # a transport needs both callbacks
+    import torch
+    if not torch.cuda.is_available():
+        rc = lib.lumen_mi_group_create(r, 0, 1, None, None, C.byref(h))                              # never initialised (no GPU here): refused, nothing leaks
+        assert rc in (capi.ERR_INVALID, capi.ERR_STATE, capi.ERR_DEVICE), rc
+    assert lib.lumen_mi_destroy(r) == capi.OK
