@@ -136,8 +136,8 @@ def test_plain_c_program_renders_as_a_tile_group(n_ranks, tmp_path):
         assert open(xout, "rb").read() == one
 
 
-@pytest.mark.parametrize("n_ranks,workload", [(2, "sandbox"), (8, "c2"), (8, "c4")])      # c4 = BASELINE's 8-GPU configuration (4K, 8 spp, depth 8)
-def test_bench_multi_rank_path_rehearsed_on_the_one_gpu(n_ranks, workload, tmp_path):
+@pytest.mark.parametrize("n_ranks,workload,transport", [(2, "sandbox", "native"), (8, "c2", "native"), (8, "c4", "native"), (2, "sandbox", "torch")])      # c4 = BASELINE's 8-GPU configuration (4K, 8 spp, depth 8)
+def test_bench_multi_rank_path_rehearsed_on_the_one_gpu(n_ranks, workload, transport, tmp_path):
     """`python bench.py --gpus N` end to end where only one GPU exists (LUMEN_BENCH_ONE_GPU=1: every rank on GPU 0, collectives over gloo with host staging): the
     self-launch, the windows and tiles, the seam exchange after every TraceFrame (sandbox: odd depth), the gather, the barrier-bracketed timing with the maximum over
     ranks and the per-rank statistics all execute, and rank 0 prints ONE well-formed line that names itself a rehearsal.  The rate is not looked at.
@@ -147,12 +147,13 @@ def test_bench_multi_rank_path_rehearsed_on_the_one_gpu(n_ranks, workload, tmp_p
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", LUMEN_BENCH_ONE_GPU="1", LUMEN_BENCH_LOG_DIR=str(tmp_path))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n_ranks), "--workload", workload, "--steps", "2", "--warmup", "1"],
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n_ranks), "--workload", workload, "--steps", "2", "--warmup", "1", "--transport", transport],
                          env=env, capture_output=True, text=True, timeout=1200)
     assert res.returncode == 0, res.stdout[-1500:] + "\n" + res.stderr[-1500:] + "\n" + _rank_logs(tmp_path)
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
     j = json.loads(lines[0])
     assert j["n_gpus"] == n_ranks and j["rccl_world"] == n_ranks and len(j["devices"]) == n_ranks and "rehearsal" in j
-    assert len(j["per_rank"]) == n_ranks and all(p["render_ms_per_step"] > 0 for p in j["per_rank"])
+    assert len(j["per_rank"]) == n_ranks and all(p["render_ms_per_step"] > 0 and p["halo_over_tile"] > 0 for p in j["per_rank"])
+    assert ("native tile group" in j["transport"]) == (transport == "native") and (j["group_self_test_ms"] is not None) == (transport == "native")
     assert j["value"] > 0 and j["scaling"] == "strong" and j["config"]["tiles"].split(" ")[0] in ("2x1", "1x2", "4x2", "2x4")
