@@ -189,7 +189,9 @@ int lumen_mi_set_instrumented(lumen_mi_renderer*, int enable);   /* use the node
  * the probes of a 32 x 32 pixel tile + its 30-pixel reach in LDS, 132 KB per block; 2: the same with the ordinary 16 x 16 tile, 92 KB per block; identical image; default 0: either evicts the other streams' kernels, measured slower on the frame),
  * "fast_resample" (arithmetic mode of the ReSTIR passes: hardware rcp / rsq / sqrt and the contracted target function; radiance within 1e-3 relative L2 of the exact mode,
  * 1e-8 measured), "fast_shade" (on top of it: the NEE contribution at depth >= 1 with hardware rcp / sqrt: changes the last bits of INDIRECT radiance and, within
- * rounding of two thresholds, whether a shadow ray is emitted; never which path continues). */
+ * rounding of two thresholds, whether a shadow ray is emitted; never which path continues), "pick_wide" (light lists of 513 .. 1 984 triangles: the candidate pick runs as
+ * 1024-thread blocks, four tiles around ONE light table in LDS, instead of gathering the lights from memory: 0 never, 1 in the fast mode (default; the exact instantiation is
+ * slower that way), 2 in both modes; identical image). */
 int lumen_mi_set_tuning(lumen_mi_renderer*, const char* key, int value);
 
 /* ---- tile sharding (new functionality: the reference is single-GPU) */

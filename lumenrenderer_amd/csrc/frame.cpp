@@ -339,7 +339,7 @@ int traceFrameAsync(R* r)
             rs = wangHash(rs);
             const uint32_t tx0 = fr.x0 / 16u, ty0 = fr.y0 / 16u;
             const uint32_t wtx = (fr.x0 + fr.ww + 15u) / 16u - tx0, wty = (fr.y0 + fr.wh + 15u) / 16u - ty0;
-            Z(sp); K->pick_primary(sp, (int)(wtx * wty), r->dscene, fr, currentIndex, fresh, rs, fr.counters + LM_CNT_RESTIR(0), fastRs);   // + visibility rays, pass 1
+            Z(sp); K->pick_primary(sp, (int)(wtx * wty), r->dscene, fr, currentIndex, fresh, rs, fr.counters + LM_CNT_RESTIR(0), fastRs | ((r->pickWide + 1) << 6));   // + visibility rays, pass 1
             LmScene scp = r->dscene;                                 // the pick-ahead stream traces with its own stack-spill area
             if (sp != st) scp.spill += (size_t)3 * r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS);
             Z(sp); K->trace_shade(sp, gridMain, scp, fr, fresh, fr.counters + LM_CNT_RESTIR(0), visPackets ? -1 : r->refillVisibility, 0);

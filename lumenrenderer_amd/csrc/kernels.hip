@@ -729,16 +729,18 @@ KN(lm_k_fill_bags)(LmScene sc, LmFrame fr, uint32_t seed, uint32_t total)
 #define LM_PICK_STATIC_LDS 1       // 1: the table is a static 16-KB array whatever the light count; 0: sized by the launch (128 B for the benchmark scene's two lights).
 #endif                             // The smaller footprint lets more blocks of this VALU-saturating kernel onto a CU and the frame loses 0.7 % (2551 -> 2533, six runs each,
                                    // builds interleaved on one box): the 16 KB double as the residency cap the other streams' kernels need.
-template <class A, int ROLE, bool LDSL = false>
+// WIDE: a 1024-thread block takes FOUR tiles (one per 256 threads, each with its own bag) and shares one light table — see lm_k_pick_primary*_wide below.
+template <class A, int ROLE, bool LDSL = false, bool WIDE = false>
 __device__ __forceinline__ void lm_pick_primary_body(const LmScene& sc, const LmFrame& fr, int cur, int rc, uint32_t seed, uint32_t* visCount, uint2* s_bag, uint32_t* s_tmp,
-                                                     float4* s_lights = nullptr, uint32_t vb = blockIdx.x)
+                                                     float4* s_lights = nullptr, uint32_t vb = blockIdx.x, bool tileOk = true)
 {
+    const uint32_t tid = WIDE ? threadIdx.x & (LM_BLOCK - 1u) : threadIdx.x;      // thread within its tile
     if (ROLE == LM_RARE && fr.counters[LM_CNT_RARE] == 0u) return;      // grid-uniform: no surface of this frame needs the second launch
 #ifdef LM_PICK_PRIO
     __builtin_amdgcn_s_setprio(LM_PICK_PRIO);          // the pick sits on the frame's critical chain (eager history passes) and is pure VALU: it must not be the kernel that waits (r06_pick_prio_ab.txt)
 #endif
     if constexpr (LDSL) {
-        for (uint32_t k = threadIdx.x; k < sc.numLights; k += LM_BLOCK) {
+        for (uint32_t k = threadIdx.x; k < sc.numLights; k += (WIDE ? 4u * LM_BLOCK : LM_BLOCK)) {
             const LmTriLight l = lm_load_light(sc.lights, k);
             const lf3 arm1 = l.p1 - l.p0, arm2 = l.p2 - l.p0;
             s_lights[4u * k] = make_float4(l.p0.x, l.p0.y, l.p0.z, arm1.x);
@@ -759,14 +761,14 @@ __device__ __forceinline__ void lm_pick_primary_body(const LmScene& sc, const Lm
     uint32_t bagSeed = lm_wang_hash(seed + (tileY * tilesX + tileX));
     const float rb = lm_random_float(bagSeed);
     const int bagIndex = (int)roundf((float)(50 - 1) * rb);
-    for (uint32_t k = threadIdx.x; k < 1000u; k += LM_BLOCK) {
+    if (tileOk) for (uint32_t k = tid; k < 1000u; k += LM_BLOCK) {
         uint2 e = fr.bags[(uint32_t)bagIndex * 1000u + k];
         if constexpr (A::contracted) e.y = f2u(A::rcp(u2f(e.y)));      // the loop multiplies by 1 / pdf: 1 000 reciprocals per tile instead of 8 192
         s_bag[k] = e;
     }
     __syncthreads();
-    const uint32_t px = tileX * 16u + (threadIdx.x & 15u), py = tileY * 16u + (threadIdx.x >> 4);
-    const bool inside = !(px < fr.x0 || py < fr.y0 || px >= fr.x0 + fr.ww || py >= fr.y0 + fr.wh);
+    const uint32_t px = tileX * 16u + (tid & 15u), py = tileY * 16u + (tid >> 4);
+    const bool inside = tileOk && !(px < fr.x0 || py < fr.y0 || px >= fr.x0 + fr.ww || py >= fr.y0 + fr.wh);
     uint32_t li = 0;
     bool shoot = false;
     lf3 vpos = v3(0.f), vdir = v3(0.f);
@@ -900,6 +902,31 @@ KN(lm_k_pick_primary_fast_lds_big)(LmScene sc, LmFrame fr, int cur, int rc, uint
     __shared__ uint32_t s_tmp[5];
     __shared__ float4 s_lights[4 * LM_PICK_LDS_LIGHTS_BIG + 1];
     lm_pick_primary_body<LmFast, LM_COMMON, true>(sc, fr, cur, rc, seed, visCount, s_bag, s_tmp, s_lights);
+}
+// ... and for LM_PICK_LDS_LIGHTS_BIG + 1 .. LM_PICK_WIDE_LIGHTS records (round 6; BASELINE config C3 has 1 026): a table of that size leaves room for one or two 256-thread
+// blocks per CU, and the pick needs its four waves per SIMD (a 1 040-record table at two blocks per CU lost 4.6 %, LOG round 5).  So the BLOCK grows instead: 1 024 threads =
+// four tiles, each quarter with its own 8-KB bag, all sixteen waves reading ONE table of 64 B x numLights (dynamic LDS: 32 KB + 64 B per light; C3 = 98 KB, one block per CU =
+// four waves per SIMD).  Same candidates, same arithmetic: the image is the one of the global-gather kernel.
+#ifndef LM_PICK_WIDE_LIGHTS
+#define LM_PICK_WIDE_LIGHTS 1984u      // 32 000 + 68 + 64 x 1 984 + 16 = 159 060 B of the CU's 163 840
+#endif
+extern "C" __global__ void __launch_bounds__(4 * LM_BLOCK, 1)
+KN(lm_k_pick_primary_wide)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount, uint32_t tiles)
+{
+    __shared__ uint2 s_bag[4000];
+    __shared__ uint32_t s_tmp[17];
+    extern __shared__ float4 s_lights[];
+    const uint32_t vb = 4u * blockIdx.x + (threadIdx.x >> 8);
+    lm_pick_primary_body<LmExact, LM_ALL, true, true>(sc, fr, cur, rc, seed, visCount, s_bag + 1000u * (threadIdx.x >> 8), s_tmp, s_lights, min(vb, tiles - 1u), vb < tiles);
+}
+extern "C" __global__ void __launch_bounds__(4 * LM_BLOCK, 1)
+KN(lm_k_pick_primary_fast_wide)(LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount, uint32_t tiles)
+{
+    __shared__ uint2 s_bag[4000];
+    __shared__ uint32_t s_tmp[17];
+    extern __shared__ float4 s_lights[];
+    const uint32_t vb = 4u * blockIdx.x + (threadIdx.x >> 8);
+    lm_pick_primary_body<LmFast, LM_COMMON, true, true>(sc, fr, cur, rc, seed, visCount, s_bag + 1000u * (threadIdx.x >> 8), s_tmp, s_lights, min(vb, tiles - 1u), vb < tiles);
 }
 // LM_PICK_PERSIST = N > 0 (round 4): the same kernel as a PERSISTENT grid of N blocks per CU that loops over the tiles, with the light table sized by the launch.  The
 // residency cap of the static table (five blocks per CU, above) is then the grid's size and no longer 24 KB of LDS per block that nobody reads: 8 KB + 64 B per light stay,
@@ -1847,9 +1874,30 @@ static void l_trace_shadow(hipStream_t s, int g, LmScene sc, LmFrame fr, const u
 static void l_fill_bags(hipStream_t s, LmScene sc, LmFrame fr, uint32_t seed, uint32_t total) { hipLaunchKernelGGL(KN(lm_k_fill_bags), LM_GRID((total + LM_BLOCK - 1) / LM_BLOCK), sc, fr, seed, total); }
 static void l_pick_primary(hipStream_t s, int tiles, LmScene sc, LmFrame fr, int cur, int rc, uint32_t seed, uint32_t* visCount, int fast)
 {
+    const int wideSel = (fast >> 6) & 3;          // tuning key "pick_wide" + 1 (frame.cpp): 0 unset = 1, else 1 never, 2 fast mode only (default), 3 both modes
+    fast &= 3;
     const bool ldsLights = sc.numLights <= LM_PICK_LDS_LIGHTS && LM_PICK_LDS_LIGHTS > 0u;
     const bool ldsBig = !ldsLights && LM_PICK_STATIC_LDS && sc.numLights <= LM_PICK_LDS_LIGHTS_BIG && LM_PICK_LDS_LIGHTS_BIG > LM_PICK_LDS_LIGHTS;      // the 32-KB table
     const size_t lightBytes = LM_PICK_STATIC_LDS ? 0u : (size_t)64 * sc.numLights + 16u;         // dynamic LDS of the *_lds kernels
+    // The exact instantiation (106 registers, long and uneven tiles) LOSES with the big block: 1 366 -> 1 569 us alone on C3, frame -5 %; the fast one gains (762 -> 519 us,
+    // lazy frame +7.9 %): profiles/r06_pick_wide.txt.  So the wide block is the fast mode's; the exact kernel stays selectable for the parity test that runs it against the oracle.
+    const bool wideOn = wideSel == 3 || (wideSel != 1 && fast);
+    const bool wide = wideOn && !ldsLights && !ldsBig && sc.numLights <= LM_PICK_WIDE_LIGHTS && LM_PICK_WIDE_LIGHTS > 0u;      // four tiles per block around one table
+    if (wide) {
+        static bool allowed = false;      // more than 64 KB of dynamic LDS has to be asked for, once per kernel
+        if (!allowed) {
+            (void)hipFuncSetAttribute((const void*)KN(lm_k_pick_primary_wide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64u * LM_PICK_WIDE_LIGHTS + 16u));
+            (void)hipFuncSetAttribute((const void*)KN(lm_k_pick_primary_fast_wide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64u * LM_PICK_WIDE_LIGHTS + 16u));
+            allowed = true;
+        }
+        const dim3 grid((unsigned)(tiles + 3) / 4u), block(4 * LM_BLOCK);
+        const size_t bytes = (size_t)64 * sc.numLights + 16u;
+        if (fast) {
+            hipLaunchKernelGGL(KN(lm_k_pick_primary_fast_wide), grid, block, bytes, s, sc, fr, cur, rc, seed, visCount, (uint32_t)tiles);
+            if (fast > 1) hipLaunchKernelGGL(KN(lm_k_pick_primary_rare), LM_GRID(tiles), sc, fr, cur, rc, seed, visCount);
+        } else hipLaunchKernelGGL(KN(lm_k_pick_primary_wide), grid, block, bytes, s, sc, fr, cur, rc, seed, visCount, (uint32_t)tiles);
+        return;
+    }
     if (fast) {
         if (ldsLights && LM_PICK_PERSIST > 0) {
             int dev = 0, cus = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);

@@ -55,6 +55,7 @@ int lumen_mi_create(lumen_mi_renderer** out)
     if (const char* e = getenv("LUMEN_MI_PACKET_PRIMARY")) (*out)->packetPrimary = atoi(e);
     if (const char* e = getenv("LUMEN_MI_FAST_SHADE")) (*out)->fastShade = atoi(e);
     if (const char* e = getenv("LUMEN_MI_SPATIAL_LDS")) (*out)->spatialLds = atoi(e);
+    if (const char* e = getenv("LUMEN_MI_PICK_WIDE")) (*out)->pickWide = atoi(e);
     if (const char* e = getenv("LUMEN_MI_TAIL_REPACK")) (*out)->tailRepack = atoi(e);
     if (const char* e = getenv("LUMEN_MI_GPU_BUILD")) (*out)->gpuBuild = atoi(e);
     if (const char* e = getenv("LUMEN_MI_LAZY_REUSE")) (*out)->lazyReuse = std::max(-1, std::min(1, atoi(e)));      // (2 = the deliberately wrong test mode: tuning key only)
@@ -720,6 +721,7 @@ int lumen_mi_set_tuning(lumen_mi_renderer* r, const char* key, int value)
     else if (k == "packet_primary") r->packetPrimary = value;
     else if (k == "packet_visibility") r->packetVisibility = value;
     else if (k == "spatial_lds") r->spatialLds = value;
+    else if (k == "pick_wide") { if (value < 0 || value > 2) return fail(LUMEN_MI_ERR_INVALID, "pick_wide: 0, 1 or 2"); r->pickWide = value; }
     else if (k == "tail_repack") r->tailRepack = value;
     else if (k == "gpu_build") { if (r->gpuBuild != value) { r->gpuBuild = value; r->sceneDirty = true; r->builtOnce = false; } }      // takes effect with a full rebuild at the next frame
     else if (k == "lazy_reuse") r->lazyReuse = value;

@@ -1707,6 +1707,51 @@ def test_c3_at_full_size_is_bit_exact_against_the_oracle():
     assert list(c[:4 + D]) == list(s[:4 + D]), (c[:12], s[:12])
     assert len(r.GetLights()[0]) == 513
     r.close(); o.close()
+    # The candidate pick of a light list above 512 records (round 6): 1024-thread blocks, four tiles around one LDS light table ("pick_wide"; the default uses it in the
+    # fast mode only).  The exact instantiation of that kernel against the oracle's frames, and the fast one against the fast global-gather kernel: the same bits.
+    w = product_from(d, W, H, D, blend=True, tuning={"pick_wide": 2})
+    for _ in range(2):
+        assert w.TraceFrameAsync()
+    w.Synchronize()
+    assert np.array_equal(w.GetRadiance().view(np.uint32), want.view(np.uint32))
+    assert list(w.GetCounters()[:4 + D]) == list(s[:4 + D])
+    w.close()
+    fast = []
+    for wide in (0, 1):
+        f = product_from(d, W, H, D, blend=True, tuning={"fast_resample": 1, "pick_wide": wide})
+        for _ in range(2):
+            assert f.TraceFrameAsync()
+        f.Synchronize()
+        fast.append((f.GetRadiance().copy(), list(f.GetCounters()[:4 + D])))
+        f.close()
+    assert np.array_equal(fast[0][0].view(np.uint32), fast[1][0].view(np.uint32)) and fast[0][1] == fast[1][1]
+
+
+def test_wide_candidate_pick_with_a_ragged_tile_count():
+    """The four-tiles-per-block candidate pick (light lists of 513 .. 1 984 records) on a window whose tile count is not a multiple of four (13 x 7 = 91 tiles of 16 x 16; the
+    last block has one live quarter) and whose right / bottom tiles are cut: the exact instantiation against the oracle, the fast one against the fast global-gather kernel."""
+    from lumenrenderer_amd.scenes import sponza_standin
+    W, H, D = 203, 101, 3
+    d = sponza_standin(extra_lights=512)
+    o = oracle_from(d, W, H, D, blend=True)
+    r = product_from(d, W, H, D, blend=True, tuning={"pick_wide": 2})
+    for _ in range(3):
+        assert r.TraceFrameAsync()
+        assert o.trace_frame() == 0
+    r.Synchronize()
+    assert np.array_equal(r.GetRadiance().view(np.uint32), o.radiance().view(np.uint32))
+    assert list(r.GetCounters()[:4 + D]) == list(o.stats(24)[:4 + D])
+    r.close(); o.close()
+    fast = []
+    for wide in (0, 1):
+        f = product_from(d, W, H, D, blend=True, tuning={"fast_resample": 1, "pick_wide": wide})
+        for _ in range(3):
+            assert f.TraceFrameAsync()
+        f.Synchronize()
+        fast.append(f.GetRadiance().copy())
+        f.close()
+    assert np.array_equal(fast[0].view(np.uint32), fast[1].view(np.uint32))
+    assert np.isfinite(fast[0]).all() and float(fast[0][..., :3].mean()) > 0.01
 
 
 def test_c4_at_full_size_is_bit_exact_against_the_oracle():
