@@ -1882,6 +1882,7 @@ static void l_pick_primary(hipStream_t s, int tiles, LmScene sc, LmFrame fr, int
     // The exact instantiation (106 registers, long and uneven tiles) LOSES with the big block: 1 366 -> 1 569 us alone on C3, frame -5 %; the fast one gains (762 -> 519 us,
     // lazy frame +7.9 %): profiles/r06_pick_wide.txt.  So the wide block is the fast mode's; the exact kernel stays selectable for the parity test that runs it against the oracle.
     const bool wideOn = wideSel == 3 || (wideSel != 1 && fast);
+    // (shorter lists keep the 256-thread blocks: the wide block at LowpolyRoom's 414 lights -0.6 %, at C2's two lights -8.6 % — more resident waves of a kernel that saturates the vector ALUs)
     const bool wide = wideOn && !ldsLights && !ldsBig && sc.numLights <= LM_PICK_WIDE_LIGHTS && LM_PICK_WIDE_LIGHTS > 0u;      // four tiles per block around one table
     if (wide) {
         static bool allowed = false;      // more than 64 KB of dynamic LDS has to be asked for, once per kernel
