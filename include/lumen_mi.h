@@ -191,7 +191,9 @@ int lumen_mi_set_instrumented(lumen_mi_renderer*, int enable);   /* use the node
  * 1e-8 measured), "fast_shade" (on top of it: the NEE contribution at depth >= 1 with hardware rcp / sqrt: changes the last bits of INDIRECT radiance and, within
  * rounding of two thresholds, whether a shadow ray is emitted; never which path continues), "pick_wide" (light lists of 513 .. 1 984 triangles: the candidate pick runs as
  * 1024-thread blocks, four tiles around ONE light table in LDS, instead of gathering the lights from memory: 0 never, 1 in the fast mode (default; the exact instantiation is
- * slower that way), 2 in both modes; identical image). */
+ * slower that way), 2 in both modes; identical image), "trace_blocks_main" / "trace_blocks_vis" / "trace_blocks_aux" (blocks per CU, 1 .. 8, of the persistent
+ * traversal launches: primary rays / the two ReSTIR visibility passes / waves >= 1 and shadow rays; main and vis: 0, default = chosen per frame — half the grid where the launch
+ * runs beside the history passes and can afford it, csrc/frame.cpp; identical image). */
 int lumen_mi_set_tuning(lumen_mi_renderer*, const char* key, int value);
 
 /* ---- tile sharding (new functionality: the reference is single-GPU) */

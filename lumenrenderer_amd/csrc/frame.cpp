@@ -252,7 +252,21 @@ int traceFrameAsync(R* r)
     uint32_t seed = wangHash(r->frameCount);                                                  // :685
     LmScene scx = r->dscene;                                                                  // same scene, its own stack-spill area
     if (overlap) scx.spill += (size_t)((twoWave && par) ? 2 : 1) * r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS);
-    const int gridMain = r->numCU * r->traceBlocksMain, gridAux = r->numCU * (overlap ? r->traceBlocksAux : r->traceBlocksMain);
+    // Persistent traversal grids, in blocks per CU.  Eight fill every wave slot of the chip with ONE kernel, and a persistent kernel frees its slots only when it ends — the blocks
+    // of the history passes and of the candidate pick beside it wait for that.  Under overlap two launches therefore take HALF the grid when that is their own loss to bear
+    // (profiles/r06_trace_blocks_ab.txt, interleaved on one box, every workload; results never depend on a grid):
+    //   * the two visibility passes, when the light list is short (<= 64 records: their rays all aim at the same few lights, short coherent any-hit walks; +0.5 ... 3 % in every
+    //     mode on C2 / C2t / C4 / C5 / Sandbox; with hundreds of lights the passes are long and the lazy frame waits for them: C3 -3.4 %, LowpolyRoom -2.4 %);
+    //   * the primary-ray launch, when the history passes run in this frame (eager / exact: the ReSTIR stream is the critical chain and runs beside it; lazy frames hang on the
+    //     wave stream instead: C4 -2 %), the window is large (>= 2 Mpixel) and the tree small enough to stay in cache (<= 2 M triangles; C5's 10 M need every slot to hide HBM
+    //     latency: -3.7 %): C2 +0.5 % fast / +1.1 % exact on top, C4 +3.3 % / +3.0 %.
+    // traceBlocksMain / traceBlocksVis > 0 (LUMEN_MI_TRACE_BLOCKS_MAIN / _VIS) force a size.  One stream: the full grid for every launch.
+    const bool lazyFrame = r->lazyReuse > 0 || (r->lazyReuse < 0 && (depthMax & 1u) == 0u);      // as decided at depth 0 below
+    const int autoMain = (!lazyFrame && fr.n >= (1u << 21) && r->triEntry.size() <= 2000000u) ? 4 : 8;
+    const int autoVis = r->dscene.numLights <= 64u ? 4 : 8;
+    const int gridAux = r->numCU * r->traceBlocksAux;
+    const int gridMain = overlap ? r->numCU * (r->traceBlocksMain > 0 ? r->traceBlocksMain : autoMain) : gridAux;
+    const int gridVis = overlap ? r->numCU * (r->traceBlocksVis > 0 ? r->traceBlocksVis : autoVis) : gridAux;
     const int tiles = (int)(((fr.ww + 15u) / 16u) * ((fr.wh + 15u) / 16u));
     // Deep waves hold too few rays to fill the machine; from the first wave expected to be shorter than `tailBelow` rays the
     // remaining depths run as one launch.  The expectation comes from the counters of the most recent frame whose
@@ -342,7 +356,7 @@ int traceFrameAsync(R* r)
             Z(sp); K->pick_primary(sp, (int)(wtx * wty), r->dscene, fr, currentIndex, fresh, rs, fr.counters + LM_CNT_RESTIR(0), fastRs | ((r->pickWide + 1) << 6));   // + visibility rays, pass 1
             LmScene scp = r->dscene;                                 // the pick-ahead stream traces with its own stack-spill area
             if (sp != st) scp.spill += (size_t)3 * r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS);
-            Z(sp); K->trace_shade(sp, gridMain, scp, fr, fresh, fr.counters + LM_CNT_RESTIR(0), visPackets ? -1 : r->refillVisibility, 0);
+            Z(sp); K->trace_shade(sp, gridVis, scp, fr, fresh, fr.counters + LM_CNT_RESTIR(0), visPackets ? -1 : r->refillVisibility, 0);
             evEnd2(r, ev, sp);
             if (pickAhead) { LM_HIP(hipEventRecord(r->evPick, sp)); LM_HIP(hipStreamWaitEvent(st, r->evPick, 0)); }
             evBegin(r, 3, ev);
@@ -361,7 +375,7 @@ int traceFrameAsync(R* r)
                 scv.spill += (size_t)3 * r->traceGrid() * 256 * (LM_STACK_DEPTH - LM_STACK_LDS);
                 LM_HIP(hipEventRecord(r->evVis, st)); LM_HIP(hipStreamWaitEvent(sv, r->evVis, 0));
             }
-            Z(sv); K->trace_shade(sv, gridMain, scv, fr, cur, fr.counters + LM_CNT_RESTIR(1), visPackets ? -1 : r->refillVisibility, lazy ? 2 : 1);   // 2: parks the weights it zeroes for the deferred first spatial pass
+            Z(sv); K->trace_shade(sv, gridVis, scv, fr, cur, fr.counters + LM_CNT_RESTIR(1), visPackets ? -1 : r->refillVisibility, lazy ? 2 : 1);   // 2: parks the weights it zeroes for the deferred first spatial pass
             if (sv != st) LM_HIP(hipEventRecord(r->evVisDone, sv));
             if (!lazy) { Z(st); K->spatial(st, tiles, fr, currentIndex, 2, 3, rs, 0, 1, fastRs); }      // the same seed as the first pass (ReSTIR.cpp: one seed for both): same candidates, same verdicts
             if (sv != st) LM_HIP(hipStreamWaitEvent(st, r->evVisDone, 0));

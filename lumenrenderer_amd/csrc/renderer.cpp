@@ -89,8 +89,9 @@ int lumen_mi_init(lumen_mi_renderer* r, const lumen_mi_settings* s)
     r->pending.output_width = r->settings.output_width = s->output_width ? s->output_width : s->render_width;
     r->pending.output_height = r->settings.output_height = s->output_height ? s->output_height : s->render_height;
     if (const char* e = getenv("LUMEN_MI_SINGLE_STREAM")) r->overlap = atoi(e) == 0;
-    if (const char* e = getenv("LUMEN_MI_TRACE_BLOCKS_MAIN")) r->traceBlocksMain = std::max(1, std::min(8, atoi(e)));
+    if (const char* e = getenv("LUMEN_MI_TRACE_BLOCKS_MAIN")) r->traceBlocksMain = std::max(0, std::min(8, atoi(e)));
     if (const char* e = getenv("LUMEN_MI_TRACE_BLOCKS_AUX")) r->traceBlocksAux = std::max(1, std::min(8, atoi(e)));
+    if (const char* e = getenv("LUMEN_MI_TRACE_BLOCKS_VIS")) r->traceBlocksVis = std::max(0, std::min(8, atoi(e)));
     if (const char* e = getenv("LUMEN_MI_AUX_PRIORITY")) r->auxPriority = atoi(e);
     if (const char* e = getenv("LUMEN_MI_AUX3_PRIORITY")) r->aux3Priority = atoi(e);
     if (!r->aux) {
@@ -722,6 +723,10 @@ int lumen_mi_set_tuning(lumen_mi_renderer* r, const char* key, int value)
     else if (k == "packet_visibility") r->packetVisibility = value;
     else if (k == "spatial_lds") r->spatialLds = value;
     else if (k == "pick_wide") { if (value < 0 || value > 2) return fail(LUMEN_MI_ERR_INVALID, "pick_wide: 0, 1 or 2"); r->pickWide = value; }
+    else if (k == "trace_blocks_main" || k == "trace_blocks_vis" || k == "trace_blocks_aux") {
+        if (value < 0 || value > 8 || (value == 0 && k == "trace_blocks_aux")) return fail(LUMEN_MI_ERR_INVALID, "trace_blocks_*: 1 .. 8 blocks per CU (main / vis: 0 = chosen per frame)");
+        (k == "trace_blocks_main" ? r->traceBlocksMain : k == "trace_blocks_vis" ? r->traceBlocksVis : r->traceBlocksAux) = value;
+    }
     else if (k == "tail_repack") r->tailRepack = value;
     else if (k == "gpu_build") { if (r->gpuBuild != value) { r->gpuBuild = value; r->sceneDirty = true; r->builtOnce = false; } }      // takes effect with a full rebuild at the next frame
     else if (k == "lazy_reuse") r->lazyReuse = value;

@@ -150,7 +150,7 @@ struct lumen_mi_renderer {
     int auxPriority = 1;                    // 1: highest priority for the aux streams, 0: default
     int aux3Priority = 0;                   // the visibility / pick-ahead stream runs at default priority (pick-ahead must not starve the main chain)
     bool overlap = true;
-    int traceBlocksMain = 8, traceBlocksAux = 8;
+    int traceBlocksMain = 0, traceBlocksAux = 8, traceBlocksVis = 0;       // blocks per CU of the persistent traversal launches: primary rays, waves >= 1 + shadow rays, visibility passes; 0 = chosen per frame (frame.cpp)
     int numCU = 256;
     const LmKernelTable* K = nullptr;
     LmKernelTable Kmix;                     // the renderer's own table: every entry from the default compilation or, per kernel class, from the -fno-slp-vectorize one (renderer.cpp applyNoSlpKernels)

@@ -1217,7 +1217,9 @@ TUNINGS = [{"tail_below": 0}, {"tail_below": 1 << 30}, {"tail_below": 6000}, {"t
            {"lazy_reuse": 1}, {"lazy_reuse": 0}, {"lazy_reuse": 1, "wave_streams": 2}, {"lazy_reuse": 1, "single_stream": 1}, {"lazy_reuse": 1, "pick_ahead": 0, "tail_below": 0},
            {"lazy_reuse": 1, "pick_ahead": 1, "wave_streams": 2, "tail_below": 6000},
            {"tail_repack": 1, "tail_below": 1 << 30}, {"tail_repack": 1, "tail_below": 6000}, {"tail_repack": 1, "tail_below": 1 << 30, "single_stream": 1, "fast_shade": 0},
-           {"gpu_build": 1}, {"gpu_build": 1, "packet_primary": 1, "tail_below": 0}]
+           {"gpu_build": 1}, {"gpu_build": 1, "packet_primary": 1, "tail_below": 0},
+           {"trace_blocks_main": 8, "trace_blocks_vis": 8}, {"trace_blocks_main": 4, "trace_blocks_vis": 4, "lazy_reuse": 1}, {"trace_blocks_main": 1, "trace_blocks_vis": 3, "trace_blocks_aux": 2},
+           {"trace_blocks_main": 2, "trace_blocks_aux": 5, "wave_streams": 2, "tail_below": 0}]
 DEEP = [{"tail_repack": 1, "tail_below": 1 << 30}, {"tail_repack": 1}, {"lazy_reuse": 0}, {"lazy_reuse": 1, "wave_streams": 2}, {"lazy_reuse": 1, "pick_ahead": 0, "single_stream": 1}, {}, {"packet_visibility": 1}, {"tail_pair": 1, "tail_below": 1 << 30}, {"tail_pair": 1}, {"pick_ahead": 0, "tail_below": 0}, {"pick_ahead": 1, "tail_below": 1 << 30}, {"single_stream": 1}, {"shadow_on_wave": 1}, {"sort_rays": 16, "tail_below": 0}, {"wave_streams": 2}]
 
 
