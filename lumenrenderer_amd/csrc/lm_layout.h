@@ -18,7 +18,9 @@
 #endif
 #define LM_STACK_DEPTH (LM_WIDTH == 8 ? 96 : 64)   // traversal stack entries per lane; the BVH builder bounds the tree so that this suffices
 #ifndef LM_STACK_LDS
+#ifndef LM_STACK_LDS
 #define LM_STACK_LDS 16          // of which in LDS; deeper entries spill to a per-thread global array
+#endif
 #endif
 #define LM_BVH2_MAX_DEPTH 40     // depth bound of the binary tree the wide tree is collapsed from.  A wide node with n children pushes n - 1 entries and
                                  // spans at least ceil(log2 n) binary levels: (n - 1) / ceil(log2 n) <= 1.5 for n <= 4 and <= 7 / 3 for n <= 8, so the
