@@ -643,6 +643,8 @@ def main():
                          "traffic_source": None if traffic_closest is None else PMC_FILE + " (replayed, not measured by this run)",
                          "traffic_over_algorithmic": None if not traffic_closest else round(traffic_closest / (alg / max(1.0, launches_per_tf)), 4),
                          "limiter": "dependent-load latency x lane divergence: the tree is served by L2 / Infinity Cache, HBM sees a few % of the algorithmic bytes",
+                         "grid_note": "since round 6 the primary-ray launch of an eager frame runs on HALF a persistent grid on purpose (csrc/frame.cpp; profiles/r06_trace_blocks_ab.txt): that launch "
+                                      "got slower (611 -> 750 us under overlap) and the frame faster, so frac is below the 0.545 of the full-grid record at a higher value",
                          "launch_ms": round(per_launch_ms, 4), "launches_per_traceframe": launches_per_tf,
                          "algorithmic_bytes_per_launch": int(alg / max(1.0, launches_per_tf)),
                          "achieved_d4_binary_node_pricing": round(gbs(alg_d4), 2)},
