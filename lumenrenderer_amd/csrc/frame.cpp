@@ -261,7 +261,7 @@ int traceFrameAsync(R* r)
     //     wave stream instead: C4 -2 %), the window is large (>= 2 Mpixel) and the tree small enough to stay in cache (<= 2 M triangles; C5's 10 M need every slot to hide HBM
     //     latency: -3.7 %): C2 +0.5 % fast / +1.1 % exact on top, C4 +3.3 % / +3.0 %.
     // traceBlocksMain / traceBlocksVis > 0 (LUMEN_MI_TRACE_BLOCKS_MAIN / _VIS) force a size.  One stream: the full grid for every launch.
-    const bool lazyFrame = r->lazyReuse > 0 || (r->lazyReuse < 0 && (depthMax & 1u) == 0u);      // as decided at depth 0 below
+    const bool lazyFrame = r->lazyReuse > 0 || (r->lazyReuse < 0 && (depthMax & 1u) == 0u);      // tuning key lazy_reuse; -1: at even path depths
     const int autoMain = (!lazyFrame && fr.n >= (1u << 21) && r->triEntry.size() <= 2000000u) ? 4 : 8;
     const int autoVis = r->dscene.numLights <= 64u ? 4 : 8;
     const int gridAux = r->numCU * r->traceBlocksAux;
@@ -362,7 +362,7 @@ int traceFrameAsync(R* r)
             evBegin(r, 3, ev);
             rs = wangHash(rs);
             // lazy reuse (tuning key lazy_reuse; -1: at even path depths): this frame's history passes are left to the next frame (above)
-            lazy = r->lazyReuse > 0 || (r->lazyReuse < 0 && (depthMax & 1u) == 0u);
+            lazy = lazyFrame;
             Z(st); K->temporal(st, tiles, fr, currentIndex, temporalIndex, cur, tmp, fresh, rs, fr.counters + LM_CNT_RESTIR(1), fastRs);         // + visibility rays, pass 2
             if (overlap) LM_HIP(hipEventRecord(r->evTemporal[par], st));
             rs = wangHash(rs);

@@ -903,10 +903,11 @@ KN(lm_k_pick_primary_fast_lds_big)(LmScene sc, LmFrame fr, int cur, int rc, uint
     __shared__ float4 s_lights[4 * LM_PICK_LDS_LIGHTS_BIG + 1];
     lm_pick_primary_body<LmFast, LM_COMMON, true>(sc, fr, cur, rc, seed, visCount, s_bag, s_tmp, s_lights);
 }
-// ... and for LM_PICK_LDS_LIGHTS_BIG + 1 .. LM_PICK_WIDE_LIGHTS records (round 6; BASELINE config C3 has 1 026): a table of that size leaves room for one or two 256-thread
-// blocks per CU, and the pick needs its four waves per SIMD (a 1 040-record table at two blocks per CU lost 4.6 %, LOG round 5).  So the BLOCK grows instead: 1 024 threads =
-// four tiles, each quarter with its own 8-KB bag, all sixteen waves reading ONE table of 64 B x numLights (dynamic LDS: 32 KB + 64 B per light; C3 = 98 KB, one block per CU =
-// four waves per SIMD).  Same candidates, same arithmetic: the image is the one of the global-gather kernel.
+// ... and for LM_PICK_LDS_LIGHTS_BIG + 1 .. LM_PICK_WIDE_LIGHTS records (round 6; BASELINE config C3: 513 records, one per quad of its 1 026 emissive triangles): a table
+// of that size leaves room for one or two 256-thread blocks per CU, and the pick needs its four waves per SIMD (a 1 040-record table at two blocks per CU lost 4.6 %, LOG
+// round 5).  So the BLOCK grows instead: 1 024 threads = four tiles, each quarter with its own 8-KB bag, all sixteen waves reading ONE table of 64 B x numLights (dynamic
+// LDS: 32 KB + 64 B per light; C3 = 65 KB, two blocks per CU; from 1 000 lights on one block per CU = four waves per SIMD).  Same candidates, same arithmetic: the image is
+// the one of the global-gather kernel.  A quarter whose tile index lies behind the last tile (tile count not a multiple of four) stages nothing and joins the barriers.
 #ifndef LM_PICK_WIDE_LIGHTS
 #define LM_PICK_WIDE_LIGHTS 1984u      // 32 000 + 68 + 64 x 1 984 + 16 = 159 060 B of the CU's 163 840
 #endif
