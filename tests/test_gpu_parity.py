@@ -545,6 +545,10 @@ def test_c_abi_reports_bad_arguments_and_call_order():
     fails(1, r.SetRenderResolution, 0, 4); fails(1, r.SetOutputResolution, 4, 0)
     fails(1, r.SetWindow, 8, 8, 8, 16)
     assert "unknown tuning key" in fails(1, r.SetTuning, "no_such_key", 1)
+    assert "pick_wide" in fails(1, r.SetTuning, "pick_wide", 3)
+    assert "trace_blocks" in fails(1, r.SetTuning, "trace_blocks_vis", 9)
+    assert "trace_blocks" in fails(1, r.SetTuning, "trace_blocks_aux", 0)                 # the waves' grid has no automatic size
+    r.SetTuning("trace_blocks_main", 0); r.SetTuning("trace_blocks_vis", 0)               # 0 = chosen per frame (the default)
     fails(1, r.GetLastFrameStat, "No such stat")
     white, normal, _ = r.CreateDefaultResources()
     texs = dict(diffuse_texture=white, normal_map=normal, metallic_roughness_texture=white, emissive_texture=white, transmission_texture=white,
@@ -1754,6 +1758,20 @@ def test_wide_candidate_pick_with_a_ragged_tile_count():
         f.close()
     assert np.array_equal(fast[0].view(np.uint32), fast[1].view(np.uint32))
     assert np.isfinite(fast[0]).all() and float(fast[0][..., :3].mean()) > 0.01
+    # the largest table the wide block takes (1 984 records = 127 KB of dynamic LDS beside the four bags: one block per CU) and the first list that gathers again
+    for extra in (1983, 1984):
+        big = sponza_standin(extra_lights=extra)
+        imgs = []
+        for wide in (0, 1):
+            f = product_from(big, W, H, D, blend=True, tuning={"fast_resample": 1, "pick_wide": wide})
+            assert len(f.GetLights()[0]) == extra + 1
+            for _ in range(2):
+                assert f.TraceFrameAsync()
+            f.Synchronize()
+            imgs.append(f.GetRadiance().copy())
+            f.close()
+        assert np.array_equal(imgs[0].view(np.uint32), imgs[1].view(np.uint32)), extra
+        assert np.isfinite(imgs[0]).all() and float(imgs[0][..., :3].mean()) > 0.01
 
 
 def test_c4_at_full_size_is_bit_exact_against_the_oracle():
