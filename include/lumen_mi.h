@@ -193,7 +193,9 @@ int lumen_mi_set_instrumented(lumen_mi_renderer*, int enable);   /* use the node
  * 1024-thread blocks, four tiles around ONE light table in LDS, instead of gathering the lights from memory: 0 never, 1 in the fast mode (default; the exact instantiation is
  * slower that way), 2 in both modes; identical image), "trace_blocks_main" / "trace_blocks_vis" / "trace_blocks_aux" (blocks per CU, 1 .. 8, of the persistent
  * traversal launches: primary rays / the two ReSTIR visibility passes / waves >= 1 and shadow rays; main and vis: 0, default = chosen per frame — half the grid where the launch
- * runs beside the history passes and can afford it, csrc/frame.cpp; identical image). */
+ * runs beside the history passes and can afford it, csrc/frame.cpp; identical image), "fuse_combine" (1, default: on eager frames the second spatial reuse pass ends with the
+ * pixel's CombineReservoirBuffers instead of a launch of its own — in the exact mode, and in the fast mode of scenes without a dielectric / clear-coat / anisotropic material; 0: two
+ * launches; identical image). */
 int lumen_mi_set_tuning(lumen_mi_renderer*, const char* key, int value);
 
 /* ---- tile sharding (new functionality: the reference is single-GPU) */

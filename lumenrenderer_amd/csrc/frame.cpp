@@ -377,9 +377,13 @@ int traceFrameAsync(R* r)
             }
             Z(sv); K->trace_shade(sv, gridVis, scv, fr, cur, fr.counters + LM_CNT_RESTIR(1), visPackets ? -1 : r->refillVisibility, lazy ? 2 : 1);   // 2: parks the weights it zeroes for the deferred first spatial pass
             if (sv != st) LM_HIP(hipEventRecord(r->evVisDone, sv));
-            if (!lazy) { Z(st); K->spatial(st, tiles, fr, currentIndex, 2, 3, rs, 0, 1, fastRs); }      // the same seed as the first pass (ReSTIR.cpp: one seed for both): same candidates, same verdicts
+            // the second spatial pass ends with the combine (one full-screen launch and one read of its own output less) when the visibility pass ran in line before it and no
+            // surface needs the second launch's role (exact mode, or a scene without such a material): tuning key fuse_combine
+            const bool fuse = !lazy && sv == st && fastRs <= 1 && r->fuseCombine != 0;
+            if (fuse) { LmFrame ff = fr; ff.fuseRc = cur; ff.fuseSeed = wangHash(rs); Z(st); K->spatial(st, tiles, ff, currentIndex, 2, 3, rs, 0, 1, fastRs | 64); }
+            else if (!lazy) { Z(st); K->spatial(st, tiles, fr, currentIndex, 2, 3, rs, 0, 1, fastRs); }      // the same seed as the first pass (ReSTIR.cpp: one seed for both): same candidates, same verdicts
             if (sv != st) LM_HIP(hipStreamWaitEvent(st, r->evVisDone, 0));
-            if (!lazy) { Z(st); K->combine(st, tiles, fr, currentIndex, cur, 3, wangHash(rs), fastRs); }
+            if (!lazy && !fuse) { Z(st); K->combine(st, tiles, fr, currentIndex, cur, 3, wangHash(rs), fastRs); }
             else { r->owed.valid = true; r->owed.fr = fr; r->owed.gbuf = currentIndex; r->owed.seed = rs; r->owed.fast = fastRs; r->owed.tiles = tiles; }
             evEnd(r, ev);
         } else if ((int)depth >= tailDepth) {

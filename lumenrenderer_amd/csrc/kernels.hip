@@ -1130,7 +1130,26 @@ KN(lm_k_restir_temporal_rare)(LmFrame fr, int cur, int prev, int rc, int rp, int
 // the neighbour draw — 92 x 92 x 16 B = 132 KB of the CU's 160 KB LDS — with coalesced loads, and the five similarity tests of a pixel read LDS
 // instead of gathering five 16-byte probes through the L1.  The probes are the same bits, so the verdicts and the image are unchanged.
 #define LM_SPATIAL_WIN ((1u << LOG_TS) + 60u)
-template <class A, int ROLE, uint32_t LOG_TS = 4, bool LDS_PROBES = false>
+// FUSE (second pass, eager frames without a second-launch role): the pass ENDS with the pixel's CombineReservoirBuffers (K26, lm_restir_combine_body below) — the reservoir it
+// has just written stays in registers as the combine's second operand instead of being read back by another full-screen launch.  The spatial output is still stored (a later
+// frame's Reset() keeps "the sample that was there"), the arithmetic and its order are the combine kernel's: same bits.
+template <class A, int ROLE>
+__device__ __forceinline__ void lm_fused_combine(const LmFrame& fr, int cur, uint32_t li, uint32_t gi, const LmReservoir& b)
+{
+    LmTarget target;
+    {
+        LmSurface s;
+        lm_gbuf_load(fr.gbuf[cur], li, s);
+        if (!lm_role_takes<ROLE>(s.mat)) return;
+        lm_target_setup<A>(s, target);
+    }
+    const int rc = lm_res_idx(fr, fr.fuseRc);
+    LmReservoir a, out;
+    lm_res_load(fr.res[rc], fr.resC[rc], li, a);
+    lm_combine2<A>(out, a, b, target, lm_wang_hash(fr.fuseSeed + gi));
+    lm_res_store(fr.res[rc], fr.resC[rc], li, out);
+}
+template <class A, int ROLE, uint32_t LOG_TS = 4, bool LDS_PROBES = false, bool FUSE = false>
 __device__ __forceinline__ void lm_restir_spatial_body(const LmFrame& fr, int cur, int rin, int rout, uint32_t seed, int margin, int pass, float4* s_probe = nullptr, uint32_t vb = blockIdx.x)
 {
     if (fr.deferred && !lm_reuse_owed(fr)) return;
@@ -1206,6 +1225,8 @@ __device__ __forceinline__ void lm_restir_spatial_body(const LmFrame& fr, int cu
     }
     auto candAt = [&](uint32_t k) { return k == 0u ? cand[0] : k == 1u ? cand[1] : k == 2u ? cand[2] : k == 3u ? cand[3] : cand[4]; };
     float4* hotOut = fr.res[rout];
+    LmReservoir fb; lm_res_fresh(fb);                               // FUSE: what this pass leaves at the pixel, the combine's second operand
+    bool fused = false;
     if (__popc(mask) > 1) {
         const uint32_t nb0 = candAt((uint32_t)__ffs((int)mask) - 1u);
         mask &= mask - 1u;
@@ -1242,11 +1263,18 @@ __device__ __forceinline__ void lm_restir_spatial_body(const LmFrame& fr, int cu
         out.count = sum;
         lm_res_update_weight<A>(out);
         lm_res_store(hotOut, fr.resC[rout], li, out);
+        if constexpr (FUSE) { fb = out; fb.count = (long long)(uint32_t)out.count; fused = true; }      // (the count as the record holds it: 32 bits)
     } else if (ROLE != LM_RARE) {
         const float4 q0 = hotOut[4u * li], q1 = hotOut[4u * li + 1u];      // Reset(): weightSum, sampleCount, weight; the sample stays
         hotOut[4u * li] = make_float4(0.f, q0.y, 0.f, 0.f);
         hotOut[4u * li + 1u] = make_float4(0.f, u2f(0u), q1.z, q1.w);
+        if constexpr (FUSE) {                                              // the combine's second operand = the record as it now stands: reset numbers, the old sample
+            lm_res_unpack(make_float4(0.f, q0.y, 0.f, 0.f), make_float4(0.f, u2f(0u), q1.z, q1.w), hotOut[4u * li + 2u], hotOut[4u * li + 3u], fb);
+            fb.s.contribution = v3(fr.resC[rout][li]);
+            fused = true;
+        }
     }
+    if constexpr (FUSE) { if (fused) lm_fused_combine<A, ROLE>(fr, cur, li, gi, fb); }
 }
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_SPATIAL_WAVES)
 KN(lm_k_restir_spatial)(LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin, int pass) { lm_restir_spatial_body<LmExact, LM_ALL>(fr, cur, rin, rout, seed, margin, pass); }
@@ -1271,6 +1299,11 @@ KN(lm_k_restir_spatial_fast_lds16)(LmFrame fr, int cur, int rin, int rout, uint3
 }
 extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_SPATIAL_WAVES)
 KN(lm_k_restir_spatial_rare)(LmFrame fr, int cur, int rin, int rout, uint32_t seed, int margin, int pass) { lm_restir_spatial_body<LmExact, LM_RARE>(fr, cur, rin, rout, seed, margin, pass); }
+// second pass + combine in one launch (tuning key fuse_combine; frame.cpp): the exact mode, and the fast mode of scenes without a second-launch material
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_SPATIAL_WAVES)
+KN(lm_k_restir_spatial_fused)(LmFrame fr, int cur, int rin, int rout, uint32_t seed) { lm_restir_spatial_body<LmExact, LM_ALL, 4, false, true>(fr, cur, rin, rout, seed, 0, 1); }
+extern "C" __global__ void __launch_bounds__(LM_BLOCK, LM_SPATIAL_FAST_WAVES)
+KN(lm_k_restir_spatial_fast_fused)(LmFrame fr, int cur, int rin, int rout, uint32_t seed) { lm_restir_spatial_body<LmFast, LM_COMMON, 4, false, true>(fr, cur, rin, rout, seed, 0, 1); }
 
 // K26 CombineReservoirBuffers — ReSTIRKernels.cu:1407-1436
 template <class A, int ROLE>
@@ -1934,6 +1967,11 @@ static void l_spatial(hipStream_t s, int g, LmFrame fr, int cur, int rin, int ro
         const int g32 = (int)(((fr.ww + 31u) / 32u) * ((fr.wh + 31u) / 32u));
         hipLaunchKernelGGL(KN(lm_k_restir_spatial_fast_lds), dim3((unsigned)g32), dim3(1024), 0, s, fr, cur, rin, rout, seed, margin);
         if ((fast & 15) > 1) hipLaunchKernelGGL(KN(lm_k_restir_spatial_rare), LM_GRID(g), fr, cur, rin, rout, seed, margin, pass);
+        return;
+    }
+    if ((fast & 64) && pass == 1 && !fr.deferred && (fast & 15) <= 1) {      // second pass + combine (fr.fuseRc, fr.fuseSeed)
+        if (fast & 15) hipLaunchKernelGGL(KN(lm_k_restir_spatial_fast_fused), LM_GRID_CAP(g, "SPATIAL", 0u), fr, cur, rin, rout, seed);
+        else hipLaunchKernelGGL(KN(lm_k_restir_spatial_fused), LM_GRID(g), fr, cur, rin, rout, seed);
         return;
     }
     fast &= 15;

@@ -134,6 +134,7 @@ struct LmFrame {
                                 // blocks whose neighbourhood holds none at once instead of loading every pixel's surface to find that out.  NULL = not tracked (every block looks)
     uint32_t* reuseMask;        // per pixel: which of its five spatial-reuse candidates passed the similarity test (bits 0..4), or LM_REUSE_FLAGGED; written
                                 // by the first spatial pass, read by the second (both draw the same candidates: the reference passes one seed to both)
+    int fuseRc; uint32_t fuseSeed;      // read by the fused second spatial pass only (lm_k_restir_spatial*_fused): the reservoir buffer and the seed of the combine it ends with
     // reservoirs, 5 buffers (the reference's two swap-chain and two spatial buffers + [4], fresh candidates when candidate
     // generation runs ahead on its own stream): one 64-byte hot record (4 float4) per pixel + a contribution plane
     float4* res[5];

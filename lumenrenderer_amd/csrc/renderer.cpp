@@ -56,6 +56,7 @@ int lumen_mi_create(lumen_mi_renderer** out)
     if (const char* e = getenv("LUMEN_MI_FAST_SHADE")) (*out)->fastShade = atoi(e);
     if (const char* e = getenv("LUMEN_MI_SPATIAL_LDS")) (*out)->spatialLds = atoi(e);
     if (const char* e = getenv("LUMEN_MI_PICK_WIDE")) (*out)->pickWide = atoi(e);
+    if (const char* e = getenv("LUMEN_MI_FUSE_COMBINE")) (*out)->fuseCombine = atoi(e);
     if (const char* e = getenv("LUMEN_MI_TAIL_REPACK")) (*out)->tailRepack = atoi(e);
     if (const char* e = getenv("LUMEN_MI_GPU_BUILD")) (*out)->gpuBuild = atoi(e);
     if (const char* e = getenv("LUMEN_MI_LAZY_REUSE")) (*out)->lazyReuse = std::max(-1, std::min(1, atoi(e)));      // (2 = the deliberately wrong test mode: tuning key only)
@@ -722,6 +723,7 @@ int lumen_mi_set_tuning(lumen_mi_renderer* r, const char* key, int value)
     else if (k == "packet_primary") r->packetPrimary = value;
     else if (k == "packet_visibility") r->packetVisibility = value;
     else if (k == "spatial_lds") r->spatialLds = value;
+    else if (k == "fuse_combine") r->fuseCombine = value;
     else if (k == "pick_wide") { if (value < 0 || value > 2) return fail(LUMEN_MI_ERR_INVALID, "pick_wide: 0, 1 or 2"); r->pickWide = value; }
     else if (k == "trace_blocks_main" || k == "trace_blocks_vis" || k == "trace_blocks_aux") {
         if (value < 0 || value > 8 || (value == 0 && k == "trace_blocks_aux")) return fail(LUMEN_MI_ERR_INVALID, "trace_blocks_*: 1 .. 8 blocks per CU (main / vis: 0 = chosen per frame)");

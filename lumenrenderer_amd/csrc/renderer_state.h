@@ -203,6 +203,7 @@ struct lumen_mi_renderer {
     int gpuBuild = 0;                       // 1: a scene's full tree build runs on the device (bvh_gpu.hip, LBVH); 0: host binned-SAH build (better tree, default)
     uint64_t gpuBuilds = 0;                 // device builds since creation (counter [56])
     int tailRepack = 0;                     // path tail: 1 = the repacking variant (256 paths per block, survivors packed through LDS after every depth); 0 = one path per lane to the end
+    int fuseCombine = 1;                    // eager frames: the second spatial pass ends with the combine (lm_k_restir_spatial*_fused): 1 on (default), 0 off
     int pickWide = 1;                       // light lists of 513 .. 1 984 records: the candidate pick as 1024-thread blocks around one LDS table: 0 never, 1 fast mode only, 2 both modes
     int spatialLds = 0;                     // fast mode: the first spatial pass stages its probe window in LDS (lm_k_restir_spatial_fast_lds): 1 on, 0 off
     int packetVisibility = 0;               // the ReSTIR visibility rays likewise (lm_k_restir_trace_shade_packet): 1 on, 0 off (default), -1 the primary wave's rule.

@@ -1223,7 +1223,8 @@ TUNINGS = [{"tail_below": 0}, {"tail_below": 1 << 30}, {"tail_below": 6000}, {"t
            {"tail_repack": 1, "tail_below": 1 << 30}, {"tail_repack": 1, "tail_below": 6000}, {"tail_repack": 1, "tail_below": 1 << 30, "single_stream": 1, "fast_shade": 0},
            {"gpu_build": 1}, {"gpu_build": 1, "packet_primary": 1, "tail_below": 0},
            {"trace_blocks_main": 8, "trace_blocks_vis": 8}, {"trace_blocks_main": 4, "trace_blocks_vis": 4, "lazy_reuse": 1}, {"trace_blocks_main": 1, "trace_blocks_vis": 3, "trace_blocks_aux": 2},
-           {"trace_blocks_main": 2, "trace_blocks_aux": 5, "wave_streams": 2, "tail_below": 0}]
+           {"trace_blocks_main": 2, "trace_blocks_aux": 5, "wave_streams": 2, "tail_below": 0},
+           {"fuse_combine": 0}, {"fuse_combine": 0, "lazy_reuse": 0, "pick_ahead": 0}, {"fuse_combine": 1, "lazy_reuse": 0, "pick_ahead": 0}, {"fuse_combine": 1, "lazy_reuse": 0, "single_stream": 1}]
 DEEP = [{"tail_repack": 1, "tail_below": 1 << 30}, {"tail_repack": 1}, {"lazy_reuse": 0}, {"lazy_reuse": 1, "wave_streams": 2}, {"lazy_reuse": 1, "pick_ahead": 0, "single_stream": 1}, {}, {"packet_visibility": 1}, {"tail_pair": 1, "tail_below": 1 << 30}, {"tail_pair": 1}, {"pick_ahead": 0, "tail_below": 0}, {"pick_ahead": 1, "tail_below": 1 << 30}, {"single_stream": 1}, {"shadow_on_wave": 1}, {"sort_rays": 16, "tail_below": 0}, {"wave_streams": 2}]
 
 
@@ -1731,6 +1732,31 @@ def test_c3_at_full_size_is_bit_exact_against_the_oracle():
         fast.append((f.GetRadiance().copy(), list(f.GetCounters()[:4 + D])))
         f.close()
     assert np.array_equal(fast[0][0].view(np.uint32), fast[1][0].view(np.uint32)) and fast[0][1] == fast[1][1]
+
+
+def test_fused_second_spatial_pass_and_combine_is_the_same_image_in_both_modes():
+    """On eager frames the second spatial reuse pass ends with the pixel's combine ("fuse_combine", default) instead of a launch of its own: the exact mode against the
+    oracle (odd depth = the history is read every frame; a window that cuts tiles), and the fast mode — which has no bit-level oracle — fused against unfused, bit for bit."""
+    from lumenrenderer_amd.scenes import sponza_standin
+    W, H, D = 331, 203, 5
+    d = sponza_standin()
+    o = oracle_from(d, W, H, D, blend=True)
+    for _ in range(4):
+        assert o.trace_frame() == 0
+    want = o.radiance()
+    imgs = {}
+    for mode, fuse in ((0, 1), (0, 0), (1, 1), (1, 0)):
+        r = product_from(d, W, H, D, blend=True, tuning={"fast_resample": mode, "fuse_combine": fuse, "lazy_reuse": 0})
+        for _ in range(4):
+            assert r.TraceFrameAsync()
+        r.Synchronize()
+        imgs[(mode, fuse)] = (r.GetRadiance().copy(), list(r.GetCounters()[:4 + D]))
+        r.close()
+    for fuse in (1, 0):
+        assert np.array_equal(imgs[(0, fuse)][0].view(np.uint32), want.view(np.uint32)), fuse
+        assert imgs[(0, fuse)][1] == list(o.stats(24)[:4 + D])
+    assert np.array_equal(imgs[(1, 1)][0].view(np.uint32), imgs[(1, 0)][0].view(np.uint32)) and imgs[(1, 1)][1] == imgs[(1, 0)][1]
+    o.close()
 
 
 def test_wide_candidate_pick_with_a_ragged_tile_count():
