@@ -1919,11 +1919,12 @@ static void l_pick_primary(hipStream_t s, int tiles, LmScene sc, LmFrame fr, int
     // (shorter lists keep the 256-thread blocks: the wide block at LowpolyRoom's 414 lights -0.6 %, at C2's two lights -8.6 % — more resident waves of a kernel that saturates the vector ALUs)
     const bool wide = wideOn && !ldsLights && !ldsBig && sc.numLights <= LM_PICK_WIDE_LIGHTS && LM_PICK_WIDE_LIGHTS > 0u;      // four tiles per block around one table
     if (wide) {
-        static bool allowed = false;      // more than 64 KB of dynamic LDS has to be asked for, once per kernel
-        if (!allowed) {
+        static bool allowed[64] = {};     // more than 64 KB of dynamic LDS has to be asked for, once per kernel and device
+        int dev = 0; (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || !allowed[dev]) {
             (void)hipFuncSetAttribute((const void*)KN(lm_k_pick_primary_wide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64u * LM_PICK_WIDE_LIGHTS + 16u));
             (void)hipFuncSetAttribute((const void*)KN(lm_k_pick_primary_fast_wide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64u * LM_PICK_WIDE_LIGHTS + 16u));
-            allowed = true;
+            if (dev >= 0 && dev < 64) allowed[dev] = true;
         }
         const dim3 grid((unsigned)(tiles + 3) / 4u), block(4 * LM_BLOCK);
         const size_t bytes = (size_t)64 * sc.numLights + 16u;
