@@ -156,30 +156,33 @@ def self_launch(args, argv):
         return 0
     env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import re
-    import tempfile
+    import threading
     for attempt in range(3):
         # the rendezvous port was free a moment ago; on a host that other jobs share it can be taken before the launcher listens on it (EADDRINUSE): new port, again
-        with tempfile.TemporaryFile(mode="w+") as err:
-            p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=err, text=True, env=env)
-            line_json = None
-            for line in p.stdout:
-                s = line.strip()
-                m = re.match(r"^\[[A-Za-z_]+\d+\]:(.*)$", s)      # --tee prefixes every line with its rank ("[default0]:")
-                if m and m.group(1).startswith("{") and '"metric"' in m.group(1):
-                    s = m.group(1)
-                if s.startswith("{") and '"metric"' in s:
-                    line_json = s                                   # held back: printed last
-                else:
-                    sys.stdout.write(line); sys.stdout.flush()
-            rc = p.wait()
-            err.seek(0); etext = err.read()
-        if rc != 0 and line_json is None and attempt < 2 and ("EADDRINUSE" in etext or "address already in use" in etext.lower()):
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+        etext = []
+        def pump():                                             # the child's stderr passes through as it comes (a watchdog message must not wait for the end) and is kept
+            for eline in p.stderr:
+                etext.append(eline); sys.stderr.write(eline); sys.stderr.flush()
+        t = threading.Thread(target=pump, daemon=True); t.start()
+        line_json = None
+        for line in p.stdout:
+            s = line.strip()
+            m = re.match(r"^\[[A-Za-z_]+\d+\]:(.*)$", s)      # --tee prefixes every line with its rank ("[default0]:")
+            if m and m.group(1).startswith("{") and '"metric"' in m.group(1):
+                s = m.group(1)
+            if s.startswith("{") and '"metric"' in s:
+                line_json = s                                   # held back: printed last
+            else:
+                sys.stdout.write(line); sys.stdout.flush()
+        rc = p.wait(); t.join(timeout=10)
+        err = "".join(etext)
+        if rc != 0 and line_json is None and attempt < 2 and ("EADDRINUSE" in err or "address already in use" in err.lower()):
             with socket.socket() as s2:
                 s2.bind(("127.0.0.1", 0)); port = s2.getsockname()[1]
             cmd[cmd.index("--master-port") + 1] = str(port)
             sys.stderr.write(f"bench.py: rendezvous port taken by another process, retrying on {port}\n")
             continue
-        sys.stderr.write(etext)
         break
     if line_json is not None:
         print(line_json, flush=True)
