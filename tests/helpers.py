@@ -101,3 +101,18 @@ def build_sandbox_driver(tmp_path):
     build = subprocess.run(cmd, capture_output=True, text=True)
     assert build.returncode == 0, build.stderr[-3000:]
     return exe
+
+
+def run_distributed(cmd, env, timeout=600, attempts=3):
+    """subprocess.run of a `python -m torch.distributed.run ... --master-port P ...` command line; when the launcher cannot listen on P because another job on a shared host
+    holds it (EADDRINUSE), the command runs again on a port the kernel has just handed out."""
+    import socket, subprocess
+    cmd = list(cmd)
+    for _ in range(attempts):
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+        if res.returncode == 0 or not ("EADDRINUSE" in res.stderr or "address already in use" in res.stderr.lower()) or "--master-port" not in cmd:
+            break
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+        cmd[cmd.index("--master-port") + 1] = str(port)
+    return res

@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, cornell, oracle_from, rel_l2
+from helpers import GOLDEN, cornell, oracle_from, rel_l2, run_distributed
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -264,7 +264,7 @@ def test_group_host_transport_callbacks_gloo(world, tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
            "--master-port", str(29525 + world), str(script), ROOT]
-    res = subprocess.run(cmd + [str(out)], env=env, capture_output=True, text=True, timeout=600)
+    res = run_distributed(cmd + [str(out)], env)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert os.path.exists(out)
 
@@ -323,7 +323,7 @@ def test_two_rank_tile_gather_gloo(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29517",
            str(script), ROOT, str(out)]
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    res = run_distributed(cmd, env)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert os.path.exists(out)
 
@@ -657,7 +657,7 @@ def test_seam_history_exchange_gloo(world, tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
            "--master-port", str(29519 + world), str(script), ROOT, str(out)]
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    res = run_distributed(cmd, env)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert os.path.exists(out)
 
