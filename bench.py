@@ -376,11 +376,30 @@ def main():
             dist.broadcast_object_list(box, src=0)
             transport, gid = None, box[0]
         state["stage"] = "communicator creation"
-        grp = lm_group.TileGroup(r, rank, world, group_id=gid, transport=transport)
-        assert grp.tile == tuple(tile) and grp.window == tuple(win), (grp.tile, tile, grp.window, win)
-        state["stage"] = "self-test (all-reduce on both communicators + a full-size gather)"
-        self_test_ms = grp.SelfTest()
+        native_error = ""
+        try:
+            if os.environ.get("LUMEN_BENCH_NATIVE_FAIL"):    # test hook: the fallback below, exercised where the native group would work
+                raise RuntimeError("forced by LUMEN_BENCH_NATIVE_FAIL")
+            grp = lm_group.TileGroup(r, rank, world, group_id=gid, transport=transport)
+            assert grp.tile == tuple(tile) and grp.window == tuple(win), (grp.tile, tile, grp.window, win)
+            state["stage"] = "self-test (all-reduce on both communicators + a full-size gather)"
+            self_test_ms = grp.SelfTest()
+        except Exception as ex:                              # e.g. librccl not resolvable, communicator creation refused: every rank sees the same and says so below
+            native_error = f"{type(ex).__name__}: {ex}"
         timer.cancel()
+        # the ranks agree (gloo) whether the native group stands; if it does not anywhere, ALL of them fall back to the torch.distributed transport and the line says so
+        flag = torch.tensor([1 if native_error else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            sys.stderr.write(f"bench.py rank {rank}: native tile group unavailable ({native_error or 'failed on another rank'}); falling back to --transport torch\n"); sys.stderr.flush()
+            if grp is not None:
+                try:
+                    grp.close()
+                except Exception:
+                    pass
+            grp, native = None, False
+            args.transport = "torch (fallback: native tile group unavailable" + (": " + native_error[:160] if native_error else "") + ")"
+            dist.destroy_process_group()
     if (world > 1 or force_pg) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         if one_gpu:
@@ -612,7 +631,7 @@ def main():
             "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "rccl_world": rccl_world, "devices": devices,
-            **({"transport": ("native tile group (csrc/group.cpp): " + ("host transport over gloo, rehearsal" if one_gpu else "RCCL resolved by the library, two communicators, gather on its own stream, double-buffered")) if grp is not None else "torch.distributed (tiles.py)",
+            **({"transport": ("native tile group (csrc/group.cpp): " + ("host transport over gloo, rehearsal" if one_gpu else "RCCL resolved by the library, two communicators, gather on its own stream, double-buffered")) if grp is not None else ("torch.distributed (tiles.py)" + (" — " + args.transport if str(args.transport).startswith("torch (fallback") else "")),
                 "group_self_test_ms": round(self_test_ms, 2) if grp is not None else None} if world > 1 else {}),
             **({"rehearsal": f"{world} ranks share ONE GPU over gloo with host staging (LUMEN_BENCH_ONE_GPU=1): the N-rank code path executed, NOT a measurement"} if one_gpu else {}),
             # both arithmetic modes at the top level, so that `value` cannot be read without its mode: "fast" = hardware rcp / rsq / sqrt +

@@ -144,7 +144,7 @@ def test_plain_c_program_renders_as_a_tile_group(n_ranks, tmp_path):
         assert open(xout, "rb").read() == one
 
 
-@pytest.mark.parametrize("n_ranks,workload,transport", [(2, "sandbox", "native"), (8, "c2", "native"), (8, "c4", "native"), (2, "sandbox", "torch")])      # c4 = BASELINE's 8-GPU configuration (4K, 8 spp, depth 8)
+@pytest.mark.parametrize("n_ranks,workload,transport", [(2, "sandbox", "native"), (8, "c2", "native"), (8, "c4", "native"), (2, "sandbox", "torch"), (2, "sandbox", "native-fails")])      # c4 = BASELINE's 8-GPU configuration (4K, 8 spp, depth 8)
 def test_bench_multi_rank_path_rehearsed_on_the_one_gpu(n_ranks, workload, transport, tmp_path):
     """`python bench.py --gpus N` end to end where only one GPU exists (LUMEN_BENCH_ONE_GPU=1: every rank on GPU 0, collectives over gloo with host staging): the
     self-launch, the windows and tiles, the seam exchange after every TraceFrame (sandbox: odd depth), the gather, the barrier-bracketed timing with the maximum over
@@ -155,7 +155,9 @@ def test_bench_multi_rank_path_rehearsed_on_the_one_gpu(n_ranks, workload, trans
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", LUMEN_BENCH_ONE_GPU="1", LUMEN_BENCH_LOG_DIR=str(tmp_path))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n_ranks), "--workload", workload, "--steps", "2", "--warmup", "1", "--transport", transport],
+    if transport == "native-fails":                       # the native group refuses (forced): every rank falls back to the torch.distributed transport and the line says so
+        env["LUMEN_BENCH_NATIVE_FAIL"] = "1"
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n_ranks), "--workload", workload, "--steps", "2", "--warmup", "1", "--transport", transport.split("-")[0]],
                          env=env, capture_output=True, text=True, timeout=1200)
     assert res.returncode == 0, res.stdout[-1500:] + "\n" + res.stderr[-1500:] + "\n" + _rank_logs(tmp_path)
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
@@ -163,5 +165,6 @@ def test_bench_multi_rank_path_rehearsed_on_the_one_gpu(n_ranks, workload, trans
     j = json.loads(lines[0])
     assert j["n_gpus"] == n_ranks and j["rccl_world"] == n_ranks and len(j["devices"]) == n_ranks and "rehearsal" in j
     assert len(j["per_rank"]) == n_ranks and all(p["render_ms_per_step"] > 0 and p["halo_over_tile"] > 0 for p in j["per_rank"])
-    assert ("native tile group" in j["transport"]) == (transport == "native") and (j["group_self_test_ms"] is not None) == (transport == "native")
+    assert j["transport"].startswith("native tile group") == (transport == "native") and (j["group_self_test_ms"] is not None) == (transport == "native")
+    assert ("fallback" in j["transport"]) == (transport == "native-fails")
     assert j["value"] > 0 and j["scaling"] == "strong" and j["config"]["tiles"].split(" ")[0] in ("2x1", "1x2", "4x2", "2x4")
