@@ -545,6 +545,12 @@ def main():
     odd = depth % 2 == 1
     reuse_pass = None if (args.no_other_reuse or world > 1 or emu or odd) else timed_pass(fast, not lazy)
     reuse_other = None if (args.no_other_reuse or args.no_exact or world > 1 or emu or odd) else timed_pass(not fast, not lazy)
+    # the same frame with FULL persistent traversal grids everywhere (what rounds 1 - 5 ran): the roofline kernel's launch is faster that way and the frame slower; both on the line
+    full_grid_pass = None
+    if not (args.no_other_reuse or world > 1 or emu):
+        r.SetTuning("trace_blocks_main", 8); r.SetTuning("trace_blocks_vis", 8)
+        full_grid_pass = timed_pass(fast, lazy)
+        r.SetTuning("trace_blocks_main", 0); r.SetTuning("trace_blocks_vis", 0)
     r.SetTuning("fast_resample", 1 if fast else 0); r.SetTuning("lazy_reuse", -1 if lazy else 0)
     passes = {(fast, lazy): main_pass, (not fast, lazy): other_pass, (fast, not lazy): reuse_pass, (not fast, not lazy): reuse_other}      # (fast?, lazy?) -> pass or None
     rate = lambda f, l, key="value", nd=3: None if passes[(f, l)] is None else round(passes[(f, l)][key], nd)
@@ -679,7 +685,11 @@ def main():
                          "traffic_over_algorithmic": None if not traffic_closest else round(traffic_closest / (alg / max(1.0, launches_per_tf)), 4),
                          "limiter": "dependent-load latency x lane divergence: the tree is served by L2 / Infinity Cache, HBM sees a few % of the algorithmic bytes",
                          "grid_note": "since round 6 the primary-ray launch of an eager frame runs on HALF a persistent grid on purpose (csrc/frame.cpp; profiles/r06_trace_blocks_ab.txt): that launch "
-                                      "got slower (611 -> 750 us under overlap) and the frame faster, so frac is below the 0.545 of the full-grid record at a higher value",
+                                      "got slower (611 -> 730 us under overlap) and the frame faster, so frac is below the 0.545 of the full-grid record at a higher value; frac_full_grid / value_full_grid = the same run "
+                                      "with tuning keys trace_blocks_main = trace_blocks_vis = 8",
+                         **({} if full_grid_pass is None or full_grid_pass["kernel_ms"]["closest"][1] == 0 else
+                            {"frac_full_grid": round(achieved / HBM_PEAK_GBS * per_launch_ms / (full_grid_pass["kernel_ms"]["closest"][0] / full_grid_pass["kernel_ms"]["closest"][1]), 5),
+                             "value_full_grid": round(full_grid_pass["value"], 3)}),
                          "launch_ms": round(per_launch_ms, 4), "launches_per_traceframe": launches_per_tf,
                          "algorithmic_bytes_per_launch": int(alg / max(1.0, launches_per_tf)),
                          "achieved_d4_binary_node_pricing": round(gbs(alg_d4), 2)},
